@@ -1,0 +1,349 @@
+"""CPU oracle for the distortion hot path -- TEST INFRASTRUCTURE ONLY.
+
+numpy-facing wrappers over ``oracle/vkx_oracle.c`` (built by ``oracle/Makefile`` into
+``oracle/_build/libvkx_oracle.so``).  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import this package; the product package
+``vkit_amd`` never does.
+
+Parity status: **unpinned at the cv2 boundary** (OpenCV is neither vendored in the reference
+nor installed here); the numpy-only members are pinned by ``tests/golden``.  See the header of
+``vkx_oracle.c`` for the per-function provenance.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, '_build', 'libvkx_oracle.so')
+
+SOLVER_HYBRID = 0  # closed-form homography, Jacobi-SVD only for degenerate quads (parity definition)
+SOLVER_JACOBI = 1  # restatement of OpenCV's built-in DECOMP_SVD path for every cell
+
+
+def build(force=False):
+    src = os.path.join(_HERE, 'vkx_oracle.c')
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.run(['make', '-C', _HERE], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+    return _lib
+
+
+def _p(arr):
+    return arr.ctypes.data_as(ctypes.c_void_p)
+
+
+_ss = ctypes.c_ssize_t
+
+
+def _as3(img):
+    if img.ndim == 2:
+        return img.reshape(img.shape[0], img.shape[1], 1), True
+    return img, False
+
+
+def remap(src, map_x, map_y):
+    """cv.remap(src, map_x, map_y, INTER_LINEAR), BORDER_CONSTANT 0; uint8 HxW[xC] or float32 HxW."""
+    map_x = np.ascontiguousarray(map_x, dtype=np.float32)
+    map_y = np.ascontiguousarray(map_y, dtype=np.float32)
+    dh, dw = map_x.shape
+    src = np.ascontiguousarray(src)
+    if src.dtype == np.uint8:
+        s3, squeeze = _as3(src)
+        sh, sw, cn = s3.shape
+        dst = np.zeros((dh, dw, cn), np.uint8)
+        rc = lib().vko_remap_u8(_p(s3), sh, sw, cn, _ss(sw * cn), _p(map_x), _p(map_y), _ss(dw),
+                                _p(dst), dh, dw, _ss(dw * cn))
+        assert rc == 0
+        return dst[:, :, 0] if squeeze else dst
+    assert src.dtype == np.float32 and src.ndim == 2
+    sh, sw = src.shape
+    dst = np.zeros((dh, dw), np.float32)
+    rc = lib().vko_remap_f32(_p(src), sh, sw, _ss(sw), _p(map_x), _p(map_y), _ss(dw), _p(dst), dh, dw,
+                             _ss(dw))
+    assert rc == 0
+    return dst
+
+
+def _sample_fixed(src, X, Y):
+    dh, dw = X.shape
+    src = np.ascontiguousarray(src)
+    if src.dtype == np.uint8:
+        s3, squeeze = _as3(src)
+        sh, sw, cn = s3.shape
+        dst = np.zeros((dh, dw, cn), np.uint8)
+        rc = lib().vko_sample_fixed_u8(_p(s3), sh, sw, cn, _ss(sw * cn), _p(X), _p(Y), _p(dst), dh, dw,
+                                       _ss(dw * cn))
+        assert rc == 0
+        return dst[:, :, 0] if squeeze else dst
+    assert src.dtype == np.float32 and src.ndim == 2
+    sh, sw = src.shape
+    dst = np.zeros((dh, dw), np.float32)
+    rc = lib().vko_sample_fixed_f32(_p(src), sh, sw, _ss(sw), _p(X), _p(Y), _p(dst), dh, dw, _ss(dw))
+    assert rc == 0
+    return dst
+
+
+def warp_affine_coords(M, dsize):
+    dw, dh = int(dsize[0]), int(dsize[1])
+    M = np.ascontiguousarray(np.asarray(M, dtype=np.float64).reshape(6))
+    X = np.zeros((dh, dw), np.int32)
+    Y = np.zeros((dh, dw), np.int32)
+    assert lib().vko_warp_affine_coords(_p(M), dh, dw, _p(X), _p(Y)) == 0
+    return X, Y
+
+
+def warp_perspective_coords(M, dsize):
+    dw, dh = int(dsize[0]), int(dsize[1])
+    M = np.ascontiguousarray(np.asarray(M, dtype=np.float64).reshape(9))
+    X = np.zeros((dh, dw), np.int32)
+    Y = np.zeros((dh, dw), np.int32)
+    assert lib().vko_warp_perspective_coords(_p(M), dh, dw, _p(X), _p(Y)) == 0
+    return X, Y
+
+
+def warp_affine(src, M, dsize):
+    """cv.warpAffine(src, M, dsize): M is the forward 2x3 matrix, dsize = (width, height)."""
+    X, Y = warp_affine_coords(M, dsize)
+    return _sample_fixed(src, X, Y)
+
+
+def warp_perspective(src, M, dsize):
+    """cv.warpPerspective(src, M, dsize): M is the forward 3x3 matrix, dsize = (width, height)."""
+    X, Y = warp_perspective_coords(M, dsize)
+    return _sample_fixed(src, X, Y)
+
+
+def get_perspective_transform(pts_from, pts_to, solver=SOLVER_HYBRID):
+    a = np.ascontiguousarray(np.asarray(pts_from, dtype=np.float32).reshape(8))
+    b = np.ascontiguousarray(np.asarray(pts_to, dtype=np.float32).reshape(8))
+    H = np.zeros(9, np.float64)
+    lib().vko_get_perspective_transform(_p(a), _p(b), int(solver), _p(H))
+    return H.reshape(3, 3)
+
+
+def fill_poly(shape, pts, closed_form=False):
+    """cv.fillPoly(zeros(shape, uint8), [pts], 1); pts int32 (N, 2) as (x, y), inside the array."""
+    h, w = int(shape[0]), int(shape[1])
+    pts = np.ascontiguousarray(np.asarray(pts, dtype=np.int32).reshape(-1, 2))
+    img = np.zeros((h, w), np.uint8)
+    fn = lib().vko_fill_poly_closed_form if closed_form else lib().vko_fill_poly
+    assert fn(_p(img), h, w, _p(pts), int(pts.shape[0])) == 0
+    return img
+
+
+def grid_to_map(src_vertices, dst_vertices, dst_shape, solver=SOLVER_HYBRID, want_owner=False):
+    """ImageGrid.generate_remap_params: vertices int32 (rows, cols, 2) as (x, y)."""
+    sv = np.ascontiguousarray(src_vertices, dtype=np.int32)
+    dv = np.ascontiguousarray(dst_vertices, dtype=np.int32)
+    rows, cols = sv.shape[:2]
+    dh, dw = int(dst_shape[0]), int(dst_shape[1])
+    mx = np.zeros((dh, dw), np.float32)
+    my = np.zeros((dh, dw), np.float32)
+    owner = np.zeros((dh, dw), np.int32) if want_owner else None
+    rc = lib().vko_grid_to_map(_p(sv), _p(dv), rows, cols, dh, dw, int(solver), _p(mx), _p(my),
+                               _p(owner) if want_owner else None)
+    assert rc == 0
+    return (mx, my, owner) if want_owner else (mx, my)
+
+
+def gaussian_kernel_q8(ksize, sigma):
+    k = np.zeros(ksize, np.uint16)
+    assert lib().vko_gaussian_kernel_q8(int(ksize), ctypes.c_double(sigma), _p(k)) == 0
+    return k
+
+
+def gaussian_blur(img, ksize, sigma):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    s3, squeeze = _as3(img)
+    h, w, cn = s3.shape
+    dst = np.zeros_like(s3)
+    rc = lib().vko_gaussian_blur_u8(_p(s3), h, w, cn, _ss(w * cn), int(ksize), ctypes.c_double(sigma),
+                                    _p(dst), _ss(w * cn))
+    assert rc == 0
+    return dst[:, :, 0] if squeeze else dst
+
+
+def rgb2hsv_full(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    dst = np.zeros_like(img)
+    lib().vko_rgb2hsv_full(_p(img), ctypes.c_size_t(img.size // 3), _p(dst))
+    return dst
+
+
+def hsv2rgb_full(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    dst = np.zeros_like(img)
+    lib().vko_hsv2rgb_full(_p(img), ctypes.c_size_t(img.size // 3), _p(dst))
+    return dst
+
+
+def color_shift_rgb(img, delta):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    dst = np.zeros_like(img)
+    lib().vko_color_shift_rgb(_p(img), ctypes.c_size_t(img.size // 3), int(delta), _p(dst))
+    return dst
+
+
+def mean_shift(img, delta, threshold=None, channels=None, cycle=False):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    chmask = 0
+    if channels:
+        for c in channels:
+            chmask |= 1 << c
+    dst = np.zeros_like(img)
+    lib().vko_mean_shift_u8(_p(img), ctypes.c_size_t(img.size // cn), cn, int(delta),
+                            int(threshold is not None), int(threshold or 0), int(cycle), chmask, _p(dst))
+    return dst
+
+
+def add_noise_i16(img, noise):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    noise = np.ascontiguousarray(noise, dtype=np.int16)
+    assert img.shape == noise.shape
+    dst = np.zeros_like(img)
+    lib().vko_add_noise_i16(_p(img), _p(noise), ctypes.c_size_t(img.size), _p(dst))
+    return dst
+
+
+def fill(dst, box, value, mask=None, alpha=1.0):
+    """fill_np_array restricted to uint8 destinations; ``dst`` is modified in place.
+
+    box = (up, left, height, width); value: tuple/int (constant) or uint8 array [h, w(, c)];
+    mask: uint8 [h, w] or None; alpha: python float or float32 array [h, w].
+    """
+    assert dst.dtype == np.uint8 and dst.flags.c_contiguous and dst.flags.writeable
+    d3, _ = _as3(dst)
+    h, w, cn = d3.shape
+    up, left, bh, bw = (int(v) for v in box)
+    mask_p, mask_step = None, 0
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        assert mask.shape == (bh, bw)
+        mask_p, mask_step = _p(mask), bw
+    alpha_p, alpha_step, alpha_s = None, 0, 1.0
+    if isinstance(alpha, np.ndarray):
+        alpha = np.ascontiguousarray(alpha, dtype=np.float32)
+        assert alpha.shape == (bh, bw)
+        alpha_p, alpha_step = _p(alpha), bw
+    else:
+        alpha_s = float(alpha)
+    vplane_p, vstep, vconst_p = None, 0, None
+    if isinstance(value, np.ndarray):
+        value = np.ascontiguousarray(value.astype(np.uint8))
+        v3, _ = _as3(value)
+        assert v3.shape == (bh, bw, cn)
+        vplane_p, vstep = _p(v3), bw * cn
+    else:
+        vconst = np.full(cn, value, dtype=np.uint8) if not isinstance(value, tuple) else np.asarray(
+            value, dtype=np.uint8)
+        assert vconst.shape == (cn,)
+        vconst_p = _p(vconst)
+    rc = lib().vko_fill_u8(_p(d3), h, w, cn, _ss(w * cn), up, left, bh, bw, mask_p, _ss(mask_step), alpha_p,
+                           _ss(alpha_step), ctypes.c_double(alpha_s), vplane_p, _ss(vstep), vconst_p)
+    if rc == -2:
+        raise RuntimeError(f'alpha={alpha_s} is invalid.')
+    assert rc == 0, rc
+    return dst
+
+
+def line_streak(img, thickness=1, gap=4, dash_thickness=0, dash_gap=0, color=(0, 0, 0), alpha=1.0,
+                enable_vert=True, enable_hori=True):
+    out = np.array(img, dtype=np.uint8, order='C')
+    o3, _ = _as3(out)
+    h, w, cn = o3.shape
+    col = np.asarray(color, dtype=np.uint8)
+    assert col.shape == (cn,)
+    rc = lib().vko_line_streak_u8(_p(o3), h, w, cn, _ss(w * cn), int(thickness), int(gap), int(dash_thickness),
+                                  int(dash_gap), _p(col), ctypes.c_double(alpha), int(enable_vert),
+                                  int(enable_hori))
+    assert rc == 0
+    return out
+
+
+def rodrigues(rvec):
+    r = np.ascontiguousarray(np.asarray(rvec, dtype=np.float64).reshape(3))
+    R = np.zeros(9, np.float64)
+    lib().vko_rodrigues(_p(r), _p(R))
+    return R.reshape(3, 3)
+
+
+def project_points(pts3, rvec, tvec, fx, fy, cx=0.0, cy=0.0):
+    p = np.ascontiguousarray(np.asarray(pts3, dtype=np.float64).reshape(-1, 3))
+    r = np.ascontiguousarray(np.asarray(rvec, dtype=np.float64).reshape(3))
+    t = np.ascontiguousarray(np.asarray(tvec, dtype=np.float64).reshape(3))
+    out = np.zeros((p.shape[0], 2), np.float64)
+    lib().vko_project_points(_p(p), ctypes.c_size_t(p.shape[0]), _p(r), _p(t), ctypes.c_double(fx),
+                             ctypes.c_double(fy), ctypes.c_double(cx), ctypes.c_double(cy), _p(out))
+    return out
+
+
+def _centered_boxes(height, width, aspect_ratio, short_side_min, short_side_step):
+    """generate_centered_boxes -- photometric/streak.py:109-145; boxes as (up, down, left, right)."""
+    cy, cx = height // 2, width // 2
+    boxes = []
+    idx = 0
+    while True:
+        short_side = short_side_min + idx * short_side_step
+        if aspect_ratio >= 1:
+            h_min = short_side
+            w_min = round(h_min * aspect_ratio)
+        elif 0 < aspect_ratio < 1:
+            w_min = short_side
+            h_min = round(w_min / aspect_ratio)
+        else:
+            raise NotImplementedError()
+        up = cy - h_min // 2
+        down = up + h_min - 1
+        left = cx - w_min // 2
+        right = left + w_min - 1
+        if (0 <= up and down < height) or (0 <= left and right < width):
+            boxes.append((up, down, left, right))
+            idx += 1
+        else:
+            break
+    return boxes
+
+
+def rectangle_streak(img, thickness=1, aspect_ratio=None, dash_thickness=0, dash_gap=0, short_side_min=10,
+                     short_side_step=10, color=(0, 0, 0), alpha=1.0):
+    """rectangle_streak_image -- photometric/streak.py:160-272 (numpy-only in the reference)."""
+    out = np.array(img, dtype=np.uint8, order='C')
+    H, W = out.shape[:2]
+    if aspect_ratio is None:
+        aspect_ratio = W / H
+    vert = np.zeros((H, W), np.uint8)
+    hori = np.zeros((H, W), np.uint8)
+    for (up, down, left, right) in _centered_boxes(H, W, aspect_ratio, short_side_min, short_side_step):
+        in_up, in_down = down - thickness + 1, up + thickness - 1
+        in_left, in_right = right - thickness + 1, left + thickness - 1
+        b_up, b_down = max(0, up), min(H - 1, down)
+        if 0 <= in_right < W and b_up <= b_down:
+            vert[b_up:b_down + 1, max(0, left):in_right + 1] = 1
+        if 0 <= in_left < W and b_up <= b_down:
+            vert[b_up:b_down + 1, in_left:min(W - 1, right) + 1] = 1
+        b_left, b_right = max(0, in_right + 1), min(W - 1, in_left - 1)
+        if 0 <= in_down < H and b_left <= b_right:
+            hori[max(0, up):in_down + 1, b_left:b_right + 1] = 1
+        if 0 <= in_up < H and b_left <= b_right:
+            hori[in_up:min(H - 1, down) + 1, b_left:b_right + 1] = 1
+    if dash_thickness > 0 and dash_gap > 0:
+        step = dash_thickness + dash_gap
+        for off in range(dash_gap):
+            vert[off::step] = 0
+            hori[:, off::step] = 0
+    fill(out, (0, 0, H, W), tuple(color), mask=vert, alpha=float(alpha))
+    fill(out, (0, 0, H, W), tuple(color), mask=hori, alpha=float(alpha))
+    return out

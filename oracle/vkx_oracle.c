@@ -1,0 +1,1073 @@
+/*
+ * vkx_oracle.c -- CPU restatement of the arithmetic on vkit's distortion hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product (vkit_amd + libvkx.so) never
+ * links, imports or executes anything in oracle/.
+ *
+ * Parity status: *unpinned at the cv2 boundary*.  The reference (/root/reference, pure
+ * Python) delegates the arithmetic below to OpenCV (opencv-python-headless >=4.5.1.48,
+ * setup.cfg:20-22), which is neither vendored in the reference nor installed in this
+ * image.  Functions marked [cv2] restate the published OpenCV 4.5.x algorithm; functions
+ * marked [numpy] restate numpy arithmetic that the reference runs itself and ARE pinned
+ * against golden vectors produced by importing the reference (tests/golden/).
+ *
+ * Every function cites the reference call site it stands in for (paths relative to
+ * /root/reference/vkit).
+ *
+ * Plain scalar C99, one thread, no SIMD, no FMA contraction (build with
+ * -ffp-contract=off); explicit fma() only where the reference's BLAS uses it.
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <limits.h>
+#include <float.h>
+
+#define VKO_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------
+ * Rounding helpers: OpenCV cvRound on x86 = cvtss2si / cvtsd2si (round-half-even, the
+ * "integer indefinite" 0x80000000 for NaN / out-of-range).
+ * ---------------------------------------------------------------------------------- */
+static inline int cv_round_d(double v)
+{
+    if (!(v >= -2147483648.5 && v < 2147483647.5)) return INT_MIN;
+    return (int)nearbyint(v);
+}
+static inline int cv_round_f(float v) { return cv_round_d((double)v); }
+static inline int sat_short(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+static inline uint8_t sat_u8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+/* ------------------------------------------------------------------------------------
+ * [cv2] Bilinear interpolation tables of cv::remap (imgwarp.cpp initInterTab2D):
+ * INTER_BITS=5, INTER_TAB_SIZE=32, INTER_REMAP_COEF_BITS=15.  The int16 table is the
+ * float table * 32768 with saturate_cast<short>, followed by the "sum must be 32768"
+ * fix-up; the only entry it changes is (fy,fx)=(0,0): {32767,0,0,1}.
+ * ---------------------------------------------------------------------------------- */
+static short g_tab_i[32 * 32][4];
+static float g_tab_f[32 * 32][4];
+static int g_tab_ready = 0;
+
+static void init_tabs(void)
+{
+    if (g_tab_ready) return;
+    float t1[32][2];
+    const float scale = 1.f / 32;
+    for (int i = 0; i < 32; i++) {
+        float x = i * scale;
+        t1[i][0] = 1.f - x;
+        t1[i][1] = x;
+    }
+    for (int i = 0; i < 32; i++)
+        for (int j = 0; j < 32; j++) {
+            short *it = g_tab_i[i * 32 + j];
+            float *ft = g_tab_f[i * 32 + j];
+            int isum = 0;
+            for (int k1 = 0; k1 < 2; k1++)
+                for (int k2 = 0; k2 < 2; k2++) {
+                    float v = t1[i][k1] * t1[j][k2];
+                    ft[k1 * 2 + k2] = v;
+                    it[k1 * 2 + k2] = (short)sat_short(cv_round_f(v * 32768));
+                    isum += it[k1 * 2 + k2];
+                }
+            if (isum != 32768) {
+                /* OpenCV scans a 2x2 window anchored at (ksize/2,ksize/2)=(1,1); for the
+                 * bilinear 2x2 kernel only element [1][1] lies inside the entry, the other
+                 * three probes read not-yet-written (zero) slots of the next entry. */
+                int diff = isum - 32768;
+                int probe[4] = { it[3], 0, 0, 0 };
+                int mk = 0, Mk = 0;
+                for (int k = 0; k < 4; k++) {
+                    if (probe[k] < probe[mk]) mk = k;
+                    else if (probe[k] > probe[Mk]) Mk = k;
+                }
+                /* mk == Mk == 0 -> element [1][1] */
+                (void)mk; (void)Mk;
+                it[3] = (short)(it[3] - diff);
+            }
+        }
+    g_tab_ready = 1;
+}
+
+/* One destination pixel of remapBilinear, BORDER_CONSTANT(0).  X,Y: source coordinate in
+ * 1/32 px fixed point (what remap/warpAffine/warpPerspective hand to the interpolator). */
+static inline void px_u8(const uint8_t *src, int sh, int sw, int cn, ptrdiff_t sstep,
+                         int X, int Y, uint8_t *d)
+{
+    int sx = sat_short(X >> 5), sy = sat_short(Y >> 5);
+    const short *w = g_tab_i[(Y & 31) * 32 + (X & 31)];
+    if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) {
+        for (int k = 0; k < cn; k++) d[k] = 0;
+        return;
+    }
+    int x0 = sx >= 0 && sx < sw, x1 = sx + 1 >= 0 && sx + 1 < sw;
+    int y0 = sy >= 0 && sy < sh, y1 = sy + 1 >= 0 && sy + 1 < sh;
+    for (int k = 0; k < cn; k++) {
+        int v0 = (x0 && y0) ? src[(ptrdiff_t)sy * sstep + sx * cn + k] : 0;
+        int v1 = (x1 && y0) ? src[(ptrdiff_t)sy * sstep + (sx + 1) * cn + k] : 0;
+        int v2 = (x0 && y1) ? src[(ptrdiff_t)(sy + 1) * sstep + sx * cn + k] : 0;
+        int v3 = (x1 && y1) ? src[(ptrdiff_t)(sy + 1) * sstep + (sx + 1) * cn + k] : 0;
+        d[k] = sat_u8((v0 * w[0] + v1 * w[1] + v2 * w[2] + v3 * w[3] + (1 << 14)) >> 15);
+    }
+}
+
+static inline float px_f32(const float *src, int sh, int sw, ptrdiff_t sstep_el, int X, int Y)
+{
+    int sx = sat_short(X >> 5), sy = sat_short(Y >> 5);
+    const float *w = g_tab_f[(Y & 31) * 32 + (X & 31)];
+    if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) return 0.f;
+    int x0 = sx >= 0 && sx < sw, x1 = sx + 1 >= 0 && sx + 1 < sw;
+    int y0 = sy >= 0 && sy < sh, y1 = sy + 1 >= 0 && sy + 1 < sh;
+    float v0 = (x0 && y0) ? src[(ptrdiff_t)sy * sstep_el + sx] : 0.f;
+    float v1 = (x1 && y0) ? src[(ptrdiff_t)sy * sstep_el + sx + 1] : 0.f;
+    float v2 = (x0 && y1) ? src[(ptrdiff_t)(sy + 1) * sstep_el + sx] : 0.f;
+    float v3 = (x1 && y1) ? src[(ptrdiff_t)(sy + 1) * sstep_el + sx + 1] : 0.f;
+    float p0 = v0 * w[0], p1 = v1 * w[1], p2 = v2 * w[2], p3 = v3 * w[3];
+    return ((p0 + p1) + p2) + p3;
+}
+
+/* ------------------------------------------------------------------------------------
+ * [cv2] cv.remap(src, map_x, map_y, INTER_LINEAR) -- grid_rendering/grid_blender.py:60,70,80
+ * ---------------------------------------------------------------------------------- */
+VKO_API int vko_remap_u8(const uint8_t *src, int sh, int sw, int cn, ptrdiff_t sstep,
+                         const float *mapx, const float *mapy, ptrdiff_t mstep_el,
+                         uint8_t *dst, int dh, int dw, ptrdiff_t dstep)
+{
+    init_tabs();
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++) {
+            int X = cv_round_f(mapx[(ptrdiff_t)y * mstep_el + x] * 32);
+            int Y = cv_round_f(mapy[(ptrdiff_t)y * mstep_el + x] * 32);
+            px_u8(src, sh, sw, cn, sstep, X, Y, dst + (ptrdiff_t)y * dstep + x * cn);
+        }
+    return 0;
+}
+
+VKO_API int vko_remap_f32(const float *src, int sh, int sw, ptrdiff_t sstep_el,
+                          const float *mapx, const float *mapy, ptrdiff_t mstep_el,
+                          float *dst, int dh, int dw, ptrdiff_t dstep_el)
+{
+    init_tabs();
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++) {
+            int X = cv_round_f(mapx[(ptrdiff_t)y * mstep_el + x] * 32);
+            int Y = cv_round_f(mapy[(ptrdiff_t)y * mstep_el + x] * 32);
+            dst[(ptrdiff_t)y * dstep_el + x] = px_f32(src, sh, sw, sstep_el, X, Y);
+        }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * [cv2] cv.warpAffine(mat, trans_mat(2x3 forward), dsize) -- geometric/affine.py:38-43
+ * imgwarp.cpp: M -> double, inverted in double, AB_BITS=10 fixed-point row/col deltas.
+ * Writes the 1/32-px fixed point coordinates of every destination pixel.
+ * ---------------------------------------------------------------------------------- */
+static void affine_invert(const double Mf[6], double M[6])
+{
+    memcpy(M, Mf, sizeof(double) * 6);
+    double D = M[0] * M[4] - M[1] * M[3];
+    D = D != 0 ? 1. / D : 0;
+    double A11 = M[4] * D, A22 = M[0] * D;
+    M[0] = A11; M[1] *= -D;
+    M[3] *= -D; M[4] = A22;
+    double b1 = -M[0] * M[2] - M[1] * M[5];
+    double b2 = -M[3] * M[2] - M[4] * M[5];
+    M[2] = b1; M[5] = b2;
+}
+
+VKO_API int vko_warp_affine_coords(const double Mfwd[6], int dh, int dw, int *X, int *Y)
+{
+    double M[6];
+    affine_invert(Mfwd, M);
+    const int AB_SCALE = 1 << 10, round_delta = 16;
+    int *adelta = (int *)malloc(sizeof(int) * 2 * (size_t)dw), *bdelta = adelta + dw;
+    if (!adelta) return -1;
+    for (int x = 0; x < dw; x++) {
+        adelta[x] = cv_round_d(M[0] * x * AB_SCALE);
+        bdelta[x] = cv_round_d(M[3] * x * AB_SCALE);
+    }
+    for (int y = 0; y < dh; y++) {
+        int X0 = cv_round_d((M[1] * y + M[2]) * AB_SCALE) + round_delta;
+        int Y0 = cv_round_d((M[4] * y + M[5]) * AB_SCALE) + round_delta;
+        for (int x = 0; x < dw; x++) {
+            X[(size_t)y * dw + x] = (X0 + adelta[x]) >> 5;
+            Y[(size_t)y * dw + x] = (Y0 + bdelta[x]) >> 5;
+        }
+    }
+    free(adelta);
+    return 0;
+}
+
+/* [cv2] cv.warpPerspective(mat, trans_mat(3x3 forward), dsize) -- geometric/affine.py:43.
+ * cv::invert 3x3 (cofactors * 1/det), then per pixel in double with the 32x32 block
+ * decomposition of WarpPerspectiveInvoker (X0 is evaluated at the block's first column). */
+static int invert3(const double *S, double *t)
+{
+#define Sd(r, c) S[(r) * 3 + (c)]
+    double d = Sd(0, 0) * (Sd(1, 1) * Sd(2, 2) - Sd(1, 2) * Sd(2, 1)) -
+               Sd(0, 1) * (Sd(1, 0) * Sd(2, 2) - Sd(1, 2) * Sd(2, 0)) +
+               Sd(0, 2) * (Sd(1, 0) * Sd(2, 1) - Sd(1, 1) * Sd(2, 0));
+    if (d == 0.) return 0;
+    d = 1. / d;
+    t[0] = (Sd(1, 1) * Sd(2, 2) - Sd(1, 2) * Sd(2, 1)) * d;
+    t[1] = (Sd(0, 2) * Sd(2, 1) - Sd(0, 1) * Sd(2, 2)) * d;
+    t[2] = (Sd(0, 1) * Sd(1, 2) - Sd(0, 2) * Sd(1, 1)) * d;
+    t[3] = (Sd(1, 2) * Sd(2, 0) - Sd(1, 0) * Sd(2, 2)) * d;
+    t[4] = (Sd(0, 0) * Sd(2, 2) - Sd(0, 2) * Sd(2, 0)) * d;
+    t[5] = (Sd(0, 2) * Sd(1, 0) - Sd(0, 0) * Sd(1, 2)) * d;
+    t[6] = (Sd(1, 0) * Sd(2, 1) - Sd(1, 1) * Sd(2, 0)) * d;
+    t[7] = (Sd(0, 1) * Sd(2, 0) - Sd(0, 0) * Sd(2, 1)) * d;
+    t[8] = (Sd(0, 0) * Sd(1, 1) - Sd(0, 1) * Sd(1, 0)) * d;
+#undef Sd
+    return 1;
+}
+
+VKO_API int vko_warp_perspective_coords(const double Mfwd[9], int dh, int dw, int *X, int *Y)
+{
+    double M[9];
+    if (!invert3(Mfwd, M)) memset(M, 0, sizeof M); /* cv::invert leaves zeros on failure */
+    const int BLOCK_SZ = 32;
+    int bh0 = BLOCK_SZ / 2 < dh ? BLOCK_SZ / 2 : dh;
+    int bw0 = BLOCK_SZ * BLOCK_SZ / bh0 < dw ? BLOCK_SZ * BLOCK_SZ / bh0 : dw;
+    for (int y = 0; y < dh; y++)
+        for (int xb = 0; xb < dw; xb += bw0) {
+            int bw = bw0 < dw - xb ? bw0 : dw - xb;
+            double X0 = M[0] * xb + M[1] * y + M[2];
+            double Y0 = M[3] * xb + M[4] * y + M[5];
+            double W0 = M[6] * xb + M[7] * y + M[8];
+            for (int x1 = 0; x1 < bw; x1++) {
+                double W = W0 + M[6] * x1;
+                W = W ? 32 / W : 0;
+                double fX = fmax((double)INT_MIN, fmin((double)INT_MAX, (X0 + M[0] * x1) * W));
+                double fY = fmax((double)INT_MIN, fmin((double)INT_MAX, (Y0 + M[3] * x1) * W));
+                X[(size_t)y * dw + xb + x1] = cv_round_d(fX);
+                Y[(size_t)y * dw + xb + x1] = cv_round_d(fY);
+            }
+        }
+    return 0;
+}
+
+/* Interpolate with precomputed fixed-point coordinates (tail of warpAffine/Perspective). */
+VKO_API int vko_sample_fixed_u8(const uint8_t *src, int sh, int sw, int cn, ptrdiff_t sstep,
+                                const int *X, const int *Y, uint8_t *dst, int dh, int dw,
+                                ptrdiff_t dstep)
+{
+    init_tabs();
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++)
+            px_u8(src, sh, sw, cn, sstep, X[(size_t)y * dw + x], Y[(size_t)y * dw + x],
+                  dst + (ptrdiff_t)y * dstep + x * cn);
+    return 0;
+}
+
+VKO_API int vko_sample_fixed_f32(const float *src, int sh, int sw, ptrdiff_t sstep_el,
+                                 const int *X, const int *Y, float *dst, int dh, int dw,
+                                 ptrdiff_t dstep_el)
+{
+    init_tabs();
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++)
+            dst[(ptrdiff_t)y * dstep_el + x] =
+                px_f32(src, sh, sw, sstep_el, X[(size_t)y * dw + x], Y[(size_t)y * dw + x]);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * [cv2] cv.getPerspectiveTransform(from(4x2 f32), to(4x2 f32), DECOMP_SVD)
+ *   grid_rendering/type.py:172-176,189-193; geometric/affine.py:326-330,386-390.
+ *
+ * Two solvers:
+ *   solver 1 (JACOBI): restatement of OpenCV's built-in path: 8x8 DLT system in double
+ *     (the -x*X products are formed in FLOAT, as Point2f arithmetic does), one-sided
+ *     Jacobi SVD (lapack.cpp JacobiSVDImpl_) and SVBkSb back substitution with the
+ *     2*DBL_EPSILON*sum(w) cut-off -> minimum-norm least squares for singular systems.
+ *   solver 0 (HYBRID, the parity definition used by the product): a closed-form
+ *     quad->quad homography built from exact integer sub-determinants when no three
+ *     vertices of either quad are collinear, solver 1 otherwise.
+ * cv2 wheels are built against LAPACK (dgesdd), so even solver 1 is not bit-identical to a
+ * given cv2 binary; all accurate solvers agree to ~1e-9 px on the maps they induce.
+ * ---------------------------------------------------------------------------------- */
+static void jacobi_svd8(double At[8][8], double W[8], double Vt[8][8])
+{
+    const int m = 8, n = 8;
+    const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
+    int i, j, k, iter, max_iter = 30 > m ? 30 : m;
+    double c, s, sd;
+    for (i = 0; i < n; i++) {
+        for (k = 0, sd = 0; k < m; k++) { double t = At[i][k]; sd += t * t; }
+        W[i] = sd;
+        for (k = 0; k < n; k++) Vt[i][k] = 0;
+        Vt[i][i] = 1;
+    }
+    for (iter = 0; iter < max_iter; iter++) {
+        int changed = 0;
+        for (i = 0; i < n - 1; i++)
+            for (j = i + 1; j < n; j++) {
+                double *Ai = At[i], *Aj = At[j];
+                double a = W[i], p = 0, b = W[j];
+                for (k = 0; k < m; k++) p += Ai[k] * Aj[k];
+                if (fabs(p) <= eps * sqrt(a * b)) continue;
+                p *= 2;
+                double beta = a - b, gamma = hypot(p, beta);
+                if (beta < 0) {
+                    double delta = (gamma - beta) * 0.5;
+                    s = sqrt(delta / gamma);
+                    c = p / (gamma * s * 2);
+                } else {
+                    c = sqrt((gamma + beta) / (gamma * 2));
+                    s = p / (gamma * c * 2);
+                }
+                a = b = 0;
+                for (k = 0; k < m; k++) {
+                    double t0 = c * Ai[k] + s * Aj[k];
+                    double t1 = -s * Ai[k] + c * Aj[k];
+                    Ai[k] = t0; Aj[k] = t1;
+                    a += t0 * t0; b += t1 * t1;
+                }
+                W[i] = a; W[j] = b;
+                changed = 1;
+                double *Vi = Vt[i], *Vj = Vt[j];
+                for (k = 0; k < n; k++) {
+                    double t0 = c * Vi[k] + s * Vj[k];
+                    double t1 = -s * Vi[k] + c * Vj[k];
+                    Vi[k] = t0; Vj[k] = t1;
+                }
+            }
+        if (!changed) break;
+    }
+    for (i = 0; i < n; i++) {
+        for (k = 0, sd = 0; k < m; k++) { double t = At[i][k]; sd += t * t; }
+        W[i] = sqrt(sd);
+    }
+    for (i = 0; i < n - 1; i++) {
+        j = i;
+        for (k = i + 1; k < n; k++)
+            if (W[j] < W[k]) j = k;
+        if (i != j) {
+            double t = W[i]; W[i] = W[j]; W[j] = t;
+            for (k = 0; k < m; k++) { t = At[i][k]; At[i][k] = At[j][k]; At[j][k] = t; }
+            for (k = 0; k < n; k++) { t = Vt[i][k]; Vt[i][k] = Vt[j][k]; Vt[j][k] = t; }
+        }
+    }
+    for (i = 0; i < n; i++) {
+        sd = W[i];
+        s = sd > minval ? 1 / sd : 0.;
+        for (k = 0; k < m; k++) At[i][k] *= s;
+    }
+}
+
+static void homography_jacobi(const float from[8], const float to[8], double H[9])
+{
+    double a[8][8], b[8], At[8][8], W[8], Vt[8][8], x[8];
+    for (int i = 0; i < 4; i++) {
+        float fx = from[2 * i], fy = from[2 * i + 1], tx = to[2 * i], ty = to[2 * i + 1];
+        a[i][0] = a[i + 4][3] = fx;
+        a[i][1] = a[i + 4][4] = fy;
+        a[i][2] = a[i + 4][5] = 1;
+        a[i][3] = a[i][4] = a[i][5] = a[i + 4][0] = a[i + 4][1] = a[i + 4][2] = 0;
+        a[i][6] = (double)(-fx * tx);     /* float product, as Point2f arithmetic */
+        a[i][7] = (double)(-fy * tx);
+        a[i + 4][6] = (double)(-fx * ty);
+        a[i + 4][7] = (double)(-fy * ty);
+        b[i] = tx;
+        b[i + 4] = ty;
+    }
+    for (int r = 0; r < 8; r++)
+        for (int c = 0; c < 8; c++) At[c][r] = a[r][c];
+    jacobi_svd8(At, W, Vt);
+    /* SVBkSb, nb == 1: x = sum_i (u_i . b / w_i) v_i over w_i above the cut-off */
+    double threshold = 0;
+    for (int i = 0; i < 8; i++) { x[i] = 0; threshold += W[i]; }
+    threshold *= DBL_EPSILON * 2;
+    for (int i = 0; i < 8; i++) {
+        double wi = W[i];
+        if (fabs(wi) <= threshold) continue;
+        wi = 1 / wi;
+        double s = 0;
+        for (int j = 0; j < 8; j++) s += At[i][j] * b[j];
+        s *= wi;
+        for (int j = 0; j < 8; j++) x[j] = x[j] + s * Vt[i][j];
+    }
+    for (int i = 0; i < 8; i++) H[i] = x[i];
+    H[8] = 1.;
+}
+
+/* den * (unit square -> quad) as an exact-integer matrix (Heckbert's square-to-quad). */
+static void square_to_quad_scaled(const double q[8], double G[9])
+{
+    double x0 = q[0], y0 = q[1], x1 = q[2], y1 = q[3], x2 = q[4], y2 = q[5], x3 = q[6], y3 = q[7];
+    double sx = x0 - x1 + x2 - x3, sy = y0 - y1 + y2 - y3;
+    double dx1 = x1 - x2, dy1 = y1 - y2, dx2 = x3 - x2, dy2 = y3 - y2;
+    double den = dx1 * dy2 - dx2 * dy1;
+    double g = sx * dy2 - dx2 * sy;
+    double h = dx1 * sy - sx * dy1;
+    G[0] = den * (x1 - x0) + g * x1; G[1] = den * (x3 - x0) + h * x3; G[2] = den * x0;
+    G[3] = den * (y1 - y0) + g * y1; G[4] = den * (y3 - y0) + h * y3; G[5] = den * y0;
+    G[6] = g;                        G[7] = h;                        G[8] = den;
+}
+
+static int quad_in_general_position(const double q[8])
+{
+    for (int a = 0; a < 4; a++) {
+        int b = (a + 1) & 3, c = (a + 2) & 3;
+        double cr = (q[2 * b] - q[2 * a]) * (q[2 * c + 1] - q[2 * a + 1]) -
+                    (q[2 * b + 1] - q[2 * a + 1]) * (q[2 * c] - q[2 * a]);
+        if (cr == 0) return 0;
+    }
+    return 1;
+}
+
+static int homography_direct(const float from[8], const float to[8], double H[9])
+{
+    double qf[8], qt[8], Gf[9], Gt[9], Af[9], Hp[9];
+    for (int i = 0; i < 8; i++) { qf[i] = from[i]; qt[i] = to[i]; }
+    if (!quad_in_general_position(qf) || !quad_in_general_position(qt)) return 0;
+    square_to_quad_scaled(qf, Gf);
+    square_to_quad_scaled(qt, Gt);
+    /* adjugate of Gf (exact in double for pixel-sized integer vertices) */
+    Af[0] = Gf[4] * Gf[8] - Gf[5] * Gf[7];
+    Af[1] = Gf[2] * Gf[7] - Gf[1] * Gf[8];
+    Af[2] = Gf[1] * Gf[5] - Gf[2] * Gf[4];
+    Af[3] = Gf[5] * Gf[6] - Gf[3] * Gf[8];
+    Af[4] = Gf[0] * Gf[8] - Gf[2] * Gf[6];
+    Af[5] = Gf[2] * Gf[3] - Gf[0] * Gf[5];
+    Af[6] = Gf[3] * Gf[7] - Gf[4] * Gf[6];
+    Af[7] = Gf[1] * Gf[6] - Gf[0] * Gf[7];
+    Af[8] = Gf[0] * Gf[4] - Gf[1] * Gf[3];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++)
+            Hp[r * 3 + c] = (Gt[r * 3] * Af[c] + Gt[r * 3 + 1] * Af[3 + c]) + Gt[r * 3 + 2] * Af[6 + c];
+    if (Hp[8] == 0 || !isfinite(Hp[8])) return 0;
+    for (int i = 0; i < 8; i++) H[i] = Hp[i] / Hp[8];
+    H[8] = 1.;
+    return 1;
+}
+
+VKO_API int vko_get_perspective_transform(const float from[8], const float to[8], int solver,
+                                          double H[9])
+{
+    if (solver == 0 && homography_direct(from, to, H)) return 0;
+    homography_jacobi(from, to, H);
+    return solver == 0 ? 1 : 0; /* 1 = hybrid fell back to the SVD path */
+}
+
+/* ------------------------------------------------------------------------------------
+ * [cv2] cv.fillPoly(mask, [pts], 1) with LINE_8, shift 0 -- element/polygon.py:70-77.
+ * drawing.cpp of OpenCV 4.5.1 (the reference's minimum pinned version):
+ *   CollectPolyEdges: every edge is first drawn with the 8-connected Bresenham Line()
+ *   (LineIterator, left_to_right), then non-horizontal edges enter the edge table with
+ *   16.16 fixed-point x and dx = (dX<<16)/dY (C division);
+ *   FillEdgeCollection: scanlines y0 <= y < y1, x-sorted active edges paired even-odd,
+ *   span [ (xa + 65535) >> 16 , xb >> 16 ].
+ * ---------------------------------------------------------------------------------- */
+static void draw_line8(uint8_t *img, int h, int w, int x1, int y1, int x2, int y2)
+{
+    /* All callers pass in-image end points (polygon relative to its own bounding box). */
+    (void)h;
+    int dx = x2 - x1, dy = y2 - y1;
+    int s = dx < 0 ? -1 : 0;
+    /* left_to_right */
+    dx = (dx ^ s) - s;
+    dy = (dy ^ s) - s;
+    x1 ^= (x1 ^ x2) & s;
+    y1 ^= (y1 ^ y2) & s;
+    ptrdiff_t istep = w, bt_pix = 1;
+    uint8_t *ptr = img + (ptrdiff_t)y1 * w + x1;
+    s = dy < 0 ? -1 : 0;
+    dy = (dy ^ s) - s;
+    istep = (istep ^ s) - s;
+    s = dy > dx ? -1 : 0;
+    /* conditional swaps */
+    dx ^= dy & s; dy ^= dx & s; dx ^= dy & s;
+    { ptrdiff_t t; if (s) { t = bt_pix; bt_pix = istep; istep = t; } }
+    int err = dx - (dy + dy);
+    int plusDelta = dx + dx, minusDelta = -(dy + dy);
+    ptrdiff_t plusStep = istep, minusStep = bt_pix;
+    int count = dx + 1;
+    for (int i = 0; i < count; i++) {
+        *ptr = 1;
+        int mask = err < 0 ? -1 : 0;
+        err += minusDelta + (plusDelta & mask);
+        ptr += minusStep + (mask ? plusStep : 0);
+    }
+}
+
+typedef struct PolyEdge {
+    int y0, y1;
+    int64_t x, dx;
+    struct PolyEdge *next;
+} PolyEdge;
+
+static int cmp_edges(const void *pa, const void *pb)
+{
+    const PolyEdge *a = (const PolyEdge *)pa, *b = (const PolyEdge *)pb;
+    if (a->y0 != b->y0) return a->y0 < b->y0 ? -1 : 1;
+    if (a->x != b->x) return a->x < b->x ? -1 : 1;
+    if (a->dx != b->dx) return a->dx < b->dx ? -1 : 1;
+    return 0;
+}
+
+VKO_API int vko_fill_poly(uint8_t *img, int h, int w, const int32_t *pts, int npts)
+{
+    if (npts <= 0) return 0;
+    PolyEdge *edges = (PolyEdge *)calloc((size_t)npts + 2, sizeof(PolyEdge));
+    if (!edges) return -1;
+    int total = 0;
+    int64_t p0x = (int64_t)pts[2 * (npts - 1)] << 16, p0y = pts[2 * (npts - 1) + 1];
+    for (int i = 0; i < npts; i++) {
+        int64_t p1x = (int64_t)pts[2 * i] << 16, p1y = pts[2 * i + 1];
+        int t0x = (int)((p0x + (1 << 15)) >> 16), t1x = (int)((p1x + (1 << 15)) >> 16);
+        draw_line8(img, h, w, t0x, (int)p0y, t1x, (int)p1y);
+        if (p0y != p1y) {
+            PolyEdge e;
+            if (p0y < p1y) { e.y0 = (int)p0y; e.y1 = (int)p1y; e.x = p0x; }
+            else           { e.y0 = (int)p1y; e.y1 = (int)p0y; e.x = p1x; }
+            e.dx = (p1x - p0x) / (p1y - p0y);
+            e.next = 0;
+            edges[total++] = e;
+        }
+        p0x = p1x; p0y = p1y;
+    }
+    if (total < 2) { free(edges); return 0; }
+    int y_max = INT_MIN;
+    for (int i = 0; i < total; i++) if (edges[i].y1 > y_max) y_max = edges[i].y1;
+    qsort(edges, (size_t)total, sizeof(PolyEdge), cmp_edges);
+    PolyEdge tmp; memset(&tmp, 0, sizeof tmp);
+    edges[total].y0 = INT_MAX; /* sentinel */
+    int i = 0;
+    tmp.next = 0;
+    PolyEdge *e = &edges[i];
+    if (y_max > h) y_max = h;
+    for (int y = e->y0; y < y_max; y++) {
+        PolyEdge *last, *prelast, *keep_prelast;
+        int draw = 0;
+        int clipline = y < 0;
+        prelast = &tmp;
+        last = tmp.next;
+        while (last || e->y0 == y) {
+            if (last && last->y1 == y) {
+                prelast->next = last->next;
+                last = last->next;
+                continue;
+            }
+            keep_prelast = prelast;
+            if (last && (e->y0 > y || last->x < e->x)) {
+                prelast = last;
+                last = last->next;
+            } else if (i < total) {
+                prelast->next = e;
+                e->next = last;
+                prelast = e;
+                e = &edges[++i];
+            } else
+                break;
+            if (draw) {
+                if (!clipline) {
+                    uint8_t *timg = img + (ptrdiff_t)y * w;
+                    int x1, x2;
+                    if (keep_prelast->x > prelast->x) {
+                        x1 = (int)((prelast->x + 65535) >> 16);
+                        x2 = (int)(keep_prelast->x >> 16);
+                    } else {
+                        x1 = (int)((keep_prelast->x + 65535) >> 16);
+                        x2 = (int)(prelast->x >> 16);
+                    }
+                    if (x1 < w && x2 >= 0) {
+                        if (x1 < 0) x1 = 0;
+                        if (x2 >= w) x2 = w - 1;
+                        for (int x = x1; x <= x2; x++) timg[x] = 1;
+                    }
+                }
+                keep_prelast->x += keep_prelast->dx;
+                prelast->x += prelast->dx;
+            }
+            draw ^= 1;
+        }
+        /* bubble sort of the active list by the advanced x */
+        keep_prelast = 0;
+        do {
+            prelast = &tmp;
+            last = tmp.next;
+            PolyEdge *last_exchange = 0;
+            while (last != keep_prelast && last && last->next != 0) {
+                PolyEdge *te = last->next;
+                if (last->x > te->x) {
+                    prelast->next = te;
+                    last->next = te->next;
+                    te->next = last;
+                    prelast = te;
+                    last_exchange = prelast;
+                } else {
+                    prelast = last;
+                    last = te;
+                }
+            }
+            if (last_exchange == 0) break;
+            keep_prelast = last_exchange;
+        } while (keep_prelast != tmp.next && keep_prelast != &tmp);
+    }
+    free(edges);
+    return 0;
+}
+
+/* Independent closed-form statement of the same fill (used to cross-check the literal
+ * scan converter above and as the specification the HIP rasteriser is written against):
+ * pixel set = Bresenham pixels of the edges  U  even-odd spans of the half-open edges. */
+static int bres_minor(int k, int dmaj, int dmin)
+{
+    /* number of minor steps taken after k major steps: ceil((2*k*dmin - dmaj)/(2*dmaj)), >= 0 */
+    if (dmaj == 0) return 0;
+    long num = 2L * k * dmin - dmaj;
+    if (num <= 0) return 0;
+    return (int)((num + 2L * dmaj - 1) / (2L * dmaj));
+}
+
+VKO_API int vko_fill_poly_closed_form(uint8_t *img, int h, int w, const int32_t *pts, int npts)
+{
+    (void)h;
+    if (npts <= 0) return 0;
+    int y_lo = INT_MAX, y_hi = INT_MIN;
+    for (int i = 0; i < npts; i++) {
+        int a = (i + npts - 1) % npts;
+        int xa = pts[2 * a], ya = pts[2 * a + 1], xb = pts[2 * i], yb = pts[2 * i + 1];
+        /* Bresenham from the left end */
+        int lx = xa, ly = ya, rx = xb, ry = yb;
+        if (xb < xa) { lx = xb; ly = yb; rx = xa; ry = ya; }
+        int dx = rx - lx, dy = ry - ly, ady = dy < 0 ? -dy : dy, sy = dy < 0 ? -1 : 1;
+        if (ady > dx) {
+            for (int k = 0; k <= ady; k++) img[(ptrdiff_t)(ly + sy * k) * w + lx + bres_minor(k, ady, dx)] = 1;
+        } else {
+            for (int k = 0; k <= dx; k++) img[(ptrdiff_t)(ly + sy * bres_minor(k, dx, ady)) * w + lx + k] = 1;
+        }
+        if (ya != yb) {
+            if ((ya < yb ? ya : yb) < y_lo) y_lo = ya < yb ? ya : yb;
+            if ((ya > yb ? ya : yb) > y_hi) y_hi = ya > yb ? ya : yb;
+        }
+    }
+    int64_t *xs = (int64_t *)malloc(sizeof(int64_t) * (size_t)npts);
+    if (!xs) return -1;
+    for (int y = y_lo; y < y_hi; y++) {
+        int n = 0;
+        for (int i = 0; i < npts; i++) {
+            int a = (i + npts - 1) % npts;
+            int64_t xa = (int64_t)pts[2 * a] << 16, xb = (int64_t)pts[2 * i] << 16;
+            int ya = pts[2 * a + 1], yb = pts[2 * i + 1];
+            if (ya == yb) continue;
+            int64_t dxe = (xb - xa) / (yb - ya);
+            int y0 = ya < yb ? ya : yb, y1 = ya < yb ? yb : ya;
+            int64_t x0 = ya < yb ? xa : xb;
+            if (y0 <= y && y < y1) xs[n++] = x0 + (int64_t)(y - y0) * dxe;
+        }
+        for (int a = 1; a < n; a++) { /* insertion sort */
+            int64_t v = xs[a]; int b = a - 1;
+            while (b >= 0 && xs[b] > v) { xs[b + 1] = xs[b]; b--; }
+            xs[b + 1] = v;
+        }
+        for (int a = 0; a + 1 < n; a += 2) {
+            int x1 = (int)((xs[a] + 65535) >> 16), x2 = (int)(xs[a + 1] >> 16);
+            if (x1 < 0) x1 = 0;
+            if (x2 >= w) x2 = w - 1;
+            for (int x = x1; x <= x2; x++) img[(ptrdiff_t)y * w + x] = 1;
+        }
+    }
+    free(xs);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * ImageGrid.generate_remap_params -- grid_rendering/type.py:209-261 (with :182-207 and
+ * element/polygon.py:70-133).  Vertices are the ROUNDED integer grid points, (rows x cols
+ * x 2) int32 as (x, y).  Cells in row-major order; later cells overwrite earlier ones;
+ * pixels whose denominator is exactly 0 are skipped; untouched pixels stay (0, 0).
+ * The per-pixel product np.matmul(inv_H (3x3 f64), [x; y; 1]) is a BLAS dgemm whose
+ * micro-kernel accumulates k = 0,1,2 with FMA: acc = fma(m2, 1, fma(m1, y, m0 * x))
+ * (verified against numpy 2.2.6 + OpenBLAS 0.3.29 for every N >= 2).
+ * ---------------------------------------------------------------------------------- */
+VKO_API int vko_grid_to_map(const int32_t *src_v, const int32_t *dst_v, int rows, int cols,
+                            int dh, int dw, int solver, float *map_x, float *map_y,
+                            int32_t *owner /* optional, cell index + 1 */)
+{
+    memset(map_x, 0, sizeof(float) * (size_t)dh * dw);
+    memset(map_y, 0, sizeof(float) * (size_t)dh * dw);
+    if (owner) memset(owner, 0, sizeof(int32_t) * (size_t)dh * dw);
+    for (int r = 0; r + 1 < rows; r++)
+        for (int c = 0; c + 1 < cols; c++) {
+            int idx[4] = { r * cols + c, r * cols + c + 1, (r + 1) * cols + c + 1, (r + 1) * cols + c };
+            float from[8], to[8];
+            int32_t q[8];
+            int xmin = INT_MAX, xmax = INT_MIN, ymin = INT_MAX, ymax = INT_MIN;
+            for (int k = 0; k < 4; k++) {
+                q[2 * k] = dst_v[2 * idx[k]]; q[2 * k + 1] = dst_v[2 * idx[k] + 1];
+                from[2 * k] = (float)q[2 * k]; from[2 * k + 1] = (float)q[2 * k + 1];
+                to[2 * k] = (float)src_v[2 * idx[k]]; to[2 * k + 1] = (float)src_v[2 * idx[k] + 1];
+                if (q[2 * k] < xmin) xmin = q[2 * k];
+                if (q[2 * k] > xmax) xmax = q[2 * k];
+                if (q[2 * k + 1] < ymin) ymin = q[2 * k + 1];
+                if (q[2 * k + 1] > ymax) ymax = q[2 * k + 1];
+            }
+            double H[9];
+            vko_get_perspective_transform(from, to, solver, H);
+            int bw = xmax - xmin + 1, bh = ymax - ymin + 1, np_ = 4;
+            int32_t rel[8];
+            for (int k = 0; k < 4; k++) { rel[2 * k] = q[2 * k] - xmin; rel[2 * k + 1] = q[2 * k + 1] - ymin; }
+            /* PointList.from_np_array drops a closing duplicate (element/point.py:163-166) */
+            if (rel[0] == rel[6] && rel[1] == rel[7]) np_ = 3;
+            uint8_t *mask = (uint8_t *)calloc((size_t)bw * bh, 1);
+            if (!mask) return -1;
+            vko_fill_poly(mask, bh, bw, rel, np_);
+            for (int yy = 0; yy < bh; yy++)
+                for (int xx = 0; xx < bw; xx++) {
+                    if (!mask[(size_t)yy * bw + xx]) continue;
+                    int X = xx + xmin, Y = yy + ymin;
+                    if (X < 0 || X >= dw || Y < 0 || Y >= dh) continue; /* cannot happen for a valid grid */
+                    double fx = (double)X, fy = (double)Y;
+                    double nx = fma(H[2], 1.0, fma(H[1], fy, H[0] * fx));
+                    double ny = fma(H[5], 1.0, fma(H[4], fy, H[3] * fx));
+                    double de = fma(H[8], 1.0, fma(H[7], fy, H[6] * fx));
+                    if (de == 0) continue;
+                    map_x[(size_t)Y * dw + X] = (float)(nx / de);
+                    map_y[(size_t)Y * dw + X] = (float)(ny / de);
+                    if (owner) owner[(size_t)Y * dw + X] = r * (cols - 1) + c + 1;
+                }
+            free(mask);
+        }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * [cv2] cv.GaussianBlur(u8, (k,k), sigma) -- photometric/blur.py:54-69.
+ * OpenCV >= 4.2 bit-exact path (smooth.dispatch.cpp / smooth.simd.hpp): kernel in double
+ * (getGaussianKernelBitExact), quantised to unsigned 8.8 fixed point with error diffusion
+ * and centre = 256 - 2*sum(others) (getGaussianKernelFixedPoint_ED), horizontal pass
+ * u8*8.8 -> 8.8, vertical pass 8.8*8.8 -> 16.16, (v + 32768) >> 16.  BORDER_REFLECT_101.
+ * ---------------------------------------------------------------------------------- */
+VKO_API int vko_gaussian_kernel_q8(int n, double sigma, uint16_t *kq)
+{
+    if (n <= 0 || (n & 1) == 0 || n > 255) return -1;
+    if (sigma <= 0) return -2; /* not reachable from the path (sigma sampled in [0.5, 1]) */
+    double scale2X = -0.125 / (sigma * sigma);
+    int n2 = (n - 1) / 2;
+    double values[128], kd[255];
+    double sum = 0;
+    for (int i = 0, x = 1 - n; i < n2; i++, x += 2) {
+        double t = exp((double)(x * x) * scale2X);
+        values[i] = t;
+        sum += t;
+    }
+    sum *= 2;
+    sum += 1;
+    double mul1 = 1. / sum;
+    for (int i = 0; i < n2; i++) { double t = values[i] * mul1; kd[i] = t; kd[n - 1 - i] = t; }
+    kd[n2] = 1. * mul1;
+    /* error-diffused 8.8 quantisation */
+    double err = 0;
+    int64_t isum = 0;
+    for (int i = 0; i < n2; i++) {
+        double adj = kd[i] * 256. + err;
+        int64_t v0 = cv_round_d(adj);
+        err = adj - (double)v0;
+        kq[i] = (uint16_t)v0;
+        kq[n - 1 - i] = (uint16_t)v0;
+        isum += v0;
+    }
+    isum *= 2;
+    kq[n2] = (uint16_t)(256 - isum);
+    return 0;
+}
+
+static inline int reflect101(int p, int len)
+{
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    do {
+        if (p < 0) p = -p;            /* -p - 1 + delta, delta = 1 */
+        else p = 2 * (len - 1) - p;   /* len - 1 - (p - len) - delta */
+    } while ((unsigned)p >= (unsigned)len);
+    return p;
+}
+
+VKO_API int vko_gaussian_blur_u8(const uint8_t *src, int h, int w, int cn, ptrdiff_t sstep,
+                                 int ksize, double sigma, uint8_t *dst, ptrdiff_t dstep)
+{
+    uint16_t kx[255], ky[255];
+    int kw = ksize, kh = ksize;
+    if (h == 1) kh = 1; /* GaussianBlur collapses the kernel on 1-pixel-high/wide images */
+    if (w == 1) kw = 1;
+    if (kw == 1 && kh == 1) {
+        for (int y = 0; y < h; y++) memcpy(dst + (ptrdiff_t)y * dstep, src + (ptrdiff_t)y * sstep, (size_t)w * cn);
+        return 0;
+    }
+    if (kw > 1) { if (vko_gaussian_kernel_q8(kw, sigma, kx)) return -1; } else kx[0] = 256;
+    if (kh > 1) { if (vko_gaussian_kernel_q8(kh, sigma, ky)) return -1; } else ky[0] = 256;
+    uint16_t *tmp = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)h * w * cn);
+    if (!tmp) return -1;
+    int rx = kw / 2, ry = kh / 2;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            for (int c = 0; c < cn; c++) {
+                uint32_t acc = 0;
+                for (int i = 0; i < kw; i++) {
+                    int xx = reflect101(x + i - rx, w);
+                    acc += (uint32_t)kx[i] * src[(ptrdiff_t)y * sstep + xx * cn + c];
+                }
+                tmp[((size_t)y * w + x) * cn + c] = (uint16_t)(acc > 65535 ? 65535 : acc);
+            }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            for (int c = 0; c < cn; c++) {
+                uint32_t acc = 0;
+                for (int j = 0; j < kh; j++) {
+                    int yy = reflect101(y + j - ry, h);
+                    acc += (uint32_t)ky[j] * tmp[((size_t)yy * w + x) * cn + c];
+                }
+                dst[(ptrdiff_t)y * dstep + x * cn + c] = sat_u8((int)((acc + 32768u) >> 16));
+            }
+    free(tmp);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * [cv2] cv.cvtColor RGB2HSV_FULL / HSV2RGB_FULL on uint8 -- element/image.py:188-202,
+ * 794-808, reached from photometric/color.py:93-116 (color_shift).
+ * RGB->HSV: integer LUT division (color_hsv.simd.hpp RGB2HSV_b), exactly reproducible.
+ * HSV->RGB: float formula of HSV2RGB_native (scalar path, no FMA).  cv2's SIMD lanes use an
+ * algebraically equal but differently associated form (v - v*s ...), so a given cv2 binary
+ * may differ from this definition by 1 LSB on rare tie pixels.
+ * ---------------------------------------------------------------------------------- */
+static int g_sdiv[256], g_hdiv256[256], g_hsv_ready = 0;
+static void init_hsv(void)
+{
+    if (g_hsv_ready) return;
+    g_sdiv[0] = g_hdiv256[0] = 0;
+    for (int i = 1; i < 256; i++) {
+        g_sdiv[i] = cv_round_d((255 << 12) / (1. * i));
+        g_hdiv256[i] = cv_round_d((256 << 12) / (6. * i));
+    }
+    g_hsv_ready = 1;
+}
+
+static inline void rgb2hsv_px(const uint8_t *s, uint8_t *d)
+{
+    int r = s[0], g = s[1], b = s[2];
+    int v = b, vmin = b;
+    if (g > v) v = g;
+    if (r > v) v = r;
+    if (g < vmin) vmin = g;
+    if (r < vmin) vmin = r;
+    int diff = v - vmin;
+    int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
+    int sat = (diff * g_sdiv[v] + (1 << 11)) >> 12;
+    int hh = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+    hh = (hh * g_hdiv256[diff] + (1 << 11)) >> 12;
+    hh += hh < 0 ? 256 : 0;
+    d[0] = sat_u8(hh);
+    d[1] = (uint8_t)sat;
+    d[2] = (uint8_t)v;
+}
+
+static inline void hsv2rgb_px(const uint8_t *s, uint8_t *d)
+{
+    static const int sector_data[6][3] = { {1,3,0}, {1,0,2}, {3,0,1}, {0,2,1}, {0,1,3}, {2,1,0} };
+    const float hscale = 6.0f / 256;
+    float h = (float)s[0];
+    float sat = s[1] * (1.0f / 255.0f);
+    float v = s[2] * (1.0f / 255.0f);
+    float b, g, r;
+    if (sat == 0) b = g = r = v;
+    else {
+        float tab[4];
+        h *= hscale;
+        h = fmodf(h, 6.f);
+        int sector = (int)floorf(h);
+        h -= sector;
+        if ((unsigned)sector >= 6u) { sector = 0; h = 0.f; }
+        tab[0] = v;
+        tab[1] = v * (1.f - sat);
+        tab[2] = v * (1.f - sat * h);
+        tab[3] = v * (1.f - sat * (1.f - h));
+        b = tab[sector_data[sector][0]];
+        g = tab[sector_data[sector][1]];
+        r = tab[sector_data[sector][2]];
+    }
+    d[0] = sat_u8(cv_round_f(r * 255.0f));
+    d[1] = sat_u8(cv_round_f(g * 255.0f));
+    d[2] = sat_u8(cv_round_f(b * 255.0f));
+}
+
+VKO_API int vko_rgb2hsv_full(const uint8_t *src, size_t npx, uint8_t *dst)
+{
+    init_hsv();
+    for (size_t i = 0; i < npx; i++) rgb2hsv_px(src + 3 * i, dst + 3 * i);
+    return 0;
+}
+
+VKO_API int vko_hsv2rgb_full(const uint8_t *src, size_t npx, uint8_t *dst)
+{
+    for (size_t i = 0; i < npx; i++) hsv2rgb_px(src + 3 * i, dst + 3 * i);
+    return 0;
+}
+
+/* color_shift on an RGB image: RGB->HSV_FULL, H = (H + delta) mod 256 (python modulo),
+ * HSV_FULL->RGB -- photometric/color.py:93-116, :32-55, photometric/opt.py:45-57. */
+VKO_API int vko_color_shift_rgb(const uint8_t *src, size_t npx, int delta, uint8_t *dst)
+{
+    init_hsv();
+    for (size_t i = 0; i < npx; i++) {
+        uint8_t hsv[3];
+        rgb2hsv_px(src + 3 * i, hsv);
+        int hh = ((int)hsv[0] + delta) % 256;
+        if (hh < 0) hh += 256;
+        hsv[0] = (uint8_t)hh;
+        hsv2rgb_px(hsv, dst + 3 * i);
+    }
+    return 0;
+}
+
+/* [numpy] mean_shift core: int16(px) + delta, optional threshold gate, CLIP or CYCLE
+ * -- photometric/color.py:32-55, photometric/opt.py:41-57.  channels bit mask (0 = all). */
+VKO_API int vko_mean_shift_u8(const uint8_t *src, size_t npx, int cn, int delta, int has_thr,
+                              int thr, int cycle, unsigned chmask, uint8_t *dst)
+{
+    for (size_t i = 0; i < npx; i++)
+        for (int c = 0; c < cn; c++) {
+            int v = src[i * cn + c];
+            if (chmask == 0 || (chmask >> c) & 1) {
+                if (delta != 0) {
+                    int apply = 1;
+                    if (has_thr) apply = delta > 0 ? (v <= thr) : (thr <= v);
+                    if (apply) v += delta;
+                    if (cycle) { v %= 256; if (v < 0) v += 256; }
+                    else v = v < 0 ? 0 : (v > 255 ? 255 : v);
+                }
+            }
+            dst[i * cn + c] = (uint8_t)v;
+        }
+    return 0;
+}
+
+/* [numpy] gaussion_noise tail: clip(int16(px) + int16 noise, 0, 255) -- photometric/noise.py:51-53 */
+VKO_API int vko_add_noise_i16(const uint8_t *src, const int16_t *noise, size_t n, uint8_t *dst)
+{
+    for (size_t i = 0; i < n; i++) {
+        int v = (int16_t)((int16_t)src[i] + noise[i]);
+        dst[i] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * [numpy] fill_np_array -- element/opt.py:118-209 via Box.fill_np_array element/box.py:311-340.
+ * One layer onto a uint8 HxWxC destination, in place.
+ *   box          : up, left, bh, bw (inside dst)
+ *   mask         : optional uint8 [bh, bw], selected where > 0
+ *   alpha_plane  : optional float32 [bh, bw]; if mask == NULL selects alpha > 0
+ *   alpha_scalar : used when alpha_plane == NULL (already a Python float)
+ *   value_plane  : optional uint8 [bh, bw, cn]; else value_const[cn]
+ * Blend: out = (uint8) trunc( fl32(fl32(1 - a) * fl32(dst)) + fl32(a * fl32(val)) ).
+ * ---------------------------------------------------------------------------------- */
+VKO_API int vko_fill_u8(uint8_t *dst, int h, int w, int cn, ptrdiff_t dstep, int up, int left,
+                        int bh, int bw, const uint8_t *mask, ptrdiff_t mask_step,
+                        const float *alpha_plane, ptrdiff_t alpha_step_el, double alpha_scalar,
+                        const uint8_t *value_plane, ptrdiff_t value_step,
+                        const uint8_t *value_const)
+{
+    if (up < 0 || left < 0 || up + bh > h || left + bw > w) return -1;
+    if (!alpha_plane) {
+        if (alpha_scalar < 0.0 || alpha_scalar > 1.0) return -2;
+        if (alpha_scalar == 0.0) return 0;
+    }
+    float a_s = (float)alpha_scalar;
+    for (int y = 0; y < bh; y++)
+        for (int x = 0; x < bw; x++) {
+            float a = alpha_plane ? alpha_plane[(ptrdiff_t)y * alpha_step_el + x] : a_s;
+            int sel = mask ? mask[(ptrdiff_t)y * mask_step + x] > 0 : (alpha_plane ? a > 0.0f : 1);
+            if (!sel) continue;
+            uint8_t *d = dst + (ptrdiff_t)(up + y) * dstep + (left + x) * cn;
+            const uint8_t *v = value_plane ? value_plane + (ptrdiff_t)y * value_step + x * cn : value_const;
+            if (!alpha_plane && alpha_scalar == 1.0) {
+                for (int c = 0; c < cn; c++) d[c] = v[c];
+            } else {
+                float w1 = a, w0 = 1.0f - w1;
+                for (int c = 0; c < cn; c++) {
+                    float t0 = w0 * (float)d[c];
+                    float t1 = w1 * (float)v[c];
+                    float s = t0 + t1;
+                    d[c] = (uint8_t)s;
+                }
+            }
+        }
+    return 0;
+}
+
+/* [numpy] line_streak masks + two sequential blends -- photometric/streak.py:24-41,56-99 */
+VKO_API int vko_line_streak_u8(uint8_t *img, int h, int w, int cn, ptrdiff_t step, int thickness,
+                               int gap, int dash_thickness, int dash_gap, const uint8_t *color,
+                               double alpha, int enable_vert, int enable_hori)
+{
+    int st = thickness + gap, dst_ = dash_thickness + dash_gap;
+    int dash = dash_thickness > 0 && dash_gap > 0;
+    uint8_t *mask = (uint8_t *)malloc((size_t)h * w);
+    if (!mask) return -1;
+    for (int pass = 0; pass < 2; pass++) {
+        if (pass == 0 && !enable_vert) continue;
+        if (pass == 1 && !enable_hori) continue;
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                int m;
+                if (pass == 0) { m = (x % st) < thickness; if (dash && (y % dst_) < dash_gap) m = 0; }
+                else           { m = (y % st) < thickness; if (dash && (x % dst_) < dash_gap) m = 0; }
+                mask[(size_t)y * w + x] = (uint8_t)m;
+            }
+        int rc = vko_fill_u8(img, h, w, cn, step, 0, 0, h, w, mask, w, 0, 0, alpha, 0, 0, color);
+        if (rc) { free(mask); return rc; }
+    }
+    free(mask);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * [cv2] cv.Rodrigues(rvec) (double internals) and cv.projectPoints with zero distortion
+ * -- geometric/camera.py:96, :189-195.  calib3d/calibration.cpp cvRodrigues2 /
+ * cvProjectPoints2Internal.
+ * ---------------------------------------------------------------------------------- */
+VKO_API int vko_rodrigues(const double r_in[3], double R[9])
+{
+    double rx = r_in[0], ry = r_in[1], rz = r_in[2];
+    double theta = sqrt(rx * rx + ry * ry + rz * rz);
+    if (theta < DBL_EPSILON) {
+        memset(R, 0, sizeof(double) * 9);
+        R[0] = R[4] = R[8] = 1;
+        return 0;
+    }
+    double c = cos(theta), s = sin(theta), c1 = 1. - c, itheta = theta ? 1. / theta : 0.;
+    rx *= itheta; ry *= itheta; rz *= itheta;
+    double rrt[9] = { rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz };
+    double r_x[9] = { 0, -rz, ry, rz, 0, -rx, -ry, rx, 0 };
+    double I[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    for (int k = 0; k < 9; k++) R[k] = c * I[k] + c1 * rrt[k] + s * r_x[k];
+    return 0;
+}
+
+VKO_API int vko_project_points(const double *pts3, size_t n, const double rvec[3],
+                               const double tvec[3], double fx, double fy, double cx, double cy,
+                               double *out2)
+{
+    double R[9];
+    vko_rodrigues(rvec, R);
+    for (size_t i = 0; i < n; i++) {
+        double X = pts3[3 * i], Y = pts3[3 * i + 1], Z = pts3[3 * i + 2];
+        double x = R[0] * X + R[1] * Y + R[2] * Z + tvec[0];
+        double y = R[3] * X + R[4] * Y + R[5] * Z + tvec[1];
+        double z = R[6] * X + R[7] * Y + R[8] * Z + tvec[2];
+        z = z ? 1. / z : 1;
+        x *= z; y *= z;
+        out2[2 * i] = x * fx + cx;
+        out2[2 * i + 1] = y * fy + cy;
+    }
+    return 0;
+}
+
+VKO_API int vko_version(void) { return 1; }

@@ -1,0 +1,325 @@
+"""The CPU oracle against the golden vectors produced by the real reference (numpy-only members)
+and against its own invariants (cv2-restatement members).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+from numpy.random import default_rng
+
+import oracle as O
+
+
+@pytest.fixture(scope='module')
+def G(golden_dir):
+    return np.load(os.path.join(golden_dir, 'numpy_path.npz'))
+
+
+# ------------------------------------------------------------------ fill_np_array (pinned)
+def test_fill_known_answer(G):
+    bg = np.full((4, 4, 3), 200, np.uint8)
+    a = np.linspace(0, 1, 16, dtype=np.float32).reshape(4, 4)
+    O.fill(bg, (0, 0, 4, 4), (10, 20, 30), alpha=a)
+    assert (bg == G['fill_ka_out']).all()
+    # channel 0, truncation, alpha == 0 pixel untouched
+    assert bg[:, :, 0].tolist() == [[200, 187, 174, 162], [149, 136, 124, 111], [98, 85, 73, 60], [47, 35, 22, 10]]
+
+
+def test_fill_score_map_layer(G):
+    page = G['fill_sm_in'].copy()
+    O.fill(page, tuple(G['fill_sm_box']), (10, 20, 30), alpha=G['fill_sm_alpha'])
+    assert (page == G['fill_sm_out']).all()
+
+
+def test_fill_mask_layers(G):
+    page0, m, val = G['fill_sm_in'], G['fill_mask_mask'], G['fill_mask_value']
+    page = page0.copy()
+    O.fill(page, (0, 0, 40, 56), val, mask=m)
+    assert (page == G['fill_mask_out']).all()
+    for a in (0.3, 0.5, 0.999, 1.0, 0.0):
+        page = page0.copy()
+        O.fill(page, (0, 0, 40, 56), (7, 99, 250), mask=m, alpha=a)
+        assert (page == G[f'fill_mask_const_a{a}']).all(), a
+        page = page0.copy()
+        O.fill(page, (0, 0, 40, 56), val, mask=m, alpha=a)
+        assert (page == G[f'fill_mask_img_a{a}']).all(), a
+
+
+def test_fill_box_layers(G):
+    page0, sub = G['fill_sm_in'], G['fill_box_value']
+    for a in (0.25, 1.0):
+        page = page0.copy()
+        O.fill(page, (3, 8, 10, 17), sub, alpha=a)
+        assert (page == G[f'fill_box_img_a{a}']).all()
+    page = page0.copy()
+    O.fill(page, (3, 8, 10, 17), (200, 10, 10), mask=G['fill_box_mask'], alpha=0.7)
+    assert (page == G['fill_box_mask_out']).all()
+    page = page0.copy()
+    O.fill(page, (3, 8, 10, 17), (200, 10, 10), alpha=G['fill_box_alpha'])
+    assert (page == G['fill_box_alpha_out']).all()
+
+
+def test_fill_rejects_bad_alpha():
+    page = np.zeros((4, 4, 3), np.uint8)
+    with pytest.raises(RuntimeError):
+        O.fill(page, (0, 0, 4, 4), (1, 2, 3), alpha=1.5)
+
+
+# ------------------------------------------------------------------ photometric numpy members (pinned)
+def test_noise(G):
+    src = G['photo_src']
+    plane = np.round(default_rng(1).normal(0, 10, src.shape)).astype(np.int16)
+    assert (plane == G['noise_std10_seed1_plane']).all()
+    assert (O.add_noise_i16(src, plane) == G['noise_std10_seed1']).all()
+    plane = np.round(default_rng(2).normal(0, 33.3, src.shape)).astype(np.int16)
+    assert (O.add_noise_i16(src, plane) == G['noise_std33_seed2']).all()
+
+
+def test_noise_known_answer():
+    # SURVEY Appendix B.2
+    img = default_rng(0).integers(0, 256, (8, 8, 3), dtype=np.uint8)
+    plane = np.round(default_rng(1).normal(0, 10, img.shape)).astype(np.int16)
+    out = O.add_noise_i16(img, plane)
+    assert out[0, :3].tolist() == [[98, 138, 197], [204, 216, 239], [10, 169, 37]]
+
+
+def test_mean_shift(G):
+    src = G['photo_src']
+    assert (O.mean_shift(src, 100) == G['mean_shift_100']).all()
+    assert (O.mean_shift(src, -60, channels=[1]) == G['mean_shift_m60_c1']).all()
+    assert (O.mean_shift(src, 128, threshold=127, cycle=True) == G['mean_shift_128_cycle_thr']).all()
+    assert (O.mean_shift(src, -128, threshold=128, cycle=True) == G['mean_shift_m128_cycle_thr']).all()
+    assert (O.mean_shift(src, 40, threshold=200) == G['mean_shift_40_thr200']).all()
+    # value-level asserts of the reference's own test (tests/mechanism/test_photometric_distortion.py:21-80)
+    assert (O.mean_shift(src, 255) == 255).all()
+    assert (O.mean_shift(src, 256, cycle=True) == src).all()
+    assert O.mean_shift(src, 128, threshold=127, cycle=True).min() >= 128
+    assert O.mean_shift(src, -128, threshold=128, cycle=True).max() <= 255
+
+
+def test_hue_add_on_hsv(G):
+    src = G['photo_src']
+    assert (O.mean_shift(src, 37, channels=[0], cycle=True) == G['color_shift_hsv_37']).all()
+    assert (O.mean_shift(src, -200, channels=[0], cycle=True) == G['color_shift_hsv_m200']).all()
+
+
+def test_streaks(G):
+    src = G['photo_src']
+    assert (O.line_streak(src, alpha=0.3) == G['line_streak_a03']).all()
+    assert (O.line_streak(src, thickness=2, gap=5, dash_thickness=3, dash_gap=2, color=(9, 8, 7), alpha=0.5)
+            == G['line_streak_dash']).all()
+    assert (O.line_streak(src, thickness=1, gap=3, alpha=1.0, enable_hori=False, color=(1, 2, 3))
+            == G['line_streak_vert_a1']).all()
+    assert (O.rectangle_streak(src, thickness=2, short_side_min=4, short_side_step=5, alpha=0.6, color=(5, 6, 7))
+            == G['rect_streak']).all()
+    assert (O.rectangle_streak(src, thickness=1, aspect_ratio=0.7, short_side_min=3, short_side_step=4,
+                               dash_thickness=2, dash_gap=1, alpha=1.0) == G['rect_streak_dash']).all()
+
+
+def test_line_streak_known_answer():
+    img = default_rng(0).integers(0, 256, (8, 8, 3), dtype=np.uint8)
+    out = O.line_streak(img, alpha=0.3)
+    assert out[0, :2].tolist() == [[46, 63, 94], [151, 144, 164]]
+
+
+# ------------------------------------------------------------------ cv2 restatements: invariants
+def test_bilinear_tables():
+    # the {32767, 0, 0, 1} entry at (0, 0) must behave like a pure copy: integer coordinates reproduce the source
+    src = default_rng(0).integers(0, 256, (9, 11, 3), dtype=np.uint8)
+    ys, xs = np.mgrid[0:9, 0:11].astype(np.float32)
+    assert (O.remap(src, xs, ys) == src).all()
+
+
+def test_remap_border_and_rounding():
+    src = np.arange(1, 13, dtype=np.uint8).reshape(3, 4) * 20
+    # fully outside -> 0 ; half-in taps see zeros
+    mx = np.array([[-2.0, -1.0, -0.5, 3.5, 4.0, 0.0]], np.float32)
+    my = np.array([[0.0, 0.0, 0.0, 0.0, 0.0, 2.5]], np.float32)
+    out = O.remap(src, mx, my)
+    assert out[0, 0] == 0 and out[0, 1] == 0 and out[0, 4] == 0
+    assert out[0, 2] == (20 * 16 * 32 * 32 + 16384) >> 15        # half of pixel (0,0)
+    assert out[0, 3] == (80 * 16 * 32 * 32 + 16384) >> 15        # half of pixel (0,3)
+    assert out[0, 5] == (180 * 16 * 32 * 32 + 16384) >> 15       # half of pixel (2,0)
+    # 1/32 quantisation, round half to even: 1/64 -> 0.5/32 rounds to 0; 3/64 -> 1.5/32 rounds to 2
+    mx = np.array([[1 / 64, 3 / 64]], np.float32)
+    out = O.remap(src, mx, np.zeros((1, 2), np.float32))
+    assert out[0, 0] == 20
+    assert out[0, 1] == (20 * 30 * 32 * 32 + 40 * 2 * 32 * 32 + 16384) >> 15
+    # float32 path, same coordinates
+    srcf = src.astype(np.float32) / 255
+    outf = O.remap(srcf, mx, np.zeros((1, 2), np.float32))
+    assert outf[0, 0] == srcf[0, 0]
+    w1 = np.float32(2 / 32)
+    expect = np.float32(srcf[0, 0] * (np.float32(1) - w1)) + np.float32(srcf[0, 1] * w1)
+    assert outf[0, 1] == expect
+
+
+def test_remap_huge_coordinates_are_border():
+    src = np.full((4, 4), 255, np.uint8)
+    mx = np.array([[1e30, -1e30, np.inf, np.nan, 1e9]], np.float32)
+    out = O.remap(src, mx, np.zeros_like(mx))
+    assert (out == 0).all()
+
+
+def test_warp_affine_rotate90_exact():
+    src = default_rng(5).integers(0, 256, (7, 5, 3), dtype=np.uint8)
+    # forward map (x, y) -> (H-1-y, x): a clockwise quarter turn, dsize (H, W)
+    M = np.array([[0, -1, 6], [1, 0, 0]], np.float64)
+    out = O.warp_affine(src, M, (7, 5))
+    assert (out == np.rot90(src, -1)).all()
+
+
+def test_warp_affine_known_state():
+    # RotateState(30 deg, 512x512) from the reference: identity on interior integer hits
+    M = np.array([[0.8660253882408142, -0.5, 256.0], [0.5, 0.8660253882408142, 0.0]])
+    X, Y = O.warp_affine_coords(M, (700, 700))
+    assert X.shape == (700, 700)
+    # destination (256, 0) is the image of source (0, 0)
+    assert X[0, 256] == 0 and Y[0, 256] == 0
+
+
+def test_warp_perspective_matches_affine_when_affine():
+    src = default_rng(6).integers(0, 256, (40, 33), dtype=np.uint8)
+    M2 = np.array([[0.9, 0.1, 3.0], [-0.2, 1.1, 1.5]])
+    M3 = np.vstack([M2, [0, 0, 1]])
+    a = O.warp_affine(src, M2, (50, 45))
+    p = O.warp_perspective(src, M3, (50, 45))
+    # different fixed-point pipelines (10-bit deltas vs double per pixel): at most 1/32 px apart
+    assert np.abs(a.astype(int) - p.astype(int)).max() <= 8
+    assert (a == p).mean() > 0.7
+
+
+def test_homography_solvers_agree_and_interpolate():
+    rng = default_rng(0)
+    for _ in range(200):
+        base = rng.integers(0, 4000, 2)
+        src = np.array([[0, 0], [20, 0], [20, 20], [0, 20]]) + base
+        dst = src + rng.integers(-6, 7, (4, 2))
+        H0 = O.get_perspective_transform(dst, src, O.SOLVER_HYBRID)
+        H1 = O.get_perspective_transform(dst, src, O.SOLVER_JACOBI)
+        for H, tol in ((H0, 1e-9), (H1, 1e-6)):
+            p = np.c_[dst, np.ones(4)] @ H.T
+            p = p[:, :2] / p[:, 2:]
+            assert np.abs(p - src).max() < tol
+        assert H0[2, 2] == 1.0 and H1[2, 2] == 1.0
+
+
+def test_homography_degenerate_falls_back_to_least_squares():
+    # collapsed quad (two coincident columns): the closed form declines, the SVD path returns finite numbers
+    dst = np.array([[10, 0], [10, 0], [10, 20], [10, 20]], np.float32)
+    src = np.array([[510, 0], [511, 0], [511, 20], [510, 20]], np.float32)
+    H = O.get_perspective_transform(dst, src, O.SOLVER_HYBRID)
+    assert np.isfinite(H).all()
+
+
+def test_fill_poly_literal_equals_closed_form():
+    rng = default_rng(1)
+    for _ in range(1500):
+        n = int(rng.integers(3, 6))
+        pts = np.stack([rng.integers(0, 30, n), rng.integers(0, 30, n)], 1)
+        pts -= pts.min(0)
+        shape = (pts[:, 1].max() + 1, pts[:, 0].max() + 1)
+        assert (O.fill_poly(shape, pts) == O.fill_poly(shape, pts, closed_form=True)).all()
+
+
+def test_fill_poly_rectangle_and_triangle():
+    m = O.fill_poly((5, 7), [[0, 0], [6, 0], [6, 4], [0, 4]])
+    assert m.all()
+    m = O.fill_poly((5, 5), [[0, 0], [4, 0], [0, 4]])
+    # boundary pixels belong to the polygon; the hypotenuse is the Bresenham anti-diagonal
+    assert m.tolist() == [[1, 1, 1, 1, 1], [1, 1, 1, 1, 0], [1, 1, 1, 0, 0], [1, 1, 0, 0, 0], [1, 0, 0, 0, 0]]
+
+
+def test_grid_to_map_structure_against_reference_loop(golden_dir):
+    """The reference's own generate_remap_params loop (cv2 calls substituted by the oracle's
+    getPerspectiveTransform / fillPoly) and the oracle's C restatement give the same maps."""
+    S = np.load(os.path.join(golden_dir, 'structure_oracle_patched.npz'))
+    for key in ('mls_96x80_s1_l8', 'mls_64x64_s0_l5'):
+        gx, gy = S[key + '_map_x'], S[key + '_map_y']
+        mx, my = O.grid_to_map(S[key + '_src_grid'], S[key + '_dst_grid'], gx.shape)
+        assert (mx == gx).all() and (my == gy).all(), key
+
+
+def test_grid_to_map_identity_grid():
+    ys = list(range(0, 64, 15)) + [63]
+    xs = list(range(0, 50, 15)) + [49]
+    v = np.array([[(x, y) for x in xs] for y in ys], np.int32)
+    mx, my, owner = O.grid_to_map(v, v, (64, 50), want_owner=True)
+    gy, gx = np.mgrid[0:64, 0:50]
+    assert (mx == gx).all() and (my == gy).all()
+    # last writer wins on shared edges: the pixel at an interior vertex belongs to the lower-right cell
+    assert owner[15, 15] == 1 * (len(xs) - 1) + 1 + 1
+    assert (owner > 0).all()
+
+
+def test_grid_solvers_agree_on_maps(golden_dir):
+    S = np.load(os.path.join(golden_dir, 'structure_oracle_patched.npz'))
+    key = 'mls_96x80_s1_l8'
+    a = O.grid_to_map(S[key + '_src_grid'], S[key + '_dst_grid'], S[key + '_map_x'].shape, O.SOLVER_HYBRID)
+    b = O.grid_to_map(S[key + '_src_grid'], S[key + '_dst_grid'], S[key + '_map_x'].shape, O.SOLVER_JACOBI)
+    # degenerate cells aside, both solvers induce the same map to float32 resolution
+    dx = np.abs(a[0] - b[0])
+    assert np.quantile(dx, 0.999) < 1e-4
+
+
+def test_gaussian_kernel_q8():
+    assert O.gaussian_kernel_q8(5, 1.0).tolist() == [14, 62, 104, 62, 14]
+    for k, s in ((3, 0.5), (3, 0.7), (3, 0.83), (5, 0.9), (7, 2.0), (9, 2.5)):
+        q = O.gaussian_kernel_q8(k, s)
+        assert q.sum() == 256 and (q == q[::-1]).all() and q.argmax() == k // 2
+
+
+def test_gaussian_blur_properties():
+    rng = default_rng(2)
+    const = np.full((9, 8, 3), 77, np.uint8)
+    assert (O.gaussian_blur(const, 5, 1.0) == 77).all()
+    img = rng.integers(0, 256, (12, 10), dtype=np.uint8)
+    k = O.gaussian_kernel_q8(3, 0.7).astype(np.int64)
+    out = O.gaussian_blur(img, 3, 0.7)
+    pad = np.pad(img.astype(np.int64), 1, mode='reflect')
+    hor = sum(k[i] * pad[:, i:i + 10] for i in range(3))
+    ver = sum(k[j] * hor[j:j + 12] for j in range(3))
+    assert (out == ((ver + 32768) >> 16)).all()
+    one_row = rng.integers(0, 256, (1, 10, 3), dtype=np.uint8)
+    out = O.gaussian_blur(one_row, 3, 0.7)
+    assert out.shape == one_row.shape
+
+
+def test_hsv_conversions():
+    rng = default_rng(3)
+    gray = np.repeat(rng.integers(0, 256, (50, 1), dtype=np.uint8), 3, axis=1).reshape(50, 1, 3)
+    hsv = O.rgb2hsv_full(gray)
+    assert (hsv[..., 0] == 0).all() and (hsv[..., 1] == 0).all() and (hsv[..., 2] == gray[..., 0]).all()
+    assert (O.hsv2rgb_full(hsv) == gray).all()
+    prim = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 0]]], np.uint8)
+    assert O.rgb2hsv_full(prim)[0].tolist() == [[0, 255, 255], [85, 255, 255], [171, 255, 255], [43, 255, 255]]
+    assert (O.hsv2rgb_full(O.rgb2hsv_full(prim)) == prim).all()
+    img = rng.integers(0, 256, (20, 20, 3), dtype=np.uint8)
+    # a full turn of the hue wheel is the plain RGB->HSV->RGB round trip
+    rt = O.hsv2rgb_full(O.rgb2hsv_full(img))
+    assert (O.color_shift_rgb(img, 256) == rt).all() and (O.color_shift_rgb(img, 0) == rt).all()
+    assert np.abs(rt.astype(int) - img.astype(int)).max() <= 6
+    # shift composes with the explicit pipeline
+    hsv = O.rgb2hsv_full(img)
+    hsv[..., 0] = (hsv[..., 0].astype(int) + 37) % 256
+    assert (O.color_shift_rgb(img, 37) == O.hsv2rgb_full(hsv)).all()
+
+
+def test_rodrigues_and_projection():
+    R = O.rodrigues([0, 0, np.pi / 2])
+    assert np.allclose(R, [[0, -1, 0], [1, 0, 0], [0, 0, 1]], atol=1e-15)
+    assert (O.rodrigues([0, 0, 0]) == np.eye(3)).all()
+    pts = np.array([[1.0, 2.0, 0.0], [3.0, -1.0, 2.0]])
+    out = O.project_points(pts, [0, 0, 0], [0, 0, 10], 100.0, 100.0)
+    assert np.allclose(out, [[10, 20], [25, -100 / 12]])
+
+
+def test_policy_fixture_known_answer(golden_dir):
+    with open(os.path.join(golden_dir, 'policy_configs.json')) as f:
+        recs = json.load(f)
+    rec = [r for r in recs if r['name'] == 'camera_cubic_curve' and r['seed'] == 0 and r['level'] == 5
+           and r['shape'] == [2048, 2048]][0]['config']
+    # SURVEY 8(d)
+    assert abs(rec['curve_alpha'] + 12.7058) < 1e-4 and abs(rec['curve_beta'] + 34.3899) < 1e-4
+    assert abs(rec['curve_direction'] - 146.3886) < 1e-4 and rec['grid_size'] == 20
+    assert rec['camera_model_config']['rotation_theta'] == 8
