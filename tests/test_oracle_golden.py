@@ -293,7 +293,8 @@ def test_hsv_conversions():
     assert (O.hsv2rgb_full(hsv) == gray).all()
     prim = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 0]]], np.uint8)
     assert O.rgb2hsv_full(prim)[0].tolist() == [[0, 255, 255], [85, 255, 255], [171, 255, 255], [43, 255, 255]]
-    assert (O.hsv2rgb_full(O.rgb2hsv_full(prim)) == prim).all()
+    # 8-bit hue quantisation: 85/256 is not exactly a third of the wheel
+    assert O.hsv2rgb_full(O.rgb2hsv_full(prim))[0].tolist() == [[255, 0, 0], [2, 255, 0], [2, 0, 255], [253, 255, 0]]
     img = rng.integers(0, 256, (20, 20, 3), dtype=np.uint8)
     # a full turn of the hue wheel is the plain RGB->HSV->RGB round trip
     rt = O.hsv2rgb_full(O.rgb2hsv_full(img))
