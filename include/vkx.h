@@ -1,0 +1,189 @@
+/*
+ * vkx.h -- C ABI of libvkx.so: the MI355X (gfx950) implementation of vkit's per-pixel
+ * distortion hot path.  This header is the drop-in boundary: it is what a binding on the
+ * reference side (ctypes) loads instead of the cv2 / numpy calls cited
+ * at each entry point.  Paths are relative to the reference's vkit/ package.
+ *
+ * Conventions
+ *   - Every function returns 0 (VKX_OK) or a negative error code; vkx_last_error() returns a
+ *     thread-local human readable message for the last failure on the calling thread.
+ *   - A vkx_ctx owns one HIP stream and all device scratch of one (process, GPU) pair.  Calls
+ *     on one ctx must be serialised by the caller.  ctypes releases the GIL around calls.
+ *   - `*_dev` entry points take DEVICE pointers, enqueue on the ctx stream and return
+ *     immediately (vkx_ctx_sync to wait).  Entry points without the suffix take HOST
+ *     pointers, stage through ctx scratch and are synchronous; the library never retains a
+ *     host pointer past the call.
+ *   - Images are row-major, channel-interleaved; `*_stride` is the row pitch in BYTES for
+ *     uint8 planes and in ELEMENTS for float32 / int16 / int32 planes (`*_stride_el`).
+ *   - Integer and byte results are bit-exact with oracle/ (the CPU restatement of the
+ *     reference's numpy/OpenCV arithmetic); float32 results (ScoreMap) are bit-exact too,
+ *     the stated tolerance against cv2 itself is 2 ulp.
+ */
+#ifndef VKX_H_
+#define VKX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VKX_OK 0
+#define VKX_ERR_INVALID (-1)     /* bad argument */
+#define VKX_ERR_HIP (-2)         /* HIP runtime failure (message has the hipError string) */
+#define VKX_ERR_NOMEM (-3)
+#define VKX_ERR_UNSUPPORTED (-4)
+
+typedef struct vkx_ctx vkx_ctx;
+
+/* ---- context, stream, memory -------------------------------------------------------- */
+int vkx_version(void);
+const char *vkx_last_error(void);
+int vkx_device_count(int *count);
+int vkx_ctx_create(int device, vkx_ctx **out);
+int vkx_ctx_destroy(vkx_ctx *ctx);
+int vkx_ctx_sync(vkx_ctx *ctx);
+/* Borrow an external hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL restores
+ * the ctx's own stream. */
+int vkx_ctx_set_stream(vkx_ctx *ctx, void *hip_stream);
+void *vkx_ctx_stream(vkx_ctx *ctx);
+int vkx_malloc(vkx_ctx *ctx, size_t bytes, void **dptr);
+int vkx_free(vkx_ctx *ctx, void *dptr);
+int vkx_upload(vkx_ctx *ctx, void *dptr, const void *hptr, size_t bytes);   /* synchronous */
+int vkx_download(vkx_ctx *ctx, void *hptr, const void *dptr, size_t bytes); /* synchronous */
+int vkx_memset(vkx_ctx *ctx, void *dptr, int value, size_t bytes);          /* async */
+
+/* ---- backward-map bilinear remap ----------------------------------------------------
+ * cv.remap(src, map_x, map_y, cv.INTER_LINEAR), BORDER_CONSTANT 0
+ *   mechanism/distortion/geometric/grid_rendering/grid_blender.py:60 (Image), :80 (Mask,
+ *   bilinear on 0/1 bytes), :70 (ScoreMap).  cn in {1,3,4} for uint8. */
+int vkx_remap_u8_dev(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t src_stride,
+                     const float *map_x, const float *map_y, ptrdiff_t map_stride_el,
+                     uint8_t *dst, int dh, int dw, ptrdiff_t dst_stride);
+int vkx_remap_f32_dev(vkx_ctx *ctx, const float *src, int sh, int sw, ptrdiff_t src_stride_el,
+                      const float *map_x, const float *map_y, ptrdiff_t map_stride_el,
+                      float *dst, int dh, int dw, ptrdiff_t dst_stride_el);
+int vkx_remap_u8(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t src_stride,
+                 const float *map_x, const float *map_y, ptrdiff_t map_stride_el,
+                 uint8_t *dst, int dh, int dw, ptrdiff_t dst_stride);
+int vkx_remap_f32(vkx_ctx *ctx, const float *src, int sh, int sw, ptrdiff_t src_stride_el,
+                  const float *map_x, const float *map_y, ptrdiff_t map_stride_el,
+                  float *dst, int dh, int dw, ptrdiff_t dst_stride_el);
+
+/* ---- affine / perspective warps -----------------------------------------------------
+ * cv.warpAffine(mat, trans_mat, dsize) / cv.warpPerspective(mat, trans_mat, dsize)
+ *   mechanism/distortion/geometric/affine.py:38-43 (affine_mat), used by :430-456.
+ * M is the FORWARD matrix (row-major 2x3 / 3x3, float32-valued doubles), dsize = (dw, dh). */
+int vkx_warp_affine_u8_dev(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t src_stride,
+                           const double M[6], uint8_t *dst, int dh, int dw, ptrdiff_t dst_stride);
+int vkx_warp_affine_f32_dev(vkx_ctx *ctx, const float *src, int sh, int sw, ptrdiff_t src_stride_el,
+                            const double M[6], float *dst, int dh, int dw, ptrdiff_t dst_stride_el);
+int vkx_warp_perspective_u8_dev(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t src_stride,
+                                const double M[9], uint8_t *dst, int dh, int dw, ptrdiff_t dst_stride);
+int vkx_warp_perspective_f32_dev(vkx_ctx *ctx, const float *src, int sh, int sw, ptrdiff_t src_stride_el,
+                                 const double M[9], float *dst, int dh, int dw, ptrdiff_t dst_stride_el);
+int vkx_warp_affine_u8(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t src_stride,
+                       const double M[6], uint8_t *dst, int dh, int dw, ptrdiff_t dst_stride);
+int vkx_warp_affine_f32(vkx_ctx *ctx, const float *src, int sh, int sw, ptrdiff_t src_stride_el,
+                        const double M[6], float *dst, int dh, int dw, ptrdiff_t dst_stride_el);
+int vkx_warp_perspective_u8(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t src_stride,
+                            const double M[9], uint8_t *dst, int dh, int dw, ptrdiff_t dst_stride);
+int vkx_warp_perspective_f32(vkx_ctx *ctx, const float *src, int sh, int sw, ptrdiff_t src_stride_el,
+                             const double M[9], float *dst, int dh, int dw, ptrdiff_t dst_stride_el);
+
+/* ---- image-grid distortions: grid -> dense map, and the fused grid remap ------------
+ * ImageGrid.generate_remap_params  grid_rendering/type.py:209-261 with get_inv_trans_mat
+ * (:182-197, cv.getPerspectiveTransform DECOMP_SVD) and the per-cell cv.fillPoly raster
+ * (:199-207, element/polygon.py:70-77).  Vertices: int32 [rows, cols, 2] as (x, y), the ROUNDED
+ * grid points of the source / destination ImageGrid.  Unfilled pixels map to (0, 0).
+ * owner (optional): int32 [dh, dw], 1 + row-major index of the cell that wrote the pixel. */
+int vkx_grid_to_map_dev(vkx_ctx *ctx, const int32_t *src_vertices, const int32_t *dst_vertices, int rows,
+                        int cols, int dh, int dw, float *map_x, float *map_y, ptrdiff_t map_stride_el,
+                        int32_t *owner);
+int vkx_grid_to_map(vkx_ctx *ctx, const int32_t *src_vertices, const int32_t *dst_vertices, int rows,
+                    int cols, int dh, int dw, float *map_x, float *map_y, ptrdiff_t map_stride_el,
+                    int32_t *owner);
+
+/* Shared-grid multi-element remap (blend_src_to_dst_{image,mask,score_map},
+ * grid_blender.py:54-81 through one DistortionStateImageGridBased): the dense map is never
+ * written to memory; every element is gathered in the same pass. */
+typedef struct vkx_elem {
+    const void *src;      /* uint8 [sh, sw, cn] or float32 [sh, sw] */
+    void *dst;            /* same type, [dh, dw(, cn)] */
+    ptrdiff_t src_stride; /* bytes (uint8) / elements (float32) */
+    ptrdiff_t dst_stride;
+    int32_t cn;           /* 1, 3, 4 for uint8; 1 for float32 */
+    int32_t is_f32;       /* 0: uint8, 1: float32 */
+} vkx_elem;
+int vkx_grid_remap_dev(vkx_ctx *ctx, const vkx_elem *elems, int n_elems, int sh, int sw,
+                       const int32_t *src_vertices, const int32_t *dst_vertices, int rows, int cols,
+                       int dh, int dw);
+int vkx_grid_remap(vkx_ctx *ctx, const vkx_elem *elems, int n_elems, int sh, int sw,
+                   const int32_t *src_vertices, const int32_t *dst_vertices, int rows, int cols,
+                   int dh, int dw);
+
+/* ---- photometric members ------------------------------------------------------------ */
+/* cv.GaussianBlur(mat, (k, k), sigma), BORDER_REFLECT_101  photometric/blur.py:54-69 */
+int vkx_gaussian_blur_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                             int ksize, double sigma, uint8_t *dst, ptrdiff_t dst_stride);
+int vkx_gaussian_blur_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                         int ksize, double sigma, uint8_t *dst, ptrdiff_t dst_stride);
+/* color_shift on RGB: cvtColor RGB2HSV_FULL, H = (H + delta) mod 256, HSV2RGB_FULL
+ *   photometric/color.py:93-116, element/image.py:188-202,771-814.  In place allowed. */
+int vkx_color_shift_rgb_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t src_stride, int delta,
+                            uint8_t *dst, ptrdiff_t dst_stride);
+int vkx_color_shift_rgb(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t src_stride, int delta,
+                        uint8_t *dst, ptrdiff_t dst_stride);
+/* cv.cvtColor(.., COLOR_RGB2HSV_FULL / COLOR_HSV2RGB_FULL)  element/image.py:794-808 */
+int vkx_cvt_rgb_hsv_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t src_stride, int to_hsv,
+                           uint8_t *dst, ptrdiff_t dst_stride);
+int vkx_cvt_rgb_hsv_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t src_stride, int to_hsv,
+                       uint8_t *dst, ptrdiff_t dst_stride);
+/* _mean_shift  photometric/color.py:32-55 + photometric/opt.py:41-57.  channel_mask 0 = all. */
+int vkx_mean_shift_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                          int delta, int has_threshold, int threshold, int cycle, unsigned channel_mask,
+                          uint8_t *dst, ptrdiff_t dst_stride);
+int vkx_mean_shift_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                      int delta, int has_threshold, int threshold, int cycle, unsigned channel_mask,
+                      uint8_t *dst, ptrdiff_t dst_stride);
+/* gaussion_noise_image tail: clip(int16(px) + noise, 0, 255)  photometric/noise.py:51-53.
+ * noise: int16 [h, w, cn] = round(rng.normal(0, std, shape)), C order. */
+int vkx_add_noise_i16_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                          const int16_t *noise, ptrdiff_t noise_stride_el, uint8_t *dst, ptrdiff_t dst_stride);
+int vkx_add_noise_i16(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                      const int16_t *noise, ptrdiff_t noise_stride_el, uint8_t *dst, ptrdiff_t dst_stride);
+/* line_streak_image  photometric/streak.py:56-99 (+ :24-41), in place. */
+int vkx_line_streak_u8_dev(vkx_ctx *ctx, uint8_t *img, int h, int w, int cn, ptrdiff_t stride, int thickness,
+                           int gap, int dash_thickness, int dash_gap, const uint8_t color[4], double alpha,
+                           int enable_vert, int enable_hori);
+int vkx_line_streak_u8(vkx_ctx *ctx, uint8_t *img, int h, int w, int cn, ptrdiff_t stride, int thickness,
+                       int gap, int dash_thickness, int dash_gap, const uint8_t color[4], double alpha,
+                       int enable_vert, int enable_hori);
+
+/* ---- alpha composite ----------------------------------------------------------------
+ * fill_np_array  element/opt.py:118-209 reached through Box.fill_np_array element/box.py:311-340
+ * (Box.fill_image :394-416, Mask.fill_image element/mask.py:601-612, ScoreMap.fill_image
+ * element/score_map.py:678-687); layer order = PageAssemblerStep.run
+ * pipeline/text_detection/page_assembler.py:155-236.  Layers are applied in order, in place.
+ * All plane pointers of a layer live in the same memory space as dst (device for *_dev). */
+typedef struct vkx_layer {
+    int32_t up, left, height, width; /* box inside dst */
+    const uint8_t *mask;             /* optional [height, width] uint8: selected where > 0 */
+    ptrdiff_t mask_stride;
+    const float *alpha;              /* optional [height, width] float32; selects alpha > 0 if !mask */
+    ptrdiff_t alpha_stride_el;
+    double alpha_scalar;             /* used when alpha == NULL; must be in [0, 1] */
+    const uint8_t *value;            /* optional [height, width, cn] uint8 */
+    ptrdiff_t value_stride;
+    uint8_t value_const[4];          /* used when value == NULL */
+} vkx_layer;
+int vkx_fill_u8_dev(vkx_ctx *ctx, uint8_t *dst, int h, int w, int cn, ptrdiff_t dst_stride,
+                    const vkx_layer *layers, int n_layers);
+int vkx_fill_u8(vkx_ctx *ctx, uint8_t *dst, int h, int w, int cn, ptrdiff_t dst_stride,
+                const vkx_layer *layers, int n_layers);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VKX_H_ */

@@ -290,6 +290,15 @@ VKO_API int vko_sample_fixed_f32(const float *src, int sh, int sw, ptrdiff_t sst
  * cv2 wheels are built against LAPACK (dgesdd), so even solver 1 is not bit-identical to a
  * given cv2 binary; all accurate solvers agree to ~1e-9 px on the maps they induce.
  * ---------------------------------------------------------------------------------- */
+static double vk_hypot(double a, double b)
+{
+    a = fabs(a); b = fabs(b);
+    if (a < b) { double t = a; a = b; b = t; }
+    if (a == 0) return 0;
+    double r = b / a;
+    return a * sqrt(1 + r * r);
+}
+
 static void jacobi_svd8(double At[8][8], double W[8], double Vt[8][8])
 {
     const int m = 8, n = 8;
@@ -311,7 +320,9 @@ static void jacobi_svd8(double At[8][8], double W[8], double Vt[8][8])
                 for (k = 0; k < m; k++) p += Ai[k] * Aj[k];
                 if (fabs(p) <= eps * sqrt(a * b)) continue;
                 p *= 2;
-                double beta = a - b, gamma = hypot(p, beta);
+                /* OpenCV calls libm hypot(p, beta); evaluated here with the scaled form below (a few
+                 * ulp apart at most) so that the CPU and GPU statements agree bit for bit. */
+                double beta = a - b, gamma = vk_hypot(p, beta);
                 if (beta < 0) {
                     double delta = (gamma - beta) * 0.5;
                     s = sqrt(delta / gamma);

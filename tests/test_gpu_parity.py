@@ -1,0 +1,305 @@
+"""Parity of the HIP path (through the C ABI of libvkx.so) against the CPU oracle.  Needs an MI355X.
+
+Bar: bit-exact for uint8 / index planes; float32 (ScoreMap) planes are compared bit-for-bit as well
+(the documented tolerance against cv2 itself is 2 ulp)."""
+import os
+
+import numpy as np
+import pytest
+from numpy.random import default_rng
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def N():
+    from vkit_amd import _native
+    _native.default_ctx()
+    return _native
+
+
+@pytest.fixture(scope='module')
+def grids(golden_dir):
+    """name -> (src_vertices, dst_vertices, dst_shape, src_shape)."""
+    out = {}
+    M = np.load(os.path.join(golden_dir, 'mls_states.npz'))
+    for key in ('64x64_s0_l5', '96x80_s1_l8', '130x257_s2_l10', '512x512_s0_l5', '300x200_s3_l1'):
+        dv = M[key + '_dst_grid']
+        sv = M[key + '_src_grid']
+        h, w = (int(v) for v in key.split('_')[0].split('x'))
+        out['mls_' + key] = (sv, dv, (int(dv[..., 1].max()) + 1, int(dv[..., 0].max()) + 1), (h, w))
+    S = np.load(os.path.join(golden_dir, 'structure_oracle_patched.npz'))
+    for key in [k[:-len('_dst_grid')] for k in S.files if k.startswith('cam_') and k.endswith('_dst_grid')]:
+        dv = S[key + '_dst_grid']
+        h, w = (int(v) for v in key.split('_')[2].split('x'))
+        gs = max(15, int(0.01 * max(h, w)))
+        ys = list(range(0, h, gs)) + ([h - 1] if (h - 1) % gs else [])
+        xs = list(range(0, w, gs)) + ([w - 1] if (w - 1) % gs else [])
+        sv = np.array([[(x, y) for x in xs] for y in ys], np.int32)
+        assert sv.shape == dv.shape, key
+        out[key] = (sv, dv, tuple(int(v) for v in S[key + '_result_shape']), (h, w))
+    return out
+
+
+def synthetic_grid(h, w, gs, amp, seed=0):
+    ys = list(range(0, h, gs)) + ([h - 1] if (h - 1) % gs else [])
+    xs = list(range(0, w, gs)) + ([w - 1] if (w - 1) % gs else [])
+    sv = np.array([[(x, y) for x in xs] for y in ys], np.int32)
+    rng = default_rng(seed)
+    fy, fx = sv[..., 1] / h, sv[..., 0] / w
+    px, py = rng.uniform(0, 6.28, 2)
+    dx = amp * np.sin(2.1 * np.pi * fy + px) * np.cos(1.3 * np.pi * fx) + 0.04 * amp * sv[..., 1] / gs
+    dy = amp * np.cos(1.7 * np.pi * fx + py) * np.sin(2.3 * np.pi * fy)
+    dv = np.stack([np.rint(sv[..., 0] * 1.03 + dx), np.rint(sv[..., 1] * 1.05 + dy)], -1).astype(np.int32)
+    dv[..., 0] -= dv[..., 0].min()
+    dv[..., 1] -= dv[..., 1].min()
+    return sv, dv, (int(dv[..., 1].max()) + 1, int(dv[..., 0].max()) + 1)
+
+
+# ------------------------------------------------------------------------------------------ remap / warps
+def test_remap_u8_and_f32_random_maps(N):
+    rng = default_rng(0)
+    for (sh, sw, dh, dw) in [(37, 53, 41, 67), (1, 1, 5, 5), (2, 129, 64, 64), (200, 3, 33, 300)]:
+        mx = rng.uniform(-3, sw + 3, (dh, dw)).astype(np.float32)
+        my = rng.uniform(-3, sh + 3, (dh, dw)).astype(np.float32)
+        mx[0, 0], my[0, 0] = 1e30, -1e30
+        mx[-1, -1] = np.nan
+        mx[0, -1] = np.inf
+        mx[1 % dh, 0] = sw - 1
+        my[1 % dh, 0] = sh - 1
+        for cn in (1, 3, 4):
+            src = rng.integers(0, 256, (sh, sw, cn) if cn > 1 else (sh, sw), dtype=np.uint8)
+            assert (N.remap(src, mx, my) == O.remap(src, mx, my)).all(), (sh, sw, cn)
+        srcf = rng.random((sh, sw), dtype=np.float32)
+        a, b = N.remap(srcf, mx, my), O.remap(srcf, mx, my)
+        assert (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
+def test_remap_mask_is_bilinear_threshold(N):
+    rng = default_rng(1)
+    m = (rng.random((50, 60)) < 0.5).astype(np.uint8)
+    mx = rng.uniform(0, 59, (70, 80)).astype(np.float32)
+    my = rng.uniform(0, 49, (70, 80)).astype(np.float32)
+    got = N.remap(m, mx, my)
+    assert (got == O.remap(m, mx, my)).all()
+    assert set(np.unique(got)) <= {0, 1}
+
+
+def test_warp_affine(N):
+    rng = default_rng(2)
+    src = rng.integers(0, 256, (61, 47, 3), dtype=np.uint8)
+    srcf = rng.random((61, 47), dtype=np.float32)
+    for M, dsize in [
+        (np.array([[0.8660253882408142, -0.5, 31.0], [0.5, 0.8660253882408142, 0.0]]), (73, 77)),
+        (np.array([[1, -0.5773502588272095, 36.0], [0, 1, 0]]), (84, 61)),
+        (np.array([[0, -1, 60], [1, 0, 0]], float), (61, 47)),
+        (np.array([[1e-9, 0, 0], [0, 1e-9, 0]]), (8, 8)),
+        (np.array([[0, 0, 0], [0, 0, 0]], float), (8, 8)),
+    ]:
+        assert (N.warp_affine(src, M, dsize) == O.warp_affine(src, M, dsize)).all()
+        assert (N.warp_affine(src[..., 0], M, dsize) == O.warp_affine(src[..., 0], M, dsize)).all()
+        a, b = N.warp_affine(srcf, M, dsize), O.warp_affine(srcf, M, dsize)
+        assert (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
+def test_warp_perspective(N):
+    rng = default_rng(3)
+    src = rng.integers(0, 256, (90, 130, 3), dtype=np.uint8)
+    srcf = rng.random((90, 130), dtype=np.float32)
+    pts_src = np.array([[0, 0], [129, 0], [129, 89], [0, 89]], np.float32)
+    for shrink in (0, 7, 31):
+        pts_dst = np.array([[0, shrink // 2], [129, 0], [129, 89], [0, 89 - (shrink - shrink // 2)]], np.float32)
+        M = O.get_perspective_transform(pts_src, pts_dst, O.SOLVER_JACOBI)
+        for dsize in ((130, 90), (200, 33)):
+            assert (N.warp_perspective(src, M, dsize) == O.warp_perspective(src, M, dsize)).all()
+            a, b = N.warp_perspective(srcf, M, dsize), O.warp_perspective(srcf, M, dsize)
+            assert (a.view(np.uint32) == b.view(np.uint32)).all()
+    singular = np.zeros((3, 3))
+    assert (N.warp_perspective(src, singular, (16, 16)) == O.warp_perspective(src, singular, (16, 16))).all()
+
+
+# ------------------------------------------------------------------------------------------ grid distortions
+def test_grid_to_map_on_reference_grids(N, grids):
+    for name, (sv, dv, dshape, _sshape) in grids.items():
+        mx, my, ow = N.grid_to_map(sv, dv, dshape, want_owner=True)
+        ex, ey, eo = O.grid_to_map(sv, dv, dshape, want_owner=True)
+        assert (ow == eo).all(), name
+        assert (mx.view(np.uint32) == ex.view(np.uint32)).all(), name
+        assert (my.view(np.uint32) == ey.view(np.uint32)).all(), name
+
+
+def test_grid_to_map_degenerate_and_folded_cells(N):
+    # collapsed last column, a bow-tie cell and a zero-area cell: the Jacobi-SVD / den == 0 paths
+    sv = np.array([[(x, y) for x in (0, 15, 30, 31)] for y in (0, 15, 30, 45)], np.int32)
+    dv = sv.copy()
+    dv[:, 3, 0] = dv[:, 2, 0]               # last column collapses onto its neighbour
+    dv[1, 1] = (22, 20)
+    dv[2, 1] = (9, 24)                      # fold
+    dv[3, 0] = dv[3, 1]                     # degenerate bottom-left cell
+    dshape = (int(dv[..., 1].max()) + 1, int(dv[..., 0].max()) + 1)
+    mx, my, ow = N.grid_to_map(sv, dv, dshape, want_owner=True)
+    ex, ey, eo = O.grid_to_map(sv, dv, dshape, want_owner=True)
+    assert (ow == eo).all()
+    ok = np.isfinite(ex) & np.isfinite(ey)
+    assert (mx[ok].view(np.uint32) == ex[ok].view(np.uint32)).all()
+    assert (my[ok].view(np.uint32) == ey[ok].view(np.uint32)).all()
+    assert (np.isfinite(mx) == np.isfinite(ex)).all()
+
+
+def test_grid_remap_shared_map_three_elements(N, grids):
+    rng = default_rng(4)
+    for name in ('mls_96x80_s1_l8', 'mls_130x257_s2_l10', 'cam_cubic_200x312_s3_l9', 'cam_fold_128x160_s2_l6'):
+        sv, dv, dshape, (h, w) = grids[name]
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        mask = (rng.random((h, w)) < 0.5).astype(np.uint8)
+        score = rng.random((h, w), dtype=np.float32)
+        got = N.grid_remap([img, mask, score], sv, dv, dshape)
+        mx, my = O.grid_to_map(sv, dv, dshape)
+        assert (got[0] == O.remap(img, mx, my)).all(), name
+        assert (got[1] == O.remap(mask, mx, my)).all(), name
+        assert (got[2].view(np.uint32) == O.remap(score, mx, my).view(np.uint32)).all(), name
+
+
+def test_grid_remap_identity_is_identity_full_size(N):
+    h = w = 2048
+    ys = list(range(0, h, 20)) + [h - 1]
+    xs = list(range(0, w, 20)) + [w - 1]
+    v = np.array([[(x, y) for x in xs] for y in ys], np.int32)
+    img = default_rng(1000).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    out = N.grid_remap([img], v, v, (h, w))[0]
+    assert (out == img).all()
+
+
+def test_grid_remap_full_size_against_oracle(N):
+    h = w = 2048
+    sv, dv, dshape = synthetic_grid(h, w, 20, 14.0, seed=7)
+    img = default_rng(1001).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    got = N.grid_remap([img], sv, dv, dshape)[0]
+    mx, my, eo = O.grid_to_map(sv, dv, dshape, want_owner=True)
+    want = O.remap(img, mx, my)
+    assert got.shape == want.shape
+    assert (got == want).all()
+    gx, gy, go = N.grid_to_map(sv, dv, dshape, want_owner=True)
+    assert (go == eo).all() and (gx.view(np.uint32) == mx.view(np.uint32)).all()
+
+
+def test_grid_4096_shared_state_three_outputs(N):
+    h = w = 4096
+    sv, dv, dshape = synthetic_grid(h, w, 40, 30.0, seed=9)
+    rng = default_rng(5)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    mask = (rng.random((h, w)) < 0.5).astype(np.uint8)
+    score = rng.random((h, w), dtype=np.float32)
+    got = N.grid_remap([img, mask, score], sv, dv, dshape)
+    mx, my = O.grid_to_map(sv, dv, dshape)
+    assert (got[0] == O.remap(img, mx, my)).all()
+    assert (got[1] == O.remap(mask, mx, my)).all()
+    assert (got[2].view(np.uint32) == O.remap(score, mx, my).view(np.uint32)).all()
+
+
+# ------------------------------------------------------------------------------------------ photometric
+def test_gaussian_blur(N):
+    rng = default_rng(6)
+    for shape in [(40, 50, 3), (33, 65), (1, 17, 3), (19, 1), (2, 2, 3), (3, 200, 4), (5, 5)]:
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        for ksize, sigma in [(3, 0.5), (3, 0.7), (5, 0.9), (5, 1.0), (7, 2.0)]:
+            assert (N.gaussian_blur(img, ksize, sigma) == O.gaussian_blur(img, ksize, sigma)).all(), (shape, ksize)
+
+
+def test_color_shift_and_cvt(N):
+    rng = default_rng(7)
+    img = rng.integers(0, 256, (70, 90, 3), dtype=np.uint8)
+    # every (r, g, b) corner case: grays, primaries, v == r == g ties
+    special = np.array([[[0, 0, 0], [255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [7, 7, 3], [3, 7, 7],
+                         [7, 3, 7], [1, 0, 0], [254, 255, 255]]], np.uint8)
+    for im in (img, special):
+        assert (N.cvt_rgb_hsv(im, True) == O.rgb2hsv_full(im)).all()
+        assert (N.cvt_rgb_hsv(im, False) == O.hsv2rgb_full(im)).all()
+        for delta in (0, 37, -37, 127, -127, 255, 256, -300):
+            assert (N.color_shift_rgb(im, delta) == O.color_shift_rgb(im, delta)).all(), delta
+
+
+def test_color_conversions_exhaustive_hsv_cube_slice(N):
+    # all 2^24 HSV triples -> RGB (the float path): 4096 x 4096 image
+    h = np.arange(256, dtype=np.uint8)
+    cube = np.stack(np.meshgrid(h, h, h, indexing='ij'), -1).reshape(4096, 4096, 3)
+    assert (N.cvt_rgb_hsv(cube, False) == O.hsv2rgb_full(cube)).all()
+    assert (N.cvt_rgb_hsv(cube, True) == O.rgb2hsv_full(cube)).all()
+
+
+def test_mean_shift_noise_streak(N, golden_dir):
+    G = np.load(os.path.join(golden_dir, 'numpy_path.npz'))
+    src = G['photo_src']
+    assert (N.mean_shift(src, 100) == G['mean_shift_100']).all()
+    assert (N.mean_shift(src, -60, channels=[1]) == G['mean_shift_m60_c1']).all()
+    assert (N.mean_shift(src, 128, threshold=127, cycle=True) == G['mean_shift_128_cycle_thr']).all()
+    assert (N.mean_shift(src, -128, threshold=128, cycle=True) == G['mean_shift_m128_cycle_thr']).all()
+    assert (N.mean_shift(src, 40, threshold=200) == G['mean_shift_40_thr200']).all()
+    assert (N.mean_shift(src, 37, channels=[0], cycle=True) == G['color_shift_hsv_37']).all()
+    assert (N.add_noise_i16(src, G['noise_std10_seed1_plane']) == G['noise_std10_seed1']).all()
+    big = default_rng(8).integers(-400, 400, src.shape).astype(np.int16)
+    assert (N.add_noise_i16(src, big) == O.add_noise_i16(src, big)).all()
+    assert (N.line_streak(src, 1, 4, 0, 0, (0, 0, 0), 0.3, True, True) == G['line_streak_a03']).all()
+    assert (N.line_streak(src, 2, 5, 3, 2, (9, 8, 7), 0.5, True, True) == G['line_streak_dash']).all()
+    assert (N.line_streak(src, 1, 3, 0, 0, (1, 2, 3), 1.0, True, False) == G['line_streak_vert_a1']).all()
+    gray = src[..., 0].copy()
+    assert (N.line_streak(gray, 2, 3, 0, 0, (9,), 0.25, True, True) ==
+            O.line_streak(gray, 2, 3, color=(9,), alpha=0.25)).all()
+
+
+def test_fill_layers_against_reference_goldens(N, golden_dir):
+    G = np.load(os.path.join(golden_dir, 'numpy_path.npz'))
+    page0, m, val = G['fill_sm_in'], G['fill_mask_mask'], G['fill_mask_value']
+
+    def run(layers):
+        page = page0.copy()
+        N.fill(page, layers)
+        return page
+
+    assert (run([N.make_layer(tuple(G['fill_sm_box']), 3, (10, 20, 30), alpha=G['fill_sm_alpha'])]) == G['fill_sm_out']).all()
+    assert (run([N.make_layer((0, 0, 40, 56), 3, val, mask=m)]) == G['fill_mask_out']).all()
+    for a in (0.3, 0.5, 0.999, 1.0, 0.0):
+        assert (run([N.make_layer((0, 0, 40, 56), 3, (7, 99, 250), mask=m, alpha=a)]) == G[f'fill_mask_const_a{a}']).all()
+        assert (run([N.make_layer((0, 0, 40, 56), 3, val, mask=m, alpha=a)]) == G[f'fill_mask_img_a{a}']).all()
+    for a in (0.25, 1.0):
+        assert (run([N.make_layer((3, 8, 10, 17), 3, G['fill_box_value'], alpha=a)]) == G[f'fill_box_img_a{a}']).all()
+    assert (run([N.make_layer((3, 8, 10, 17), 3, (200, 10, 10), mask=G['fill_box_mask'], alpha=0.7)])
+            == G['fill_box_mask_out']).all()
+    assert (run([N.make_layer((3, 8, 10, 17), 3, (200, 10, 10), alpha=G['fill_box_alpha'])]) == G['fill_box_alpha_out']).all()
+    with pytest.raises(N.VkxError):
+        run([N.make_layer((0, 0, 4, 4), 3, (1, 2, 3), alpha=1.5)])
+    with pytest.raises(N.VkxError):
+        run([N.make_layer((38, 0, 4, 4), 3, (1, 2, 3))])
+
+
+def test_fill_page_of_text_layers(N):
+    """C4-shaped composite: 1024^2 page, 64 text-line layers 32x512, ~30 % non-zero alpha, glyph colour."""
+    rng = default_rng(9)
+    page = np.full((1024, 1024, 3), int(rng.integers(127, 256)), np.uint8)
+    want = page.copy()
+    layers = []
+    for _ in range(64):
+        up, left = int(rng.integers(0, 1024 - 32)), int(rng.integers(0, 1024 - 512))
+        alpha = rng.random((32, 512), dtype=np.float32)
+        alpha[rng.random((32, 512)) > 0.3] = 0
+        layers.append(N.make_layer((up, left, 32, 512), 3, (10, 20, 30), alpha=alpha))
+        O.fill(want, (up, left, 32, 512), (10, 20, 30), alpha=alpha)
+    N.fill(page, layers)
+    assert (page == want).all()
+
+
+def test_chain_c3_one_full_size_image(N):
+    """camera-like grid remap + gaussian_blur + color_shift + gaussion_noise on one 2048^2 image."""
+    h = w = 2048
+    sv, dv, dshape = synthetic_grid(h, w, 20, 18.0, seed=3)
+    img = default_rng(1002).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    got = N.grid_remap([img], sv, dv, dshape)[0]
+    got = N.gaussian_blur(got, 5, 1.0)
+    got = N.color_shift_rgb(got, 37)
+    noise = np.round(default_rng(5002).normal(0, 10.0, got.shape)).astype(np.int16)
+    got = N.add_noise_i16(got, noise)
+    mx, my = O.grid_to_map(sv, dv, dshape)
+    want = O.add_noise_i16(O.color_shift_rgb(O.gaussian_blur(O.remap(img, mx, my), 5, 1.0), 37), noise)
+    assert (got == want).all()

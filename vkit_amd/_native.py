@@ -1,0 +1,441 @@
+"""ctypes binding of libvkx.so (include/vkx.h) and numpy-facing call helpers.
+
+The HIP library is the only implementation of the pixel work: importing this module fails loudly when
+``vkit_amd/libvkx.so`` has not been built (``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C vkit_amd/csrc``), and every call raises :class:`VkxError` when no MI355X is visible.  There is
+no CPU fallback.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libvkx.so')
+
+c_int = ctypes.c_int
+c_void_p = ctypes.c_void_p
+c_ssize = ctypes.c_ssize_t
+c_size = ctypes.c_size_t
+c_double = ctypes.c_double
+c_uint = ctypes.c_uint
+
+
+class VkxError(RuntimeError):
+    pass
+
+
+class VkxElem(ctypes.Structure):
+    _fields_ = [
+        ('src', c_void_p),
+        ('dst', c_void_p),
+        ('src_stride', c_ssize),
+        ('dst_stride', c_ssize),
+        ('cn', ctypes.c_int32),
+        ('is_f32', ctypes.c_int32),
+    ]
+
+
+class VkxLayer(ctypes.Structure):
+    _fields_ = [
+        ('up', ctypes.c_int32),
+        ('left', ctypes.c_int32),
+        ('height', ctypes.c_int32),
+        ('width', ctypes.c_int32),
+        ('mask', c_void_p),
+        ('mask_stride', c_ssize),
+        ('alpha', c_void_p),
+        ('alpha_stride_el', c_ssize),
+        ('alpha_scalar', c_double),
+        ('value', c_void_p),
+        ('value_stride', c_ssize),
+        ('value_const', ctypes.c_uint8 * 4),
+    ]
+
+
+# name -> argtypes; every function returns int unless noted.
+_PLANE_U8 = [c_void_p, c_int, c_int, c_int, c_ssize]  # ptr, h, w, cn, stride
+_SIGNATURES = {
+    'vkx_device_count': [ctypes.POINTER(c_int)],
+    'vkx_ctx_create': [c_int, ctypes.POINTER(c_void_p)],
+    'vkx_ctx_destroy': [c_void_p],
+    'vkx_ctx_sync': [c_void_p],
+    'vkx_ctx_set_stream': [c_void_p, c_void_p],
+    'vkx_malloc': [c_void_p, c_size, ctypes.POINTER(c_void_p)],
+    'vkx_free': [c_void_p, c_void_p],
+    'vkx_upload': [c_void_p, c_void_p, c_void_p, c_size],
+    'vkx_download': [c_void_p, c_void_p, c_void_p, c_size],
+    'vkx_memset': [c_void_p, c_void_p, c_int, c_size],
+}
+for _sfx in ('', '_dev'):
+    _SIGNATURES['vkx_remap_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_void_p, c_ssize, c_void_p, c_int, c_int, c_ssize]
+    _SIGNATURES['vkx_remap_f32' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_void_p, c_void_p, c_ssize,
+                                           c_void_p, c_int, c_int, c_ssize]
+    for _w in ('vkx_warp_affine', 'vkx_warp_perspective'):
+        _SIGNATURES[_w + '_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_void_p, c_int, c_int, c_ssize]
+        _SIGNATURES[_w + '_f32' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_void_p, c_void_p, c_int, c_int,
+                                           c_ssize]
+    _SIGNATURES['vkx_grid_to_map' + _sfx] = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                             c_void_p, c_ssize, c_void_p]
+    _SIGNATURES['vkx_grid_remap' + _sfx] = [c_void_p, ctypes.POINTER(VkxElem), c_int, c_int, c_int, c_void_p, c_void_p,
+                                            c_int, c_int, c_int, c_int]
+    _SIGNATURES['vkx_gaussian_blur_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_int, c_double, c_void_p, c_ssize]
+    _SIGNATURES['vkx_color_shift_rgb' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_int, c_void_p, c_ssize]
+    _SIGNATURES['vkx_cvt_rgb_hsv_u8' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_int, c_void_p, c_ssize]
+    _SIGNATURES['vkx_mean_shift_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_int, c_int, c_int, c_int, c_uint, c_void_p,
+                                                                        c_ssize]
+    _SIGNATURES['vkx_add_noise_i16' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_ssize, c_void_p, c_ssize]
+    _SIGNATURES['vkx_line_streak_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_int, c_int, c_int, c_int, c_void_p, c_double,
+                                                                         c_int, c_int]
+    _SIGNATURES['vkx_fill_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [ctypes.POINTER(VkxLayer), c_int]
+
+EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['vkx_version', 'vkx_last_error', 'vkx_ctx_stream'])
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def lib():
+    """The loaded shared library (argtypes installed).  Raises ImportError if it was never built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise ImportError(
+                    f'{LIB_PATH} is missing: build the HIP extension first '
+                    '(python -c "import __graft_entry__ as g; g.build()").  vkit_amd has no CPU fallback.')
+            handle = ctypes.CDLL(LIB_PATH)
+            for name, args in _SIGNATURES.items():
+                fn = getattr(handle, name)
+                fn.argtypes = args
+                fn.restype = c_int
+            handle.vkx_version.restype = c_int
+            handle.vkx_last_error.restype = ctypes.c_char_p
+            handle.vkx_ctx_stream.restype = c_void_p
+            handle.vkx_ctx_stream.argtypes = [c_void_p]
+            _lib = handle
+    return _lib
+
+
+def last_error():
+    return lib().vkx_last_error().decode('utf-8', 'replace')
+
+
+def check(rc):
+    if rc != 0:
+        raise VkxError(f'libvkx error {rc}: {last_error()}')
+
+
+def device_count():
+    n = c_int(0)
+    check(lib().vkx_device_count(ctypes.byref(n)))
+    return n.value
+
+
+class Context:
+    """One HIP stream + device scratch on one GPU.  Not thread safe; use one per thread."""
+
+    def __init__(self, device=0):
+        self._h = c_void_p()
+        self.device = int(device)
+        check(lib().vkx_ctx_create(self.device, ctypes.byref(self._h)))
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise VkxError('context already destroyed')
+        return self._h
+
+    def sync(self):
+        check(lib().vkx_ctx_sync(self.handle))
+
+    def set_stream(self, stream_ptr):
+        check(lib().vkx_ctx_set_stream(self.handle, c_void_p(stream_ptr) if stream_ptr else None))
+
+    def close(self):
+        if self._h:
+            lib().vkx_ctx_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+_ctx_lock = threading.Lock()
+
+
+def default_device():
+    for key in ('VKX_DEVICE', 'LOCAL_RANK'):
+        if os.environ.get(key, '') != '':
+            n = device_count()
+            return int(os.environ[key]) % max(n, 1)
+    return 0
+
+
+def default_ctx():
+    """Process-wide context (per thread) on ``VKX_DEVICE`` / ``LOCAL_RANK`` / GPU 0."""
+    key = (os.getpid(), threading.get_ident())
+    ctx = _default_ctx.get(key)
+    if ctx is None:
+        with _ctx_lock:
+            ctx = _default_ctx.get(key)
+            if ctx is None:
+                ctx = Context(default_device())
+                _default_ctx[key] = ctx
+    return ctx
+
+
+# --------------------------------------------------------------------------------------------------------------
+# numpy helpers over the host-pointer entry points
+# --------------------------------------------------------------------------------------------------------------
+def _ptr(a):
+    return c_void_p(a.ctypes.data)
+
+
+def _u8_plane(img):
+    """C-contiguous uint8 view + (h, w, cn, stride)."""
+    img = np.ascontiguousarray(img)
+    if img.dtype != np.uint8:
+        raise TypeError(f'expected uint8, got {img.dtype}')
+    if img.ndim == 2:
+        h, w = img.shape
+        cn = 1
+    elif img.ndim == 3:
+        h, w, cn = img.shape
+    else:
+        raise ValueError(f'expected HxW or HxWxC, got shape {img.shape}')
+    return img, h, w, cn, w * cn
+
+
+def _out_like(img, dh, dw):
+    shape = (dh, dw) if img.ndim == 2 else (dh, dw, img.shape[2])
+    return np.empty(shape, dtype=img.dtype)
+
+
+def remap(src, map_x, map_y, ctx=None):
+    ctx = ctx or default_ctx()
+    map_x = np.ascontiguousarray(map_x, dtype=np.float32)
+    map_y = np.ascontiguousarray(map_y, dtype=np.float32)
+    if map_x.shape != map_y.shape or map_x.ndim != 2:
+        raise ValueError('map_x / map_y must be 2-D and of equal shape')
+    dh, dw = map_x.shape
+    if src.dtype == np.float32:
+        src = np.ascontiguousarray(src)
+        if src.ndim != 2:
+            raise ValueError('float32 sources are single channel')
+        sh, sw = src.shape
+        dst = np.empty((dh, dw), np.float32)
+        check(lib().vkx_remap_f32(ctx.handle, _ptr(src), sh, sw, sw, _ptr(map_x), _ptr(map_y), dw, _ptr(dst), dh, dw, dw))
+        return dst
+    src, sh, sw, cn, sstride = _u8_plane(src)
+    dst = _out_like(src, dh, dw)
+    check(lib().vkx_remap_u8(ctx.handle, _ptr(src), sh, sw, cn, sstride, _ptr(map_x), _ptr(map_y), dw, _ptr(dst), dh, dw,
+                             dw * cn))
+    return dst
+
+
+def _warp(kind, src, mat, dsize, ctx):
+    ctx = ctx or default_ctx()
+    dw, dh = int(dsize[0]), int(dsize[1])
+    n = 6 if kind == 'affine' else 9
+    M = np.ascontiguousarray(np.asarray(mat, dtype=np.float64).reshape(n))
+    if src.dtype == np.float32:
+        src = np.ascontiguousarray(src)
+        if src.ndim != 2:
+            raise ValueError('float32 sources are single channel')
+        sh, sw = src.shape
+        dst = np.empty((dh, dw), np.float32)
+        fn = lib().vkx_warp_affine_f32 if kind == 'affine' else lib().vkx_warp_perspective_f32
+        check(fn(ctx.handle, _ptr(src), sh, sw, sw, _ptr(M), _ptr(dst), dh, dw, dw))
+        return dst
+    src, sh, sw, cn, sstride = _u8_plane(src)
+    dst = _out_like(src, dh, dw)
+    fn = lib().vkx_warp_affine_u8 if kind == 'affine' else lib().vkx_warp_perspective_u8
+    check(fn(ctx.handle, _ptr(src), sh, sw, cn, sstride, _ptr(M), _ptr(dst), dh, dw, dw * cn))
+    return dst
+
+
+def warp_affine(src, mat, dsize, ctx=None):
+    return _warp('affine', src, mat, dsize, ctx)
+
+
+def warp_perspective(src, mat, dsize, ctx=None):
+    return _warp('perspective', src, mat, dsize, ctx)
+
+
+def _vertices(v):
+    v = np.ascontiguousarray(v, dtype=np.int32)
+    if v.ndim != 3 or v.shape[2] != 2:
+        raise ValueError('vertices must be int32 [rows, cols, 2] as (x, y)')
+    return v
+
+
+def grid_to_map(src_vertices, dst_vertices, dst_shape, want_owner=False, ctx=None):
+    ctx = ctx or default_ctx()
+    sv, dv = _vertices(src_vertices), _vertices(dst_vertices)
+    if sv.shape != dv.shape:
+        raise ValueError('source / destination grids differ in shape')
+    rows, cols = sv.shape[:2]
+    dh, dw = int(dst_shape[0]), int(dst_shape[1])
+    mx = np.empty((dh, dw), np.float32)
+    my = np.empty((dh, dw), np.float32)
+    owner = np.empty((dh, dw), np.int32) if want_owner else None
+    check(lib().vkx_grid_to_map(ctx.handle, _ptr(sv), _ptr(dv), rows, cols, dh, dw, _ptr(mx), _ptr(my), dw,
+                                _ptr(owner) if want_owner else None))
+    return (mx, my, owner) if want_owner else (mx, my)
+
+
+def grid_remap(mats, src_vertices, dst_vertices, dst_shape, ctx=None):
+    """Gathers every array of ``mats`` (uint8 HxW[xC] / float32 HxW, all of one source shape) through one grid."""
+    ctx = ctx or default_ctx()
+    sv, dv = _vertices(src_vertices), _vertices(dst_vertices)
+    rows, cols = sv.shape[:2]
+    dh, dw = int(dst_shape[0]), int(dst_shape[1])
+    outs = []
+    for i in range(0, len(mats), 4):
+        chunk = [np.ascontiguousarray(m) for m in mats[i:i + 4]]
+        sh, sw = chunk[0].shape[:2]
+        arr = (VkxElem * len(chunk))()
+        chunk_out = []
+        for j, m in enumerate(chunk):
+            if m.shape[:2] != (sh, sw):
+                raise ValueError('all elements of one call must share the source shape')
+            if m.dtype == np.float32:
+                if m.ndim != 2:
+                    raise ValueError('float32 elements are single channel')
+                out = np.empty((dh, dw), np.float32)
+                arr[j] = VkxElem(m.ctypes.data, out.ctypes.data, sw, dw, 1, 1)
+            elif m.dtype == np.uint8:
+                cn = 1 if m.ndim == 2 else m.shape[2]
+                out = _out_like(m, dh, dw)
+                arr[j] = VkxElem(m.ctypes.data, out.ctypes.data, sw * cn, dw * cn, cn, 0)
+            else:
+                raise TypeError(f'unsupported dtype {m.dtype}')
+            chunk_out.append(out)
+        check(lib().vkx_grid_remap(ctx.handle, arr, len(chunk), sh, sw, _ptr(sv), _ptr(dv), rows, cols, dh, dw))
+        outs.extend(chunk_out)
+    return outs
+
+
+def gaussian_blur(img, ksize, sigma, ctx=None):
+    ctx = ctx or default_ctx()
+    img, h, w, cn, stride = _u8_plane(img)
+    dst = np.empty_like(img)
+    check(lib().vkx_gaussian_blur_u8(ctx.handle, _ptr(img), h, w, cn, stride, int(ksize), float(sigma), _ptr(dst), stride))
+    return dst
+
+
+def color_shift_rgb(img, delta, ctx=None):
+    ctx = ctx or default_ctx()
+    img, h, w, cn, stride = _u8_plane(img)
+    if cn != 3:
+        raise ValueError('color_shift_rgb needs an HxWx3 image')
+    dst = np.empty_like(img)
+    check(lib().vkx_color_shift_rgb(ctx.handle, _ptr(img), h, w, stride, int(delta), _ptr(dst), stride))
+    return dst
+
+
+def cvt_rgb_hsv(img, to_hsv, ctx=None):
+    ctx = ctx or default_ctx()
+    img, h, w, cn, stride = _u8_plane(img)
+    if cn != 3:
+        raise ValueError('RGB <-> HSV needs an HxWx3 image')
+    dst = np.empty_like(img)
+    check(lib().vkx_cvt_rgb_hsv_u8(ctx.handle, _ptr(img), h, w, stride, int(bool(to_hsv)), _ptr(dst), stride))
+    return dst
+
+
+def mean_shift(img, delta, threshold=None, channels=None, cycle=False, ctx=None):
+    ctx = ctx or default_ctx()
+    img, h, w, cn, stride = _u8_plane(img)
+    chmask = 0
+    for c in channels or ():
+        chmask |= 1 << int(c)
+    dst = np.empty_like(img)
+    check(lib().vkx_mean_shift_u8(ctx.handle, _ptr(img), h, w, cn, stride, int(delta), int(threshold is not None),
+                                  int(threshold or 0), int(bool(cycle)), chmask, _ptr(dst), stride))
+    return dst
+
+
+def add_noise_i16(img, noise, ctx=None):
+    ctx = ctx or default_ctx()
+    img, h, w, cn, stride = _u8_plane(img)
+    noise = np.ascontiguousarray(noise, dtype=np.int16)
+    if noise.shape != img.shape:
+        raise ValueError('noise plane must have the image shape')
+    dst = np.empty_like(img)
+    check(lib().vkx_add_noise_i16(ctx.handle, _ptr(img), h, w, cn, stride, _ptr(noise), w * cn, _ptr(dst), stride))
+    return dst
+
+
+def line_streak(img, thickness, gap, dash_thickness, dash_gap, color, alpha, enable_vert, enable_hori, ctx=None):
+    """Returns a new array (the kernel works in place on a copy)."""
+    ctx = ctx or default_ctx()
+    out = np.array(img, dtype=np.uint8, order='C')
+    _, h, w, cn, stride = _u8_plane(out)
+    col = np.zeros(4, np.uint8)
+    col[:cn] = np.asarray(color, dtype=np.uint8).reshape(-1)[:cn]
+    check(lib().vkx_line_streak_u8(ctx.handle, _ptr(out), h, w, cn, stride, int(thickness), int(gap), int(dash_thickness),
+                                   int(dash_gap), _ptr(col), float(alpha), int(bool(enable_vert)), int(bool(enable_hori))))
+    return out
+
+
+def make_layer(box, cn, value, mask=None, alpha=1.0):
+    """One composite layer.  box = (up, left, height, width).  Returns (VkxLayer, keepalive list)."""
+    up, left, bh, bw = (int(v) for v in box)
+    keep = []
+    layer = VkxLayer()
+    layer.up, layer.left, layer.height, layer.width = up, left, bh, bw
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        if mask.shape != (bh, bw):
+            raise ValueError(f'mask shape {mask.shape} != box shape {(bh, bw)}')
+        keep.append(mask)
+        layer.mask, layer.mask_stride = mask.ctypes.data, bw
+    if isinstance(alpha, np.ndarray):
+        alpha = np.ascontiguousarray(alpha, dtype=np.float32)
+        if alpha.shape != (bh, bw):
+            raise ValueError(f'alpha shape {alpha.shape} != box shape {(bh, bw)}')
+        keep.append(alpha)
+        layer.alpha, layer.alpha_stride_el = alpha.ctypes.data, bw
+        layer.alpha_scalar = 1.0
+    else:
+        layer.alpha_scalar = float(alpha)
+    if isinstance(value, np.ndarray):
+        value = np.ascontiguousarray(value.astype(np.uint8, copy=False))
+        want = (bh, bw) if cn == 1 and value.ndim == 2 else (bh, bw, cn)
+        if value.shape != want:
+            raise RuntimeError('value is np.ndarray but shape is not matched.')
+        keep.append(value)
+        layer.value, layer.value_stride = value.ctypes.data, bw * cn
+    else:
+        if isinstance(value, tuple):
+            if len(value) != cn:
+                raise RuntimeError('value is tuple but len(value) != num_channels.')
+            vals = value
+        else:
+            vals = (value,) * cn
+        for c in range(cn):
+            layer.value_const[c] = int(np.uint8(vals[c]))
+    return layer, keep
+
+
+def fill(dst, layers, ctx=None):
+    """Applies ``layers`` (list of (VkxLayer, keepalive)) to the writable uint8 array ``dst`` in place."""
+    ctx = ctx or default_ctx()
+    if dst.dtype != np.uint8 or not dst.flags.c_contiguous or not dst.flags.writeable:
+        raise ValueError('dst must be a writable C-contiguous uint8 array')
+    h, w = dst.shape[:2]
+    cn = 1 if dst.ndim == 2 else dst.shape[2]
+    arr = (VkxLayer * max(len(layers), 1))()
+    for i, (layer, _keep) in enumerate(layers):
+        arr[i] = layer
+    check(lib().vkx_fill_u8(ctx.handle, _ptr(dst), h, w, cn, w * cn, arr, len(layers)))
+    return dst

@@ -1,0 +1,157 @@
+// Context, stream and memory management of libvkx.so.
+#include "vkx_internal.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+
+static thread_local char g_err[512] = "";
+
+void vkx_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+VKX_EXPORT const char *vkx_last_error(void) { return g_err; }
+VKX_EXPORT int vkx_version(void) { return 1; }
+
+VKX_EXPORT int vkx_device_count(int *count)
+{
+    VKX_REQUIRE(count != nullptr, "count is NULL");
+    VKX_HIP(hipGetDeviceCount(count));
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_ctx_create(int device, vkx_ctx **out)
+{
+    VKX_REQUIRE(out != nullptr, "out is NULL");
+    int n = 0;
+    VKX_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) {
+        vkx_set_error("vkx_ctx_create: device %d out of range (%d visible)", device, n);
+        return VKX_ERR_INVALID;
+    }
+    VKX_HIP(hipSetDevice(device));
+    vkx_ctx *ctx = new (std::nothrow) vkx_ctx();
+    if (!ctx) { vkx_set_error("out of host memory"); return VKX_ERR_NOMEM; }
+    ctx->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        vkx_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+        delete ctx;
+        return VKX_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return VKX_OK;
+}
+
+static void scratch_release(vkx_scratch *s)
+{
+    if (s->ptr) (void)hipFree(s->ptr);
+    s->ptr = nullptr;
+    s->cap = 0;
+}
+
+VKX_EXPORT int vkx_ctx_destroy(vkx_ctx *ctx)
+{
+    if (!ctx) return VKX_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    scratch_release(&ctx->owner);
+    scratch_release(&ctx->cells);
+    scratch_release(&ctx->misc);
+    scratch_release(&ctx->tables);
+    for (auto &s : ctx->stage) scratch_release(&s);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_ctx_sync(vkx_ctx *ctx)
+{
+    VKX_REQUIRE(ctx != nullptr, "ctx is NULL");
+    VKX_HIP(hipStreamSynchronize(ctx->stream));
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_ctx_set_stream(vkx_ctx *ctx, void *hip_stream)
+{
+    VKX_REQUIRE(ctx != nullptr, "ctx is NULL");
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return VKX_OK;
+}
+
+VKX_EXPORT void *vkx_ctx_stream(vkx_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int vkx_scratch_reserve(vkx_ctx *ctx, vkx_scratch *s, size_t bytes)
+{
+    if (bytes <= s->cap) return VKX_OK;
+    VKX_HIP(hipSetDevice(ctx->device));
+    if (s->ptr) {
+        // the old block may still be in use by work queued on the stream
+        VKX_HIP(hipStreamSynchronize(ctx->stream));
+        VKX_HIP(hipFree(s->ptr));
+        s->ptr = nullptr;
+        s->cap = 0;
+    }
+    size_t cap = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&s->ptr, cap);
+    if (e != hipSuccess) {
+        s->ptr = nullptr;
+        vkx_set_error("hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? VKX_ERR_NOMEM : VKX_ERR_HIP;
+    }
+    s->cap = cap;
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_malloc(vkx_ctx *ctx, size_t bytes, void **dptr)
+{
+    VKX_REQUIRE(ctx && dptr, "NULL argument");
+    VKX_HIP(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        vkx_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? VKX_ERR_NOMEM : VKX_ERR_HIP;
+    }
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_free(vkx_ctx *ctx, void *dptr)
+{
+    VKX_REQUIRE(ctx != nullptr, "ctx is NULL");
+    if (!dptr) return VKX_OK;
+    VKX_HIP(hipSetDevice(ctx->device));
+    VKX_HIP(hipStreamSynchronize(ctx->stream));
+    VKX_HIP(hipFree(dptr));
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_upload(vkx_ctx *ctx, void *dptr, const void *hptr, size_t bytes)
+{
+    VKX_REQUIRE(ctx && (bytes == 0 || (dptr && hptr)), "NULL argument");
+    if (!bytes) return VKX_OK;
+    VKX_HIP(hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, ctx->stream));
+    VKX_HIP(hipStreamSynchronize(ctx->stream));
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_download(vkx_ctx *ctx, void *hptr, const void *dptr, size_t bytes)
+{
+    VKX_REQUIRE(ctx && (bytes == 0 || (dptr && hptr)), "NULL argument");
+    if (!bytes) return VKX_OK;
+    VKX_HIP(hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    VKX_HIP(hipStreamSynchronize(ctx->stream));
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_memset(vkx_ctx *ctx, void *dptr, int value, size_t bytes)
+{
+    VKX_REQUIRE(ctx && (bytes == 0 || dptr), "NULL argument");
+    if (!bytes) return VKX_OK;
+    VKX_HIP(hipMemsetAsync(dptr, value, bytes, ctx->stream));
+    return VKX_OK;
+}

@@ -1,0 +1,302 @@
+// Host-pointer entry points: stage the caller's numpy buffers through ctx scratch, run the *_dev
+// implementation on the ctx stream, copy the results back and synchronise.  Nothing here computes pixels.
+#include "vkx_internal.h"
+
+namespace {
+
+// Collects the planes of one call, packs them into a single device allocation (stage[0]) and moves them with
+// hipMemcpy2DAsync so arbitrary host row pitches are honoured.
+class HostStage {
+public:
+    explicit HostStage(vkx_ctx *ctx) : ctx_(ctx) {}
+
+    // returns the plane id; device pitch is row_bytes (tightly packed)
+    int add(const void *host_in, void *host_out, size_t row_bytes, int rows, ptrdiff_t host_pitch)
+    {
+        Plane p;
+        p.in = host_in; p.out = host_out; p.row_bytes = row_bytes; p.rows = rows; p.pitch = host_pitch;
+        p.off = total_;
+        total_ += (row_bytes * (size_t)(rows > 0 ? rows : 0) + 255) & ~(size_t)255;
+        planes_.push_back(p);
+        return (int)planes_.size() - 1;
+    }
+
+    int commit()
+    {
+        int rc = vkx_scratch_reserve(ctx_, &ctx_->stage[0], total_ ? total_ : 256);
+        if (rc) return rc;
+        base_ = (uint8_t *)ctx_->stage[0].ptr;
+        for (auto &p : planes_) {
+            if (!p.in || p.row_bytes == 0 || p.rows <= 0) continue;
+            VKX_HIP(hipMemcpy2DAsync(base_ + p.off, p.row_bytes, p.in, (size_t)p.pitch, p.row_bytes, (size_t)p.rows,
+                                     hipMemcpyHostToDevice, ctx_->stream));
+        }
+        return VKX_OK;
+    }
+
+    template <class T> T *dev(int id) const { return id < 0 ? nullptr : (T *)(base_ + planes_[id].off); }
+
+    int finish()
+    {
+        for (auto &p : planes_) {
+            if (!p.out || p.row_bytes == 0 || p.rows <= 0) continue;
+            VKX_HIP(hipMemcpy2DAsync(p.out, (size_t)p.pitch, base_ + p.off, p.row_bytes, p.row_bytes, (size_t)p.rows,
+                                     hipMemcpyDeviceToHost, ctx_->stream));
+        }
+        VKX_HIP(hipStreamSynchronize(ctx_->stream));
+        return VKX_OK;
+    }
+
+private:
+    struct Plane {
+        const void *in;
+        void *out;
+        size_t row_bytes;
+        int rows;
+        ptrdiff_t pitch;
+        size_t off;
+    };
+    vkx_ctx *ctx_;
+    std::vector<Plane> planes_;
+    size_t total_ = 0;
+    uint8_t *base_ = nullptr;
+};
+
+#define VKX_TRY(expr)            \
+    do {                         \
+        int rc__ = (expr);       \
+        if (rc__) return rc__;   \
+    } while (0)
+
+} // namespace
+
+VKX_EXPORT int vkx_remap_u8(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t src_stride,
+                            const float *map_x, const float *map_y, ptrdiff_t map_stride_el, uint8_t *dst, int dh,
+                            int dw, ptrdiff_t dst_stride)
+{
+    VKX_REQUIRE(ctx && src && map_x && map_y && dst, "NULL argument");
+    VKX_REQUIRE(sh > 0 && sw > 0 && dh >= 0 && dw >= 0 && cn > 0, "bad shape");
+    HostStage st(ctx);
+    const int s = st.add(src, nullptr, (size_t)sw * cn, sh, src_stride);
+    const int mx = st.add(map_x, nullptr, (size_t)dw * 4, dh, map_stride_el * 4);
+    const int my = st.add(map_y, nullptr, (size_t)dw * 4, dh, map_stride_el * 4);
+    const int d = st.add(nullptr, dst, (size_t)dw * cn, dh, dst_stride);
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_remap_u8_dev(ctx, st.dev<uint8_t>(s), sh, sw, cn, (ptrdiff_t)sw * cn, st.dev<float>(mx),
+                             st.dev<float>(my), dw, st.dev<uint8_t>(d), dh, dw, (ptrdiff_t)dw * cn));
+    return st.finish();
+}
+
+VKX_EXPORT int vkx_remap_f32(vkx_ctx *ctx, const float *src, int sh, int sw, ptrdiff_t src_stride_el,
+                             const float *map_x, const float *map_y, ptrdiff_t map_stride_el, float *dst, int dh, int dw,
+                             ptrdiff_t dst_stride_el)
+{
+    VKX_REQUIRE(ctx && src && map_x && map_y && dst, "NULL argument");
+    VKX_REQUIRE(sh > 0 && sw > 0 && dh >= 0 && dw >= 0, "bad shape");
+    HostStage st(ctx);
+    const int s = st.add(src, nullptr, (size_t)sw * 4, sh, src_stride_el * 4);
+    const int mx = st.add(map_x, nullptr, (size_t)dw * 4, dh, map_stride_el * 4);
+    const int my = st.add(map_y, nullptr, (size_t)dw * 4, dh, map_stride_el * 4);
+    const int d = st.add(nullptr, dst, (size_t)dw * 4, dh, dst_stride_el * 4);
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_remap_f32_dev(ctx, st.dev<float>(s), sh, sw, sw, st.dev<float>(mx), st.dev<float>(my), dw,
+                              st.dev<float>(d), dh, dw, dw));
+    return st.finish();
+}
+
+#define VKX_WARP_HOST(NAME, MLEN)                                                                                   \
+    VKX_EXPORT int NAME##_u8(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t src_stride,          \
+                             const double M[MLEN], uint8_t *dst, int dh, int dw, ptrdiff_t dst_stride)                \
+    {                                                                                                                 \
+        VKX_REQUIRE(ctx && src && M && dst, "NULL argument");                                                         \
+        VKX_REQUIRE(sh > 0 && sw > 0 && dh >= 0 && dw >= 0 && cn > 0, "bad shape");                                   \
+        HostStage st(ctx);                                                                                            \
+        const int s = st.add(src, nullptr, (size_t)sw * cn, sh, src_stride);                                          \
+        const int d = st.add(nullptr, dst, (size_t)dw * cn, dh, dst_stride);                                          \
+        VKX_TRY(st.commit());                                                                                         \
+        VKX_TRY(NAME##_u8_dev(ctx, st.dev<uint8_t>(s), sh, sw, cn, (ptrdiff_t)sw * cn, M, st.dev<uint8_t>(d), dh, dw, \
+                              (ptrdiff_t)dw * cn));                                                                   \
+        return st.finish();                                                                                           \
+    }                                                                                                                 \
+    VKX_EXPORT int NAME##_f32(vkx_ctx *ctx, const float *src, int sh, int sw, ptrdiff_t src_stride_el,                \
+                              const double M[MLEN], float *dst, int dh, int dw, ptrdiff_t dst_stride_el)              \
+    {                                                                                                                 \
+        VKX_REQUIRE(ctx && src && M && dst, "NULL argument");                                                         \
+        VKX_REQUIRE(sh > 0 && sw > 0 && dh >= 0 && dw >= 0, "bad shape");                                             \
+        HostStage st(ctx);                                                                                            \
+        const int s = st.add(src, nullptr, (size_t)sw * 4, sh, src_stride_el * 4);                                    \
+        const int d = st.add(nullptr, dst, (size_t)dw * 4, dh, dst_stride_el * 4);                                    \
+        VKX_TRY(st.commit());                                                                                         \
+        VKX_TRY(NAME##_f32_dev(ctx, st.dev<float>(s), sh, sw, sw, M, st.dev<float>(d), dh, dw, dw));                  \
+        return st.finish();                                                                                           \
+    }
+
+VKX_WARP_HOST(vkx_warp_affine, 6)
+VKX_WARP_HOST(vkx_warp_perspective, 9)
+
+VKX_EXPORT int vkx_grid_to_map(vkx_ctx *ctx, const int32_t *src_vertices, const int32_t *dst_vertices, int rows,
+                               int cols, int dh, int dw, float *map_x, float *map_y, ptrdiff_t map_stride_el,
+                               int32_t *owner)
+{
+    VKX_REQUIRE(ctx && src_vertices && dst_vertices && map_x && map_y, "NULL argument");
+    VKX_REQUIRE(rows >= 2 && cols >= 2 && dh > 0 && dw > 0, "bad shape");
+    HostStage st(ctx);
+    const size_t vbytes = (size_t)rows * cols * 2 * sizeof(int32_t);
+    const int sv = st.add(src_vertices, nullptr, vbytes, 1, (ptrdiff_t)vbytes);
+    const int dv = st.add(dst_vertices, nullptr, vbytes, 1, (ptrdiff_t)vbytes);
+    const int mx = st.add(nullptr, map_x, (size_t)dw * 4, dh, map_stride_el * 4);
+    const int my = st.add(nullptr, map_y, (size_t)dw * 4, dh, map_stride_el * 4);
+    const int ow = owner ? st.add(nullptr, owner, (size_t)dw * 4, dh, (ptrdiff_t)dw * 4) : -1;
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_grid_to_map_dev(ctx, st.dev<int32_t>(sv), st.dev<int32_t>(dv), rows, cols, dh, dw, st.dev<float>(mx),
+                                st.dev<float>(my), dw, st.dev<int32_t>(ow)));
+    return st.finish();
+}
+
+VKX_EXPORT int vkx_grid_remap(vkx_ctx *ctx, const vkx_elem *elems, int n_elems, int sh, int sw,
+                              const int32_t *src_vertices, const int32_t *dst_vertices, int rows, int cols, int dh, int dw)
+{
+    VKX_REQUIRE(ctx && elems && src_vertices && dst_vertices, "NULL argument");
+    VKX_REQUIRE(n_elems >= 1 && n_elems <= 4, "1..4 elements per call");
+    VKX_REQUIRE(rows >= 2 && cols >= 2 && dh > 0 && dw > 0 && sh > 0 && sw > 0, "bad shape");
+    HostStage st(ctx);
+    const size_t vbytes = (size_t)rows * cols * 2 * sizeof(int32_t);
+    const int sv = st.add(src_vertices, nullptr, vbytes, 1, (ptrdiff_t)vbytes);
+    const int dv = st.add(dst_vertices, nullptr, vbytes, 1, (ptrdiff_t)vbytes);
+    int sid[4], did[4];
+    for (int i = 0; i < n_elems; i++) {
+        const vkx_elem &e = elems[i];
+        VKX_REQUIRE(e.src && e.dst && e.cn >= 1 && e.cn <= 4, "bad element");
+        const size_t esz = e.is_f32 ? 4 : 1;
+        sid[i] = st.add(e.src, nullptr, (size_t)sw * e.cn * esz, sh, e.src_stride * (ptrdiff_t)esz);
+        did[i] = st.add(nullptr, e.dst, (size_t)dw * e.cn * esz, dh, e.dst_stride * (ptrdiff_t)esz);
+    }
+    VKX_TRY(st.commit());
+    vkx_elem de[4];
+    for (int i = 0; i < n_elems; i++) {
+        de[i] = elems[i];
+        de[i].src = st.dev<uint8_t>(sid[i]);
+        de[i].dst = st.dev<uint8_t>(did[i]);
+        de[i].src_stride = (ptrdiff_t)sw * elems[i].cn;
+        de[i].dst_stride = (ptrdiff_t)dw * elems[i].cn;
+    }
+    VKX_TRY(vkx_grid_remap_dev(ctx, de, n_elems, sh, sw, st.dev<int32_t>(sv), st.dev<int32_t>(dv), rows, cols, dh, dw));
+    return st.finish();
+}
+
+VKX_EXPORT int vkx_gaussian_blur_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                                    int ksize, double sigma, uint8_t *dst, ptrdiff_t dst_stride)
+{
+    VKX_REQUIRE(ctx && src && dst, "NULL argument");
+    VKX_REQUIRE(h >= 0 && w >= 0 && cn > 0, "bad shape");
+    HostStage st(ctx);
+    const int s = st.add(src, nullptr, (size_t)w * cn, h, src_stride);
+    const int d = st.add(nullptr, dst, (size_t)w * cn, h, dst_stride);
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_gaussian_blur_u8_dev(ctx, st.dev<uint8_t>(s), h, w, cn, (ptrdiff_t)w * cn, ksize, sigma,
+                                     st.dev<uint8_t>(d), (ptrdiff_t)w * cn));
+    return st.finish();
+}
+
+VKX_EXPORT int vkx_color_shift_rgb(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t src_stride, int delta,
+                                   uint8_t *dst, ptrdiff_t dst_stride)
+{
+    VKX_REQUIRE(ctx && src && dst, "NULL argument");
+    VKX_REQUIRE(h >= 0 && w >= 0, "bad shape");
+    HostStage st(ctx);
+    const int s = st.add(src, dst, (size_t)w * 3, h, src_stride);
+    (void)dst_stride;
+    VKX_REQUIRE(src_stride == dst_stride, "host color_shift needs equal source / destination pitch");
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_color_shift_rgb_dev(ctx, st.dev<uint8_t>(s), h, w, (ptrdiff_t)w * 3, delta, st.dev<uint8_t>(s),
+                                    (ptrdiff_t)w * 3));
+    return st.finish();
+}
+
+VKX_EXPORT int vkx_cvt_rgb_hsv_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t src_stride, int to_hsv,
+                                  uint8_t *dst, ptrdiff_t dst_stride)
+{
+    VKX_REQUIRE(ctx && src && dst, "NULL argument");
+    VKX_REQUIRE(h >= 0 && w >= 0, "bad shape");
+    HostStage st(ctx);
+    const int s = st.add(src, nullptr, (size_t)w * 3, h, src_stride);
+    const int d = st.add(nullptr, dst, (size_t)w * 3, h, dst_stride);
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_cvt_rgb_hsv_u8_dev(ctx, st.dev<uint8_t>(s), h, w, (ptrdiff_t)w * 3, to_hsv, st.dev<uint8_t>(d),
+                                   (ptrdiff_t)w * 3));
+    return st.finish();
+}
+
+VKX_EXPORT int vkx_mean_shift_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride, int delta,
+                                 int has_threshold, int threshold, int cycle, unsigned channel_mask, uint8_t *dst,
+                                 ptrdiff_t dst_stride)
+{
+    VKX_REQUIRE(ctx && src && dst, "NULL argument");
+    VKX_REQUIRE(h >= 0 && w >= 0 && cn > 0, "bad shape");
+    HostStage st(ctx);
+    const int s = st.add(src, nullptr, (size_t)w * cn, h, src_stride);
+    const int d = st.add(nullptr, dst, (size_t)w * cn, h, dst_stride);
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_mean_shift_u8_dev(ctx, st.dev<uint8_t>(s), h, w, cn, (ptrdiff_t)w * cn, delta, has_threshold, threshold,
+                                  cycle, channel_mask, st.dev<uint8_t>(d), (ptrdiff_t)w * cn));
+    return st.finish();
+}
+
+VKX_EXPORT int vkx_add_noise_i16(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                                 const int16_t *noise, ptrdiff_t noise_stride_el, uint8_t *dst, ptrdiff_t dst_stride)
+{
+    VKX_REQUIRE(ctx && src && noise && dst, "NULL argument");
+    VKX_REQUIRE(h >= 0 && w >= 0 && cn > 0, "bad shape");
+    HostStage st(ctx);
+    const int s = st.add(src, nullptr, (size_t)w * cn, h, src_stride);
+    const int n = st.add(noise, nullptr, (size_t)w * cn * 2, h, noise_stride_el * 2);
+    const int d = st.add(nullptr, dst, (size_t)w * cn, h, dst_stride);
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_add_noise_i16_dev(ctx, st.dev<uint8_t>(s), h, w, cn, (ptrdiff_t)w * cn, st.dev<int16_t>(n),
+                                  (ptrdiff_t)w * cn, st.dev<uint8_t>(d), (ptrdiff_t)w * cn));
+    return st.finish();
+}
+
+VKX_EXPORT int vkx_line_streak_u8(vkx_ctx *ctx, uint8_t *img, int h, int w, int cn, ptrdiff_t stride, int thickness,
+                                  int gap, int dash_thickness, int dash_gap, const uint8_t color[4], double alpha,
+                                  int enable_vert, int enable_hori)
+{
+    VKX_REQUIRE(ctx && img, "NULL argument");
+    VKX_REQUIRE(h >= 0 && w >= 0 && cn > 0, "bad shape");
+    HostStage st(ctx);
+    const int s = st.add(img, img, (size_t)w * cn, h, stride);
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_line_streak_u8_dev(ctx, st.dev<uint8_t>(s), h, w, cn, (ptrdiff_t)w * cn, thickness, gap, dash_thickness,
+                                   dash_gap, color, alpha, enable_vert, enable_hori));
+    return st.finish();
+}
+
+VKX_EXPORT int vkx_fill_u8(vkx_ctx *ctx, uint8_t *dst, int h, int w, int cn, ptrdiff_t dst_stride,
+                           const vkx_layer *layers, int n_layers)
+{
+    VKX_REQUIRE(ctx && dst, "NULL argument");
+    VKX_REQUIRE(h >= 0 && w >= 0 && cn > 0, "bad shape");
+    VKX_REQUIRE(n_layers >= 0 && (n_layers == 0 || layers), "bad layer list");
+    HostStage st(ctx);
+    const int d = st.add(dst, dst, (size_t)w * cn, h, dst_stride);
+    std::vector<int> mid(n_layers, -1), aid(n_layers, -1), vid(n_layers, -1);
+    for (int i = 0; i < n_layers; i++) {
+        const vkx_layer &l = layers[i];
+        VKX_REQUIRE(l.height >= 0 && l.width >= 0, "bad layer box");
+        if (l.mask) mid[i] = st.add(l.mask, nullptr, (size_t)l.width, l.height, l.mask_stride);
+        if (l.alpha) aid[i] = st.add(l.alpha, nullptr, (size_t)l.width * 4, l.height, l.alpha_stride_el * 4);
+        if (l.value) vid[i] = st.add(l.value, nullptr, (size_t)l.width * cn, l.height, l.value_stride);
+    }
+    VKX_TRY(st.commit());
+    std::vector<vkx_layer> dl(layers, layers + n_layers);
+    for (int i = 0; i < n_layers; i++) {
+        dl[i].mask = st.dev<uint8_t>(mid[i]);
+        dl[i].mask_stride = layers[i].width;
+        dl[i].alpha = st.dev<float>(aid[i]);
+        dl[i].alpha_stride_el = layers[i].width;
+        dl[i].value = st.dev<uint8_t>(vid[i]);
+        dl[i].value_stride = (ptrdiff_t)layers[i].width * cn;
+    }
+    VKX_TRY(vkx_fill_u8_dev(ctx, st.dev<uint8_t>(d), h, w, cn, (ptrdiff_t)w * cn, dl.data(), n_layers));
+    return st.finish();
+}

@@ -1,0 +1,396 @@
+// Photometric members of the distortion chain on gfx950 (per-pixel integer / float32 work, HBM bound).
+// Arithmetic specification and reference citations: oracle/vkx_oracle.c.
+#include "vkx_internal.h"
+
+#include <math.h>
+
+namespace {
+
+constexpr int kMaxKsize = 31;
+struct BlurKernel {
+    uint16_t k[kMaxKsize]; // unsigned 8.8 fixed point, sums to 256
+    int kw, kh;
+};
+
+// getGaussianKernelBitExact + getGaussianKernelFixedPoint_ED (OpenCV >= 4.2): double kernel, error-diffused
+// 8.8 quantisation, centre tap = 256 - 2 * sum(others).
+int gaussian_kernel_q8(int n, double sigma, uint16_t *kq)
+{
+    if (n <= 0 || (n & 1) == 0 || n > kMaxKsize || !(sigma > 0)) return -1;
+    const double scale2X = -0.125 / (sigma * sigma);
+    const int n2 = (n - 1) / 2;
+    double values[kMaxKsize], kd[kMaxKsize];
+    double sum = 0;
+    for (int i = 0, x = 1 - n; i < n2; i++, x += 2) {
+        const double t = exp((double)(x * x) * scale2X);
+        values[i] = t;
+        sum += t;
+    }
+    sum *= 2;
+    sum += 1;
+    const double mul1 = 1. / sum;
+    for (int i = 0; i < n2; i++) { kd[i] = values[i] * mul1; }
+    double err = 0;
+    long long isum = 0;
+    for (int i = 0; i < n2; i++) {
+        const double adj = kd[i] * 256. + err;
+        const long long v0 = (long long)nearbyint(adj);
+        err = adj - (double)v0;
+        kq[i] = (uint16_t)v0;
+        kq[n - 1 - i] = (uint16_t)v0;
+        isum += v0;
+    }
+    kq[n2] = (uint16_t)(256 - 2 * isum);
+    return 0;
+}
+
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    do {
+        if (p < 0) p = -p;
+        else p = 2 * (len - 1) - p;
+    } while ((unsigned)p >= (unsigned)len);
+    return p;
+}
+
+// Horizontal u8 x 8.8 -> 8.8 then vertical 8.8 x 8.8 -> 16.16, (v + 2^15) >> 16, BORDER_REFLECT_101.
+template <int CN>
+__global__ void __launch_bounds__(256) k_gaussian_blur(const uint8_t *__restrict__ src, int h, int w, ptrdiff_t sstride,
+                                                       uint8_t *__restrict__ dst, ptrdiff_t dstride, BlurKernel K)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const int rx = K.kw / 2, ry = K.kh / 2;
+    uint32_t acc[CN];
+#pragma unroll
+    for (int c = 0; c < CN; c++) acc[c] = 0;
+    for (int j = 0; j < K.kh; j++) {
+        const uint8_t *row = src + (ptrdiff_t)reflect101(y + j - ry, h) * sstride;
+        uint32_t hacc[CN];
+#pragma unroll
+        for (int c = 0; c < CN; c++) hacc[c] = 0;
+        for (int i = 0; i < K.kw; i++) {
+            const uint8_t *p = row + (ptrdiff_t)reflect101(x + i - rx, w) * CN;
+            const uint32_t kx = K.kw == 1 ? 256u : K.k[i];
+#pragma unroll
+            for (int c = 0; c < CN; c++) hacc[c] += kx * p[c];
+        }
+        const uint32_t ky = K.kh == 1 ? 256u : K.k[j];
+#pragma unroll
+        for (int c = 0; c < CN; c++) acc[c] += ky * min(hacc[c], 65535u);
+    }
+    uint8_t *d = dst + (ptrdiff_t)y * dstride + (ptrdiff_t)x * CN;
+#pragma unroll
+    for (int c = 0; c < CN; c++) d[c] = (uint8_t)vkd::clamp_u8((int)((acc[c] + 32768u) >> 16));
+}
+
+// ---- cvtColor RGB <-> HSV_FULL (uint8) -----------------------------------------------------------------------
+// RGB->HSV is OpenCV's integer LUT division; the two 256-entry tables (cvRound of doubles) are built on the
+// host once and passed in device memory.
+struct HsvTables {
+    int sdiv[256];
+    int hdiv[256];
+};
+
+__device__ __forceinline__ void rgb2hsv_px(const int *__restrict__ sdiv, const int *__restrict__ hdiv, int r, int g, int b,
+                                           int &H, int &S, int &V)
+{
+    int v = max(b, max(g, r)), vmin = min(b, min(g, r));
+    const int diff = v - vmin;
+    const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
+    S = (diff * sdiv[v] + (1 << 11)) >> 12;
+    int hh = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+    hh = (hh * hdiv[diff] + (1 << 11)) >> 12;
+    hh += hh < 0 ? 256 : 0;
+    H = vkd::clamp_u8(hh);
+    V = v;
+}
+
+// HSV2RGB_native (float32, scalar path of color_hsv.simd.hpp), no FMA.
+__device__ __forceinline__ void hsv2rgb_px(int H, int S, int V, int &r, int &g, int &b)
+{
+    const float hscale = 6.0f / 256;
+    float h = (float)H;
+    const float s = S * (1.0f / 255.0f);
+    const float v = V * (1.0f / 255.0f);
+    float fb, fg, fr;
+    if (s == 0) {
+        fb = fg = fr = v;
+    } else {
+        h *= hscale;              // < 6 for every 8-bit hue: the fmod(h, 6) of the reference is the identity
+        int sector = (int)floorf(h);
+        h -= sector;
+        if ((unsigned)sector >= 6u) { sector = 0; h = 0.f; }
+        const float t0 = v;
+        const float t1 = v * (1.f - s);
+        const float t2 = v * (1.f - s * h);
+        const float t3 = v * (1.f - s * (1.f - h));
+        // sector_data = {1,3,0}, {1,0,2}, {3,0,1}, {0,2,1}, {0,1,3}, {2,1,0}  (b, g, r)
+        switch (sector) {
+        case 0: fb = t1; fg = t3; fr = t0; break;
+        case 1: fb = t1; fg = t0; fr = t2; break;
+        case 2: fb = t3; fg = t0; fr = t1; break;
+        case 3: fb = t0; fg = t2; fr = t1; break;
+        case 4: fb = t0; fg = t1; fr = t3; break;
+        default: fb = t2; fg = t1; fr = t0; break;
+        }
+    }
+    r = vkd::clamp_u8(vkd::cv_round(fr * 255.0f));
+    g = vkd::clamp_u8(vkd::cv_round(fg * 255.0f));
+    b = vkd::clamp_u8(vkd::cv_round(fb * 255.0f));
+}
+
+// mode 0: color_shift (RGB -> HSV, H += delta mod 256, HSV -> RGB); 1: RGB -> HSV; 2: HSV -> RGB
+template <int MODE>
+__global__ void __launch_bounds__(256) k_hsv(const uint8_t *__restrict__ src, int h, int w, ptrdiff_t sstride,
+                                             uint8_t *__restrict__ dst, ptrdiff_t dstride, int delta,
+                                             const HsvTables *__restrict__ T)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const uint8_t *s = src + (ptrdiff_t)y * sstride + (ptrdiff_t)x * 3;
+    uint8_t *d = dst + (ptrdiff_t)y * dstride + (ptrdiff_t)x * 3;
+    int a = s[0], b = s[1], c = s[2];
+    if (MODE == 0 || MODE == 1) {
+        int H, S, V;
+        rgb2hsv_px(T->sdiv, T->hdiv, a, b, c, H, S, V);
+        a = H; b = S; c = V;
+    }
+    if (MODE == 0) {
+        int hh = (a + delta) % 256;
+        if (hh < 0) hh += 256;
+        a = hh;
+    }
+    if (MODE == 0 || MODE == 2) {
+        int r, g, bl;
+        hsv2rgb_px(a, b, c, r, g, bl);
+        a = r; b = g; c = bl;
+    }
+    d[0] = (uint8_t)a; d[1] = (uint8_t)b; d[2] = (uint8_t)c;
+}
+
+__global__ void __launch_bounds__(256) k_mean_shift(const uint8_t *__restrict__ src, int h, int w, int cn, ptrdiff_t sstride,
+                                                    uint8_t *__restrict__ dst, ptrdiff_t dstride, int delta, int has_thr,
+                                                    int thr, int cycle, unsigned chmask)
+{
+    const int xe = blockIdx.x * 64 + threadIdx.x; // element index within the row
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (xe >= w * cn || y >= h) return;
+    const int c = xe % cn;
+    int v = src[(ptrdiff_t)y * sstride + xe];
+    if ((chmask == 0 || ((chmask >> c) & 1u)) && delta != 0) {
+        bool apply = true;
+        if (has_thr) apply = delta > 0 ? (v <= thr) : (thr <= v);
+        if (apply) v += delta;
+        if (cycle) { v %= 256; if (v < 0) v += 256; }
+        else v = vkd::clamp_u8(v);
+    }
+    dst[(ptrdiff_t)y * dstride + xe] = (uint8_t)v;
+}
+
+__global__ void __launch_bounds__(256) k_add_noise(const uint8_t *__restrict__ src, int h, int wc, ptrdiff_t sstride,
+                                                   const int16_t *__restrict__ noise, ptrdiff_t nstride,
+                                                   uint8_t *__restrict__ dst, ptrdiff_t dstride)
+{
+    const int xe = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (xe >= wc || y >= h) return;
+    const int v = (int16_t)((int16_t)src[(ptrdiff_t)y * sstride + xe] + noise[(ptrdiff_t)y * nstride + xe]);
+    dst[(ptrdiff_t)y * dstride + xe] = (uint8_t)vkd::clamp_u8(v);
+}
+
+// fill_np_array blend of one value: trunc(fl32(fl32(1 - a) * dst) + fl32(a * val)), products rounded separately.
+__device__ __forceinline__ uint8_t blend_u8(uint8_t d, uint8_t v, float w1)
+{
+    const float w0 = 1.0f - w1;
+    const float t0 = w0 * (float)d;
+    const float t1 = w1 * (float)v;
+    const float s = t0 + t1;
+    return (uint8_t)s;
+}
+
+struct StreakParams {
+    int thickness, step, dash_step, dash_gap, dash;
+    int enable_vert, enable_hori;
+    int copy;       // alpha == 1.0: plain masked copy
+    float alpha;
+    uint8_t color[4];
+};
+
+template <int CN>
+__global__ void __launch_bounds__(256) k_line_streak(uint8_t *img, int h, int w, ptrdiff_t stride, StreakParams P)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    bool mv = P.enable_vert && (x % P.step) < P.thickness;
+    bool mh = P.enable_hori && (y % P.step) < P.thickness;
+    if (P.dash) {
+        if ((y % P.dash_step) < P.dash_gap) mv = false;
+        if ((x % P.dash_step) < P.dash_gap) mh = false;
+    }
+    if (!mv && !mh) return;
+    uint8_t *d = img + (ptrdiff_t)y * stride + (ptrdiff_t)x * CN;
+#pragma unroll
+    for (int c = 0; c < CN; c++) {
+        uint8_t v = d[c];
+        // vertical stripes first, then horizontal ones: crossings are blended twice (streak.py:96-99)
+        if (mv) v = P.copy ? P.color[c] : blend_u8(v, P.color[c], P.alpha);
+        if (mh) v = P.copy ? P.color[c] : blend_u8(v, P.color[c], P.alpha);
+        d[c] = v;
+    }
+}
+
+int check_plane(vkx_ctx *ctx, const void *src, const void *dst, int h, int w)
+{
+    VKX_REQUIRE(ctx && src && dst, "NULL argument");
+    VKX_REQUIRE(h >= 0 && w >= 0, "bad shape");
+    return VKX_OK;
+}
+
+} // namespace
+
+VKX_EXPORT int vkx_gaussian_blur_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                                        int ksize, double sigma, uint8_t *dst, ptrdiff_t dst_stride)
+{
+    int rc = check_plane(ctx, src, dst, h, w);
+    if (rc) return rc;
+    VKX_REQUIRE(src != dst, "gaussian blur cannot run in place");
+    if (h == 0 || w == 0) return VKX_OK;
+    BlurKernel K;
+    K.kw = w == 1 ? 1 : ksize;
+    K.kh = h == 1 ? 1 : ksize;
+    if (ksize == 1) { K.kw = K.kh = 1; }
+    if (K.kw > 1 || K.kh > 1) {
+        if (gaussian_kernel_q8(ksize, sigma, K.k)) {
+            vkx_set_error("gaussian blur: unsupported ksize=%d sigma=%g (odd ksize <= %d, sigma > 0)", ksize, sigma,
+                          kMaxKsize);
+            return VKX_ERR_UNSUPPORTED;
+        }
+    }
+    dim3 block(64, 4), grid(vkx_blocks(w, 64), vkx_blocks(h, 4));
+    switch (cn) {
+    case 1: k_gaussian_blur<1><<<grid, block, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K); break;
+    case 3: k_gaussian_blur<3><<<grid, block, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K); break;
+    case 4: k_gaussian_blur<4><<<grid, block, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K); break;
+    default: vkx_set_error("unsupported channel count %d", cn); return VKX_ERR_UNSUPPORTED;
+    }
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
+static int hsv_tables(vkx_ctx *ctx, const HsvTables **out)
+{
+    if (!ctx->tables_ready) {
+        int rc = vkx_scratch_reserve(ctx, &ctx->tables, sizeof(HsvTables));
+        if (rc) return rc;
+        HsvTables T;
+        T.sdiv[0] = T.hdiv[0] = 0;
+        for (int i = 1; i < 256; i++) {
+            T.sdiv[i] = (int)nearbyint((255 << 12) / (1. * i));
+            T.hdiv[i] = (int)nearbyint((256 << 12) / (6. * i));
+        }
+        VKX_HIP(hipMemcpyAsync(ctx->tables.ptr, &T, sizeof T, hipMemcpyHostToDevice, ctx->stream));
+        VKX_HIP(hipStreamSynchronize(ctx->stream)); // T lives on this stack frame
+        ctx->tables_ready = true;
+    }
+    *out = (const HsvTables *)ctx->tables.ptr;
+    return VKX_OK;
+}
+
+template <int MODE>
+static int launch_hsv(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t src_stride, int delta, uint8_t *dst,
+                      ptrdiff_t dst_stride)
+{
+    int rc = check_plane(ctx, src, dst, h, w);
+    if (rc) return rc;
+    if (h == 0 || w == 0) return VKX_OK;
+    const HsvTables *T = nullptr;
+    rc = hsv_tables(ctx, &T);
+    if (rc) return rc;
+    dim3 block(64, 4), grid(vkx_blocks(w, 64), vkx_blocks(h, 4));
+    k_hsv<MODE><<<grid, block, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, delta, T);
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_color_shift_rgb_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t src_stride, int delta,
+                                       uint8_t *dst, ptrdiff_t dst_stride)
+{
+    return launch_hsv<0>(ctx, src, h, w, src_stride, delta, dst, dst_stride);
+}
+
+VKX_EXPORT int vkx_cvt_rgb_hsv_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t src_stride, int to_hsv,
+                                      uint8_t *dst, ptrdiff_t dst_stride)
+{
+    return to_hsv ? launch_hsv<1>(ctx, src, h, w, src_stride, 0, dst, dst_stride)
+                  : launch_hsv<2>(ctx, src, h, w, src_stride, 0, dst, dst_stride);
+}
+
+VKX_EXPORT int vkx_mean_shift_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                                     int delta, int has_threshold, int threshold, int cycle, unsigned channel_mask,
+                                     uint8_t *dst, ptrdiff_t dst_stride)
+{
+    int rc = check_plane(ctx, src, dst, h, w);
+    if (rc) return rc;
+    VKX_REQUIRE(cn >= 1 && cn <= 4, "1..4 channels");
+    if (h == 0 || w == 0) return VKX_OK;
+    dim3 block(64, 4), grid(vkx_blocks((size_t)w * cn, 64), vkx_blocks(h, 4));
+    k_mean_shift<<<grid, block, 0, ctx->stream>>>(src, h, w, cn, src_stride, dst, dst_stride, delta, has_threshold,
+                                                  threshold, cycle, channel_mask);
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_add_noise_i16_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                                     const int16_t *noise, ptrdiff_t noise_stride_el, uint8_t *dst, ptrdiff_t dst_stride)
+{
+    int rc = check_plane(ctx, src, dst, h, w);
+    if (rc) return rc;
+    VKX_REQUIRE(noise != nullptr, "NULL noise plane");
+    VKX_REQUIRE(cn >= 1 && cn <= 4, "1..4 channels");
+    if (h == 0 || w == 0) return VKX_OK;
+    dim3 block(64, 4), grid(vkx_blocks((size_t)w * cn, 64), vkx_blocks(h, 4));
+    k_add_noise<<<grid, block, 0, ctx->stream>>>(src, h, w * cn, src_stride, noise, noise_stride_el, dst, dst_stride);
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_line_streak_u8_dev(vkx_ctx *ctx, uint8_t *img, int h, int w, int cn, ptrdiff_t stride, int thickness,
+                                      int gap, int dash_thickness, int dash_gap, const uint8_t color[4], double alpha,
+                                      int enable_vert, int enable_hori)
+{
+    int rc = check_plane(ctx, img, img, h, w);
+    if (rc) return rc;
+    VKX_REQUIRE(color != nullptr, "NULL color");
+    VKX_REQUIRE(thickness + gap > 0, "thickness + gap must be positive");
+    if (alpha < 0.0 || alpha > 1.0) {
+        vkx_set_error("alpha=%g is invalid.", alpha);
+        return VKX_ERR_INVALID;
+    }
+    if (h == 0 || w == 0 || alpha == 0.0 || (!enable_vert && !enable_hori)) return VKX_OK;
+    StreakParams P;
+    P.thickness = thickness;
+    P.step = thickness + gap;
+    P.dash = dash_thickness > 0 && dash_gap > 0;
+    P.dash_step = P.dash ? dash_thickness + dash_gap : 1;
+    P.dash_gap = dash_gap;
+    P.enable_vert = enable_vert;
+    P.enable_hori = enable_hori;
+    P.copy = alpha == 1.0;
+    P.alpha = (float)alpha;
+    for (int c = 0; c < 4; c++) P.color[c] = c < cn ? color[c] : 0;
+    dim3 block(64, 4), grid(vkx_blocks(w, 64), vkx_blocks(h, 4));
+    switch (cn) {
+    case 1: k_line_streak<1><<<grid, block, 0, ctx->stream>>>(img, h, w, stride, P); break;
+    case 3: k_line_streak<3><<<grid, block, 0, ctx->stream>>>(img, h, w, stride, P); break;
+    case 4: k_line_streak<4><<<grid, block, 0, ctx->stream>>>(img, h, w, stride, P); break;
+    default: vkx_set_error("unsupported channel count %d", cn); return VKX_ERR_UNSUPPORTED;
+    }
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}

@@ -1,0 +1,205 @@
+// cv.remap / cv.warpAffine / cv.warpPerspective (INTER_LINEAR, BORDER_CONSTANT 0) on gfx950.
+// One lane per destination pixel, 64 consecutive pixels of a row per wavefront; the arithmetic is
+// the integer fixed-point pipeline of OpenCV's imgwarp.cpp (see oracle/vkx_oracle.c for citations).
+#include "vkx_internal.h"
+
+namespace {
+
+struct CoordMap {      // cv.remap: coordinates come from two float planes
+    const float *mx, *my;
+    ptrdiff_t stride;
+    __device__ __forceinline__ void operator()(int x, int y, int &X, int &Y) const
+    {
+        X = vkd::cv_round(mx[(ptrdiff_t)y * stride + x] * 32.f);
+        Y = vkd::cv_round(my[(ptrdiff_t)y * stride + x] * 32.f);
+    }
+};
+
+struct CoordAffine {   // warpAffine: inverse matrix, AB_BITS = 10 fixed point
+    double m[6];
+    __device__ __forceinline__ void operator()(int x, int y, int &X, int &Y) const
+    {
+        const int adelta = vkd::cv_round(m[0] * x * 1024);
+        const int bdelta = vkd::cv_round(m[3] * x * 1024);
+        const int X0 = vkd::cv_round((m[1] * y + m[2]) * 1024) + 16;
+        const int Y0 = vkd::cv_round((m[4] * y + m[5]) * 1024) + 16;
+        X = (X0 + adelta) >> 5;
+        Y = (Y0 + bdelta) >> 5;
+    }
+};
+
+struct CoordPerspective { // warpPerspective: inverse matrix, per pixel in double, 32x32 blocks
+    double m[9];
+    int bw0;
+    __device__ __forceinline__ void operator()(int x, int y, int &X, int &Y) const
+    {
+        const int xb = (x / bw0) * bw0, x1 = x - xb;
+        const double X0 = m[0] * xb + m[1] * y + m[2];
+        const double Y0 = m[3] * xb + m[4] * y + m[5];
+        const double W0 = m[6] * xb + m[7] * y + m[8];
+        double W = W0 + m[6] * x1;
+        W = W ? 32 / W : 0;
+        const double fX = fmax((double)INT_MIN, fmin((double)INT_MAX, (X0 + m[0] * x1) * W));
+        const double fY = fmax((double)INT_MIN, fmin((double)INT_MAX, (Y0 + m[3] * x1) * W));
+        X = vkd::cv_round(fX);
+        Y = vkd::cv_round(fY);
+    }
+};
+
+template <int CN, class Coord>
+__global__ void __launch_bounds__(256) k_sample_u8(const uint8_t *__restrict__ src, int sh, int sw, ptrdiff_t sstride,
+                                                   uint8_t *__restrict__ dst, int dh, int dw, ptrdiff_t dstride,
+                                                   Coord coord)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= dw || y >= dh) return;
+    int X, Y;
+    coord(x, y, X, Y);
+    uint8_t px[CN];
+    vkd::sample_u8<CN>(src, sh, sw, sstride, X, Y, px);
+    uint8_t *d = dst + (ptrdiff_t)y * dstride + (ptrdiff_t)x * CN;
+#pragma unroll
+    for (int k = 0; k < CN; k++) d[k] = px[k];
+}
+
+template <class Coord>
+__global__ void __launch_bounds__(256) k_sample_f32(const float *__restrict__ src, int sh, int sw, ptrdiff_t sstride,
+                                                    float *__restrict__ dst, int dh, int dw, ptrdiff_t dstride,
+                                                    Coord coord)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= dw || y >= dh) return;
+    int X, Y;
+    coord(x, y, X, Y);
+    dst[(ptrdiff_t)y * dstride + x] = vkd::sample_f32(src, sh, sw, sstride, X, Y);
+}
+
+template <class Coord>
+int launch_u8(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t sstride, uint8_t *dst, int dh,
+              int dw, ptrdiff_t dstride, const Coord &coord)
+{
+    VKX_REQUIRE(ctx && src && dst, "NULL argument");
+    VKX_REQUIRE(sh > 0 && sw > 0 && dh >= 0 && dw >= 0, "bad shape");
+    VKX_REQUIRE(sh <= 32767 && sw <= 32767, "source larger than 32767 px (cv.remap limit)");
+    if (dh == 0 || dw == 0) return VKX_OK;
+    dim3 block(64, 4), grid(vkx_blocks(dw, 64), vkx_blocks(dh, 4));
+    switch (cn) {
+    case 1: k_sample_u8<1, Coord><<<grid, block, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, coord); break;
+    case 3: k_sample_u8<3, Coord><<<grid, block, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, coord); break;
+    case 4: k_sample_u8<4, Coord><<<grid, block, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, coord); break;
+    default: vkx_set_error("unsupported channel count %d", cn); return VKX_ERR_UNSUPPORTED;
+    }
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
+template <class Coord>
+int launch_f32(vkx_ctx *ctx, const float *src, int sh, int sw, ptrdiff_t sstride, float *dst, int dh, int dw,
+               ptrdiff_t dstride, const Coord &coord)
+{
+    VKX_REQUIRE(ctx && src && dst, "NULL argument");
+    VKX_REQUIRE(sh > 0 && sw > 0 && dh >= 0 && dw >= 0, "bad shape");
+    VKX_REQUIRE(sh <= 32767 && sw <= 32767, "source larger than 32767 px (cv.remap limit)");
+    if (dh == 0 || dw == 0) return VKX_OK;
+    dim3 block(64, 4), grid(vkx_blocks(dw, 64), vkx_blocks(dh, 4));
+    k_sample_f32<Coord><<<grid, block, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, coord);
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
+// cv::warpAffine's in-place inversion of the forward 2x3 matrix (double).
+CoordAffine make_affine(const double Mf[6])
+{
+    CoordAffine c;
+    double M[6];
+    for (int i = 0; i < 6; i++) M[i] = Mf[i];
+    double D = M[0] * M[4] - M[1] * M[3];
+    D = D != 0 ? 1. / D : 0;
+    const double A11 = M[4] * D, A22 = M[0] * D;
+    M[0] = A11; M[1] *= -D;
+    M[3] *= -D; M[4] = A22;
+    const double b1 = -M[0] * M[2] - M[1] * M[5];
+    const double b2 = -M[3] * M[2] - M[4] * M[5];
+    M[2] = b1; M[5] = b2;
+    for (int i = 0; i < 6; i++) c.m[i] = M[i];
+    return c;
+}
+
+// cv::invert of a 3x3 double matrix (cofactors times 1/det; zeros when singular) and the block width of
+// WarpPerspectiveInvoker.
+CoordPerspective make_perspective(const double S[9], int dh, int dw)
+{
+    CoordPerspective c;
+    auto at = [&](int r, int col) { return S[r * 3 + col]; };
+    double d = at(0, 0) * (at(1, 1) * at(2, 2) - at(1, 2) * at(2, 1)) -
+               at(0, 1) * (at(1, 0) * at(2, 2) - at(1, 2) * at(2, 0)) +
+               at(0, 2) * (at(1, 0) * at(2, 1) - at(1, 1) * at(2, 0));
+    if (d == 0.) {
+        for (int i = 0; i < 9; i++) c.m[i] = 0;
+    } else {
+        d = 1. / d;
+        c.m[0] = (at(1, 1) * at(2, 2) - at(1, 2) * at(2, 1)) * d;
+        c.m[1] = (at(0, 2) * at(2, 1) - at(0, 1) * at(2, 2)) * d;
+        c.m[2] = (at(0, 1) * at(1, 2) - at(0, 2) * at(1, 1)) * d;
+        c.m[3] = (at(1, 2) * at(2, 0) - at(1, 0) * at(2, 2)) * d;
+        c.m[4] = (at(0, 0) * at(2, 2) - at(0, 2) * at(2, 0)) * d;
+        c.m[5] = (at(0, 2) * at(1, 0) - at(0, 0) * at(1, 2)) * d;
+        c.m[6] = (at(1, 0) * at(2, 1) - at(1, 1) * at(2, 0)) * d;
+        c.m[7] = (at(0, 1) * at(2, 0) - at(0, 0) * at(2, 1)) * d;
+        c.m[8] = (at(0, 0) * at(1, 1) - at(0, 1) * at(1, 0)) * d;
+    }
+    const int BLOCK_SZ = 32;
+    const int bh0 = BLOCK_SZ / 2 < dh ? BLOCK_SZ / 2 : (dh > 0 ? dh : 1);
+    c.bw0 = BLOCK_SZ * BLOCK_SZ / bh0 < dw ? BLOCK_SZ * BLOCK_SZ / bh0 : (dw > 0 ? dw : 1);
+    return c;
+}
+
+} // namespace
+
+VKX_EXPORT int vkx_remap_u8_dev(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t src_stride,
+                                const float *map_x, const float *map_y, ptrdiff_t map_stride_el, uint8_t *dst,
+                                int dh, int dw, ptrdiff_t dst_stride)
+{
+    VKX_REQUIRE(map_x && map_y, "NULL map");
+    return launch_u8(ctx, src, sh, sw, cn, src_stride, dst, dh, dw, dst_stride, CoordMap{map_x, map_y, map_stride_el});
+}
+
+VKX_EXPORT int vkx_remap_f32_dev(vkx_ctx *ctx, const float *src, int sh, int sw, ptrdiff_t src_stride_el,
+                                 const float *map_x, const float *map_y, ptrdiff_t map_stride_el, float *dst, int dh,
+                                 int dw, ptrdiff_t dst_stride_el)
+{
+    VKX_REQUIRE(map_x && map_y, "NULL map");
+    return launch_f32(ctx, src, sh, sw, src_stride_el, dst, dh, dw, dst_stride_el,
+                      CoordMap{map_x, map_y, map_stride_el});
+}
+
+VKX_EXPORT int vkx_warp_affine_u8_dev(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t src_stride,
+                                      const double M[6], uint8_t *dst, int dh, int dw, ptrdiff_t dst_stride)
+{
+    VKX_REQUIRE(M != nullptr, "NULL matrix");
+    return launch_u8(ctx, src, sh, sw, cn, src_stride, dst, dh, dw, dst_stride, make_affine(M));
+}
+
+VKX_EXPORT int vkx_warp_affine_f32_dev(vkx_ctx *ctx, const float *src, int sh, int sw, ptrdiff_t src_stride_el,
+                                       const double M[6], float *dst, int dh, int dw, ptrdiff_t dst_stride_el)
+{
+    VKX_REQUIRE(M != nullptr, "NULL matrix");
+    return launch_f32(ctx, src, sh, sw, src_stride_el, dst, dh, dw, dst_stride_el, make_affine(M));
+}
+
+VKX_EXPORT int vkx_warp_perspective_u8_dev(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn,
+                                           ptrdiff_t src_stride, const double M[9], uint8_t *dst, int dh, int dw,
+                                           ptrdiff_t dst_stride)
+{
+    VKX_REQUIRE(M != nullptr, "NULL matrix");
+    return launch_u8(ctx, src, sh, sw, cn, src_stride, dst, dh, dw, dst_stride, make_perspective(M, dh, dw));
+}
+
+VKX_EXPORT int vkx_warp_perspective_f32_dev(vkx_ctx *ctx, const float *src, int sh, int sw, ptrdiff_t src_stride_el,
+                                            const double M[9], float *dst, int dh, int dw, ptrdiff_t dst_stride_el)
+{
+    VKX_REQUIRE(M != nullptr, "NULL matrix");
+    return launch_f32(ctx, src, sh, sw, src_stride_el, dst, dh, dw, dst_stride_el, make_perspective(M, dh, dw));
+}

@@ -1,0 +1,138 @@
+// Internal definitions shared by the translation units of libvkx.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <limits.h>
+#include <string>
+#include <vector>
+
+#include "../../include/vkx.h"
+
+#define VKX_EXPORT extern "C" __attribute__((visibility("default")))
+
+void vkx_set_error(const char *fmt, ...);
+
+#define VKX_HIP(call)                                                                      \
+    do {                                                                                   \
+        hipError_t e__ = (call);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            vkx_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, \
+                          __LINE__);                                                       \
+            return VKX_ERR_HIP;                                                            \
+        }                                                                                  \
+    } while (0)
+
+#define VKX_REQUIRE(cond, msg)                                     \
+    do {                                                           \
+        if (!(cond)) {                                             \
+            vkx_set_error("%s: requirement failed: %s", __func__, msg); \
+            return VKX_ERR_INVALID;                                \
+        }                                                          \
+    } while (0)
+
+#define VKX_LAUNCH_CHECK()                                                   \
+    do {                                                                     \
+        hipError_t e__ = hipGetLastError();                                  \
+        if (e__ != hipSuccess) {                                             \
+            vkx_set_error("kernel launch failed in %s: %s", __func__, hipGetErrorString(e__)); \
+            return VKX_ERR_HIP;                                              \
+        }                                                                    \
+    } while (0)
+
+// A grow-only device scratch slot (owner maps, cell tables, staging for the host entry points).
+struct vkx_scratch {
+    void *ptr = nullptr;
+    size_t cap = 0;
+};
+
+struct vkx_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    vkx_scratch owner;    // int32 [dh, dw]
+    vkx_scratch cells;    // CellRec [n_cells]
+    vkx_scratch misc;     // small parameter blocks (layers, element descriptors)
+    vkx_scratch tables;   // constant lookup tables (HSV division LUTs), uploaded once
+    bool tables_ready = false;
+    vkx_scratch stage[6]; // staging planes of the host-pointer entry points
+};
+
+int vkx_scratch_reserve(vkx_ctx *ctx, vkx_scratch *s, size_t bytes);
+
+static inline unsigned vkx_blocks(size_t n, unsigned per_block)
+{
+    size_t b = (n + per_block - 1) / per_block;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device helpers.  Everything here must agree bit-for-bit with oracle/vkx_oracle.c; the library
+// is compiled with -ffp-contract=off so a*b+c is never fused unless written as fma().
+// ---------------------------------------------------------------------------------------------
+namespace vkd {
+
+// OpenCV cvRound on x86: round-half-even, "integer indefinite" outside int32 / NaN.
+__device__ __forceinline__ int cv_round(float v)
+{
+    if (!(v >= -2147483648.f && v < 2147483648.f)) return INT_MIN;
+    return __float2int_rn(v);
+}
+__device__ __forceinline__ int cv_round(double v)
+{
+    if (!(v >= -2147483648.5 && v < 2147483647.5)) return INT_MIN;
+    return __double2int_rn(v);
+}
+__device__ __forceinline__ int sat_short(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+__device__ __forceinline__ int clamp_u8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+// One destination pixel of cv::remapBilinear on uint8, BORDER_CONSTANT 0.  X, Y are the source
+// coordinate in 1/32 px.  The int16 weight table of OpenCV is (32-fy)(32-fx)*32 etc. (with the
+// {32767,0,0,1} quirk at fy=fx=0); (sum*32 + 2^14) >> 15 == (sum + 512) >> 10 for every entry,
+// the quirk entry included, so the table never needs to be materialised.
+template <int CN>
+__device__ __forceinline__ void sample_u8(const uint8_t *__restrict__ src, int sh, int sw, ptrdiff_t sstride,
+                                          int X, int Y, uint8_t *out)
+{
+    const int sx = sat_short(X >> 5), sy = sat_short(Y >> 5);
+    const int fx = X & 31, fy = Y & 31;
+    if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) {
+#pragma unroll
+        for (int k = 0; k < CN; k++) out[k] = 0;
+        return;
+    }
+    const bool x0 = sx >= 0, x1 = sx + 1 < sw, y0 = sy >= 0, y1 = sy + 1 < sh;
+    const uint8_t *r0 = src + (ptrdiff_t)sy * sstride + (ptrdiff_t)sx * CN;
+    const uint8_t *r1 = r0 + sstride;
+    const int w00 = (32 - fy) * (32 - fx), w01 = (32 - fy) * fx, w10 = fy * (32 - fx), w11 = fy * fx;
+#pragma unroll
+    for (int k = 0; k < CN; k++) {
+        const int v0 = (x0 && y0) ? r0[k] : 0;
+        const int v1 = (x1 && y0) ? r0[CN + k] : 0;
+        const int v2 = (x0 && y1) ? r1[k] : 0;
+        const int v3 = (x1 && y1) ? r1[CN + k] : 0;
+        out[k] = (uint8_t)((v0 * w00 + v1 * w01 + v2 * w10 + v3 * w11 + 512) >> 10);
+    }
+}
+
+__device__ __forceinline__ float sample_f32(const float *__restrict__ src, int sh, int sw, ptrdiff_t sstride_el,
+                                            int X, int Y)
+{
+    const int sx = sat_short(X >> 5), sy = sat_short(Y >> 5);
+    const int fx = X & 31, fy = Y & 31;
+    if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) return 0.f;
+    const bool x0 = sx >= 0, x1 = sx + 1 < sw, y0 = sy >= 0, y1 = sy + 1 < sh;
+    const float *r0 = src + (ptrdiff_t)sy * sstride_el + sx;
+    const float *r1 = r0 + sstride_el;
+    const float ax = fx * (1.f / 32), ay = fy * (1.f / 32);
+    const float bx = 1.f - ax, by = 1.f - ay;
+    const float w0 = by * bx, w1 = by * ax, w2 = ay * bx, w3 = ay * ax; // exact products (5 bit x 5 bit)
+    const float v0 = (x0 && y0) ? r0[0] : 0.f;
+    const float v1 = (x1 && y0) ? r0[1] : 0.f;
+    const float v2 = (x0 && y1) ? r1[0] : 0.f;
+    const float v3 = (x1 && y1) ? r1[1] : 0.f;
+    const float p0 = v0 * w0, p1 = v1 * w1, p2 = v2 * w2, p3 = v3 * w3;
+    return ((p0 + p1) + p2) + p3;
+}
+
+} // namespace vkd
