@@ -1,0 +1,219 @@
+"""Image element (reference: vkit/element/image.py).
+
+uint8 HxW[xC] (or float32 for the ``*_GCN`` modes) plus an ``ImageMode`` tag.  Mode conversion on the hot
+path is RGB <-> HSV (``cv.COLOR_RGB2HSV_FULL`` / ``cv.COLOR_HSV2RGB_FULL``, reference image.py:188-202,771-814)
+and runs in the ``k_hsv`` HIP kernel; other conversions are outside the accelerated path and raise.
+"""
+from enum import Enum, unique
+from typing import Optional, Tuple, Union
+
+import attrs
+import numpy as np
+
+from ._writable import WritableContext
+from .type import Shapable
+
+
+@unique
+class ImageMode(Enum):
+    RGB = 'rgb'
+    RGB_GCN = 'rgb_gcn'
+    RGBA = 'rgba'
+    HSV = 'hsv'
+    HSV_GCN = 'hsv_gcn'
+    HSL = 'hsl'
+    HSL_GCN = 'hsl_gcn'
+    GRAYSCALE = 'grayscale'
+    GRAYSCALE_GCN = 'grayscale_gcn'
+    NONE = 'none'
+
+    def to_ndim(self):
+        if self in (ImageMode.GRAYSCALE, ImageMode.GRAYSCALE_GCN):
+            return 2
+        if self is ImageMode.NONE:
+            raise NotImplementedError()
+        return 3
+
+    def to_dtype(self):
+        if self is ImageMode.NONE:
+            raise NotImplementedError()
+        return np.float32 if self.in_gcn_mode() else np.uint8
+
+    def to_num_channels(self):
+        if self is ImageMode.RGBA:
+            return 4
+        if self in (ImageMode.GRAYSCALE, ImageMode.GRAYSCALE_GCN):
+            return None
+        if self is ImageMode.NONE:
+            raise NotImplementedError()
+        return 3
+
+    def supports_gcn_mode(self):
+        return self in _TO_GCN
+
+    def to_gcn_mode(self):
+        if not self.supports_gcn_mode():
+            raise RuntimeError(f'image_mode={self} not supported.')
+        return _TO_GCN[self]
+
+    def in_gcn_mode(self):
+        return self in _FROM_GCN
+
+    def to_non_gcn_mode(self):
+        if not self.in_gcn_mode():
+            raise RuntimeError(f'image_mode={self} not in gcn mode.')
+        return _FROM_GCN[self]
+
+
+_TO_GCN = {
+    ImageMode.RGB: ImageMode.RGB_GCN,
+    ImageMode.HSV: ImageMode.HSV_GCN,
+    ImageMode.HSL: ImageMode.HSL_GCN,
+    ImageMode.GRAYSCALE: ImageMode.GRAYSCALE_GCN,
+}
+_FROM_GCN = {gcn: plain for plain, gcn in _TO_GCN.items()}
+
+
+@attrs.define
+class ImageSetItemConfig:
+    value: Union['Image', np.ndarray, Tuple[int, ...], int]
+    alpha: Union[np.ndarray, float] = 1.0
+
+
+@attrs.define(frozen=True, eq=False)
+class Image(Shapable):
+    mat: np.ndarray
+    mode: ImageMode = ImageMode.NONE
+    box: Optional['Box'] = None
+
+    def __attrs_post_init__(self):
+        if self.mode != ImageMode.NONE:
+            assert self.mode.to_dtype() == self.mat.dtype
+            assert self.mode.to_ndim() == self.mat.ndim
+        else:
+            # infer the mode from the array (uint8 only)
+            if self.mat.dtype == np.float32:
+                raise NotImplementedError('mode is None and mat.dtype == np.float32.')
+            if self.mat.dtype != np.uint8:
+                raise NotImplementedError(f'Invalid mat.dtype={self.mat.dtype}.')
+            if self.mat.ndim == 2:
+                mode = ImageMode.GRAYSCALE
+            elif self.mat.ndim == 3 and self.mat.shape[2] == 4:
+                mode = ImageMode.RGBA
+            elif self.mat.ndim == 3 and self.mat.shape[2] == 3:
+                mode = ImageMode.RGB
+            elif self.mat.ndim == 3:
+                raise NotImplementedError(f'Invalid num_channels={self.mat.shape[2]}.')
+            else:
+                raise NotImplementedError(f'mat.ndim={self.mat.ndim} not supported.')
+            object.__setattr__(self, 'mode', mode)
+        self.mat.flags.writeable = False
+        if self.box and self.shape != self.box.shape:
+            raise RuntimeError('self.shape != box.shape.')
+
+    # ---- constructors
+    @classmethod
+    def from_shape(cls, shape: Tuple[int, int], num_channels: int = 3, value: Union[Tuple[int, ...], int] = 255):
+        height, width = shape
+        if num_channels == 0:
+            mat_shape = (height, width)
+        else:
+            assert num_channels > 0
+            if isinstance(value, tuple):
+                assert len(value) == num_channels
+            mat_shape = (height, width, num_channels)
+        return cls(mat=np.full(mat_shape, fill_value=value, dtype=np.uint8))
+
+    @classmethod
+    def from_shapable(cls, shapable: Shapable, num_channels: int = 3, value: Union[Tuple[int, ...], int] = 255):
+        return cls.from_shape(shapable.shape, num_channels=num_channels, value=value)
+
+    # ---- properties
+    @property
+    def height(self):
+        return self.mat.shape[0]
+
+    @property
+    def width(self):
+        return self.mat.shape[1]
+
+    @property
+    def num_channels(self):
+        return 0 if self.mat.ndim == 2 else self.mat.shape[2]
+
+    @property
+    def writable_context(self):
+        return WritableContext(self)
+
+    # ---- operators
+    def copy(self):
+        return attrs.evolve(self, mat=self.mat.copy())
+
+    def assign_mat(self, mat: np.ndarray):
+        with self.writable_context:
+            object.__setattr__(self, 'mat', mat)
+
+    def __setitem__(self, element, config):
+        """image[box | polygon | mask | score_map] = value | ImageSetItemConfig (reference image.py:667-712)."""
+        if isinstance(config, ImageSetItemConfig):
+            value, alpha = config.value, config.alpha
+        else:
+            value, alpha = config, 1.0
+        if isinstance(value, tuple):
+            assert value and isinstance(value[0], int)
+        if isinstance(element, ScoreMap):
+            element.fill_image(image=self, value=value)
+        else:
+            element.fill_image(image=self, value=value, alpha=alpha)
+
+    def __getitem__(self, element):
+        return element.extract_image(self)
+
+    def to_box_attached(self, box: 'Box'):
+        assert self.height == box.height and self.width == box.width
+        return attrs.evolve(self, box=box)
+
+    def to_box_detached(self):
+        assert self.box
+        return attrs.evolve(self, box=None)
+
+    def to_shifted_image(self, offset_y: int = 0, offset_x: int = 0):
+        assert self.box
+        return attrs.evolve(self, box=self.box.to_shifted_box(offset_y=offset_y, offset_x=offset_x))
+
+    def to_cropped_image(self, up=None, down=None, left=None, right=None):
+        assert not self.box
+        up = up or 0
+        down = down or self.height - 1
+        left = left or 0
+        right = right or self.width - 1
+        return attrs.evolve(self, mat=self.mat[up:down + 1, left:right + 1])
+
+    def to_target_mode_image(self, target_mode: ImageMode):
+        if target_mode == self.mode:
+            return self
+        pair = (self.mode, target_mode)
+        if pair == (ImageMode.RGB, ImageMode.HSV) or pair == (ImageMode.HSV, ImageMode.RGB):
+            from vkit_amd import _native
+            mat = _native.cvt_rgb_hsv(self.mat, to_hsv=(target_mode == ImageMode.HSV))
+            return Image(mat=mat, mode=target_mode)
+        raise NotImplementedError(f'image mode conversion {self.mode} -> {target_mode} is outside the accelerated path')
+
+    def to_rgb_image(self):
+        return self.to_target_mode_image(ImageMode.RGB)
+
+    def to_hsv_image(self):
+        return self.to_target_mode_image(ImageMode.HSV)
+
+    def to_grayscale_image(self):
+        return self.to_target_mode_image(ImageMode.GRAYSCALE)
+
+    def to_hsl_image(self):
+        return self.to_target_mode_image(ImageMode.HSL)
+
+    def to_rgba_image(self):
+        return self.to_target_mode_image(ImageMode.RGBA)
+
+
+from .box import Box  # noqa: E402
+from .score_map import ScoreMap  # noqa: E402

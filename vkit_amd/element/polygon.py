@@ -1,0 +1,104 @@
+"""Polygon element (reference: vkit/element/polygon.py), reduced to what the distortion path touches:
+vertex bookkeeping, integer bounding box, clipping / shifting / resizing of the vertex list.  The per-cell
+polygon rasterisation that the reference performs with ``cv.fillPoly`` (polygon.py:70-77) lives in the HIP
+grid kernels; shapely / pyclipper based operations are outside the accelerated path.
+"""
+from typing import Iterable, Optional, Sequence, Tuple, Union
+
+import attrs
+import numpy as np
+
+from .type import Shapable
+
+
+@attrs.define(frozen=True, eq=False)
+class Polygon:
+    points: 'PointTuple'
+
+    _bounding_box: Optional['Box'] = attrs.field(default=None, init=False, repr=False)
+
+    def __attrs_post_init__(self):
+        assert self.points
+
+    @classmethod
+    def create(cls, points: Union['PointList', 'PointTuple', Iterable['Point']]):
+        return cls(points=PointTuple(points))
+
+    @property
+    def num_points(self):
+        return len(self.points)
+
+    @property
+    def bounding_box(self):
+        if self._bounding_box is None:
+            xy = self.to_smooth_np_array()  # integer positions as float32 (PointTuple quirk)
+            box = Box(up=round(float(xy[:, 1].min())), down=round(float(xy[:, 1].max())),
+                      left=round(float(xy[:, 0].min())), right=round(float(xy[:, 0].max())))
+            object.__setattr__(self, '_bounding_box', box)
+        return self._bounding_box
+
+    def to_bounding_box(self):
+        return self.bounding_box
+
+    # ---- conversion
+    @classmethod
+    def from_xy_pairs(cls, xy_pairs):
+        return cls(points=PointTuple.from_xy_pairs(xy_pairs))
+
+    def to_xy_pairs(self):
+        return self.points.to_xy_pairs()
+
+    def to_smooth_xy_pairs(self):
+        return self.points.to_smooth_xy_pairs()
+
+    @classmethod
+    def from_flatten_xy_pairs(cls, flatten_xy_pairs: Sequence):
+        return cls(points=PointTuple.from_flatten_xy_pairs(flatten_xy_pairs))
+
+    def to_flatten_xy_pairs(self):
+        return self.points.to_flatten_xy_pairs()
+
+    def to_smooth_flatten_xy_pairs(self):
+        return self.points.to_smooth_flatten_xy_pairs()
+
+    @classmethod
+    def from_np_array(cls, np_points: np.ndarray):
+        return cls(points=PointTuple.from_np_array(np_points))
+
+    def to_np_array(self):
+        return self.points.to_np_array()
+
+    def to_smooth_np_array(self):
+        return self.points.to_smooth_np_array()
+
+    # ---- operators
+    def to_clipped_points(self, shapable_or_shape: Union[Shapable, Tuple[int, int]]):
+        return self.points.to_clipped_points(shapable_or_shape)
+
+    def to_clipped_polygon(self, shapable_or_shape: Union[Shapable, Tuple[int, int]]):
+        return Polygon(points=self.to_clipped_points(shapable_or_shape))
+
+    def to_shifted_points(self, offset_y: int = 0, offset_x: int = 0):
+        return self.points.to_shifted_points(offset_y=offset_y, offset_x=offset_x)
+
+    def to_relative_points(self, origin_y: int, origin_x: int):
+        return self.points.to_relative_points(origin_y=origin_y, origin_x=origin_x)
+
+    def to_shifted_polygon(self, offset_y: int = 0, offset_x: int = 0):
+        return Polygon(points=self.to_shifted_points(offset_y=offset_y, offset_x=offset_x))
+
+    def to_relative_polygon(self, origin_y: int, origin_x: int):
+        return Polygon(points=self.to_relative_points(origin_y=origin_y, origin_x=origin_x))
+
+    def to_conducted_resized_polygon(self, shapable_or_shape, resized_height: Optional[int] = None,
+                                     resized_width: Optional[int] = None):
+        return Polygon(points=self.points.to_conducted_resized_points(
+            shapable_or_shape, resized_height=resized_height, resized_width=resized_width))
+
+
+def generate_fill_by_polygons_mask(shape, polygons, mode):
+    raise NotImplementedError('polygon set operations are outside the accelerated path')
+
+
+from .point import Point, PointList, PointTuple  # noqa: E402
+from .box import Box  # noqa: E402

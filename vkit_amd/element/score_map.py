@@ -1,0 +1,107 @@
+"""Float32 score / probability plane (reference: vkit/element/score_map.py).
+
+On the hot path a ScoreMap is (a) an element that grid / affine distortions remap with float32 bilinear
+weights and (b) the per-pixel alpha of a text-line layer in the page composite.
+"""
+from typing import Optional, Tuple
+
+import attrs
+import numpy as np
+
+from ._writable import WritableContext
+from .type import ElementSetOperationMode, Shapable
+
+
+@attrs.define(frozen=True, eq=False)
+class ScoreMap(Shapable):
+    mat: np.ndarray
+    box: Optional['Box'] = None
+    is_prob: bool = True
+
+    def __attrs_post_init__(self):
+        if self.mat.ndim != 2:
+            raise RuntimeError('ndim should == 2.')
+        if self.box and self.shape != self.box.shape:
+            raise RuntimeError('self.shape != box.shape.')
+        if self.mat.dtype != np.float32:
+            raise RuntimeError('mat.dtype != np.float32')
+        self.mat.flags.writeable = False
+        if self.is_prob and self.mat.size:
+            if self.mat.min() < 0.0 or self.mat.max() > 1.0:
+                raise RuntimeError('score not in range [0.0, 1.0]')
+
+    @classmethod
+    def from_shape(cls, shape: Tuple[int, int], value: float = 0.0, is_prob: bool = True):
+        height, width = shape
+        if is_prob:
+            assert 0.0 <= value <= 1.0
+        return cls(mat=np.full((height, width), fill_value=value, dtype=np.float32), is_prob=is_prob)
+
+    @classmethod
+    def from_shapable(cls, shapable: Shapable, value: float = 0.0, is_prob: bool = True):
+        return cls.from_shape(shapable.shape, value=value, is_prob=is_prob)
+
+    @property
+    def height(self):
+        return self.mat.shape[0]
+
+    @property
+    def width(self):
+        return self.mat.shape[1]
+
+    @property
+    def equivalent_box(self):
+        return self.box or Box.from_shapable(self)
+
+    @property
+    def writable_context(self):
+        return WritableContext(self)
+
+    def copy(self):
+        return attrs.evolve(self, mat=self.mat.copy())
+
+    def assign_mat(self, mat: np.ndarray):
+        with self.writable_context:
+            object.__setattr__(self, 'mat', mat)
+
+    def to_shifted_score_map(self, offset_y: int = 0, offset_x: int = 0):
+        assert self.box
+        return attrs.evolve(self, box=self.box.to_shifted_box(offset_y=offset_y, offset_x=offset_x))
+
+    def to_cropped_score_map(self, up=None, down=None, left=None, right=None):
+        assert not self.box
+        up = up or 0
+        down = down or self.height - 1
+        left = left or 0
+        right = right or self.width - 1
+        return attrs.evolve(self, mat=self.mat[up:down + 1, left:right + 1])
+
+    def to_box_attached(self, box: 'Box'):
+        assert self.height == box.height and self.width == box.width
+        return attrs.evolve(self, box=box)
+
+    def to_box_detached(self):
+        assert self.box
+        return attrs.evolve(self, box=None)
+
+    def to_mask(self, threshold: float = 0.0):
+        return Mask(mat=(self.mat > threshold).astype(np.uint8), box=self.box)
+
+    # self is both the selection (alpha > 0) and the weight
+    def fill_np_array(self, mat: np.ndarray, value, keep_max_value: bool = False, keep_min_value: bool = False):
+        self.equivalent_box.fill_np_array(mat, value, alpha=self, keep_max_value=keep_max_value,
+                                          keep_min_value=keep_min_value)
+
+    def fill_image(self, image: 'Image', value):
+        self.equivalent_box.fill_image(image, value, alpha=self)
+
+
+def generate_fill_by_score_maps_mask(shape, score_maps, mode: ElementSetOperationMode):
+    if mode == ElementSetOperationMode.UNION:
+        return None
+    raise NotImplementedError('non-UNION score-map set operations are outside the accelerated path')
+
+
+from .box import Box  # noqa: E402
+from .mask import Mask  # noqa: E402
+from .image import Image  # noqa: E402

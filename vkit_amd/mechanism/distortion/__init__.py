@@ -1,0 +1,43 @@
+"""``vkit_amd.mechanism.distortion``: the distortions of the accelerated path under the names the reference
+exports (vkit/mechanism/distortion/__init__.py:17-108)."""
+from .interface import (
+    Distortion,
+    DistortionConfig,
+    DistortionInternals,
+    DistortionNopState,
+    DistortionResult,
+    DistortionState,
+)
+
+# photometric
+from .photometric.opt import OutOfBoundBehavior
+from .photometric.color import MeanShiftConfig, mean_shift, ColorShiftConfig, color_shift
+from .photometric.blur import GaussianBlurConfig, gaussian_blur
+from .photometric.noise import GaussionNoiseConfig, gaussion_noise
+from .photometric.streak import LineStreakConfig, line_streak, RectangleStreakConfig, rectangle_streak
+
+# geometric
+from .geometric.affine import (
+    ShearHoriConfig,
+    shear_hori,
+    ShearVertConfig,
+    shear_vert,
+    RotateConfig,
+    rotate,
+    SkewHoriConfig,
+    skew_hori,
+    SkewVertConfig,
+    skew_vert,
+)
+from .geometric.mls import SimilarityMlsConfig, similarity_mls
+from .geometric.camera import (
+    CameraModelConfig,
+    CameraPlaneOnlyConfig,
+    camera_plane_only,
+    CameraCubicCurveConfig,
+    camera_cubic_curve,
+    CameraPlaneLineFoldConfig,
+    camera_plane_line_fold,
+    CameraPlaneLineCurveConfig,
+    camera_plane_line_curve,
+)

@@ -1,0 +1,285 @@
+"""Affine / perspective distortions: shear_hori, shear_vert, rotate, skew_hori, skew_vert
+(reference: vkit/mechanism/distortion/geometric/affine.py).
+
+The state objects hold the FORWARD matrix as float32 (2x3, or 3x3 for the skews) and ``dsize = (width,
+height)`` exactly as the reference computes them; pixels go through ``vkx_warp_affine_*`` /
+``vkx_warp_perspective_*`` (OpenCV's fixed-point warp pipeline restated in HIP), points through the same
+float32 matrix product the reference uses.
+"""
+import math
+from typing import Iterable, Optional, Sequence, Tuple, Type, TypeVar, Union
+
+import attrs
+import numpy as np
+from numpy.random import Generator as RandomGenerator
+
+from vkit_amd import _native
+from vkit_amd.element import Image, Mask, Point, PointList, PointTuple, Polygon, ScoreMap
+from ..interface import Distortion, DistortionConfig, DistortionState
+
+
+def affine_mat(trans_mat: np.ndarray, dsize: Tuple[int, int], mat: np.ndarray) -> np.ndarray:
+    if trans_mat.shape[0] == 2:
+        return _native.warp_affine(mat, trans_mat, dsize)
+    assert trans_mat.shape[0] == 3
+    return _native.warp_perspective(mat, trans_mat, dsize)
+
+
+def affine_np_points(trans_mat: np.ndarray, np_points: np.ndarray) -> np.ndarray:
+    homogeneous = np.concatenate((np_points.transpose(), np.ones((1, np_points.shape[0]), dtype=np.float32)))
+    moved = np.matmul(trans_mat, homogeneous)
+    if trans_mat.shape[0] == 3:
+        moved = moved[:2, :] / moved[2, :]
+    return moved.transpose()
+
+
+def affine_points(trans_mat: np.ndarray, points: PointTuple):
+    return PointTuple.from_np_array(affine_np_points(trans_mat, points.to_smooth_np_array()))
+
+
+def affine_polygons(trans_mat: np.ndarray, polygons: Sequence[Polygon]) -> Sequence[Polygon]:
+    # one matrix product for the vertices of all polygons
+    flat = PointList()
+    spans = []
+    for polygon in polygons:
+        spans.append((len(flat), len(flat) + polygon.num_points))
+        flat.extend(polygon.points)
+    moved = affine_np_points(trans_mat, flat.to_smooth_np_array())
+    return [Polygon.from_np_array(moved[begin:end]) for begin, end in spans]
+
+
+def convert_dsize_to_result_shape(dsize: Optional[Tuple[int, int]]):
+    if dsize:
+        return dsize[1], dsize[0]
+
+
+class _AffineState(DistortionState):
+    trans_mat: Optional[np.ndarray]
+    dsize: Optional[Tuple[int, int]]
+
+    @property
+    def result_shape(self):
+        return convert_dsize_to_result_shape(self.dsize)
+
+
+@attrs.define
+class ShearHoriConfig(DistortionConfig):
+    # degrees in (-90, 90); positive shears to the right
+    angle: int
+
+    @property
+    def is_nop(self):
+        return self.angle == 0
+
+
+class ShearHoriState(_AffineState):
+
+    def __init__(self, config: ShearHoriConfig, shape: Tuple[int, int], rng: Optional[RandomGenerator]):
+        height, width = shape
+        tan_phi = math.tan(math.radians(config.angle))
+        shift_x = abs(height * tan_phi)
+        if config.angle == 0:
+            self.trans_mat, self.dsize = None, None
+            return
+        self.dsize = (math.ceil(width + shift_x), height)
+        offset = shift_x if config.angle > 0 else 0
+        self.trans_mat = np.asarray([(1, -tan_phi, offset), (0, 1, 0)], dtype=np.float32)
+
+
+@attrs.define
+class ShearVertConfig(DistortionConfig):
+    # degrees in (-90, 90); positive shears downwards
+    angle: int
+
+    @property
+    def is_nop(self):
+        return self.angle == 0
+
+
+class ShearVertState(_AffineState):
+
+    def __init__(self, config: ShearVertConfig, shape: Tuple[int, int], rng: Optional[RandomGenerator]):
+        height, width = shape
+        tan_abs_phi = math.tan(math.radians(abs(config.angle)))
+        shift_y = width * tan_abs_phi
+        if config.angle == 0:
+            self.trans_mat, self.dsize = None, None
+            return
+        self.dsize = (width, math.ceil(height + shift_y))
+        if config.angle < 0:
+            self.trans_mat = np.asarray([(1, 0, 0), (-tan_abs_phi, 1, shift_y)], dtype=np.float32)
+        else:
+            self.trans_mat = np.asarray([(1, 0, 0), (tan_abs_phi, 1, 0)], dtype=np.float32)
+
+
+@attrs.define
+class RotateConfig(DistortionConfig):
+    # clockwise degrees
+    angle: int
+
+    @property
+    def is_nop(self):
+        return self.angle == 0
+
+
+class RotateState(_AffineState):
+
+    def __init__(self, config: RotateConfig, shape: Tuple[int, int], rng: Optional[RandomGenerator]):
+        height, width = shape
+        rad = math.radians(config.angle % 360)
+        sin, cos = math.sin, math.cos
+        # translation that keeps the rotated page in the positive quadrant, and the rotated extent,
+        # per 90-degree sector (the sector-local angle keeps every term non-negative)
+        if rad <= math.pi / 2:
+            shift_x, shift_y = height * sin(rad), 0
+            dst_width = height * sin(rad) + width * cos(rad)
+            dst_height = height * cos(rad) + width * sin(rad)
+        elif rad <= math.pi:
+            local = rad - math.pi / 2
+            shift_x = width * sin(local) + height * cos(local)
+            shift_y = height * sin(local)
+            dst_width = shift_x
+            dst_height = shift_y + width * cos(local)
+        elif rad < math.pi * 3 / 2:
+            local = rad - math.pi
+            shift_x = width * cos(local)
+            shift_y = width * sin(local) + height * cos(local)
+            dst_width = shift_x + height * sin(local)
+            dst_height = shift_y
+        else:
+            local = rad - math.pi * 3 / 2
+            shift_x, shift_y = 0, width * cos(local)
+            dst_width = width * sin(local) + height * cos(local)
+            dst_height = shift_y + height * sin(local)
+        self.trans_mat = np.asarray(
+            [(cos(rad), -sin(rad), math.ceil(shift_x)), (sin(rad), cos(rad), math.ceil(shift_y))], dtype=np.float32)
+        self.dsize = (math.ceil(dst_width), math.ceil(dst_height))
+
+
+def _skew_transform(src_xy_pairs, dst_xy_pairs):
+    """cv.getPerspectiveTransform(src, dst, DECOMP_SVD) of the reference (affine.py:326-330, 386-390)."""
+    from .grid_rendering.homography import get_perspective_transform
+    return get_perspective_transform(np.asarray(src_xy_pairs, dtype=np.float32), np.asarray(dst_xy_pairs, dtype=np.float32))
+
+
+@attrs.define
+class SkewHoriConfig(DistortionConfig):
+    # (-1, 0]: shrink the left side; [0, 1): shrink the right side
+    ratio: float
+
+    @property
+    def is_nop(self):
+        return self.ratio == 0
+
+
+class SkewHoriState(_AffineState):
+
+    def __init__(self, config: SkewHoriConfig, shape: Tuple[int, int], rng: Optional[RandomGenerator]):
+        height, width = shape
+        right, bottom = width - 1, height - 1
+        shrink = round(height * abs(config.ratio))
+        up = shrink // 2
+        down = shrink - up
+        src = [(0, 0), (right, 0), (right, bottom), (0, bottom)]
+        if config.ratio < 0:
+            dst = [(0, up), (right, 0), (right, bottom), (0, height - down - 1)]
+        else:
+            dst = [(0, 0), (right, up), (right, height - down - 1), (0, bottom)]
+        self.trans_mat = _skew_transform(src, dst)
+        self.dsize = (width, height)
+
+
+@attrs.define
+class SkewVertConfig(DistortionConfig):
+    # (-1, 0]: shrink the upper side; [0, 1): shrink the lower side
+    ratio: float
+
+    @property
+    def is_nop(self):
+        return self.ratio == 0
+
+
+class SkewVertState(_AffineState):
+
+    def __init__(self, config: SkewVertConfig, shape: Tuple[int, int], rng: Optional[RandomGenerator]):
+        height, width = shape
+        right, bottom = width - 1, height - 1
+        shrink = round(width * abs(config.ratio))
+        left = shrink // 2
+        rest = shrink - left
+        src = [(0, 0), (right, 0), (right, bottom), (0, bottom)]
+        if config.ratio < 0:
+            dst = [(left, 0), (width - rest - 1, 0), (right, bottom), (0, bottom)]
+        else:
+            # NOTE: the lower-left corner uses the *right* share of the shrink, as the reference does (affine.py:382)
+            dst = [(0, 0), (right, 0), (width - rest - 1, bottom), (rest, bottom)]
+        self.trans_mat = _skew_transform(src, dst)
+        self.dsize = (width, height)
+
+
+def affine_trait_func_mat(config, state, mat: np.ndarray):
+    assert state
+    if config.is_nop:
+        return mat
+    assert state.trans_mat is not None and state.dsize is not None
+    return affine_mat(state.trans_mat, state.dsize, mat)
+
+
+def affine_trait_func_image(config, state, image: Image, rng: Optional[RandomGenerator]):
+    # the mode is re-inferred from the array, like the reference (affine.py:436)
+    return Image(mat=affine_trait_func_mat(config, state, image.mat))
+
+
+def affine_trait_func_score_map(config, state, score_map: ScoreMap, rng: Optional[RandomGenerator]):
+    assert state
+    return ScoreMap(mat=affine_trait_func_mat(config, state, score_map.mat))
+
+
+def affine_trait_func_mask(config, state, mask: Mask, rng: Optional[RandomGenerator]):
+    assert state
+    return Mask(mat=affine_trait_func_mat(config, state, mask.mat))
+
+
+def affine_trait_func_points(config, state, shape: Tuple[int, int],
+                             points: Union[PointList, PointTuple, Iterable[Point]], rng: Optional[RandomGenerator]):
+    assert state
+    points = PointTuple(points)
+    if config.is_nop:
+        return points
+    assert state.trans_mat is not None
+    return affine_points(state.trans_mat, points)
+
+
+def affine_trait_func_polygons(config, state, shape: Tuple[int, int], polygons: Iterable[Polygon],
+                               rng: Optional[RandomGenerator]):
+    assert state
+    polygons = tuple(polygons)
+    if config.is_nop:
+        return polygons
+    assert state.trans_mat is not None
+    return affine_polygons(state.trans_mat, polygons)
+
+
+_T_CONFIG = TypeVar('_T_CONFIG')
+_T_STATE = TypeVar('_T_STATE')
+
+
+class DistortionAffine(Distortion[_T_CONFIG, _T_STATE]):
+
+    def __init__(self, config_cls: Type[_T_CONFIG], state_cls: Type[_T_STATE]):
+        super().__init__(
+            config_cls=config_cls,
+            state_cls=state_cls,
+            func_image=affine_trait_func_image,
+            func_mask=affine_trait_func_mask,
+            func_score_map=affine_trait_func_score_map,
+            func_points=affine_trait_func_points,
+            func_polygons=affine_trait_func_polygons,
+        )
+
+
+shear_hori = DistortionAffine(config_cls=ShearHoriConfig, state_cls=ShearHoriState)
+shear_vert = DistortionAffine(config_cls=ShearVertConfig, state_cls=ShearVertState)
+rotate = DistortionAffine(config_cls=RotateConfig, state_cls=RotateState)
+skew_hori = DistortionAffine(config_cls=SkewHoriConfig, state_cls=SkewHoriState)
+skew_vert = DistortionAffine(config_cls=SkewVertConfig, state_cls=SkewVertState)

@@ -1,0 +1,132 @@
+"""Image-grid based geometric distortions (reference: grid_rendering/interface.py).
+
+``DistortionStateImageGridBased`` owns a source / destination ``ImageGrid`` pair; ``FuncImageGridBased`` blends
+Image / Mask / ScoreMap through ONE device-side grid (cell homographies + exact cv.fillPoly ownership + bilinear
+gather, csrc/grid.hip) and projects points on the host with the per-cell homography of the containing source
+cell."""
+from typing import Generic, Optional, Tuple, Type, TypeVar
+
+import numpy as np
+from numpy.random import Generator as RandomGenerator
+
+from vkit_amd import _native
+from vkit_amd.element import Image, Mask, Point, ScoreMap
+from ...interface import Distortion, DistortionConfig, DistortionState
+from .grid_creator import create_dst_image_grid_and_shift_amounts_and_resize_ratios
+from .image_grid import ImageGrid
+from .point_projector import PointProjector
+
+_T_CONFIG = TypeVar('_T_CONFIG', bound=DistortionConfig)
+
+
+class DistortionStateImageGridBased(DistortionState[_T_CONFIG]):
+    src_image_grid: ImageGrid
+    dst_image_grid: ImageGrid
+    shift_amount_y: float
+    shift_amount_x: float
+    resize_ratio_y: float
+    resize_ratio_x: float
+
+    def initialize_image_grid_based(self, src_image_grid: ImageGrid, point_projector: PointProjector,
+                                    resize_as_src: bool = False):
+        self.src_image_grid = src_image_grid
+        (
+            self.dst_image_grid,
+            (self.shift_amount_y, self.shift_amount_x),
+            (self.resize_ratio_y, self.resize_ratio_x),
+        ) = create_dst_image_grid_and_shift_amounts_and_resize_ratios(src_image_grid, point_projector,
+                                                                      resize_as_src=resize_as_src)
+
+    def shift_and_resize_point(self, point: Point):
+        return Point.create(
+            y=(point.smooth_y - self.shift_amount_y) * self.resize_ratio_y,
+            x=(point.smooth_x - self.shift_amount_x) * self.resize_ratio_x,
+        )
+
+    @property
+    def result_shape(self):
+        return self.dst_image_grid.image_height, self.dst_image_grid.image_width
+
+
+_T_STATE = TypeVar('_T_STATE', bound=DistortionStateImageGridBased)
+
+
+def blend_src_to_dst(mat: np.ndarray, src_image_grid: ImageGrid, dst_image_grid: ImageGrid) -> np.ndarray:
+    """cv.remap(mat, map_x, map_y, INTER_LINEAR) through the grid, without materialising the maps."""
+    return _native.grid_remap([mat], src_image_grid.vertices, dst_image_grid.vertices, dst_image_grid.image_shape)[0]
+
+
+class FuncImageGridBased(Generic[_T_CONFIG, _T_STATE]):
+
+    @classmethod
+    def func_image(cls, config, state, image: Image, rng: Optional[RandomGenerator]):
+        assert state
+        return Image(mat=blend_src_to_dst(image.mat, state.src_image_grid, state.dst_image_grid), mode=image.mode)
+
+    @classmethod
+    def func_score_map(cls, config, state, score_map: ScoreMap, rng: Optional[RandomGenerator]):
+        assert state
+        return ScoreMap(mat=blend_src_to_dst(score_map.mat, state.src_image_grid, state.dst_image_grid))
+
+    @classmethod
+    def func_mask(cls, config, state, mask: Mask, rng: Optional[RandomGenerator]):
+        # bilinear on the 0/1 bytes, exactly like the reference (grid_blender.py:74-81): no nearest neighbour
+        assert state
+        return Mask(mat=blend_src_to_dst(mask.mat, state.src_image_grid, state.dst_image_grid))
+
+    @classmethod
+    def func_active_mask(cls, config, state, shape: Tuple[int, int], rng: Optional[RandomGenerator]):
+        assert state
+        raise NotImplementedError('active-mask rasterisation of the destination border polygon is not on the '
+                                  'accelerated path yet')
+
+    @classmethod
+    def func_point(cls, config, state, shape: Tuple[int, int], point: Point, rng: Optional[RandomGenerator]):
+        assert state
+        src_grid, dst_grid = state.src_image_grid, state.dst_image_grid
+        assert src_grid.grid_size
+        row = point.y // src_grid.grid_size
+        col = point.x // src_grid.grid_size
+        trans_mat = src_grid.get_trans_mat(row, col, dst_grid)
+        tx, ty, t = np.matmul(trans_mat, (point.smooth_x, point.smooth_y, 1.0))
+        return Point.create(y=float(ty / t), x=float(tx / t))
+
+
+class DistortionImageGridBased(Distortion[_T_CONFIG, _T_STATE]):
+
+    def __init__(self, config_cls: Type[_T_CONFIG], state_cls: Type[_T_STATE]):
+        funcs = FuncImageGridBased[_T_CONFIG, _T_STATE]
+        super().__init__(
+            config_cls=config_cls,
+            state_cls=state_cls,
+            func_image=funcs.func_image,
+            func_mask=funcs.func_mask,
+            func_score_map=funcs.func_score_map,
+            func_active_mask=funcs.func_active_mask,
+            func_point=funcs.func_point,
+        )
+
+    def distort(self, config_or_config_generator, shapable_or_shape=None, image=None, mask=None, score_map=None,
+                **kwargs):
+        """Same contract as ``Distortion.distort``; Image + Mask + ScoreMap of one call share ONE device pass
+        (one ownership raster, one homography evaluation per pixel, three gathers) instead of three."""
+        shared = [e for e in (image, mask, score_map) if e is not None]
+        if len(shared) < 2:
+            return super().distort(config_or_config_generator, shapable_or_shape, image=image, mask=mask,
+                                   score_map=score_map, **kwargs)
+        result = super().distort(config_or_config_generator, shapable_or_shape or shared[0].shape, image=None,
+                                 mask=None, score_map=None, get_state=True,
+                                 **{k: v for k, v in kwargs.items() if k != 'get_state'})
+        state = result.state
+        outs = _native.grid_remap([e.mat for e in shared], state.src_image_grid.vertices,
+                                  state.dst_image_grid.vertices, state.dst_image_grid.image_shape)
+        it = iter(outs)
+        if image is not None:
+            result.image = Image(mat=next(it), mode=image.mode)
+        if mask is not None:
+            result.mask = Mask(mat=next(it))
+        if score_map is not None:
+            result.score_map = ScoreMap(mat=next(it))
+        if not kwargs.get('get_state'):
+            result.state = None
+        return result

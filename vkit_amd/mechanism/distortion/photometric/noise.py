@@ -1,0 +1,52 @@
+"""``gaussion_noise`` (sic, reference: photometric/noise.py:25-61).
+
+The samples come from the caller-visible numpy Generator stream -- ``np.round(rng.normal(0, std, shape))`` in C
+order, one draw per channel value -- so that a stored ``config.rng_state`` reproduces the same pixels; the add
+and clip run on the GPU (``vkx_add_noise_i16``)."""
+from typing import Any, Mapping, Optional
+
+import attrs
+import numpy as np
+from numpy.random import Generator as RandomGenerator
+
+from vkit_amd import _native
+from vkit_amd.element import Image
+from ..interface import Distortion, DistortionConfig, DistortionNopState
+
+
+@attrs.define
+class GaussionNoiseConfig(DistortionConfig):
+    std: float
+
+    _rng_state: Optional[Mapping[str, Any]] = None
+
+    @property
+    def supports_rng_state(self) -> bool:
+        return True
+
+    @property
+    def rng_state(self) -> Optional[Mapping[str, Any]]:
+        return self._rng_state
+
+    @rng_state.setter
+    def rng_state(self, val: Mapping[str, Any]):
+        self._rng_state = val
+
+
+def gaussion_noise_plane(std: float, shape, rng: RandomGenerator) -> np.ndarray:
+    """int16 round-half-even of N(0, std) draws, the reference's sample order."""
+    return np.round(rng.normal(0, std, shape)).astype(np.int16)
+
+
+def gaussion_noise_image(config: GaussionNoiseConfig, state, image: Image, rng: Optional[RandomGenerator]):
+    assert rng
+    noise = gaussion_noise_plane(config.std, image.mat.shape, rng)
+    # the mode is re-inferred from the array, like the reference
+    return Image(mat=_native.add_noise_i16(image.mat, noise))
+
+
+gaussion_noise = Distortion(
+    config_cls=GaussionNoiseConfig,
+    state_cls=DistortionNopState[GaussionNoiseConfig],
+    func_image=gaussion_noise_image,
+)
