@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Benchmark of the distortion hot path on MI355X: BASELINE config 3.
+
+Workload (per GPU): B independent 2048x2048 RGB page images, each with its own ``camera_cubic_curve`` state
+(config from the reference-compatible generator at level 5, seed = image index), through
+    image-grid remap  ->  gaussian_blur(sigma=1.0, k=5)  ->  color_shift(delta=37)  ->  gaussion_noise(std=10)
+with every input (images, integer vertex lattices, numpy-generated int16 noise planes) resident in HBM before the
+timed region.  A "step" is one pass of the chain over the whole batch.  Images shard across GPUs without any
+exchange (one process per GPU, weak scaling: every GPU processes its own B images).
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task description):
+  value      = source megapixels (H*W per image) processed per second by all ranks together
+  roofline   = algorithmic bytes / HIP-event duration of the dominant kernel, against the 8 TB/s HBM peak
+  cpu_baseline = the CPU oracle (port of the reference arithmetic, 1 thread) on a bounded sample, rank 0, N=1 only
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+BLUR_SIGMA = 1.0
+HUE_DELTA = 37
+NOISE_STD = 10.0
+LEVEL = 5
+
+
+def _noise_plane(args):
+    seed, shape = args
+    return np.round(np.random.default_rng(seed).normal(0, NOISE_STD, shape)).astype(np.int16)
+
+
+def make_state(index, size):
+    from numpy.random import default_rng
+    from vkit_amd.mechanism import distortion as D
+    from vkit_amd.mechanism.distortion_policy.geometric import camera as P_cam
+    gen = P_cam.CameraCubicCurveConfigGenerator(P_cam.CameraCubicCurveConfigGeneratorConfig(), LEVEL)
+    cfg = gen((size, size), default_rng(index))
+    return D.camera_cubic_curve.generate_state(cfg, (size, size))
+
+
+def cpu_baseline(size, n_images):
+    """The oracle (CPU restatement of the reference arithmetic) on the first ``n_images`` images, one thread."""
+    import oracle as O
+    states = [make_state(i, size) for i in range(n_images)]
+    images = [np.random.default_rng(1000 + i).integers(0, 256, (size, size, 3), dtype=np.uint8) for i in range(n_images)]
+    noises = [_noise_plane((5000 + i, tuple(s.result_shape) + (3,))) for i, s in enumerate(states)]
+    O.lib()
+    t0 = time.perf_counter()
+    checksum = 0
+    for img, st, noise in zip(images, states, noises):
+        mx, my = O.grid_to_map(st.src_image_grid.vertices, st.dst_image_grid.vertices, st.result_shape)
+        out = O.remap(img, mx, my)
+        out = O.gaussian_blur(out, 5, BLUR_SIGMA)
+        out = O.color_shift_rgb(out, HUE_DELTA)
+        out = O.add_noise_i16(out, noise)
+        checksum += int(out[::97, ::89].sum())
+    dt = time.perf_counter() - t0
+    return {
+        'value': n_images * size * size / dt / 1e6,
+        'unit': 'Mpixels/s',
+        'cores': 1,
+        'kind': 'port',
+        'sample': f'{n_images} images of the same workload (grid->map, remap, blur, hue shift, noise add; noise planes '
+                  f'precomputed as for the GPU), {dt:.1f} s on 1 thread of {os.cpu_count()} host cores',
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=256, help='images per GPU')
+    ap.add_argument('--size', type=int, default=2048)
+    ap.add_argument('--cpu-sample', type=int, default=8, help='images timed on the CPU oracle (rank 0, N=1)')
+    ap.add_argument('--verify', type=int, default=1, help='images of the batch checked against the oracle')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+
+    import __graft_entry__
+    if rank == 0 or not os.path.exists(os.path.join(ROOT, 'vkit_amd', 'libvkx.so')):
+        __graft_entry__.build()
+
+    B, size = args.batch, args.size
+    first = rank * B  # global index of this rank's first image
+
+    # ---- host-side setup (no GPU yet): states and noise planes -------------------------------------------------
+    t_setup = time.perf_counter()
+    states = [make_state(first + j, size) for j in range(B)]
+    workers = max(1, min(32, (os.cpu_count() or 1) // max(world, 1)))
+    noise_jobs = [(5000 + first + j, tuple(states[j].result_shape) + (3,)) for j in range(B)]
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from vkit_amd import _native
+    from vkit_amd.batch import ChainBatch
+    ctx = _native.Context(local_rank)
+    batch = ChainBatch(ctx)
+    with mp.get_context('spawn').Pool(workers) as pool:
+        for j, noise in enumerate(pool.imap(_noise_plane, noise_jobs, chunksize=1)):
+            image = np.random.default_rng(1000 + first + j).integers(0, 256, (size, size, 3), dtype=np.uint8)
+            batch.add(image, states[j], blur_sigma=BLUR_SIGMA, hue_delta=HUE_DELTA, noise=noise)
+    t_setup = time.perf_counter() - t_setup
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def full_sync():
+        ctx.sync()
+        torch.cuda.synchronize()
+
+    # ---- warmup, then K timed steps ------------------------------------------------------------------------------
+    for _ in range(args.warmup):
+        batch.run()
+    full_sync()
+    ctx.set_timing(True)
+    ctx.reset_timings()
+    barrier()
+    full_sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.run()
+    full_sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_times = ctx.timings()
+    ctx.set_timing(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- parity spot check of this very batch against the oracle (outside the timed region) -------------------------
+    verified = 0
+    if rank == 0 and args.verify > 0:
+        import oracle as O
+        for j in range(min(args.verify, B)):
+            st = states[j]
+            img = np.random.default_rng(1000 + first + j).integers(0, 256, (size, size, 3), dtype=np.uint8)
+            mx, my = O.grid_to_map(st.src_image_grid.vertices, st.dst_image_grid.vertices, st.result_shape)
+            want = O.add_noise_i16(O.color_shift_rgb(O.gaussian_blur(O.remap(img, mx, my), 5, BLUR_SIGMA), HUE_DELTA),
+                                   _noise_plane(noise_jobs[j]))
+            got = batch.result(j)
+            if not (got == want).all():
+                raise SystemExit(f'bench: image {j} differs from the oracle ({int((got != want).sum())} bytes)')
+            verified += 1
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    src_px = batch.source_pixels            # per rank, per step
+    dst_px = batch.result_pixels
+    total_px = src_px * world * args.steps
+    value = total_px / elapsed / 1e6
+
+    # ---- roofline of the dominant kernel: algorithmic bytes per launch / mean HIP-event duration -------------------
+    S, D = src_px / B, dst_px / B           # mean source / result pixels per image (= per launch)
+    algorithmic = {                         # bytes a launch has to move at the very least
+        'k_owner_remap': 3 * S + 3 * D,
+        'k_grid_photo_fused': 3 * S + 3 * D + 6 * D,   # + the int16 noise plane, which is an API input here
+        'k_gaussian_blur': 3 * D + 3 * D,
+        'k_hsv': 3 * D + 3 * D,
+        'k_add_noise': 3 * D + 6 * D + 3 * D,
+        'k_cell_raster': 4 * D,             # the ownership plane it produces
+        'k_cell_setup': 0,
+    }
+    dominant = max(kernel_times, key=lambda k: kernel_times[k][0])
+    dom_ms, dom_n = kernel_times[dominant]
+    avg_s = dom_ms / 1e3 / max(dom_n, 1)
+    achieved = algorithmic.get(dominant, 0) / avg_s / 1e9 if avg_s > 0 else 0.0
+    chain_bytes = (3 * S + 3 * D) * B       # the fully fused figure for the whole chain, per step
+    kernel_sum_s = sum(v[0] for v in kernel_times.values()) / 1e3 / args.steps
+    result = {
+        'metric': 'Mpixels/s (2048^2 RGB, geo+photo chain)',
+        'value': value,
+        'unit': 'Mpixels/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': elapsed / args.steps * 1e3,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'u8',
+        'data': 'synthetic',
+        'config': {
+            'workload': f'C3 fused chain: camera_cubic_curve remap (level {LEVEL}) + gaussian_blur(sigma={BLUR_SIGMA}) + '
+                        f'color_shift({HUE_DELTA}) + gaussion_noise(std={NOISE_STD}, numpy int16 planes resident in HBM), '
+                        f'{size}x{size}x3 uint8, batch {B} per GPU',
+            'batch_per_gpu': B,
+            'image': f'{size}x{size}x3',
+            'mean_result_pixels': D,
+            'sharding': f'{world} process(es), one per GPU, independent images, no collective',
+            'verified_against_oracle': verified,
+            'setup_s': round(t_setup, 1),
+        },
+        'roofline': {
+            'bound': 'hbm',
+            'kernel': dominant,
+            'achieved': achieved,
+            'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s',
+            'frac': achieved / HBM_PEAK_GBS,
+            'traffic': None,
+            'avg_launch_ms': avg_s * 1e3,
+            'algorithmic_bytes_per_launch': algorithmic.get(dominant, 0),
+            'chain_frac': chain_bytes / kernel_sum_s / 1e9 / HBM_PEAK_GBS if kernel_sum_s > 0 else 0.0,
+            'kernels_ms_per_step': {k: round(v[0] / args.steps, 3) for k, v in sorted(kernel_times.items())},
+        },
+    }
+    if world == 1:
+        result['cpu_baseline'] = cpu_baseline(size, args.cpu_sample)
+    else:
+        result['cpu_baseline'] = None
+    print(json.dumps(result))
+    sys.stdout.flush()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -183,6 +183,38 @@ int vkx_fill_u8_dev(vkx_ctx *ctx, uint8_t *dst, int h, int w, int cn, ptrdiff_t 
 int vkx_fill_u8(vkx_ctx *ctx, uint8_t *dst, int h, int w, int cn, ptrdiff_t dst_stride,
                 const vkx_layer *layers, int n_layers);
 
+/* ---- batched geometric + photometric chain (device resident) ---------------------------
+ * RandomDistortion's geometric stage followed by photometric members on one page image
+ * (mechanism/distortion_policy/random_distortion.py:190-203 applied through
+ * Distortion.distort, mechanism/distortion/interface.py:824-912), for a ragged batch of
+ * independent images: image-grid remap -> gaussian_blur -> color_shift -> gaussion_noise.
+ * `items` is a HOST array; every pointer inside is a DEVICE pointer. */
+typedef struct vkx_chain_item {
+    const uint8_t *src;            /* uint8 [sh, sw, 3] */
+    uint8_t *dst;                  /* uint8 [dh, dw, 3] */
+    ptrdiff_t src_stride, dst_stride;
+    int32_t sh, sw, dh, dw;
+    const int32_t *src_vertices;   /* int32 [rows, cols, 2] (x, y) */
+    const int32_t *dst_vertices;
+    int32_t rows, cols;
+    const int16_t *noise;          /* optional int16 [dh, dw, 3]; NULL = no noise stage */
+    ptrdiff_t noise_stride_el;
+    double blur_sigma;
+    int32_t blur_ksize;            /* <= 1 = no blur stage */
+    int32_t hue_delta;
+    int32_t hue_enabled;           /* 0 = no color_shift stage */
+    int32_t reserved;
+} vkx_chain_item;
+int vkx_chain_rgb_batch_dev(vkx_ctx *ctx, const vkx_chain_item *items, int n_items);
+
+/* ---- per-kernel timing -----------------------------------------------------------------
+ * When enabled, every kernel launch is bracketed by a hipEvent pair recorded on the ctx
+ * stream; vkx_ctx_collect_timings synchronises and folds them into per-kernel totals. */
+int vkx_ctx_set_timing(vkx_ctx *ctx, int enabled);
+int vkx_ctx_collect_timings(vkx_ctx *ctx, int *n_kernels);
+int vkx_ctx_get_timing(vkx_ctx *ctx, int index, const char **name, double *total_ms, long long *launches);
+int vkx_ctx_reset_timings(vkx_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,30 @@ class VkxElem(ctypes.Structure):
     ]
 
 
+class VkxChainItem(ctypes.Structure):
+    _fields_ = [
+        ('src', c_void_p),
+        ('dst', c_void_p),
+        ('src_stride', c_ssize),
+        ('dst_stride', c_ssize),
+        ('sh', ctypes.c_int32),
+        ('sw', ctypes.c_int32),
+        ('dh', ctypes.c_int32),
+        ('dw', ctypes.c_int32),
+        ('src_vertices', c_void_p),
+        ('dst_vertices', c_void_p),
+        ('rows', ctypes.c_int32),
+        ('cols', ctypes.c_int32),
+        ('noise', c_void_p),
+        ('noise_stride_el', c_ssize),
+        ('blur_sigma', c_double),
+        ('blur_ksize', ctypes.c_int32),
+        ('hue_delta', ctypes.c_int32),
+        ('hue_enabled', ctypes.c_int32),
+        ('reserved', ctypes.c_int32),
+    ]
+
+
 class VkxLayer(ctypes.Structure):
     _fields_ = [
         ('up', ctypes.c_int32),
@@ -67,6 +91,12 @@ _SIGNATURES = {
     'vkx_upload': [c_void_p, c_void_p, c_void_p, c_size],
     'vkx_download': [c_void_p, c_void_p, c_void_p, c_size],
     'vkx_memset': [c_void_p, c_void_p, c_int, c_size],
+    'vkx_chain_rgb_batch_dev': [c_void_p, ctypes.POINTER(VkxChainItem), c_int],
+    'vkx_ctx_set_timing': [c_void_p, c_int],
+    'vkx_ctx_collect_timings': [c_void_p, ctypes.POINTER(c_int)],
+    'vkx_ctx_get_timing': [c_void_p, c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_double),
+                           ctypes.POINTER(ctypes.c_longlong)],
+    'vkx_ctx_reset_timings': [c_void_p],
 }
 for _sfx in ('', '_dev'):
     _SIGNATURES['vkx_remap_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_void_p, c_ssize, c_void_p, c_int, c_int, c_ssize]
@@ -154,6 +184,40 @@ class Context:
 
     def set_stream(self, stream_ptr):
         check(lib().vkx_ctx_set_stream(self.handle, c_void_p(stream_ptr) if stream_ptr else None))
+
+    def set_timing(self, enabled):
+        check(lib().vkx_ctx_set_timing(self.handle, int(bool(enabled))))
+
+    def reset_timings(self):
+        check(lib().vkx_ctx_reset_timings(self.handle))
+
+    def timings(self):
+        """{kernel name: (total milliseconds, launches)} measured with HIP events on the launch stream."""
+        n = c_int(0)
+        check(lib().vkx_ctx_collect_timings(self.handle, ctypes.byref(n)))
+        out = {}
+        for i in range(n.value):
+            name, ms, cnt = ctypes.c_char_p(), c_double(), ctypes.c_longlong()
+            check(lib().vkx_ctx_get_timing(self.handle, i, ctypes.byref(name), ctypes.byref(ms), ctypes.byref(cnt)))
+            out[name.value.decode()] = (ms.value, cnt.value)
+        return out
+
+    def malloc(self, nbytes):
+        ptr = c_void_p()
+        check(lib().vkx_malloc(self.handle, int(nbytes), ctypes.byref(ptr)))
+        return ptr.value
+
+    def free(self, ptr):
+        check(lib().vkx_free(self.handle, c_void_p(ptr)))
+
+    def upload(self, dptr, array):
+        array = np.ascontiguousarray(array)
+        check(lib().vkx_upload(self.handle, c_void_p(dptr), _ptr(array), array.nbytes))
+
+    def download(self, dptr, array):
+        assert array.flags.c_contiguous and array.flags.writeable
+        check(lib().vkx_download(self.handle, _ptr(array), c_void_p(dptr), array.nbytes))
+        return array
 
     def close(self):
         if self._h:

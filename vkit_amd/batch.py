@@ -1,0 +1,98 @@
+"""Device-resident batch API: the distortion chain over a ragged batch of independent page images that stay in
+HBM between the geometric and the photometric members (BASELINE config 3).
+
+``ChainBatch`` owns the device buffers of its images (sources, destinations, vertex lattices, optional noise
+planes) and issues the whole batch with ONE ``vkx_chain_rgb_batch_dev`` call.  Images shard across GPUs by
+giving every process (one per GPU) its own ``ChainBatch``; there is no exchange step.
+"""
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from vkit_amd import _native
+from vkit_amd.mechanism.distortion.geometric.grid_rendering.interface import DistortionStateImageGridBased
+from vkit_amd.mechanism.distortion.photometric.blur import _estimate_gaussian_kernel_size
+
+
+class ChainBatch:
+
+    def __init__(self, ctx: Optional[_native.Context] = None):
+        self.ctx = ctx or _native.default_ctx()
+        self._items: List[_native.VkxChainItem] = []
+        self._owned: List[int] = []
+        self._dst_shapes: List[Tuple[int, int]] = []
+        self._array = None
+
+    def _put(self, array: np.ndarray) -> int:
+        array = np.ascontiguousarray(array)
+        ptr = self.ctx.malloc(array.nbytes)
+        self._owned.append(ptr)
+        self.ctx.upload(ptr, array)
+        return ptr
+
+    def add(self, image: np.ndarray, state: DistortionStateImageGridBased, blur_sigma: Optional[float] = None,
+            hue_delta: Optional[int] = None, noise: Optional[np.ndarray] = None):
+        """Registers one HxWx3 uint8 image with its image-grid state and per-image photometric parameters."""
+        if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
+            raise ValueError('ChainBatch takes HxWx3 uint8 images')
+        sh, sw = image.shape[:2]
+        dh, dw = state.result_shape
+        sv, dv = state.src_image_grid.vertices, state.dst_image_grid.vertices
+        item = _native.VkxChainItem()
+        item.src = self._put(image)
+        item.dst = self.ctx.malloc(dh * dw * 3)
+        self._owned.append(item.dst)
+        item.src_stride, item.dst_stride = sw * 3, dw * 3
+        item.sh, item.sw, item.dh, item.dw = sh, sw, dh, dw
+        item.src_vertices, item.dst_vertices = self._put(sv), self._put(dv)
+        item.rows, item.cols = sv.shape[0], sv.shape[1]
+        if noise is not None:
+            if noise.shape != (dh, dw, 3):
+                raise ValueError(f'noise plane must be {(dh, dw, 3)}, got {noise.shape}')
+            item.noise = self._put(noise.astype(np.int16, copy=False))
+            item.noise_stride_el = dw * 3
+        if blur_sigma is not None:
+            item.blur_sigma = float(blur_sigma)
+            item.blur_ksize = _estimate_gaussian_kernel_size(blur_sigma)
+        if hue_delta is not None:
+            item.hue_delta, item.hue_enabled = int(hue_delta), 1
+        self._items.append(item)
+        self._dst_shapes.append((dh, dw))
+        self._array = None
+        return len(self._items) - 1
+
+    def __len__(self):
+        return len(self._items)
+
+    @property
+    def source_pixels(self) -> int:
+        return sum(int(it.sh) * int(it.sw) for it in self._items)
+
+    @property
+    def result_pixels(self) -> int:
+        return sum(h * w for h, w in self._dst_shapes)
+
+    def run(self):
+        """Enqueues the chain for every image on the ctx stream (asynchronous)."""
+        if self._array is None:
+            self._array = (_native.VkxChainItem * max(len(self._items), 1))(*self._items)
+        _native.check(_native.lib().vkx_chain_rgb_batch_dev(self.ctx.handle, self._array, len(self._items)))
+
+    def result(self, index: int) -> np.ndarray:
+        self.ctx.sync()
+        dh, dw = self._dst_shapes[index]
+        out = np.empty((dh, dw, 3), np.uint8)
+        return self.ctx.download(self._items[index].dst, out)
+
+    def close(self):
+        for ptr in self._owned:
+            self.ctx.free(ptr)
+        self._owned.clear()
+        self._items.clear()
+        self._array = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

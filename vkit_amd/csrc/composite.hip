@@ -79,9 +79,9 @@ VKX_EXPORT int vkx_fill_u8_dev(vkx_ctx *ctx, uint8_t *dst, int h, int w, int cn,
         for (int c = 0; c < 4; c++) L.value_const[c] = l.value_const[c];
         dim3 block(64, 4), grid(vkx_blocks(l.width, 64), vkx_blocks(l.height, 4));
         switch (cn) {
-        case 1: k_fill<1><<<grid, block, 0, ctx->stream>>>(dst, dst_stride, L); break;
-        case 3: k_fill<3><<<grid, block, 0, ctx->stream>>>(dst, dst_stride, L); break;
-        default: k_fill<4><<<grid, block, 0, ctx->stream>>>(dst, dst_stride, L); break;
+        case 1: { VKX_TIMED(ctx, "k_fill"); k_fill<1><<<grid, block, 0, ctx->stream>>>(dst, dst_stride, L); } break;
+        case 3: { VKX_TIMED(ctx, "k_fill"); k_fill<3><<<grid, block, 0, ctx->stream>>>(dst, dst_stride, L); } break;
+        default: { VKX_TIMED(ctx, "k_fill"); k_fill<4><<<grid, block, 0, ctx->stream>>>(dst, dst_stride, L); } break;
         }
         VKX_LAUNCH_CHECK();
     }

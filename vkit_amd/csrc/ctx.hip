@@ -65,6 +65,9 @@ VKX_EXPORT int vkx_ctx_destroy(vkx_ctx *ctx)
     scratch_release(&ctx->misc);
     scratch_release(&ctx->tables);
     for (auto &s : ctx->stage) scratch_release(&s);
+    for (auto &s : ctx->chain) scratch_release(&s);
+    for (auto &l : ctx->launches) { (void)hipEventDestroy(l.start); (void)hipEventDestroy(l.stop); }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return VKX_OK;
@@ -153,5 +156,90 @@ VKX_EXPORT int vkx_memset(vkx_ctx *ctx, void *dptr, int value, size_t bytes)
     VKX_REQUIRE(ctx && (bytes == 0 || dptr), "NULL argument");
     if (!bytes) return VKX_OK;
     VKX_HIP(hipMemsetAsync(dptr, value, bytes, ctx->stream));
+    return VKX_OK;
+}
+
+// ---- per-kernel timing -------------------------------------------------------------------------------------
+static hipEvent_t take_event(vkx_ctx *ctx)
+{
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+vkx_timed::vkx_timed(vkx_ctx *c, const char *kernel_name) : ctx(c), slot(-1)
+{
+    if (!ctx || !ctx->timing) return;
+    int id = -1;
+    for (size_t i = 0; i < ctx->timing_names.size(); i++)
+        if (ctx->timing_names[i] == kernel_name) { id = (int)i; break; }
+    if (id < 0) {
+        ctx->timing_names.emplace_back(kernel_name);
+        ctx->timing_ms.push_back(0.0);
+        ctx->timing_count.push_back(0);
+        id = (int)ctx->timing_names.size() - 1;
+    }
+    vkx_ctx::TimedLaunch l{id, take_event(ctx), take_event(ctx)};
+    if (!l.start || !l.stop) return;
+    (void)hipEventRecord(l.start, ctx->stream);
+    ctx->launches.push_back(l);
+    slot = (int)ctx->launches.size() - 1;
+}
+
+vkx_timed::~vkx_timed()
+{
+    if (slot >= 0) (void)hipEventRecord(ctx->launches[slot].stop, ctx->stream);
+}
+
+VKX_EXPORT int vkx_ctx_set_timing(vkx_ctx *ctx, int enabled)
+{
+    VKX_REQUIRE(ctx != nullptr, "ctx is NULL");
+    ctx->timing = enabled != 0;
+    return VKX_OK;
+}
+
+// Synchronises the stream, folds every recorded launch into the per-kernel totals and returns their number.
+VKX_EXPORT int vkx_ctx_collect_timings(vkx_ctx *ctx, int *n_kernels)
+{
+    VKX_REQUIRE(ctx && n_kernels, "NULL argument");
+    VKX_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto &l : ctx->launches) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, l.start, l.stop) == hipSuccess) {
+            ctx->timing_ms[l.name_id] += ms;
+            ctx->timing_count[l.name_id] += 1;
+        }
+        ctx->event_pool.push_back(l.start);
+        ctx->event_pool.push_back(l.stop);
+    }
+    ctx->launches.clear();
+    *n_kernels = (int)ctx->timing_names.size();
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_ctx_get_timing(vkx_ctx *ctx, int index, const char **name, double *total_ms, long long *launches)
+{
+    VKX_REQUIRE(ctx && name && total_ms && launches, "NULL argument");
+    VKX_REQUIRE(index >= 0 && index < (int)ctx->timing_names.size(), "index out of range");
+    *name = ctx->timing_names[index].c_str();
+    *total_ms = ctx->timing_ms[index];
+    *launches = ctx->timing_count[index];
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_ctx_reset_timings(vkx_ctx *ctx)
+{
+    VKX_REQUIRE(ctx != nullptr, "ctx is NULL");
+    int n = 0;
+    int rc = vkx_ctx_collect_timings(ctx, &n);
+    if (rc) return rc;
+    ctx->timing_names.clear();
+    ctx->timing_ms.clear();
+    ctx->timing_count.clear();
     return VKX_OK;
 }

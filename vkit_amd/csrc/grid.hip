@@ -364,9 +364,9 @@ int build_owner(vkx_ctx *ctx, const int32_t *src_v, const int32_t *dst_v, int ro
     if (rc) return rc;
     VKX_HIP(hipMemsetAsync(owner, 0, sizeof(int32_t) * (size_t)dh * dw, ctx->stream));
     CellRec *cells = (CellRec *)ctx->cells.ptr;
-    k_cell_setup<<<vkx_blocks(ncell, 64), 64, 0, ctx->stream>>>(src_v, dst_v, rows, cols, cells);
+    { VKX_TIMED(ctx, "k_cell_setup"); k_cell_setup<<<vkx_blocks(ncell, 64), 64, 0, ctx->stream>>>(src_v, dst_v, rows, cols, cells); }
     VKX_LAUNCH_CHECK();
-    k_cell_raster<<<ncell, 64, 0, ctx->stream>>>(cells, ncell, owner, dh, dw);
+    { VKX_TIMED(ctx, "k_cell_raster"); k_cell_raster<<<ncell, 64, 0, ctx->stream>>>(cells, ncell, owner, dh, dw); }
     VKX_LAUNCH_CHECK();
     return VKX_OK;
 }
@@ -387,8 +387,8 @@ VKX_EXPORT int vkx_grid_to_map_dev(vkx_ctx *ctx, const int32_t *src_vertices, co
     int rc = build_owner(ctx, src_vertices, dst_vertices, rows, cols, dh, dw, own);
     if (rc) return rc;
     dim3 block(64, 4), grid(vkx_blocks(dw, 64), vkx_blocks(dh, 4));
-    k_owner_to_map<<<grid, block, 0, ctx->stream>>>((const CellRec *)ctx->cells.ptr, own, dh, dw, map_x, map_y,
-                                                    map_stride_el);
+    { VKX_TIMED(ctx, "k_owner_to_map"); k_owner_to_map<<<grid, block, 0, ctx->stream>>>((const CellRec *)ctx->cells.ptr, own, dh, dw, map_x, map_y,
+                                                    map_stride_el); }
     VKX_LAUNCH_CHECK();
     return VKX_OK;
 }
@@ -414,7 +414,7 @@ VKX_EXPORT int vkx_grid_remap_dev(vkx_ctx *ctx, const vkx_elem *elems, int n_ele
     rc = build_owner(ctx, src_vertices, dst_vertices, rows, cols, dh, dw, own);
     if (rc) return rc;
     dim3 block(64, 4), grid(vkx_blocks(dw, 64), vkx_blocks(dh, 4));
-    k_owner_remap<<<grid, block, 0, ctx->stream>>>((const CellRec *)ctx->cells.ptr, own, dh, dw, sh, sw, pack);
+    { VKX_TIMED(ctx, "k_owner_remap"); k_owner_remap<<<grid, block, 0, ctx->stream>>>((const CellRec *)ctx->cells.ptr, own, dh, dw, sh, sw, pack); }
     VKX_LAUNCH_CHECK();
     return VKX_OK;
 }

@@ -274,9 +274,9 @@ VKX_EXPORT int vkx_gaussian_blur_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h,
     }
     dim3 block(64, 4), grid(vkx_blocks(w, 64), vkx_blocks(h, 4));
     switch (cn) {
-    case 1: k_gaussian_blur<1><<<grid, block, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K); break;
-    case 3: k_gaussian_blur<3><<<grid, block, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K); break;
-    case 4: k_gaussian_blur<4><<<grid, block, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K); break;
+    case 1: { VKX_TIMED(ctx, "k_gaussian_blur"); k_gaussian_blur<1><<<grid, block, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K); } break;
+    case 3: { VKX_TIMED(ctx, "k_gaussian_blur"); k_gaussian_blur<3><<<grid, block, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K); } break;
+    case 4: { VKX_TIMED(ctx, "k_gaussian_blur"); k_gaussian_blur<4><<<grid, block, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K); } break;
     default: vkx_set_error("unsupported channel count %d", cn); return VKX_ERR_UNSUPPORTED;
     }
     VKX_LAUNCH_CHECK();
@@ -313,7 +313,7 @@ static int launch_hsv(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t 
     rc = hsv_tables(ctx, &T);
     if (rc) return rc;
     dim3 block(64, 4), grid(vkx_blocks(w, 64), vkx_blocks(h, 4));
-    k_hsv<MODE><<<grid, block, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, delta, T);
+    { VKX_TIMED(ctx, "k_hsv"); k_hsv<MODE><<<grid, block, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, delta, T); }
     VKX_LAUNCH_CHECK();
     return VKX_OK;
 }
@@ -340,8 +340,8 @@ VKX_EXPORT int vkx_mean_shift_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, in
     VKX_REQUIRE(cn >= 1 && cn <= 4, "1..4 channels");
     if (h == 0 || w == 0) return VKX_OK;
     dim3 block(64, 4), grid(vkx_blocks((size_t)w * cn, 64), vkx_blocks(h, 4));
-    k_mean_shift<<<grid, block, 0, ctx->stream>>>(src, h, w, cn, src_stride, dst, dst_stride, delta, has_threshold,
-                                                  threshold, cycle, channel_mask);
+    { VKX_TIMED(ctx, "k_mean_shift"); k_mean_shift<<<grid, block, 0, ctx->stream>>>(src, h, w, cn, src_stride, dst, dst_stride, delta, has_threshold,
+                                                  threshold, cycle, channel_mask); }
     VKX_LAUNCH_CHECK();
     return VKX_OK;
 }
@@ -355,7 +355,7 @@ VKX_EXPORT int vkx_add_noise_i16_dev(vkx_ctx *ctx, const uint8_t *src, int h, in
     VKX_REQUIRE(cn >= 1 && cn <= 4, "1..4 channels");
     if (h == 0 || w == 0) return VKX_OK;
     dim3 block(64, 4), grid(vkx_blocks((size_t)w * cn, 64), vkx_blocks(h, 4));
-    k_add_noise<<<grid, block, 0, ctx->stream>>>(src, h, w * cn, src_stride, noise, noise_stride_el, dst, dst_stride);
+    { VKX_TIMED(ctx, "k_add_noise"); k_add_noise<<<grid, block, 0, ctx->stream>>>(src, h, w * cn, src_stride, noise, noise_stride_el, dst, dst_stride); }
     VKX_LAUNCH_CHECK();
     return VKX_OK;
 }
@@ -386,9 +386,9 @@ VKX_EXPORT int vkx_line_streak_u8_dev(vkx_ctx *ctx, uint8_t *img, int h, int w, 
     for (int c = 0; c < 4; c++) P.color[c] = c < cn ? color[c] : 0;
     dim3 block(64, 4), grid(vkx_blocks(w, 64), vkx_blocks(h, 4));
     switch (cn) {
-    case 1: k_line_streak<1><<<grid, block, 0, ctx->stream>>>(img, h, w, stride, P); break;
-    case 3: k_line_streak<3><<<grid, block, 0, ctx->stream>>>(img, h, w, stride, P); break;
-    case 4: k_line_streak<4><<<grid, block, 0, ctx->stream>>>(img, h, w, stride, P); break;
+    case 1: { VKX_TIMED(ctx, "k_line_streak"); k_line_streak<1><<<grid, block, 0, ctx->stream>>>(img, h, w, stride, P); } break;
+    case 3: { VKX_TIMED(ctx, "k_line_streak"); k_line_streak<3><<<grid, block, 0, ctx->stream>>>(img, h, w, stride, P); } break;
+    case 4: { VKX_TIMED(ctx, "k_line_streak"); k_line_streak<4><<<grid, block, 0, ctx->stream>>>(img, h, w, stride, P); } break;
     default: vkx_set_error("unsupported channel count %d", cn); return VKX_ERR_UNSUPPORTED;
     }
     VKX_LAUNCH_CHECK();

@@ -86,9 +86,9 @@ int launch_u8(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_
     if (dh == 0 || dw == 0) return VKX_OK;
     dim3 block(64, 4), grid(vkx_blocks(dw, 64), vkx_blocks(dh, 4));
     switch (cn) {
-    case 1: k_sample_u8<1, Coord><<<grid, block, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, coord); break;
-    case 3: k_sample_u8<3, Coord><<<grid, block, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, coord); break;
-    case 4: k_sample_u8<4, Coord><<<grid, block, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, coord); break;
+    case 1: { VKX_TIMED(ctx, "k_sample_u8"); k_sample_u8<1, Coord><<<grid, block, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, coord); } break;
+    case 3: { VKX_TIMED(ctx, "k_sample_u8"); k_sample_u8<3, Coord><<<grid, block, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, coord); } break;
+    case 4: { VKX_TIMED(ctx, "k_sample_u8"); k_sample_u8<4, Coord><<<grid, block, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, coord); } break;
     default: vkx_set_error("unsupported channel count %d", cn); return VKX_ERR_UNSUPPORTED;
     }
     VKX_LAUNCH_CHECK();
@@ -104,7 +104,7 @@ int launch_f32(vkx_ctx *ctx, const float *src, int sh, int sw, ptrdiff_t sstride
     VKX_REQUIRE(sh <= 32767 && sw <= 32767, "source larger than 32767 px (cv.remap limit)");
     if (dh == 0 || dw == 0) return VKX_OK;
     dim3 block(64, 4), grid(vkx_blocks(dw, 64), vkx_blocks(dh, 4));
-    k_sample_f32<Coord><<<grid, block, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, coord);
+    { VKX_TIMED(ctx, "k_sample_f32"); k_sample_f32<Coord><<<grid, block, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, coord); }
     VKX_LAUNCH_CHECK();
     return VKX_OK;
 }

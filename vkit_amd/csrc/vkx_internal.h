@@ -56,7 +56,26 @@ struct vkx_ctx {
     vkx_scratch tables;   // constant lookup tables (HSV division LUTs), uploaded once
     bool tables_ready = false;
     vkx_scratch stage[6]; // staging planes of the host-pointer entry points
+    vkx_scratch chain[2]; // ping-pong planes of the batched chain entry point
+
+    // Optional per-kernel timing with HIP events recorded on the launch stream (vkx_ctx_set_timing).
+    bool timing = false;
+    struct TimedLaunch { int name_id; hipEvent_t start, stop; };
+    std::vector<TimedLaunch> launches;       // recorded, not yet folded into the totals
+    std::vector<hipEvent_t> event_pool;      // reusable events
+    std::vector<std::string> timing_names;
+    std::vector<double> timing_ms;
+    std::vector<long long> timing_count;
 };
+
+// RAII scope around ONE kernel launch: records a start / stop event pair on the ctx stream when timing is on.
+struct vkx_timed {
+    vkx_ctx *ctx;
+    int slot;
+    vkx_timed(vkx_ctx *ctx, const char *kernel_name);
+    ~vkx_timed();
+};
+#define VKX_TIMED(ctx, name) vkx_timed timed_scope__(ctx, name)
 
 int vkx_scratch_reserve(vkx_ctx *ctx, vkx_scratch *s, size_t bytes);
 
