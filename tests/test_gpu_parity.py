@@ -303,3 +303,87 @@ def test_chain_c3_one_full_size_image(N):
     mx, my = O.grid_to_map(sv, dv, dshape)
     want = O.add_noise_i16(O.color_shift_rgb(O.gaussian_blur(O.remap(img, mx, my), 5, 1.0), 37), noise)
     assert (got == want).all()
+
+
+# ------------------------------------------------------------------------------------------ batched chain
+def _chain_case(N, grids, names, seed, blur_sigmas, hue_deltas, with_noise):
+    from vkit_amd.batch import ChainBatch
+
+    class _State:  # the two attributes ChainBatch reads from an image-grid state
+        def __init__(self, sv, dv, dshape):
+            from types import SimpleNamespace
+            self.src_image_grid = SimpleNamespace(vertices=sv)
+            self.dst_image_grid = SimpleNamespace(vertices=dv)
+            self.result_shape = dshape
+
+    rng = default_rng(seed)
+    batch = ChainBatch()
+    expect = []
+    for i, name in enumerate(names):
+        sv, dv, dshape, (h, w) = grids[name]
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        sigma = blur_sigmas[i % len(blur_sigmas)]
+        delta = hue_deltas[i % len(hue_deltas)]
+        noise = rng.integers(-60, 60, tuple(dshape) + (3,)).astype(np.int16) if with_noise[i % len(with_noise)] else None
+        batch.add(img, _State(sv, dv, dshape), blur_sigma=sigma, hue_delta=delta, noise=noise)
+        mx, my = O.grid_to_map(sv, dv, dshape)
+        want = O.remap(img, mx, my)
+        if sigma is not None:
+            from vkit_amd.mechanism.distortion.photometric.blur import _estimate_gaussian_kernel_size
+            want = O.gaussian_blur(want, _estimate_gaussian_kernel_size(sigma), sigma)
+        if delta is not None:
+            want = O.color_shift_rgb(want, delta)
+        if noise is not None:
+            want = O.add_noise_i16(want, noise)
+        expect.append(want)
+    batch.run()
+    for i, want in enumerate(expect):
+        got = batch.result(i)
+        assert got.shape == want.shape, names[i]
+        bad = int((got != want).sum())
+        assert bad == 0, (names[i], bad, np.argwhere((got != want).any(axis=2))[:5].tolist())
+    batch.close()
+
+
+def test_chain_batch_ragged_against_oracle(N, grids):
+    names = sorted(grids)
+    _chain_case(N, grids, names, 11, [1.0, 0.6, None, 2.0], [37, None, -120], [True, False, True])
+    _chain_case(N, grids, names[::-1], 12, [None], [None], [False])       # remap only
+    _chain_case(N, grids, names, 13, [0.9], [255], [True])
+
+
+def test_chain_batch_degenerate_grid(N):
+    sv = np.array([[(x, y) for x in (0, 15, 30, 31)] for y in (0, 15, 30, 45)], np.int32)
+    dv = sv.copy()
+    dv[:, 3, 0] = dv[:, 2, 0]
+    dv[1, 1] = (22, 20)
+    dv[2, 1] = (9, 24)
+    dv[3, 0] = dv[3, 1]
+    dshape = (int(dv[..., 1].max()) + 1, int(dv[..., 0].max()) + 1)
+    grids = {'deg': (sv, dv, dshape, (46, 32))}
+    # non-finite map entries (den ~ 0 in degenerate cells) are compared through the pixels they produce
+    _chain_case(N, grids, ['deg'], 14, [1.0], [99], [True])
+
+
+def test_chain_batch_full_size(N):
+    sv, dv, dshape = synthetic_grid(2048, 2048, 20, 18.0, seed=3)
+    grids = {'big': (sv, dv, dshape, (2048, 2048))}
+    _chain_case(N, grids, ['big'], 15, [1.0], [37], [True])
+    sv, dv, dshape = synthetic_grid(1000, 1500, 15, 9.0, seed=4)
+    grids = {'odd': (sv, dv, dshape, (1000, 1500))}
+    _chain_case(N, grids, ['odd'], 16, [0.7], [-5], [False])
+
+
+def test_chain_batch_staged_path_subprocess(N):
+    """The per-stage fallback of vkx_chain_rgb_batch_dev (VKX_CHAIN_STAGED=1) gives the same pixels."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys; sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'tests'));"
+        "import numpy as np; import test_gpu_parity as T; from vkit_amd import _native as N;"
+        "g = {}; sv, dv, ds = T.synthetic_grid(300, 420, 15, 7.0, seed=5); g['a'] = (sv, dv, ds, (300, 420));"
+        "T._chain_case(N, g, ['a'], 17, [1.0], [37], [True]); T._chain_case(N, g, ['a'], 18, [None], [None], [True]); print('ok')")
+    env = dict(os.environ, VKX_CHAIN_STAGED='1')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'ok' in out.stdout, out.stdout + out.stderr

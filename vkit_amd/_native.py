@@ -124,6 +124,32 @@ EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['vkx_version', 'vkx_last_error', 
 
 _lib = None
 _lib_lock = threading.Lock()
+HIP_RUNTIME = 'system'
+
+
+def _preload_shared_hip_runtime():
+    """One HIP / HSA runtime per process.
+
+    PyTorch-ROCm wheels bundle their own ``libamdhip64.so`` (SONAME ``libamdhip64.so.7``, same as /opt/rocm's).
+    Two HSA runtimes in one process cannot both open the device: whichever initialises second reports "no
+    ROCm-capable device".  So when torch is installed, its copy is loaded first (RTLD_GLOBAL); ``libvkx.so``'s
+    ``NEEDED libamdhip64.so.7`` then binds to it by SONAME, and a later ``import torch`` reuses the same object.
+    ``VKX_HIP_RUNTIME=system`` opts out (processes that never import torch).
+    """
+    global HIP_RUNTIME
+    if os.environ.get('VKX_HIP_RUNTIME', '') == 'system':
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], 'lib', 'libamdhip64.so')
+    if os.path.exists(path):
+        ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        HIP_RUNTIME = path
 
 
 def lib():
@@ -137,6 +163,7 @@ def lib():
                 raise ImportError(
                     f'{LIB_PATH} is missing: build the HIP extension first '
                     '(python -c "import __graft_entry__ as g; g.build()").  vkit_amd has no CPU fallback.')
+            _preload_shared_hip_runtime()
             handle = ctypes.CDLL(LIB_PATH)
             for name, args in _SIGNATURES.items():
                 fn = getattr(handle, name)

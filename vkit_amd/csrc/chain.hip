@@ -7,6 +7,8 @@
 // two ctx-owned planes so only the final stage writes the caller's destination.
 #include "vkx_internal.h"
 
+#include <stdlib.h>
+
 VKX_EXPORT int vkx_chain_rgb_batch_dev(vkx_ctx *ctx, const vkx_chain_item *items, int n_items)
 {
     VKX_REQUIRE(ctx != nullptr, "ctx is NULL");
@@ -18,6 +20,12 @@ VKX_EXPORT int vkx_chain_rgb_batch_dev(vkx_ctx *ctx, const vkx_chain_item *items
         VKX_REQUIRE(it.sh > 0 && it.sw > 0 && it.dh > 0 && it.dw > 0, "bad shape in chain item");
         const size_t bytes = (size_t)it.dh * it.dw * 3;
         if (bytes > max_plane) max_plane = bytes;
+    }
+    // Preferred: the tile-fused kernel (fused.hip).  VKX_CHAIN_STAGED=1 forces the per-stage kernels (A/B runs).
+    static const bool staged_only = [] { const char *e = getenv("VKX_CHAIN_STAGED"); return e && e[0] == '1'; }();
+    if (!staged_only) {
+        const int frc = vkx_chain_fused_try(ctx, items, n_items);
+        if (frc != VKX_ERR_UNSUPPORTED) return frc;
     }
     for (int k = 0; k < 2; k++) {
         int rc = vkx_scratch_reserve(ctx, &ctx->chain[k], max_plane);

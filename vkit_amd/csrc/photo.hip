@@ -283,6 +283,8 @@ VKX_EXPORT int vkx_gaussian_blur_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h,
     return VKX_OK;
 }
 
+int vkx_gaussian_kernel_q8_host(int n, double sigma, uint16_t *kq) { return gaussian_kernel_q8(n, sigma, kq); }
+
 static int hsv_tables(vkx_ctx *ctx, const HsvTables **out)
 {
     if (!ctx->tables_ready) {
@@ -393,4 +395,13 @@ VKX_EXPORT int vkx_line_streak_u8_dev(vkx_ctx *ctx, uint8_t *img, int h, int w, 
     }
     VKX_LAUNCH_CHECK();
     return VKX_OK;
+}
+
+// Device copy of the RGB->HSV division tables {int sdiv[256]; int hdiv[256];} for other translation units.
+int vkx_hsv_tables(vkx_ctx *ctx, const void **out)
+{
+    const HsvTables *T = nullptr;
+    int rc = hsv_tables(ctx, &T);
+    *out = T;
+    return rc;
 }

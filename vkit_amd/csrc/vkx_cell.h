@@ -1,0 +1,232 @@
+// Per-cell device code shared by grid.hip and fused.hip: the dst->src homography of one lattice cell and the
+// cv.fillPoly edge table of its destination quad.  Specification and reference citations:
+// oracle/vkx_oracle.c (homography_direct / homography_jacobi, vko_fill_poly_closed_form).
+#pragma once
+#include "vkx_internal.h"
+
+#include <float.h>
+
+namespace vkc {
+
+// den * (unit square -> quad) as an exact-integer matrix (Heckbert's square-to-quad construction).
+__device__ inline void square_to_quad_scaled(const double q[8], double G[9])
+{
+    const double x0 = q[0], y0 = q[1], x1 = q[2], y1 = q[3], x2 = q[4], y2 = q[5], x3 = q[6], y3 = q[7];
+    const double sx = x0 - x1 + x2 - x3, sy = y0 - y1 + y2 - y3;
+    const double dx1 = x1 - x2, dy1 = y1 - y2, dx2 = x3 - x2, dy2 = y3 - y2;
+    const double den = dx1 * dy2 - dx2 * dy1;
+    const double g = sx * dy2 - dx2 * sy;
+    const double h = dx1 * sy - sx * dy1;
+    G[0] = den * (x1 - x0) + g * x1; G[1] = den * (x3 - x0) + h * x3; G[2] = den * x0;
+    G[3] = den * (y1 - y0) + g * y1; G[4] = den * (y3 - y0) + h * y3; G[5] = den * y0;
+    G[6] = g;                        G[7] = h;                        G[8] = den;
+}
+
+__device__ inline bool quad_in_general_position(const double q[8])
+{
+    for (int a = 0; a < 4; a++) {
+        const int b = (a + 1) & 3, c = (a + 2) & 3;
+        const double cr = (q[2 * b] - q[2 * a]) * (q[2 * c + 1] - q[2 * a + 1]) -
+                          (q[2 * b + 1] - q[2 * a + 1]) * (q[2 * c] - q[2 * a]);
+        if (cr == 0) return false;
+    }
+    return true;
+}
+
+// Closed-form quad -> quad homography (no three collinear vertices on either side).
+__device__ inline bool homography_direct(const double qf[8], const double qt[8], double H[9])
+{
+    if (!quad_in_general_position(qf) || !quad_in_general_position(qt)) return false;
+    double Gf[9], Gt[9], Af[9], Hp[9];
+    square_to_quad_scaled(qf, Gf);
+    square_to_quad_scaled(qt, Gt);
+    Af[0] = Gf[4] * Gf[8] - Gf[5] * Gf[7];
+    Af[1] = Gf[2] * Gf[7] - Gf[1] * Gf[8];
+    Af[2] = Gf[1] * Gf[5] - Gf[2] * Gf[4];
+    Af[3] = Gf[5] * Gf[6] - Gf[3] * Gf[8];
+    Af[4] = Gf[0] * Gf[8] - Gf[2] * Gf[6];
+    Af[5] = Gf[2] * Gf[3] - Gf[0] * Gf[5];
+    Af[6] = Gf[3] * Gf[7] - Gf[4] * Gf[6];
+    Af[7] = Gf[1] * Gf[6] - Gf[0] * Gf[7];
+    Af[8] = Gf[0] * Gf[4] - Gf[1] * Gf[3];
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++)
+            Hp[r * 3 + c] = (Gt[r * 3] * Af[c] + Gt[r * 3 + 1] * Af[3 + c]) + Gt[r * 3 + 2] * Af[6 + c];
+    if (Hp[8] == 0 || !isfinite(Hp[8])) return false;
+    for (int i = 0; i < 8; i++) H[i] = Hp[i] / Hp[8];
+    H[8] = 1.;
+    return true;
+}
+
+__device__ inline double vk_hypot(double a, double b)
+{
+    a = fabs(a); b = fabs(b);
+    if (a < b) { const double t = a; a = b; b = t; }
+    if (a == 0) return 0;
+    const double r = b / a;
+    return a * sqrt(1 + r * r);
+}
+
+// Minimum-norm least squares of the 8x8 DLT system: one-sided Jacobi SVD + back substitution with the
+// 2*eps*sum(w) cut-off.  Only reached for degenerate quads (a handful per image), written for clarity.
+__device__ __noinline__ void homography_jacobi(const float from[8], const float to[8], double H[9])
+{
+    double At[8][8], W[8], Vt[8][8], b[8], x[8];
+    for (int i = 0; i < 4; i++) {
+        const float fx = from[2 * i], fy = from[2 * i + 1], tx = to[2 * i], ty = to[2 * i + 1];
+        for (int c = 0; c < 8; c++) { At[c][i] = 0; At[c][i + 4] = 0; }
+        At[0][i] = fx; At[1][i] = fy; At[2][i] = 1;
+        At[3][i + 4] = fx; At[4][i + 4] = fy; At[5][i + 4] = 1;
+        At[6][i] = (double)(-fx * tx);      // float products, as cv::Point2f arithmetic forms them
+        At[7][i] = (double)(-fy * tx);
+        At[6][i + 4] = (double)(-fx * ty);
+        At[7][i + 4] = (double)(-fy * ty);
+        b[i] = tx;
+        b[i + 4] = ty;
+    }
+    const int m = 8, n = 8;
+    const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
+    double c, s, sd;
+    for (int i = 0; i < n; i++) {
+        sd = 0;
+        for (int k = 0; k < m; k++) { const double t = At[i][k]; sd += t * t; }
+        W[i] = sd;
+        for (int k = 0; k < n; k++) Vt[i][k] = 0;
+        Vt[i][i] = 1;
+    }
+    for (int iter = 0; iter < 30; iter++) {
+        bool changed = false;
+        for (int i = 0; i < n - 1; i++)
+            for (int j = i + 1; j < n; j++) {
+                double a = W[i], p = 0, bb = W[j];
+                for (int k = 0; k < m; k++) p += At[i][k] * At[j][k];
+                if (fabs(p) <= eps * sqrt(a * bb)) continue;
+                p *= 2;
+                const double beta = a - bb, gamma = vk_hypot(p, beta);
+                if (beta < 0) {
+                    const double delta = (gamma - beta) * 0.5;
+                    s = sqrt(delta / gamma);
+                    c = p / (gamma * s * 2);
+                } else {
+                    c = sqrt((gamma + beta) / (gamma * 2));
+                    s = p / (gamma * c * 2);
+                }
+                a = bb = 0;
+                for (int k = 0; k < m; k++) {
+                    const double t0 = c * At[i][k] + s * At[j][k];
+                    const double t1 = -s * At[i][k] + c * At[j][k];
+                    At[i][k] = t0; At[j][k] = t1;
+                    a += t0 * t0; bb += t1 * t1;
+                }
+                W[i] = a; W[j] = bb;
+                changed = true;
+                for (int k = 0; k < n; k++) {
+                    const double t0 = c * Vt[i][k] + s * Vt[j][k];
+                    const double t1 = -s * Vt[i][k] + c * Vt[j][k];
+                    Vt[i][k] = t0; Vt[j][k] = t1;
+                }
+            }
+        if (!changed) break;
+    }
+    for (int i = 0; i < n; i++) {
+        sd = 0;
+        for (int k = 0; k < m; k++) { const double t = At[i][k]; sd += t * t; }
+        W[i] = sqrt(sd);
+    }
+    for (int i = 0; i < n - 1; i++) {
+        int j = i;
+        for (int k = i + 1; k < n; k++)
+            if (W[j] < W[k]) j = k;
+        if (i != j) {
+            double t = W[i]; W[i] = W[j]; W[j] = t;
+            for (int k = 0; k < m; k++) { t = At[i][k]; At[i][k] = At[j][k]; At[j][k] = t; }
+            for (int k = 0; k < n; k++) { t = Vt[i][k]; Vt[i][k] = Vt[j][k]; Vt[j][k] = t; }
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        sd = W[i];
+        s = sd > minval ? 1 / sd : 0.;
+        for (int k = 0; k < m; k++) At[i][k] *= s;
+    }
+    double threshold = 0;
+    for (int i = 0; i < 8; i++) { x[i] = 0; threshold += W[i]; }
+    threshold *= DBL_EPSILON * 2;
+    for (int i = 0; i < 8; i++) {
+        double wi = W[i];
+        if (fabs(wi) <= threshold) continue;
+        wi = 1 / wi;
+        double acc = 0;
+        for (int j = 0; j < 8; j++) acc += At[i][j] * b[j];
+        acc *= wi;
+        for (int j = 0; j < 8; j++) x[j] = x[j] + acc * Vt[i][j];
+    }
+    for (int i = 0; i < 8; i++) H[i] = x[i];
+    H[8] = 1.;
+}
+
+// Number of minor-axis steps an 8-connected Bresenham line (cv::LineIterator, walked from its left end) has
+// taken after k major steps: ceil((2 k dmin - dmaj) / (2 dmaj)), never negative.
+__device__ __forceinline__ int bres_minor(int k, int dmaj, int dmin)
+{
+    if (dmaj == 0) return 0;
+    const long long num = 2LL * k * dmin - dmaj;
+    if (num <= 0) return 0;
+    return (int)((num + 2LL * dmaj - 1) / (2LL * dmaj));
+}
+
+// Compact per-cell record (128 B): everything a tile needs to rasterise the cell and to map its pixels.
+// Coordinates are limited to [0, 32767] (the same limit cv.remap imposes through its int16 coordinates).
+struct CellC {
+    double H[8];       // row-major inverse homography, H[8] == 1 implied
+    int ex[4];         // 16.16 x of edge i (vertex (i+3)&3 -> vertex i) at its upper end
+    int edx[4];        // 16.16 dx per scanline (C division of (dX << 16) by dY); 0 for horizontal edges
+    short vx[4], vy[4];
+    int flags;         // bit 0: the projective denominator may vanish inside the bounding box
+    int pad[3];
+};
+static_assert(sizeof(CellC) == 128, "CellC layout");
+
+// Builds the record of cell `cell` (row-major index over (rows-1) x (cols-1)) and returns its bounding box.
+__device__ inline void build_cell(const int32_t *__restrict__ src_v, const int32_t *__restrict__ dst_v, int rows, int cols,
+                                  int cell, CellC &rec, int &xmin, int &xmax, int &ymin, int &ymax)
+{
+    (void)rows;
+    const int r = cell / (cols - 1), c = cell - r * (cols - 1);
+    const int idx[4] = {r * cols + c, r * cols + c + 1, (r + 1) * cols + c + 1, (r + 1) * cols + c};
+    float from[8], to[8];
+    double qf[8], qt[8], H[9];
+    int vx[4], vy[4];
+    xmin = INT_MAX; xmax = INT_MIN; ymin = INT_MAX; ymax = INT_MIN;
+    for (int k = 0; k < 4; k++) {
+        vx[k] = dst_v[2 * idx[k]]; vy[k] = dst_v[2 * idx[k] + 1];
+        from[2 * k] = (float)vx[k]; from[2 * k + 1] = (float)vy[k];
+        to[2 * k] = (float)src_v[2 * idx[k]]; to[2 * k + 1] = (float)src_v[2 * idx[k] + 1];
+        qf[2 * k] = from[2 * k]; qf[2 * k + 1] = from[2 * k + 1];
+        qt[2 * k] = to[2 * k]; qt[2 * k + 1] = to[2 * k + 1];
+        xmin = min(xmin, vx[k]); xmax = max(xmax, vx[k]);
+        ymin = min(ymin, vy[k]); ymax = max(ymax, vy[k]);
+        rec.vx[k] = (short)vx[k]; rec.vy[k] = (short)vy[k];
+    }
+    if (!homography_direct(qf, qt, H)) homography_jacobi(from, to, H);
+    for (int i = 0; i < 8; i++) rec.H[i] = H[i];
+    for (int i = 0; i < 4; i++) {
+        const int a = (i + 3) & 3;
+        const long long xa = (long long)vx[a] << 16, xb = (long long)vx[i] << 16;
+        const int ya = vy[a], yb = vy[i];
+        if (ya == yb) { rec.ex[i] = 0; rec.edx[i] = 0; continue; }
+        rec.edx[i] = (int)((xb - xa) / (long long)(yb - ya));
+        rec.ex[i] = (int)(ya < yb ? xa : xb);
+    }
+    // The projective denominator is affine in (x, y): its extrema over the bounding box sit at the corners.
+    double dmin = DBL_MAX, dmax = -DBL_MAX;
+    const int cx[2] = {xmin, xmax}, cy[2] = {ymin, ymax};
+    for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 2; b++) {
+            const double d = H[6] * cx[a] + H[7] * cy[b] + 1.0;
+            dmin = fmin(dmin, d); dmax = fmax(dmax, d);
+        }
+    rec.flags = (dmin > 1e-6 || dmax < -1e-6) && isfinite(dmin) && isfinite(dmax) ? 0 : 1;
+    rec.pad[0] = rec.pad[1] = rec.pad[2] = 0;
+}
+
+} // namespace vkc

@@ -155,3 +155,8 @@ __device__ __forceinline__ float sample_f32(const float *__restrict__ src, int s
 }
 
 } // namespace vkd
+
+// cross-translation-unit helpers
+int vkx_hsv_tables(vkx_ctx *ctx, const void **out);                      // photo.hip
+int vkx_gaussian_kernel_q8_host(int n, double sigma, uint16_t *kq);      // photo.hip
+int vkx_chain_fused_try(vkx_ctx *ctx, const vkx_chain_item *items, int n_items);  // fused.hip
