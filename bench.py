@@ -84,6 +84,8 @@ def main():
     ap.add_argument('--size', type=int, default=2048)
     ap.add_argument('--cpu-sample', type=int, default=8, help='images timed on the CPU oracle (rank 0, N=1)')
     ap.add_argument('--verify', type=int, default=1, help='images of the batch checked against the oracle')
+    ap.add_argument('--noise-workers', type=int, default=-1,
+                    help='processes generating the numpy noise planes (0 = in this process, e.g. under rocprofv3)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -102,7 +104,9 @@ def main():
     # ---- host-side setup (no GPU yet): states and noise planes -------------------------------------------------
     t_setup = time.perf_counter()
     states = [make_state(first + j, size) for j in range(B)]
-    workers = max(1, min(32, (os.cpu_count() or 1) // max(world, 1)))
+    workers = args.noise_workers
+    if workers < 0:
+        workers = max(1, min(32, (os.cpu_count() or 1) // max(world, 1)))
     noise_jobs = [(5000 + first + j, tuple(states[j].result_shape) + (3,)) for j in range(B)]
 
     import torch
@@ -115,10 +119,14 @@ def main():
     from vkit_amd.batch import ChainBatch
     ctx = _native.Context(local_rank)
     batch = ChainBatch(ctx)
-    with mp.get_context('spawn').Pool(workers) as pool:
-        for j, noise in enumerate(pool.imap(_noise_plane, noise_jobs, chunksize=1)):
-            image = np.random.default_rng(1000 + first + j).integers(0, 256, (size, size, 3), dtype=np.uint8)
-            batch.add(image, states[j], blur_sigma=BLUR_SIGMA, hue_delta=HUE_DELTA, noise=noise)
+    pool = mp.get_context('spawn').Pool(workers) if workers > 0 else None
+    planes = pool.imap(_noise_plane, noise_jobs, chunksize=1) if pool else map(_noise_plane, noise_jobs)
+    for j, noise in enumerate(planes):
+        image = np.random.default_rng(1000 + first + j).integers(0, 256, (size, size, 3), dtype=np.uint8)
+        batch.add(image, states[j], blur_sigma=BLUR_SIGMA, hue_delta=HUE_DELTA, noise=noise)
+    if pool:
+        pool.close()
+        pool.join()
     t_setup = time.perf_counter() - t_setup
 
     def barrier():
@@ -177,15 +185,18 @@ def main():
     value = total_px / elapsed / 1e6
 
     # ---- roofline of the dominant kernel: algorithmic bytes per launch / mean HIP-event duration -------------------
-    S, D = src_px / B, dst_px / B           # mean source / result pixels per image (= per launch)
+    S, D = src_px / B, dst_px / B           # mean source / result pixels per image
     algorithmic = {                         # bytes a launch has to move at the very least
-        'k_owner_remap': 3 * S + 3 * D,
-        'k_grid_photo_fused': 3 * S + 3 * D + 6 * D,   # + the int16 noise plane, which is an API input here
+        'k_owner_remap': 3 * S + 3 * D,     # per-image launches ...
+        # ... and the batch-wide launches: one launch covers all B images.  3S + 3D for the images plus 6D for
+        # the int16 noise plane, which is an API input here.
+        'k_chain_fused': (3 * S + 3 * D + 6 * D) * B,
         'k_gaussian_blur': 3 * D + 3 * D,
         'k_hsv': 3 * D + 3 * D,
         'k_add_noise': 3 * D + 6 * D + 3 * D,
         'k_cell_raster': 4 * D,             # the ownership plane it produces
         'k_cell_setup': 0,
+        'k_chain_setup': 0,
     }
     dominant = max(kernel_times, key=lambda k: kernel_times[k][0])
     dom_ms, dom_n = kernel_times[dominant]

@@ -18,6 +18,7 @@
 #include "vkx_cell.h"
 
 #include <float.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -178,7 +179,7 @@ __global__ void __launch_bounds__(NTHREADS) k_chain_fused(const ItemDev *__restr
                                                           int n_items, int total_tiles,
                                                           const vkc::CellC *__restrict__ cells,
                                                           const TileBin *__restrict__ bins,
-                                                          const HsvLut *__restrict__ lut)
+                                                          const HsvLut *__restrict__ lut, int phase_limit)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS carve (all offsets multiples of 16)
@@ -290,6 +291,7 @@ __global__ void __launch_bounds__(NTHREADS) k_chain_fused(const ItemDev *__restr
         }
     }
     __syncthreads();
+    if (phase_limit == 1) return;
 
     // ---- C: source coordinates and bilinear gather for the tile + halo; packed RGB replaces the owner in LDS
     for (int p = tid; p < Ew * Eh; p += NTHREADS) {
@@ -310,6 +312,7 @@ __global__ void __launch_bounds__(NTHREADS) k_chain_fused(const ItemDev *__restr
         own[p] = gather_rgb(it.src, it.sh, it.sw, it.sstride, X, Y);
     }
     __syncthreads();
+    if (phase_limit == 2) return;
 
     // ---- D: horizontal 8.8 pass over the rows of the window, for the tile's own columns
     if (R > 0) {
@@ -330,6 +333,8 @@ __global__ void __launch_bounds__(NTHREADS) k_chain_fused(const ItemDev *__restr
         }
         __syncthreads();
     }
+
+    if (phase_limit == 3) return;
 
     // ---- E: vertical pass, hue shift, noise, store
     for (int q = tid; q < th * tw; q += NTHREADS) {
@@ -435,7 +440,8 @@ int vkx_chain_fused_try(vkx_ctx *ctx, const vkx_chain_item *items, int n_items)
         attr_set = true;
     }
     const int nwg = (int)(((tiles + 7) / 8) * 8);
-    { VKX_TIMED(ctx, "k_chain_fused"); k_chain_fused<<<nwg, NTHREADS, kFusedLds, ctx->stream>>>(d_items, d_tile_prefix, n_items, (int)tiles, cells, bins, lut); }
+    static const int phase_limit = [] { const char *e = getenv("VKX_FUSED_PHASES"); return e ? atoi(e) : 0; }();  // profiling aid: stop after phase A (1), C (2), D (3)
+    { VKX_TIMED(ctx, "k_chain_fused"); k_chain_fused<<<nwg, NTHREADS, kFusedLds, ctx->stream>>>(d_items, d_tile_prefix, n_items, (int)tiles, cells, bins, lut, phase_limit); }
     VKX_LAUNCH_CHECK();
     return VKX_OK;
 }
