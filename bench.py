@@ -203,6 +203,15 @@ def main():
     avg_s = dom_ms / 1e3 / max(dom_n, 1)
     achieved = algorithmic.get(dominant, 0) / avg_s / 1e9 if avg_s > 0 else 0.0
     chain_bytes = (3 * S + 3 * D) * B       # the fully fused figure for the whole chain, per step
+    # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), measured in separate
+    # rocprofv3 --pmc passes (profiles/) on the same workload and scaled by the number of images of this launch.
+    traffic, traffic_source = None, None
+    tpath = os.path.join(ROOT, 'profiles', 'r1c_traffic.json')
+    if dominant == 'k_chain_fused' and size == 2048 and os.path.exists(tpath):
+        with open(tpath) as fin:
+            tj = json.load(fin)
+        traffic = tj['hbm_bytes_per_image'] * B
+        traffic_source = 'profiles/r1c_traffic.json'
     kernel_sum_s = sum(v[0] for v in kernel_times.values()) / 1e3 / args.steps
     result = {
         'metric': 'Mpixels/s (2048^2 RGB, geo+photo chain)',
@@ -235,7 +244,8 @@ def main():
             'peak': HBM_PEAK_GBS,
             'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS,
-            'traffic': None,
+            'traffic': traffic,
+            'traffic_source': traffic_source,
             'avg_launch_ms': avg_s * 1e3,
             'algorithmic_bytes_per_launch': algorithmic.get(dominant, 0),
             'chain_frac': chain_bytes / kernel_sum_s / 1e9 / HBM_PEAK_GBS if kernel_sum_s > 0 else 0.0,
