@@ -183,6 +183,16 @@ int vkx_fill_u8_dev(vkx_ctx *ctx, uint8_t *dst, int h, int w, int cn, ptrdiff_t 
 int vkx_fill_u8(vkx_ctx *ctx, uint8_t *dst, int h, int w, int cn, ptrdiff_t dst_stride,
                 const vkx_layer *layers, int n_layers);
 
+/* ---- polygon rasterisation -----------------------------------------------------------
+ * cv.fillPoly(zeros((h, w), uint8), [pts], 1): PolygonInternals.np_mask element/polygon.py:70-77
+ * (Bresenham LINE_8 outline + even-odd scanline spans).  pts: HOST int32 [npts, 2] as (x, y), all
+ * inside the mask.  *_dev: mask is a device plane that is OR-ed into; host variant: mask is
+ * overwritten with the 0/1 raster. */
+int vkx_fill_poly_mask_u8_dev(vkx_ctx *ctx, const int32_t *pts_host, int npts, uint8_t *mask, int h, int w,
+                              ptrdiff_t mask_stride);
+int vkx_fill_poly_mask_u8(vkx_ctx *ctx, const int32_t *pts_host, int npts, uint8_t *mask, int h, int w,
+                          ptrdiff_t mask_stride);
+
 /* ---- batched geometric + photometric chain (device resident) ---------------------------
  * RandomDistortion's geometric stage followed by photometric members on one page image
  * (mechanism/distortion_policy/random_distortion.py:190-203 applied through

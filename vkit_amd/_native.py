@@ -119,6 +119,7 @@ for _sfx in ('', '_dev'):
     _SIGNATURES['vkx_line_streak_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_int, c_int, c_int, c_int, c_void_p, c_double,
                                                                          c_int, c_int]
     _SIGNATURES['vkx_fill_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [ctypes.POINTER(VkxLayer), c_int]
+    _SIGNATURES['vkx_fill_poly_mask_u8' + _sfx] = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_ssize]
 
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['vkx_version', 'vkx_last_error', 'vkx_ctx_stream'])
 
@@ -476,6 +477,16 @@ def line_streak(img, thickness, gap, dash_thickness, dash_gap, color, alpha, ena
     check(lib().vkx_line_streak_u8(ctx.handle, _ptr(out), h, w, cn, stride, int(thickness), int(gap), int(dash_thickness),
                                    int(dash_gap), _ptr(col), float(alpha), int(bool(enable_vert)), int(bool(enable_hori))))
     return out
+
+
+def fill_poly_mask(shape, pts, ctx=None):
+    """cv.fillPoly(zeros(shape, uint8), [pts], 1); pts int (N, 2) as (x, y), all inside the array."""
+    ctx = ctx or default_ctx()
+    h, w = int(shape[0]), int(shape[1])
+    pts = np.ascontiguousarray(np.asarray(pts, dtype=np.int32).reshape(-1, 2))
+    mask = np.empty((h, w), np.uint8)
+    check(lib().vkx_fill_poly_mask_u8(ctx.handle, _ptr(pts), int(pts.shape[0]), _ptr(mask), h, w, w))
+    return mask
 
 
 def make_layer(box, cn, value, mask=None, alpha=1.0):

@@ -77,8 +77,11 @@ class FuncImageGridBased(Generic[_T_CONFIG, _T_STATE]):
     @classmethod
     def func_active_mask(cls, config, state, shape: Tuple[int, int], rng: Optional[RandomGenerator]):
         assert state
-        raise NotImplementedError('active-mask rasterisation of the destination border polygon is not on the '
-                                  'accelerated path yet')
+        # reference grid_rendering/interface.py:177-192: border polygon of the destination lattice, filled with 1
+        dst_grid = state.dst_image_grid
+        active_mask = Mask.from_shape((dst_grid.image_height, dst_grid.image_width))
+        dst_grid.generate_border_polygon().fill_mask(active_mask)
+        return active_mask
 
     @classmethod
     def func_point(cls, config, state, shape: Tuple[int, int], point: Point, rng: Optional[RandomGenerator]):
