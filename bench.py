@@ -88,9 +88,8 @@ def main():
                     help='processes generating the numpy noise planes (0 = in this process, e.g. under rocprofv3)')
     args = ap.parse_args()
 
-    rank = int(os.environ.get('RANK', 0))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
+    from vkit_amd import shard
+    rank, local_rank, world = shard.world_from_env()
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
 
@@ -99,7 +98,7 @@ def main():
         __graft_entry__.build()
 
     B, size = args.batch, args.size
-    first = rank * B  # global index of this rank's first image
+    first, _ = shard.weak_span(B, rank)  # global index of this rank's first image
 
     # ---- host-side setup (no GPU yet): states and noise planes -------------------------------------------------
     t_setup = time.perf_counter()
@@ -110,10 +109,8 @@ def main():
     noise_jobs = [(5000 + first + j, tuple(states[j].result_shape) + (3,)) for j in range(B)]
 
     import torch
-    import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    group = shard.Group(backend='nccl' if world > 1 else None, device=torch.device('cuda', local_rank))
 
     from vkit_amd import _native
     from vkit_amd.batch import ChainBatch
@@ -129,35 +126,20 @@ def main():
         pool.join()
     t_setup = time.perf_counter() - t_setup
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
     def full_sync():
         ctx.sync()
         torch.cuda.synchronize()
 
-    # ---- warmup, then K timed steps ------------------------------------------------------------------------------
+    # ---- warmup, then K timed steps (barrier + device sync on both sides, MAX over ranks) -------------------------
     for _ in range(args.warmup):
         batch.run()
     full_sync()
     ctx.set_timing(True)
     ctx.reset_timings()
-    barrier()
-    full_sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        batch.run()
-    full_sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = shard.timed_steps(group, batch.run, steps=args.steps, warmup=0, device_sync=full_sync)
     kernel_times = ctx.timings()
     ctx.set_timing(False)
-
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    group.close()  # every rank is past the closing barrier and the MAX reduction: nothing collective is left
 
     # ---- parity spot check of this very batch against the oracle (outside the timed region) -------------------------
     verified = 0
@@ -175,8 +157,6 @@ def main():
             verified += 1
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
         return
 
     src_px = batch.source_pixels            # per rank, per step
@@ -258,8 +238,6 @@ def main():
         result['cpu_baseline'] = None
     print(json.dumps(result))
     sys.stdout.flush()
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -1,0 +1,107 @@
+"""Sharding of independent work units (images, pages) over one process per GPU.
+
+The path has no exchange step: every image is distorted on its own, exactly like the reference's
+process pool hands whole pipeline runs to workers (reference: vkit/utility/pool.py:65-96, process_idx -> its own
+rng / resources).  So there is no data-path collective; ``torch.distributed`` is used for the rendezvous, the
+barriers that bracket a timed region and one MAX all-reduce of the elapsed time.  Backend ``nccl`` (RCCL) on the
+GPUs, ``gloo`` in the CPU tests.
+"""
+import os
+import time
+from typing import Callable, Optional, Tuple
+
+
+def world_from_env() -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) as torch.distributed.run exports them; (0, 0, 1) for a plain launch."""
+    return (int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)),
+            int(os.environ.get('WORLD_SIZE', 1)))
+
+
+def weak_span(units_per_rank: int, rank: int) -> Tuple[int, int]:
+    """Weak scaling: every rank owns ``units_per_rank`` consecutive global indices -> (first, count)."""
+    if units_per_rank < 0 or rank < 0:
+        raise ValueError('units_per_rank and rank must be >= 0')
+    return rank * units_per_rank, units_per_rank
+
+
+def strong_span(total_units: int, rank: int, world: int) -> Tuple[int, int]:
+    """Strong scaling: ``total_units`` split into ``world`` contiguous chunks whose sizes differ by at most one
+    (the first ``total_units % world`` ranks get the extra unit) -> (first, count)."""
+    if world <= 0 or not 0 <= rank < world or total_units < 0:
+        raise ValueError(f'bad span request total={total_units} rank={rank} world={world}')
+    base, extra = divmod(total_units, world)
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
+def device_for(local_rank: int, n_devices: int) -> int:
+    """process -> GPU, the pool's ``process_idx % n`` rule (reference: vkit/utility/pool.py:65-96)."""
+    if n_devices <= 0:
+        raise RuntimeError('no GPU visible')
+    return local_rank % n_devices
+
+
+class Group:
+    """Rendezvous + the three collectives a sharded run needs (barrier, MAX of a float, SUM of an int)."""
+
+    def __init__(self, backend: Optional[str] = None, device=None):
+        self.rank, self.local_rank, self.world = world_from_env()
+        self.backend = backend
+        self.device = device
+        self._dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            if backend is None:
+                raise ValueError('a backend is required when WORLD_SIZE > 1')
+            kwargs = {}
+            if backend == 'nccl' and device is not None:
+                kwargs['device_id'] = device
+            dist.init_process_group(backend, **kwargs)
+            self._dist = dist
+
+    def barrier(self):
+        if self._dist is not None:
+            self._dist.barrier()
+
+    def _tensor(self, value, dtype):
+        import torch
+        dev = self.device if self.backend == 'nccl' and self.device is not None else 'cpu'
+        return torch.tensor([value], dtype=dtype, device=dev)
+
+    def max_float(self, value: float) -> float:
+        if self._dist is None:
+            return float(value)
+        import torch
+        t = self._tensor(value, torch.float64)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_int(self, value: int) -> int:
+        if self._dist is None:
+            return int(value)
+        import torch
+        t = self._tensor(value, torch.int64)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+        return int(t.item())
+
+    def close(self):
+        if self._dist is not None:
+            self._dist.destroy_process_group()
+            self._dist = None
+
+
+def timed_steps(group: Group, step: Callable[[], None], steps: int, warmup: int,
+                device_sync: Callable[[], None]) -> float:
+    """``warmup`` untimed passes, then exactly ``steps`` passes bracketed by barrier + device sync on both sides;
+    returns the elapsed seconds, MAX over ranks."""
+    for _ in range(warmup):
+        step()
+    device_sync()
+    group.barrier()
+    device_sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    device_sync()
+    group.barrier()
+    return group.max_float(time.perf_counter() - t0)
