@@ -177,11 +177,50 @@ typedef struct vkx_layer {
     const uint8_t *value;            /* optional [height, width, cn] uint8 */
     ptrdiff_t value_stride;
     uint8_t value_const[4];          /* used when value == NULL */
+    int32_t mode;                    /* VKX_FILL_*: keep_max_value / keep_min_value, element/opt.py:150-158 */
 } vkx_layer;
+#define VKX_FILL_PLAIN 0
+#define VKX_FILL_KEEP_MAX 1 /* write only where dst < value; acts when alpha is the scalar 1.0, like the reference */
+#define VKX_FILL_KEEP_MIN 2 /* write only where dst > value */
 int vkx_fill_u8_dev(vkx_ctx *ctx, uint8_t *dst, int h, int w, int cn, ptrdiff_t dst_stride,
                     const vkx_layer *layers, int n_layers);
 int vkx_fill_u8(vkx_ctx *ctx, uint8_t *dst, int h, int w, int cn, ptrdiff_t dst_stride,
                 const vkx_layer *layers, int n_layers);
+
+/* float32 destinations: ScoreMap fills (Box.fill_score_map element/box.py:368-392, Mask.fill_score_map
+ * element/mask.py:575-599, Polygon.fill_score_map element/polygon.py:475-487), the label height maps of
+ * pipeline/text_detection/page_distortion.py:163-314. */
+typedef struct vkx_layer_f32 {
+    int32_t up, left, height, width;
+    const uint8_t *mask;
+    ptrdiff_t mask_stride;
+    const float *alpha;
+    ptrdiff_t alpha_stride_el;
+    double alpha_scalar;
+    const float *value;              /* optional [height, width] float32 */
+    ptrdiff_t value_stride_el;
+    float value_const;
+    int32_t mode;
+} vkx_layer_f32;
+int vkx_fill_f32_dev(vkx_ctx *ctx, float *dst, int h, int w, ptrdiff_t dst_stride_el,
+                     const vkx_layer_f32 *layers, int n_layers);
+int vkx_fill_f32(vkx_ctx *ctx, float *dst, int h, int w, ptrdiff_t dst_stride_el,
+                 const vkx_layer_f32 *layers, int n_layers);
+
+/* ---- bicubic resize ------------------------------------------------------------------
+ * cv.resize(mat, (dw, dh), interpolation=cv.INTER_CUBIC): Image.to_resized_image element/image.py:836-852
+ * (bottom layer of fill_page_inactive_region, pipeline/text_detection/page_distortion.py:146-161),
+ * Mask.to_resized_mask element/mask.py:454-479 (on the 0/255 plane), ScoreMap.to_resized_score_map
+ * element/score_map.py:616-640.  Keys cubic A = -0.75, replicated border, 11-bit fixed-point coefficients and
+ * (sum + 2^21) >> 22 rounding for uint8 (OpenCV's scalar path); float32 sums left to right. */
+int vkx_resize_cubic_u8_dev(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t src_stride,
+                            uint8_t *dst, int dh, int dw, ptrdiff_t dst_stride);
+int vkx_resize_cubic_f32_dev(vkx_ctx *ctx, const float *src, int sh, int sw, ptrdiff_t src_stride_el,
+                             float *dst, int dh, int dw, ptrdiff_t dst_stride_el);
+int vkx_resize_cubic_u8(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t src_stride,
+                        uint8_t *dst, int dh, int dw, ptrdiff_t dst_stride);
+int vkx_resize_cubic_f32(vkx_ctx *ctx, const float *src, int sh, int sw, ptrdiff_t src_stride_el,
+                         float *dst, int dh, int dw, ptrdiff_t dst_stride_el);
 
 /* ---- polygon rasterisation -----------------------------------------------------------
  * cv.fillPoly(zeros((h, w), uint8), [pts], 1): PolygonInternals.np_mask element/polygon.py:70-77
@@ -192,6 +231,22 @@ int vkx_fill_poly_mask_u8_dev(vkx_ctx *ctx, const int32_t *pts_host, int npts, u
                               ptrdiff_t mask_stride);
 int vkx_fill_poly_mask_u8(vkx_ctx *ctx, const int32_t *pts_host, int npts, uint8_t *mask, int h, int w,
                           ptrdiff_t mask_stride);
+
+/* Ordered paint of many polygons into one label plane pair -- the label rasterisation after distortion,
+ * pipeline/text_detection/page_distortion.py:163-314 (for polygon in order: polygon.fill_mask(mask) /
+ * polygon.fill_score_map(score_map, value)), element/polygon.py:458-487.  Polygon i covers the cv.fillPoly
+ * raster of its vertices; where polygons overlap the LAST one in the list wins, exactly like the sequential
+ * fills.  Pixels inside any polygon get mask = 1 and score = values[winner]; other pixels are untouched.
+ * pts_host: HOST int32 [total_pts, 2] (x, y) in plane coordinates (parts outside the plane are clipped);
+ * poly_offsets_host: HOST int32 [n_polys + 1]; values_host: HOST float32 [n_polys] (required with score).
+ * mask / score: either may be NULL.  A polygon with more than 64 crossings on one scanline is refused
+ * (VKX_ERR_UNSUPPORTED; paint such polygons one by one through vkx_fill_poly_mask_u8 + vkx_fill_*). */
+int vkx_paint_polys_dev(vkx_ctx *ctx, const int32_t *pts_host, const int32_t *poly_offsets_host, int n_polys,
+                        const float *values_host, uint8_t *mask, ptrdiff_t mask_stride, float *score,
+                        ptrdiff_t score_stride_el, int h, int w);
+int vkx_paint_polys(vkx_ctx *ctx, const int32_t *pts_host, const int32_t *poly_offsets_host, int n_polys,
+                    const float *values_host, uint8_t *mask, ptrdiff_t mask_stride, float *score,
+                    ptrdiff_t score_stride_el, int h, int w);
 
 /* ---- batched geometric + photometric chain (device resident) ---------------------------
  * RandomDistortion's geometric stage followed by photometric members on one page image

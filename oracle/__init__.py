@@ -218,15 +218,16 @@ def add_noise_i16(img, noise):
     return dst
 
 
-def fill(dst, box, value, mask=None, alpha=1.0):
-    """fill_np_array restricted to uint8 destinations; ``dst`` is modified in place.
+FILL_PLAIN, FILL_KEEP_MAX, FILL_KEEP_MIN = 0, 1, 2
 
-    box = (up, left, height, width); value: tuple/int (constant) or uint8 array [h, w(, c)];
-    mask: uint8 [h, w] or None; alpha: python float or float32 array [h, w].
+
+def fill(dst, box, value, mask=None, alpha=1.0, mode=FILL_PLAIN):
+    """fill_np_array on uint8 (HxW[xC]) or float32 (HxW) destinations; ``dst`` is modified in place.
+
+    box = (up, left, height, width); value: tuple / scalar (constant) or array [h, w(, c)] of dst's dtype;
+    mask: uint8 [h, w] or None; alpha: python float or float32 array [h, w]; mode: keep_max / keep_min.
     """
-    assert dst.dtype == np.uint8 and dst.flags.c_contiguous and dst.flags.writeable
-    d3, _ = _as3(dst)
-    h, w, cn = d3.shape
+    assert dst.flags.c_contiguous and dst.flags.writeable
     up, left, bh, bw = (int(v) for v in box)
     mask_p, mask_step = None, 0
     if mask is not None:
@@ -240,21 +241,60 @@ def fill(dst, box, value, mask=None, alpha=1.0):
         alpha_p, alpha_step = _p(alpha), bw
     else:
         alpha_s = float(alpha)
-    vplane_p, vstep, vconst_p = None, 0, None
-    if isinstance(value, np.ndarray):
-        value = np.ascontiguousarray(value.astype(np.uint8))
-        v3, _ = _as3(value)
-        assert v3.shape == (bh, bw, cn)
-        vplane_p, vstep = _p(v3), bw * cn
+    if dst.dtype == np.float32:
+        assert dst.ndim == 2
+        h, w = dst.shape
+        vplane_p, vstep, vconst = None, 0, 0.0
+        if isinstance(value, np.ndarray):
+            value = np.ascontiguousarray(value.astype(np.float32))
+            assert value.shape == (bh, bw)
+            vplane_p, vstep = _p(value), bw
+        else:
+            vconst = float(np.float32(value))
+        rc = lib().vko_fill_f32(_p(dst), h, w, _ss(w), up, left, bh, bw, mask_p, _ss(mask_step), alpha_p,
+                                _ss(alpha_step), ctypes.c_double(alpha_s), vplane_p, _ss(vstep),
+                                ctypes.c_float(vconst), int(mode))
     else:
-        vconst = np.full(cn, value, dtype=np.uint8) if not isinstance(value, tuple) else np.asarray(
-            value, dtype=np.uint8)
-        assert vconst.shape == (cn,)
-        vconst_p = _p(vconst)
-    rc = lib().vko_fill_u8(_p(d3), h, w, cn, _ss(w * cn), up, left, bh, bw, mask_p, _ss(mask_step), alpha_p,
-                           _ss(alpha_step), ctypes.c_double(alpha_s), vplane_p, _ss(vstep), vconst_p)
+        assert dst.dtype == np.uint8
+        d3, _ = _as3(dst)
+        h, w, cn = d3.shape
+        vplane_p, vstep, vconst_p = None, 0, None
+        if isinstance(value, np.ndarray):
+            value = np.ascontiguousarray(value.astype(np.uint8))
+            v3, _ = _as3(value)
+            assert v3.shape == (bh, bw, cn)
+            vplane_p, vstep = _p(v3), bw * cn
+        else:
+            vconst = np.full(cn, value, dtype=np.uint8) if not isinstance(value, tuple) else np.asarray(
+                value, dtype=np.uint8)
+            assert vconst.shape == (cn,)
+            vconst_p = _p(vconst)
+        rc = lib().vko_fill_u8_mode(_p(d3), h, w, cn, _ss(w * cn), up, left, bh, bw, mask_p, _ss(mask_step),
+                                    alpha_p, _ss(alpha_step), ctypes.c_double(alpha_s), vplane_p, _ss(vstep),
+                                    vconst_p, int(mode))
     if rc == -2:
         raise RuntimeError(f'alpha={alpha_s} is invalid.')
+    assert rc == 0, rc
+    return dst
+
+
+def resize_cubic(src, dsize_hw):
+    """cv.resize(src, (dw, dh), interpolation=cv.INTER_CUBIC) for uint8 HxW[xC] or float32 HxW."""
+    dh, dw = int(dsize_hw[0]), int(dsize_hw[1])
+    src = np.ascontiguousarray(src)
+    if src.dtype == np.float32:
+        assert src.ndim == 2
+        sh, sw = src.shape
+        dst = np.empty((dh, dw), np.float32)
+        rc = lib().vko_resize_cubic_f32(_p(src), sh, sw, _ss(sw), _p(dst), dh, dw, _ss(dw))
+    else:
+        assert src.dtype == np.uint8
+        s3, squeeze = _as3(src)
+        sh, sw, cn = s3.shape
+        dst = np.empty((dh, dw, cn), np.uint8)
+        rc = lib().vko_resize_cubic_u8(_p(s3), sh, sw, cn, _ss(sw * cn), _p(dst), dh, dw, _ss(dw * cn))
+        if squeeze:
+            dst = dst[:, :, 0]
     assert rc == 0, rc
     return dst
 

@@ -1013,6 +1013,61 @@ VKO_API int vko_fill_u8(uint8_t *dst, int h, int w, int cn, ptrdiff_t dstep, int
     return 0;
 }
 
+/* [numpy] the same function with keep_max_value / keep_min_value (element/opt.py:150-158): they act only in
+ * the scalar alpha == 1 branch; mode 0 plain, 1 keep max (write where dst < value), 2 keep min. */
+VKO_API int vko_fill_u8_mode(uint8_t *dst, int h, int w, int cn, ptrdiff_t dstep, int up, int left,
+                             int bh, int bw, const uint8_t *mask, ptrdiff_t mask_step,
+                             const float *alpha_plane, ptrdiff_t alpha_step_el, double alpha_scalar,
+                             const uint8_t *value_plane, ptrdiff_t value_step,
+                             const uint8_t *value_const, int mode)
+{
+    if (mode == 0 || alpha_plane || alpha_scalar != 1.0)
+        return vko_fill_u8(dst, h, w, cn, dstep, up, left, bh, bw, mask, mask_step, alpha_plane,
+                           alpha_step_el, alpha_scalar, value_plane, value_step, value_const);
+    if (up < 0 || left < 0 || up + bh > h || left + bw > w) return -1;
+    for (int y = 0; y < bh; y++)
+        for (int x = 0; x < bw; x++) {
+            if (mask && !(mask[(ptrdiff_t)y * mask_step + x] > 0)) continue;
+            uint8_t *d = dst + (ptrdiff_t)(up + y) * dstep + (left + x) * cn;
+            const uint8_t *v = value_plane ? value_plane + (ptrdiff_t)y * value_step + x * cn : value_const;
+            for (int c = 0; c < cn; c++)
+                if (mode == 1 ? d[c] < v[c] : d[c] > v[c]) d[c] = v[c];
+        }
+    return 0;
+}
+
+/* float32 destinations (ScoreMap): same branches, blend kept in float32 (astype(float32) is the identity). */
+VKO_API int vko_fill_f32(float *dst, int h, int w, ptrdiff_t dstep_el, int up, int left, int bh, int bw,
+                         const uint8_t *mask, ptrdiff_t mask_step, const float *alpha_plane,
+                         ptrdiff_t alpha_step_el, double alpha_scalar, const float *value_plane,
+                         ptrdiff_t value_step_el, float value_const, int mode)
+{
+    if (up < 0 || left < 0 || up + bh > h || left + bw > w) return -1;
+    if (!alpha_plane) {
+        if (alpha_scalar < 0.0 || alpha_scalar > 1.0) return -2;
+        if (alpha_scalar == 0.0) return 0;
+    }
+    float a_s = (float)alpha_scalar;
+    int copy = !alpha_plane && alpha_scalar == 1.0;
+    for (int y = 0; y < bh; y++)
+        for (int x = 0; x < bw; x++) {
+            float a = alpha_plane ? alpha_plane[(ptrdiff_t)y * alpha_step_el + x] : a_s;
+            int sel = mask ? mask[(ptrdiff_t)y * mask_step + x] > 0 : (alpha_plane ? a > 0.0f : 1);
+            if (!sel) continue;
+            float *d = dst + (ptrdiff_t)(up + y) * dstep_el + (left + x);
+            float v = value_plane ? value_plane[(ptrdiff_t)y * value_step_el + x] : value_const;
+            if (copy) {
+                if (mode == 0 || (mode == 1 ? *d < v : *d > v)) *d = v;
+            } else {
+                float w1 = a, w0 = 1.0f - w1;
+                float t0 = w0 * *d;
+                float t1 = w1 * v;
+                *d = t0 + t1;
+            }
+        }
+    return 0;
+}
+
 /* [numpy] line_streak masks + two sequential blends -- photometric/streak.py:24-41,56-99 */
 VKO_API int vko_line_streak_u8(uint8_t *img, int h, int w, int cn, ptrdiff_t step, int thickness,
                                int gap, int dash_thickness, int dash_gap, const uint8_t *color,
@@ -1036,6 +1091,124 @@ VKO_API int vko_line_streak_u8(uint8_t *img, int h, int w, int cn, ptrdiff_t ste
         if (rc) { free(mask); return rc; }
     }
     free(mask);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
+ * [cv2] cv.resize(src, (dw, dh), interpolation=cv.INTER_CUBIC) -- element/image.py:836-852 (bottom layer
+ * of fill_page_inactive_region, pipeline/text_detection/page_distortion.py:146-161), element/mask.py:454-479,
+ * element/score_map.py:616-640.  imgproc/resize.cpp, generic path: resizeGeneric_ with HResizeCubic /
+ * VResizeCubic (scalar code; cv2's SIMD vertical pass for uint8 evaluates the same sum in float32 and can
+ * differ by 1 LSB -- parity unpinned at this boundary like every other cv2 call).
+ *   scale = 1 / (dsize / ssize) in double; per destination index d: f = (float)((d + 0.5) * scale - 0.5),
+ *   s = floor(f), f -= s; taps s-1 .. s+2 with border replication; Keys cubic, A = -0.75, in float32.
+ *   uint8: coefficients rounded to 11-bit fixed point (cvRound), horizontal pass in int32, vertical pass
+ *   saturate_u8((sum + (1 << 21)) >> 22).  float32: both passes in float32, left to right, no FMA.
+ * ---------------------------------------------------------------------------------- */
+static void vko_cubic_coeffs(float x, float c[4])
+{
+    const float A = -0.75f;
+    c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+    c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+    c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+    c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
+static int vko_clip_index(int x, int n) { return x < 0 ? 0 : (x >= n ? n - 1 : x); }
+
+static void vko_resize_axis(int ssize, int dsize, int *ofs, float *coef /* [dsize][4] */)
+{
+    double inv_scale = (double)dsize / ssize;
+    double scale = 1. / inv_scale;
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s0 = (int)floorf(f);
+        f -= s0;
+        ofs[d] = s0;
+        vko_cubic_coeffs(f, coef + 4 * d);
+    }
+}
+
+VKO_API int vko_resize_cubic_u8(const uint8_t *src, int sh, int sw, int cn, ptrdiff_t sstep,
+                                uint8_t *dst, int dh, int dw, ptrdiff_t dstep)
+{
+    if (sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || cn <= 0) return -1;
+    int *xofs = (int *)malloc(sizeof(int) * dw), *yofs = (int *)malloc(sizeof(int) * dh);
+    float *xc = (float *)malloc(sizeof(float) * 4 * dw), *yc = (float *)malloc(sizeof(float) * 4 * dh);
+    short *xa = (short *)malloc(sizeof(short) * 4 * dw), *yb = (short *)malloc(sizeof(short) * 4 * dh);
+    int32_t *rows = (int32_t *)malloc(sizeof(int32_t) * 4 * (size_t)dw * cn);
+    if (!xofs || !yofs || !xc || !yc || !xa || !yb || !rows) return -2;
+    vko_resize_axis(sw, dw, xofs, xc);
+    vko_resize_axis(sh, dh, yofs, yc);
+    for (int i = 0; i < 4 * dw; i++) xa[i] = (short)sat_short(cv_round_f(xc[i] * 2048.f));
+    for (int i = 0; i < 4 * dh; i++) yb[i] = (short)sat_short(cv_round_f(yc[i] * 2048.f));
+    for (int dy = 0; dy < dh; dy++) {
+        for (int k = 0; k < 4; k++) {
+            const uint8_t *S = src + (ptrdiff_t)vko_clip_index(yofs[dy] - 1 + k, sh) * sstep;
+            int32_t *D = rows + (size_t)k * dw * cn;
+            for (int dx = 0; dx < dw; dx++)
+                for (int c = 0; c < cn; c++) {
+                    uint32_t v = 0;
+                    for (int j = 0; j < 4; j++) {
+                        int sx = vko_clip_index(xofs[dx] - 1 + j, sw);
+                        v += (uint32_t)((int32_t)S[sx * cn + c] * (int32_t)xa[4 * dx + j]);
+                    }
+                    D[dx * cn + c] = (int32_t)v;
+                }
+        }
+        uint8_t *out = dst + (ptrdiff_t)dy * dstep;
+        for (int x = 0; x < dw * cn; x++) {
+            uint32_t v = 0;
+            for (int k = 0; k < 4; k++)
+                v += (uint32_t)rows[(size_t)k * dw * cn + x] * (uint32_t)(int32_t)yb[4 * dy + k];
+            int32_t r = ((int32_t)(v + (1u << 21))) >> 22;
+            out[x] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+        }
+    }
+    free(xofs); free(yofs); free(xc); free(yc); free(xa); free(yb); free(rows);
+    return 0;
+}
+
+VKO_API int vko_resize_cubic_f32(const float *src, int sh, int sw, ptrdiff_t sstep_el, float *dst, int dh,
+                                 int dw, ptrdiff_t dstep_el)
+{
+    if (sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0) return -1;
+    int *xofs = (int *)malloc(sizeof(int) * dw), *yofs = (int *)malloc(sizeof(int) * dh);
+    float *xc = (float *)malloc(sizeof(float) * 4 * dw), *yc = (float *)malloc(sizeof(float) * 4 * dh);
+    float *rows = (float *)malloc(sizeof(float) * 4 * (size_t)dw);
+    if (!xofs || !yofs || !xc || !yc || !rows) return -2;
+    vko_resize_axis(sw, dw, xofs, xc);
+    vko_resize_axis(sh, dh, yofs, yc);
+    for (int dy = 0; dy < dh; dy++) {
+        for (int k = 0; k < 4; k++) {
+            const float *S = src + (ptrdiff_t)vko_clip_index(yofs[dy] - 1 + k, sh) * sstep_el;
+            float *D = rows + (size_t)k * dw;
+            for (int dx = 0; dx < dw; dx++) {
+                const float *a = xc + 4 * dx;
+                float t0 = S[vko_clip_index(xofs[dx] - 1, sw)] * a[0];
+                float t1 = S[vko_clip_index(xofs[dx], sw)] * a[1];
+                float t2 = S[vko_clip_index(xofs[dx] + 1, sw)] * a[2];
+                float t3 = S[vko_clip_index(xofs[dx] + 2, sw)] * a[3];
+                float v = t0 + t1;
+                v = v + t2;
+                v = v + t3;
+                D[dx] = v;
+            }
+        }
+        float *out = dst + (ptrdiff_t)dy * dstep_el;
+        const float *b = yc + 4 * dy;
+        for (int x = 0; x < dw; x++) {
+            float t0 = rows[x] * b[0];
+            float t1 = rows[(size_t)dw + x] * b[1];
+            float t2 = rows[(size_t)2 * dw + x] * b[2];
+            float t3 = rows[(size_t)3 * dw + x] * b[3];
+            float v = t0 + t1;
+            v = v + t2;
+            v = v + t3;
+            out[x] = v;
+        }
+    }
+    free(xofs); free(yofs); free(xc); free(yc); free(rows);
     return 0;
 }
 

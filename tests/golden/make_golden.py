@@ -164,6 +164,49 @@ def gen_numpy_path():
 
 
 # --------------------------------------------------------------------------------------------
+def gen_fill_modes():
+    """fill_np_array on float32 score maps and with keep_max_value / keep_min_value (label rasterisation)."""
+    out = {}
+    rng = default_rng(77)
+    sm0 = (rng.random((24, 40), dtype=np.float32) * 30).astype(np.float32)
+    m = (rng.random((24, 40)) < 0.45).astype(np.uint8)
+    val = (rng.random((24, 40), dtype=np.float32) * 30).astype(np.float32)
+    out['f32_in'], out['f32_mask'], out['f32_value'] = sm0, m, val
+    for tag, kwargs in [('plain', {}), ('max', dict(keep_max_value=True)), ('min', dict(keep_min_value=True))]:
+        sm = ScoreMap(mat=sm0.copy(), is_prob=False)
+        Mask(mat=m).fill_score_map(sm, 12.5, **kwargs)
+        out[f'f32_mask_const_{tag}'] = sm.mat.copy()
+        sm = ScoreMap(mat=sm0.copy(), is_prob=False)
+        Mask(mat=m).fill_score_map(sm, ScoreMap(mat=val, is_prob=False), **kwargs)
+        out[f'f32_mask_plane_{tag}'] = sm.mat.copy()
+        sm = ScoreMap(mat=sm0.copy(), is_prob=False)
+        Box(up=2, down=19, left=5, right=33).fill_score_map(sm, 7.25, **kwargs)
+        out[f'f32_box_const_{tag}'] = sm.mat.copy()
+    out['f32_box'] = np.asarray([2, 5, 18, 29])
+    # uint8 destinations with the keep modes (Mask.fill_mask / fill_np_array on an image plane)
+    mk0 = rng.integers(0, 4, (24, 40)).astype(np.uint8)
+    mv = rng.integers(0, 4, (24, 40)).astype(np.uint8)
+    out['u8_in'], out['u8_value'] = mk0, mv
+    for tag, kwargs in [('max', dict(keep_max_value=True)), ('min', dict(keep_min_value=True))]:
+        mk = Mask(mat=mk0.copy())
+        Mask(mat=m).fill_mask(mk, 2, **kwargs)
+        out[f'u8_mask_const_{tag}'] = mk.mat.copy()
+        mk = Mask(mat=mk0.copy())
+        Mask(mat=m).fill_mask(mk, mv, **kwargs)
+        out[f'u8_mask_plane_{tag}'] = mk.mat.copy()
+    # float32 blends (alpha array / scalar) through the raw function
+    from vkit.element.opt import fill_np_array
+    alpha = (rng.random((24, 40), dtype=np.float32) * (rng.random((24, 40)) < 0.6)).astype(np.float32)
+    out['f32_alpha'] = alpha
+    dst = sm0.copy()
+    fill_np_array(dst, val, np_mask=alpha > 0, alpha=alpha)
+    out['f32_alpha_plane'] = dst
+    dst = sm0.copy()
+    fill_np_array(dst, 3.0, alpha=0.3)
+    out['f32_alpha_scalar'] = dst
+    np.savez_compressed(os.path.join(HERE, 'fill_modes.npz'), **out)
+
+
 def gen_mls_states():
     out = {}
     cases = [(64, 64, 0, 5), (96, 80, 1, 8), (130, 257, 2, 10), (512, 512, 0, 5), (300, 200, 3, 1)]
@@ -384,6 +427,7 @@ def gen_structure_oracle_patched():
 
 if __name__ == '__main__':
     gen_numpy_path()
+    gen_fill_modes()
     gen_mls_states()
     gen_affine_states()
     gen_policy_configs()

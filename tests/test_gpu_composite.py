@@ -1,0 +1,409 @@
+"""Composite, label rasterisation, bicubic resize and the two pipeline steps, GPU (through the C ABI) vs oracle."""
+import os
+
+import numpy as np
+import pytest
+from numpy.random import default_rng
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def N():
+    from vkit_amd import _native
+    return _native
+
+
+# ------------------------------------------------------------------ fill modes / float32 destinations
+def test_fill_modes_against_reference_goldens(N, golden_dir):
+    from vkit_amd.element import Box, Mask, ScoreMap
+    F = np.load(os.path.join(golden_dir, 'fill_modes.npz'))
+    sm0, m, val = F['f32_in'], F['f32_mask'], F['f32_value']
+    for tag, kwargs in (('plain', {}), ('max', dict(keep_max_value=True)), ('min', dict(keep_min_value=True))):
+        sm = ScoreMap(mat=sm0.copy(), is_prob=False)
+        Mask(mat=m).fill_score_map(sm, 12.5, **kwargs)
+        np.testing.assert_array_equal(sm.mat, F[f'f32_mask_const_{tag}'])
+        sm = ScoreMap(mat=sm0.copy(), is_prob=False)
+        Mask(mat=m).fill_score_map(sm, ScoreMap(mat=val, is_prob=False), **kwargs)
+        np.testing.assert_array_equal(sm.mat, F[f'f32_mask_plane_{tag}'])
+        sm = ScoreMap(mat=sm0.copy(), is_prob=False)
+        Box(up=2, down=19, left=5, right=33).fill_score_map(sm, 7.25, **kwargs)
+        np.testing.assert_array_equal(sm.mat, F[f'f32_box_const_{tag}'])
+    mk0, mv = F['u8_in'], F['u8_value']
+    for tag, kwargs in (('max', dict(keep_max_value=True)), ('min', dict(keep_min_value=True))):
+        mk = Mask(mat=mk0.copy())
+        Mask(mat=m).fill_mask(mk, 2, **kwargs)
+        np.testing.assert_array_equal(mk.mat, F[f'u8_mask_const_{tag}'])
+        mk = Mask(mat=mk0.copy())
+        Mask(mat=m).fill_mask(mk, mv, **kwargs)
+        np.testing.assert_array_equal(mk.mat, F[f'u8_mask_plane_{tag}'])
+    from vkit_amd.element.opt import fill_np_array
+    dst = sm0.copy()
+    fill_np_array(dst, val, np_mask=F['f32_alpha'] > 0, alpha=F['f32_alpha'])
+    np.testing.assert_array_equal(dst, F['f32_alpha_plane'])
+    dst = sm0.copy()
+    fill_np_array(dst, 3.0, alpha=0.3)
+    np.testing.assert_array_equal(dst, F['f32_alpha_scalar'])
+    # the reference fails on (2-D destination, mask, fractional scalar alpha): same exception type
+    with pytest.raises(IndexError):
+        fill_np_array(sm0.copy(), 3.0, np_mask=m.astype(bool), alpha=0.3)
+
+
+def test_deferred_fill_equals_sequential(N):
+    from vkit_amd.element import Box, Image, Mask, ScoreMap
+    from vkit_amd.element.opt import deferred_fill
+    rng = default_rng(11)
+    base = rng.integers(0, 256, (120, 160, 3), dtype=np.uint8)
+    layers = []
+    for _ in range(40):
+        h, w = int(rng.integers(4, 40)), int(rng.integers(4, 80))
+        up, left = int(rng.integers(0, 120 - h)), int(rng.integers(0, 160 - w))
+        kind = int(rng.integers(0, 4))
+        box = Box(up=up, down=up + h - 1, left=left, right=left + w - 1)
+        if kind == 0:
+            alpha = (rng.random((h, w), dtype=np.float32) * (rng.random((h, w)) < 0.4)).astype(np.float32)
+            layers.append(('score', ScoreMap(mat=alpha, box=box), tuple(int(v) for v in rng.integers(0, 256, 3))))
+        elif kind == 1:
+            layers.append(('box', box, Image(mat=rng.integers(0, 256, (h, w, 3), dtype=np.uint8)),
+                           float(rng.random())))
+        elif kind == 2:
+            layers.append(('mask', Mask(mat=(rng.random((h, w)) < 0.5).astype(np.uint8), box=box),
+                           Image(mat=rng.integers(0, 256, (h, w, 3), dtype=np.uint8))))
+        else:
+            layers.append(('box', box, Image(mat=rng.integers(0, 256, (h, w, 3), dtype=np.uint8)), 1.0))
+
+    def apply(image):
+        for layer in layers:
+            if layer[0] == 'score':
+                image[layer[1]] = layer[2]
+            elif layer[0] == 'box':
+                layer[1].fill_image(image, layer[2], alpha=layer[3])
+            else:
+                layer[1].fill_image(image, layer[2])
+
+    sequential = Image(mat=base.copy())
+    apply(sequential)
+    deferred = Image(mat=base.copy())
+    with deferred_fill(deferred.mat) as session:
+        apply(deferred)
+        assert len(session.layers) == len(layers)
+        np.testing.assert_array_equal(deferred.mat, base)  # nothing written yet
+    np.testing.assert_array_equal(deferred.mat, sequential.mat)
+    # and both equal the oracle applied layer by layer
+    want = base.copy()
+    for layer in layers:
+        box = layer[1].box if layer[0] != 'box' else layer[1]
+        geo = (box.up, box.left, box.height, box.width)
+        if layer[0] == 'score':
+            O.fill(want, geo, layer[2], alpha=layer[1].mat)
+        elif layer[0] == 'box':
+            O.fill(want, geo, layer[2].mat, alpha=layer[3])
+        else:
+            O.fill(want, geo, layer[2].mat, mask=layer[1].mat)
+    np.testing.assert_array_equal(sequential.mat, want)
+
+
+# ------------------------------------------------------------------ bicubic resize
+@pytest.mark.parametrize('src_shape,dst_shape', [((20, 30), (33, 47)), ((64, 64), (64, 64)), ((97, 131), (40, 55)),
+                                                 ((5, 7), (50, 3)), ((1, 1), (9, 9)), ((300, 200), (301, 199))])
+def test_resize_cubic_small(N, src_shape, dst_shape):
+    rng = default_rng(3)
+    for cn in (1, 3, 4):
+        shape = src_shape if cn == 1 else src_shape + (cn,)
+        src = rng.integers(0, 256, shape, dtype=np.uint8)
+        np.testing.assert_array_equal(N.resize_cubic(src, dst_shape), O.resize_cubic(src, dst_shape))
+    f = (rng.random(src_shape, dtype=np.float32) * 40 - 5).astype(np.float32)
+    np.testing.assert_array_equal(N.resize_cubic(f, dst_shape), O.resize_cubic(f, dst_shape))
+
+
+def test_resize_cubic_extremes_and_elements(N):
+    from vkit_amd.element import Image, Mask, ScoreMap
+    rng = default_rng(4)
+    # saturating overshoot: checkerboard of 0 / 255
+    src = ((np.indices((40, 40)).sum(axis=0) % 2) * 255).astype(np.uint8)
+    np.testing.assert_array_equal(N.resize_cubic(src, (93, 71)), O.resize_cubic(src, (93, 71)))
+    image = Image(mat=rng.integers(0, 256, (60, 80, 3), dtype=np.uint8))
+    np.testing.assert_array_equal(image.to_resized_image(resized_height=45).mat,
+                                  O.resize_cubic(image.mat, (45, 60)))
+    mask = Mask(mat=(rng.random((60, 80)) < 0.5).astype(np.uint8))
+    want = (O.resize_cubic(mask.mat * 255, (90, 100)) > 0).astype(np.uint8)
+    np.testing.assert_array_equal(mask.to_resized_mask(resized_height=90, resized_width=100).mat, want)
+    score = ScoreMap(mat=rng.random((60, 80), dtype=np.float32))
+    want = np.clip(O.resize_cubic(score.mat, (31, 99)), 0.0, 1.0)
+    np.testing.assert_array_equal(score.to_resized_score_map(resized_height=31, resized_width=99).mat, want)
+
+
+def test_resize_cubic_full_size_page(N):
+    src = default_rng(5).integers(0, 256, (2048, 2048, 3), dtype=np.uint8)
+    np.testing.assert_array_equal(N.resize_cubic(src, (2147, 2115)), O.resize_cubic(src, (2147, 2115)))
+
+
+# ------------------------------------------------------------------ ordered polygon paint (label rasterisation)
+def _paint_reference(shape, polygons, values):
+    mask = np.zeros(shape, np.uint8)
+    score = np.zeros(shape, np.float32)
+    h, w = shape
+    for pts, value in zip(polygons, values):
+        pts = np.asarray(pts, np.int32)
+        x0, y0 = int(pts[:, 0].min()), int(pts[:, 1].min())
+        x1, y1 = int(pts[:, 0].max()), int(pts[:, 1].max())
+        raster = O.fill_poly((y1 - y0 + 1, x1 - x0 + 1), pts - np.asarray([x0, y0], np.int32)).astype(bool)
+        ys, xs = np.nonzero(raster)
+        ys, xs = ys + y0, xs + x0
+        keep = (ys >= 0) & (ys < h) & (xs >= 0) & (xs < w)
+        mask[ys[keep], xs[keep]] = 1
+        score[ys[keep], xs[keep]] = np.float32(value)
+    return mask, score
+
+
+def test_paint_polys_overlaps_and_clipping(N):
+    rng = default_rng(21)
+    shape = (180, 260)
+    polygons, values = [], []
+    for _ in range(300):
+        cx, cy = int(rng.integers(-10, 270)), int(rng.integers(-10, 190))
+        n = int(rng.integers(3, 9))
+        ang = np.sort(rng.uniform(0, 2 * np.pi, n))
+        rad = rng.uniform(3, 40, n)
+        polygons.append(np.stack([cx + rad * np.cos(ang), cy + rad * np.sin(ang)], axis=1).round().astype(np.int32))
+        values.append(float(rng.uniform(1, 50)))
+    mask = np.zeros(shape, np.uint8)
+    score = np.zeros(shape, np.float32)
+    N.paint_polys(polygons, values=values, mask=mask, score=score)
+    want_mask, want_score = _paint_reference(shape, polygons, values)
+    np.testing.assert_array_equal(mask, want_mask)
+    np.testing.assert_array_equal(score, want_score)
+    # mask only, onto a plane that already has content: untouched outside the polygons
+    pre = (rng.random(shape) < 0.1).astype(np.uint8)
+    out = pre.copy()
+    N.paint_polys(polygons[:5], mask=out)
+    np.testing.assert_array_equal(out, pre | _paint_reference(shape, polygons[:5], [1] * 5)[0])
+    # nothing to paint is a no-op
+    N.paint_polys([], mask=out)
+
+
+def test_paint_polys_page_of_char_boxes(N):
+    """Thousands of small quadrilaterals (char boxes) on a 2048^2 page, heights painted large to small."""
+    rng = default_rng(22)
+    shape = (2048, 2048)
+    polygons, values = [], []
+    for row in range(60):
+        y = 20 + row * 33
+        x = 15
+        while x < 2000:
+            w, h = int(rng.integers(8, 30)), int(rng.integers(14, 30))
+            skew = int(rng.integers(-3, 4))
+            polygons.append(np.asarray([(x + skew, y), (x + w + skew, y + 1), (x + w, y + h), (x, y + h - 1)], np.int32))
+            values.append(float(h) + float(rng.random()))
+            x += w - int(rng.integers(0, 4))  # neighbours overlap a little
+    order = np.argsort(values)[::-1]
+    polygons = [polygons[i] for i in order]
+    values = [values[i] for i in order]
+    assert len(polygons) > 3000
+    mask = np.zeros(shape, np.uint8)
+    score = np.zeros(shape, np.float32)
+    N.paint_polys(polygons, values=values, mask=mask, score=score)
+    want_mask, want_score = _paint_reference(shape, polygons, values)
+    np.testing.assert_array_equal(mask, want_mask)
+    np.testing.assert_array_equal(score, want_score)
+
+
+# ------------------------------------------------------------------ pipeline steps
+def _synthetic_page_input(seed, size=256, n_lines=24):
+    """A C4-shaped page: gray background, one page image, text-line score-map layers, one symbol, one seal."""
+    from vkit_amd.element import Box, Image, Mask, Point, PointList, Polygon, ScoreMap
+    from vkit_amd.pipeline import text_detection as T
+    rng = default_rng(seed)
+    gray = int(rng.integers(127, 256))
+    background = Image(mat=np.full((size, size, 3), gray, np.uint8))
+    bottom = Image(mat=rng.integers(0, 256, (size, size, 3), dtype=np.uint8))
+    page_images = [T.PageImage(image=Image(mat=rng.integers(0, 256, (40, 60, 3), dtype=np.uint8)),
+                               box=Box(up=10, down=49, left=20, right=79), alpha=0.8)]
+    text_lines, polygons, ups, downs, sizes, char_polygons, char_ups, char_downs = [], [], [], [], [], [], [], []
+    lh, lw = size // 16, size // 2
+    for i in range(n_lines):
+        up = int(rng.integers(0, size - lh))
+        left = int(rng.integers(0, size - lw))
+        box = Box(up=up, down=up + lh - 1, left=left, right=left + lw - 1)
+        alpha = (rng.random((lh, lw), dtype=np.float32) * (rng.random((lh, lw)) < 0.3)).astype(np.float32)
+        if i % 5 == 4:  # a line without score map: mask + rendered image
+            text_lines.append(T.TextLine(image=Image(mat=rng.integers(0, 256, (lh, lw, 3), dtype=np.uint8), box=box),
+                                         mask=Mask(mat=(alpha > 0).astype(np.uint8), box=box), score_map=None,
+                                         glyph_color=(10, 20, 30)))
+        else:
+            text_lines.append(T.TextLine(image=Image(mat=np.zeros((lh, lw, 3), np.uint8), box=box),
+                                         mask=Mask(mat=(alpha > 0).astype(np.uint8), box=box),
+                                         score_map=ScoreMap(mat=alpha, box=box), glyph_color=(10, 20, 30)))
+        polygons.append(Polygon.from_xy_pairs([(left, up), (left + lw - 1, up), (left + lw - 1, up + lh - 1),
+                                               (left, up + lh - 1)]))
+        ups.extend([Point.create(y=up, x=left), Point.create(y=up, x=left + lw - 1)])
+        downs.extend([Point.create(y=up + lh - 1, x=left), Point.create(y=up + lh - 1, x=left + lw - 1)])
+        sizes.append(2)
+        for c in range(6):
+            cl = left + c * (lw // 6)
+            char_polygons.append(Polygon.from_xy_pairs([(cl, up), (cl + lw // 6 - 2, up), (cl + lw // 6 - 2, up + lh - 1),
+                                                        (cl, up + lh - 1)]))
+            char_ups.append(Point.create(y=up, x=cl + 3))
+            char_downs.append(Point.create(y=up + lh - 1 - (c % 3), x=cl + 3))
+    seal_mask = np.zeros((41, 41), np.uint8)
+    yy, xx = np.ogrid[:41, :41]
+    seal_mask[((yy - 20) ** 2 + (xx - 20) ** 2 <= 400) & ((yy - 20) ** 2 + (xx - 20) ** 2 >= 300)] = 1
+    seal_text = (rng.random((41, 41), dtype=np.float32) * (rng.random((41, 41)) < 0.2)).astype(np.float32)
+    seals = T.PageSealImpressionTextLineCollection(
+        height=size, width=size,
+        seal_impressions=[T.SealImpression(alpha=0.7, color=(200, 20, 30), background_mask=Mask(mat=seal_mask))],
+        seal_impression_resources=[T.SealImpressionResource(
+            box=Box(up=size // 2, down=size // 2 + 40, left=size // 2, right=size // 2 + 40), angle=25,
+            text_line_filled_score_map=ScoreMap(mat=seal_text),
+            char_polygons=[Polygon.from_xy_pairs([(5, 5), (15, 5), (15, 15), (5, 15)])])])
+    barcode = np.zeros((size, size), np.float32)
+    barcode[size - 40:size - 10, 10:70:2] = 1.0
+    bbox_alpha = np.zeros((size, size), np.float32)
+    bbox_alpha[5:8, 5:size - 5] = 0.5
+    return T.PageAssemblerStepInput(
+        page_layout_step_output=T.PageLayoutStepOutput(T.PageLayout(
+            height=size, width=size,
+            disconnected_text_regions=[T.DisconnectedTextRegion(polygons[0])],
+            non_text_regions=[T.NonTextRegion(Polygon.from_xy_pairs([(3, 3), (30, 4), (28, 28), (4, 30)]))])),
+        page_background_step_output=T.PageBackgroundStepOutput(background),
+        page_image_step_output=T.PageImageStepOutput(
+            page_image_collection=T.PageImageCollection(height=size, width=size, page_images=page_images),
+            page_bottom_layer_image=bottom),
+        page_barcode_step_output=T.PageBarcodeStepOutput(height=size, width=size,
+                                                         barcode_qr_score_maps=[ScoreMap(mat=barcode)]),
+        page_text_line_step_output=T.PageTextLineStepOutput(
+            page_text_line_collection=T.PageTextLineCollection(height=size, width=size, text_lines=text_lines),
+            page_seal_impression_text_line_collection=seals),
+        page_non_text_symbol_step_output=T.PageNonTextSymbolStepOutput(
+            images=[Image(mat=rng.integers(0, 256, (12, 12, 3), dtype=np.uint8))],
+            boxes=[Box(up=100, down=111, left=7, right=18)],
+            alphas=[(rng.random((12, 12), dtype=np.float32)).astype(np.float32)]),
+        page_text_line_bounding_box_step_output=T.PageTextLineBoundingBoxStepOutput(
+            score_maps=[ScoreMap(mat=bbox_alpha)], colors=[(255, 0, 0)]),
+        page_text_line_label_step_output=T.PageTextLineLabelStepOutput(
+            page_char_polygon_collection=T.PageCharPolygonCollection(
+                height=size, width=size, char_polygons=char_polygons, adjusted_char_polygons=char_polygons,
+                height_points_up=PointList(char_ups), height_points_down=PointList(char_downs)),
+            page_text_line_polygon_collection=T.PageTextLinePolygonCollection(
+                height=size, width=size, polygons=polygons, height_points_group_sizes=sizes,
+                height_points_up=PointList(ups), height_points_down=PointList(downs))),
+    )
+
+
+def test_page_assembler_layer_order(N):
+    from vkit_amd.mechanism.distortion import rotate
+    from vkit_amd.pipeline import text_detection as T
+    step_input = _synthetic_page_input(seed=7)
+    page = T.page_assembler_step_factory.create().run(step_input, default_rng(0)).page
+
+    # the same layer list applied one by one with the oracle, in the reference's order
+    want = step_input.page_background_step_output.background_image.mat.copy()
+    full = (0, 0) + want.shape[:2]
+    for page_image in step_input.page_image_step_output.page_image_collection.page_images:
+        b = page_image.box
+        O.fill(want, (b.up, b.left, b.height, b.width), page_image.image.mat, alpha=page_image.alpha)
+    for score_map in step_input.page_barcode_step_output.barcode_qr_score_maps:
+        O.fill(want, full, (0, 0, 0), alpha=score_map.mat)
+    out = step_input.page_text_line_bounding_box_step_output
+    for score_map, color in zip(out.score_maps, out.colors):
+        O.fill(want, full, color, alpha=score_map.mat)
+    for text_line in step_input.page_text_line_step_output.page_text_line_collection.text_lines:
+        b = text_line.box
+        geo = (b.up, b.left, b.height, b.width)
+        if text_line.score_map:
+            O.fill(want, geo, text_line.glyph_color, alpha=text_line.score_map.mat)
+        else:
+            O.fill(want, geo, text_line.image.mat, mask=text_line.mask.mat)
+    symbols = step_input.page_non_text_symbol_step_output
+    for image, b, alpha in zip(symbols.images, symbols.boxes, symbols.alphas):
+        O.fill(want, (b.up, b.left, b.height, b.width), image.mat, alpha=alpha)
+    seals = step_input.page_text_line_step_output.page_seal_impression_text_line_collection
+    for seal, resource in zip(seals.seal_impressions, seals.seal_impression_resources):
+        rotated = rotate.distort({'angle': resource.angle}, mask=seal.background_mask,
+                                 score_map=resource.text_line_filled_score_map)
+        center = resource.box.get_center_point()
+        up = center.y - rotated.mask.height // 2
+        left = center.x - rotated.mask.width // 2
+        geo = (up, left, rotated.mask.height, rotated.mask.width)
+        O.fill(want, geo, seal.color, mask=rotated.mask.mat, alpha=seal.alpha)
+        O.fill(want, geo, seal.color, alpha=rotated.score_map.mat)
+    np.testing.assert_array_equal(page.image.mat, want)
+    assert len(page.page_seal_impression_char_polygon_collection.char_polygons) == 1
+    assert not page.image.mat.flags.writeable
+    assert (page.image.mat != step_input.page_background_step_output.background_image.mat).any()
+
+
+def test_page_distortion_step(N):
+    from vkit_amd.mechanism.distortion_policy import UNSUPPORTED_POLICY_NAMES, random_distortion_factory
+    from vkit_amd.element import Mask, PointList
+    from vkit_amd.pipeline import text_detection as T
+    step_input = _synthetic_page_input(seed=9)
+    page_output = T.page_assembler_step_factory.create().run(step_input, default_rng(0))
+    factory_config = {'disabled_policy_names': list(UNSUPPORTED_POLICY_NAMES), 'prob_geometric': 1.0}
+    step = T.page_distortion_step_factory.create({'random_distortion_factory_config': factory_config})
+    shapes = set()
+    for seed in range(4):
+        out = step.run(T.PageDistortionStepInput(page_output), default_rng(seed))
+        shapes.add(out.page_image.shape)
+
+        # the same chain, driven directly
+        page = page_output.page
+        active = np.ones(page.image.shape, np.uint8)
+        active[0] = active[-1] = 0
+        active[:, 0] = active[:, -1] = 0
+        chars = page.page_char_polygon_collection
+        lines = page.page_text_line_polygon_collection
+        flat_polygons = (tuple(chars.char_polygons) + tuple(chars.adjusted_char_polygons) + tuple(lines.polygons)
+                         + tuple(page.page_disconnected_text_region_collection.to_polygons())
+                         + tuple(page.page_non_text_region_collection.to_polygons())
+                         + tuple(page.page_seal_impression_char_polygon_collection.char_polygons))
+        flat_points = PointList(tuple(chars.height_points_up) + tuple(chars.height_points_down)
+                                + tuple(lines.height_points_up) + tuple(lines.height_points_down))
+        result = random_distortion_factory.create(factory_config).distort(
+            image=page.image, mask=Mask(mat=active), polygons=flat_polygons, points=flat_points,
+            rng=default_rng(seed))
+        np.testing.assert_array_equal(out.page_active_mask.mat, result.mask.mat)
+        want = result.image.mat.copy()
+        bottom = page.page_bottom_layer_image.mat
+        if bottom.shape != want.shape:
+            bottom = O.resize_cubic(bottom, want.shape[:2])
+        O.fill(want, (0, 0) + want.shape[:2], bottom, mask=(result.mask.mat == 0).astype(np.uint8))
+        np.testing.assert_array_equal(out.page_image.mat, want)
+
+        # labels: sequential fills, polygon by polygon, with the oracle raster
+        n_chars, n_lines = len(chars.char_polygons), len(lines.polygons)
+        res_polys = result.polygons
+        char_polys = res_polys[:n_chars]
+        line_polys = res_polys[2 * n_chars:2 * n_chars + n_lines]
+        res_points = result.points
+        n_cp = len(chars.height_points_up)
+        n_lp = len(lines.height_points_up)
+        cu = PointList(res_points[:n_cp]).to_smooth_np_array()
+        cd = PointList(res_points[n_cp:2 * n_cp]).to_smooth_np_array()
+        lu = PointList(res_points[2 * n_cp:2 * n_cp + n_lp]).to_smooth_np_array()
+        ld = PointList(res_points[2 * n_cp + n_lp:]).to_smooth_np_array()
+        char_h = np.linalg.norm(cd - cu, axis=1) + 1
+        line_h_pts = np.linalg.norm(ld - lu, axis=1) + 1
+        line_h, begin = [], 0
+        for g in lines.height_points_group_sizes:
+            line_h.append(float(line_h_pts[begin:begin + g].mean()))
+            begin += g
+
+        def pts_of(polygon):
+            b = polygon.bounding_box
+            return polygon.self_relative_polygon.to_np_array() + np.asarray([b.left, b.up], np.int32)
+
+        shape = want.shape[:2]
+        m, s = _paint_reference(shape, [pts_of(p) for p in line_polys], line_h)
+        np.testing.assert_array_equal(out.page_text_line_mask.mat, m)
+        np.testing.assert_array_equal(out.page_text_line_height_score_map.mat, s)
+        assert out.page_text_line_heights == line_h
+        order = tuple(reversed(char_h.argsort()))
+        m, s = _paint_reference(shape, [pts_of(char_polys[i]) for i in order], [float(char_h[i]) for i in order])
+        np.testing.assert_array_equal(out.page_char_mask.mat, m)
+        np.testing.assert_array_equal(out.page_char_height_score_map.mat, s)
+        assert out.page_char_heights == [float(v) for v in char_h]
+        assert out.page_seal_impression_char_mask.mat.sum() > 0
+    assert len(shapes) > 1  # geometric distortions did change the page shape, so the resize branch ran

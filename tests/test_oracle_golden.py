@@ -59,6 +59,23 @@ def test_fill_box_layers(G):
     assert (page == G['fill_box_alpha_out']).all()
 
 
+def test_fill_modes_float32_and_keep(golden_dir):
+    """fill_np_array on float32 score maps and with keep_max / keep_min (reference outputs, numpy-only: pinned)."""
+    F = np.load(os.path.join(golden_dir, 'fill_modes.npz'))
+    sm0, m, val = F['f32_in'], F['f32_mask'], F['f32_value']
+    full = (0, 0) + sm0.shape
+    for tag, mode in (('plain', O.FILL_PLAIN), ('max', O.FILL_KEEP_MAX), ('min', O.FILL_KEEP_MIN)):
+        assert (O.fill(sm0.copy(), full, 12.5, mask=m, mode=mode) == F[f'f32_mask_const_{tag}']).all(), tag
+        assert (O.fill(sm0.copy(), full, val, mask=m, mode=mode) == F[f'f32_mask_plane_{tag}']).all(), tag
+        assert (O.fill(sm0.copy(), tuple(F['f32_box']), 7.25, mode=mode) == F[f'f32_box_const_{tag}']).all(), tag
+    mk0, mv = F['u8_in'], F['u8_value']
+    for tag, mode in (('max', O.FILL_KEEP_MAX), ('min', O.FILL_KEEP_MIN)):
+        assert (O.fill(mk0.copy(), full, 2, mask=m, mode=mode) == F[f'u8_mask_const_{tag}']).all(), tag
+        assert (O.fill(mk0.copy(), full, mv, mask=m, mode=mode) == F[f'u8_mask_plane_{tag}']).all(), tag
+    assert (O.fill(sm0.copy(), full, val, alpha=F['f32_alpha']) == F['f32_alpha_plane']).all()
+    assert (O.fill(sm0.copy(), full, 3.0, alpha=0.3) == F['f32_alpha_scalar']).all()
+
+
 def test_fill_rejects_bad_alpha():
     page = np.zeros((4, 4, 3), np.uint8)
     with pytest.raises(RuntimeError):

@@ -75,7 +75,29 @@ class VkxLayer(ctypes.Structure):
         ('value', c_void_p),
         ('value_stride', c_ssize),
         ('value_const', ctypes.c_uint8 * 4),
+        ('mode', ctypes.c_int32),
     ]
+
+
+class VkxLayerF32(ctypes.Structure):
+    _fields_ = [
+        ('up', ctypes.c_int32),
+        ('left', ctypes.c_int32),
+        ('height', ctypes.c_int32),
+        ('width', ctypes.c_int32),
+        ('mask', c_void_p),
+        ('mask_stride', c_ssize),
+        ('alpha', c_void_p),
+        ('alpha_stride_el', c_ssize),
+        ('alpha_scalar', c_double),
+        ('value', c_void_p),
+        ('value_stride_el', c_ssize),
+        ('value_const', ctypes.c_float),
+        ('mode', ctypes.c_int32),
+    ]
+
+
+FILL_PLAIN, FILL_KEEP_MAX, FILL_KEEP_MIN = 0, 1, 2
 
 
 # name -> argtypes; every function returns int unless noted.
@@ -119,6 +141,11 @@ for _sfx in ('', '_dev'):
     _SIGNATURES['vkx_line_streak_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_int, c_int, c_int, c_int, c_void_p, c_double,
                                                                          c_int, c_int]
     _SIGNATURES['vkx_fill_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [ctypes.POINTER(VkxLayer), c_int]
+    _SIGNATURES['vkx_fill_f32' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, ctypes.POINTER(VkxLayerF32), c_int]
+    _SIGNATURES['vkx_resize_cubic_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_int, c_int, c_ssize]
+    _SIGNATURES['vkx_resize_cubic_f32' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_void_p, c_int, c_int, c_ssize]
+    _SIGNATURES['vkx_paint_polys' + _sfx] = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_ssize, c_void_p,
+                                             c_ssize, c_int, c_int]
     _SIGNATURES['vkx_fill_poly_mask_u8' + _sfx] = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_ssize]
 
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['vkx_version', 'vkx_last_error', 'vkx_ctx_stream'])
@@ -489,12 +516,62 @@ def fill_poly_mask(shape, pts, ctx=None):
     return mask
 
 
-def make_layer(box, cn, value, mask=None, alpha=1.0):
-    """One composite layer.  box = (up, left, height, width).  Returns (VkxLayer, keepalive list)."""
+def resize_cubic(src, dsize_hw, ctx=None):
+    """cv.resize(src, (dw, dh), interpolation=cv.INTER_CUBIC) for uint8 HxW[xC] or float32 HxW arrays."""
+    ctx = ctx or default_ctx()
+    dh, dw = int(dsize_hw[0]), int(dsize_hw[1])
+    if src.dtype == np.float32:
+        if src.ndim != 2:
+            raise ValueError('float32 resize takes a 2-D array')
+        src = np.ascontiguousarray(src)
+        sh, sw = src.shape
+        dst = np.empty((dh, dw), np.float32)
+        check(lib().vkx_resize_cubic_f32(ctx.handle, _ptr(src), sh, sw, sw, _ptr(dst), dh, dw, dw))
+        return dst
+    src, sh, sw, cn, stride = _u8_plane(src)
+    dst = np.empty((dh, dw) + src.shape[2:], np.uint8)
+    check(lib().vkx_resize_cubic_u8(ctx.handle, _ptr(src), sh, sw, cn, stride, _ptr(dst), dh, dw, dw * cn))
+    return dst
+
+
+def paint_polys(polygons, values=None, mask=None, score=None, ctx=None):
+    """Ordered paint of ``polygons`` (sequence of int (N_i, 2) arrays of (x, y) in plane coordinates) into the
+    writable uint8 ``mask`` and / or float32 ``score`` planes, in place: later polygons win on overlaps."""
+    ctx = ctx or default_ctx()
+    plane = mask if mask is not None else score
+    if plane is None:
+        raise ValueError('mask or score is required')
+    h, w = plane.shape
+    for arr, dt in ((mask, np.uint8), (score, np.float32)):
+        if arr is not None and (arr.dtype != dt or arr.shape != (h, w) or not arr.flags.c_contiguous
+                                or not arr.flags.writeable):
+            raise ValueError(f'planes must be writable C-contiguous {(h, w)} arrays (uint8 mask, float32 score)')
+    pts = [np.asarray(p, dtype=np.int32).reshape(-1, 2) for p in polygons]
+    offsets = np.zeros(len(pts) + 1, np.int32)
+    if pts:
+        offsets[1:] = np.cumsum([len(p) for p in pts])
+    flat = np.ascontiguousarray(np.concatenate(pts, axis=0)) if pts else np.zeros((0, 2), np.int32)
+    vals = None
+    if score is not None:
+        vals = np.ascontiguousarray(np.asarray(values, dtype=np.float32))
+        if vals.shape != (len(pts),):
+            raise ValueError('one value per polygon is required with a score plane')
+    check(lib().vkx_paint_polys(ctx.handle, _ptr(flat), _ptr(offsets), len(pts), _ptr(vals) if vals is not None else None,
+                                _ptr(mask) if mask is not None else None, w,
+                                _ptr(score) if score is not None else None, w, h, w))
+
+
+def make_layer(box, cn, value, mask=None, alpha=1.0, mode=FILL_PLAIN, dtype=np.uint8):
+    """One composite layer for a uint8 (cn channels) or float32 (cn == 1) destination.
+    box = (up, left, height, width).  Returns (VkxLayer | VkxLayerF32, keepalive list)."""
     up, left, bh, bw = (int(v) for v in box)
+    is_f32 = np.dtype(dtype) == np.float32
+    if is_f32 and cn != 1:
+        raise ValueError('float32 destinations are single channel')
     keep = []
-    layer = VkxLayer()
+    layer = VkxLayerF32() if is_f32 else VkxLayer()
     layer.up, layer.left, layer.height, layer.width = up, left, bh, bw
+    layer.mode = int(mode)
     if mask is not None:
         mask = np.ascontiguousarray(mask, dtype=np.uint8)
         if mask.shape != (bh, bw):
@@ -511,12 +588,17 @@ def make_layer(box, cn, value, mask=None, alpha=1.0):
     else:
         layer.alpha_scalar = float(alpha)
     if isinstance(value, np.ndarray):
-        value = np.ascontiguousarray(value.astype(np.uint8, copy=False))
+        value = np.ascontiguousarray(value.astype(dtype, copy=False))
         want = (bh, bw) if cn == 1 and value.ndim == 2 else (bh, bw, cn)
         if value.shape != want:
             raise RuntimeError('value is np.ndarray but shape is not matched.')
         keep.append(value)
-        layer.value, layer.value_stride = value.ctypes.data, bw * cn
+        if is_f32:
+            layer.value, layer.value_stride_el = value.ctypes.data, bw
+        else:
+            layer.value, layer.value_stride = value.ctypes.data, bw * cn
+    elif is_f32:
+        layer.value_const = float(np.float32(value))
     else:
         if isinstance(value, tuple):
             if len(value) != cn:
@@ -530,14 +612,23 @@ def make_layer(box, cn, value, mask=None, alpha=1.0):
 
 
 def fill(dst, layers, ctx=None):
-    """Applies ``layers`` (list of (VkxLayer, keepalive)) to the writable uint8 array ``dst`` in place."""
+    """Applies ``layers`` (list of (layer, keepalive) from make_layer with dst's dtype) to the writable uint8 or
+    float32 array ``dst`` in place."""
     ctx = ctx or default_ctx()
-    if dst.dtype != np.uint8 or not dst.flags.c_contiguous or not dst.flags.writeable:
-        raise ValueError('dst must be a writable C-contiguous uint8 array')
+    if dst.dtype not in (np.uint8, np.float32) or not dst.flags.c_contiguous or not dst.flags.writeable:
+        raise ValueError('dst must be a writable C-contiguous uint8 or float32 array')
     h, w = dst.shape[:2]
     cn = 1 if dst.ndim == 2 else dst.shape[2]
-    arr = (VkxLayer * max(len(layers), 1))()
+    cls = VkxLayerF32 if dst.dtype == np.float32 else VkxLayer
+    arr = (cls * max(len(layers), 1))()
     for i, (layer, _keep) in enumerate(layers):
+        if not isinstance(layer, cls):
+            raise TypeError('layer built for another destination dtype')
         arr[i] = layer
-    check(lib().vkx_fill_u8(ctx.handle, _ptr(dst), h, w, cn, w * cn, arr, len(layers)))
+    if dst.dtype == np.float32:
+        if cn != 1:
+            raise ValueError('float32 destinations are single channel')
+        check(lib().vkx_fill_f32(ctx.handle, _ptr(dst), h, w, w, arr, len(layers)))
+    else:
+        check(lib().vkx_fill_u8(ctx.handle, _ptr(dst), h, w, cn, w * cn, arr, len(layers)))
     return dst

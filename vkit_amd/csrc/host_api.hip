@@ -300,3 +300,60 @@ VKX_EXPORT int vkx_fill_u8(vkx_ctx *ctx, uint8_t *dst, int h, int w, int cn, ptr
     VKX_TRY(vkx_fill_u8_dev(ctx, st.dev<uint8_t>(d), h, w, cn, (ptrdiff_t)w * cn, dl.data(), n_layers));
     return st.finish();
 }
+
+VKX_EXPORT int vkx_fill_f32(vkx_ctx *ctx, float *dst, int h, int w, ptrdiff_t dst_stride_el,
+                            const vkx_layer_f32 *layers, int n_layers)
+{
+    VKX_REQUIRE(ctx && dst, "NULL argument");
+    VKX_REQUIRE(h >= 0 && w >= 0, "bad shape");
+    VKX_REQUIRE(n_layers >= 0 && (n_layers == 0 || layers), "bad layer list");
+    HostStage st(ctx);
+    const int d = st.add(dst, dst, (size_t)w * 4, h, dst_stride_el * 4);
+    std::vector<int> mid(n_layers, -1), aid(n_layers, -1), vid(n_layers, -1);
+    for (int i = 0; i < n_layers; i++) {
+        const vkx_layer_f32 &l = layers[i];
+        VKX_REQUIRE(l.height >= 0 && l.width >= 0, "bad layer box");
+        if (l.mask) mid[i] = st.add(l.mask, nullptr, (size_t)l.width, l.height, l.mask_stride);
+        if (l.alpha) aid[i] = st.add(l.alpha, nullptr, (size_t)l.width * 4, l.height, l.alpha_stride_el * 4);
+        if (l.value) vid[i] = st.add(l.value, nullptr, (size_t)l.width * 4, l.height, l.value_stride_el * 4);
+    }
+    VKX_TRY(st.commit());
+    std::vector<vkx_layer_f32> dl(layers, layers + n_layers);
+    for (int i = 0; i < n_layers; i++) {
+        dl[i].mask = st.dev<uint8_t>(mid[i]);
+        dl[i].mask_stride = layers[i].width;
+        dl[i].alpha = st.dev<float>(aid[i]);
+        dl[i].alpha_stride_el = layers[i].width;
+        dl[i].value = st.dev<float>(vid[i]);
+        dl[i].value_stride_el = layers[i].width;
+    }
+    VKX_TRY(vkx_fill_f32_dev(ctx, st.dev<float>(d), h, w, w, dl.data(), n_layers));
+    return st.finish();
+}
+
+VKX_EXPORT int vkx_resize_cubic_u8(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t src_stride,
+                                   uint8_t *dst, int dh, int dw, ptrdiff_t dst_stride)
+{
+    VKX_REQUIRE(ctx && src && dst, "NULL argument");
+    VKX_REQUIRE(sh > 0 && sw > 0 && dh > 0 && dw > 0 && cn > 0, "bad shape");
+    HostStage st(ctx);
+    const int s = st.add(src, nullptr, (size_t)sw * cn, sh, src_stride);
+    const int d = st.add(nullptr, dst, (size_t)dw * cn, dh, dst_stride);
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_resize_cubic_u8_dev(ctx, st.dev<uint8_t>(s), sh, sw, cn, (ptrdiff_t)sw * cn, st.dev<uint8_t>(d), dh, dw,
+                                    (ptrdiff_t)dw * cn));
+    return st.finish();
+}
+
+VKX_EXPORT int vkx_resize_cubic_f32(vkx_ctx *ctx, const float *src, int sh, int sw, ptrdiff_t src_stride_el, float *dst,
+                                    int dh, int dw, ptrdiff_t dst_stride_el)
+{
+    VKX_REQUIRE(ctx && src && dst, "NULL argument");
+    VKX_REQUIRE(sh > 0 && sw > 0 && dh > 0 && dw > 0, "bad shape");
+    HostStage st(ctx);
+    const int s = st.add(src, nullptr, (size_t)sw * 4, sh, src_stride_el * 4);
+    const int d = st.add(nullptr, dst, (size_t)dw * 4, dh, dst_stride_el * 4);
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_resize_cubic_f32_dev(ctx, st.dev<float>(s), sh, sw, sw, st.dev<float>(d), dh, dw, dw));
+    return st.finish();
+}

@@ -21,6 +21,7 @@ struct PolyEdge {
     int sy, ymajor;
     int step_base;             // prefix of (dmaj + 1) over the edges
     int y0, y1;                // scanline range of the edge (y0 == y1: horizontal, not in the edge table)
+    int poly, pad;             // batched paint: 1-based paint order of the polygon this edge belongs to
     long long x0_fix, dx_fix;  // 16.16 x at y0, dx per scanline
 };
 
@@ -85,7 +86,222 @@ __global__ void __launch_bounds__(256) k_poly_spans(const PolyEdge *__restrict__
     }
 }
 
+// Edge table of one closed contour (cv::fillPoly -> CollectPolyEdges + the LINE_8 outline).
+void build_edges(const int32_t *pts, int npts, int poly, PolyEdge *edges, long long *steps, int *ymin, int *ymax)
+{
+    for (int i = 0; i < npts; i++) {
+        const int a = (i + npts - 1) % npts;
+        PolyEdge &e = edges[i];
+        e.xa = pts[2 * a]; e.ya = pts[2 * a + 1];
+        e.xb = pts[2 * i]; e.yb = pts[2 * i + 1];
+        int lx = e.xa, ly = e.ya, rx = e.xb, ry = e.yb;
+        if (rx < lx) { std::swap(lx, rx); std::swap(ly, ry); }
+        const int dx = rx - lx, dy = ry - ly, ady = dy < 0 ? -dy : dy;
+        e.lx = lx; e.ly = ly; e.sy = dy < 0 ? -1 : 1;
+        e.ymajor = ady > dx;
+        e.dmaj = e.ymajor ? ady : dx;
+        e.dmin = e.ymajor ? dx : ady;
+        e.step_base = (int)*steps;
+        *steps += e.dmaj + 1;
+        e.y0 = std::min(e.ya, e.yb); e.y1 = std::max(e.ya, e.yb);
+        e.poly = poly; e.pad = 0;
+        if (e.ya != e.yb) {
+            const long long xa = (long long)e.xa << 16, xb = (long long)e.xb << 16;
+            e.dx_fix = (xb - xa) / (long long)(e.yb - e.ya);
+            e.x0_fix = e.ya < e.yb ? xa : xb;
+            *ymin = std::min(*ymin, e.y0); *ymax = std::max(*ymax, e.y1);
+        } else {
+            e.dx_fix = 0; e.x0_fix = 0;
+        }
+    }
+}
+
+// ---- batched ordered paint: many polygons, later ones win ------------------------------------------------------
+struct PaintItem { // one (polygon, scanline) pair
+    int edge_begin, edge_end; // the polygon's edges
+    int y, order;             // scanline, 1-based paint order
+};
+
+__global__ void __launch_bounds__(256) k_paint_outline(const PolyEdge *__restrict__ edges, int nedges, int total_steps,
+                                                       int *__restrict__ owner, int h, int w)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= total_steps) return;
+    int lo = 0, hi = nedges - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (edges[mid].step_base <= t) lo = mid; else hi = mid - 1;
+    }
+    const PolyEdge e = edges[lo];
+    const int k = t - e.step_base;
+    const int m = vkc::bres_minor(k, e.dmaj, e.dmin);
+    const int x = e.ymajor ? e.lx + m : e.lx + k;
+    const int y = e.ymajor ? e.ly + e.sy * k : e.ly + e.sy * m;
+    if ((unsigned)x < (unsigned)w && (unsigned)y < (unsigned)h) atomicMax(&owner[(size_t)y * w + x], e.poly);
+}
+
+constexpr int kPaintCross = 64; // crossings of one polygon on one scanline handled by the batched path
+
+// One wave per (polygon, scanline): lanes test the polygon's edges, crossings are ranked by counting (no sort
+// loop: rank = number of crossings that precede it, ties by edge index), spans are painted lane-parallel.
+__global__ void __launch_bounds__(256) k_paint_spans(const PolyEdge *__restrict__ edges,
+                                                     const PaintItem *__restrict__ items, int n_items,
+                                                     int *__restrict__ owner, int h, int w, int *__restrict__ overflow)
+{
+    __shared__ long long xs_all[4][kPaintCross];
+    __shared__ long long sorted_all[4][kPaintCross];
+    __shared__ int count_all[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int it = blockIdx.x * 4 + wave;
+    long long *xs = xs_all[wave], *sorted = sorted_all[wave];
+    if (lane == 0) count_all[wave] = 0;
+    __syncthreads();
+    const bool live = it < n_items;
+    PaintItem item = {0, 0, 0, 0};
+    if (live) item = items[it];
+    for (int i = item.edge_begin + lane; i < item.edge_end; i += 64) {
+        const PolyEdge &e = edges[i];
+        if (e.y0 != e.y1 && e.y0 <= item.y && item.y < e.y1) {
+            const int slot = atomicAdd(&count_all[wave], 1);
+            // tie-break on the edge index keeps the ranking a permutation
+            if (slot < kPaintCross) xs[slot] = e.x0_fix + (long long)(item.y - e.y0) * e.dx_fix;
+        }
+    }
+    __syncthreads();
+    int n = count_all[wave];
+    if (n > kPaintCross) {
+        if (lane == 0) atomicExch(overflow, 1);
+        n = 0;
+    }
+    if (lane < n) {
+        const long long v = xs[lane];
+        int rank = 0;
+        for (int j = 0; j < n; j++) {
+            const long long u = xs[j];
+            rank += (u < v) || (u == v && j < lane);
+        }
+        sorted[rank] = v;
+    }
+    __syncthreads();
+    if (!live || (unsigned)item.y >= (unsigned)h) return;
+    int *row = owner + (size_t)item.y * w;
+    for (int a = 0; a + 1 < n; a += 2) {
+        long long x1 = (sorted[a] + 65535) >> 16, x2 = sorted[a + 1] >> 16;
+        if (x1 < 0) x1 = 0;
+        if (x2 >= w) x2 = w - 1;
+        for (long long x = x1 + lane; x <= x2; x += 64) atomicMax(&row[x], item.order);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_paint_resolve(const int *__restrict__ owner, const float *__restrict__ values,
+                                                       uint8_t *__restrict__ mask, ptrdiff_t mask_stride,
+                                                       float *__restrict__ score, ptrdiff_t score_stride, int h, int w)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const int o = owner[(size_t)y * w + x];
+    if (o <= 0) return;
+    if (mask) mask[(ptrdiff_t)y * mask_stride + x] = 1;
+    if (score) score[(ptrdiff_t)y * score_stride + x] = values[o - 1];
+}
+
 } // namespace
+
+VKX_EXPORT int vkx_paint_polys_dev(vkx_ctx *ctx, const int32_t *pts_host, const int32_t *poly_offsets_host, int n_polys,
+                                   const float *values_host, uint8_t *mask, ptrdiff_t mask_stride, float *score,
+                                   ptrdiff_t score_stride_el, int h, int w)
+{
+    VKX_REQUIRE(ctx && (n_polys == 0 || (pts_host && poly_offsets_host)), "NULL argument");
+    VKX_REQUIRE(n_polys >= 0 && h > 0 && w > 0, "bad shape");
+    VKX_REQUIRE(mask || score, "no output plane");
+    VKX_REQUIRE(!score || values_host, "score output needs per-polygon values");
+    if (n_polys == 0) return VKX_OK;
+    const int total_pts = poly_offsets_host[n_polys];
+    VKX_REQUIRE(total_pts >= 0, "bad polygon offsets");
+    std::vector<PolyEdge> edges((size_t)total_pts);
+    std::vector<PaintItem> items;
+    long long steps = 0;
+    for (int p = 0; p < n_polys; p++) {
+        const int b = poly_offsets_host[p], e = poly_offsets_host[p + 1];
+        VKX_REQUIRE(b <= e && e <= total_pts, "bad polygon offsets");
+        if (b == e) continue;
+        int ymin = INT_MAX, ymax = INT_MIN;
+        build_edges(pts_host + 2 * (size_t)b, e - b, p + 1, edges.data() + b, &steps, &ymin, &ymax);
+        VKX_REQUIRE(steps < 0x7fffffff, "polygon outlines too long");
+        for (int y = std::max(ymin, 0); y < std::min(ymax, h); y++) items.push_back(PaintItem{b, e, y, p + 1});
+    }
+    const size_t ebytes = (sizeof(PolyEdge) * edges.size() + 255) & ~(size_t)255;
+    const size_t ibytes = (sizeof(PaintItem) * items.size() + 255) & ~(size_t)255;
+    const size_t vbytes = ((size_t)n_polys * 4 + 255) & ~(size_t)255;
+    int rc = vkx_scratch_reserve(ctx, &ctx->misc, 256 + ebytes + ibytes + vbytes);
+    if (rc) return rc;
+    rc = vkx_scratch_reserve(ctx, &ctx->owner, (size_t)h * w * 4);
+    if (rc) return rc;
+    unsigned char *misc = (unsigned char *)ctx->misc.ptr;
+    int *overflow = (int *)misc;
+    PolyEdge *d_edges = (PolyEdge *)(misc + 256);
+    PaintItem *d_items = (PaintItem *)(misc + 256 + ebytes);
+    float *d_values = (float *)(misc + 256 + ebytes + ibytes);
+    int *owner = (int *)ctx->owner.ptr;
+    VKX_HIP(hipMemsetAsync(overflow, 0, sizeof(int), ctx->stream));
+    VKX_HIP(hipMemsetAsync(owner, 0, (size_t)h * w * 4, ctx->stream));
+    if (!edges.empty())
+        VKX_HIP(hipMemcpyAsync(d_edges, edges.data(), sizeof(PolyEdge) * edges.size(), hipMemcpyHostToDevice, ctx->stream));
+    if (!items.empty())
+        VKX_HIP(hipMemcpyAsync(d_items, items.data(), sizeof(PaintItem) * items.size(), hipMemcpyHostToDevice, ctx->stream));
+    if (values_host)
+        VKX_HIP(hipMemcpyAsync(d_values, values_host, (size_t)n_polys * 4, hipMemcpyHostToDevice, ctx->stream));
+    VKX_HIP(hipStreamSynchronize(ctx->stream)); // host vectors live on this frame
+    if (steps > 0) {
+        { VKX_TIMED(ctx, "k_paint_outline"); k_paint_outline<<<vkx_blocks((size_t)steps, 256), 256, 0, ctx->stream>>>(d_edges, total_pts, (int)steps, owner, h, w); }
+        VKX_LAUNCH_CHECK();
+    }
+    if (!items.empty()) {
+        { VKX_TIMED(ctx, "k_paint_spans"); k_paint_spans<<<vkx_blocks(items.size(), 4), 256, 0, ctx->stream>>>(d_edges, d_items, (int)items.size(), owner, h, w, overflow); }
+        VKX_LAUNCH_CHECK();
+    }
+    {
+        dim3 grid(vkx_blocks(w, 64), vkx_blocks(h, 4));
+        { VKX_TIMED(ctx, "k_paint_resolve"); k_paint_resolve<<<grid, 256, 0, ctx->stream>>>(owner, values_host ? d_values : nullptr, mask, mask_stride, score, score_stride_el, h, w); }
+        VKX_LAUNCH_CHECK();
+    }
+    int flag = 0;
+    VKX_HIP(hipMemcpyAsync(&flag, overflow, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    VKX_HIP(hipStreamSynchronize(ctx->stream));
+    if (flag) {
+        vkx_set_error("a polygon has more than %d edge crossings on one scanline", kPaintCross);
+        return VKX_ERR_UNSUPPORTED;
+    }
+    return VKX_OK;
+}
+
+// Host planes: mask / score are updated in place (read, painted, written back).
+VKX_EXPORT int vkx_paint_polys(vkx_ctx *ctx, const int32_t *pts_host, const int32_t *poly_offsets_host, int n_polys,
+                               const float *values_host, uint8_t *mask, ptrdiff_t mask_stride, float *score,
+                               ptrdiff_t score_stride_el, int h, int w)
+{
+    VKX_REQUIRE(ctx && (mask || score), "NULL argument");
+    VKX_REQUIRE(h > 0 && w > 0, "bad shape");
+    const size_t mbytes = mask ? (((size_t)h * w + 255) & ~(size_t)255) : 0;
+    const size_t sbytes = score ? (size_t)h * w * 4 : 0;
+    int rc = vkx_scratch_reserve(ctx, &ctx->stage[1], mbytes + sbytes);
+    if (rc) return rc;
+    uint8_t *d_mask = mask ? (uint8_t *)ctx->stage[1].ptr : nullptr;
+    float *d_score = score ? (float *)((unsigned char *)ctx->stage[1].ptr + mbytes) : nullptr;
+    if (mask)
+        VKX_HIP(hipMemcpy2DAsync(d_mask, (size_t)w, mask, (size_t)mask_stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, ctx->stream));
+    if (score)
+        VKX_HIP(hipMemcpy2DAsync(d_score, (size_t)w * 4, score, (size_t)score_stride_el * 4, (size_t)w * 4, (size_t)h, hipMemcpyHostToDevice, ctx->stream));
+    rc = vkx_paint_polys_dev(ctx, pts_host, poly_offsets_host, n_polys, values_host, d_mask, w, d_score, w, h, w);
+    if (rc) return rc;
+    if (mask)
+        VKX_HIP(hipMemcpy2DAsync(mask, (size_t)mask_stride, d_mask, (size_t)w, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, ctx->stream));
+    if (score)
+        VKX_HIP(hipMemcpy2DAsync(score, (size_t)score_stride_el * 4, d_score, (size_t)w * 4, (size_t)w * 4, (size_t)h, hipMemcpyDeviceToHost, ctx->stream));
+    VKX_HIP(hipStreamSynchronize(ctx->stream));
+    return VKX_OK;
+}
 
 VKX_EXPORT int vkx_fill_poly_mask_u8_dev(vkx_ctx *ctx, const int32_t *pts_host, int npts, uint8_t *mask, int h, int w,
                                          ptrdiff_t stride)
@@ -96,31 +312,11 @@ VKX_EXPORT int vkx_fill_poly_mask_u8_dev(vkx_ctx *ctx, const int32_t *pts_host, 
     long long steps = 0;
     int ymin = INT_MAX, ymax = INT_MIN;
     for (int i = 0; i < npts; i++) {
-        const int a = (i + npts - 1) % npts;
-        PolyEdge &e = edges[i];
-        e.xa = pts_host[2 * a]; e.ya = pts_host[2 * a + 1];
-        e.xb = pts_host[2 * i]; e.yb = pts_host[2 * i + 1];
-        VKX_REQUIRE(e.xb >= 0 && e.xb < w && e.yb >= 0 && e.yb < h, "polygon vertex outside the mask");
-        int lx = e.xa, ly = e.ya, rx = e.xb, ry = e.yb;
-        if (rx < lx) { std::swap(lx, rx); std::swap(ly, ry); }
-        const int dx = rx - lx, dy = ry - ly, ady = dy < 0 ? -dy : dy;
-        e.lx = lx; e.ly = ly; e.sy = dy < 0 ? -1 : 1;
-        e.ymajor = ady > dx;
-        e.dmaj = e.ymajor ? ady : dx;
-        e.dmin = e.ymajor ? dx : ady;
-        e.step_base = (int)steps;
-        steps += e.dmaj + 1;
-        VKX_REQUIRE(steps < 0x7fffffff, "polygon outline too long");
-        e.y0 = std::min(e.ya, e.yb); e.y1 = std::max(e.ya, e.yb);
-        if (e.ya != e.yb) {
-            const long long xa = (long long)e.xa << 16, xb = (long long)e.xb << 16;
-            e.dx_fix = (xb - xa) / (long long)(e.yb - e.ya);
-            e.x0_fix = e.ya < e.yb ? xa : xb;
-            ymin = std::min(ymin, e.y0); ymax = std::max(ymax, e.y1);
-        } else {
-            e.dx_fix = 0; e.x0_fix = 0;
-        }
+        const int xb = pts_host[2 * i], yb = pts_host[2 * i + 1];
+        VKX_REQUIRE(xb >= 0 && xb < w && yb >= 0 && yb < h, "polygon vertex outside the mask");
     }
+    build_edges(pts_host, npts, 0, edges.data(), &steps, &ymin, &ymax);
+    VKX_REQUIRE(steps < 0x7fffffff, "polygon outline too long");
     const size_t ebytes = sizeof(PolyEdge) * edges.size();
     int rc = vkx_scratch_reserve(ctx, &ctx->misc, ebytes + 256);
     if (rc) return rc;

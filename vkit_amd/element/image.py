@@ -11,6 +11,7 @@ import attrs
 import numpy as np
 
 from ._writable import WritableContext
+from .opt import generate_shape_and_resized_shape
 from .type import Shapable
 
 
@@ -176,6 +177,29 @@ class Image(Shapable):
     def to_box_detached(self):
         assert self.box
         return attrs.evolve(self, box=None)
+
+    def to_resized_image(self, resized_height: Optional[int] = None, resized_width: Optional[int] = None,
+                         cv_resize_interpolation: int = 2):
+        """cv.resize(mat, (w, h), INTER_CUBIC) on the GPU (reference image.py:836-852).  Only the default
+        interpolation (cv.INTER_CUBIC == 2) is on the accelerated path."""
+        from vkit_amd import _native
+        if cv_resize_interpolation != 2:
+            raise NotImplementedError('only cv.INTER_CUBIC resizing is on the accelerated path')
+        if self.mat.dtype != np.uint8:
+            raise NotImplementedError('float32 image modes are outside the accelerated path')
+        _, _, resized_height, resized_width = generate_shape_and_resized_shape(
+            shapable_or_shape=self, resized_height=resized_height, resized_width=resized_width)
+        return attrs.evolve(self, mat=_native.resize_cubic(self.mat, (resized_height, resized_width)))
+
+    def to_conducted_resized_image(self, shapable_or_shape, resized_height: Optional[int] = None,
+                                   resized_width: Optional[int] = None, cv_resize_interpolation: int = 2):
+        assert self.box
+        resized_box = self.box.to_conducted_resized_box(shapable_or_shape=shapable_or_shape,
+                                                        resized_height=resized_height, resized_width=resized_width)
+        resized_image = self.to_box_detached().to_resized_image(
+            resized_height=resized_box.height, resized_width=resized_box.width,
+            cv_resize_interpolation=cv_resize_interpolation)
+        return resized_image.to_box_attached(resized_box)
 
     def to_shifted_image(self, offset_y: int = 0, offset_x: int = 0):
         assert self.box

@@ -43,6 +43,46 @@ def generate_shape_and_resized_shape(shapable_or_shape, resized_height: Optional
     return height, width, resized_height, resized_width
 
 
+class deferred_fill:
+    """Collects every ``fill_np_array`` aimed at ``base`` inside the ``with`` block and applies them, in call order,
+    with ONE ``vkx_fill_u8`` call on exit: the destination crosses PCIe once per page instead of once per layer
+    (the page assembler's loop, reference pipeline/text_detection/page_assembler.py:150-236).
+
+    Layer sources (value / mask / alpha arrays) must stay unchanged until the block exits, and nothing may read
+    ``base`` inside the block -- the writes have not happened yet.
+    """
+
+    def __init__(self, base: np.ndarray):
+        if base.dtype not in (np.uint8, np.float32) or not base.flags.c_contiguous:
+            raise ValueError('deferred_fill needs a C-contiguous uint8 or float32 destination')
+        self.base = base
+        self.layers = []
+
+    def accepts(self, base: np.ndarray):
+        return base is self.base
+
+    def __enter__(self):
+        _DEFERRED.append(self)
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        popped = _DEFERRED.pop()
+        assert popped is self
+        if exc_type is None and self.layers:
+            from vkit_amd import _native
+            writeable = self.base.flags.writeable
+            self.base.flags.writeable = True
+            try:
+                _native.fill(self.base, self.layers)
+            finally:
+                self.base.flags.writeable = writeable
+        self.layers = []
+        return False
+
+
+_DEFERRED = []
+
+
 def fill_np_array(
     mat: np.ndarray,
     value,
@@ -59,16 +99,23 @@ def fill_np_array(
     """
     from vkit_amd import _native
 
+    if mat.dtype == np.float32:
+        if mat.ndim != 2:
+            raise NotImplementedError('float32 fills are implemented for 2-D arrays (ScoreMap)')
+    elif mat.dtype != np.uint8:
+        raise NotImplementedError(f'fill_np_array on dtype {mat.dtype} is outside the accelerated path.')
+    mode = _native.FILL_PLAIN
     if keep_max_value or keep_min_value:
-        raise NotImplementedError('keep_max_value / keep_min_value fills (label rasterisation) are not on the '
-                                  'accelerated path yet.')
-    if mat.dtype != np.uint8:
-        raise NotImplementedError(f'fill_np_array on dtype {mat.dtype} is not on the accelerated path yet.')
+        assert not (keep_max_value and keep_min_value)
+        mode = _native.FILL_KEEP_MAX if keep_max_value else _native.FILL_KEEP_MIN
     if not isinstance(alpha, (float, np.ndarray)):
         # the reference fails here too (an int alpha misses both isinstance checks, vkit/element/opt.py:128,146,195)
         raise AttributeError(f'alpha must be a float or a numpy array, got {type(alpha).__name__}')
     if isinstance(alpha, float) and (alpha < 0.0 or alpha > 1.0):
         raise RuntimeError(f'alpha={alpha} is invalid.')
+    if isinstance(alpha, float) and 0.0 < alpha < 1.0 and np_mask is not None and mat.ndim == 2:
+        # the reference indexes shape[1] of the boolean-indexed (1-D) selection here (vkit/element/opt.py:172-176)
+        raise IndexError('tuple index out of range')
 
     if origin is None:
         base, up, left = mat, 0, 0
@@ -84,7 +131,10 @@ def fill_np_array(
     mask_u8 = None
     if np_mask is not None:
         mask_u8 = np_mask.view(np.uint8) if np_mask.dtype == np.bool_ else (np_mask > 0).view(np.uint8)
-    layer = _native.make_layer((up, left, bh, bw), cn, value, mask=mask_u8, alpha=alpha)
+    layer = _native.make_layer((up, left, bh, bw), cn, value, mask=mask_u8, alpha=alpha, mode=mode, dtype=mat.dtype)
+    if _DEFERRED and _DEFERRED[-1].accepts(base):
+        _DEFERRED[-1].layers.append(layer)
+        return
     if base.flags.c_contiguous:
         _native.fill(base, [layer])
     else:

@@ -9,6 +9,7 @@ import attrs
 import numpy as np
 
 from ._writable import WritableContext
+from .opt import generate_shape_and_resized_shape
 from .type import ElementSetOperationMode, Shapable
 
 
@@ -67,6 +68,20 @@ class ScoreMap(Shapable):
     def to_shifted_score_map(self, offset_y: int = 0, offset_x: int = 0):
         assert self.box
         return attrs.evolve(self, box=self.box.to_shifted_box(offset_y=offset_y, offset_x=offset_x))
+
+    def to_resized_score_map(self, resized_height: Optional[int] = None, resized_width: Optional[int] = None,
+                             cv_resize_interpolation: int = 2):
+        """Bicubic resize, clipped back to [0, 1] for probability maps (reference score_map.py:616-637)."""
+        from vkit_amd import _native
+        assert not self.box
+        if cv_resize_interpolation != 2:
+            raise NotImplementedError('only cv.INTER_CUBIC resizing is on the accelerated path')
+        _, _, resized_height, resized_width = generate_shape_and_resized_shape(
+            shapable_or_shape=self.shape, resized_height=resized_height, resized_width=resized_width)
+        mat = _native.resize_cubic(self.mat, (resized_height, resized_width))
+        if self.is_prob:
+            mat = np.clip(mat, 0.0, 1.0)
+        return attrs.evolve(self, mat=mat)
 
     def to_cropped_score_map(self, up=None, down=None, left=None, right=None):
         assert not self.box

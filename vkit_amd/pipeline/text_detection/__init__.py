@@ -1,0 +1,10 @@
+from .page_assembler import *  # noqa: F401,F403
+from .page_assembler import page_assembler_step_factory  # noqa: F401
+from .page_distortion import (  # noqa: F401
+    ElementFlattener,
+    PageDistortionStep,
+    PageDistortionStepConfig,
+    PageDistortionStepInput,
+    PageDistortionStepOutput,
+    page_distortion_step_factory,
+)
