@@ -82,7 +82,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=256, help='images per GPU')
     ap.add_argument('--size', type=int, default=2048)
-    ap.add_argument('--cpu-sample', type=int, default=8, help='images timed on the CPU oracle (rank 0, N=1)')
+    ap.add_argument('--cpu-sample', type=int, default=64, help='images timed on the CPU oracle (rank 0, N=1)')
     ap.add_argument('--verify', type=int, default=1, help='images of the batch checked against the oracle')
     ap.add_argument('--noise-workers', type=int, default=-1,
                     help='processes generating the numpy noise planes (0 = in this process, e.g. under rocprofv3)')

@@ -12,7 +12,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libvkx.so')
+# VKX_LIB: an alternative build of the same library (A/B experiments); the default is the in-tree libvkx.so
+LIB_PATH = os.environ.get('VKX_LIB') or os.path.join(_HERE, 'libvkx.so')
 
 c_int = ctypes.c_int
 c_void_p = ctypes.c_void_p

@@ -32,9 +32,14 @@ constexpr int NLDSCELL = 64;   // candidate cells whose records are cached in LD
 constexpr int NTHREADS = 512;
 constexpr int NWAVES = NTHREADS / 64;
 constexpr int ROWS_PER_WAVE = W / NWAVES;   // 8
-constexpr int CGROUP = 2;      // window rows a wavefront maps + gathers together (memory-level parallelism)
+// side of the tile proper: the window minus the blur halo, rounded down to whole 4-pixel (12-byte) store groups
+__host__ __device__ constexpr int tile_side(int R) { return (W - 2 * R) & ~3; }
+#ifndef VKX_FUSED_CGROUP
+#define VKX_FUSED_CGROUP 2
+#endif
+constexpr int CGROUP = VKX_FUSED_CGROUP;      // window rows a wavefront maps + gathers together (memory-level parallelism)
 #ifndef VKX_FUSED_WAVES_PER_EU
-#define VKX_FUSED_WAVES_PER_EU 6  // register budget: 6 waves/SIMD = 3 workgroups per CU
+#define VKX_FUSED_WAVES_PER_EU 8  // register budget: 64 VGPRs -> 8 waves/SIMD = 4 workgroups per CU (136 KB of LDS)
 #endif
 
 // explicit global address space: pointers loaded from a descriptor in memory would otherwise be "flat"
@@ -87,7 +92,8 @@ __device__ __forceinline__ int find_item(const int *__restrict__ prefix, int n, 
 
 __global__ void __launch_bounds__(256) k_chain_setup(const ItemDev *__restrict__ items, const int *__restrict__ cell_prefix,
                                                      int n_items, int total_cells, int slots,
-                                                     vkc::CellC *__restrict__ cells, TileBin *__restrict__ bins)
+                                                     vkc::CellC *__restrict__ cells, TileBin *__restrict__ bins,
+                                                     int *__restrict__ deferred /* [0] = count, then cell ids */)
 {
     const int gid = blockIdx.x * 256 + threadIdx.x;
     if (gid >= total_cells) return;
@@ -96,11 +102,12 @@ __global__ void __launch_bounds__(256) k_chain_setup(const ItemDev *__restrict__
     const int cell = gid - it.cell_base;
     vkc::CellC rec;
     int xmin, xmax, ymin, ymax;
-    vkc::build_cell(it.sv, it.dv, it.rows, it.cols, cell, rec, xmin, xmax, ymin, ymax);
-    cells[gid] = rec;
+    // closed-form homography here; cells whose quads have collinear vertices go to k_chain_setup_svd
+    if (vkc::build_cell<vkc::kCellDirectOnly>(it.sv, it.dv, it.rows, it.cols, cell, rec, xmin, xmax, ymin, ymax)) cells[gid] = rec;
+    else deferred[1 + atomicAdd(&deferred[0], 1)] = gid;
     // bin into every tile whose window [t*Tw - R, t*Tw + Tw + R) meets the cell's bounding box
     const int r = cell / (it.cols - 1), c = cell - r * (it.cols - 1);
-    const int Tw = W - 2 * it.R;
+    const int Tw = tile_side(it.R);
     int tx0 = (xmin - it.R) / Tw, tx1 = (xmax + it.R) / Tw, ty0 = (ymin - it.R) / Tw, ty1 = (ymax + it.R) / Tw;
     if (xmin - it.R < 0) tx0 = 0;
     if (ymin - it.R < 0) ty0 = 0;
@@ -114,6 +121,24 @@ __global__ void __launch_bounds__(256) k_chain_setup(const ItemDev *__restrict__
             atomicMax(&b->rmax1, r + 1);
             atomicMax(&b->cmax1, c + 1);
         }
+}
+
+// The deferred cells (Jacobi SVD least squares, 1.2 KB of workspace per lane): normally none.
+__global__ void __launch_bounds__(64) k_chain_setup_svd(const ItemDev *__restrict__ items, const int *__restrict__ cell_prefix,
+                                                        int n_items, vkc::CellC *__restrict__ cells,
+                                                        const int *__restrict__ deferred)
+{
+    __shared__ double ws[64 * vkc::kJacobiWs];   // 76 KB: the solver's workspace lives in LDS, the launch is scratch free
+    const int n = deferred[0];
+    for (int j = blockIdx.x * 64 + threadIdx.x; j < n; j += gridDim.x * 64) {
+        const int gid = deferred[1 + j];
+        const ItemDev &it = items[find_item(cell_prefix, n_items, gid)];
+        vkc::CellC rec;
+        int xmin, xmax, ymin, ymax;
+        vkc::build_cell<vkc::kCellJacobiWorkspace>(it.sv, it.dv, it.rows, it.cols, gid - it.cell_base, rec, xmin, xmax, ymin, ymax,
+                              ws + threadIdx.x * vkc::kJacobiWs);
+        cells[gid] = rec;
+    }
 }
 
 __device__ __forceinline__ int reflect101(int p, int len)
@@ -182,10 +207,13 @@ constexpr size_t kLdsCellH = sizeof(double) * 9 * NLDSCELL;     // 72-byte pitch
 constexpr size_t kLdsLut = sizeof(int) * 512;
 constexpr size_t kFusedLds = kLdsOwn + kLdsHbB + kLdsCellR + kLdsCellH + kLdsLut;
 
-__global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fused(const ItemDev *__restrict__ items,
-                                                          const vkc::CellC *__restrict__ cells,
-                                                          const TileBin *__restrict__ bins,
-                                                          const HsvLut *__restrict__ lut, int phase_limit)
+// INTERIOR: the tile's whole 64 x 64 window lies inside the image and its candidates fit one LDS chunk -- the common
+// case (94 % of the tiles of a 2048^2 page).  Border handling (row / column validity, BORDER_REFLECT_101 lane tables,
+// the global-memory fallback for candidates beyond the chunk) compiles away; the arithmetic is the same.
+template <bool INTERIOR>
+__device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, const int tile_id,
+                                           const vkc::CellC *__restrict__ cells, const TileBin &bin,
+                                           const HsvLut *__restrict__ lut, int phase_limit)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // `own` holds owner tags during phases A / C with a row-dependent column rotation ((x + row) & 63, against
@@ -197,24 +225,15 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
     int *lsdiv = (int *)(smem + kLdsOwn + kLdsHbB + kLdsCellR + kLdsCellH);
     int *lhdiv = lsdiv + 256;
 
-    // grid = (tile slots, images).  XCD-aware tile order: consecutive workgroup ids land on different XCDs
-    // (id % 8); give every XCD a contiguous run of an image's tiles so neighbouring tiles (shared source rows,
-    // shared cells) meet in one L2.
-    const int slots = gridDim.x;                 // multiple of 8, >= tiles of the largest image
-    const int per = slots >> 3;
-    const int tl = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-    const ItemDev &it = items[blockIdx.y];
-    if (tl >= it.tiles_x * it.tiles_y) return;
-    const int tile_id = (int)blockIdx.y * slots + tl;   // bins are laid out [image][slot]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ty = tl / it.tiles_x, tx = tl - ty * it.tiles_x;
-    const int R = it.R, K = 2 * R + 1, Tw = W - 2 * R;
+    const int R = it.R, K = 2 * R + 1, Tw = tile_side(R);
     const int dw = it.dw, dh = it.dh;
     const int x0 = tx * Tw, y0 = ty * Tw;                         // the tile proper
-    const int tw = min(Tw, dw - x0), th = min(Tw, dh - y0);
+    const int tw = INTERIOR ? Tw : min(Tw, dw - x0), th = INTERIOR ? Tw : min(Tw, dh - y0);
     const int wx0 = x0 - R, wy0 = y0 - R;                         // window origin (may be negative)
-    const int cx0 = max(wx0, 0), cx1 = min(wx0 + W, dw);          // window clipped to the image
-    const int cy0 = max(wy0, 0), cy1 = min(wy0 + W, dh);
+    const int cx0 = INTERIOR ? wx0 : max(wx0, 0), cx1 = INTERIOR ? wx0 + W : min(wx0 + W, dw);   // window clipped to the image
+    const int cy0 = INTERIOR ? wy0 : max(wy0, 0), cy1 = INTERIOR ? wy0 + W : min(wy0 + W, dh);
 
     const gsrc_t src = (gsrc_t)it.src;
     const gdst_t dst = (gdst_t)it.dst;
@@ -222,24 +241,8 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
     const ptrdiff_t sstride = it.sstride, dstride = it.dstride, nstride = it.nstride;
     const int sh = it.sh, sw = it.sw;
 
-    // Phase E of this wavefront: output rows cy = wave + 8 i, column = lane - R.  Its noise is needed last; ask
-    // for it first so HBM latency hides under the whole kernel (exactly 6 bytes per pixel: a dword + a short).
-    const int ocx = lane - R;                                     // output column inside the tile
+    const int ocx = lane - R;                                     // output column inside the tile (phase E)
     const bool ocol = ocx >= 0 && ocx < tw;
-    uint32_t nzA[ROWS_PER_WAVE];
-    uint32_t nzB[ROWS_PER_WAVE];
-#pragma unroll
-    for (int i = 0; i < ROWS_PER_WAVE; i++) {
-        nzA[i] = 0; nzB[i] = 0;
-        const int cy = wave + NWAVES * i;
-        if (noise && ocol && cy < th) {
-            const int16_t VKX_GLOBAL *np_ = noise + (ptrdiff_t)(y0 + cy) * nstride + (ptrdiff_t)(x0 + ocx) * 3;
-            nzA[i] = *(const u32_u1 VKX_GLOBAL *)np_;
-            nzB[i] = *(const u16_u1 VKX_GLOBAL *)(np_ + 2);
-        }
-    }
-
-    const TileBin bin = bins[tile_id];
     const int r0 = bin.rmin, c0 = bin.cmin;
     const int nr = max(0, bin.rmax1 - bin.rmin), ncol = max(0, bin.cmax1 - bin.cmin);
     const int nc = bin.rmax1 > 0 ? nr * ncol : 0;
@@ -267,13 +270,11 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
         if (tid < 256) lsdiv[tid] = lut->sdiv[tid];
         else lhdiv[tid - 256] = lut->hdiv[tid - 256];
     }
-    if (phase_limit == 10) return;
     for (int base = 0; base < max(nc, 1); base += NLDSCELL) {
         const int cn_ = min(NLDSCELL, nc - base);
         if (base > 0) __syncthreads();            // the previous chunk is still being read
         load_chunk(base, cn_);
         __syncthreads();
-        if (phase_limit == 11) return;
         // Work list of the chunk: for every candidate the window rows its scanlines can touch (compacted with a
         // prefix sum so that no lane idles on rows outside the cell), then one item per (candidate, edge).
         int *lpref = (int *)hbB;                 // [NLDSCELL + 1] exclusive prefix of row counts (hbB is free in A)
@@ -341,7 +342,6 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
                 }
             }
         }
-        if (phase_limit == 12) return;
         // A.2 outline: one (candidate, edge) pair per step; 8-connected Bresenham from the edge's left end,
         //     advanced incrementally (cv::LineIterator) over the part of the edge inside the window
         for (int p = tid; p < cn_ * 4; p += NTHREADS) {
@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
     if (phase_limit == 1) return;
 
     // If the candidates did not fit one chunk, LDS now holds the LAST chunk; phase C wants chunk 0.
-    if (nc > NLDSCELL) {
+    if (!INTERIOR && nc > NLDSCELL) {
         load_chunk(0, NLDSCELL);
         __syncthreads();
     }
@@ -394,11 +394,11 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
 #pragma unroll
     for (int i = 0; i < 2 * RMAX + 1; i++) kq[i] = (R > 0 && i < K) ? it.kq[i] : 0;
     const int gx = wx0 + lane;
-    const bool colok = gx >= cx0 && gx < cx1;
+    const bool colok = INTERIOR || (gx >= cx0 && gx < cx1);
     int srcl[2 * RMAX + 1];   // lane holding tap i of this lane's horizontal stencil (BORDER_REFLECT_101)
 #pragma unroll
     for (int i = 0; i < 2 * RMAX + 1; i++) {
-        int s = (R > 0 && i < K) ? reflect101(gx + i - R, dw) - wx0 : lane;
+        int s = (R > 0 && i < K) ? (INTERIOR ? lane + i - R : reflect101(gx + i - R, dw) - wx0) : lane;
         srcl[i] = min(max(s, 0), W - 1);
     }
     for (int g0 = 0; g0 < ROWS_PER_WAVE; g0 += CGROUP) {
@@ -408,14 +408,14 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
         for (int u = 0; u < CGROUP; u++) {
             const int ly = wave * ROWS_PER_WAVE + g0 + u;
             const int gy = wy0 + ly;
-            rowok[u] = gy >= cy0 && gy < cy1;
+            rowok[u] = INTERIOR || (gy >= cy0 && gy < cy1);
             X[u] = 0; Y[u] = 0;
             if (rowok[u] && colok) {
                 const uint32_t o = own[ly * W + ((lane + ly) & 63)];
                 if (o != 0) {
                     const int k = (int)o - 1;
                     double h[8];
-                    if (k < NLDSCELL) {
+                    if (INTERIOR || k < NLDSCELL) {
 #pragma unroll
                         for (int j = 0; j < 8; j++) h[j] = lch[k * 9 + j];
                     } else {
@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
 #pragma unroll
         for (int u = 0; u < CGROUP; u++) {
             const int sx = vkd::sat_short(X[u] >> 5), sy = vkd::sat_short(Y[u] >> 5);
-            fast[u] = rowok[u] && colok && sx >= 0 && sx + 2 < sw && sy >= 0 && sy + 1 < sh && phase_limit != 20;
+            fast[u] = rowok[u] && colok && sx >= 0 && sx + 2 < sw && sy >= 0 && sy + 1 < sh;
             ta[u] = 0; tb[u] = 0;
             if (fast[u]) {
                 // interior: the two 6-byte tap pairs come in as two unaligned 8-byte loads (3 sx + 8 <= 3 sw)
@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
             const int ly = wave * ROWS_PER_WAVE + g0 + u;
             if (!rowok[u]) continue;                     // uniform over the wavefront
             uint32_t px = 0;
-            if (colok && phase_limit != 20) {
+            if (colok) {
                 const int fx = X[u] & 31, fy = Y[u] & 31;
                 const int w00 = (32 - fy) * (32 - fx), w01 = (32 - fy) * fx, w10 = fy * (32 - fx), w11 = fy * fx;
                 if (fast[u]) {
@@ -468,8 +468,7 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
                     px = (uint32_t)p3[0] | ((uint32_t)p3[1] << 8) | ((uint32_t)p3[2] << 16);
                 }
             }
-            if (phase_limit == 20) px = (uint32_t)(X[u] ^ Y[u]) & 0xffffff;
-            if (R > 0 && phase_limit != 21 && phase_limit != 20) {
+            if (R > 0) {
                 // D: horizontal u8 x 8.8 pass; tap i of lane l lives in lane srcl[i]
                 uint32_t a0 = 0, a1 = 0, a2 = 0;
 #pragma unroll
@@ -489,9 +488,24 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
         }
     }
     __syncthreads();
-    if (phase_limit == 2 || phase_limit == 3) return;
+    if (phase_limit == 2) return;
 
     // ---- E: vertical pass, hue shift, noise, store.  Wavefront w takes output rows w, w + 8, ...
+    // This wavefront's output rows are cy = wave + 8 i, column = lane - R.  All their noise (exactly 6 bytes per
+    // pixel: a dword + a short) is requested up front, so eight rows of HBM latency overlap; asking earlier (before
+    // phase A) would pin 16 VGPRs through the register-heavy phases and spill.
+    uint32_t nzA[ROWS_PER_WAVE];
+    uint32_t nzB[ROWS_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < ROWS_PER_WAVE; i++) {
+        nzA[i] = 0; nzB[i] = 0;
+        const int cy = wave + NWAVES * i;
+        if (noise && ocol && cy < th) {
+            const int16_t VKX_GLOBAL *np_ = noise + (ptrdiff_t)(y0 + cy) * nstride + (ptrdiff_t)(x0 + ocx) * 3;
+            nzA[i] = *(const u32_u1 VKX_GLOBAL *)np_;
+            nzB[i] = *(const u16_u1 VKX_GLOBAL *)(np_ + 2);
+        }
+    }
     const bool hue_on = it.hue_on != 0;
     const int hue_delta = it.hue_delta;
     const int full4 = (tw >> 2) << 2;          // columns covered by whole 4-pixel (12-byte) groups
@@ -506,7 +520,7 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
 #pragma unroll
             for (int j = 0; j < 2 * RMAX + 1; j++) {
                 if (j < K) {
-                    const int yy = reflect101(gy + j - R, dh) - wy0;
+                    const int yy = INTERIOR ? cy + j : reflect101(gy + j - R, dh) - wy0;
                     const uint32_t hA = own[yy * W + lane];
                     const uint32_t hB = hbB[yy * W + lane];
                     a0 += kq[j] * (hA & 0xffff);
@@ -521,7 +535,7 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
             const uint32_t v = own[(cy + R) * W + lane];
             r = v & 0xff; g = (v >> 8) & 0xff; b = (v >> 16) & 0xff;
         }
-        if (hue_on && phase_limit != 4) hue_shift_px(lsdiv, lhdiv, hue_delta, r, g, b);
+        if (hue_on) hue_shift_px(lsdiv, lhdiv, hue_delta, r, g, b);
         if (noise) {
             r = vkd::clamp_u8((int16_t)((int16_t)r + (int16_t)(nzA[i] & 0xffff)));
             g = vkd::clamp_u8((int16_t)((int16_t)g + (int16_t)(nzA[i] >> 16)));
@@ -534,9 +548,9 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
         gdst_t drow = dst + (ptrdiff_t)gy * dstride + (ptrdiff_t)x0 * 3;
         if (ocol) {
             const int m = ocx & 3;
-            if (ocx < full4) {
+            if (INTERIOR || ocx < full4) {     // an interior tile is whole 4-pixel groups
                 if (m < 3) {
-                    const uint32_t wv = m == 0 ? (P | (Pn << 24)) : (m == 1 ? ((P >> 8) | (Pn << 16)) : ((P >> 16) | (Pn << 8)));
+                    const uint32_t wv = (P >> (8 * m)) | (Pn << (24 - 8 * m));   // one store for all three lanes
                     *(u32_u1 VKX_GLOBAL *)(drow + (ocx >> 2) * 12 + m * 4) = wv;
                 }
             } else {
@@ -547,6 +561,30 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
     }
 }
 
+__global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fused(const ItemDev *__restrict__ items,
+                                                          const vkc::CellC *__restrict__ cells,
+                                                          const TileBin *__restrict__ bins,
+                                                          const HsvLut *__restrict__ lut, int phase_limit)
+{
+    // grid = (tile slots, images).  XCD-aware tile order: consecutive workgroup ids land on different XCDs
+    // (id % 8); give every XCD a contiguous run of an image's tiles so neighbouring tiles (shared source rows,
+    // shared cells) meet in one L2.
+    const int slots = gridDim.x;                 // multiple of 8, >= tiles of the largest image
+    const int per = slots >> 3;
+    const int tl = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    const ItemDev &it = items[blockIdx.y];
+    if (tl >= it.tiles_x * it.tiles_y) return;
+    const int tile_id = (int)blockIdx.y * slots + tl;   // bins are laid out [image][slot]
+    const TileBin bin = bins[tile_id];
+    const int ty = tl / it.tiles_x, tx = tl - ty * it.tiles_x;
+    const int Tw = tile_side(it.R);
+    const int wx0 = tx * Tw - it.R, wy0 = ty * Tw - it.R;
+    const int nc = bin.rmax1 > 0 ? max(0, bin.rmax1 - bin.rmin) * max(0, bin.cmax1 - bin.cmin) : 0;
+    const bool interior = wx0 >= 0 && wy0 >= 0 && wx0 + W <= it.dw && wy0 + W <= it.dh && nc <= NLDSCELL && phase_limit != 3;
+    if (interior) chain_tile<true>(it, tl, tile_id, cells, bin, lut, phase_limit);
+    else chain_tile<false>(it, tl, tile_id, cells, bin, lut, phase_limit);
+}
+
 } // namespace
 
 // Returns VKX_ERR_UNSUPPORTED (without setting an error) when the batch has a shape the fused path does not
@@ -555,8 +593,8 @@ int vkx_chain_fused_try(vkx_ctx *ctx, const vkx_chain_item *items, int n_items)
 {
     if (n_items <= 0) return VKX_OK;
     std::vector<ItemDev> dev(n_items);
-    std::vector<int> prefix(2 * (size_t)n_items + 2);
-    int *tile_prefix = prefix.data(), *cell_prefix = prefix.data() + n_items + 1;
+    std::vector<int> prefix((size_t)n_items + 1);   // first cell of every image in the batch-wide cell table
+    int *cell_prefix = prefix.data();
     long long tiles = 0, ncells = 0;
     int max_tiles = 0;
     for (int i = 0; i < n_items; i++) {
@@ -570,23 +608,24 @@ int vkx_chain_fused_try(vkx_ctx *ctx, const vkx_chain_item *items, int n_items)
         d.sstride = it.src_stride; d.dstride = it.dst_stride; d.nstride = it.noise_stride_el;
         d.sh = it.sh; d.sw = it.sw; d.dh = it.dh; d.dw = it.dw; d.rows = it.rows; d.cols = it.cols;
         d.R = it.blur_ksize > 1 ? it.blur_ksize / 2 : 0;
-        const int Tw = W - 2 * d.R;
+        const int Tw = tile_side(d.R);
         d.tiles_x = (it.dw + Tw - 1) / Tw; d.tiles_y = (it.dh + Tw - 1) / Tw;
         d.tile_base = (int)tiles; d.cell_base = (int)ncells;
         d.hue_on = it.hue_enabled; d.hue_delta = it.hue_delta;
         for (int k = 0; k < 8; k++) d.kq[k] = 0;
         if (d.R > 0 && vkx_gaussian_kernel_q8_host(it.blur_ksize, it.blur_sigma, d.kq)) return VKX_ERR_UNSUPPORTED;
-        tile_prefix[i] = (int)tiles; cell_prefix[i] = (int)ncells;
+        cell_prefix[i] = (int)ncells;
         tiles += (long long)d.tiles_x * d.tiles_y;
         if (d.tiles_x * d.tiles_y > max_tiles) max_tiles = d.tiles_x * d.tiles_y;
         ncells += (long long)(it.rows - 1) * (it.cols - 1);
         if (tiles > 0x3fffffff || ncells > 0x3fffffff) return VKX_ERR_UNSUPPORTED;
     }
-    tile_prefix[n_items] = (int)tiles; cell_prefix[n_items] = (int)ncells;
+    cell_prefix[n_items] = (int)ncells;
 
     // device scratch: cell table, tile bins, item descriptors + prefix arrays, HSV tables
     int rc;
-    if ((rc = vkx_scratch_reserve(ctx, &ctx->cells, sizeof(vkc::CellC) * (size_t)ncells))) return rc;
+    const size_t cells_bytes = sizeof(vkc::CellC) * (size_t)ncells;   // then the deferred list: count + ids
+    if ((rc = vkx_scratch_reserve(ctx, &ctx->cells, cells_bytes + sizeof(int) * ((size_t)ncells + 1)))) return rc;
     const int slots = ((max_tiles + 7) / 8) * 8;          // tile slots per image in the launch grid
     const size_t nbins = (size_t)slots * n_items;
     if (n_items > 65535) return VKX_ERR_UNSUPPORTED;      // gridDim.y
@@ -602,14 +641,18 @@ int vkx_chain_fused_try(vkx_ctx *ctx, const vkx_chain_item *items, int n_items)
     VKX_HIP(hipMemcpyAsync(misc + prefix_off, prefix.data(), prefix_bytes, hipMemcpyHostToDevice, ctx->stream));
     VKX_HIP(hipStreamSynchronize(ctx->stream));
     const ItemDev *d_items = (const ItemDev *)(misc + items_off);
-    const int *d_tile_prefix = (const int *)(misc + prefix_off), *d_cell_prefix = d_tile_prefix + n_items + 1;
+    const int *d_cell_prefix = (const int *)(misc + prefix_off);
     TileBin *bins = (TileBin *)ctx->owner.ptr;
     vkc::CellC *cells = (vkc::CellC *)ctx->cells.ptr;
 
     // bins: mins start at 0x7f7f7f7f, maxs at 0 -> one strided 2D memset per half
     VKX_HIP(hipMemset2DAsync(bins, sizeof(TileBin), 0x7f, 8, nbins, ctx->stream));
     VKX_HIP(hipMemset2DAsync((unsigned char *)bins + 8, sizeof(TileBin), 0x00, 8, nbins, ctx->stream));
-    { VKX_TIMED(ctx, "k_chain_setup"); k_chain_setup<<<vkx_blocks((size_t)ncells, 256), 256, 0, ctx->stream>>>(d_items, d_cell_prefix, n_items, (int)ncells, slots, cells, bins); }
+    int *deferred = (int *)((unsigned char *)ctx->cells.ptr + cells_bytes);
+    VKX_HIP(hipMemsetAsync(deferred, 0, sizeof(int), ctx->stream));
+    { VKX_TIMED(ctx, "k_chain_setup"); k_chain_setup<<<vkx_blocks((size_t)ncells, 256), 256, 0, ctx->stream>>>(d_items, d_cell_prefix, n_items, (int)ncells, slots, cells, bins, deferred); }
+    VKX_LAUNCH_CHECK();
+    { VKX_TIMED(ctx, "k_chain_setup_svd"); k_chain_setup_svd<<<16, 64, 0, ctx->stream>>>(d_items, d_cell_prefix, n_items, cells, deferred); }
     VKX_LAUNCH_CHECK();
     // profiling aid: VKX_FUSED_PHASES=1|2 stops the kernel after phase A | C+D
     static const int phase_limit = [] { const char *e = getenv("VKX_FUSED_PHASES"); return e ? atoi(e) : 0; }();

@@ -69,9 +69,14 @@ __device__ inline double vk_hypot(double a, double b)
 
 // Minimum-norm least squares of the 8x8 DLT system: one-sided Jacobi SVD + back substitution with the
 // 2*eps*sum(w) cut-off.  Only reached for degenerate quads (a handful per image), written for clarity.
-__device__ __noinline__ void homography_jacobi(const float from[8], const float to[8], double H[9])
+// `ws`: kJacobiWs doubles of private workspace (thread-private scratch by default; the batched setup kernel
+// hands in LDS so that its launch needs no scratch segment at all).
+constexpr int kJacobiWs = 8 * 8 * 2 + 8 * 3;
+__device__ __forceinline__ void homography_jacobi_ws(const float from[8], const float to[8], double H[9], double *ws)
 {
-    double At[8][8], W[8], Vt[8][8], b[8], x[8];
+    double (*At)[8] = (double (*)[8])ws;
+    double (*Vt)[8] = (double (*)[8])(ws + 64);
+    double *W = ws + 128, *b = ws + 136, *x = ws + 144;
     for (int i = 0; i < 4; i++) {
         const float fx = from[2 * i], fy = from[2 * i + 1], tx = to[2 * i], ty = to[2 * i + 1];
         for (int c = 0; c < 8; c++) { At[c][i] = 0; At[c][i + 4] = 0; }
@@ -164,6 +169,12 @@ __device__ __noinline__ void homography_jacobi(const float from[8], const float 
     H[8] = 1.;
 }
 
+__device__ __noinline__ void homography_jacobi(const float from[8], const float to[8], double H[9])
+{
+    double ws[kJacobiWs];
+    homography_jacobi_ws(from, to, H, ws);
+}
+
 // Number of minor-axis steps an 8-connected Bresenham line (cv::LineIterator, walked from its left end) has
 // taken after k major steps: ceil((2 k dmin - dmaj) / (2 dmaj)), never negative.
 __device__ __forceinline__ int bres_minor(int k, int dmaj, int dmin)
@@ -187,8 +198,13 @@ struct CellC {
 static_assert(sizeof(CellC) == 128, "CellC layout");
 
 // Builds the record of cell `cell` (row-major index over (rows-1) x (cols-1)) and returns its bounding box.
-__device__ inline void build_cell(const int32_t *__restrict__ src_v, const int32_t *__restrict__ dst_v, int rows, int cols,
-                                  int cell, CellC &rec, int &xmin, int &xmax, int &ymin, int &ymax)
+// MODE kCellDirectOnly: the closed-form solver only; returns false (record incomplete) when the cell's quads are
+// not in general position, so that a caller can leave the register-hungry SVD to a second, rarely busy kernel.
+enum { kCellDirectOnly = 0, kCellJacobiPrivate = 1, kCellJacobiWorkspace = 2 };
+template <int MODE = kCellJacobiPrivate>
+__device__ inline bool build_cell(const int32_t *__restrict__ src_v, const int32_t *__restrict__ dst_v, int rows, int cols,
+                                  int cell, CellC &rec, int &xmin, int &xmax, int &ymin, int &ymax,
+                                  double *jacobi_ws = nullptr)
 {
     (void)rows;
     const int r = cell / (cols - 1), c = cell - r * (cols - 1);
@@ -207,7 +223,11 @@ __device__ inline void build_cell(const int32_t *__restrict__ src_v, const int32
         ymin = min(ymin, vy[k]); ymax = max(ymax, vy[k]);
         rec.vx[k] = (short)vx[k]; rec.vy[k] = (short)vy[k];
     }
-    if (!homography_direct(qf, qt, H)) homography_jacobi(from, to, H);
+    if (!homography_direct(qf, qt, H)) {
+        if (MODE == kCellDirectOnly) return false;
+        if (MODE == kCellJacobiWorkspace) homography_jacobi_ws(from, to, H, jacobi_ws);
+        else homography_jacobi(from, to, H);
+    }
     for (int i = 0; i < 8; i++) rec.H[i] = H[i];
     for (int i = 0; i < 4; i++) {
         const int a = (i + 3) & 3;
@@ -227,6 +247,7 @@ __device__ inline void build_cell(const int32_t *__restrict__ src_v, const int32
         }
     rec.flags = (dmin > 1e-6 || dmax < -1e-6) && isfinite(dmin) && isfinite(dmax) ? 0 : 1;
     rec.pad[0] = rec.pad[1] = rec.pad[2] = 0;
+    return true;
 }
 
 } // namespace vkc
