@@ -169,30 +169,25 @@ __device__ __forceinline__ void hue_shift_px(const int *sdiv, const int *hdiv, i
     hh += hh < 0 ? 256 : 0;
     int H = vkd::clamp_u8(hh);
     H = (H + delta) & 255;   // python modulo 256 of a sum that may be negative
-    // HSV_FULL -> RGB (float32 scalar formula, no FMA)
+    // HSV_FULL -> RGB (float32 scalar formula, no FMA).  Branch free: with s == 0 every candidate below is
+    // fv * 1.0f == fv, which is the reference's grey shortcut; H < 256 keeps the sector in 0..5.
     const float s = S * (1.0f / 255.0f);
     const float fv = v * (1.0f / 255.0f);
-    float fb, fg, fr;
-    if (s == 0) {
-        fb = fg = fr = fv;
-    } else {
-        float h = (float)H * (6.0f / 256);
-        int sector = (int)floorf(h);
-        h -= sector;
-        if ((unsigned)sector >= 6u) { sector = 0; h = 0.f; }
-        const float t0 = fv;
-        const float t1 = fv * (1.f - s);
-        const float t2 = fv * (1.f - s * h);
-        const float t3 = fv * (1.f - s * (1.f - h));
-        switch (sector) {
-        case 0: fb = t1; fg = t3; fr = t0; break;
-        case 1: fb = t1; fg = t0; fr = t2; break;
-        case 2: fb = t3; fg = t0; fr = t1; break;
-        case 3: fb = t0; fg = t2; fr = t1; break;
-        case 4: fb = t0; fg = t1; fr = t3; break;
-        default: fb = t2; fg = t1; fr = t0; break;
-        }
-    }
+    float h = (float)H * (6.0f / 256);
+    const int sector = (int)h;                 // h >= 0: truncation == floor
+    h -= (float)sector;
+    const float t0 = fv;
+    const float t1 = fv * (1.f - s);
+    const float t2 = fv * (1.f - s * h);
+    const float t3 = fv * (1.f - s * (1.f - h));
+    // sector table (b, g, r): 0 (t1,t3,t0) 1 (t1,t0,t2) 2 (t3,t0,t1) 3 (t0,t2,t1) 4 (t0,t1,t3) 5 (t2,t1,t0)
+    //   = (t1, odd ? t0 : t3, odd ? t2 : t0) rotated left by sector / 2
+    const bool odd = sector & 1;
+    const int rot = sector >> 1;
+    const float u0 = t1, u1 = odd ? t0 : t3, u2 = odd ? t2 : t0;
+    const float fb = rot == 0 ? u0 : (rot == 1 ? u1 : u2);
+    const float fg = rot == 0 ? u1 : (rot == 1 ? u2 : u0);
+    const float fr = rot == 0 ? u2 : (rot == 1 ? u0 : u1);
     // 0 <= f <= 1, so round-half-even needs neither the cvRound range check nor the saturate_cast clamp
     r = __float2int_rn(fr * 255.0f);
     g = __float2int_rn(fg * 255.0f);
