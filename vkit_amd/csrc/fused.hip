@@ -203,7 +203,7 @@ constexpr size_t kLdsLut = sizeof(int) * 512;
 constexpr size_t kFusedLds = kLdsOwn + kLdsHbB + kLdsCellR + kLdsCellH + kLdsLut;
 
 // INTERIOR: the tile's whole 64 x 64 window lies inside the image and its candidates fit one LDS chunk -- the common
-// case (94 % of the tiles of a 2048^2 page).  Border handling (row / column validity, BORDER_REFLECT_101 lane tables,
+// case (about 89 % of the tiles of a 2048^2 page).  Border handling (row / column validity, BORDER_REFLECT_101 lane tables,
 // the global-memory fallback for candidates beyond the chunk) compiles away; the arithmetic is the same.
 template <bool INTERIOR>
 __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, const int tile_id,
