@@ -161,6 +161,33 @@ int vkx_line_streak_u8(vkx_ctx *ctx, uint8_t *img, int h, int w, int cn, ptrdiff
                        int gap, int dash_thickness, int dash_gap, const uint8_t color[4], double alpha,
                        int enable_vert, int enable_hori);
 
+/* complement / posterization / channel_permutation  photometric/color.py:299-357, 423-432 (numpy only).
+ *   VKX_POINT_COMPLEMENT  p0 = threshold or -1 (none), p1 = enable_threshold_lte: v = 255 - v where selected
+ *   VKX_POINT_POSTERIZE   p0 = num_bits in [0, 7]: v &= (0xFF >> p0) << p0
+ *   VKX_POINT_PERMUTE     p0 = permutation, 2 bits per output channel: out[c] = in[(p0 >> 2c) & 3]; not in place
+ * channel_mask 0 = all channels (ignored by PERMUTE). */
+#define VKX_POINT_COMPLEMENT 0
+#define VKX_POINT_POSTERIZE 1
+#define VKX_POINT_PERMUTE 2
+int vkx_pointwise_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride, int op, int p0,
+                         int p1, unsigned channel_mask, uint8_t *dst, ptrdiff_t dst_stride);
+int vkx_pointwise_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride, int op, int p0,
+                     int p1, unsigned channel_mask, uint8_t *dst, ptrdiff_t dst_stride);
+
+/* impulse_noise  photometric/noise.py:125-150: selector uint8 [h, w] (0 keep, 1 salt = 255, 2 pepper = 0 on every
+ * channel of the pixel), drawn by the caller's numpy Generator (rng.choice). */
+int vkx_impulse_noise_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                             const uint8_t *selector, ptrdiff_t selector_stride, uint8_t *dst, ptrdiff_t dst_stride);
+int vkx_impulse_noise_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                         const uint8_t *selector, ptrdiff_t selector_stride, uint8_t *dst, ptrdiff_t dst_stride);
+
+/* speckle_noise  photometric/noise.py:172-183: uint8(clip(px + px * noise, 0, 255)) evaluated in float64, noise
+ * float64 [h, w, cn] = rng.normal(0, std, shape) of the caller's numpy Generator. */
+int vkx_speckle_noise_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                             const double *noise, ptrdiff_t noise_stride_el, uint8_t *dst, ptrdiff_t dst_stride);
+int vkx_speckle_noise_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                         const double *noise, ptrdiff_t noise_stride_el, uint8_t *dst, ptrdiff_t dst_stride);
+
 /* ---- alpha composite ----------------------------------------------------------------
  * fill_np_array  element/opt.py:118-209 reached through Box.fill_np_array element/box.py:311-340
  * (Box.fill_image :394-416, Mask.fill_image element/mask.py:601-612, ScoreMap.fill_image

@@ -278,6 +278,67 @@ def fill(dst, box, value, mask=None, alpha=1.0, mode=FILL_PLAIN):
     return dst
 
 
+def _chmask(channels):
+    mask = 0
+    for c in channels or ():
+        mask |= 1 << int(c)
+    return mask
+
+
+def complement(img, threshold=None, enable_threshold_lte=False, channels=None):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    out = np.empty_like(img)
+    rc = lib().vko_pointwise_u8(_p(img), ctypes.c_size_t(img.size // cn), cn, 0,
+                                -1 if threshold is None else int(threshold), int(bool(enable_threshold_lte)),
+                                _chmask(channels), _p(out))
+    assert rc == 0
+    return out
+
+
+def posterization(img, num_bits, channels=None):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    out = np.empty_like(img)
+    rc = lib().vko_pointwise_u8(_p(img), ctypes.c_size_t(img.size // cn), cn, 1, int(num_bits), 0,
+                                _chmask(channels), _p(out))
+    assert rc == 0
+    return out
+
+
+def permute_channels(img, indices):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    cn = img.shape[2]
+    packed = 0
+    for c, idx in enumerate(indices):
+        packed |= (int(idx) & 3) << (2 * c)
+    out = np.empty_like(img)
+    rc = lib().vko_pointwise_u8(_p(img), ctypes.c_size_t(img.size // cn), cn, 2, packed, 0, 0, _p(out))
+    assert rc == 0
+    return out
+
+
+def impulse_noise(img, selector):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    cn = 1 if img.ndim == 2 else img.shape[2]
+    selector = np.ascontiguousarray(selector, dtype=np.uint8)
+    assert selector.shape == img.shape[:2]
+    out = np.empty_like(img)
+    rc = lib().vko_impulse_noise_u8(_p(img), ctypes.c_size_t(img.size // cn), cn, _p(selector), _p(out))
+    assert rc == 0
+    return out
+
+
+def speckle_noise(img, noise):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    noise = np.ascontiguousarray(noise, dtype=np.float64)
+    assert noise.shape == img.shape
+    out = np.empty_like(img)
+    rc = lib().vko_speckle_noise_u8(_p(img), ctypes.c_size_t(img.size), _p(noise), _p(out))
+    assert rc == 0
+    return out
+
+
 def resize_cubic(src, dsize_hw):
     """cv.resize(src, (dw, dh), interpolation=cv.INTER_CUBIC) for uint8 HxW[xC] or float32 HxW."""
     dh, dw = int(dsize_hw[0]), int(dsize_hw[1])

@@ -1068,6 +1068,52 @@ VKO_API int vko_fill_f32(float *dst, int h, int w, ptrdiff_t dstep_el, int up, i
     return 0;
 }
 
+/* [numpy] complement / posterization / channel_permutation -- photometric/color.py:299-357, 423-432.
+ * op 0 complement (p0 threshold or -1, p1 lte), 1 posterize (p0 bits), 2 permute (p0: 2 bits per channel). */
+VKO_API int vko_pointwise_u8(const uint8_t *src, size_t npix, int cn, int op, int p0, int p1,
+                             unsigned chmask, uint8_t *dst)
+{
+    for (size_t i = 0; i < npix; i++)
+        for (int c = 0; c < cn; c++) {
+            int v = src[i * cn + c];
+            int on = chmask == 0 || ((chmask >> c) & 1u);
+            if (op == 0) {
+                if (on && (p0 < 0 || (p1 ? v <= p0 : p0 <= v))) v = 255 - v;
+            } else if (op == 1) {
+                if (on) v &= (0xFF >> p0) << p0;
+            } else if (op == 2) {
+                v = src[i * cn + ((p0 >> (2 * c)) & 3)];
+            } else {
+                return -1;
+            }
+            dst[i * cn + c] = (uint8_t)v;
+        }
+    return 0;
+}
+
+/* [numpy] impulse_noise -- photometric/noise.py:125-150 (selector per pixel: 1 salt, 2 pepper). */
+VKO_API int vko_impulse_noise_u8(const uint8_t *src, size_t npix, int cn, const uint8_t *sel, uint8_t *dst)
+{
+    for (size_t i = 0; i < npix; i++)
+        for (int c = 0; c < cn; c++)
+            dst[i * cn + c] = sel[i] == 1 ? 255 : (sel[i] == 2 ? 0 : src[i * cn + c]);
+    return 0;
+}
+
+/* [numpy] speckle_noise -- photometric/noise.py:172-183: float32 mat + mat * float64 noise in float64,
+ * np.clip, astype(uint8). */
+VKO_API int vko_speckle_noise_u8(const uint8_t *src, size_t n, const double *noise, uint8_t *dst)
+{
+    for (size_t i = 0; i < n; i++) {
+        double m = (double)(float)src[i];
+        double t = m * noise[i];
+        double v = m + t;
+        v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+        dst[i] = (uint8_t)v;
+    }
+    return 0;
+}
+
 /* [numpy] line_streak masks + two sequential blends -- photometric/streak.py:24-41,56-99 */
 VKO_API int vko_line_streak_u8(uint8_t *img, int h, int w, int cn, ptrdiff_t step, int thickness,
                                int gap, int dash_thickness, int dash_gap, const uint8_t *color,

@@ -207,6 +207,38 @@ def gen_fill_modes():
     np.savez_compressed(os.path.join(HERE, 'fill_modes.npz'), **out)
 
 
+def gen_pointwise_ops():
+    """complement / posterization / channel_permutation / impulse_noise / speckle_noise: numpy-only members."""
+    out = {}
+    src = default_rng(91).integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    out['src'] = src
+    img = Image(mat=src)
+    cases = [dict(), dict(threshold=100), dict(threshold=100, enable_threshold_lte=True),
+             dict(threshold=0, channels=[1]), dict(threshold=255, enable_threshold_lte=True, channels=[0, 2]),
+             dict(channels=[2])]
+    for i, kw in enumerate(cases):
+        out[f'complement_{i}'] = D.complement.distort(D.ComplementConfig(**kw), image=img).image.mat
+    out['complement_cases'] = np.asarray(json.dumps(cases))
+    for bits in range(8):
+        out[f'posterization_{bits}'] = D.posterization.distort(D.PosterizationConfig(num_bits=bits), image=img).image.mat
+    out['posterization_3_c1'] = D.posterization.distort(D.PosterizationConfig(num_bits=3, channels=[1]), image=img).image.mat
+    for seed in (0, 1, 2, 3):
+        out[f'channel_permutation_{seed}'] = D.channel_permutation.distort(D.ChannelPermutationConfig(), image=img, rng=default_rng(seed)).image.mat
+    for i, (ps, pp, seed) in enumerate([(0.02, 0.03, 0), (0.0, 0.05, 1), (0.3, 0.0, 2), (0.0, 0.0, 3)]):
+        out[f'impulse_{i}'] = D.impulse_noise.distort(D.ImpulseNoiseConfig(prob_salt=ps, prob_pepper=pp), image=img,
+                                                      rng=default_rng(seed)).image.mat
+    out['impulse_cases'] = np.asarray([[0.02, 0.03, 0], [0.0, 0.05, 1], [0.3, 0.0, 2], [0.0, 0.0, 3]])
+    for i, (std, seed) in enumerate([(0.1, 0), (0.3, 1), (1.5, 2)]):
+        out[f'speckle_{i}'] = D.speckle_noise.distort(D.SpeckleNoiseConfig(std=std), image=img, rng=default_rng(seed)).image.mat
+    out['speckle_cases'] = np.asarray([[0.1, 0], [0.3, 1], [1.5, 2]])
+    gray = Image(mat=src[:, :, 0].copy())
+    out['gray_complement_thr'] = D.complement.distort(D.ComplementConfig(threshold=128), image=gray).image.mat
+    out['gray_impulse'] = D.impulse_noise.distort(D.ImpulseNoiseConfig(prob_salt=0.1, prob_pepper=0.1), image=gray,
+                                                  rng=default_rng(5)).image.mat
+    out['gray_speckle'] = D.speckle_noise.distort(D.SpeckleNoiseConfig(std=0.2), image=gray, rng=default_rng(6)).image.mat
+    np.savez_compressed(os.path.join(HERE, 'pointwise_ops.npz'), **out)
+
+
 def gen_mls_states():
     out = {}
     cases = [(64, 64, 0, 5), (96, 80, 1, 8), (130, 257, 2, 10), (512, 512, 0, 5), (300, 200, 3, 1)]
@@ -281,6 +313,12 @@ def gen_policy_configs():
         'mean_shift': (P_color.MeanShiftConfigGenerator, P_color.MeanShiftConfigGeneratorConfig),
         'color_shift': (P_color.ColorShiftConfigGenerator, P_color.ColorShiftConfigGeneratorConfig),
         'gaussion_noise': (P_noise.GaussionNoiseConfigGenerator, P_noise.GaussionNoiseConfigGeneratorConfig),
+        'impulse_noise': (P_noise.ImpulseNoiseConfigGenerator, P_noise.ImpulseNoiseConfigGeneratorConfig),
+        'speckle_noise': (P_noise.SpeckleNoiseConfigGenerator, P_noise.SpeckleNoiseConfigGeneratorConfig),
+        'complement': (P_color.ComplementConfigGenerator, P_color.ComplementConfigGeneratorConfig),
+        'posterization': (P_color.PosterizationConfigGenerator, P_color.PosterizationConfigGeneratorConfig),
+        'channel_permutation': (P_color.ChannelPermutationConfigGenerator,
+                                P_color.ChannelPermutationConfigGeneratorConfig),
         'line_streak': (P_streak.LineStreakConfigGenerator, P_streak.LineStreakConfigGeneratorConfig),
         'rectangle_streak': (P_streak.RectangleStreakConfigGenerator, P_streak.RectangleStreakConfigGeneratorConfig),
         'ellipse_streak': (P_streak.EllipseStreakConfigGenerator, P_streak.EllipseStreakConfigGeneratorConfig),
@@ -428,6 +466,7 @@ def gen_structure_oracle_patched():
 if __name__ == '__main__':
     gen_numpy_path()
     gen_fill_modes()
+    gen_pointwise_ops()
     gen_mls_states()
     gen_affine_states()
     gen_policy_configs()

@@ -50,6 +50,12 @@ GENERATORS = {
     'mean_shift': (P_color.MeanShiftConfigGenerator, P_color.MeanShiftConfigGeneratorConfig),
     'color_shift': (P_color.ColorShiftConfigGenerator, P_color.ColorShiftConfigGeneratorConfig),
     'gaussion_noise': (P_noise.GaussionNoiseConfigGenerator, P_noise.GaussionNoiseConfigGeneratorConfig),
+    'impulse_noise': (P_noise.ImpulseNoiseConfigGenerator, P_noise.ImpulseNoiseConfigGeneratorConfig),
+    'speckle_noise': (P_noise.SpeckleNoiseConfigGenerator, P_noise.SpeckleNoiseConfigGeneratorConfig),
+    'complement': (P_color.ComplementConfigGenerator, P_color.ComplementConfigGeneratorConfig),
+    'posterization': (P_color.PosterizationConfigGenerator, P_color.PosterizationConfigGeneratorConfig),
+    'channel_permutation': (P_color.ChannelPermutationConfigGenerator,
+                            P_color.ChannelPermutationConfigGeneratorConfig),
     'line_streak': (P_streak.LineStreakConfigGenerator, P_streak.LineStreakConfigGeneratorConfig),
     'rectangle_streak': (P_streak.RectangleStreakConfigGenerator, P_streak.RectangleStreakConfigGeneratorConfig),
 }
@@ -70,7 +76,7 @@ def test_policy_configs_match_reference_draw_for_draw(golden_dir):
         # the generator consumed exactly the reference's number of draws
         assert float(rng.random()) == rec['next_random']
         checked += 1
-    assert checked > 250
+    assert checked > 340
 
 
 def test_affine_states(golden_dir):

@@ -76,6 +76,33 @@ def test_fill_modes_float32_and_keep(golden_dir):
     assert (O.fill(sm0.copy(), full, 3.0, alpha=0.3) == F['f32_alpha_scalar']).all()
 
 
+def test_pointwise_ops_against_reference(golden_dir):
+    """complement / posterization / channel_permutation / impulse / speckle: genuine reference outputs (pinned)."""
+    import json
+    P = np.load(os.path.join(golden_dir, 'pointwise_ops.npz'))
+    src = P['src']
+    for i, kw in enumerate(json.loads(str(P['complement_cases']))):
+        assert (O.complement(src, **kw) == P[f'complement_{i}']).all(), kw
+    for bits in range(8):
+        assert (O.posterization(src, bits) == P[f'posterization_{bits}']).all()
+    assert (O.posterization(src, 3, channels=[1]) == P['posterization_3_c1']).all()
+    for seed in (0, 1, 2, 3):
+        # operator rng contract: the private generator is the caller's generator state at call time
+        indices = default_rng(seed).permutation(3)
+        assert (O.permute_channels(src, indices) == P[f'channel_permutation_{seed}']).all()
+    for i, (ps, pp, seed) in enumerate(P['impulse_cases']):
+        sel = default_rng(int(seed)).choice((0, 1, 2), size=src.shape[:2], p=[1 - ps - pp, ps, pp])
+        assert (O.impulse_noise(src, sel) == P[f'impulse_{i}']).all()
+    for i, (std, seed) in enumerate(P['speckle_cases']):
+        noise = default_rng(int(seed)).normal(0, std, src.shape)
+        assert (O.speckle_noise(src, noise) == P[f'speckle_{i}']).all()
+    gray = src[:, :, 0].copy()
+    assert (O.complement(gray, threshold=128) == P['gray_complement_thr']).all()
+    sel = default_rng(5).choice((0, 1, 2), size=gray.shape, p=[0.8, 0.1, 0.1])
+    assert (O.impulse_noise(gray, sel) == P['gray_impulse']).all()
+    assert (O.speckle_noise(gray, default_rng(6).normal(0, 0.2, gray.shape)) == P['gray_speckle']).all()
+
+
 def test_fill_rejects_bad_alpha():
     page = np.zeros((4, 4, 3), np.uint8)
     with pytest.raises(RuntimeError):

@@ -139,6 +139,9 @@ for _sfx in ('', '_dev'):
     _SIGNATURES['vkx_mean_shift_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_int, c_int, c_int, c_int, c_uint, c_void_p,
                                                                         c_ssize]
     _SIGNATURES['vkx_add_noise_i16' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_ssize, c_void_p, c_ssize]
+    _SIGNATURES['vkx_pointwise_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_int, c_int, c_int, c_uint, c_void_p, c_ssize]
+    _SIGNATURES['vkx_impulse_noise_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_ssize, c_void_p, c_ssize]
+    _SIGNATURES['vkx_speckle_noise_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_ssize, c_void_p, c_ssize]
     _SIGNATURES['vkx_line_streak_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_int, c_int, c_int, c_int, c_void_p, c_double,
                                                                          c_int, c_int]
     _SIGNATURES['vkx_fill_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [ctypes.POINTER(VkxLayer), c_int]
@@ -481,6 +484,58 @@ def mean_shift(img, delta, threshold=None, channels=None, cycle=False, ctx=None)
     dst = np.empty_like(img)
     check(lib().vkx_mean_shift_u8(ctx.handle, _ptr(img), h, w, cn, stride, int(delta), int(threshold is not None),
                                   int(threshold or 0), int(bool(cycle)), chmask, _ptr(dst), stride))
+    return dst
+
+
+POINT_COMPLEMENT, POINT_POSTERIZE, POINT_PERMUTE = 0, 1, 2
+
+
+def _channel_mask(channels):
+    chmask = 0
+    for c in channels or ():
+        chmask |= 1 << int(c)
+    return chmask
+
+
+def pointwise(img, op, p0=0, p1=0, channels=None, ctx=None):
+    """complement / posterization / channel permutation (include/vkx.h VKX_POINT_*)."""
+    ctx = ctx or default_ctx()
+    img, h, w, cn, stride = _u8_plane(img)
+    dst = np.empty_like(img)
+    check(lib().vkx_pointwise_u8(ctx.handle, _ptr(img), h, w, cn, stride, int(op), int(p0), int(p1),
+                                 _channel_mask(channels), _ptr(dst), stride))
+    return dst
+
+
+def permute_channels(img, indices, ctx=None):
+    """img[:, :, indices]."""
+    packed = 0
+    for c, idx in enumerate(indices):
+        packed |= (int(idx) & 3) << (2 * c)
+    if len(indices) != (1 if img.ndim == 2 else img.shape[2]):
+        raise ValueError('one index per channel')
+    return pointwise(img, POINT_PERMUTE, packed, ctx=ctx)
+
+
+def impulse_noise(img, selector, ctx=None):
+    ctx = ctx or default_ctx()
+    img, h, w, cn, stride = _u8_plane(img)
+    selector = np.ascontiguousarray(selector, dtype=np.uint8)
+    if selector.shape != (h, w):
+        raise ValueError('selector plane must be (H, W)')
+    dst = np.empty_like(img)
+    check(lib().vkx_impulse_noise_u8(ctx.handle, _ptr(img), h, w, cn, stride, _ptr(selector), w, _ptr(dst), stride))
+    return dst
+
+
+def speckle_noise(img, noise, ctx=None):
+    ctx = ctx or default_ctx()
+    img, h, w, cn, stride = _u8_plane(img)
+    noise = np.ascontiguousarray(noise, dtype=np.float64)
+    if noise.shape != img.shape:
+        raise ValueError('noise plane must have the image shape')
+    dst = np.empty_like(img)
+    check(lib().vkx_speckle_noise_u8(ctx.handle, _ptr(img), h, w, cn, stride, _ptr(noise), w * cn, _ptr(dst), stride))
     return dst
 
 

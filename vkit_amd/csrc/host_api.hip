@@ -357,3 +357,47 @@ VKX_EXPORT int vkx_resize_cubic_f32(vkx_ctx *ctx, const float *src, int sh, int 
     VKX_TRY(vkx_resize_cubic_f32_dev(ctx, st.dev<float>(s), sh, sw, sw, st.dev<float>(d), dh, dw, dw));
     return st.finish();
 }
+
+VKX_EXPORT int vkx_pointwise_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride, int op, int p0,
+                                int p1, unsigned channel_mask, uint8_t *dst, ptrdiff_t dst_stride)
+{
+    VKX_REQUIRE(ctx && src && dst, "NULL argument");
+    VKX_REQUIRE(h >= 0 && w >= 0 && cn > 0, "bad shape");
+    HostStage st(ctx);
+    const int s = st.add(src, nullptr, (size_t)w * cn, h, src_stride);
+    const int d = st.add(nullptr, dst, (size_t)w * cn, h, dst_stride);
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_pointwise_u8_dev(ctx, st.dev<uint8_t>(s), h, w, cn, (ptrdiff_t)w * cn, op, p0, p1, channel_mask,
+                                 st.dev<uint8_t>(d), (ptrdiff_t)w * cn));
+    return st.finish();
+}
+
+VKX_EXPORT int vkx_impulse_noise_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                                    const uint8_t *selector, ptrdiff_t selector_stride, uint8_t *dst, ptrdiff_t dst_stride)
+{
+    VKX_REQUIRE(ctx && src && selector && dst, "NULL argument");
+    VKX_REQUIRE(h >= 0 && w >= 0 && cn > 0, "bad shape");
+    HostStage st(ctx);
+    const int s = st.add(src, nullptr, (size_t)w * cn, h, src_stride);
+    const int m = st.add(selector, nullptr, (size_t)w, h, selector_stride);
+    const int d = st.add(nullptr, dst, (size_t)w * cn, h, dst_stride);
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_impulse_noise_u8_dev(ctx, st.dev<uint8_t>(s), h, w, cn, (ptrdiff_t)w * cn, st.dev<uint8_t>(m), w,
+                                     st.dev<uint8_t>(d), (ptrdiff_t)w * cn));
+    return st.finish();
+}
+
+VKX_EXPORT int vkx_speckle_noise_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                                    const double *noise, ptrdiff_t noise_stride_el, uint8_t *dst, ptrdiff_t dst_stride)
+{
+    VKX_REQUIRE(ctx && src && noise && dst, "NULL argument");
+    VKX_REQUIRE(h >= 0 && w >= 0 && cn > 0, "bad shape");
+    HostStage st(ctx);
+    const int s = st.add(src, nullptr, (size_t)w * cn, h, src_stride);
+    const int n = st.add(noise, nullptr, (size_t)w * cn * 8, h, noise_stride_el * 8);
+    const int d = st.add(nullptr, dst, (size_t)w * cn, h, dst_stride);
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_speckle_noise_u8_dev(ctx, st.dev<uint8_t>(s), h, w, cn, (ptrdiff_t)w * cn, st.dev<double>(n),
+                                     (ptrdiff_t)w * cn, st.dev<uint8_t>(d), (ptrdiff_t)w * cn));
+    return st.finish();
+}

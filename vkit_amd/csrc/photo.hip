@@ -203,6 +203,57 @@ __global__ void __launch_bounds__(256) k_add_noise(const uint8_t *__restrict__ s
     dst[(ptrdiff_t)y * dstride + xe] = (uint8_t)vkd::clamp_u8(v);
 }
 
+// complement / posterization / channel_permutation (photometric/color.py:299-357, 423-432): one value per lane.
+__global__ void __launch_bounds__(256) k_pointwise(const uint8_t *__restrict__ src, int h, int w, int cn, ptrdiff_t sstride,
+                                                   uint8_t *__restrict__ dst, ptrdiff_t dstride, int op, int p0, int p1,
+                                                   unsigned chmask)
+{
+    const int xe = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (xe >= w * cn || y >= h) return;
+    const int c = xe % cn;
+    const uint8_t *row = src + (ptrdiff_t)y * sstride;
+    int v = row[xe];
+    const bool on = chmask == 0 || ((chmask >> c) & 1u);
+    if (op == VKX_POINT_COMPLEMENT) {
+        if (on && (p0 < 0 || (p1 ? v <= p0 : p0 <= v))) v = 255 - v;
+    } else if (op == VKX_POINT_POSTERIZE) {
+        if (on) v &= (0xFF >> p0) << p0;
+    } else {                                     // VKX_POINT_PERMUTE: out[c] = in[perm[c]], 2 bits per channel
+        v = row[xe - c + ((p0 >> (2 * c)) & 3)];
+    }
+    dst[(ptrdiff_t)y * dstride + xe] = (uint8_t)v;
+}
+
+// impulse_noise (photometric/noise.py:125-150): per-PIXEL selector 0 keep / 1 salt (255) / 2 pepper (0).
+__global__ void __launch_bounds__(256) k_impulse_noise(const uint8_t *__restrict__ src, int h, int w, int cn, ptrdiff_t sstride,
+                                                       const uint8_t *__restrict__ sel, ptrdiff_t sel_stride,
+                                                       uint8_t *__restrict__ dst, ptrdiff_t dstride)
+{
+    const int xe = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (xe >= w * cn || y >= h) return;
+    const int m = sel[(ptrdiff_t)y * sel_stride + xe / cn];
+    const uint8_t v = src[(ptrdiff_t)y * sstride + xe];
+    dst[(ptrdiff_t)y * dstride + xe] = m == 1 ? (uint8_t)255 : (m == 2 ? (uint8_t)0 : v);
+}
+
+// speckle_noise (photometric/noise.py:172-183): float32(px) + float32(px) * float64 noise is a float64 expression
+// in numpy; product and sum round separately; clip to [0, 255]; astype(uint8) truncates.
+__global__ void __launch_bounds__(256) k_speckle_noise(const uint8_t *__restrict__ src, int h, int wc, ptrdiff_t sstride,
+                                                       const double *__restrict__ noise, ptrdiff_t nstride,
+                                                       uint8_t *__restrict__ dst, ptrdiff_t dstride)
+{
+    const int xe = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (xe >= wc || y >= h) return;
+    const double m = (double)src[(ptrdiff_t)y * sstride + xe];
+    const double t = m * noise[(ptrdiff_t)y * nstride + xe];
+    double v = m + t;
+    v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);   // np.clip; NaN (never produced by rng.normal) would pass through
+    dst[(ptrdiff_t)y * dstride + xe] = (uint8_t)v;
+}
+
 // fill_np_array blend of one value: trunc(fl32(fl32(1 - a) * dst) + fl32(a * val)), products rounded separately.
 __device__ __forceinline__ uint8_t blend_u8(uint8_t d, uint8_t v, float w1)
 {
@@ -344,6 +395,55 @@ VKX_EXPORT int vkx_mean_shift_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, in
     dim3 block(64, 4), grid(vkx_blocks((size_t)w * cn, 64), vkx_blocks(h, 4));
     { VKX_TIMED(ctx, "k_mean_shift"); k_mean_shift<<<grid, block, 0, ctx->stream>>>(src, h, w, cn, src_stride, dst, dst_stride, delta, has_threshold,
                                                   threshold, cycle, channel_mask); }
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_pointwise_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride, int op,
+                                    int p0, int p1, unsigned channel_mask, uint8_t *dst, ptrdiff_t dst_stride)
+{
+    int rc = check_plane(ctx, src, dst, h, w);
+    if (rc) return rc;
+    VKX_REQUIRE(cn >= 1 && cn <= 4, "1..4 channels");
+    VKX_REQUIRE(op >= VKX_POINT_COMPLEMENT && op <= VKX_POINT_PERMUTE, "unknown operator");
+    if (op == VKX_POINT_COMPLEMENT) VKX_REQUIRE(p0 >= -1 && p0 <= 255, "threshold must be -1 or in [0, 255]");
+    if (op == VKX_POINT_POSTERIZE) VKX_REQUIRE(p0 >= 0 && p0 < 8, "num_bits must be in [0, 7]");
+    if (op == VKX_POINT_PERMUTE) {
+        VKX_REQUIRE(src != dst, "channel permutation cannot run in place");
+        for (int c = 0; c < cn; c++) VKX_REQUIRE(((p0 >> (2 * c)) & 3) < cn, "permutation index out of range");
+    }
+    if (h == 0 || w == 0) return VKX_OK;
+    dim3 block(64, 4), grid(vkx_blocks((size_t)w * cn, 64), vkx_blocks(h, 4));
+    { VKX_TIMED(ctx, "k_pointwise"); k_pointwise<<<grid, block, 0, ctx->stream>>>(src, h, w, cn, src_stride, dst, dst_stride, op, p0, p1, channel_mask); }
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_impulse_noise_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                                        const uint8_t *selector, ptrdiff_t selector_stride, uint8_t *dst,
+                                        ptrdiff_t dst_stride)
+{
+    int rc = check_plane(ctx, src, dst, h, w);
+    if (rc) return rc;
+    VKX_REQUIRE(selector != nullptr, "NULL selector plane");
+    VKX_REQUIRE(cn >= 1 && cn <= 4, "1..4 channels");
+    if (h == 0 || w == 0) return VKX_OK;
+    dim3 block(64, 4), grid(vkx_blocks((size_t)w * cn, 64), vkx_blocks(h, 4));
+    { VKX_TIMED(ctx, "k_impulse_noise"); k_impulse_noise<<<grid, block, 0, ctx->stream>>>(src, h, w, cn, src_stride, selector, selector_stride, dst, dst_stride); }
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_speckle_noise_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                                        const double *noise, ptrdiff_t noise_stride_el, uint8_t *dst, ptrdiff_t dst_stride)
+{
+    int rc = check_plane(ctx, src, dst, h, w);
+    if (rc) return rc;
+    VKX_REQUIRE(noise != nullptr, "NULL noise plane");
+    VKX_REQUIRE(cn >= 1 && cn <= 4, "1..4 channels");
+    if (h == 0 || w == 0) return VKX_OK;
+    dim3 block(64, 4), grid(vkx_blocks((size_t)w * cn, 64), vkx_blocks(h, 4));
+    { VKX_TIMED(ctx, "k_speckle_noise"); k_speckle_noise<<<grid, block, 0, ctx->stream>>>(src, h, w * cn, src_stride, noise, noise_stride_el, dst, dst_stride); }
     VKX_LAUNCH_CHECK();
     return VKX_OK;
 }

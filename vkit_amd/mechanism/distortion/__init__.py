@@ -11,9 +11,27 @@ from .interface import (
 
 # photometric
 from .photometric.opt import OutOfBoundBehavior
-from .photometric.color import MeanShiftConfig, mean_shift, ColorShiftConfig, color_shift
+from .photometric.color import (
+    MeanShiftConfig,
+    mean_shift,
+    ColorShiftConfig,
+    color_shift,
+    ComplementConfig,
+    complement,
+    PosterizationConfig,
+    posterization,
+    ChannelPermutationConfig,
+    channel_permutation,
+)
 from .photometric.blur import GaussianBlurConfig, gaussian_blur
-from .photometric.noise import GaussionNoiseConfig, gaussion_noise
+from .photometric.noise import (
+    GaussionNoiseConfig,
+    gaussion_noise,
+    ImpulseNoiseConfig,
+    impulse_noise,
+    SpeckleNoiseConfig,
+    speckle_noise,
+)
 from .photometric.streak import LineStreakConfig, line_streak, RectangleStreakConfig, rectangle_streak
 
 # geometric

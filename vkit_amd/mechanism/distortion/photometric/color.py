@@ -1,8 +1,8 @@
-"""Colour distortions on the accelerated path: ``mean_shift`` and ``color_shift`` (reference:
-photometric/color.py:32-116).  The remaining colour operators of the reference (brightness / std shift,
-equalisations, complement, posterisation, colour balance, channel permutation) share the per-pixel pattern
-but are not part of this path yet."""
-from typing import Optional, Sequence
+"""Colour distortions on the accelerated path: ``mean_shift``, ``color_shift`` (reference:
+photometric/color.py:32-116) and the integer per-value members ``complement``, ``posterization``,
+``channel_permutation`` (:299-357, :400-432).  The remaining colour operators of the reference (brightness / std
+shift, equalisations, colour balance) need an HSL round trip or whole-image reductions and are not on the path."""
+from typing import Any, Mapping, Optional, Sequence
 
 import attrs
 from numpy.random import Generator as RandomGenerator
@@ -69,4 +69,82 @@ color_shift = Distortion(
     config_cls=ColorShiftConfig,
     state_cls=DistortionNopState[ColorShiftConfig],
     func_image=color_shift_image,
+)
+
+
+@attrs.define
+class ComplementConfig(DistortionConfig):
+    threshold: Optional[int] = None
+    enable_threshold_lte: bool = False
+    channels: Optional[Sequence[int]] = None
+
+
+def complement_image(config: ComplementConfig, state, image: Image, rng: Optional[RandomGenerator]):
+    """255 - v on the selected channels, optionally only where ``threshold <= v`` (or ``v <= threshold``)."""
+    if config.threshold is not None:
+        assert 0 <= config.threshold <= 255
+    mat = _native.pointwise(image.mat, _native.POINT_COMPLEMENT,
+                            -1 if config.threshold is None else int(config.threshold),
+                            int(config.enable_threshold_lte), channels=config.channels)
+    return attrs.evolve(image, mat=mat)
+
+
+complement = Distortion(
+    config_cls=ComplementConfig,
+    state_cls=DistortionNopState[ComplementConfig],
+    func_image=complement_image,
+)
+
+
+@attrs.define
+class PosterizationConfig(DistortionConfig):
+    num_bits: int
+    channels: Optional[Sequence[int]] = None
+
+
+def posterization_image(config: PosterizationConfig, state, image: Image, rng: Optional[RandomGenerator]):
+    """Clears the lower ``num_bits`` bits of the selected channels."""
+    assert 0 <= config.num_bits < 8
+    if config.num_bits == 0:
+        return image
+    mat = _native.pointwise(image.mat, _native.POINT_POSTERIZE, int(config.num_bits), channels=config.channels)
+    return attrs.evolve(image, mat=mat)
+
+
+posterization = Distortion(
+    config_cls=PosterizationConfig,
+    state_cls=DistortionNopState[PosterizationConfig],
+    func_image=posterization_image,
+)
+
+
+@attrs.define
+class ChannelPermutationConfig(DistortionConfig):
+    _rng_state: Optional[Mapping[str, Any]] = None
+
+    @property
+    def supports_rng_state(self) -> bool:
+        return True
+
+    @property
+    def rng_state(self) -> Optional[Mapping[str, Any]]:
+        return self._rng_state
+
+    @rng_state.setter
+    def rng_state(self, val: Mapping[str, Any]):
+        self._rng_state = val
+
+
+def channel_permutation_image(config: ChannelPermutationConfig, state, image: Image,
+                              rng: Optional[RandomGenerator]):
+    """``mat[:, :, rng.permutation(num_channels)]``: the permutation is drawn on the host, the gather runs on the GPU."""
+    assert rng
+    indices = rng.permutation(image.num_channels)
+    return attrs.evolve(image, mat=_native.permute_channels(image.mat, indices))
+
+
+channel_permutation = Distortion(
+    config_cls=ChannelPermutationConfig,
+    state_cls=DistortionNopState[ChannelPermutationConfig],
+    func_image=channel_permutation_image,
 )

@@ -1,4 +1,6 @@
-"""``gaussion_noise`` (sic, reference: photometric/noise.py:25-61).
+"""``gaussion_noise`` (sic, reference: photometric/noise.py:25-61), ``impulse_noise`` (:100-157) and
+``speckle_noise`` (:160-190).  ``poisson_noise`` is one ``rng.poisson`` call plus a clip -- all of it random-number
+generation on the caller's stream -- and stays outside the path.
 
 The samples come from the caller-visible numpy Generator stream -- ``np.round(rng.normal(0, std, shape))`` in C
 order, one draw per channel value -- so that a stored ``config.rng_state`` reproduces the same pixels; the add
@@ -49,4 +51,74 @@ gaussion_noise = Distortion(
     config_cls=GaussionNoiseConfig,
     state_cls=DistortionNopState[GaussionNoiseConfig],
     func_image=gaussion_noise_image,
+)
+
+
+@attrs.define
+class ImpulseNoiseConfig(DistortionConfig):
+    prob_salt: float
+    prob_pepper: float
+
+    _rng_state: Optional[Mapping[str, Any]] = None
+
+    @property
+    def supports_rng_state(self) -> bool:
+        return True
+
+    @property
+    def rng_state(self) -> Optional[Mapping[str, Any]]:
+        return self._rng_state
+
+    @rng_state.setter
+    def rng_state(self, val: Mapping[str, Any]):
+        self._rng_state = val
+
+
+def impulse_noise_image(config: ImpulseNoiseConfig, state, image: Image, rng: Optional[RandomGenerator]):
+    """Salt (255) / pepper (0) on whole pixels; the per-pixel selector is ``rng.choice((0, 1, 2), size=(H, W), p=...)``
+    on the caller-visible stream, the writes run on the GPU."""
+    assert rng
+    prob_presv = 1 - config.prob_salt - config.prob_pepper
+    assert prob_presv >= 0.0
+    selector = rng.choice((0, 1, 2), size=image.shape, p=[prob_presv, config.prob_salt, config.prob_pepper])
+    return Image(mat=_native.impulse_noise(image.mat, selector.astype(np.uint8)))
+
+
+impulse_noise = Distortion(
+    config_cls=ImpulseNoiseConfig,
+    state_cls=DistortionNopState[ImpulseNoiseConfig],
+    func_image=impulse_noise_image,
+)
+
+
+@attrs.define
+class SpeckleNoiseConfig(DistortionConfig):
+    std: float
+
+    _rng_state: Optional[Mapping[str, Any]] = None
+
+    @property
+    def supports_rng_state(self) -> bool:
+        return True
+
+    @property
+    def rng_state(self) -> Optional[Mapping[str, Any]]:
+        return self._rng_state
+
+    @rng_state.setter
+    def rng_state(self, val: Mapping[str, Any]):
+        self._rng_state = val
+
+
+def speckle_noise_image(config: SpeckleNoiseConfig, state, image: Image, rng: Optional[RandomGenerator]):
+    """``clip(px + px * N(0, std))`` with float64 samples, one per channel value in C order."""
+    assert rng
+    noise = rng.normal(0, config.std, image.mat.shape)
+    return Image(mat=_native.speckle_noise(image.mat, noise))
+
+
+speckle_noise = Distortion(
+    config_cls=SpeckleNoiseConfig,
+    state_cls=DistortionNopState[SpeckleNoiseConfig],
+    func_image=speckle_noise_image,
 )

@@ -1,11 +1,12 @@
-"""Config generators of ``mean_shift`` and ``color_shift`` (reference: distortion_policy/photometric/color.py:25-104)."""
+"""Config generators of ``mean_shift``, ``color_shift``, ``complement``, ``posterization`` and ``channel_permutation``
+(reference: distortion_policy/photometric/color.py:25-104, 221-284, 319-338)."""
 from typing import Tuple
 
 import attrs
 from numpy.random import Generator as RandomGenerator
 
 from vkit_amd.mechanism import distortion
-from ..opt import sample_channels, sample_int
+from ..opt import LEVEL_MAX, sample_channels, sample_int
 from ..type import DistortionConfigGenerator, DistortionPolicyFactory
 
 
@@ -48,3 +49,60 @@ class ColorShiftConfigGenerator(DistortionConfigGenerator[ColorShiftConfigGenera
 
 
 color_shift_policy_factory = DistortionPolicyFactory(distortion.color_shift, ColorShiftConfigGenerator)
+
+
+@attrs.define
+class ComplementConfigGeneratorConfig:
+    enable_threshold_level: int = 6
+    threshold_min: int = 77
+    threshold_max: int = 177
+
+
+class ComplementConfigGenerator(DistortionConfigGenerator[ComplementConfigGeneratorConfig, distortion.ComplementConfig]):
+
+    def __call__(self, shape: Tuple[int, int], rng: RandomGenerator):
+        channels = sample_channels(rng)
+        threshold = None
+        enable_threshold_lte = (rng.random() < 0.5)
+        if self.level >= self.config.enable_threshold_level:
+            threshold = rng.integers(self.config.threshold_min, self.config.threshold_max + 1)
+        return distortion.ComplementConfig(threshold=threshold, enable_threshold_lte=enable_threshold_lte,
+                                           channels=channels)
+
+
+complement_policy_factory = DistortionPolicyFactory(distortion.complement, ComplementConfigGenerator)
+
+
+@attrs.define
+class PosterizationConfigGeneratorConfig:
+    enable_threshold_level: int = 6
+    threshold_min: int = 77
+    threshold_max: int = 177
+
+
+class PosterizationConfigGenerator(
+        DistortionConfigGenerator[PosterizationConfigGeneratorConfig, distortion.PosterizationConfig]):
+
+    def __call__(self, shape: Tuple[int, int], rng: RandomGenerator):
+        num_bits = round(self.level / LEVEL_MAX * 7)   # to [1, 7]
+        channels = sample_channels(rng)
+        return distortion.PosterizationConfig(num_bits=num_bits, channels=channels)
+
+
+posterization_policy_factory = DistortionPolicyFactory(distortion.posterization, PosterizationConfigGenerator)
+
+
+@attrs.define
+class ChannelPermutationConfigGeneratorConfig:
+    pass
+
+
+class ChannelPermutationConfigGenerator(
+        DistortionConfigGenerator[ChannelPermutationConfigGeneratorConfig, distortion.ChannelPermutationConfig]):
+
+    def __call__(self, shape: Tuple[int, int], rng: RandomGenerator):
+        return distortion.ChannelPermutationConfig()
+
+
+channel_permutation_policy_factory = DistortionPolicyFactory(distortion.channel_permutation,
+                                                             ChannelPermutationConfigGenerator)

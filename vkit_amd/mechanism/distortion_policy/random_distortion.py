@@ -49,9 +49,8 @@ class _UnsupportedPolicyFactory:
 
 
 UNSUPPORTED_POLICY_NAMES = (
-    'brightness_shift', 'std_shift', 'boundary_equalization', 'histogram_equalization', 'complement',
-    'posterization', 'color_balance', 'channel_permutation', 'defocus_blur', 'motion_blur', 'glass_blur',
-    'zoom_in_blur', 'poisson_noise', 'impulse_noise', 'speckle_noise', 'jpeg_quality', 'pixelation', 'fog',
+    'brightness_shift', 'std_shift', 'boundary_equalization', 'histogram_equalization', 'color_balance',
+    'defocus_blur', 'motion_blur', 'glass_blur', 'zoom_in_blur', 'poisson_noise', 'jpeg_quality', 'pixelation', 'fog',
     'ellipse_streak',
 )
 _U = _UnsupportedPolicyFactory
@@ -270,11 +269,12 @@ class RandomDistortionFactoryConfig:
 # (policy factories of one family, summed weight of the family); order is the reference's.
 _PHOTOMETRIC_POLICY_FACTORIES_AND_DEFAULT_WEIGHTS_SUM_PAIRS = (
     ((color.mean_shift_policy_factory, color.color_shift_policy_factory, _U('brightness_shift'), _U('std_shift'),
-      _U('boundary_equalization'), _U('histogram_equalization'), _U('complement'), _U('posterization'),
-      _U('color_balance'), _U('channel_permutation')), 10.0),
+      _U('boundary_equalization'), _U('histogram_equalization'), color.complement_policy_factory,
+      color.posterization_policy_factory, _U('color_balance'), color.channel_permutation_policy_factory), 10.0),
     ((blur.gaussian_blur_policy_factory, _U('defocus_blur'), _U('motion_blur'), _U('glass_blur'),
       _U('zoom_in_blur')), 1.0),
-    ((noise.gaussion_noise_policy_factory, _U('poisson_noise'), _U('impulse_noise'), _U('speckle_noise')), 3.0),
+    ((noise.gaussion_noise_policy_factory, _U('poisson_noise'), noise.impulse_noise_policy_factory,
+      noise.speckle_noise_policy_factory), 3.0),
     ((_U('jpeg_quality'), _U('pixelation'), _U('fog')), 1.0),
     ((streak.line_streak_policy_factory, streak.rectangle_streak_policy_factory, _U('ellipse_streak')), 1.0),
 )
