@@ -1,8 +1,14 @@
 // fill_np_array (element/opt.py:118-209) as an ordered list of box-clipped layers blended in place on gfx950:
 // the text-layer alpha composite of PageAssemblerStep.run (pipeline/text_detection/page_assembler.py:155-236).
-// One launch per layer keeps the reference's layer order on the stream; lanes cover 64 consecutive pixels of a
-// box row so destination traffic is coalesced and untouched pixels are neither read nor written.
+// A single layer is one launch over its box (k_fill).  A layer LIST is binned on the host into 64 x 16 destination
+// tiles (CSR, ascending layer index = the reference's order) and applied by ONE launch (k_composite): a workgroup
+// owns a tile, every lane keeps its pixels in registers, walks the tile's layers in order and writes back once --
+// a page of hundreds of text-line layers costs one destination read and one write instead of one launch and one
+// read-modify-write per layer.  Lanes cover 64 consecutive pixels of a row so all plane traffic is coalesced;
+// untouched pixels are neither read nor written.
 #include "vkx_internal.h"
+
+#include <vector>
 
 namespace {
 
@@ -57,6 +63,118 @@ __global__ void __launch_bounds__(256) k_fill(T *dst, ptrdiff_t dstride, LayerDe
     }
 }
 
+constexpr int kTileW = 64, kTileH = 16;
+
+// All layers overlapping one tile, in order; registers hold the lane's kTileH / 4 pixels.
+template <typename T, int CN>
+__global__ void __launch_bounds__(256) k_composite(T *dst, ptrdiff_t dstride, int h, int w,
+                                                   const LayerDev<T> *__restrict__ layers,
+                                                   const int *__restrict__ tile_ids, const int *__restrict__ tile_begin,
+                                                   const int *__restrict__ tile_layers, int tiles_x)
+{
+    const int tile = tile_ids[blockIdx.x];
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int x = tx * kTileW + (threadIdx.x & 63);
+    const int ybase = ty * kTileH + (threadIdx.x >> 6);
+    constexpr int NR = kTileH / 4;
+    T px[NR][CN];
+    bool dirty[NR];
+    const bool xin = x < w;
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        const int y = ybase + 4 * r;
+        dirty[r] = false;
+#pragma unroll
+        for (int c = 0; c < CN; c++) px[r][c] = T(0);
+        if (xin && y < h) {
+            const T *d = dst + (ptrdiff_t)y * dstride + (ptrdiff_t)x * CN;
+#pragma unroll
+            for (int c = 0; c < CN; c++) px[r][c] = d[c];
+        }
+    }
+    const int lb = tile_begin[blockIdx.x], le = tile_begin[blockIdx.x + 1];
+    for (int li = lb; li < le; li++) {
+        const LayerDev<T> &L = layers[tile_layers[li]];      // uniform: scalar loads
+        const int bx = x - L.left;
+        if (bx < 0 || bx >= L.width) continue;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int by = ybase + 4 * r - L.up;
+            if (by < 0 || by >= L.height) continue;
+            const float a = L.alpha ? L.alpha[(ptrdiff_t)by * L.alpha_stride + bx] : L.alpha_scalar;
+            const bool sel = L.mask ? L.mask[(ptrdiff_t)by * L.mask_stride + bx] > 0 : (L.alpha ? a > 0.0f : true);
+            if (!sel) continue;
+            const T *v = L.value ? L.value + (ptrdiff_t)by * L.value_stride + (ptrdiff_t)bx * CN : nullptr;
+            if (L.copy) {
+#pragma unroll
+                for (int c = 0; c < CN; c++) {
+                    const T val = v ? v[c] : L.value_const[c];
+                    if (L.mode == VKX_FILL_PLAIN || (L.mode == VKX_FILL_KEEP_MAX ? px[r][c] < val : px[r][c] > val))
+                        px[r][c] = val;
+                }
+            } else {
+                const float w1 = a, w0 = 1.0f - w1;
+#pragma unroll
+                for (int c = 0; c < CN; c++) px[r][c] = blend_px(w0, w1, px[r][c], v ? v[c] : L.value_const[c]);
+            }
+            dirty[r] = true;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        if (!dirty[r]) continue;
+        T *d = dst + (ptrdiff_t)(ybase + 4 * r) * dstride + (ptrdiff_t)x * CN;
+#pragma unroll
+        for (int c = 0; c < CN; c++) d[c] = px[r][c];
+    }
+}
+
+// Host side of k_composite: bins `devl` (already validated, skippable layers removed) into tiles, stages the CSR and
+// the layer records in ctx->misc, launches.
+template <typename T, int CN>
+int composite_launch(vkx_ctx *ctx, T *dst, int h, int w, ptrdiff_t dstride, const std::vector<LayerDev<T>> &devl)
+{
+    const int tiles_x = (w + kTileW - 1) / kTileW, tiles_y = (h + kTileH - 1) / kTileH;
+    std::vector<int> count((size_t)tiles_x * tiles_y, 0);
+    for (const LayerDev<T> &L : devl)
+        for (int ty = L.up / kTileH; ty <= (L.up + L.height - 1) / kTileH; ty++)
+            for (int tx = L.left / kTileW; tx <= (L.left + L.width - 1) / kTileW; tx++) count[(size_t)ty * tiles_x + tx]++;
+    std::vector<int> tile_ids, tile_begin, slot((size_t)tiles_x * tiles_y, -1);
+    int total = 0;
+    for (size_t t = 0; t < count.size(); t++)
+        if (count[t]) {
+            slot[t] = (int)tile_ids.size();
+            tile_ids.push_back((int)t);
+            tile_begin.push_back(total);
+            total += count[t];
+        }
+    tile_begin.push_back(total);
+    std::vector<int> cursor(tile_begin.begin(), tile_begin.end() - 1), tile_layers((size_t)total);
+    for (size_t i = 0; i < devl.size(); i++) {
+        const LayerDev<T> &L = devl[i];
+        for (int ty = L.up / kTileH; ty <= (L.up + L.height - 1) / kTileH; ty++)
+            for (int tx = L.left / kTileW; tx <= (L.left + L.width - 1) / kTileW; tx++)
+                tile_layers[(size_t)cursor[slot[(size_t)ty * tiles_x + tx]]++] = (int)i;   // ascending i per tile
+    }
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o0 = 0, o1 = o0 + up(sizeof(LayerDev<T>) * devl.size()), o2 = o1 + up(sizeof(int) * tile_ids.size());
+    const size_t o3 = o2 + up(sizeof(int) * tile_begin.size()), bytes = o3 + up(sizeof(int) * tile_layers.size());
+    int rc = vkx_scratch_reserve(ctx, &ctx->misc, bytes);
+    if (rc) return rc;
+    unsigned char *base = (unsigned char *)ctx->misc.ptr;
+    VKX_HIP(hipMemcpyAsync(base + o0, devl.data(), sizeof(LayerDev<T>) * devl.size(), hipMemcpyHostToDevice, ctx->stream));
+    VKX_HIP(hipMemcpyAsync(base + o1, tile_ids.data(), sizeof(int) * tile_ids.size(), hipMemcpyHostToDevice, ctx->stream));
+    VKX_HIP(hipMemcpyAsync(base + o2, tile_begin.data(), sizeof(int) * tile_begin.size(), hipMemcpyHostToDevice, ctx->stream));
+    VKX_HIP(hipMemcpyAsync(base + o3, tile_layers.data(), sizeof(int) * tile_layers.size(), hipMemcpyHostToDevice, ctx->stream));
+    VKX_HIP(hipStreamSynchronize(ctx->stream)); // the vectors live on this frame
+    { VKX_TIMED(ctx, "k_composite");
+      k_composite<T, CN><<<(unsigned)tile_ids.size(), 256, 0, ctx->stream>>>(
+          dst, dstride, h, w, (const LayerDev<T> *)(base + o0), (const int *)(base + o1), (const int *)(base + o2),
+          (const int *)(base + o3), tiles_x); }
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
 template <typename LAYER>
 int check_layers(const LAYER *layers, int n_layers, int h, int w)
 {
@@ -81,6 +199,20 @@ int check_layers(const LAYER *layers, int n_layers, int h, int w)
 
 } // namespace
 
+template <typename T, typename LAYER>
+bool to_layer_dev(const LAYER &l, LayerDev<T> *L)
+{
+    if (l.height == 0 || l.width == 0) return false;
+    if (!l.alpha && l.alpha_scalar == 0.0) return false; // element/opt.py:143-144
+    L->up = l.up; L->left = l.left; L->height = l.height; L->width = l.width;
+    L->mask = l.mask; L->mask_stride = l.mask_stride;
+    L->alpha = l.alpha; L->alpha_stride = l.alpha_stride_el;
+    L->alpha_scalar = (float)l.alpha_scalar;
+    L->copy = !l.alpha && l.alpha_scalar == 1.0;
+    L->mode = l.mode;
+    return true;
+}
+
 VKX_EXPORT int vkx_fill_u8_dev(vkx_ctx *ctx, uint8_t *dst, int h, int w, int cn, ptrdiff_t dst_stride,
                                const vkx_layer *layers, int n_layers)
 {
@@ -89,28 +221,32 @@ VKX_EXPORT int vkx_fill_u8_dev(vkx_ctx *ctx, uint8_t *dst, int h, int w, int cn,
     VKX_REQUIRE(cn == 1 || cn == 3 || cn == 4, "1, 3 or 4 channels");
     int rc = check_layers(layers, n_layers, h, w);
     if (rc) return rc;
+    std::vector<LayerDev<uint8_t>> devl;
+    devl.reserve((size_t)n_layers);
     for (int i = 0; i < n_layers; i++) {
-        const vkx_layer &l = layers[i];
-        if (l.height == 0 || l.width == 0) continue;
-        if (!l.alpha && l.alpha_scalar == 0.0) continue; // element/opt.py:143-144
         LayerDev<uint8_t> L;
-        L.up = l.up; L.left = l.left; L.height = l.height; L.width = l.width;
-        L.mask = l.mask; L.mask_stride = l.mask_stride;
-        L.alpha = l.alpha; L.alpha_stride = l.alpha_stride_el;
-        L.value = l.value; L.value_stride = l.value_stride;
-        L.alpha_scalar = (float)l.alpha_scalar;
-        L.copy = !l.alpha && l.alpha_scalar == 1.0;
-        L.mode = l.mode;
-        for (int c = 0; c < 4; c++) L.value_const[c] = l.value_const[c];
-        dim3 block(64, 4), grid(vkx_blocks(l.width, 64), vkx_blocks(l.height, 4));
+        if (!to_layer_dev(layers[i], &L)) continue;
+        L.value = layers[i].value; L.value_stride = layers[i].value_stride;
+        for (int c = 0; c < 4; c++) L.value_const[c] = layers[i].value_const[c];
+        devl.push_back(L);
+    }
+    if (devl.empty()) return VKX_OK;
+    if (devl.size() == 1) {
+        const LayerDev<uint8_t> &L = devl[0];
+        dim3 block(64, 4), grid(vkx_blocks(L.width, 64), vkx_blocks(L.height, 4));
         switch (cn) {
         case 1: { VKX_TIMED(ctx, "k_fill"); k_fill<uint8_t, 1><<<grid, block, 0, ctx->stream>>>(dst, dst_stride, L); } break;
         case 3: { VKX_TIMED(ctx, "k_fill"); k_fill<uint8_t, 3><<<grid, block, 0, ctx->stream>>>(dst, dst_stride, L); } break;
         default: { VKX_TIMED(ctx, "k_fill"); k_fill<uint8_t, 4><<<grid, block, 0, ctx->stream>>>(dst, dst_stride, L); } break;
         }
         VKX_LAUNCH_CHECK();
+        return VKX_OK;
     }
-    return VKX_OK;
+    switch (cn) {
+    case 1: return composite_launch<uint8_t, 1>(ctx, dst, h, w, dst_stride, devl);
+    case 3: return composite_launch<uint8_t, 3>(ctx, dst, h, w, dst_stride, devl);
+    default: return composite_launch<uint8_t, 4>(ctx, dst, h, w, dst_stride, devl);
+    }
 }
 
 VKX_EXPORT int vkx_fill_f32_dev(vkx_ctx *ctx, float *dst, int h, int w, ptrdiff_t dst_stride_el,
@@ -120,22 +256,23 @@ VKX_EXPORT int vkx_fill_f32_dev(vkx_ctx *ctx, float *dst, int h, int w, ptrdiff_
     VKX_REQUIRE(n_layers >= 0 && (n_layers == 0 || layers), "bad layer list");
     int rc = check_layers(layers, n_layers, h, w);
     if (rc) return rc;
+    std::vector<LayerDev<float>> devl;
+    devl.reserve((size_t)n_layers);
     for (int i = 0; i < n_layers; i++) {
-        const vkx_layer_f32 &l = layers[i];
-        if (l.height == 0 || l.width == 0) continue;
-        if (!l.alpha && l.alpha_scalar == 0.0) continue;
         LayerDev<float> L;
-        L.up = l.up; L.left = l.left; L.height = l.height; L.width = l.width;
-        L.mask = l.mask; L.mask_stride = l.mask_stride;
-        L.alpha = l.alpha; L.alpha_stride = l.alpha_stride_el;
-        L.value = l.value; L.value_stride = l.value_stride_el;
-        L.alpha_scalar = (float)l.alpha_scalar;
-        L.copy = !l.alpha && l.alpha_scalar == 1.0;
-        L.mode = l.mode;
-        L.value_const[0] = l.value_const;
-        dim3 block(64, 4), grid(vkx_blocks(l.width, 64), vkx_blocks(l.height, 4));
+        if (!to_layer_dev(layers[i], &L)) continue;
+        L.value = layers[i].value; L.value_stride = layers[i].value_stride_el;
+        L.value_const[0] = layers[i].value_const;
+        L.value_const[1] = L.value_const[2] = L.value_const[3] = 0.f;
+        devl.push_back(L);
+    }
+    if (devl.empty()) return VKX_OK;
+    if (devl.size() == 1) {
+        const LayerDev<float> &L = devl[0];
+        dim3 block(64, 4), grid(vkx_blocks(L.width, 64), vkx_blocks(L.height, 4));
         { VKX_TIMED(ctx, "k_fill"); k_fill<float, 1><<<grid, block, 0, ctx->stream>>>(dst, dst_stride_el, L); }
         VKX_LAUNCH_CHECK();
+        return VKX_OK;
     }
-    return VKX_OK;
+    return composite_launch<float, 1>(ctx, dst, h, w, dst_stride_el, devl);
 }
