@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of one PMC group between two env settings.  Usage: tools_ab.sh "<counters>" "<envA>" "<envB>"
+# A/B of one PMC group between two env settings.  Usage: tools/ab.sh "<counters>" "<envA>" "<envB>"
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --batch 16 --steps 2 --warmup 1 --cpu-sample 0 --verify 0 --noise-workers 0"

@@ -1,5 +1,5 @@
 #!/bin/bash
-# timing A/B between library builds: tools_ab2.sh <libA> <libB> ...
+# timing A/B between library builds: tools/ab2.sh <libA> <libB> ...
 cd /root/repo
 for L in "$@"; do
   echo "== $L"

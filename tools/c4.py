@@ -2,6 +2,10 @@
 """C4-shaped page composite timing (device resident): 64 text-line score-map layers of 32 x 512 on a 1024^2 RGB page."""
 import ctypes
 import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import time
 
 import numpy as np

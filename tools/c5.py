@@ -2,6 +2,10 @@
 """C5 timing: one 4096^2 similarity_mls state applied to Image + Mask + ScoreMap (device resident, generic grid path),
 and C2-style single 2048^2 RGB image through the same path."""
 import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import time
 
 import numpy as np

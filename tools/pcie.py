@@ -3,6 +3,10 @@
 the same ChainBatch.  Upload (pageable numpy memory, synchronous vkx_upload) + one pass + download of every result.
 This is NOT the bench value (bench.py times with inputs resident in HBM)."""
 import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sys
 import time
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Collects rocprofv3 PMC counters for the bench (run on the GPU box via gpurun). Usage: tools_pmc.sh <tag> <batch>
+# Collects rocprofv3 PMC counters for the bench (run on the GPU box via gpurun). Usage: tools/pmc.sh <tag> <batch>
 # Each --pmc group is its own pass, with --kernel-trace only (no sys/hip/hsa tracing).
 TAG=${1:-r1}; BATCH=${2:-32}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}

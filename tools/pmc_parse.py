@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 outputs of tools_record.sh (gpurun_out/{stats,pmc}_<tag>) into the committed summaries:
+"""Turns the rocprofv3 outputs of tools/record.sh (gpurun_out/{stats,pmc}_<tag>) into the committed summaries:
 profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.md, profiles/<tag>_traffic.json.
 
 HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are collected in
 separate --pmc passes; both are reported in KiB; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 B, so it is
 doubled.  WRITE_SIZE is taken as reported (uncalibrated, stated as such).
-Usage: tools_pmc_parse.py <tag> <images-per-launch>"""
+Usage: tools/pmc_parse.py <tag> <images-per-launch>"""
 import csv
 import glob
 import json
@@ -14,7 +14,7 @@ import shutil
 import sys
 from collections import defaultdict
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
@@ -37,7 +37,7 @@ def main():
                 counts[short][row['Counter_Name']] += 1
     lines = [f'# rocprofv3 PMC counters, {tag}, bench.py --batch {images} --steps 2 --warmup 1 (per launch, mean over '
              'the dispatches of the run)', '',
-             'Separate `--pmc` passes with `--kernel-trace` only (tools_pmc.sh).  One launch covers the whole batch.', '']
+             'Separate `--pmc` passes with `--kernel-trace` only (tools/pmc.sh).  One launch covers the whole batch.', '']
     traffic = {}
     for kernel in sorted(sums):
         lines += [f'## {kernel}', '', '| counter | per launch | per image |', '|---|---|---|']

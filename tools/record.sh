@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round record on the GPU box: default bench line, rocprofv3 kernel stats (batch 64), PMC passes (batch 32).
-# Usage (through gpurun): ./tools_record.sh <tag>
+# Usage (through gpurun): ./tools/record.sh <tag>
 TAG=${1:-r1}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $ROOT/gpurun_out
@@ -10,4 +10,4 @@ cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/stats_$TAG -o stats -- \
     python $ROOT/bench.py --batch 64 --steps 3 --warmup 1 --cpu-sample 0 --verify 0 --noise-workers 0 \
     > $ROOT/gpurun_out/stats_$TAG.log 2>&1; echo "stats rc=$?"
-$ROOT/tools_pmc.sh $TAG 32
+$ROOT/tools/pmc.sh $TAG 32
