@@ -110,7 +110,8 @@ def main():
 
     import torch
     torch.cuda.set_device(local_rank)
-    group = shard.Group(backend='nccl' if world > 1 else None, device=torch.device('cuda', local_rank))
+    group = shard.Group(backend='nccl' if (world > 1 or 'MASTER_ADDR' in os.environ) else None,
+                        device=torch.device('cuda', local_rank))
 
     from vkit_amd import _native
     from vkit_amd.batch import ChainBatch

@@ -49,10 +49,12 @@ class Group:
         self.backend = backend
         self.device = device
         self._dist = None
-        if self.world > 1:
+        if self.world > 1 and backend is None:
+            raise ValueError('a backend is required when WORLD_SIZE > 1')
+        # a single rank launched by torch.distributed.run (MASTER_ADDR set) still forms a group when a backend is
+        # given, so that the 1-GPU driver run exercises the same RCCL path as the N-GPU one
+        if backend is not None and (self.world > 1 or 'MASTER_ADDR' in os.environ):
             import torch.distributed as dist
-            if backend is None:
-                raise ValueError('a backend is required when WORLD_SIZE > 1')
             kwargs = {}
             if backend == 'nccl' and device is not None:
                 kwargs['device_id'] = device
