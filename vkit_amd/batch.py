@@ -5,7 +5,7 @@ HBM between the geometric and the photometric members (BASELINE config 3).
 planes) and issues the whole batch with ONE ``vkx_chain_rgb_batch_dev`` call.  Images shard across GPUs by
 giving every process (one per GPU) its own ``ChainBatch``; there is no exchange step.
 """
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Optional, Tuple
 
 import numpy as np
 

@@ -59,7 +59,6 @@ struct ItemDev {
     int sh, sw, dh, dw;
     int rows, cols;
     int tiles_x, tiles_y;
-    int tile_base;     // index of this image's first tile in the batch-wide numbering
     int cell_base;     // index of this image's first cell in the batch-wide cell table
     int R;             // blur radius (0 = no blur); the tile proper is (64 - 2R) pixels wide and high
     int hue_on, hue_delta;
@@ -605,7 +604,7 @@ int vkx_chain_fused_try(vkx_ctx *ctx, const vkx_chain_item *items, int n_items)
         d.R = it.blur_ksize > 1 ? it.blur_ksize / 2 : 0;
         const int Tw = tile_side(d.R);
         d.tiles_x = (it.dw + Tw - 1) / Tw; d.tiles_y = (it.dh + Tw - 1) / Tw;
-        d.tile_base = (int)tiles; d.cell_base = (int)ncells;
+        d.cell_base = (int)ncells;
         d.hue_on = it.hue_enabled; d.hue_delta = it.hue_delta;
         for (int k = 0; k < 8; k++) d.kq[k] = 0;
         if (d.R > 0 && vkx_gaussian_kernel_q8_host(it.blur_ksize, it.blur_sigma, d.kq)) return VKX_ERR_UNSUPPORTED;

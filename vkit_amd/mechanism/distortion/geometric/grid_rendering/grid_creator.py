@@ -4,7 +4,6 @@ projected lattice is shifted so that its rounded minimum sits at the origin and 
 source size."""
 import numpy as np
 
-from vkit_amd.element import PointTuple
 from .image_grid import ImageGrid
 from .point_projector import PointProjector
 

@@ -19,7 +19,7 @@ from ..distortion.interface import Distortion, DistortionResult
 from .geometric import affine, camera, mls
 from .opt import LEVEL_MAX, LEVEL_MIN
 from .photometric import blur, color, noise, streak
-from .type import DistortionPolicy, DistortionPolicyFactory
+from .type import DistortionPolicy
 
 logger = logging.getLogger(__name__)
 
