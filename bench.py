@@ -169,9 +169,9 @@ def main():
     S, D = src_px / B, dst_px / B           # mean source / result pixels per image
     algorithmic = {                         # bytes a launch has to move at the very least
         'k_owner_remap': 3 * S + 3 * D,     # per-image launches ...
-        # ... and the batch-wide launches: one launch covers all B images.  3S + 3D for the images plus 6D for
-        # the int16 noise plane, which is an API input here.
-        'k_chain_fused': (3 * S + 3 * D + 6 * D) * B,
+        # ... and the batch-wide launches: one launch covers all B images.  SURVEY 8(d)'s figure for the fully
+        # fused geo+photo chain is 3S + 3D per image (~6.2 B per source pixel); that is the numerator used here.
+        'k_chain_fused': (3 * S + 3 * D) * B,
         'k_gaussian_blur': 3 * D + 3 * D,
         'k_hsv': 3 * D + 3 * D,
         'k_add_noise': 3 * D + 6 * D + 3 * D,
@@ -179,10 +179,15 @@ def main():
         'k_cell_setup': 0,
         'k_chain_setup': 0,
     }
+    # The int16 noise plane is an API input of this workload (host numpy Generator stream, SURVEY 8(d): "+6 D when
+    # host-generated int16 noise is an input"); the kernel has to read it, so it is reported next to the strict figure.
+    noise_input_bytes = 6 * D * B
     dominant = max(kernel_times, key=lambda k: kernel_times[k][0])
     dom_ms, dom_n = kernel_times[dominant]
     avg_s = dom_ms / 1e3 / max(dom_n, 1)
     achieved = algorithmic.get(dominant, 0) / avg_s / 1e9 if avg_s > 0 else 0.0
+    achieved_with_noise = ((algorithmic.get(dominant, 0) + (noise_input_bytes if dominant == 'k_chain_fused' else 0))
+                           / avg_s / 1e9 if avg_s > 0 else 0.0)
     chain_bytes = (3 * S + 3 * D) * B       # the fully fused figure for the whole chain, per step
     # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), measured in separate
     # rocprofv3 --pmc passes (profiles/) on the same workload and scaled by the number of images of this launch.
@@ -229,6 +234,11 @@ def main():
             'traffic_source': traffic_source,
             'avg_launch_ms': avg_s * 1e3,
             'algorithmic_bytes_per_launch': algorithmic.get(dominant, 0),
+            'noise_input_bytes_per_launch': noise_input_bytes if dominant == 'k_chain_fused' else 0,
+            'achieved_incl_noise_input': achieved_with_noise,
+            'frac_incl_noise_input': achieved_with_noise / HBM_PEAK_GBS,
+            'traffic_note': 'traffic = FETCH_SIZE x2 + WRITE_SIZE of separate --pmc passes; it contains the 6 D noise '
+                            'input that the strict 3S+3D numerator leaves out',
             'chain_frac': chain_bytes / kernel_sum_s / 1e9 / HBM_PEAK_GBS if kernel_sum_s > 0 else 0.0,
             'kernels_ms_per_step': {k: round(v[0] / args.steps, 3) for k, v in sorted(kernel_times.items())},
         },
