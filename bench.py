@@ -93,9 +93,18 @@ def main():
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
 
-    import __graft_entry__
-    if rank == 0 or not os.path.exists(os.path.join(ROOT, 'vkit_amd', 'libvkx.so')):
-        __graft_entry__.build()
+    # The libraries are prebuilt in-tree (__graft_entry__.build()); build here only when they are missing, on rank 0,
+    # while the other ranks wait -- never relink a library another rank may be loading.
+    libs = [os.path.join(ROOT, 'vkit_amd', 'libvkx.so'), os.path.join(ROOT, 'oracle', '_build', 'libvkx_oracle.so')]
+    if not all(os.path.exists(p) for p in libs):
+        if rank == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        else:
+            deadline = time.time() + 900
+            while not all(os.path.exists(p) for p in libs) and time.time() < deadline:
+                time.sleep(1.0)
+            time.sleep(2.0)
 
     B, size = args.batch, args.size
     first, _ = shard.weak_span(B, rank)  # global index of this rank's first image

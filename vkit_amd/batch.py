@@ -37,7 +37,10 @@ class ChainBatch:
             raise ValueError('ChainBatch takes HxWx3 uint8 images')
         sh, sw = image.shape[:2]
         dh, dw = state.result_shape
-        sv, dv = state.src_image_grid.vertices, state.dst_image_grid.vertices
+        sv = _native._vertices(state.src_image_grid.vertices)   # int32 [rows, cols, 2], whatever the caller holds
+        dv = _native._vertices(state.dst_image_grid.vertices)
+        if sv.shape != dv.shape:
+            raise ValueError('source / destination grids differ in shape')
         item = _native.VkxChainItem()
         item.src = self._put(image)
         item.dst = self.ctx.malloc(dh * dw * 3)
