@@ -161,6 +161,31 @@ int vkx_line_streak_u8(vkx_ctx *ctx, uint8_t *img, int h, int w, int cn, ptrdiff
                        int gap, int dash_thickness, int dash_gap, const uint8_t color[4], double alpha,
                        int enable_vert, int enable_hori);
 
+/* cv.cvtColor on uint8 images, the codes Image.to_target_mode_image uses (element/image.py:188-202,771-814).
+ * HSL images of the reference are HLS with the last two channels swapped on the host. */
+#define VKX_CVT_RGB2HSV_FULL 0
+#define VKX_CVT_HSV2RGB_FULL 1
+#define VKX_CVT_RGB2HLS_FULL 2
+#define VKX_CVT_HLS2RGB_FULL 3
+#define VKX_CVT_RGB2GRAY 4   /* [h, w, 3] -> [h, w]; not in place */
+#define VKX_CVT_GRAY2RGB 5   /* [h, w] -> [h, w, 3]; not in place */
+int vkx_cvt_color_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t src_stride, int code,
+                         uint8_t *dst, ptrdiff_t dst_stride);
+int vkx_cvt_color_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t src_stride, int code,
+                     uint8_t *dst, ptrdiff_t dst_stride);
+/* brightness_shift on RGB with the default HSL intermediate  photometric/color.py:125-160: RGB2HLS_FULL,
+ * L = clip(L + delta), HLS2RGB_FULL, one pass.  In place allowed. */
+int vkx_brightness_shift_rgb_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t src_stride, int delta,
+                                 uint8_t *dst, ptrdiff_t dst_stride);
+int vkx_brightness_shift_rgb(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t src_stride, int delta,
+                             uint8_t *dst, ptrdiff_t dst_stride);
+/* color_balance on RGB  photometric/color.py:364-397: uint8(clip(fl32(1 - ratio) * gray + fl32(ratio) * px)),
+ * gray = RGB2GRAY of the pixel.  In place allowed. */
+int vkx_color_balance_rgb_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t src_stride, double ratio,
+                              uint8_t *dst, ptrdiff_t dst_stride);
+int vkx_color_balance_rgb(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t src_stride, double ratio,
+                          uint8_t *dst, ptrdiff_t dst_stride);
+
 /* complement / posterization / channel_permutation  photometric/color.py:299-357, 423-432 (numpy only).
  *   VKX_POINT_COMPLEMENT  p0 = threshold or -1 (none), p1 = enable_threshold_lte: v = 255 - v where selected
  *   VKX_POINT_POSTERIZE   p0 = num_bits in [0, 7]: v &= (0xFF >> p0) << p0

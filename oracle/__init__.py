@@ -278,6 +278,35 @@ def fill(dst, box, value, mask=None, alpha=1.0, mode=FILL_PLAIN):
     return dst
 
 
+def _px3(fn, img, *args, out_channels=3):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    assert img.ndim == 3 and img.shape[2] == 3
+    out = np.empty(img.shape if out_channels == 3 else img.shape[:2], np.uint8)
+    rc = fn(_p(img), ctypes.c_size_t(img.shape[0] * img.shape[1]), *args, _p(out))
+    assert rc == 0
+    return out
+
+
+def rgb2hls_full(img):
+    return _px3(lib().vko_rgb2hls_full, img)
+
+
+def hls2rgb_full(img):
+    return _px3(lib().vko_hls2rgb_full, img)
+
+
+def rgb2gray(img):
+    return _px3(lib().vko_rgb2gray, img, out_channels=1)
+
+
+def brightness_shift_rgb(img, delta):
+    return _px3(lib().vko_brightness_shift_rgb, img, int(delta))
+
+
+def color_balance_rgb(img, ratio):
+    return _px3(lib().vko_color_balance_rgb, img, ctypes.c_double(ratio))
+
+
 def _chmask(channels):
     mask = 0
     for c in channels or ():

@@ -937,6 +937,124 @@ VKO_API int vko_color_shift_rgb(const uint8_t *src, size_t npx, int delta, uint8
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------
+ * [cv2] cv.cvtColor RGB2HLS_FULL / HLS2RGB_FULL / RGB2GRAY on uint8 -- element/image.py:188-202,771-814
+ * (HSL images are HLS with the last two channels swapped by the reference, :183-186,207-210).
+ * imgproc/color_hsv.simd.hpp RGB2HLS_b / HLS2RGB_b: 8-bit data go through the float formula (RGB2HLS_f /
+ * HLS2RGB_f, scalar path restated here; products and sums round separately), hrange = 256 for *_FULL;
+ * color_rgb.simd.hpp RGB2Gray<uchar>: 15-bit fixed point, (R*9798 + G*19235 + B*3735 + 2^14) >> 15.
+ * ---------------------------------------------------------------------------------- */
+static void rgb2hls_px(const uint8_t *p, uint8_t *q)
+{
+    float r = p[0] * (1.f / 255.f), g = p[1] * (1.f / 255.f), b = p[2] * (1.f / 255.f);
+    float h = 0.f, s = 0.f, l;
+    float vmin, vmax, diff;
+    vmax = vmin = r;
+    if (vmax < g) vmax = g;
+    if (vmax < b) vmax = b;
+    if (vmin > g) vmin = g;
+    if (vmin > b) vmin = b;
+    diff = vmax - vmin;
+    l = (vmax + vmin) * 0.5f;
+    if (diff > FLT_EPSILON) {
+        s = l < 0.5f ? diff / (vmax + vmin) : diff / (2 - vmax - vmin);
+        diff = 60.f / diff;
+        if (vmax == r) h = (g - b) * diff;
+        else if (vmax == g) h = (b - r) * diff + 120.f;
+        else h = (r - g) * diff + 240.f;
+        if (h < 0.f) h += 360.f;
+    }
+    const float hscale = 256.f / 360.f;
+    q[0] = sat_u8(cv_round_f(h * hscale));
+    q[1] = sat_u8(cv_round_f(l * 255.f));
+    q[2] = sat_u8(cv_round_f(s * 255.f));
+}
+
+static void hls2rgb_px(const uint8_t *p, uint8_t *q)
+{
+    float h = (float)p[0], l = p[1] * (1.f / 255.f), s = p[2] * (1.f / 255.f);
+    float b = l, g = l, r = l;
+    if (s != 0) {
+        static const int sector_data[][3] = { { 1, 3, 0 }, { 1, 0, 2 }, { 3, 0, 1 }, { 0, 2, 1 }, { 0, 1, 3 }, { 2, 1, 0 } };
+        float tab[4];
+        const float hscale = 6.f / 256.f;
+        float p2 = l <= 0.5f ? l * (1 + s) : l + s - l * s;
+        float p1 = 2 * l - p2;
+        h *= hscale;
+        if (h < 0) do h += 6; while (h < 0);
+        else if (h >= 6) do h -= 6; while (h >= 6);
+        int sector = (int)floorf(h);
+        h -= sector;
+        tab[0] = p2;
+        tab[1] = p1;
+        tab[2] = p1 + (p2 - p1) * (1 - h);
+        tab[3] = p1 + (p2 - p1) * h;
+        b = tab[sector_data[sector][0]];
+        g = tab[sector_data[sector][1]];
+        r = tab[sector_data[sector][2]];
+    }
+    q[0] = sat_u8(cv_round_f(r * 255.f));
+    q[1] = sat_u8(cv_round_f(g * 255.f));
+    q[2] = sat_u8(cv_round_f(b * 255.f));
+}
+
+VKO_API int vko_rgb2hls_full(const uint8_t *src, size_t npx, uint8_t *dst)
+{
+    for (size_t i = 0; i < npx; i++) rgb2hls_px(src + 3 * i, dst + 3 * i);
+    return 0;
+}
+
+VKO_API int vko_hls2rgb_full(const uint8_t *src, size_t npx, uint8_t *dst)
+{
+    for (size_t i = 0; i < npx; i++) hls2rgb_px(src + 3 * i, dst + 3 * i);
+    return 0;
+}
+
+static uint8_t rgb2gray_px(const uint8_t *p)
+{
+    return (uint8_t)((p[0] * 9798 + p[1] * 19235 + p[2] * 3735 + (1 << 14)) >> 15);
+}
+
+VKO_API int vko_rgb2gray(const uint8_t *src, size_t npx, uint8_t *dst)
+{
+    for (size_t i = 0; i < npx; i++) dst[i] = rgb2gray_px(src + 3 * i);
+    return 0;
+}
+
+/* brightness_shift on an RGB image with the default HSL intermediate -- photometric/color.py:125-160:
+ * RGB -> HLS_FULL, L = clip(L + delta) (the reference's channel 2 of its H,S,L order), HLS_FULL -> RGB. */
+VKO_API int vko_brightness_shift_rgb(const uint8_t *src, size_t npx, int delta, uint8_t *dst)
+{
+    for (size_t i = 0; i < npx; i++) {
+        uint8_t hls[3];
+        rgb2hls_px(src + 3 * i, hls);
+        if (delta != 0) {
+            int l = (int)hls[1] + delta;
+            hls[1] = (uint8_t)(l < 0 ? 0 : (l > 255 ? 255 : l));
+        }
+        hls2rgb_px(hls, dst + 3 * i);
+    }
+    return 0;
+}
+
+/* color_balance on an RGB image -- photometric/color.py:364-397: gray = RGB2GRAY replicated to 3 channels,
+ * float32 blend fl32(1 - ratio) * gray + fl32(ratio) * px (products and sum round separately), np.clip, astype. */
+VKO_API int vko_color_balance_rgb(const uint8_t *src, size_t npx, double ratio, uint8_t *dst)
+{
+    const float w0 = (float)(1 - ratio), w1 = (float)ratio;
+    for (size_t i = 0; i < npx; i++) {
+        const float gray = (float)rgb2gray_px(src + 3 * i);
+        for (int c = 0; c < 3; c++) {
+            float t0 = w0 * gray;
+            float t1 = w1 * (float)src[3 * i + c];
+            float v = t0 + t1;
+            v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
+            dst[3 * i + c] = (uint8_t)v;
+        }
+    }
+    return 0;
+}
+
 /* [numpy] mean_shift core: int16(px) + delta, optional threshold gate, CLIP or CYCLE
  * -- photometric/color.py:32-55, photometric/opt.py:41-57.  channels bit mask (0 = all). */
 VKO_API int vko_mean_shift_u8(const uint8_t *src, size_t npx, int cn, int delta, int has_thr,

@@ -316,6 +316,8 @@ def gen_policy_configs():
         'impulse_noise': (P_noise.ImpulseNoiseConfigGenerator, P_noise.ImpulseNoiseConfigGeneratorConfig),
         'speckle_noise': (P_noise.SpeckleNoiseConfigGenerator, P_noise.SpeckleNoiseConfigGeneratorConfig),
         'complement': (P_color.ComplementConfigGenerator, P_color.ComplementConfigGeneratorConfig),
+        'brightness_shift': (P_color.BrightnessShiftConfigGenerator, P_color.BrightnessShiftConfigGeneratorConfig),
+        'color_balance': (P_color.ColorBalanceConfigGenerator, P_color.ColorBalanceConfigGeneratorConfig),
         'posterization': (P_color.PosterizationConfigGenerator, P_color.PosterizationConfigGeneratorConfig),
         'channel_permutation': (P_color.ChannelPermutationConfigGenerator,
                                 P_color.ChannelPermutationConfigGeneratorConfig),

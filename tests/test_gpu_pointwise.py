@@ -86,3 +86,54 @@ def test_bad_arguments_are_refused():
         N.pointwise(src, 7)
     with pytest.raises(N.VkxError):
         N.pointwise(src, N.POINT_PERMUTE, 0b111111)  # index 3 on a 3-channel image
+
+
+def _rgb_cube():
+    v = np.arange(256, dtype=np.uint8)
+    return np.stack(np.meshgrid(v, v, v, indexing='ij'), axis=-1).reshape(4096, 4096, 3)
+
+
+def test_hls_gray_conversions_exhaustive():
+    """Every 24-bit colour through RGB2HLS_FULL, HLS2RGB_FULL, RGB2GRAY, brightness_shift and color_balance."""
+    from vkit_amd import _native as N
+    cube = _rgb_cube()
+    np.testing.assert_array_equal(N.cvt_color(cube, N.CVT_RGB2HLS_FULL), O.rgb2hls_full(cube))
+    np.testing.assert_array_equal(N.cvt_color(cube, N.CVT_HLS2RGB_FULL), O.hls2rgb_full(cube))
+    np.testing.assert_array_equal(N.cvt_color(cube, N.CVT_RGB2GRAY), O.rgb2gray(cube))
+    for delta in (0, 1, -37, 127, -127):
+        np.testing.assert_array_equal(N.brightness_shift_rgb(cube, delta), O.brightness_shift_rgb(cube, delta))
+    for ratio in (0.0, 0.123456789, 0.5, 0.999, 1.0):
+        np.testing.assert_array_equal(N.color_balance_rgb(cube, ratio), O.color_balance_rgb(cube, ratio))
+    gray = default_rng(1).integers(0, 256, (37, 41), dtype=np.uint8)
+    np.testing.assert_array_equal(N.cvt_color(gray, N.CVT_GRAY2RGB), np.repeat(gray[:, :, None], 3, axis=2))
+    with pytest.raises(N.VkxError):
+        N.color_balance_rgb(cube[:4, :4], 1.5)
+
+
+def test_image_modes_and_operators():
+    from vkit_amd.element import Image, ImageMode
+    from vkit_amd.mechanism import distortion as D
+    rng = default_rng(3)
+    rgb = Image(mat=rng.integers(0, 256, (45, 67, 3), dtype=np.uint8))
+    hsl = rgb.to_hsl_image()
+    assert hsl.mode == ImageMode.HSL
+    np.testing.assert_array_equal(hsl.mat, O.rgb2hls_full(rgb.mat)[:, :, [0, 2, 1]])
+    np.testing.assert_array_equal(hsl.to_rgb_image().mat, O.hls2rgb_full(O.rgb2hls_full(rgb.mat)))
+    gray = rgb.to_grayscale_image()
+    assert gray.mode == ImageMode.GRAYSCALE and gray.mat.ndim == 2
+    np.testing.assert_array_equal(gray.mat, O.rgb2gray(rgb.mat))
+    np.testing.assert_array_equal(gray.to_hsv_image().mat,
+                                  O.rgb2hsv_full(np.repeat(O.rgb2gray(rgb.mat)[:, :, None], 3, axis=2)))
+    # brightness_shift: fused RGB path == the reference's three-step path through an HSL image
+    out = D.brightness_shift.distort({'delta': 40}, image=rgb).image
+    np.testing.assert_array_equal(out.mat, O.brightness_shift_rgb(rgb.mat, 40))
+    stepwise = O.mean_shift(hsl.mat, 40, channels=[2])
+    np.testing.assert_array_equal(D.brightness_shift.distort({'delta': 40}, image=hsl).image.mat, stepwise)
+    np.testing.assert_array_equal(out.mat, O.hls2rgb_full(stepwise[:, :, [0, 2, 1]]))
+    # HSV intermediate on request
+    hsv_way = D.brightness_shift.distort({'delta': -25, 'intermediate_image_mode': 'hsv'}, image=rgb).image
+    np.testing.assert_array_equal(hsv_way.mat,
+                                  O.hsv2rgb_full(O.mean_shift(O.rgb2hsv_full(rgb.mat), -25, channels=[2])))
+    out = D.color_balance.distort({'ratio': 0.3}, image=rgb).image
+    np.testing.assert_array_equal(out.mat, O.color_balance_rgb(rgb.mat, 0.3))
+    assert D.color_balance.distort({'ratio': 0.3}, image=gray).image is gray

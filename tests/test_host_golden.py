@@ -53,6 +53,8 @@ GENERATORS = {
     'impulse_noise': (P_noise.ImpulseNoiseConfigGenerator, P_noise.ImpulseNoiseConfigGeneratorConfig),
     'speckle_noise': (P_noise.SpeckleNoiseConfigGenerator, P_noise.SpeckleNoiseConfigGeneratorConfig),
     'complement': (P_color.ComplementConfigGenerator, P_color.ComplementConfigGeneratorConfig),
+    'brightness_shift': (P_color.BrightnessShiftConfigGenerator, P_color.BrightnessShiftConfigGeneratorConfig),
+    'color_balance': (P_color.ColorBalanceConfigGenerator, P_color.ColorBalanceConfigGeneratorConfig),
     'posterization': (P_color.PosterizationConfigGenerator, P_color.PosterizationConfigGeneratorConfig),
     'channel_permutation': (P_color.ChannelPermutationConfigGenerator,
                             P_color.ChannelPermutationConfigGeneratorConfig),
@@ -76,7 +78,7 @@ def test_policy_configs_match_reference_draw_for_draw(golden_dir):
         # the generator consumed exactly the reference's number of draws
         assert float(rng.random()) == rec['next_random']
         checked += 1
-    assert checked > 340
+    assert checked > 370
 
 
 def test_affine_states(golden_dir):

@@ -139,6 +139,9 @@ for _sfx in ('', '_dev'):
     _SIGNATURES['vkx_mean_shift_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_int, c_int, c_int, c_int, c_uint, c_void_p,
                                                                         c_ssize]
     _SIGNATURES['vkx_add_noise_i16' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_ssize, c_void_p, c_ssize]
+    _SIGNATURES['vkx_cvt_color_u8' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_int, c_void_p, c_ssize]
+    _SIGNATURES['vkx_brightness_shift_rgb' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_int, c_void_p, c_ssize]
+    _SIGNATURES['vkx_color_balance_rgb' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_double, c_void_p, c_ssize]
     _SIGNATURES['vkx_pointwise_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_int, c_int, c_int, c_uint, c_void_p, c_ssize]
     _SIGNATURES['vkx_impulse_noise_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_ssize, c_void_p, c_ssize]
     _SIGNATURES['vkx_speckle_noise_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_ssize, c_void_p, c_ssize]
@@ -488,6 +491,40 @@ def mean_shift(img, delta, threshold=None, channels=None, cycle=False, ctx=None)
 
 
 POINT_COMPLEMENT, POINT_POSTERIZE, POINT_PERMUTE = 0, 1, 2
+CVT_RGB2HSV_FULL, CVT_HSV2RGB_FULL, CVT_RGB2HLS_FULL, CVT_HLS2RGB_FULL, CVT_RGB2GRAY, CVT_GRAY2RGB = range(6)
+
+
+def cvt_color(img, code, ctx=None):
+    """cv.cvtColor for the codes of include/vkx.h (VKX_CVT_*)."""
+    ctx = ctx or default_ctx()
+    img, h, w, cn, stride = _u8_plane(img)
+    want_cn = 1 if code == CVT_GRAY2RGB else 3
+    if cn != want_cn:
+        raise ValueError(f'conversion code {code} takes {want_cn}-channel input')
+    dst = np.empty((h, w) if code == CVT_RGB2GRAY else (h, w, 3), np.uint8)
+    check(lib().vkx_cvt_color_u8(ctx.handle, _ptr(img), h, w, stride, int(code), _ptr(dst),
+                                 w if code == CVT_RGB2GRAY else w * 3))
+    return dst
+
+
+def brightness_shift_rgb(img, delta, ctx=None):
+    ctx = ctx or default_ctx()
+    img, h, w, cn, stride = _u8_plane(img)
+    if cn != 3:
+        raise ValueError('expected an RGB image')
+    dst = np.empty_like(img)
+    check(lib().vkx_brightness_shift_rgb(ctx.handle, _ptr(img), h, w, stride, int(delta), _ptr(dst), stride))
+    return dst
+
+
+def color_balance_rgb(img, ratio, ctx=None):
+    ctx = ctx or default_ctx()
+    img, h, w, cn, stride = _u8_plane(img)
+    if cn != 3:
+        raise ValueError('expected an RGB image')
+    dst = np.empty_like(img)
+    check(lib().vkx_color_balance_rgb(ctx.handle, _ptr(img), h, w, stride, float(ratio), _ptr(dst), stride))
+    return dst
 
 
 def _channel_mask(channels):

@@ -401,3 +401,46 @@ VKX_EXPORT int vkx_speckle_noise_u8(vkx_ctx *ctx, const uint8_t *src, int h, int
                                      (ptrdiff_t)w * cn, st.dev<uint8_t>(d), (ptrdiff_t)w * cn));
     return st.finish();
 }
+
+VKX_EXPORT int vkx_cvt_color_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t src_stride, int code, uint8_t *dst,
+                                ptrdiff_t dst_stride)
+{
+    VKX_REQUIRE(ctx && src && dst, "NULL argument");
+    VKX_REQUIRE(h >= 0 && w >= 0, "bad shape");
+    const int scn = code == VKX_CVT_GRAY2RGB ? 1 : 3, dcn = code == VKX_CVT_RGB2GRAY ? 1 : 3;
+    HostStage st(ctx);
+    const int s = st.add(src, nullptr, (size_t)w * scn, h, src_stride);
+    const int d = st.add(nullptr, dst, (size_t)w * dcn, h, dst_stride);
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_cvt_color_u8_dev(ctx, st.dev<uint8_t>(s), h, w, (ptrdiff_t)w * scn, code, st.dev<uint8_t>(d),
+                                 (ptrdiff_t)w * dcn));
+    return st.finish();
+}
+
+VKX_EXPORT int vkx_brightness_shift_rgb(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t src_stride, int delta,
+                                        uint8_t *dst, ptrdiff_t dst_stride)
+{
+    VKX_REQUIRE(ctx && src && dst, "NULL argument");
+    VKX_REQUIRE(h >= 0 && w >= 0, "bad shape");
+    HostStage st(ctx);
+    const int s = st.add(src, nullptr, (size_t)w * 3, h, src_stride);
+    const int d = st.add(nullptr, dst, (size_t)w * 3, h, dst_stride);
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_brightness_shift_rgb_dev(ctx, st.dev<uint8_t>(s), h, w, (ptrdiff_t)w * 3, delta, st.dev<uint8_t>(d),
+                                         (ptrdiff_t)w * 3));
+    return st.finish();
+}
+
+VKX_EXPORT int vkx_color_balance_rgb(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t src_stride, double ratio,
+                                     uint8_t *dst, ptrdiff_t dst_stride)
+{
+    VKX_REQUIRE(ctx && src && dst, "NULL argument");
+    VKX_REQUIRE(h >= 0 && w >= 0, "bad shape");
+    HostStage st(ctx);
+    const int s = st.add(src, nullptr, (size_t)w * 3, h, src_stride);
+    const int d = st.add(nullptr, dst, (size_t)w * 3, h, dst_stride);
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_color_balance_rgb_dev(ctx, st.dev<uint8_t>(s), h, w, (ptrdiff_t)w * 3, ratio, st.dev<uint8_t>(d),
+                                      (ptrdiff_t)w * 3));
+    return st.finish();
+}

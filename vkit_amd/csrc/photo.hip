@@ -2,6 +2,8 @@
 // Arithmetic specification and reference citations: oracle/vkx_oracle.c.
 #include "vkx_internal.h"
 
+#include <float.h>
+
 #include <math.h>
 
 namespace {
@@ -169,6 +171,106 @@ __global__ void __launch_bounds__(256) k_hsv(const uint8_t *__restrict__ src, in
         int r, g, bl;
         hsv2rgb_px(a, b, c, r, g, bl);
         a = r; b = g; c = bl;
+    }
+    d[0] = (uint8_t)a; d[1] = (uint8_t)b; d[2] = (uint8_t)c;
+}
+
+// RGB2HLS_f / HLS2RGB_f through the 8-bit wrappers (color_hsv.simd.hpp, scalar path), hrange 256, no FMA.
+__device__ __forceinline__ void rgb2hls_px(int R, int G, int B, int &H, int &L, int &S)
+{
+    const float r = R * (1.f / 255.f), g = G * (1.f / 255.f), b = B * (1.f / 255.f);
+    float h = 0.f, s = 0.f;
+    const float vmax = fmaxf(r, fmaxf(g, b)), vmin = fminf(r, fminf(g, b));
+    float diff = vmax - vmin;
+    const float l = (vmax + vmin) * 0.5f;
+    if (diff > FLT_EPSILON) {
+        s = l < 0.5f ? diff / (vmax + vmin) : diff / (2 - vmax - vmin);
+        diff = 60.f / diff;
+        if (vmax == r) h = (g - b) * diff;
+        else if (vmax == g) h = (b - r) * diff + 120.f;
+        else h = (r - g) * diff + 240.f;
+        if (h < 0.f) h += 360.f;
+    }
+    const float hscale = 256.f / 360.f;
+    H = vkd::clamp_u8(vkd::cv_round(h * hscale));
+    L = vkd::clamp_u8(vkd::cv_round(l * 255.f));
+    S = vkd::clamp_u8(vkd::cv_round(s * 255.f));
+}
+
+__device__ __forceinline__ void hls2rgb_px(int H, int L, int S, int &R, int &G, int &B)
+{
+    float h = (float)H;
+    const float l = L * (1.f / 255.f), s = S * (1.f / 255.f);
+    float b = l, g = l, r = l;
+    if (s != 0) {
+        const float hscale = 6.f / 256.f;
+        const float p2 = l <= 0.5f ? l * (1 + s) : l + s - l * s;
+        const float p1 = 2 * l - p2;
+        h *= hscale;               // 0 <= h < 6 for every 8-bit hue
+        const int sector = (int)floorf(h);
+        h -= sector;
+        const float t0 = p2, t1 = p1, t2 = p1 + (p2 - p1) * (1 - h), t3 = p1 + (p2 - p1) * h;
+        switch (sector) {          // sector_data (b, g, r), the table of the HSV inverse
+        case 0: b = t1; g = t3; r = t0; break;
+        case 1: b = t1; g = t0; r = t2; break;
+        case 2: b = t3; g = t0; r = t1; break;
+        case 3: b = t0; g = t2; r = t1; break;
+        case 4: b = t0; g = t1; r = t3; break;
+        default: b = t2; g = t1; r = t0; break;
+        }
+    }
+    R = vkd::clamp_u8(vkd::cv_round(r * 255.f));
+    G = vkd::clamp_u8(vkd::cv_round(g * 255.f));
+    B = vkd::clamp_u8(vkd::cv_round(b * 255.f));
+}
+
+// RGB2Gray<uchar>: 15-bit fixed point
+__device__ __forceinline__ int rgb2gray_px(int R, int G, int B) { return (R * 9798 + G * 19235 + B * 3735 + (1 << 14)) >> 15; }
+
+// mode 0: brightness_shift (RGB -> HLS, L = clip(L + delta), HLS -> RGB); 1: RGB -> HLS; 2: HLS -> RGB;
+//      3: RGB -> GRAY (1 channel out); 4: GRAY -> RGB; 5: color_balance (w0 * gray + w1 * px, clip, truncate)
+template <int MODE>
+__global__ void __launch_bounds__(256) k_cvt(const uint8_t *__restrict__ src, int h, int w, ptrdiff_t sstride,
+                                             uint8_t *__restrict__ dst, ptrdiff_t dstride, int delta, float w0, float w1)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    constexpr int SCN = MODE == 4 ? 1 : 3, DCN = MODE == 3 ? 1 : 3;
+    const uint8_t *s = src + (ptrdiff_t)y * sstride + (ptrdiff_t)x * SCN;
+    uint8_t *d = dst + (ptrdiff_t)y * dstride + (ptrdiff_t)x * DCN;
+    if (MODE == 4) {
+        const uint8_t v = s[0];
+        d[0] = v; d[1] = v; d[2] = v;
+        return;
+    }
+    int a = s[0], b = s[1], c = s[2];
+    if (MODE == 3) {
+        d[0] = (uint8_t)rgb2gray_px(a, b, c);
+        return;
+    }
+    if (MODE == 5) {
+        const float gray = (float)rgb2gray_px(a, b, c);
+        const int in[3] = {a, b, c};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float t0 = w0 * gray, t1 = w1 * (float)in[k];
+            float v = t0 + t1;
+            v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
+            d[k] = (uint8_t)v;
+        }
+        return;
+    }
+    if (MODE == 0 || MODE == 1) {
+        int H, L, S;
+        rgb2hls_px(a, b, c, H, L, S);
+        a = H; b = L; c = S;
+    }
+    if (MODE == 0 && delta != 0) b = vkd::clamp_u8(b + delta);
+    if (MODE == 0 || MODE == 2) {
+        int R, G, B;
+        hls2rgb_px(a, b, c, R, G, B);
+        a = R; b = G; c = B;
     }
     d[0] = (uint8_t)a; d[1] = (uint8_t)b; d[2] = (uint8_t)c;
 }
@@ -382,6 +484,55 @@ VKX_EXPORT int vkx_cvt_rgb_hsv_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, i
 {
     return to_hsv ? launch_hsv<1>(ctx, src, h, w, src_stride, 0, dst, dst_stride)
                   : launch_hsv<2>(ctx, src, h, w, src_stride, 0, dst, dst_stride);
+}
+
+template <int MODE>
+static int launch_cvt(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t src_stride, int delta, float w0, float w1,
+                      uint8_t *dst, ptrdiff_t dst_stride)
+{
+    int rc = check_plane(ctx, src, dst, h, w);
+    if (rc) return rc;
+    if (h == 0 || w == 0) return VKX_OK;
+    dim3 block(64, 4), grid(vkx_blocks(w, 64), vkx_blocks(h, 4));
+    { VKX_TIMED(ctx, "k_cvt"); k_cvt<MODE><<<grid, block, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, delta, w0, w1); }
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_cvt_color_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t src_stride, int code,
+                                    uint8_t *dst, ptrdiff_t dst_stride)
+{
+    switch (code) {
+    case VKX_CVT_RGB2HLS_FULL: return launch_cvt<1>(ctx, src, h, w, src_stride, 0, 0.f, 0.f, dst, dst_stride);
+    case VKX_CVT_HLS2RGB_FULL: return launch_cvt<2>(ctx, src, h, w, src_stride, 0, 0.f, 0.f, dst, dst_stride);
+    case VKX_CVT_RGB2GRAY:
+        VKX_REQUIRE(src != dst, "RGB2GRAY cannot run in place");
+        return launch_cvt<3>(ctx, src, h, w, src_stride, 0, 0.f, 0.f, dst, dst_stride);
+    case VKX_CVT_GRAY2RGB:
+        VKX_REQUIRE(src != dst, "GRAY2RGB cannot run in place");
+        return launch_cvt<4>(ctx, src, h, w, src_stride, 0, 0.f, 0.f, dst, dst_stride);
+    case VKX_CVT_RGB2HSV_FULL: return vkx_cvt_rgb_hsv_u8_dev(ctx, src, h, w, src_stride, 1, dst, dst_stride);
+    case VKX_CVT_HSV2RGB_FULL: return vkx_cvt_rgb_hsv_u8_dev(ctx, src, h, w, src_stride, 0, dst, dst_stride);
+    default:
+        vkx_set_error("unknown colour conversion code %d", code);
+        return VKX_ERR_INVALID;
+    }
+}
+
+VKX_EXPORT int vkx_brightness_shift_rgb_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t src_stride, int delta,
+                                            uint8_t *dst, ptrdiff_t dst_stride)
+{
+    return launch_cvt<0>(ctx, src, h, w, src_stride, delta, 0.f, 0.f, dst, dst_stride);
+}
+
+VKX_EXPORT int vkx_color_balance_rgb_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t src_stride, double ratio,
+                                         uint8_t *dst, ptrdiff_t dst_stride)
+{
+    if (!(ratio >= 0.0 && ratio <= 1.0)) {
+        vkx_set_error("ratio=%g is invalid.", ratio);
+        return VKX_ERR_INVALID;
+    }
+    return launch_cvt<5>(ctx, src, h, w, src_stride, 0, (float)(1 - ratio), (float)ratio, dst, dst_stride);
 }
 
 VKX_EXPORT int vkx_mean_shift_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,

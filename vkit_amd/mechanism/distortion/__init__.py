@@ -22,6 +22,10 @@ from .photometric.color import (
     posterization,
     ChannelPermutationConfig,
     channel_permutation,
+    BrightnessShiftConfig,
+    brightness_shift,
+    ColorBalanceConfig,
+    color_balance,
 )
 from .photometric.blur import GaussianBlurConfig, gaussian_blur
 from .photometric.noise import (

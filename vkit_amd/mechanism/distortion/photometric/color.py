@@ -1,7 +1,8 @@
 """Colour distortions on the accelerated path: ``mean_shift``, ``color_shift`` (reference:
 photometric/color.py:32-116) and the integer per-value members ``complement``, ``posterization``,
-``channel_permutation`` (:299-357, :400-432).  The remaining colour operators of the reference (brightness / std
-shift, equalisations, colour balance) need an HSL round trip or whole-image reductions and are not on the path."""
+``channel_permutation`` (:299-357, :400-432), ``brightness_shift`` (:125-160) and ``color_balance`` (:360-397).  The
+remaining colour operators of the reference (std shift, the equalisations) need whole-image reductions in numpy's
+summation order and are not on the path."""
 from typing import Any, Mapping, Optional, Sequence
 
 import attrs
@@ -147,4 +148,54 @@ channel_permutation = Distortion(
     config_cls=ChannelPermutationConfig,
     state_cls=DistortionNopState[ChannelPermutationConfig],
     func_image=channel_permutation_image,
+)
+
+
+@attrs.define
+class BrightnessShiftConfig(DistortionConfig):
+    delta: int
+    intermediate_image_mode: ImageMode = ImageMode.HSL
+
+
+def brightness_shift_image(config: BrightnessShiftConfig, state, image: Image, rng: Optional[RandomGenerator]):
+    """Adds ``delta`` to the lightness (HSL) / value (HSV) channel with clipping.  An RGB image with the default HSL
+    intermediate takes one fused kernel (RGB -> HLS_FULL, L += delta, HLS_FULL -> RGB)."""
+    mode = image.mode
+    if mode == ImageMode.RGB and config.intermediate_image_mode == ImageMode.HSL:
+        return Image(mat=_native.brightness_shift_rgb(image.mat, config.delta), mode=ImageMode.RGB)
+    if mode not in (ImageMode.HSV, ImageMode.HSL):
+        assert config.intermediate_image_mode in (ImageMode.HSV, ImageMode.HSL)
+        image = image.to_target_mode_image(config.intermediate_image_mode)
+    image = _mean_shift(image, [2], config.delta, None, OutOfBoundBehavior.CLIP)
+    if mode not in (ImageMode.HSV, ImageMode.HSL):
+        image = image.to_target_mode_image(mode)
+    return image
+
+
+brightness_shift = Distortion(
+    config_cls=BrightnessShiftConfig,
+    state_cls=DistortionNopState[BrightnessShiftConfig],
+    func_image=brightness_shift_image,
+)
+
+
+@attrs.define
+class ColorBalanceConfig(DistortionConfig):
+    ratio: float
+
+
+def color_balance_image(config: ColorBalanceConfig, state, image: Image, rng: Optional[RandomGenerator]):
+    """Blend towards the grey version of the image: ``(1 - ratio) * gray + ratio * px`` in float32, truncated."""
+    if image.mode == ImageMode.GRAYSCALE:
+        return image
+    assert 0.0 <= config.ratio <= 1.0
+    if image.mode != ImageMode.RGB:
+        raise NotImplementedError(f'color_balance on image mode {image.mode} is outside the accelerated path')
+    return attrs.evolve(image, mat=_native.color_balance_rgb(image.mat, config.ratio))
+
+
+color_balance = Distortion(
+    config_cls=ColorBalanceConfig,
+    state_cls=DistortionNopState[ColorBalanceConfig],
+    func_image=color_balance_image,
 )

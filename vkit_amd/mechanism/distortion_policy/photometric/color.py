@@ -6,7 +6,7 @@ import attrs
 from numpy.random import Generator as RandomGenerator
 
 from vkit_amd.mechanism import distortion
-from ..opt import LEVEL_MAX, sample_channels, sample_int
+from ..opt import LEVEL_MAX, sample_channels, sample_float, sample_int
 from ..type import DistortionConfigGenerator, DistortionPolicyFactory
 
 
@@ -106,3 +106,37 @@ class ChannelPermutationConfigGenerator(
 
 channel_permutation_policy_factory = DistortionPolicyFactory(distortion.channel_permutation,
                                                              ChannelPermutationConfigGenerator)
+
+
+@attrs.define
+class BrightnessShiftConfigGeneratorConfig:
+    delta_max: int = 127
+    prob_negative: float = 0.5
+
+
+class BrightnessShiftConfigGenerator(
+        DistortionConfigGenerator[BrightnessShiftConfigGeneratorConfig, distortion.BrightnessShiftConfig]):
+
+    def __call__(self, shape: Tuple[int, int], rng: RandomGenerator):
+        return distortion.BrightnessShiftConfig(
+            delta=sample_int(self.level, 0, self.config.delta_max, self.config.prob_negative, rng))
+
+
+brightness_shift_policy_factory = DistortionPolicyFactory(distortion.brightness_shift, BrightnessShiftConfigGenerator)
+
+
+@attrs.define
+class ColorBalanceConfigGeneratorConfig:
+    ratio_min: float = 0.0
+    ratio_max: float = 1.0
+
+
+class ColorBalanceConfigGenerator(
+        DistortionConfigGenerator[ColorBalanceConfigGeneratorConfig, distortion.ColorBalanceConfig]):
+
+    def __call__(self, shape: Tuple[int, int], rng: RandomGenerator):
+        return distortion.ColorBalanceConfig(
+            ratio=sample_float(self.level, self.config.ratio_min, self.config.ratio_max, None, rng, inverse_level=True))
+
+
+color_balance_policy_factory = DistortionPolicyFactory(distortion.color_balance, ColorBalanceConfigGenerator)
