@@ -204,11 +204,12 @@ constexpr size_t kFusedLds = kLdsOwn + kLdsHbB + kLdsCellR + kLdsCellH + kLdsLut
 // INTERIOR: the tile's whole 64 x 64 window lies inside the image and its candidates fit one LDS chunk -- the common
 // case (about 89 % of the tiles of a 2048^2 page).  Border handling (row / column validity, BORDER_REFLECT_101 lane tables,
 // the global-memory fallback for candidates beyond the chunk) compiles away; the arithmetic is the same.
-template <bool INTERIOR>
+template <int KIND>   // 0 generic, 1 interior, 2 empty
 __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, const int tile_id,
                                            const vkc::CellC *__restrict__ cells, const TileBin &bin,
                                            const HsvLut *__restrict__ lut, int phase_limit)
 {
+    constexpr bool INTERIOR = KIND == 1, EMPTY = KIND == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // `own` holds owner tags during phases A / C with a row-dependent column rotation ((x + row) & 63, against
     // bank conflicts of the raster), then the horizontal sums / packed pixels of phases D / E unrotated.
@@ -257,232 +258,235 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
         }
     };
 
-    // ---- A: clear the ownership plane, then rasterise the candidates chunk by chunk out of LDS
-#pragma unroll
-    for (int i = 0; i < W * W / NTHREADS / 4; i++) ((uint4 *)own)[tid + i * NTHREADS] = make_uint4(0, 0, 0, 0);
-    if (it.hue_on) {
-        if (tid < 256) lsdiv[tid] = lut->sdiv[tid];
-        else lhdiv[tid - 256] = lut->hdiv[tid - 256];
-    }
-    for (int base = 0; base < max(nc, 1); base += NLDSCELL) {
-        const int cn_ = min(NLDSCELL, nc - base);
-        if (base > 0) __syncthreads();            // the previous chunk is still being read
-        load_chunk(base, cn_);
-        __syncthreads();
-        // Work list of the chunk: for every candidate the window rows its scanlines can touch (compacted with a
-        // prefix sum so that no lane idles on rows outside the cell), then one item per (candidate, edge).
-        int *lpref = (int *)hbB;                 // [NLDSCELL + 1] exclusive prefix of row counts (hbB is free in A)
-        int *lylo = lpref + NLDSCELL + 1;        // [NLDSCELL] first window row of each candidate
-        if (wave == 0) {
-            int hk = 0, ylo = 0;
-            if (lane < cn_) {
-                const CellR &c = lcr[lane];
-                int vmin = INT_MAX, vmax = INT_MIN;
-#pragma unroll
-                for (int i = 0; i < 4; i++) { vmin = min(vmin, (int)c.vy[i]); vmax = max(vmax, (int)c.vy[i]); }
-                ylo = max(vmin, cy0);
-                hk = max(0, min(vmax, cy1) - ylo);    // scanlines vmin <= y < vmax
-            }
-            int incl = hk;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int t = __shfl_up(incl, d, 64);
-                if (lane >= d) incl += t;
-            }
-            lpref[lane + 1] = incl;
-            if (lane == 0) lpref[0] = 0;
-            lylo[lane] = ylo;
-        }
-        __syncthreads();
-        const int nrows = lpref[NLDSCELL];
-        // A.1 interior: spans [ceil(xa), floor(xb)] of the x-sorted edge crossings (16.16 fixed point) of one
-        //     (candidate, scanline) item, clipped to the window
-        for (int p = tid; p < nrows; p += NTHREADS) {
-            int lo = 0, hi = cn_ - 1;            // largest kk with lpref[kk] <= p
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (lpref[mid] <= p) lo = mid; else hi = mid - 1;
-            }
-            const int kk = lo;
-            const int y = lylo[kk] + (p - lpref[kk]);
-            const int row = y - wy0;
-            const CellR &c = lcr[kk];
-            const uint32_t tag = (uint32_t)(base + kk) + 1;
-            int xs[4], n = 0, xmin = INT_MAX, xmax = INT_MIN;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int a = (i + 3) & 3;
-                const int ya = c.vy[a], yb = c.vy[i];
-                xmin = min(xmin, (int)c.vx[i]);
-                xmax = max(xmax, (int)c.vx[i]);
-                const int e0 = min(ya, yb), e1 = max(ya, yb);
-                if (e0 != e1 && e0 <= y && y < e1) xs[n++] = c.ex[i] + (y - e0) * c.edx[i];
-            }
-            for (int a = 1; a < n; a++) {
-                const int v = xs[a];
-                int b = a - 1;
-                while (b >= 0 && xs[b] > v) { xs[b + 1] = xs[b]; b--; }
-                xs[b + 1] = v;
-            }
-            const bool check = c.flags & 1;
-            const double h6 = check ? lch[kk * 9 + 6] : 0.0, h7 = check ? lch[kk * 9 + 7] : 0.0;
-            uint32_t *o = own + row * W;
-            for (int a = 0; a + 1 < n; a += 2) {
-                const int x1 = max(max((xs[a] + 65535) >> 16, xmin), cx0);
-                const int x2 = min(min(xs[a + 1] >> 16, xmax), cx1 - 1);
-                for (int x = x1; x <= x2; x++) {
-                    if (check && fma(1.0, 1.0, fma(h7, (double)y, h6 * (double)x)) == 0) continue;
-                    atomicMax(o + ((x - wx0 + row) & 63), tag);   // swizzled column, see the note at `own`
-                }
-            }
-        }
-        // A.2 outline: one (candidate, edge) pair per step; 8-connected Bresenham from the edge's left end,
-        //     advanced incrementally (cv::LineIterator) over the part of the edge inside the window
-        for (int p = tid; p < cn_ * 4; p += NTHREADS) {
-            const int kk = p >> 2, i = p & 3;
-            const CellR &c = lcr[kk];
-            const uint32_t tag = (uint32_t)(base + kk) + 1;
-            const int a = (i + 3) & 3;
-            int lx = c.vx[a], ly = c.vy[a], rx = c.vx[i], ry = c.vy[i];
-            if (rx < lx) { const int t1 = lx, t2 = ly; lx = rx; ly = ry; rx = t1; ry = t2; }
-            const int dx = rx - lx, dy = ry - ly, ady = dy < 0 ? -dy : dy, sy = dy < 0 ? -1 : 1;
-            const bool ymajor = ady > dx;
-            const int dmaj = ymajor ? ady : dx, dmin = ymajor ? dx : ady;
-            int k0, k1;   // range of major steps whose pixel can lie inside the window
-            if (ymajor) {
-                if (sy > 0) { k0 = max(0, cy0 - ly); k1 = min(ady, cy1 - 1 - ly); }
-                else        { k0 = max(0, ly - (cy1 - 1)); k1 = min(ady, ly - cy0); }
-            } else {
-                k0 = max(0, cx0 - lx); k1 = min(dx, cx1 - 1 - lx);
-            }
-            if (k0 > k1) continue;
-            int m = vkc::bres_minor(k0, dmaj, dmin);
-            // LineIterator's error term after k0 steps: err = dmaj - 2 dmin (k0 + 1) + 2 dmaj m
-            long long err = (long long)dmaj - 2LL * dmin * (k0 + 1) + 2LL * dmaj * m;
-            const bool check = c.flags & 1;
-            const double h6 = check ? lch[kk * 9 + 6] : 0.0, h7 = check ? lch[kk * 9 + 7] : 0.0;
-            for (int s = k0; s <= k1; s++) {
-                const int x = ymajor ? lx + m : lx + s;
-                const int y = ymajor ? ly + sy * s : ly + sy * m;
-                if (x >= cx0 && x < cx1 && y >= cy0 && y < cy1 &&
-                    !(check && fma(1.0, 1.0, fma(h7, (double)y, h6 * (double)x)) == 0))
-                    atomicMax(own + (y - wy0) * W + ((x - wx0 + y - wy0) & 63), tag);
-                const bool step = err < 0;
-                err += -2LL * dmin + (step ? 2LL * dmaj : 0LL);
-                m += step ? 1 : 0;
-            }
-        }
-    }
-    __syncthreads();
-    if (phase_limit == 1) return;
-
-    // If the candidates did not fit one chunk, LDS now holds the LAST chunk; phase C wants chunk 0.
-    if (!INTERIOR && nc > NLDSCELL) {
-        load_chunk(0, NLDSCELL);
-        __syncthreads();
-    }
-
-    // ---- C + D: every wavefront owns 8 consecutive window rows; CGROUP rows at a time so that the fp64 chains
-    //      and the gathers of several rows overlap.  Lane = window column.
     uint32_t kq[2 * RMAX + 1];
 #pragma unroll
     for (int i = 0; i < 2 * RMAX + 1; i++) kq[i] = (R > 0 && i < K) ? it.kq[i] : 0;
-    const int gx = wx0 + lane;
-    const bool colok = INTERIOR || (gx >= cx0 && gx < cx1);
-    int srcl[2 * RMAX + 1];   // lane holding tap i of this lane's horizontal stencil (BORDER_REFLECT_101)
+    if constexpr (!EMPTY) {
+        // ---- A: clear the ownership plane, then rasterise the candidates chunk by chunk out of LDS
 #pragma unroll
-    for (int i = 0; i < 2 * RMAX + 1; i++) {
-        int s = (R > 0 && i < K) ? (INTERIOR ? lane + i - R : reflect101(gx + i - R, dw) - wx0) : lane;
-        srcl[i] = min(max(s, 0), W - 1);
-    }
-    for (int g0 = 0; g0 < ROWS_PER_WAVE; g0 += CGROUP) {
-        int X[CGROUP], Y[CGROUP];
-        bool rowok[CGROUP];
+        for (int i = 0; i < W * W / NTHREADS / 4; i++) ((uint4 *)own)[tid + i * NTHREADS] = make_uint4(0, 0, 0, 0);
+        if (it.hue_on) {
+            if (tid < 256) lsdiv[tid] = lut->sdiv[tid];
+            else lhdiv[tid - 256] = lut->hdiv[tid - 256];
+        }
+        for (int base = 0; base < max(nc, 1); base += NLDSCELL) {
+            const int cn_ = min(NLDSCELL, nc - base);
+            if (base > 0) __syncthreads();            // the previous chunk is still being read
+            load_chunk(base, cn_);
+            __syncthreads();
+            // Work list of the chunk: for every candidate the window rows its scanlines can touch (compacted with a
+            // prefix sum so that no lane idles on rows outside the cell), then one item per (candidate, edge).
+            int *lpref = (int *)hbB;                 // [NLDSCELL + 1] exclusive prefix of row counts (hbB is free in A)
+            int *lylo = lpref + NLDSCELL + 1;        // [NLDSCELL] first window row of each candidate
+            if (wave == 0) {
+                int hk = 0, ylo = 0;
+                if (lane < cn_) {
+                    const CellR &c = lcr[lane];
+                    int vmin = INT_MAX, vmax = INT_MIN;
 #pragma unroll
-        for (int u = 0; u < CGROUP; u++) {
-            const int ly = wave * ROWS_PER_WAVE + g0 + u;
-            const int gy = wy0 + ly;
-            rowok[u] = INTERIOR || (gy >= cy0 && gy < cy1);
-            X[u] = 0; Y[u] = 0;
-            if (rowok[u] && colok) {
-                const uint32_t o = own[ly * W + ((lane + ly) & 63)];
-                if (o != 0) {
-                    const int k = (int)o - 1;
-                    double h[8];
-                    if (INTERIOR || k < NLDSCELL) {
+                    for (int i = 0; i < 4; i++) { vmin = min(vmin, (int)c.vy[i]); vmax = max(vmax, (int)c.vy[i]); }
+                    ylo = max(vmin, cy0);
+                    hk = max(0, min(vmax, cy1) - ylo);    // scanlines vmin <= y < vmax
+                }
+                int incl = hk;
 #pragma unroll
-                        for (int j = 0; j < 8; j++) h[j] = lch[k * 9 + j];
-                    } else {
-                        const vkc::CellC VKX_GLOBAL *gc =
-                            (const vkc::CellC VKX_GLOBAL *)(gcell + (r0 + k / ncol) * cw + (c0 + k % ncol));
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int t = __shfl_up(incl, d, 64);
+                    if (lane >= d) incl += t;
+                }
+                lpref[lane + 1] = incl;
+                if (lane == 0) lpref[0] = 0;
+                lylo[lane] = ylo;
+            }
+            __syncthreads();
+            const int nrows = lpref[NLDSCELL];
+            // A.1 interior: spans [ceil(xa), floor(xb)] of the x-sorted edge crossings (16.16 fixed point) of one
+            //     (candidate, scanline) item, clipped to the window
+            for (int p = tid; p < nrows; p += NTHREADS) {
+                int lo = 0, hi = cn_ - 1;            // largest kk with lpref[kk] <= p
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (lpref[mid] <= p) lo = mid; else hi = mid - 1;
+                }
+                const int kk = lo;
+                const int y = lylo[kk] + (p - lpref[kk]);
+                const int row = y - wy0;
+                const CellR &c = lcr[kk];
+                const uint32_t tag = (uint32_t)(base + kk) + 1;
+                int xs[4], n = 0, xmin = INT_MAX, xmax = INT_MIN;
 #pragma unroll
-                        for (int j = 0; j < 8; j++) h[j] = gc->H[j];
+                for (int i = 0; i < 4; i++) {
+                    const int a = (i + 3) & 3;
+                    const int ya = c.vy[a], yb = c.vy[i];
+                    xmin = min(xmin, (int)c.vx[i]);
+                    xmax = max(xmax, (int)c.vx[i]);
+                    const int e0 = min(ya, yb), e1 = max(ya, yb);
+                    if (e0 != e1 && e0 <= y && y < e1) xs[n++] = c.ex[i] + (y - e0) * c.edx[i];
+                }
+                for (int a = 1; a < n; a++) {
+                    const int v = xs[a];
+                    int b = a - 1;
+                    while (b >= 0 && xs[b] > v) { xs[b + 1] = xs[b]; b--; }
+                    xs[b + 1] = v;
+                }
+                const bool check = c.flags & 1;
+                const double h6 = check ? lch[kk * 9 + 6] : 0.0, h7 = check ? lch[kk * 9 + 7] : 0.0;
+                uint32_t *o = own + row * W;
+                for (int a = 0; a + 1 < n; a += 2) {
+                    const int x1 = max(max((xs[a] + 65535) >> 16, xmin), cx0);
+                    const int x2 = min(min(xs[a + 1] >> 16, xmax), cx1 - 1);
+                    for (int x = x1; x <= x2; x++) {
+                        if (check && fma(1.0, 1.0, fma(h7, (double)y, h6 * (double)x)) == 0) continue;
+                        atomicMax(o + ((x - wx0 + row) & 63), tag);   // swizzled column, see the note at `own`
                     }
-                    const double fx = (double)gx, fy = (double)gy;
-                    const double nx = fma(h[2], 1.0, fma(h[1], fy, h[0] * fx));
-                    const double ny = fma(h[5], 1.0, fma(h[4], fy, h[3] * fx));
-                    const double de = fma(1.0, 1.0, fma(h[7], fy, h[6] * fx));
-                    X[u] = vkd::cv_round((float)(nx / de) * 32.f);
-                    Y[u] = vkd::cv_round((float)(ny / de) * 32.f);
                 }
             }
-        }
-        unsigned long long ta[CGROUP], tb[CGROUP];
-        bool fast[CGROUP];
-#pragma unroll
-        for (int u = 0; u < CGROUP; u++) {
-            const int sx = vkd::sat_short(X[u] >> 5), sy = vkd::sat_short(Y[u] >> 5);
-            fast[u] = rowok[u] && colok && sx >= 0 && sx + 2 < sw && sy >= 0 && sy + 1 < sh;
-            ta[u] = 0; tb[u] = 0;
-            if (fast[u]) {
-                // interior: the two 6-byte tap pairs come in as two unaligned 8-byte loads (3 sx + 8 <= 3 sw)
-                const gsrc_t q0 = src + (ptrdiff_t)sy * sstride + (ptrdiff_t)sx * 3;
-                ta[u] = *(const u64_u1 VKX_GLOBAL *)q0;
-                tb[u] = *(const u64_u1 VKX_GLOBAL *)(q0 + sstride);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < CGROUP; u++) {
-            const int ly = wave * ROWS_PER_WAVE + g0 + u;
-            if (!rowok[u]) continue;                     // uniform over the wavefront
-            uint32_t px = 0;
-            if (colok) {
-                const int fx = X[u] & 31, fy = Y[u] & 31;
-                const int w00 = (32 - fy) * (32 - fx), w01 = (32 - fy) * fx, w10 = fy * (32 - fx), w11 = fy * fx;
-                if (fast[u]) {
-#pragma unroll
-                    for (int k = 0; k < 3; k++) {
-                        const int v0 = (int)((ta[u] >> (8 * k)) & 0xff), v1 = (int)((ta[u] >> (8 * (k + 3))) & 0xff);
-                        const int v2 = (int)((tb[u] >> (8 * k)) & 0xff), v3 = (int)((tb[u] >> (8 * (k + 3))) & 0xff);
-                        px |= (uint32_t)((v0 * w00 + v1 * w01 + v2 * w10 + v3 * w11 + 512) >> 10) << (8 * k);
-                    }
+            // A.2 outline: one (candidate, edge) pair per step; 8-connected Bresenham from the edge's left end,
+            //     advanced incrementally (cv::LineIterator) over the part of the edge inside the window
+            for (int p = tid; p < cn_ * 4; p += NTHREADS) {
+                const int kk = p >> 2, i = p & 3;
+                const CellR &c = lcr[kk];
+                const uint32_t tag = (uint32_t)(base + kk) + 1;
+                const int a = (i + 3) & 3;
+                int lx = c.vx[a], ly = c.vy[a], rx = c.vx[i], ry = c.vy[i];
+                if (rx < lx) { const int t1 = lx, t2 = ly; lx = rx; ly = ry; rx = t1; ry = t2; }
+                const int dx = rx - lx, dy = ry - ly, ady = dy < 0 ? -dy : dy, sy = dy < 0 ? -1 : 1;
+                const bool ymajor = ady > dx;
+                const int dmaj = ymajor ? ady : dx, dmin = ymajor ? dx : ady;
+                int k0, k1;   // range of major steps whose pixel can lie inside the window
+                if (ymajor) {
+                    if (sy > 0) { k0 = max(0, cy0 - ly); k1 = min(ady, cy1 - 1 - ly); }
+                    else        { k0 = max(0, ly - (cy1 - 1)); k1 = min(ady, ly - cy0); }
                 } else {
-                    uint8_t p3[3];
-                    vkd::sample_u8<3>(it.src, sh, sw, sstride, X[u], Y[u], p3);
-                    px = (uint32_t)p3[0] | ((uint32_t)p3[1] << 8) | ((uint32_t)p3[2] << 16);
+                    k0 = max(0, cx0 - lx); k1 = min(dx, cx1 - 1 - lx);
                 }
-            }
-            if (R > 0) {
-                // D: horizontal u8 x 8.8 pass; tap i of lane l lives in lane srcl[i]
-                uint32_t a0 = 0, a1 = 0, a2 = 0;
-#pragma unroll
-                for (int i = 0; i < 2 * RMAX + 1; i++) {
-                    if (i < K) {
-                        const uint32_t v = (uint32_t)__shfl((int)px, srcl[i], 64);
-                        a0 += kq[i] * (v & 0xff);
-                        a1 += kq[i] * ((v >> 8) & 0xff);
-                        a2 += kq[i] * ((v >> 16) & 0xff);
-                    }
+                if (k0 > k1) continue;
+                int m = vkc::bres_minor(k0, dmaj, dmin);
+                // LineIterator's error term after k0 steps: err = dmaj - 2 dmin (k0 + 1) + 2 dmaj m
+                long long err = (long long)dmaj - 2LL * dmin * (k0 + 1) + 2LL * dmaj * m;
+                const bool check = c.flags & 1;
+                const double h6 = check ? lch[kk * 9 + 6] : 0.0, h7 = check ? lch[kk * 9 + 7] : 0.0;
+                for (int s = k0; s <= k1; s++) {
+                    const int x = ymajor ? lx + m : lx + s;
+                    const int y = ymajor ? ly + sy * s : ly + sy * m;
+                    if (x >= cx0 && x < cx1 && y >= cy0 && y < cy1 &&
+                        !(check && fma(1.0, 1.0, fma(h7, (double)y, h6 * (double)x)) == 0))
+                        atomicMax(own + (y - wy0) * W + ((x - wx0 + y - wy0) & 63), tag);
+                    const bool step = err < 0;
+                    err += -2LL * dmin + (step ? 2LL * dmaj : 0LL);
+                    m += step ? 1 : 0;
                 }
-                own[ly * W + lane] = a0 | (a1 << 16);
-                hbB[ly * W + lane] = (uint16_t)a2;
-            } else {
-                own[ly * W + lane] = px;
             }
         }
+        __syncthreads();
+        if (phase_limit == 1) return;
+
+        // If the candidates did not fit one chunk, LDS now holds the LAST chunk; phase C wants chunk 0.
+        if (!INTERIOR && nc > NLDSCELL) {
+            load_chunk(0, NLDSCELL);
+            __syncthreads();
+        }
+
+        // ---- C + D: every wavefront owns 8 consecutive window rows; CGROUP rows at a time so that the fp64 chains
+        //      and the gathers of several rows overlap.  Lane = window column.
+        const int gx = wx0 + lane;
+        const bool colok = INTERIOR || (gx >= cx0 && gx < cx1);
+        int srcl[2 * RMAX + 1];   // lane holding tap i of this lane's horizontal stencil (BORDER_REFLECT_101)
+#pragma unroll
+        for (int i = 0; i < 2 * RMAX + 1; i++) {
+            int s = (R > 0 && i < K) ? (INTERIOR ? lane + i - R : reflect101(gx + i - R, dw) - wx0) : lane;
+            srcl[i] = min(max(s, 0), W - 1);
+        }
+        for (int g0 = 0; g0 < ROWS_PER_WAVE; g0 += CGROUP) {
+            int X[CGROUP], Y[CGROUP];
+            bool rowok[CGROUP];
+#pragma unroll
+            for (int u = 0; u < CGROUP; u++) {
+                const int ly = wave * ROWS_PER_WAVE + g0 + u;
+                const int gy = wy0 + ly;
+                rowok[u] = INTERIOR || (gy >= cy0 && gy < cy1);
+                X[u] = 0; Y[u] = 0;
+                if (rowok[u] && colok) {
+                    const uint32_t o = own[ly * W + ((lane + ly) & 63)];
+                    if (o != 0) {
+                        const int k = (int)o - 1;
+                        double h[8];
+                        if (INTERIOR || k < NLDSCELL) {
+#pragma unroll
+                            for (int j = 0; j < 8; j++) h[j] = lch[k * 9 + j];
+                        } else {
+                            const vkc::CellC VKX_GLOBAL *gc =
+                                (const vkc::CellC VKX_GLOBAL *)(gcell + (r0 + k / ncol) * cw + (c0 + k % ncol));
+#pragma unroll
+                            for (int j = 0; j < 8; j++) h[j] = gc->H[j];
+                        }
+                        const double fx = (double)gx, fy = (double)gy;
+                        const double nx = fma(h[2], 1.0, fma(h[1], fy, h[0] * fx));
+                        const double ny = fma(h[5], 1.0, fma(h[4], fy, h[3] * fx));
+                        const double de = fma(1.0, 1.0, fma(h[7], fy, h[6] * fx));
+                        X[u] = vkd::cv_round((float)(nx / de) * 32.f);
+                        Y[u] = vkd::cv_round((float)(ny / de) * 32.f);
+                    }
+                }
+            }
+            unsigned long long ta[CGROUP], tb[CGROUP];
+            bool fast[CGROUP];
+#pragma unroll
+            for (int u = 0; u < CGROUP; u++) {
+                const int sx = vkd::sat_short(X[u] >> 5), sy = vkd::sat_short(Y[u] >> 5);
+                fast[u] = rowok[u] && colok && sx >= 0 && sx + 2 < sw && sy >= 0 && sy + 1 < sh;
+                ta[u] = 0; tb[u] = 0;
+                if (fast[u]) {
+                    // interior: the two 6-byte tap pairs come in as two unaligned 8-byte loads (3 sx + 8 <= 3 sw)
+                    const gsrc_t q0 = src + (ptrdiff_t)sy * sstride + (ptrdiff_t)sx * 3;
+                    ta[u] = *(const u64_u1 VKX_GLOBAL *)q0;
+                    tb[u] = *(const u64_u1 VKX_GLOBAL *)(q0 + sstride);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < CGROUP; u++) {
+                const int ly = wave * ROWS_PER_WAVE + g0 + u;
+                if (!rowok[u]) continue;                     // uniform over the wavefront
+                uint32_t px = 0;
+                if (colok) {
+                    const int fx = X[u] & 31, fy = Y[u] & 31;
+                    const int w00 = (32 - fy) * (32 - fx), w01 = (32 - fy) * fx, w10 = fy * (32 - fx), w11 = fy * fx;
+                    if (fast[u]) {
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            const int v0 = (int)((ta[u] >> (8 * k)) & 0xff), v1 = (int)((ta[u] >> (8 * (k + 3))) & 0xff);
+                            const int v2 = (int)((tb[u] >> (8 * k)) & 0xff), v3 = (int)((tb[u] >> (8 * (k + 3))) & 0xff);
+                            px |= (uint32_t)((v0 * w00 + v1 * w01 + v2 * w10 + v3 * w11 + 512) >> 10) << (8 * k);
+                        }
+                    } else {
+                        uint8_t p3[3];
+                        vkd::sample_u8<3>(it.src, sh, sw, sstride, X[u], Y[u], p3);
+                        px = (uint32_t)p3[0] | ((uint32_t)p3[1] << 8) | ((uint32_t)p3[2] << 16);
+                    }
+                }
+                if (R > 0) {
+                    // D: horizontal u8 x 8.8 pass; tap i of lane l lives in lane srcl[i]
+                    uint32_t a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+                    for (int i = 0; i < 2 * RMAX + 1; i++) {
+                        if (i < K) {
+                            const uint32_t v = (uint32_t)__shfl((int)px, srcl[i], 64);
+                            a0 += kq[i] * (v & 0xff);
+                            a1 += kq[i] * ((v >> 8) & 0xff);
+                            a2 += kq[i] * ((v >> 16) & 0xff);
+                        }
+                    }
+                    own[ly * W + lane] = a0 | (a1 << 16);
+                    hbB[ly * W + lane] = (uint16_t)a2;
+                } else {
+                    own[ly * W + lane] = px;
+                }
+            }
+        }
+        __syncthreads();
+        if (phase_limit == 2) return;
+
     }
-    __syncthreads();
-    if (phase_limit == 2) return;
 
     // ---- E: vertical pass, hue shift, noise, store.  Wavefront w takes output rows w, w + 8, ...
     // This wavefront's output rows are cy = wave + 8 i, column = lane - R.  All their noise (exactly 6 bytes per
@@ -503,12 +507,21 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
     const bool hue_on = it.hue_on != 0;
     const int hue_delta = it.hue_delta;
     const int full4 = (tw >> 2) << 2;          // columns covered by whole 4-pixel (12-byte) groups
+    // EMPTY: no lattice cell reaches the window, so every pixel of it maps to (0, 0) (the reference's unfilled map
+    // entries) = the source's first pixel; the blur of a constant is that constant (kernel taps sum to 256), and the
+    // hue shift is evaluated once per lane instead of once per pixel.
+    int er = 0, eg = 0, eb = 0;
+    if constexpr (EMPTY) {
+        er = src[0]; eg = src[1]; eb = src[2];
+        if (hue_on) hue_shift_px(lut->sdiv, lut->hdiv, hue_delta, er, eg, eb);
+    }
 #pragma unroll
     for (int i = 0; i < ROWS_PER_WAVE; i++) {
         const int cy = wave + NWAVES * i;
         if (cy >= th) continue;                 // uniform over the wavefront
         const int gy = y0 + cy;
-        int r = 0, g = 0, b = 0;
+        int r = er, g = eg, b = eb;
+        if constexpr (!EMPTY) {
         if (R > 0) {
             uint32_t a0 = 0, a1 = 0, a2 = 0;
 #pragma unroll
@@ -530,6 +543,7 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
             r = v & 0xff; g = (v >> 8) & 0xff; b = (v >> 16) & 0xff;
         }
         if (hue_on) hue_shift_px(lsdiv, lhdiv, hue_delta, r, g, b);
+        }
         if (noise) {
             r = vkd::clamp_u8((int16_t)((int16_t)r + (int16_t)(nzA[i] & 0xffff)));
             g = vkd::clamp_u8((int16_t)((int16_t)g + (int16_t)(nzA[i] >> 16)));
@@ -563,11 +577,15 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
     // grid = (tile slots, images).  XCD-aware tile order: consecutive workgroup ids land on different XCDs
     // (id % 8); give every XCD a contiguous run of an image's tiles so neighbouring tiles (shared source rows,
     // shared cells) meet in one L2.
+    // The run an XCD takes rotates with the image index: the cheap tiles (outside the distorted page, mostly the
+    // first and last rows) would otherwise always land on the same two XCDs and leave them idle at the end.
     const int slots = gridDim.x;                 // multiple of 8, >= tiles of the largest image
-    const int per = slots >> 3;
-    const int tl = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
     const ItemDev &it = items[blockIdx.y];
-    if (tl >= it.tiles_x * it.tiles_y) return;
+    const int ntiles = it.tiles_x * it.tiles_y;
+    const int per = (ntiles + 7) >> 3;           // this image's run length
+    const int run = (int)((blockIdx.x + blockIdx.y) & 7), pos = (int)(blockIdx.x >> 3);
+    const int tl = run * per + pos;
+    if (pos >= per || tl >= ntiles) return;
     const int tile_id = (int)blockIdx.y * slots + tl;   // bins are laid out [image][slot]
     const TileBin bin = bins[tile_id];
     const int ty = tl / it.tiles_x, tx = tl - ty * it.tiles_x;
@@ -575,8 +593,9 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
     const int wx0 = tx * Tw - it.R, wy0 = ty * Tw - it.R;
     const int nc = bin.rmax1 > 0 ? max(0, bin.rmax1 - bin.rmin) * max(0, bin.cmax1 - bin.cmin) : 0;
     const bool interior = wx0 >= 0 && wy0 >= 0 && wx0 + W <= it.dw && wy0 + W <= it.dh && nc <= NLDSCELL && phase_limit != 3;
-    if (interior) chain_tile<true>(it, tl, tile_id, cells, bin, lut, phase_limit);
-    else chain_tile<false>(it, tl, tile_id, cells, bin, lut, phase_limit);
+    if (nc == 0) chain_tile<2>(it, tl, tile_id, cells, bin, lut, phase_limit);
+    else if (interior) chain_tile<1>(it, tl, tile_id, cells, bin, lut, phase_limit);
+    else chain_tile<0>(it, tl, tile_id, cells, bin, lut, phase_limit);
 }
 
 } // namespace
