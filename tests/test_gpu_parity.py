@@ -352,6 +352,34 @@ def test_chain_batch_ragged_against_oracle(N, grids):
     _chain_case(N, grids, names, 13, [0.9], [255], [True])
 
 
+def test_chain_batch_fuzz(N):
+    """Random shapes / lattices / parameters in ragged batches: tile borders, partial tiles, windows wider than the
+    image, empty tiles (lattices that leave part of the result uncovered), folds, every blur radius of the fused path."""
+    rng = default_rng(2024)
+    sigmas = [None, 0.5, 0.7, 1.0, 1.3, 2.0]
+    for round_ in range(6):
+        grids, names = {}, []
+        for i in range(10):
+            h, w = int(rng.integers(2, 330)), int(rng.integers(2, 330))
+            gs = int(rng.integers(5, 45))
+            sv, dv, dshape = synthetic_grid(h, w, gs, float(rng.uniform(0, 14)), seed=int(rng.integers(1 << 30)))
+            kind = int(rng.integers(0, 4))
+            if kind == 0:      # leave a margin: the result is larger than the warped page (uncovered tiles)
+                dv = dv + np.asarray([int(rng.integers(0, 150)), int(rng.integers(0, 150))], np.int32)
+                dshape = (int(dv[..., 1].max()) + 1 + int(rng.integers(0, 140)),
+                          int(dv[..., 0].max()) + 1 + int(rng.integers(0, 140)))
+            elif kind == 1 and dv.shape[0] > 2 and dv.shape[1] > 2:   # a fold: one interior vertex jumps
+                r, c = int(rng.integers(1, dv.shape[0] - 1)), int(rng.integers(1, dv.shape[1] - 1))
+                dv[r, c] = dv[r - 1, c - 1]
+            name = f'f{round_}_{i}'
+            grids[name] = (sv, dv, dshape, (h, w))
+            names.append(name)
+        _chain_case(N, grids, names, 1000 + round_,
+                    [sigmas[int(k)] for k in rng.integers(0, len(sigmas), 10)],
+                    [None if k % 3 == 0 else int(k) - 128 for k in rng.integers(0, 256, 10)],
+                    [bool(k) for k in rng.integers(0, 2, 10)])
+
+
 def test_chain_batch_degenerate_grid(N):
     sv = np.array([[(x, y) for x in (0, 15, 30, 31)] for y in (0, 15, 30, 45)], np.int32)
     dv = sv.copy()
