@@ -103,6 +103,21 @@ def test_pointwise_ops_against_reference(golden_dir):
     assert (O.speckle_noise(gray, default_rng(6).normal(0, 0.2, gray.shape)) == P['gray_speckle']).all()
 
 
+def test_colour_conversion_known_answers():
+    """Primaries through the [cv2] colour conversions: hrange 256 for the *_FULL codes (240 deg -> 171, 60 deg -> 43),
+    lightness / saturation of pure colours, BT.601 grey weights (76 / 150 / 29)."""
+    prim = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 0], [0, 255, 255], [255, 0, 255],
+                      [255, 255, 255], [0, 0, 0], [128, 128, 128]]], np.uint8)
+    assert O.rgb2hsv_full(prim)[0].tolist() == [[0, 255, 255], [85, 255, 255], [171, 255, 255], [43, 255, 255],
+                                                [128, 255, 255], [213, 255, 255], [0, 0, 255], [0, 0, 0], [0, 0, 128]]
+    assert O.rgb2hls_full(prim)[0].tolist() == [[0, 128, 255], [85, 128, 255], [171, 128, 255], [43, 128, 255],
+                                                [128, 128, 255], [213, 128, 255], [0, 255, 0], [0, 0, 0], [0, 128, 0]]
+    assert O.rgb2gray(prim)[0].tolist() == [76, 150, 29, 226, 179, 105, 255, 0, 128]
+    # L = 128 is 128/255 > 0.5: the 8-bit round trip of a pure colour comes back one step off the axis
+    assert O.hls2rgb_full(O.rgb2hls_full(prim))[0, :3].tolist() == [[255, 1, 1], [3, 255, 1], [3, 1, 255]]
+    assert (O.hsv2rgb_full(O.rgb2hsv_full(prim))[0, :3] == [[255, 0, 0], [2, 255, 0], [2, 0, 255]]).all()
+
+
 def test_fill_rejects_bad_alpha():
     page = np.zeros((4, 4, 3), np.uint8)
     with pytest.raises(RuntimeError):
