@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""C2 timing: similarity_mls (level 5) grid remap only, 2048^2 RGB, one ragged batch through the fused tile kernel
+(device resident).  MLS states are built on the host (pure Python per vertex), so the batch is 16 images."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from numpy.random import default_rng
+
+from vkit_amd import _native as N
+from vkit_amd.batch import ChainBatch
+from vkit_amd.mechanism import distortion as D
+from vkit_amd.mechanism.distortion_policy.geometric import mls as P_mls
+
+B, SIZE = 16, 2048
+ctx = N.Context(0)
+gen = P_mls.SimilarityMlsConfigGenerator(P_mls.SimilarityMlsConfigGeneratorConfig(), 5)
+t0 = time.perf_counter()
+states = [D.similarity_mls.generate_state(gen((SIZE, SIZE), default_rng(i)), (SIZE, SIZE)) for i in range(B)]
+t_states = time.perf_counter() - t0
+batch = ChainBatch(ctx)
+for i, st in enumerate(states):
+    batch.add(default_rng(1000 + i).integers(0, 256, (SIZE, SIZE, 3), dtype=np.uint8), st)
+batch.run(); ctx.sync()
+ctx.set_timing(True); ctx.reset_timings()
+t0 = time.perf_counter()
+for _ in range(5):
+    batch.run()
+ctx.sync()
+dt = (time.perf_counter() - t0) / 5
+k = ctx.timings()
+S, Dp = batch.source_pixels, batch.result_pixels
+fused_s = k['k_chain_fused'][0] / k['k_chain_fused'][1] / 1e3
+print(json.dumps({'images': B, 'host_state_s_per_image': round(t_states / B, 3), 'ms_per_batch': round(dt * 1e3, 3),
+                  'Mpx_s': round(S / dt / 1e6), 'kernels_ms': {n: round(v[0] / v[1], 3) for n, v in k.items()},
+                  'k_chain_fused_GBps_3S_3D': round(3 * (S + Dp) / fused_s / 1e9, 1),
+                  'frac_of_8TBps': round(3 * (S + Dp) / fused_s / 8e12, 4)}))
