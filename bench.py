@@ -75,6 +75,48 @@ def cpu_baseline(size, n_images):
     }
 
 
+def _cpu_worker(rank, n_procs, per_proc, size, barrier, queue):
+    """One process of the all-cores CPU leg: prepares its images, meets the others at the barrier, runs the oracle."""
+    import oracle as O
+    idx = [rank * per_proc + j for j in range(per_proc)]
+    states = [make_state(i, size) for i in idx]
+    images = [np.random.default_rng(1000 + i).integers(0, 256, (size, size, 3), dtype=np.uint8) for i in idx]
+    noises = [_noise_plane((5000 + i, tuple(s.result_shape) + (3,))) for i, s in zip(idx, states)]
+    O.lib()
+    barrier.wait()
+    t0 = time.time()
+    for img, st, noise in zip(images, states, noises):
+        mx, my = O.grid_to_map(st.src_image_grid.vertices, st.dst_image_grid.vertices, st.result_shape)
+        O.add_noise_i16(O.color_shift_rgb(O.gaussian_blur(O.remap(img, mx, my), 5, BLUR_SIGMA), HUE_DELTA), noise)
+    queue.put((t0, time.time()))
+
+
+def cpu_baseline_all_cores(size, n_procs, per_proc):
+    """The same oracle, one single-threaded process per core, all processes timed between a common barrier and the
+    last one to finish."""
+    ctx = mp.get_context('spawn')
+    barrier, queue = ctx.Barrier(n_procs), ctx.Queue()
+    procs = [ctx.Process(target=_cpu_worker, args=(r, n_procs, per_proc, size, barrier, queue)) for r in range(n_procs)]
+    for p in procs:
+        p.start()
+    spans, deadline = [], time.time() + 300
+    while len(spans) < n_procs and time.time() < deadline:
+        try:
+            spans.append(queue.get(timeout=1.0))
+        except Exception:                      # queue.Empty: keep waiting while every worker is alive or done cleanly
+            if any(p.exitcode not in (None, 0) for p in procs):
+                break
+    for p in procs:
+        p.join(timeout=5)
+        if p.is_alive():
+            p.terminate()
+    if len(spans) < n_procs:
+        return None
+    dt = max(e for _, e in spans) - min(b for b, _ in spans)
+    return {'value': n_procs * per_proc * size * size / dt / 1e6, 'unit': 'Mpixels/s', 'cores': n_procs,
+            'sample': f'{n_procs} processes x {per_proc} images, {dt:.1f} s'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -83,6 +125,8 @@ def main():
     ap.add_argument('--batch', type=int, default=256, help='images per GPU')
     ap.add_argument('--size', type=int, default=2048)
     ap.add_argument('--cpu-sample', type=int, default=64, help='images timed on the CPU oracle (rank 0, N=1)')
+    ap.add_argument('--cpu-procs', type=int, default=-1,
+                    help='processes of the all-cores CPU leg (-1 = min(64, cores), 0 = skip)')
     ap.add_argument('--verify', type=int, default=1, help='images of the batch checked against the oracle')
     ap.add_argument('--noise-workers', type=int, default=-1,
                     help='processes generating the numpy noise planes (0 = in this process, e.g. under rocprofv3)')
@@ -254,6 +298,11 @@ def main():
     }
     if world == 1:
         result['cpu_baseline'] = cpu_baseline(size, args.cpu_sample)
+        n_procs = min(64, os.cpu_count() or 1) if args.cpu_procs < 0 else args.cpu_procs
+        if n_procs > 1 and args.cpu_sample > 0:
+            all_cores = cpu_baseline_all_cores(size, n_procs, 4)
+            if all_cores is not None:
+                result['cpu_baseline']['all_cores'] = all_cores
     else:
         result['cpu_baseline'] = None
     print(json.dumps(result))
