@@ -402,6 +402,26 @@ def test_chain_batch_full_size(N):
     _chain_case(N, grids, ['odd'], 16, [0.7], [-5], [False])
 
 
+def test_grid_remap_global_plane_path_subprocess(N):
+    """vkx_grid_remap takes the tile kernel by default; VKX_GRID_GLOBAL=1 forces the global-ownership-plane kernels.
+    Both must give the oracle's pixels for uint8 x 1 / 3 / 4 channels and float32 through one shared lattice."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys; sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'tests'));"
+        "import numpy as np; import oracle as O; import test_gpu_parity as T; from vkit_amd import _native as N;"
+        "rng = np.random.default_rng(9);"
+        "sv, dv, ds = T.synthetic_grid(333, 410, 17, 8.0, seed=6);"
+        "mats = [rng.integers(0, 256, (333, 410, 3), dtype=np.uint8), rng.integers(0, 2, (333, 410), dtype=np.uint8),"
+        "        rng.random((333, 410), dtype=np.float32), rng.integers(0, 256, (333, 410, 4), dtype=np.uint8)];"
+        "outs = N.grid_remap(mats, sv, dv, ds); mx, my = O.grid_to_map(sv, dv, ds);"
+        "assert all((o == O.remap(m, mx, my)).all() for o, m in zip(outs, mats)); print('ok')")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env in (dict(os.environ), dict(os.environ, VKX_GRID_GLOBAL='1')):
+        out = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and 'ok' in out.stdout, out.stdout + out.stderr
+
+
 def test_chain_batch_staged_path_subprocess(N):
     """The per-stage fallback of vkx_chain_rgb_batch_dev (VKX_CHAIN_STAGED=1) gives the same pixels."""
     import subprocess

@@ -23,6 +23,7 @@
 
 #include <float.h>
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -63,6 +64,15 @@ struct ItemDev {
     int R;             // blur radius (0 = no blur); the tile proper is (64 - 2R) pixels wide and high
     int hue_on, hue_delta;
     unsigned short kq[8];
+    // element mode (k_tile_remap): the same tile machinery gathers up to four elements of any supported type through
+    // the shared lattice instead of running the RGB chain
+    int n_elems, pad_;
+    struct Elem {
+        const void *src;
+        void *dst;
+        ptrdiff_t sstride, dstride;   // bytes (uint8) / elements (float32)
+        int cn, is_f32;
+    } el[4];
 };
 
 struct TileBin {       // candidate cell rectangle of one tile: [rmin, rmax] x [cmin, cmax]
@@ -204,7 +214,7 @@ constexpr size_t kFusedLds = kLdsOwn + kLdsHbB + kLdsCellR + kLdsCellH + kLdsLut
 // INTERIOR: the tile's whole 64 x 64 window lies inside the image and its candidates fit one LDS chunk -- the common
 // case (about 89 % of the tiles of a 2048^2 page).  Border handling (row / column validity, BORDER_REFLECT_101 lane tables,
 // the global-memory fallback for candidates beyond the chunk) compiles away; the arithmetic is the same.
-template <int KIND>   // 0 generic, 1 interior, 2 empty
+template <int KIND>   // 0 generic, 1 interior, 2 empty, 3 element remap (no photometric stage, any element types)
 __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, const int tile_id,
                                            const vkc::CellC *__restrict__ cells, const TileBin &bin,
                                            const HsvLut *__restrict__ lut, int phase_limit)
@@ -429,6 +439,37 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
                     }
                 }
             }
+            if constexpr (KIND == 3) {
+                // element mode: R = 0, the window is the tile; every element is sampled at the shared coordinate
+#pragma unroll
+                for (int u = 0; u < CGROUP; u++) {
+                    const int gy = wy0 + wave * ROWS_PER_WAVE + g0 + u;
+                    if (!(rowok[u] && colok)) continue;
+                    for (int e = 0; e < it.n_elems; e++) {
+                        const ItemDev::Elem &el = it.el[e];
+                        if (el.is_f32) {
+                            ((float *)el.dst)[(ptrdiff_t)gy * el.dstride + gx] =
+                                vkd::sample_f32((const float *)el.src, sh, sw, el.sstride, X[u], Y[u]);
+                        } else {
+                            uint8_t *d = (uint8_t *)el.dst + (ptrdiff_t)gy * el.dstride + (ptrdiff_t)gx * el.cn;
+                            const uint8_t *sp = (const uint8_t *)el.src;
+                            if (el.cn == 1) {
+                                vkd::sample_u8<1>(sp, sh, sw, el.sstride, X[u], Y[u], d);
+                            } else if (el.cn == 3) {
+                                uint8_t p3[3];
+                                vkd::sample_u8<3>(sp, sh, sw, el.sstride, X[u], Y[u], p3);
+                                d[0] = p3[0]; d[1] = p3[1]; d[2] = p3[2];
+                            } else {
+                                uint8_t p4[4];
+                                vkd::sample_u8<4>(sp, sh, sw, el.sstride, X[u], Y[u], p4);
+                                *(uint32_t *)d = (uint32_t)p4[0] | ((uint32_t)p4[1] << 8) | ((uint32_t)p4[2] << 16) |
+                                                 ((uint32_t)p4[3] << 24);
+                            }
+                        }
+                    }
+                }
+                continue;
+            }
             unsigned long long ta[CGROUP], tb[CGROUP];
             bool fast[CGROUP];
 #pragma unroll
@@ -483,6 +524,7 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
                 }
             }
         }
+        if constexpr (KIND == 3) return;   // element mode ends with the gathers
         __syncthreads();
         if (phase_limit == 2) return;
 
@@ -598,7 +640,73 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
     else chain_tile<0>(it, tl, tile_id, cells, bin, lut, phase_limit);
 }
 
+// Element mode of the same tile machinery: Image / Mask / ScoreMap (uint8 x 1, 3, 4 channels, float32) of one call
+// gathered through the shared lattice in one launch -- ownership in LDS, no dense map, no int32 ownership plane in HBM.
+__global__ void __launch_bounds__(NTHREADS, 4) k_tile_remap(const ItemDev *__restrict__ items,
+                                                           const vkc::CellC *__restrict__ cells,
+                                                           const TileBin *__restrict__ bins)
+{
+    const int slots = gridDim.x;
+    const ItemDev &it = items[blockIdx.y];
+    const int ntiles = it.tiles_x * it.tiles_y;
+    const int per = (ntiles + 7) >> 3;
+    const int run = (int)((blockIdx.x + blockIdx.y) & 7), pos = (int)(blockIdx.x >> 3);
+    const int tl = run * per + pos;
+    if (pos >= per || tl >= ntiles) return;
+    const int tile_id = (int)blockIdx.y * slots + tl;
+    const TileBin bin = bins[tile_id];
+    chain_tile<3>(it, tl, tile_id, cells, bin, nullptr, 0);
+}
+
 } // namespace
+
+// Shared host tail of the two tile kernels: scratch, descriptor upload, cell setup, launch.
+static int launch_tiles(vkx_ctx *ctx, std::vector<ItemDev> &dev, std::vector<int> &prefix, long long ncells, int max_tiles,
+                        bool elements)
+{
+    const int n_items = (int)dev.size();
+    int rc;
+    // device scratch: cell table, tile bins, item descriptors + prefix arrays, HSV tables
+    const size_t cells_bytes = sizeof(vkc::CellC) * (size_t)ncells;   // then the deferred list: count + ids
+    if ((rc = vkx_scratch_reserve(ctx, &ctx->cells, cells_bytes + sizeof(int) * ((size_t)ncells + 1)))) return rc;
+    const int slots = ((max_tiles + 7) / 8) * 8;          // tile slots per image in the launch grid
+    const size_t nbins = (size_t)slots * n_items;
+    if (n_items > 65535) return VKX_ERR_UNSUPPORTED;      // gridDim.y
+    if ((rc = vkx_scratch_reserve(ctx, &ctx->owner, sizeof(TileBin) * nbins))) return rc;
+    const size_t items_bytes = sizeof(ItemDev) * (size_t)n_items, prefix_bytes = sizeof(int) * prefix.size();
+    const size_t items_off = 0, prefix_off = (items_bytes + 255) & ~(size_t)255;
+    if ((rc = vkx_scratch_reserve(ctx, &ctx->misc, prefix_off + prefix_bytes))) return rc;
+    const HsvLut *lut = nullptr;
+    if (!elements && (rc = vkx_hsv_tables(ctx, (const void **)&lut))) return rc;
+    unsigned char *misc = (unsigned char *)ctx->misc.ptr;
+    // the host vectors die with this frame, so the upload is completed before returning from this block
+    VKX_HIP(hipMemcpyAsync(misc + items_off, dev.data(), items_bytes, hipMemcpyHostToDevice, ctx->stream));
+    VKX_HIP(hipMemcpyAsync(misc + prefix_off, prefix.data(), prefix_bytes, hipMemcpyHostToDevice, ctx->stream));
+    VKX_HIP(hipStreamSynchronize(ctx->stream));
+    const ItemDev *d_items = (const ItemDev *)(misc + items_off);
+    const int *d_cell_prefix = (const int *)(misc + prefix_off);
+    TileBin *bins = (TileBin *)ctx->owner.ptr;
+    vkc::CellC *cells = (vkc::CellC *)ctx->cells.ptr;
+
+    // bins: mins start at 0x7f7f7f7f, maxs at 0 -> one strided 2D memset per half
+    VKX_HIP(hipMemset2DAsync(bins, sizeof(TileBin), 0x7f, 8, nbins, ctx->stream));
+    VKX_HIP(hipMemset2DAsync((unsigned char *)bins + 8, sizeof(TileBin), 0x00, 8, nbins, ctx->stream));
+    int *deferred = (int *)((unsigned char *)ctx->cells.ptr + cells_bytes);
+    VKX_HIP(hipMemsetAsync(deferred, 0, sizeof(int), ctx->stream));
+    { VKX_TIMED(ctx, "k_chain_setup"); k_chain_setup<<<vkx_blocks((size_t)ncells, 256), 256, 0, ctx->stream>>>(d_items, d_cell_prefix, n_items, (int)ncells, slots, cells, bins, deferred); }
+    VKX_LAUNCH_CHECK();
+    { VKX_TIMED(ctx, "k_chain_setup_svd"); k_chain_setup_svd<<<16, 64, 0, ctx->stream>>>(d_items, d_cell_prefix, n_items, cells, deferred); }
+    VKX_LAUNCH_CHECK();
+    // profiling aid: VKX_FUSED_PHASES=1|2 stops the kernel after phase A | C+D
+    static const int phase_limit = [] { const char *e = getenv("VKX_FUSED_PHASES"); return e ? atoi(e) : 0; }();
+    if (elements) {
+        { VKX_TIMED(ctx, "k_tile_remap"); k_tile_remap<<<dim3(slots, n_items), NTHREADS, kFusedLds, ctx->stream>>>(d_items, cells, bins); }
+    } else {
+        { VKX_TIMED(ctx, "k_chain_fused"); k_chain_fused<<<dim3(slots, n_items), NTHREADS, kFusedLds, ctx->stream>>>(d_items, cells, bins, lut, phase_limit); }
+    }
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
 
 // Returns VKX_ERR_UNSUPPORTED (without setting an error) when the batch has a shape the fused path does not
 // take; the caller then runs the per-stage kernels.
@@ -635,41 +743,36 @@ int vkx_chain_fused_try(vkx_ctx *ctx, const vkx_chain_item *items, int n_items)
     }
     cell_prefix[n_items] = (int)ncells;
 
-    // device scratch: cell table, tile bins, item descriptors + prefix arrays, HSV tables
-    int rc;
-    const size_t cells_bytes = sizeof(vkc::CellC) * (size_t)ncells;   // then the deferred list: count + ids
-    if ((rc = vkx_scratch_reserve(ctx, &ctx->cells, cells_bytes + sizeof(int) * ((size_t)ncells + 1)))) return rc;
-    const int slots = ((max_tiles + 7) / 8) * 8;          // tile slots per image in the launch grid
-    const size_t nbins = (size_t)slots * n_items;
-    if (n_items > 65535) return VKX_ERR_UNSUPPORTED;      // gridDim.y
-    if ((rc = vkx_scratch_reserve(ctx, &ctx->owner, sizeof(TileBin) * nbins))) return rc;
-    const size_t items_bytes = sizeof(ItemDev) * (size_t)n_items, prefix_bytes = sizeof(int) * prefix.size();
-    const size_t items_off = 0, prefix_off = (items_bytes + 255) & ~(size_t)255;
-    if ((rc = vkx_scratch_reserve(ctx, &ctx->misc, prefix_off + prefix_bytes))) return rc;
-    const HsvLut *lut = nullptr;
-    if ((rc = vkx_hsv_tables(ctx, (const void **)&lut))) return rc;
-    unsigned char *misc = (unsigned char *)ctx->misc.ptr;
-    // the host vectors die with this frame, so the upload is completed before returning from this block
-    VKX_HIP(hipMemcpyAsync(misc + items_off, dev.data(), items_bytes, hipMemcpyHostToDevice, ctx->stream));
-    VKX_HIP(hipMemcpyAsync(misc + prefix_off, prefix.data(), prefix_bytes, hipMemcpyHostToDevice, ctx->stream));
-    VKX_HIP(hipStreamSynchronize(ctx->stream));
-    const ItemDev *d_items = (const ItemDev *)(misc + items_off);
-    const int *d_cell_prefix = (const int *)(misc + prefix_off);
-    TileBin *bins = (TileBin *)ctx->owner.ptr;
-    vkc::CellC *cells = (vkc::CellC *)ctx->cells.ptr;
+    return launch_tiles(ctx, dev, prefix, ncells, max_tiles, false);
+}
 
-    // bins: mins start at 0x7f7f7f7f, maxs at 0 -> one strided 2D memset per half
-    VKX_HIP(hipMemset2DAsync(bins, sizeof(TileBin), 0x7f, 8, nbins, ctx->stream));
-    VKX_HIP(hipMemset2DAsync((unsigned char *)bins + 8, sizeof(TileBin), 0x00, 8, nbins, ctx->stream));
-    int *deferred = (int *)((unsigned char *)ctx->cells.ptr + cells_bytes);
-    VKX_HIP(hipMemsetAsync(deferred, 0, sizeof(int), ctx->stream));
-    { VKX_TIMED(ctx, "k_chain_setup"); k_chain_setup<<<vkx_blocks((size_t)ncells, 256), 256, 0, ctx->stream>>>(d_items, d_cell_prefix, n_items, (int)ncells, slots, cells, bins, deferred); }
-    VKX_LAUNCH_CHECK();
-    { VKX_TIMED(ctx, "k_chain_setup_svd"); k_chain_setup_svd<<<16, 64, 0, ctx->stream>>>(d_items, d_cell_prefix, n_items, cells, deferred); }
-    VKX_LAUNCH_CHECK();
-    // profiling aid: VKX_FUSED_PHASES=1|2 stops the kernel after phase A | C+D
-    static const int phase_limit = [] { const char *e = getenv("VKX_FUSED_PHASES"); return e ? atoi(e) : 0; }();
-    { VKX_TIMED(ctx, "k_chain_fused"); k_chain_fused<<<dim3(slots, n_items), NTHREADS, kFusedLds, ctx->stream>>>(d_items, cells, bins, lut, phase_limit); }
-    VKX_LAUNCH_CHECK();
-    return VKX_OK;
+// vkx_grid_remap through the tile kernel; VKX_ERR_UNSUPPORTED (no error set) for shapes it does not take.
+int vkx_tile_remap_try(vkx_ctx *ctx, const vkx_elem *elems, int n_elems, int sh, int sw, const int32_t *src_vertices,
+                       const int32_t *dst_vertices, int rows, int cols, int dh, int dw)
+{
+    if (n_elems < 1 || n_elems > 4 || rows < 2 || cols < 2) return VKX_ERR_UNSUPPORTED;
+    if (sh > 32767 || sw > 32767 || dh > 32767 || dw > 32767 || sh < 1 || sw < 1 || dh < 1 || dw < 1) return VKX_ERR_UNSUPPORTED;
+    std::vector<ItemDev> dev(1);
+    std::vector<int> prefix(2);
+    ItemDev &d = dev[0];
+    memset(&d, 0, sizeof(d));
+    d.sv = src_vertices; d.dv = dst_vertices;
+    d.sh = sh; d.sw = sw; d.dh = dh; d.dw = dw; d.rows = rows; d.cols = cols;
+    d.R = 0;
+    const int Tw = tile_side(0);
+    d.tiles_x = (dw + Tw - 1) / Tw; d.tiles_y = (dh + Tw - 1) / Tw;
+    d.cell_base = 0;
+    d.n_elems = n_elems;
+    for (int e = 0; e < n_elems; e++) {
+        if (!elems[e].src || !elems[e].dst) return VKX_ERR_UNSUPPORTED;
+        if (!elems[e].is_f32 && elems[e].cn != 1 && elems[e].cn != 3 && elems[e].cn != 4) return VKX_ERR_UNSUPPORTED;
+        if (elems[e].is_f32 && elems[e].cn != 1) return VKX_ERR_UNSUPPORTED;
+        d.el[e].src = elems[e].src; d.el[e].dst = elems[e].dst;
+        d.el[e].sstride = elems[e].src_stride; d.el[e].dstride = elems[e].dst_stride;
+        d.el[e].cn = elems[e].cn; d.el[e].is_f32 = elems[e].is_f32;
+    }
+    const long long ncells = (long long)(rows - 1) * (cols - 1);
+    if ((long long)d.tiles_x * d.tiles_y > 0x3fffffff || ncells > 0x3fffffff) return VKX_ERR_UNSUPPORTED;
+    prefix[0] = 0; prefix[1] = (int)ncells;
+    return launch_tiles(ctx, dev, prefix, ncells, d.tiles_x * d.tiles_y, true);
 }

@@ -14,6 +14,8 @@
 #include "vkx_internal.h"
 #include "vkx_cell.h"
 
+#include <stdlib.h>
+
 namespace {
 
 using vkc::CellC;
@@ -202,7 +204,13 @@ VKX_EXPORT int vkx_grid_remap_dev(vkx_ctx *ctx, const vkx_elem *elems, int n_ele
         if (elems[i].is_f32) VKX_REQUIRE(elems[i].cn == 1, "float32 elements are single channel");
         else VKX_REQUIRE(elems[i].cn == 1 || elems[i].cn == 3 || elems[i].cn == 4, "uint8 elements need 1, 3 or 4 channels");
     }
-    int rc = vkx_scratch_reserve(ctx, &ctx->owner, sizeof(int32_t) * (size_t)dh * dw);
+    // tile kernel first (ownership in LDS, one launch for all elements); the global-ownership-plane kernels below take
+    // whatever it declines (VKX_GRID_GLOBAL=1 forces them: the two paths must agree bit for bit)
+    static const bool force_global = getenv("VKX_GRID_GLOBAL") != nullptr;
+    int rc = force_global ? VKX_ERR_UNSUPPORTED
+                          : vkx_tile_remap_try(ctx, elems, n_elems, sh, sw, src_vertices, dst_vertices, rows, cols, dh, dw);
+    if (rc != VKX_ERR_UNSUPPORTED) return rc;
+    rc = vkx_scratch_reserve(ctx, &ctx->owner, sizeof(int32_t) * (size_t)dh * dw);
     if (rc) return rc;
     int32_t *own = (int32_t *)ctx->owner.ptr;
     rc = build_owner(ctx, src_vertices, dst_vertices, rows, cols, dh, dw, own);

@@ -160,3 +160,5 @@ __device__ __forceinline__ float sample_f32(const float *__restrict__ src, int s
 int vkx_hsv_tables(vkx_ctx *ctx, const void **out);                      // photo.hip
 int vkx_gaussian_kernel_q8_host(int n, double sigma, uint16_t *kq);      // photo.hip
 int vkx_chain_fused_try(vkx_ctx *ctx, const vkx_chain_item *items, int n_items);  // fused.hip
+int vkx_tile_remap_try(vkx_ctx *ctx, const vkx_elem *elems, int n_elems, int sh, int sw, const int32_t *src_vertices,
+                       const int32_t *dst_vertices, int rows, int cols, int dh, int dw);  // fused.hip
