@@ -304,7 +304,8 @@ int vkx_paint_polys(vkx_ctx *ctx, const int32_t *pts_host, const int32_t *poly_o
  * RandomDistortion's geometric stage followed by photometric members on one page image
  * (mechanism/distortion_policy/random_distortion.py:190-203 applied through
  * Distortion.distort, mechanism/distortion/interface.py:824-912), for a ragged batch of
- * independent images: image-grid remap -> gaussian_blur -> color_shift -> gaussion_noise.
+ * independent images: image-grid remap -> gaussian_blur -> color_shift -> gaussion_noise -> line_streak
+ * (photometric/streak.py:56-99); stages with a disabled parameter are skipped.
  * `items` is a HOST array; every pointer inside is a DEVICE pointer. */
 typedef struct vkx_chain_item {
     const uint8_t *src;            /* uint8 [sh, sw, 3] */
@@ -320,7 +321,12 @@ typedef struct vkx_chain_item {
     int32_t blur_ksize;            /* <= 1 = no blur stage */
     int32_t hue_delta;
     int32_t hue_enabled;           /* 0 = no color_shift stage */
+    int32_t streak_enabled;        /* 0 = no line_streak stage */
+    int32_t streak_thickness, streak_gap, streak_dash_thickness, streak_dash_gap;
+    int32_t streak_enable_vert, streak_enable_hori;
+    uint8_t streak_color[4];
     int32_t reserved;
+    double streak_alpha;           /* in [0, 1] */
 } vkx_chain_item;
 int vkx_chain_rgb_batch_dev(vkx_ctx *ctx, const vkx_chain_item *items, int n_items);
 

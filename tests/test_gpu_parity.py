@@ -306,7 +306,7 @@ def test_chain_c3_one_full_size_image(N):
 
 
 # ------------------------------------------------------------------------------------------ batched chain
-def _chain_case(N, grids, names, seed, blur_sigmas, hue_deltas, with_noise):
+def _chain_case(N, grids, names, seed, blur_sigmas, hue_deltas, with_noise, streaks=(None,)):
     from vkit_amd.batch import ChainBatch
 
     class _State:  # the two attributes ChainBatch reads from an image-grid state
@@ -325,7 +325,8 @@ def _chain_case(N, grids, names, seed, blur_sigmas, hue_deltas, with_noise):
         sigma = blur_sigmas[i % len(blur_sigmas)]
         delta = hue_deltas[i % len(hue_deltas)]
         noise = rng.integers(-60, 60, tuple(dshape) + (3,)).astype(np.int16) if with_noise[i % len(with_noise)] else None
-        batch.add(img, _State(sv, dv, dshape), blur_sigma=sigma, hue_delta=delta, noise=noise)
+        streak = streaks[i % len(streaks)]
+        batch.add(img, _State(sv, dv, dshape), blur_sigma=sigma, hue_delta=delta, noise=noise, streak=streak)
         mx, my = O.grid_to_map(sv, dv, dshape)
         want = O.remap(img, mx, my)
         if sigma is not None:
@@ -335,6 +336,9 @@ def _chain_case(N, grids, names, seed, blur_sigmas, hue_deltas, with_noise):
             want = O.color_shift_rgb(want, delta)
         if noise is not None:
             want = O.add_noise_i16(want, noise)
+        if streak is not None:
+            want = O.line_streak(want, streak.thickness, streak.gap, streak.dash_thickness, streak.dash_gap, streak.color,
+                                 streak.alpha, streak.enable_vert, streak.enable_hori)
         expect.append(want)
     batch.run()
     for i, want in enumerate(expect):
@@ -374,10 +378,23 @@ def test_chain_batch_fuzz(N):
             name = f'f{round_}_{i}'
             grids[name] = (sv, dv, dshape, (h, w))
             names.append(name)
+        from vkit_amd.mechanism.distortion import LineStreakConfig
+        streaks = []
+        for k in range(10):
+            if rng.random() < 0.5:
+                streaks.append(None)
+                continue
+            dash = rng.random() < 0.5
+            streaks.append(LineStreakConfig(
+                thickness=int(rng.integers(1, 4)), gap=int(rng.integers(1, 30)),
+                dash_thickness=int(rng.integers(1, 20)) if dash else 0, dash_gap=int(rng.integers(1, 9)) if dash else 0,
+                color=tuple(int(v) for v in rng.integers(0, 256, 3)),
+                alpha=float(rng.choice([1.0, 0.5, 0.25, float(rng.random())])),
+                enable_vert=bool(rng.random() < 0.8), enable_hori=bool(rng.random() < 0.8)))
         _chain_case(N, grids, names, 1000 + round_,
                     [sigmas[int(k)] for k in rng.integers(0, len(sigmas), 10)],
                     [None if k % 3 == 0 else int(k) - 128 for k in rng.integers(0, 256, 10)],
-                    [bool(k) for k in rng.integers(0, 2, 10)])
+                    [bool(k) for k in rng.integers(0, 2, 10)], streaks)
 
 
 def test_chain_batch_degenerate_grid(N):
@@ -430,7 +447,9 @@ def test_chain_batch_staged_path_subprocess(N):
         "import os, sys; sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'tests'));"
         "import numpy as np; import test_gpu_parity as T; from vkit_amd import _native as N;"
         "g = {}; sv, dv, ds = T.synthetic_grid(300, 420, 15, 7.0, seed=5); g['a'] = (sv, dv, ds, (300, 420));"
-        "T._chain_case(N, g, ['a'], 17, [1.0], [37], [True]); T._chain_case(N, g, ['a'], 18, [None], [None], [True]); print('ok')")
+        "from vkit_amd.mechanism.distortion import LineStreakConfig as L;"
+        "T._chain_case(N, g, ['a'], 17, [1.0], [37], [True], [L(thickness=2, gap=9, alpha=0.4, color=(9, 200, 30))]);"
+        "T._chain_case(N, g, ['a'], 18, [None], [None], [True]); print('ok')")
     env = dict(os.environ, VKX_CHAIN_STAGED='1')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=600)

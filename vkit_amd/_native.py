@@ -58,7 +58,16 @@ class VkxChainItem(ctypes.Structure):
         ('blur_ksize', ctypes.c_int32),
         ('hue_delta', ctypes.c_int32),
         ('hue_enabled', ctypes.c_int32),
+        ('streak_enabled', ctypes.c_int32),
+        ('streak_thickness', ctypes.c_int32),
+        ('streak_gap', ctypes.c_int32),
+        ('streak_dash_thickness', ctypes.c_int32),
+        ('streak_dash_gap', ctypes.c_int32),
+        ('streak_enable_vert', ctypes.c_int32),
+        ('streak_enable_hori', ctypes.c_int32),
+        ('streak_color', ctypes.c_uint8 * 4),
         ('reserved', ctypes.c_int32),
+        ('streak_alpha', c_double),
     ]
 
 

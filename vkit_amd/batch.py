@@ -31,8 +31,9 @@ class ChainBatch:
         return ptr
 
     def add(self, image: np.ndarray, state: DistortionStateImageGridBased, blur_sigma: Optional[float] = None,
-            hue_delta: Optional[int] = None, noise: Optional[np.ndarray] = None):
-        """Registers one HxWx3 uint8 image with its image-grid state and per-image photometric parameters."""
+            hue_delta: Optional[int] = None, noise: Optional[np.ndarray] = None, streak=None):
+        """Registers one HxWx3 uint8 image with its image-grid state and per-image photometric parameters (stage order:
+        remap, gaussian_blur, color_shift, gaussion_noise, line_streak; ``None`` skips a stage)."""
         if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
             raise ValueError('ChainBatch takes HxWx3 uint8 images')
         sh, sw = image.shape[:2]
@@ -59,6 +60,14 @@ class ChainBatch:
             item.blur_ksize = _estimate_gaussian_kernel_size(blur_sigma)
         if hue_delta is not None:
             item.hue_delta, item.hue_enabled = int(hue_delta), 1
+        if streak is not None:   # a LineStreakConfig (or any object with its fields)
+            item.streak_enabled = 1
+            item.streak_thickness, item.streak_gap = int(streak.thickness), int(streak.gap)
+            item.streak_dash_thickness, item.streak_dash_gap = int(streak.dash_thickness), int(streak.dash_gap)
+            item.streak_enable_vert, item.streak_enable_hori = int(streak.enable_vert), int(streak.enable_hori)
+            for c in range(3):
+                item.streak_color[c] = int(streak.color[c])
+            item.streak_alpha = float(streak.alpha)
         self._items.append(item)
         self._dst_shapes.append((dh, dw))
         self._array = None

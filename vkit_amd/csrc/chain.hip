@@ -1,5 +1,5 @@
 // The batched geometric + photometric chain on device-resident RGB images:
-//   image-grid remap (camera_* / similarity_mls state) -> gaussian_blur -> color_shift -> gaussion_noise,
+//   image-grid remap (camera_* / similarity_mls state) -> gaussian_blur -> color_shift -> gaussion_noise -> line_streak,
 // i.e. BASELINE config 3.  Every item is an independent image with its own grid, destination size and
 // parameters (ragged batch); stages with a disabled parameter are skipped.
 //
@@ -18,6 +18,13 @@ VKX_EXPORT int vkx_chain_rgb_batch_dev(vkx_ctx *ctx, const vkx_chain_item *items
         const vkx_chain_item &it = items[i];
         VKX_REQUIRE(it.src && it.dst && it.src_vertices && it.dst_vertices, "NULL plane in chain item");
         VKX_REQUIRE(it.sh > 0 && it.sw > 0 && it.dh > 0 && it.dw > 0, "bad shape in chain item");
+        if (it.streak_enabled) {
+            VKX_REQUIRE(it.streak_thickness + it.streak_gap > 0, "streak thickness + gap must be positive");
+            if (it.streak_alpha < 0.0 || it.streak_alpha > 1.0) {
+                vkx_set_error("alpha=%g is invalid.", it.streak_alpha);
+                return VKX_ERR_INVALID;
+            }
+        }
         const size_t bytes = (size_t)it.dh * it.dw * 3;
         if (bytes > max_plane) max_plane = bytes;
     }
@@ -76,6 +83,12 @@ VKX_EXPORT int vkx_chain_rgb_batch_dev(vkx_ctx *ctx, const vkx_chain_item *items
             rc = vkx_add_noise_i16_dev(ctx, cur, it.dh, it.dw, 3, cur_stride, it.noise, it.noise_stride_el, out, ostride);
             if (rc) return rc;
             cur = out; cur_stride = ostride;
+        }
+        if (it.streak_enabled) {   // in place on the caller's destination, which the last stage above has written
+            rc = vkx_line_streak_u8_dev(ctx, it.dst, it.dh, it.dw, 3, it.dst_stride, it.streak_thickness, it.streak_gap,
+                                        it.streak_dash_thickness, it.streak_dash_gap, it.streak_color, it.streak_alpha,
+                                        it.streak_enable_vert, it.streak_enable_hori);
+            if (rc) return rc;
         }
     }
     return VKX_OK;

@@ -64,6 +64,11 @@ struct ItemDev {
     int R;             // blur radius (0 = no blur); the tile proper is (64 - 2R) pixels wide and high
     int hue_on, hue_delta;
     unsigned short kq[8];
+    // line_streak stage (photometric/streak.py:56-99), after the noise
+    int streak_on, streak_step, streak_thickness, streak_dash, streak_dash_step, streak_dash_gap;
+    int streak_vert, streak_hori, streak_copy;
+    int streak_color[3];
+    float streak_alpha;
     // element mode (k_tile_remap): the same tile machinery gathers up to four elements of any supported type through
     // the shared lattice instead of running the RGB chain
     int n_elems, pad_;
@@ -214,7 +219,8 @@ constexpr size_t kFusedLds = kLdsOwn + kLdsHbB + kLdsCellR + kLdsCellH + kLdsLut
 // INTERIOR: the tile's whole 64 x 64 window lies inside the image and its candidates fit one LDS chunk -- the common
 // case (about 89 % of the tiles of a 2048^2 page).  Border handling (row / column validity, BORDER_REFLECT_101 lane tables,
 // the global-memory fallback for candidates beyond the chunk) compiles away; the arithmetic is the same.
-template <int KIND>   // 0 generic, 1 interior, 2 empty, 3 element remap (no photometric stage, any element types)
+// STREAK: the line_streak stage is compiled in (its own kernel instance, so batches without it keep the lean one)
+template <int KIND, bool STREAK = false>   // 0 generic, 1 interior, 2 empty, 3 element remap (any element types)
 __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, const int tile_id,
                                            const vkc::CellC *__restrict__ cells, const TileBin &bin,
                                            const HsvLut *__restrict__ lut, int phase_limit)
@@ -549,6 +555,9 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
     const bool hue_on = it.hue_on != 0;
     const int hue_delta = it.hue_delta;
     const int full4 = (tw >> 2) << 2;          // columns covered by whole 4-pixel (12-byte) groups
+    const bool streak_on = STREAK && it.streak_on != 0;
+    const int sxm = streak_on ? (x0 + ocx) % it.streak_step : 0;        // this lane's column phase in the stripe period
+    const int sxd = streak_on ? (x0 + ocx) % it.streak_dash_step : 0;
     // EMPTY: no lattice cell reaches the window, so every pixel of it maps to (0, 0) (the reference's unfilled map
     // entries) = the source's first pixel; the blur of a constant is that constant (kernel taps sum to 256), and the
     // hue shift is evaluated once per lane instead of once per pixel.
@@ -591,6 +600,27 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
             g = vkd::clamp_u8((int16_t)((int16_t)g + (int16_t)(nzA[i] >> 16)));
             b = vkd::clamp_u8((int16_t)((int16_t)b + (int16_t)(nzB[i] & 0xffff)));
         }
+        if (STREAK && streak_on) {
+            // stripe masks: vertical x % (t + g) < t, horizontal y % (t + g) < t, dash gaps cut them; vertical stripes
+            // are blended first, then horizontal ones (crossings twice); trunc(fl32(1 - a) * v + a * c)
+            const int ym = gy % it.streak_step, yd = gy % it.streak_dash_step;
+            bool mv = it.streak_vert && sxm < it.streak_thickness;
+            bool mh = it.streak_hori && ym < it.streak_thickness;
+            if (it.streak_dash) {
+                if (yd < it.streak_dash_gap) mv = false;
+                if (sxd < it.streak_dash_gap) mh = false;
+            }
+            const float w1 = it.streak_alpha, w0 = 1.0f - w1;
+            int *ch[3] = {&r, &g, &b};
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                int v = *ch[c];
+                const int col = it.streak_color[c];
+                if (mv) { const float t0 = w0 * (float)v, t1 = w1 * (float)col; v = it.streak_copy ? col : (int)(uint8_t)(t0 + t1); }
+                if (mh) { const float t0 = w0 * (float)v, t1 = w1 * (float)col; v = it.streak_copy ? col : (int)(uint8_t)(t0 + t1); }
+                *ch[c] = v;
+            }
+        }
         // 4 adjacent pixels = 12 bytes = 3 dwords: lanes with (column & 3) = 0, 1, 2 each build one dword from
         // their own pixel and their right neighbour's
         const uint32_t P = (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16);
@@ -611,6 +641,7 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
     }
 }
 
+template <bool STREAK>
 __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fused(const ItemDev *__restrict__ items,
                                                           const vkc::CellC *__restrict__ cells,
                                                           const TileBin *__restrict__ bins,
@@ -635,9 +666,9 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
     const int wx0 = tx * Tw - it.R, wy0 = ty * Tw - it.R;
     const int nc = bin.rmax1 > 0 ? max(0, bin.rmax1 - bin.rmin) * max(0, bin.cmax1 - bin.cmin) : 0;
     const bool interior = wx0 >= 0 && wy0 >= 0 && wx0 + W <= it.dw && wy0 + W <= it.dh && nc <= NLDSCELL && phase_limit != 3;
-    if (nc == 0) chain_tile<2>(it, tl, tile_id, cells, bin, lut, phase_limit);
-    else if (interior) chain_tile<1>(it, tl, tile_id, cells, bin, lut, phase_limit);
-    else chain_tile<0>(it, tl, tile_id, cells, bin, lut, phase_limit);
+    if (nc == 0) chain_tile<2, STREAK>(it, tl, tile_id, cells, bin, lut, phase_limit);
+    else if (interior) chain_tile<1, STREAK>(it, tl, tile_id, cells, bin, lut, phase_limit);
+    else chain_tile<0, STREAK>(it, tl, tile_id, cells, bin, lut, phase_limit);
 }
 
 // Element mode of the same tile machinery: Image / Mask / ScoreMap (uint8 x 1, 3, 4 channels, float32) of one call
@@ -702,7 +733,11 @@ static int launch_tiles(vkx_ctx *ctx, std::vector<ItemDev> &dev, std::vector<int
     if (elements) {
         { VKX_TIMED(ctx, "k_tile_remap"); k_tile_remap<<<dim3(slots, n_items), NTHREADS, kFusedLds, ctx->stream>>>(d_items, cells, bins); }
     } else {
-        { VKX_TIMED(ctx, "k_chain_fused"); k_chain_fused<<<dim3(slots, n_items), NTHREADS, kFusedLds, ctx->stream>>>(d_items, cells, bins, lut, phase_limit); }
+        bool streak = false;
+        for (const ItemDev &d : dev) streak = streak || d.streak_on != 0;
+        VKX_TIMED(ctx, "k_chain_fused");
+        if (streak) k_chain_fused<true><<<dim3(slots, n_items), NTHREADS, kFusedLds, ctx->stream>>>(d_items, cells, bins, lut, phase_limit);
+        else k_chain_fused<false><<<dim3(slots, n_items), NTHREADS, kFusedLds, ctx->stream>>>(d_items, cells, bins, lut, phase_limit);
     }
     VKX_LAUNCH_CHECK();
     return VKX_OK;
@@ -733,6 +768,19 @@ int vkx_chain_fused_try(vkx_ctx *ctx, const vkx_chain_item *items, int n_items)
         d.tiles_x = (it.dw + Tw - 1) / Tw; d.tiles_y = (it.dh + Tw - 1) / Tw;
         d.cell_base = (int)ncells;
         d.hue_on = it.hue_enabled; d.hue_delta = it.hue_delta;
+        d.streak_on = it.streak_enabled && it.streak_alpha != 0.0 && (it.streak_enable_vert || it.streak_enable_hori);
+        if (it.streak_enabled) {
+            if (it.streak_thickness + it.streak_gap <= 0) return VKX_ERR_UNSUPPORTED;   // the staged path reports it
+            d.streak_thickness = it.streak_thickness;
+            d.streak_step = it.streak_thickness + it.streak_gap;
+            d.streak_dash = it.streak_dash_thickness > 0 && it.streak_dash_gap > 0;
+            d.streak_dash_step = d.streak_dash ? it.streak_dash_thickness + it.streak_dash_gap : 1;
+            d.streak_dash_gap = it.streak_dash_gap;
+            d.streak_vert = it.streak_enable_vert; d.streak_hori = it.streak_enable_hori;
+            d.streak_copy = it.streak_alpha == 1.0;
+            d.streak_alpha = (float)it.streak_alpha;
+            for (int c = 0; c < 3; c++) d.streak_color[c] = it.streak_color[c];
+        }
         for (int k = 0; k < 8; k++) d.kq[k] = 0;
         if (d.R > 0 && vkx_gaussian_kernel_q8_host(it.blur_ksize, it.blur_sigma, d.kq)) return VKX_ERR_UNSUPPORTED;
         cell_prefix[i] = (int)ncells;
