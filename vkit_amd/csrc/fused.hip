@@ -236,7 +236,9 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
     int *lsdiv = (int *)(smem + kLdsOwn + kLdsHbB + kLdsCellR + kLdsCellH);
     int *lhdiv = lsdiv + 256;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the wavefront index is uniform: read it into an SGPR so that every row index, row address and row predicate
+    // derived from it is scalar arithmetic instead of per-lane (64-bit, quarter-rate) multiplies
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ty = tl / it.tiles_x, tx = tl - ty * it.tiles_x;
     const int R = it.R, K = 2 * R + 1, Tw = tile_side(R);
     const int dw = it.dw, dh = it.dh;
