@@ -177,9 +177,10 @@ __device__ __forceinline__ void hue_shift_px(const int *sdiv, const int *hdiv, i
     const int v = max(b, max(g, r)), vmin = min(b, min(g, r));
     const int diff = v - vmin;
     const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
-    const int S = (diff * sdiv[v] + (1 << 11)) >> 12;
+    // table entries are < 2^24 (255 << 12, 256 << 12 / 6), diff and hh < 2^11: 24-bit multiplies (full rate) are exact
+    const int S = (__mul24(diff, sdiv[v]) + (1 << 11)) >> 12;
     int hh = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
-    hh = (hh * hdiv[diff] + (1 << 11)) >> 12;
+    hh = (__mul24(hh, hdiv[diff]) + (1 << 11)) >> 12;
     hh += hh < 0 ? 256 : 0;
     int H = vkd::clamp_u8(hh);
     H = (H + delta) & 255;   // python modulo 256 of a sum that may be negative
