@@ -105,6 +105,28 @@ def test_deferred_fill_equals_sequential(N):
     np.testing.assert_array_equal(sequential.mat, want)
 
 
+def test_deferred_fill_float32_layers(N):
+    """A list of float32 layers (height-map style fills with masks, keep-max / keep-min, alpha planes) in one launch."""
+    from vkit_amd.element import Box, Mask, ScoreMap
+    from vkit_amd.element.opt import deferred_fill
+    rng = default_rng(31)
+    base = (rng.random((90, 130), dtype=np.float32) * 20).astype(np.float32)
+    score = ScoreMap(mat=base.copy(), is_prob=False)
+    want = base.copy()
+    with deferred_fill(score.mat) as session:
+        for i in range(30):
+            h, w = int(rng.integers(3, 40)), int(rng.integers(3, 60))
+            up, left = int(rng.integers(0, 90 - h)), int(rng.integers(0, 130 - w))
+            box = Box(up=up, down=up + h - 1, left=left, right=left + w - 1)
+            mask = (rng.random((h, w)) < 0.6).astype(np.uint8)
+            value = float(rng.uniform(0, 40))
+            mode = i % 3
+            Mask(mat=mask, box=box).fill_score_map(score, value, keep_max_value=(mode == 1), keep_min_value=(mode == 2))
+            O.fill(want, (up, left, h, w), value, mask=mask, mode=mode)
+        assert len(session.layers) == 30
+    np.testing.assert_array_equal(score.mat, want)
+
+
 # ------------------------------------------------------------------ bicubic resize
 @pytest.mark.parametrize('src_shape,dst_shape', [((20, 30), (33, 47)), ((64, 64), (64, 64)), ((97, 131), (40, 55)),
                                                  ((5, 7), (50, 3)), ((1, 1), (9, 9)), ((300, 200), (301, 199))])
