@@ -199,6 +199,18 @@ int vkx_pointwise_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn,
 int vkx_pointwise_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride, int op, int p0,
                      int p1, unsigned channel_mask, uint8_t *dst, ptrdiff_t dst_stride);
 
+/* The two halves of boundary_equalization / histogram_equalization  photometric/color.py:214-285:
+ *   vkx_histogram_u8  per-channel histogram int32 [cn][256] (exact integer reduction; device pointer for *_dev)
+ *   vkx_apply_lut_u8  dst[c] = lut[c][src[c]] on the channels of channel_mask (0 = all); lut is a HOST uint8 [cn][256]
+ * Between them the host turns the histogram into the table: min / max and the float32 scale for the boundary
+ * equalisation (numpy arithmetic of :222-243 per distinct value), cv.equalizeHist's cumulative table for the other. */
+int vkx_histogram_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride, int32_t *hist);
+int vkx_histogram_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride, int32_t *hist);
+int vkx_apply_lut_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                         const uint8_t *lut_host, unsigned channel_mask, uint8_t *dst, ptrdiff_t dst_stride);
+int vkx_apply_lut_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                     const uint8_t *lut_host, unsigned channel_mask, uint8_t *dst, ptrdiff_t dst_stride);
+
 /* impulse_noise  photometric/noise.py:125-150: selector uint8 [h, w] (0 keep, 1 salt = 255, 2 pepper = 0 on every
  * channel of the pixel), drawn by the caller's numpy Generator (rng.choice). */
 int vkx_impulse_noise_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,

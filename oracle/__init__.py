@@ -368,6 +368,67 @@ def speckle_noise(img, noise):
     return out
 
 
+def _select(img, channels):
+    return img[:, :, list(channels)] if channels else img
+
+
+def boundary_equalization(img, channels=None):
+    """[numpy] boundary_equalization_image -- photometric/color.py:214-252, photometric/opt.py:49-57: per channel
+    (v - min) * (255 / (max - min)) in float32, np.round, clip, uint8.  Plain numpy, the reference's statements."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    mat = _select(img, channels).astype(np.float32)
+    if mat.ndim == 2:
+        delta = mat.max() - mat.min()
+        if delta == 0.0:
+            return img
+        mat -= mat.min()
+        mat *= np.float32(255.0) / delta
+    else:
+        flat = mat.reshape(-1, mat.shape[-1])
+        val_min, val_max = flat.min(axis=0), flat.max(axis=0)
+        delta = val_max - val_min
+        mask = delta > 0
+        if not mask.any():
+            return img
+        mat[:, :, mask] -= val_min[mask]
+        mat[:, :, mask] *= 255.0 / delta[mask]
+    mat = np.clip(np.round(mat), 0, 255).astype(np.uint8)
+    if channels:
+        out = img.copy()
+        out[:, :, list(channels)] = mat
+        return out
+    return mat
+
+
+def equalize_hist_plane(plane):
+    """[cv2] cv.equalizeHist -- imgproc/histogram.cpp: lut[i] = saturate_u8(cvRound(cumsum * scale)), scale =
+    255 / (total - hist[first non-zero bin]) in float32; a single-valued plane comes back unchanged."""
+    plane = np.ascontiguousarray(plane, dtype=np.uint8)
+    hist = np.bincount(plane.ravel(), minlength=256).astype(np.int64)
+    first = int(np.nonzero(hist)[0][0]) if plane.size else 0
+    total = plane.size
+    if plane.size == 0 or hist[first] == total:
+        return plane.copy()
+    scale = np.float32(255.0) / np.float32(total - hist[first])
+    lut = np.zeros(256, np.uint8)
+    acc = 0
+    for i in range(first + 1, 256):
+        acc += int(hist[i])
+        lut[i] = np.uint8(min(max(int(np.rint(np.float32(acc) * scale)), 0), 255))
+    return lut[plane]
+
+
+def histogram_equalization(img, channels=None):
+    """histogram_equalization_image -- photometric/color.py:255-285: cv.equalizeHist on every selected channel."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    if img.ndim == 2:
+        return equalize_hist_plane(img)
+    out = img.copy()
+    for c in (channels if channels else range(img.shape[2])):
+        out[:, :, c] = equalize_hist_plane(img[:, :, c])
+    return out
+
+
 def resize_cubic(src, dsize_hw):
     """cv.resize(src, (dw, dh), interpolation=cv.INTER_CUBIC) for uint8 HxW[xC] or float32 HxW."""
     dh, dw = int(dsize_hw[0]), int(dsize_hw[1])

@@ -231,6 +231,15 @@ def gen_pointwise_ops():
     for i, (std, seed) in enumerate([(0.1, 0), (0.3, 1), (1.5, 2)]):
         out[f'speckle_{i}'] = D.speckle_noise.distort(D.SpeckleNoiseConfig(std=std), image=img, rng=default_rng(seed)).image.mat
     out['speckle_cases'] = np.asarray([[0.1, 0], [0.3, 1], [1.5, 2]])
+    low = (src // 3 + 40).astype(np.uint8)          # a narrow value range, so the equalisation has work to do
+    low[:, :, 1] = 77                                 # one flat channel (delta == 0: left alone)
+    out['beq_src'] = low
+    limg = Image(mat=low)
+    out['beq_all'] = D.boundary_equalization.distort(D.BoundaryEqualizationConfig(), image=limg).image.mat
+    out['beq_c02'] = D.boundary_equalization.distort(D.BoundaryEqualizationConfig(channels=[0, 2]), image=limg).image.mat
+    out['beq_c1'] = D.boundary_equalization.distort(D.BoundaryEqualizationConfig(channels=[1]), image=limg).image.mat
+    out['beq_gray'] = D.boundary_equalization.distort(D.BoundaryEqualizationConfig(),
+                                                       image=Image(mat=low[:, :, 0].copy())).image.mat
     gray = Image(mat=src[:, :, 0].copy())
     out['gray_complement_thr'] = D.complement.distort(D.ComplementConfig(threshold=128), image=gray).image.mat
     out['gray_impulse'] = D.impulse_noise.distort(D.ImpulseNoiseConfig(prob_salt=0.1, prob_pepper=0.1), image=gray,
@@ -316,6 +325,10 @@ def gen_policy_configs():
         'impulse_noise': (P_noise.ImpulseNoiseConfigGenerator, P_noise.ImpulseNoiseConfigGeneratorConfig),
         'speckle_noise': (P_noise.SpeckleNoiseConfigGenerator, P_noise.SpeckleNoiseConfigGeneratorConfig),
         'complement': (P_color.ComplementConfigGenerator, P_color.ComplementConfigGeneratorConfig),
+        'boundary_equalization': (P_color.BoundaryEqualizationConfigGenerator,
+                                  P_color.BoundaryEqualizationConfigGeneratorConfig),
+        'histogram_equalization': (P_color.HistogramEqualizationConfigGenerator,
+                                   P_color.HistogramEqualizationConfigGeneratorConfig),
         'brightness_shift': (P_color.BrightnessShiftConfigGenerator, P_color.BrightnessShiftConfigGeneratorConfig),
         'color_balance': (P_color.ColorBalanceConfigGenerator, P_color.ColorBalanceConfigGeneratorConfig),
         'posterization': (P_color.PosterizationConfigGenerator, P_color.PosterizationConfigGeneratorConfig),

@@ -53,6 +53,10 @@ GENERATORS = {
     'impulse_noise': (P_noise.ImpulseNoiseConfigGenerator, P_noise.ImpulseNoiseConfigGeneratorConfig),
     'speckle_noise': (P_noise.SpeckleNoiseConfigGenerator, P_noise.SpeckleNoiseConfigGeneratorConfig),
     'complement': (P_color.ComplementConfigGenerator, P_color.ComplementConfigGeneratorConfig),
+    'boundary_equalization': (P_color.BoundaryEqualizationConfigGenerator,
+                              P_color.BoundaryEqualizationConfigGeneratorConfig),
+    'histogram_equalization': (P_color.HistogramEqualizationConfigGenerator,
+                               P_color.HistogramEqualizationConfigGeneratorConfig),
     'brightness_shift': (P_color.BrightnessShiftConfigGenerator, P_color.BrightnessShiftConfigGeneratorConfig),
     'color_balance': (P_color.ColorBalanceConfigGenerator, P_color.ColorBalanceConfigGeneratorConfig),
     'posterization': (P_color.PosterizationConfigGenerator, P_color.PosterizationConfigGeneratorConfig),
@@ -78,7 +82,7 @@ def test_policy_configs_match_reference_draw_for_draw(golden_dir):
         # the generator consumed exactly the reference's number of draws
         assert float(rng.random()) == rec['next_random']
         checked += 1
-    assert checked > 370
+    assert checked > 400
 
 
 def test_affine_states(golden_dir):

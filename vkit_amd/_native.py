@@ -151,6 +151,8 @@ for _sfx in ('', '_dev'):
     _SIGNATURES['vkx_cvt_color_u8' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_int, c_void_p, c_ssize]
     _SIGNATURES['vkx_brightness_shift_rgb' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_int, c_void_p, c_ssize]
     _SIGNATURES['vkx_color_balance_rgb' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_double, c_void_p, c_ssize]
+    _SIGNATURES['vkx_histogram_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p]
+    _SIGNATURES['vkx_apply_lut_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_uint, c_void_p, c_ssize]
     _SIGNATURES['vkx_pointwise_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_int, c_int, c_int, c_uint, c_void_p, c_ssize]
     _SIGNATURES['vkx_impulse_noise_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_ssize, c_void_p, c_ssize]
     _SIGNATURES['vkx_speckle_noise_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_ssize, c_void_p, c_ssize]
@@ -561,6 +563,28 @@ def permute_channels(img, indices, ctx=None):
     if len(indices) != (1 if img.ndim == 2 else img.shape[2]):
         raise ValueError('one index per channel')
     return pointwise(img, POINT_PERMUTE, packed, ctx=ctx)
+
+
+def histogram(img, ctx=None):
+    """Per-channel histogram, int32 [cn, 256]."""
+    ctx = ctx or default_ctx()
+    img, h, w, cn, stride = _u8_plane(img)
+    hist = np.zeros((cn, 256), np.int32)
+    check(lib().vkx_histogram_u8(ctx.handle, _ptr(img), h, w, cn, stride, _ptr(hist)))
+    return hist
+
+
+def apply_lut(img, lut, channels=None, ctx=None):
+    """dst[..., c] = lut[c][img[..., c]] on the selected channels; lut uint8 [cn, 256]."""
+    ctx = ctx or default_ctx()
+    img, h, w, cn, stride = _u8_plane(img)
+    lut = np.ascontiguousarray(lut, dtype=np.uint8)
+    if lut.shape != (cn, 256):
+        raise ValueError(f'table must be uint8 [{cn}, 256]')
+    dst = np.empty_like(img)
+    check(lib().vkx_apply_lut_u8(ctx.handle, _ptr(img), h, w, cn, stride, _ptr(lut), _channel_mask(channels),
+                                 _ptr(dst), stride))
+    return dst
 
 
 def impulse_noise(img, selector, ctx=None):

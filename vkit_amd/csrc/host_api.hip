@@ -444,3 +444,30 @@ VKX_EXPORT int vkx_color_balance_rgb(vkx_ctx *ctx, const uint8_t *src, int h, in
                                       (ptrdiff_t)w * 3));
     return st.finish();
 }
+
+VKX_EXPORT int vkx_histogram_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride, int32_t *hist)
+{
+    VKX_REQUIRE(ctx && src && hist, "NULL argument");
+    VKX_REQUIRE(h >= 0 && w >= 0 && cn >= 1 && cn <= 4, "bad shape");
+    HostStage st(ctx);
+    const int s = st.add(src, nullptr, (size_t)w * cn, h, src_stride);
+    const int d = st.add(nullptr, hist, sizeof(int32_t) * 256 * cn, 1, sizeof(int32_t) * 256 * cn);
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_histogram_u8_dev(ctx, st.dev<uint8_t>(s), h, w, cn, (ptrdiff_t)w * cn, st.dev<int32_t>(d)));
+    return st.finish();
+}
+
+VKX_EXPORT int vkx_apply_lut_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                                const uint8_t *lut_host, unsigned channel_mask, uint8_t *dst, ptrdiff_t dst_stride)
+{
+    VKX_REQUIRE(ctx && src && dst && lut_host, "NULL argument");
+    VKX_REQUIRE(h >= 0 && w >= 0 && cn >= 1 && cn <= 4, "bad shape");
+    HostStage st(ctx);
+    const int s = st.add(src, nullptr, (size_t)w * cn, h, src_stride);
+    const int d = st.add(nullptr, dst, (size_t)w * cn, h, dst_stride);
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_apply_lut_u8_dev(ctx, st.dev<uint8_t>(s), h, w, cn, (ptrdiff_t)w * cn, lut_host, channel_mask,
+                                 st.dev<uint8_t>(d), (ptrdiff_t)w * cn));
+    return st.finish();
+}
+

@@ -2,6 +2,8 @@
 // Arithmetic specification and reference citations: oracle/vkx_oracle.c.
 #include "vkx_internal.h"
 
+#include <algorithm>
+
 #include <float.h>
 
 #include <math.h>
@@ -356,6 +358,38 @@ __global__ void __launch_bounds__(256) k_speckle_noise(const uint8_t *__restrict
     dst[(ptrdiff_t)y * dstride + xe] = (uint8_t)v;
 }
 
+// Per-channel histogram (the reduction half of boundary_equalization / histogram_equalization, photometric/color.py:
+// 214-285): a workgroup accumulates into LDS counters and flushes once.  Integer counts: exact in any order.
+__global__ void __launch_bounds__(256) k_histogram(const uint8_t *__restrict__ src, int h, int w, int cn, ptrdiff_t sstride,
+                                                   int *__restrict__ hist /* [cn][256] */)
+{
+    __shared__ int lh[4 * 256];
+    for (int i = threadIdx.x; i < cn * 256; i += 256) lh[i] = 0;
+    __syncthreads();
+    const int wc = w * cn;
+    for (int y = blockIdx.y; y < h; y += gridDim.y) {
+        const uint8_t *row = src + (ptrdiff_t)y * sstride;
+        for (int xe = blockIdx.x * 256 + threadIdx.x; xe < wc; xe += gridDim.x * 256)
+            atomicAdd(&lh[(xe % cn) * 256 + row[xe]], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cn * 256; i += 256)
+        if (lh[i]) atomicAdd(&hist[i], lh[i]);
+}
+
+// dst[c] = lut[c][src[c]] on the selected channels (the per-value half of the two equalisations).
+__global__ void __launch_bounds__(256) k_apply_lut(const uint8_t *__restrict__ src, int h, int w, int cn, ptrdiff_t sstride,
+                                                   uint8_t *__restrict__ dst, ptrdiff_t dstride,
+                                                   const uint8_t *__restrict__ lut /* [cn][256] */, unsigned chmask)
+{
+    const int xe = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (xe >= w * cn || y >= h) return;
+    const int c = xe % cn;
+    const uint8_t v = src[(ptrdiff_t)y * sstride + xe];
+    dst[(ptrdiff_t)y * dstride + xe] = (chmask == 0 || ((chmask >> c) & 1u)) ? lut[c * 256 + v] : v;
+}
+
 // fill_np_array blend of one value: trunc(fl32(fl32(1 - a) * dst) + fl32(a * val)), products rounded separately.
 __device__ __forceinline__ uint8_t blend_u8(uint8_t d, uint8_t v, float w1)
 {
@@ -595,6 +629,38 @@ VKX_EXPORT int vkx_speckle_noise_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h,
     if (h == 0 || w == 0) return VKX_OK;
     dim3 block(64, 4), grid(vkx_blocks((size_t)w * cn, 64), vkx_blocks(h, 4));
     { VKX_TIMED(ctx, "k_speckle_noise"); k_speckle_noise<<<grid, block, 0, ctx->stream>>>(src, h, w * cn, src_stride, noise, noise_stride_el, dst, dst_stride); }
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_histogram_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                                    int32_t *hist)
+{
+    VKX_REQUIRE(ctx && src && hist, "NULL argument");
+    VKX_REQUIRE(h >= 0 && w >= 0, "bad shape");
+    VKX_REQUIRE(cn >= 1 && cn <= 4, "1..4 channels");
+    VKX_HIP(hipMemsetAsync(hist, 0, sizeof(int32_t) * 256 * cn, ctx->stream));
+    if (h == 0 || w == 0) return VKX_OK;
+    dim3 grid(std::min(vkx_blocks((size_t)w * cn, 256), 16u), std::min((unsigned)h, 256u));
+    { VKX_TIMED(ctx, "k_histogram"); k_histogram<<<grid, 256, 0, ctx->stream>>>(src, h, w, cn, src_stride, hist); }
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_apply_lut_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                                    const uint8_t *lut_host, unsigned channel_mask, uint8_t *dst, ptrdiff_t dst_stride)
+{
+    int rc = check_plane(ctx, src, dst, h, w);
+    if (rc) return rc;
+    VKX_REQUIRE(lut_host != nullptr, "NULL table");
+    VKX_REQUIRE(cn >= 1 && cn <= 4, "1..4 channels");
+    if (h == 0 || w == 0) return VKX_OK;
+    rc = vkx_scratch_reserve(ctx, &ctx->misc, 1024);
+    if (rc) return rc;
+    VKX_HIP(hipMemcpyAsync(ctx->misc.ptr, lut_host, (size_t)256 * cn, hipMemcpyHostToDevice, ctx->stream));
+    VKX_HIP(hipStreamSynchronize(ctx->stream));   // the table is the caller's memory
+    dim3 block(64, 4), grid(vkx_blocks((size_t)w * cn, 64), vkx_blocks(h, 4));
+    { VKX_TIMED(ctx, "k_apply_lut"); k_apply_lut<<<grid, block, 0, ctx->stream>>>(src, h, w, cn, src_stride, dst, dst_stride, (const uint8_t *)ctx->misc.ptr, channel_mask); }
     VKX_LAUNCH_CHECK();
     return VKX_OK;
 }

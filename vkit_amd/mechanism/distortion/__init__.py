@@ -26,6 +26,10 @@ from .photometric.color import (
     brightness_shift,
     ColorBalanceConfig,
     color_balance,
+    BoundaryEqualizationConfig,
+    boundary_equalization,
+    HistogramEqualizationConfig,
+    histogram_equalization,
 )
 from .photometric.blur import GaussianBlurConfig, gaussian_blur
 from .photometric.noise import (

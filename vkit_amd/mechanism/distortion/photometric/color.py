@@ -1,11 +1,13 @@
 """Colour distortions on the accelerated path: ``mean_shift``, ``color_shift`` (reference:
 photometric/color.py:32-116) and the integer per-value members ``complement``, ``posterization``,
-``channel_permutation`` (:299-357, :400-432), ``brightness_shift`` (:125-160) and ``color_balance`` (:360-397).  The
-remaining colour operators of the reference (std shift, the equalisations) need whole-image reductions in numpy's
-summation order and are not on the path."""
+``channel_permutation`` (:299-357, :400-432), ``brightness_shift`` (:125-160), ``color_balance`` (:360-397) and the two
+equalisations (:205-285): a per-channel histogram on the GPU (exact integer reduction), a 256-entry table per channel
+built on the host with the reference's arithmetic, and a table pass on the GPU.  ``std_shift`` needs a float32 mean in
+numpy's sequential summation order and is not on the path."""
 from typing import Any, Mapping, Optional, Sequence
 
 import attrs
+import numpy as np
 from numpy.random import Generator as RandomGenerator
 
 from vkit_amd import _native
@@ -198,4 +200,85 @@ color_balance = Distortion(
     config_cls=ColorBalanceConfig,
     state_cls=DistortionNopState[ColorBalanceConfig],
     func_image=color_balance_image,
+)
+
+
+def _selected_channels(image: Image, channels: Optional[Sequence[int]]):
+    return list(channels) if channels else list(range(max(image.num_channels, 1)))
+
+
+@attrs.define
+class BoundaryEqualizationConfig(DistortionConfig):
+    channels: Optional[Sequence[int]] = None
+
+
+def boundary_equalization_image(config: BoundaryEqualizationConfig, state, image: Image,
+                                rng: Optional[RandomGenerator]):
+    """Stretch every selected channel to [0, 255]: ``round((v - min) * (255 / (max - min)))`` in float32.  The minimum /
+    maximum come from the GPU histogram; the per-value expression is evaluated once per grey level into a table."""
+    hist = _native.histogram(image.mat)
+    selected = _selected_channels(image, config.channels)
+    lut = np.tile(np.arange(256, dtype=np.uint8), (hist.shape[0], 1))
+    levels = np.arange(256, dtype=np.float32)
+    any_delta = False
+    for c in selected:
+        present = np.nonzero(hist[c])[0]
+        if present.size == 0:
+            continue
+        vmin, vmax = np.float32(present[0]), np.float32(present[-1])
+        delta = vmax - vmin
+        if not delta > 0:
+            continue            # a flat channel is left alone (reference :232-240)
+        any_delta = True
+        # 3-D images divide a python float by a float32 array, 2-D ones by a float32 scalar: float32 either way
+        values = (levels - vmin) * (np.float32(255.0) / delta)
+        lut[c] = np.clip(np.round(values), 0, 255).astype(np.uint8)
+    if not any_delta:
+        return image
+    return attrs.evolve(image, mat=_native.apply_lut(image.mat, lut, channels=selected))
+
+
+boundary_equalization = Distortion(
+    config_cls=BoundaryEqualizationConfig,
+    state_cls=DistortionNopState[BoundaryEqualizationConfig],
+    func_image=boundary_equalization_image,
+)
+
+
+@attrs.define
+class HistogramEqualizationConfig(DistortionConfig):
+    channels: Optional[Sequence[int]] = None
+
+
+def _equalize_hist_table(hist_c: np.ndarray) -> np.ndarray:
+    """cv.equalizeHist's table from one channel histogram (imgproc/histogram.cpp): cumulative count above the first
+    occupied bin times 255 / (total - count of that bin), float32, rounded half to even, saturated."""
+    lut = np.arange(256, dtype=np.uint8)
+    present = np.nonzero(hist_c)[0]
+    total = int(hist_c.sum())
+    if present.size == 0 or int(hist_c[present[0]]) == total:
+        return lut                                           # single-valued plane: unchanged
+    first = int(present[0])
+    scale = np.float32(255.0) / np.float32(total - int(hist_c[first]))
+    cum = np.cumsum(hist_c.astype(np.int64))
+    acc = (cum - cum[first]).astype(np.float32)            # sum of bins first+1 .. i
+    table = np.clip(np.rint(acc * scale), 0, 255).astype(np.uint8)
+    table[:first + 1] = 0
+    return table
+
+
+def histogram_equalization_image(config: HistogramEqualizationConfig, state, image: Image,
+                                 rng: Optional[RandomGenerator]):
+    hist = _native.histogram(image.mat)
+    selected = _selected_channels(image, config.channels)
+    lut = np.tile(np.arange(256, dtype=np.uint8), (hist.shape[0], 1))
+    for c in selected:
+        lut[c] = _equalize_hist_table(hist[c])
+    return attrs.evolve(image, mat=_native.apply_lut(image.mat, lut, channels=selected))
+
+
+histogram_equalization = Distortion(
+    config_cls=HistogramEqualizationConfig,
+    state_cls=DistortionNopState[HistogramEqualizationConfig],
+    func_image=histogram_equalization_image,
 )

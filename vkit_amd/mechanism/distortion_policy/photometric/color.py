@@ -140,3 +140,36 @@ class ColorBalanceConfigGenerator(
 
 
 color_balance_policy_factory = DistortionPolicyFactory(distortion.color_balance, ColorBalanceConfigGenerator)
+
+
+@attrs.define
+class BoundaryEqualizationConfigGeneratorConfig:
+    pass
+
+
+class BoundaryEqualizationConfigGenerator(
+        DistortionConfigGenerator[BoundaryEqualizationConfigGeneratorConfig, distortion.BoundaryEqualizationConfig]):
+
+    def __call__(self, shape: Tuple[int, int], rng: RandomGenerator):
+        return distortion.BoundaryEqualizationConfig(channels=sample_channels(rng))
+
+
+boundary_equalization_policy_factory = DistortionPolicyFactory(distortion.boundary_equalization,
+                                                               BoundaryEqualizationConfigGenerator)
+
+
+@attrs.define
+class HistogramEqualizationConfigGeneratorConfig:
+    pass
+
+
+class HistogramEqualizationConfigGenerator(
+        DistortionConfigGenerator[HistogramEqualizationConfigGeneratorConfig, distortion.HistogramEqualizationConfig]):
+
+    def __call__(self, shape: Tuple[int, int], rng: RandomGenerator):
+        return distortion.HistogramEqualizationConfig(channels=sample_channels(rng))
+
+
+histogram_equalization_policy_factory = DistortionPolicyFactory(distortion.histogram_equalization,
+                                                                HistogramEqualizationConfigGenerator)
+
