@@ -39,7 +39,7 @@ from vkit.mechanism import distortion as D  # noqa: E402
 from vkit.mechanism.distortion_policy import random_distortion as RD  # noqa: E402
 from vkit.mechanism.distortion_policy.geometric import mls as P_mls, camera as P_cam, affine as P_aff  # noqa: E402
 from vkit.mechanism.distortion_policy.photometric import (  # noqa: E402
-    blur as P_blur, color as P_color, noise as P_noise, streak as P_streak,
+    blur as P_blur, color as P_color, noise as P_noise, streak as P_streak, effect as P_effect,
 )
 from vkit.mechanism.distortion.geometric.mls import SimilarityMlsState  # noqa: E402
 from vkit.mechanism.distortion.geometric import affine as G_aff  # noqa: E402
@@ -240,6 +240,13 @@ def gen_pointwise_ops():
     out['beq_c1'] = D.boundary_equalization.distort(D.BoundaryEqualizationConfig(channels=[1]), image=limg).image.mat
     out['beq_gray'] = D.boundary_equalization.distort(D.BoundaryEqualizationConfig(),
                                                        image=Image(mat=low[:, :, 0].copy())).image.mat
+    for i, (rough, rmax, rmin, seed) in enumerate([(0.5, 1.0, 0.0, 0), (0.85, 0.6, 0.1, 1), (0.2, 0.3, 0.0, 2)]):
+        out[f'fog_{i}'] = D.fog.distort(D.FogConfig(roughness=rough, ratio_max=rmax, ratio_min=rmin), image=img,
+                                        rng=default_rng(seed)).image.mat
+    out['fog_cases'] = np.asarray([[0.5, 1.0, 0.0, 0], [0.85, 0.6, 0.1, 1], [0.2, 0.3, 0.0, 2]])
+    wide = Image(mat=default_rng(92).integers(0, 256, (70, 300, 3), dtype=np.uint8))
+    out['fog_wide_src'] = wide.mat
+    out['fog_wide'] = D.fog.distort(D.FogConfig(roughness=0.6, fog_rgb=(200, 10, 30)), image=wide, rng=default_rng(7)).image.mat
     gray = Image(mat=src[:, :, 0].copy())
     out['gray_complement_thr'] = D.complement.distort(D.ComplementConfig(threshold=128), image=gray).image.mat
     out['gray_impulse'] = D.impulse_noise.distort(D.ImpulseNoiseConfig(prob_salt=0.1, prob_pepper=0.1), image=gray,
@@ -325,6 +332,7 @@ def gen_policy_configs():
         'impulse_noise': (P_noise.ImpulseNoiseConfigGenerator, P_noise.ImpulseNoiseConfigGeneratorConfig),
         'speckle_noise': (P_noise.SpeckleNoiseConfigGenerator, P_noise.SpeckleNoiseConfigGeneratorConfig),
         'complement': (P_color.ComplementConfigGenerator, P_color.ComplementConfigGeneratorConfig),
+        'fog': (P_effect.FogConfigGenerator, P_effect.FogConfigGeneratorConfig),
         'boundary_equalization': (P_color.BoundaryEqualizationConfigGenerator,
                                   P_color.BoundaryEqualizationConfigGeneratorConfig),
         'histogram_equalization': (P_color.HistogramEqualizationConfigGenerator,

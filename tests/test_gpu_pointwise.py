@@ -177,3 +177,23 @@ def test_equalisations(P):
     gray = Image(mat=low[:, :, 0].copy())
     np.testing.assert_array_equal(D.histogram_equalization.distort({}, image=gray).image.mat,
                                   O.histogram_equalization(gray.mat))
+
+
+def test_fog_reproduces_reference_outputs(P):
+    """fog: host diamond-square field (caller's rng stream) + one page-sized alpha layer on the GPU; numpy-only in the
+    reference, so the outputs below are genuine reference outputs."""
+    from vkit_amd.element import Image
+    from vkit_amd.mechanism import distortion as D
+    img = Image(mat=P['src'])
+    for i, (rough, rmax, rmin, seed) in enumerate(P['fog_cases']):
+        out = D.fog.distort({'roughness': float(rough), 'ratio_max': float(rmax), 'ratio_min': float(rmin)}, image=img,
+                            rng=default_rng(int(seed))).image
+        np.testing.assert_array_equal(out.mat, P[f'fog_{i}'])
+    wide = Image(mat=P['fog_wide_src'])
+    out = D.fog.distort({'roughness': 0.6, 'fog_rgb': (200, 10, 30)}, image=wide, rng=default_rng(7)).image
+    np.testing.assert_array_equal(out.mat, P['fog_wide'])
+    # through an HSV image: RGB round trip around the blend, like the reference's to_rgb_image / to_original_image
+    hsv = img.to_hsv_image()
+    got = D.fog.distort({'roughness': 0.5}, image=hsv, rng=default_rng(0)).image
+    rgb = D.fog.distort({'roughness': 0.5}, image=hsv.to_rgb_image(), rng=default_rng(0)).image
+    np.testing.assert_array_equal(got.mat, O.rgb2hsv_full(rgb.mat))

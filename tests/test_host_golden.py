@@ -14,8 +14,8 @@ from vkit_amd.mechanism.distortion.geometric.grid_rendering.interface import Fun
 from vkit_amd.mechanism.distortion.interface import Distortion, DistortionConfig, DistortionNopState
 from vkit_amd.mechanism.distortion_policy import RandomDistortionFactoryConfig, random_distortion_factory
 from vkit_amd.mechanism.distortion_policy.geometric import affine as P_aff, camera as P_cam, mls as P_mls
-from vkit_amd.mechanism.distortion_policy.photometric import blur as P_blur, color as P_color, noise as P_noise, \
-    streak as P_streak
+from vkit_amd.mechanism.distortion_policy.photometric import blur as P_blur, color as P_color, effect as P_effect, \
+    noise as P_noise, streak as P_streak
 from vkit_amd.utility import dyn_structure
 
 
@@ -53,6 +53,7 @@ GENERATORS = {
     'impulse_noise': (P_noise.ImpulseNoiseConfigGenerator, P_noise.ImpulseNoiseConfigGeneratorConfig),
     'speckle_noise': (P_noise.SpeckleNoiseConfigGenerator, P_noise.SpeckleNoiseConfigGeneratorConfig),
     'complement': (P_color.ComplementConfigGenerator, P_color.ComplementConfigGeneratorConfig),
+    'fog': (P_effect.FogConfigGenerator, P_effect.FogConfigGeneratorConfig),
     'boundary_equalization': (P_color.BoundaryEqualizationConfigGenerator,
                               P_color.BoundaryEqualizationConfigGeneratorConfig),
     'histogram_equalization': (P_color.HistogramEqualizationConfigGenerator,
@@ -82,7 +83,7 @@ def test_policy_configs_match_reference_draw_for_draw(golden_dir):
         # the generator consumed exactly the reference's number of draws
         assert float(rng.random()) == rec['next_random']
         checked += 1
-    assert checked > 400
+    assert checked > 420
 
 
 def test_affine_states(golden_dir):
@@ -200,7 +201,7 @@ def test_random_distortion_table_and_sampling(golden_dir):
 
 def test_unsupported_policy_fails_loudly():
     rd = random_distortion_factory.create(None)
-    fog = [p for p in rd.stages[0].config.distortion_policies if p.name == 'fog'][0]
+    fog = [p for p in rd.stages[0].config.distortion_policies if p.name == 'jpeg_quality'][0]
     with pytest.raises(NotImplementedError):
         fog.distort(level=3, image=None, rng=default_rng(0))
 

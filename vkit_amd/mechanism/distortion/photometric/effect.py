@@ -1,0 +1,115 @@
+"""``fog`` (reference: photometric/effect.py:89-216).  The fog density field is a diamond-square fractal drawn from the
+caller-visible numpy Generator stream on the host (like every random plane of the path); the per-pixel work -- blend
+every pixel towards the fog colour with the field as float32 alpha, ``uint8(clip((1 - a) * px + a * fog))`` -- is the
+alpha composite ``vkx_fill_u8`` with one page-sized layer.  ``jpeg_quality`` and ``pixelation`` of the same reference
+module are outside the path (an encoder round trip; INTER_LINEAR / INTER_NEAREST resizing)."""
+from typing import Any, Mapping, Optional, Tuple
+
+import attrs
+import numpy as np
+from numpy.random import Generator as RandomGenerator
+
+from vkit_amd import _native
+from vkit_amd.element import Image, ImageMode
+from ..interface import Distortion, DistortionConfig, DistortionNopState
+
+
+def generate_diamond_square_mask(shape: Tuple[int, int], roughness: float, rng: RandomGenerator):
+    """Midpoint-displacement field on a (2^k + 1)^2 lattice, cropped at a random offset.  Draw order and arithmetic follow
+    the reference statement by statement: four corner draws; per level the diamond centres, then the two families of
+    edge midpoints, each ``(1 - r^level) * neighbour_sum / 4 + r^level * uniform`` with wrap-around neighbours."""
+    assert 0.0 <= roughness <= 1.0
+    height, width = shape
+    size = int(2**np.ceil(np.log2(max(height, width))) + 1)
+    field = np.zeros((size, size), dtype=np.float32)
+    field[0, 0] = rng.uniform(0.0, 1.0)
+    field[0, -1] = rng.uniform(0.0, 1.0)
+    field[-1, -1] = rng.uniform(0.0, 1.0)
+    field[-1, 0] = rng.uniform(0.0, 1.0)
+
+    step, level = size - 1, 0
+    while step >= 2:
+        noise_weight = roughness**level
+        half = step // 2
+        corners = field[0:size:step, 0:size:step]
+        pair_down = corners + np.roll(corners, shift=-1, axis=0)    # corner + the one below (wraps)
+        pair_right = corners + np.roll(corners, shift=-1, axis=1)   # corner + the one to the right (wraps)
+
+        # centres of the squares
+        around = (pair_down + pair_right)[:-1, :-1]
+        centres = (1 - noise_weight) * around / 4 + noise_weight * rng.uniform(0, 1, around.shape)
+        field[half:size:step, half:size:step] = centres
+
+        # midpoints of the horizontal edges: the two corners of the edge + the centres above and below
+        centres_vert = centres + np.roll(centres, shift=1, axis=0)
+        centres_vert = np.vstack([centres_vert, centres_vert[0]])
+        around = pair_right[:, :-1] + centres_vert
+        field[0:size:step, half:size:step] = ((1 - noise_weight) * around / 4
+                                              + noise_weight * rng.uniform(0, 1, around.shape))
+
+        # midpoints of the vertical edges
+        centres_hori = centres + np.roll(centres, shift=1, axis=1)
+        centres_hori = np.hstack([centres_hori, centres_hori[0].reshape(-1, 1)])
+        around = pair_down[:-1] + centres_hori
+        field[half:size:step, 0:size:step] = ((1 - noise_weight) * around / 4
+                                              + noise_weight * rng.uniform(0, 1, around.shape))
+        level += 1
+        step = half
+
+    up = rng.integers(0, size - height + 1)
+    left = rng.integers(0, size - width + 1)
+    return field[up:up + height, left:left + width]
+
+
+@attrs.define
+class FogConfig(DistortionConfig):
+    roughness: float
+    fog_rgb: Tuple[int, int, int] = (226, 238, 234)
+    ratio_max: float = 1.0
+    ratio_min: float = 0.0
+
+    _rng_state: Optional[Mapping[str, Any]] = None
+
+    @property
+    def supports_rng_state(self) -> bool:
+        return True
+
+    @property
+    def rng_state(self) -> Optional[Mapping[str, Any]]:
+        return self._rng_state
+
+    @rng_state.setter
+    def rng_state(self, val: Mapping[str, Any]):
+        self._rng_state = val
+
+
+def fog_image(config: FogConfig, state, image: Image, rng: Optional[RandomGenerator]):
+    mode = image.mode
+    if mode == ImageMode.GRAYSCALE:
+        raise NotImplementedError('fog on GRAYSCALE images (a fractional grey fog value) is outside the accelerated path')
+    if mode != ImageMode.RGB:
+        image = image.to_rgb_image()
+    assert rng is not None
+    mask = generate_diamond_square_mask(image.shape, config.roughness, rng)
+    # stretch the field to [ratio_min, ratio_max] (float32 in place, like the reference)
+    mask = np.array(mask, dtype=np.float32)
+    mask -= mask.min()
+    mask /= mask.max()
+    assert config.ratio_min < config.ratio_max
+    mask *= (config.ratio_max - config.ratio_min)
+    mask += config.ratio_min
+
+    mat = np.array(image.mat)
+    layer = _native.make_layer((0, 0, image.height, image.width), 3, tuple(int(v) for v in config.fog_rgb), alpha=mask)
+    _native.fill(mat, [layer])
+    image = attrs.evolve(image, mat=mat)
+    if mode != ImageMode.RGB:
+        image = image.to_target_mode_image(mode)
+    return image
+
+
+fog = Distortion(
+    config_cls=FogConfig,
+    state_cls=DistortionNopState[FogConfig],
+    func_image=fog_image,
+)

@@ -1,0 +1,28 @@
+"""Config generator of ``fog`` (reference: distortion_policy/photometric/effect.py:88-130)."""
+from typing import Tuple
+
+import attrs
+from numpy.random import Generator as RandomGenerator
+
+from vkit_amd.mechanism import distortion
+from ..opt import sample_float
+from ..type import DistortionConfigGenerator, DistortionPolicyFactory
+
+
+@attrs.define
+class FogConfigGeneratorConfig:
+    roughness_min: float = 0.2
+    roughness_max: float = 0.85
+    ratio_max_min: float = 0.2
+    ratio_max_max: float = 0.75
+
+
+class FogConfigGenerator(DistortionConfigGenerator[FogConfigGeneratorConfig, distortion.FogConfig]):
+
+    def __call__(self, shape: Tuple[int, int], rng: RandomGenerator):
+        roughness = sample_float(self.level, self.config.roughness_min, self.config.roughness_max, None, rng)
+        ratio_max = sample_float(self.level, self.config.ratio_max_min, self.config.ratio_max_max, None, rng)
+        return distortion.FogConfig(roughness=roughness, ratio_max=ratio_max)
+
+
+fog_policy_factory = DistortionPolicyFactory(distortion.fog, FogConfigGenerator)
