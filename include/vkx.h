@@ -211,6 +211,16 @@ int vkx_apply_lut_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn,
 int vkx_apply_lut_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
                      const uint8_t *lut_host, unsigned channel_mask, uint8_t *dst, ptrdiff_t dst_stride);
 
+/* mat[pos_y, pos_x] -- numpy advanced indexing with two int32 index planes [dh, dw]: the pixel shuffle of
+ * glass_blur  photometric/blur.py:204-250 (the planes come from the caller's numpy Generator stream).  Entries outside
+ * the source are an error (VKX_ERR_INVALID). */
+int vkx_gather_u8_dev(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t src_stride,
+                      const int32_t *pos_y, const int32_t *pos_x, ptrdiff_t pos_stride_el, uint8_t *dst, int dh, int dw,
+                      ptrdiff_t dst_stride);
+int vkx_gather_u8(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t src_stride,
+                  const int32_t *pos_y, const int32_t *pos_x, ptrdiff_t pos_stride_el, uint8_t *dst, int dh, int dw,
+                  ptrdiff_t dst_stride);
+
 /* impulse_noise  photometric/noise.py:125-150: selector uint8 [h, w] (0 keep, 1 salt = 255, 2 pepper = 0 on every
  * channel of the pixel), drawn by the caller's numpy Generator (rng.choice). */
 int vkx_impulse_noise_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,

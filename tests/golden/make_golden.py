@@ -247,6 +247,18 @@ def gen_pointwise_ops():
     wide = Image(mat=default_rng(92).integers(0, 256, (70, 300, 3), dtype=np.uint8))
     out['fog_wide_src'] = wide.mat
     out['fog_wide'] = D.fog.distort(D.FogConfig(roughness=0.6, fog_rgb=(200, 10, 30)), image=wide, rng=default_rng(7)).image.mat
+    # glass_blur's pixel shuffle: the blur is stubbed with the identity and the image encodes its own coordinates, so
+    # the output IS the (row, column) source plane pair of the reference's numpy bookkeeping
+    coords = np.zeros((97, 141, 3), np.uint8)
+    coords[:, :, 0] = np.arange(97).reshape(-1, 1)
+    coords[:, :, 1] = np.arange(141).reshape(1, -1)
+    saved_blur = cv_stub.GaussianBlur
+    cv_stub.GaussianBlur = lambda mat, ksize, sigma: mat
+    for i, (delta, loop, seed) in enumerate([(1, 1, 0), (1, 4, 1), (2, 5, 2), (3, 2, 3)]):
+        out[f'glass_planes_{i}'] = D.glass_blur.distort(D.GlassBlurConfig(sigma=1.0, delta=delta, loop=loop),
+                                                         image=Image(mat=coords), rng=default_rng(seed)).image.mat[:, :, :2]
+    out['glass_cases'] = np.asarray([(1, 1, 0), (1, 4, 1), (2, 5, 2), (3, 2, 3)])
+    cv_stub.GaussianBlur = saved_blur
     gray = Image(mat=src[:, :, 0].copy())
     out['gray_complement_thr'] = D.complement.distort(D.ComplementConfig(threshold=128), image=gray).image.mat
     out['gray_impulse'] = D.impulse_noise.distort(D.ImpulseNoiseConfig(prob_salt=0.1, prob_pepper=0.1), image=gray,
@@ -332,6 +344,7 @@ def gen_policy_configs():
         'impulse_noise': (P_noise.ImpulseNoiseConfigGenerator, P_noise.ImpulseNoiseConfigGeneratorConfig),
         'speckle_noise': (P_noise.SpeckleNoiseConfigGenerator, P_noise.SpeckleNoiseConfigGeneratorConfig),
         'complement': (P_color.ComplementConfigGenerator, P_color.ComplementConfigGeneratorConfig),
+        'glass_blur': (P_blur.GlassBlurConfigGenerator, P_blur.GlassBlurConfigGeneratorConfig),
         'fog': (P_effect.FogConfigGenerator, P_effect.FogConfigGeneratorConfig),
         'boundary_equalization': (P_color.BoundaryEqualizationConfigGenerator,
                                   P_color.BoundaryEqualizationConfigGeneratorConfig),

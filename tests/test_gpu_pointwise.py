@@ -197,3 +197,29 @@ def test_fog_reproduces_reference_outputs(P):
     got = D.fog.distort({'roughness': 0.5}, image=hsv, rng=default_rng(0)).image
     rgb = D.fog.distort({'roughness': 0.5}, image=hsv.to_rgb_image(), rng=default_rng(0)).image
     np.testing.assert_array_equal(got.mat, O.rgb2hsv_full(rgb.mat))
+
+
+def test_glass_blur_and_gather(P):
+    from vkit_amd import _native as N
+    from vkit_amd.element import Image
+    from vkit_amd.mechanism import distortion as D
+    from vkit_amd.mechanism.distortion.photometric.blur import _estimate_gaussian_kernel_size, glass_shuffle_planes
+    rng = default_rng(17)
+    for cn in (1, 3, 4):
+        src = rng.integers(0, 256, (61, 83) + ((cn,) if cn > 1 else ()), dtype=np.uint8)
+        py = rng.integers(0, 61, (40, 120))
+        px = rng.integers(0, 83, (40, 120))
+        np.testing.assert_array_equal(N.gather(src, py, px), src[py, px])
+    with pytest.raises(N.VkxError):
+        N.gather(np.zeros((4, 4), np.uint8), np.full((2, 2), 4), np.zeros((2, 2), int))
+    # the operator: blur (oracle) then the reference-pinned shuffle planes (tests/test_host_golden.py)
+    src = P['src']
+    for sigma, delta, loop, seed in ((1.0, 1, 3, 0), (0.6, 2, 5, 1)):
+        out = D.glass_blur.distort({'sigma': sigma, 'delta': delta, 'loop': loop}, image=Image(mat=src),
+                                   rng=default_rng(seed)).image
+        pos_y, pos_x = glass_shuffle_planes(src.shape[:2], delta, loop, default_rng(seed))
+        want = O.gaussian_blur(src, _estimate_gaussian_kernel_size(sigma), sigma)[pos_y, pos_x]
+        np.testing.assert_array_equal(out.mat, want)
+    big = rng.integers(0, 256, (2048, 2048, 3), dtype=np.uint8)
+    pos_y, pos_x = glass_shuffle_planes((2048, 2048), 1, 2, default_rng(5))
+    np.testing.assert_array_equal(N.gather(big, pos_y, pos_x), big[pos_y, pos_x])

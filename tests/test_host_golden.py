@@ -54,6 +54,7 @@ GENERATORS = {
     'speckle_noise': (P_noise.SpeckleNoiseConfigGenerator, P_noise.SpeckleNoiseConfigGeneratorConfig),
     'complement': (P_color.ComplementConfigGenerator, P_color.ComplementConfigGeneratorConfig),
     'fog': (P_effect.FogConfigGenerator, P_effect.FogConfigGeneratorConfig),
+    'glass_blur': (P_blur.GlassBlurConfigGenerator, P_blur.GlassBlurConfigGeneratorConfig),
     'boundary_equalization': (P_color.BoundaryEqualizationConfigGenerator,
                               P_color.BoundaryEqualizationConfigGeneratorConfig),
     'histogram_equalization': (P_color.HistogramEqualizationConfigGenerator,
@@ -83,7 +84,7 @@ def test_policy_configs_match_reference_draw_for_draw(golden_dir):
         # the generator consumed exactly the reference's number of draws
         assert float(rng.random()) == rec['next_random']
         checked += 1
-    assert checked > 420
+    assert checked > 440
 
 
 def test_affine_states(golden_dir):
@@ -197,6 +198,17 @@ def test_random_distortion_table_and_sampling(golden_dir):
     rd2 = random_distortion_factory.create(RandomDistortionFactoryConfig(
         force_post_rotate=True, disabled_policy_names=['defocus_blur', 'zoom_in_blur']))
     assert [[p.name for p in s.config.distortion_policies] for s in rd2.stages] == ref['post_rotate_stage_names']
+
+
+def test_glass_shuffle_planes_match_reference(golden_dir):
+    """The index planes of glass_blur's pixel shuffle (numpy bookkeeping on the rng stream) against the reference."""
+    from vkit_amd.mechanism.distortion.photometric.blur import glass_shuffle_planes
+    P = np.load(os.path.join(golden_dir, 'pointwise_ops.npz'))
+    for i, (delta, loop, seed) in enumerate(P['glass_cases']):
+        pos_y, pos_x = glass_shuffle_planes((97, 141), int(delta), int(loop), default_rng(int(seed)))
+        planes = P[f'glass_planes_{i}']
+        assert (pos_y == planes[:, :, 0]).all() and (pos_x == planes[:, :, 1]).all(), i
+        assert (pos_y != np.arange(97).reshape(-1, 1)).any()
 
 
 def test_unsupported_policy_fails_loudly():

@@ -153,6 +153,7 @@ for _sfx in ('', '_dev'):
     _SIGNATURES['vkx_color_balance_rgb' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_double, c_void_p, c_ssize]
     _SIGNATURES['vkx_histogram_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p]
     _SIGNATURES['vkx_apply_lut_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_uint, c_void_p, c_ssize]
+    _SIGNATURES['vkx_gather_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_void_p, c_ssize, c_void_p, c_int, c_int, c_ssize]
     _SIGNATURES['vkx_pointwise_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_int, c_int, c_int, c_uint, c_void_p, c_ssize]
     _SIGNATURES['vkx_impulse_noise_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_ssize, c_void_p, c_ssize]
     _SIGNATURES['vkx_speckle_noise_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_ssize, c_void_p, c_ssize]
@@ -584,6 +585,21 @@ def apply_lut(img, lut, channels=None, ctx=None):
     dst = np.empty_like(img)
     check(lib().vkx_apply_lut_u8(ctx.handle, _ptr(img), h, w, cn, stride, _ptr(lut), _channel_mask(channels),
                                  _ptr(dst), stride))
+    return dst
+
+
+def gather(img, pos_y, pos_x, ctx=None):
+    """img[pos_y, pos_x] for two integer index planes of one shape."""
+    ctx = ctx or default_ctx()
+    img, h, w, cn, stride = _u8_plane(img)
+    pos_y = np.ascontiguousarray(pos_y, dtype=np.int32)
+    pos_x = np.ascontiguousarray(pos_x, dtype=np.int32)
+    if pos_y.ndim != 2 or pos_y.shape != pos_x.shape:
+        raise ValueError('index planes must be 2-D and of one shape')
+    dh, dw = pos_y.shape
+    dst = np.empty((dh, dw) + img.shape[2:], np.uint8)
+    check(lib().vkx_gather_u8(ctx.handle, _ptr(img), h, w, cn, stride, _ptr(pos_y), _ptr(pos_x), dw, _ptr(dst), dh, dw,
+                              dw * cn))
     return dst
 
 

@@ -471,3 +471,20 @@ VKX_EXPORT int vkx_apply_lut_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, 
     return st.finish();
 }
 
+VKX_EXPORT int vkx_gather_u8(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t src_stride,
+                             const int32_t *pos_y, const int32_t *pos_x, ptrdiff_t pos_stride_el, uint8_t *dst, int dh, int dw,
+                             ptrdiff_t dst_stride)
+{
+    VKX_REQUIRE(ctx && src && pos_y && pos_x && dst, "NULL argument");
+    VKX_REQUIRE(sh >= 0 && sw >= 0 && dh >= 0 && dw >= 0 && cn > 0, "bad shape");
+    HostStage st(ctx);
+    const int s = st.add(src, nullptr, (size_t)sw * cn, sh, src_stride);
+    const int py = st.add(pos_y, nullptr, (size_t)dw * 4, dh, pos_stride_el * 4);
+    const int px = st.add(pos_x, nullptr, (size_t)dw * 4, dh, pos_stride_el * 4);
+    const int d = st.add(nullptr, dst, (size_t)dw * cn, dh, dst_stride);
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_gather_u8_dev(ctx, st.dev<uint8_t>(s), sh, sw, cn, (ptrdiff_t)sw * cn, st.dev<int32_t>(py), st.dev<int32_t>(px),
+                              dw, st.dev<uint8_t>(d), dh, dw, (ptrdiff_t)dw * cn));
+    return st.finish();
+}
+

@@ -390,6 +390,30 @@ __global__ void __launch_bounds__(256) k_apply_lut(const uint8_t *__restrict__ s
     dst[(ptrdiff_t)y * dstride + xe] = (chmask == 0 || ((chmask >> c) & 1u)) ? lut[c * 256 + v] : v;
 }
 
+// mat[pos_y, pos_x] (numpy advanced indexing with two index planes): the pixel shuffle of glass_blur,
+// photometric/blur.py:204-250.  Indices are validated on the device: an out-of-range entry raises the flag.
+template <int CN>
+__global__ void __launch_bounds__(256) k_gather(const uint8_t *__restrict__ src, int sh, int sw, ptrdiff_t sstride,
+                                                const int32_t *__restrict__ pos_y, const int32_t *__restrict__ pos_x,
+                                                ptrdiff_t pstride, uint8_t *__restrict__ dst, int dh, int dw,
+                                                ptrdiff_t dstride, int *__restrict__ bad)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= dw || y >= dh) return;
+    const int sy = pos_y[(ptrdiff_t)y * pstride + x], sx = pos_x[(ptrdiff_t)y * pstride + x];
+    uint8_t *d = dst + (ptrdiff_t)y * dstride + (ptrdiff_t)x * CN;
+    if ((unsigned)sy >= (unsigned)sh || (unsigned)sx >= (unsigned)sw) {
+        atomicExch(bad, 1);
+#pragma unroll
+        for (int c = 0; c < CN; c++) d[c] = 0;
+        return;
+    }
+    const uint8_t *p = src + (ptrdiff_t)sy * sstride + (ptrdiff_t)sx * CN;
+#pragma unroll
+    for (int c = 0; c < CN; c++) d[c] = p[c];
+}
+
 // fill_np_array blend of one value: trunc(fl32(fl32(1 - a) * dst) + fl32(a * val)), products rounded separately.
 __device__ __forceinline__ uint8_t blend_u8(uint8_t d, uint8_t v, float w1)
 {
@@ -662,6 +686,39 @@ VKX_EXPORT int vkx_apply_lut_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int
     dim3 block(64, 4), grid(vkx_blocks((size_t)w * cn, 64), vkx_blocks(h, 4));
     { VKX_TIMED(ctx, "k_apply_lut"); k_apply_lut<<<grid, block, 0, ctx->stream>>>(src, h, w, cn, src_stride, dst, dst_stride, (const uint8_t *)ctx->misc.ptr, channel_mask); }
     VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_gather_u8_dev(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t src_stride,
+                                 const int32_t *pos_y, const int32_t *pos_x, ptrdiff_t pos_stride_el, uint8_t *dst, int dh,
+                                 int dw, ptrdiff_t dst_stride)
+{
+    VKX_REQUIRE(ctx && src && pos_y && pos_x && dst, "NULL argument");
+    VKX_REQUIRE(sh >= 0 && sw >= 0 && dh >= 0 && dw >= 0, "bad shape");
+    VKX_REQUIRE(cn == 1 || cn == 3 || cn == 4, "1, 3 or 4 channels");
+    VKX_REQUIRE(src != dst, "gather cannot run in place");
+    if (dh == 0 || dw == 0) return VKX_OK;
+    int rc = vkx_scratch_reserve(ctx, &ctx->misc, 256);
+    if (rc) return rc;
+    int *bad = (int *)ctx->misc.ptr;
+    VKX_HIP(hipMemsetAsync(bad, 0, sizeof(int), ctx->stream));
+    dim3 block(64, 4), grid(vkx_blocks(dw, 64), vkx_blocks(dh, 4));
+    {
+        VKX_TIMED(ctx, "k_gather");
+        switch (cn) {
+        case 1: k_gather<1><<<grid, block, 0, ctx->stream>>>(src, sh, sw, src_stride, pos_y, pos_x, pos_stride_el, dst, dh, dw, dst_stride, bad); break;
+        case 3: k_gather<3><<<grid, block, 0, ctx->stream>>>(src, sh, sw, src_stride, pos_y, pos_x, pos_stride_el, dst, dh, dw, dst_stride, bad); break;
+        default: k_gather<4><<<grid, block, 0, ctx->stream>>>(src, sh, sw, src_stride, pos_y, pos_x, pos_stride_el, dst, dh, dw, dst_stride, bad); break;
+        }
+    }
+    VKX_LAUNCH_CHECK();
+    int flag = 0;
+    VKX_HIP(hipMemcpyAsync(&flag, bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    VKX_HIP(hipStreamSynchronize(ctx->stream));
+    if (flag) {
+        vkx_set_error("gather index outside the %dx%d source", sh, sw);
+        return VKX_ERR_INVALID;
+    }
     return VKX_OK;
 }
 

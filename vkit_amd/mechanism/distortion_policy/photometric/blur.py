@@ -1,11 +1,12 @@
-"""Config generator of ``gaussian_blur`` (reference: distortion_policy/photometric/blur.py:25-53)."""
+"""Config generators of ``gaussian_blur`` and ``glass_blur`` (reference: distortion_policy/photometric/blur.py:25-53,
+121-170)."""
 from typing import Tuple
 
 import attrs
 from numpy.random import Generator as RandomGenerator
 
 from vkit_amd.mechanism import distortion
-from ..opt import sample_float
+from ..opt import sample_float, sample_int
 from ..type import DistortionConfigGenerator, DistortionPolicyFactory
 
 
@@ -24,3 +25,27 @@ class GaussianBlurConfigGenerator(
 
 
 gaussian_blur_policy_factory = DistortionPolicyFactory(distortion.gaussian_blur, GaussianBlurConfigGenerator)
+
+
+@attrs.define
+class GlassBlurConfigGeneratorConfig:
+    sigma_min: float = 0.5
+    sigma_max: float = 1.0
+    delta_min: int = 1
+    delta_max: int = 1
+    loop_min: int = 1
+    loop_max: int = 4
+
+
+class GlassBlurConfigGenerator(DistortionConfigGenerator[GlassBlurConfigGeneratorConfig, distortion.GlassBlurConfig]):
+
+    def __call__(self, shape: Tuple[int, int], rng: RandomGenerator):
+        cfg = self.config
+        sigma = sample_float(self.level, cfg.sigma_min, cfg.sigma_max, None, rng)
+        delta = sample_int(self.level, cfg.delta_min, cfg.delta_max, None, rng)
+        loop = sample_int(self.level, cfg.loop_min, cfg.loop_max, None, rng)
+        return distortion.GlassBlurConfig(sigma=sigma, delta=delta, loop=loop)
+
+
+glass_blur_policy_factory = DistortionPolicyFactory(distortion.glass_blur, GlassBlurConfigGenerator)
+

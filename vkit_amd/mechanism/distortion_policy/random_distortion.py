@@ -50,7 +50,7 @@ class _UnsupportedPolicyFactory:
 
 UNSUPPORTED_POLICY_NAMES = (
     'std_shift',
-    'defocus_blur', 'motion_blur', 'glass_blur', 'zoom_in_blur', 'poisson_noise', 'jpeg_quality', 'pixelation',
+    'defocus_blur', 'motion_blur', 'zoom_in_blur', 'poisson_noise', 'jpeg_quality', 'pixelation',
     'ellipse_streak',
 )
 _U = _UnsupportedPolicyFactory
@@ -271,7 +271,7 @@ _PHOTOMETRIC_POLICY_FACTORIES_AND_DEFAULT_WEIGHTS_SUM_PAIRS = (
     ((color.mean_shift_policy_factory, color.color_shift_policy_factory, color.brightness_shift_policy_factory, _U('std_shift'),
       color.boundary_equalization_policy_factory, color.histogram_equalization_policy_factory, color.complement_policy_factory,
       color.posterization_policy_factory, color.color_balance_policy_factory, color.channel_permutation_policy_factory), 10.0),
-    ((blur.gaussian_blur_policy_factory, _U('defocus_blur'), _U('motion_blur'), _U('glass_blur'),
+    ((blur.gaussian_blur_policy_factory, _U('defocus_blur'), _U('motion_blur'), blur.glass_blur_policy_factory,
       _U('zoom_in_blur')), 1.0),
     ((noise.gaussion_noise_policy_factory, _U('poisson_noise'), noise.impulse_noise_policy_factory,
       noise.speckle_noise_policy_factory), 3.0),
