@@ -296,6 +296,17 @@ int vkx_resize_cubic_u8(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn
 int vkx_resize_cubic_f32(vkx_ctx *ctx, const float *src, int sh, int sw, ptrdiff_t src_stride_el,
                          float *dst, int dh, int dw, ptrdiff_t dst_stride_el);
 
+/* cv.resize with the interpolation codes of cv2 (NEAREST 0, LINEAR 1, CUBIC 2) on uint8: pixelation
+ * photometric/effect.py:61-79 shrinks with INTER_LINEAR and grows back with INTER_NEAREST.  LINEAR: 11-bit
+ * coefficients, OpenCV's two-stage vertical rounding, an exact 2 x 2 shrink is the INTER_AREA box. */
+#define VKX_INTER_NEAREST 0
+#define VKX_INTER_LINEAR 1
+#define VKX_INTER_CUBIC 2
+int vkx_resize_u8_dev(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t src_stride,
+                      uint8_t *dst, int dh, int dw, ptrdiff_t dst_stride, int interpolation);
+int vkx_resize_u8(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t src_stride,
+                  uint8_t *dst, int dh, int dw, ptrdiff_t dst_stride, int interpolation);
+
 /* ---- polygon rasterisation -----------------------------------------------------------
  * cv.fillPoly(zeros((h, w), uint8), [pts], 1): PolygonInternals.np_mask element/polygon.py:70-77
  * (Bresenham LINE_8 outline + even-odd scanline spans).  pts: HOST int32 [npts, 2] as (x, y), all

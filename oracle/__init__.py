@@ -368,6 +368,34 @@ def speckle_noise(img, noise):
     return out
 
 
+def _resize_u8(fn, src, dsize_hw):
+    dh, dw = int(dsize_hw[0]), int(dsize_hw[1])
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    s3, squeeze = _as3(src)
+    sh, sw, cn = s3.shape
+    dst = np.empty((dh, dw, cn), np.uint8)
+    rc = fn(_p(s3), sh, sw, cn, _ss(sw * cn), _p(dst), dh, dw, _ss(dw * cn))
+    assert rc == 0, rc
+    return dst[:, :, 0] if squeeze else dst
+
+
+def resize_linear(src, dsize_hw):
+    """cv.resize(src, (dw, dh), interpolation=cv.INTER_LINEAR) on uint8."""
+    return _resize_u8(lib().vko_resize_linear_u8, src, dsize_hw)
+
+
+def resize_nearest(src, dsize_hw):
+    """cv.resize(src, (dw, dh), interpolation=cv.INTER_NEAREST) on uint8."""
+    return _resize_u8(lib().vko_resize_nearest_u8, src, dsize_hw)
+
+
+def pixelation(img, ratio):
+    """pixelation_image -- photometric/effect.py:61-79."""
+    h, w = img.shape[:2]
+    small = resize_linear(img, (round(h * ratio), round(w * ratio)))
+    return resize_nearest(small, (h, w))
+
+
 def _select(img, channels):
     return img[:, :, list(channels)] if channels else img
 

@@ -1376,6 +1376,84 @@ VKO_API int vko_resize_cubic_f32(const float *src, int sh, int sw, ptrdiff_t sst
     return 0;
 }
 
+/* [cv2] cv.resize(..., INTER_LINEAR) and INTER_NEAREST on uint8 -- photometric/effect.py:61-79 (pixelation:
+ * shrink bilinearly, grow back with nearest neighbour).  imgproc/resize.cpp:
+ *   LINEAR  f = (float)((d + 0.5) * scale - 0.5), s = floor(f), f -= s; s < 0 -> (s, f) = (0, 0); s >= size - 1 ->
+ *           (size - 1, 0) horizontally (rows are clipped instead); coefficients (1 - f, f) as cvRound(c * 2048) shorts;
+ *           horizontal pass in int32; vertical pass uchar((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2).
+ *           An exact 2 x 2 shrink is routed to INTER_AREA: (a + b + c + d + 2) >> 2.
+ *   NEAREST source index = min(floor(d * scale), size - 1), scale = 1 / (dsize / ssize) in double. */
+static void vko_linear_axis(int ssize, int dsize, int *ofs, short *coef, int horizontal)
+{
+    double inv_scale = (double)dsize / ssize, scale = 1. / inv_scale;
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s0 = (int)floorf(f);
+        f -= s0;
+        if (horizontal) {
+            if (s0 < 0) { f = 0; s0 = 0; }
+            if (s0 >= ssize - 1) { f = 0; s0 = ssize - 1; }
+        }
+        ofs[d] = s0;
+        coef[2 * d] = (short)sat_short(cv_round_f((1.f - f) * 2048.f));
+        coef[2 * d + 1] = (short)sat_short(cv_round_f(f * 2048.f));
+    }
+}
+
+VKO_API int vko_resize_linear_u8(const uint8_t *src, int sh, int sw, int cn, ptrdiff_t sstep, uint8_t *dst,
+                                 int dh, int dw, ptrdiff_t dstep)
+{
+    if (sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || cn <= 0) return -1;
+    if (sw == 2 * dw && sh == 2 * dh) {   /* is_area_fast with iscale 2: INTER_AREA's 2 x 2 box */
+        for (int y = 0; y < dh; y++)
+            for (int x = 0; x < dw; x++)
+                for (int c = 0; c < cn; c++) {
+                    const uint8_t *p = src + (ptrdiff_t)(2 * y) * sstep + (2 * x) * cn + c;
+                    dst[(ptrdiff_t)y * dstep + x * cn + c] = (uint8_t)((p[0] + p[cn] + p[sstep] + p[sstep + cn] + 2) >> 2);
+                }
+        return 0;
+    }
+    int *xofs = (int *)malloc(sizeof(int) * dw), *yofs = (int *)malloc(sizeof(int) * dh);
+    short *xa = (short *)malloc(sizeof(short) * 2 * dw), *yb = (short *)malloc(sizeof(short) * 2 * dh);
+    if (!xofs || !yofs || !xa || !yb) return -2;
+    vko_linear_axis(sw, dw, xofs, xa, 1);
+    vko_linear_axis(sh, dh, yofs, yb, 0);
+    for (int dy = 0; dy < dh; dy++) {
+        const uint8_t *S0 = src + (ptrdiff_t)vko_clip_index(yofs[dy], sh) * sstep;
+        const uint8_t *S1 = src + (ptrdiff_t)vko_clip_index(yofs[dy] + 1, sh) * sstep;
+        int b0 = yb[2 * dy], b1 = yb[2 * dy + 1];
+        for (int dx = 0; dx < dw; dx++) {
+            int sx0 = xofs[dx], sx1 = vko_clip_index(sx0 + 1, sw);
+            int a0 = xa[2 * dx], a1 = xa[2 * dx + 1];
+            for (int c = 0; c < cn; c++) {
+                int h0 = S0[sx0 * cn + c] * a0 + S0[sx1 * cn + c] * a1;
+                int h1 = S1[sx0 * cn + c] * a0 + S1[sx1 * cn + c] * a1;
+                dst[(ptrdiff_t)dy * dstep + dx * cn + c] =
+                    (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+            }
+        }
+    }
+    free(xofs); free(yofs); free(xa); free(yb);
+    return 0;
+}
+
+VKO_API int vko_resize_nearest_u8(const uint8_t *src, int sh, int sw, int cn, ptrdiff_t sstep, uint8_t *dst,
+                                  int dh, int dw, ptrdiff_t dstep)
+{
+    if (sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || cn <= 0) return -1;
+    double ifx = 1. / ((double)dw / sw), ify = 1. / ((double)dh / sh);
+    for (int y = 0; y < dh; y++) {
+        int sy = (int)floor(y * ify);
+        if (sy > sh - 1) sy = sh - 1;
+        for (int x = 0; x < dw; x++) {
+            int sx = (int)floor(x * ifx);
+            if (sx > sw - 1) sx = sw - 1;
+            for (int c = 0; c < cn; c++) dst[(ptrdiff_t)y * dstep + x * cn + c] = src[(ptrdiff_t)sy * sstep + sx * cn + c];
+        }
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------
  * [cv2] cv.Rodrigues(rvec) (double internals) and cv.projectPoints with zero distortion
  * -- geometric/camera.py:96, :189-195.  calib3d/calibration.cpp cvRodrigues2 /

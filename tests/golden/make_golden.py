@@ -346,6 +346,7 @@ def gen_policy_configs():
         'complement': (P_color.ComplementConfigGenerator, P_color.ComplementConfigGeneratorConfig),
         'glass_blur': (P_blur.GlassBlurConfigGenerator, P_blur.GlassBlurConfigGeneratorConfig),
         'fog': (P_effect.FogConfigGenerator, P_effect.FogConfigGeneratorConfig),
+        'pixelation': (P_effect.PixelationConfigGenerator, P_effect.PixelationConfigGeneratorConfig),
         'boundary_equalization': (P_color.BoundaryEqualizationConfigGenerator,
                                   P_color.BoundaryEqualizationConfigGeneratorConfig),
         'histogram_equalization': (P_color.HistogramEqualizationConfigGenerator,

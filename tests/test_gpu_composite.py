@@ -429,3 +429,30 @@ def test_page_distortion_step(N):
         assert out.page_char_heights == [float(v) for v in char_h]
         assert out.page_seal_impression_char_mask.mat.sum() > 0
     assert len(shapes) > 1  # geometric distortions did change the page shape, so the resize branch ran
+
+
+@pytest.mark.parametrize('src_shape,dst_shape', [((20, 30), (33, 47)), ((64, 64), (32, 32)), ((97, 131), (40, 55)),
+                                                 ((5, 7), (50, 3)), ((1, 1), (9, 9)), ((300, 200), (113, 77)),
+                                                 ((40, 60), (40, 60))])
+def test_resize_linear_and_nearest(N, src_shape, dst_shape):
+    rng = default_rng(13)
+    for cn in (1, 3, 4):
+        shape = src_shape if cn == 1 else src_shape + (cn,)
+        src = rng.integers(0, 256, shape, dtype=np.uint8)
+        np.testing.assert_array_equal(N.resize(src, dst_shape, N.INTER_LINEAR), O.resize_linear(src, dst_shape))
+        np.testing.assert_array_equal(N.resize(src, dst_shape, N.INTER_NEAREST), O.resize_nearest(src, dst_shape))
+        np.testing.assert_array_equal(N.resize(src, dst_shape, N.INTER_CUBIC), O.resize_cubic(src, dst_shape))
+
+
+def test_pixelation_operator(N):
+    from vkit_amd.element import Image
+    from vkit_amd.mechanism import distortion as D
+    rng = default_rng(14)
+    image = Image(mat=rng.integers(0, 256, (257, 311, 3), dtype=np.uint8))
+    for ratio in (0.31, 0.5, 0.77, 0.999):
+        np.testing.assert_array_equal(D.pixelation.distort({'ratio': ratio}, image=image).image.mat,
+                                      O.pixelation(image.mat, ratio))
+    big = Image(mat=rng.integers(0, 256, (2048, 2048, 3), dtype=np.uint8))
+    np.testing.assert_array_equal(D.pixelation.distort({'ratio': 0.5}, image=big).image.mat, O.pixelation(big.mat, 0.5))
+    np.testing.assert_array_equal(image.to_resized_image(resized_height=100, cv_resize_interpolation=1).mat,
+                                  O.resize_linear(image.mat, (100, round(100 * 311 / 257))))

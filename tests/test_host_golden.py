@@ -54,6 +54,7 @@ GENERATORS = {
     'speckle_noise': (P_noise.SpeckleNoiseConfigGenerator, P_noise.SpeckleNoiseConfigGeneratorConfig),
     'complement': (P_color.ComplementConfigGenerator, P_color.ComplementConfigGeneratorConfig),
     'fog': (P_effect.FogConfigGenerator, P_effect.FogConfigGeneratorConfig),
+    'pixelation': (P_effect.PixelationConfigGenerator, P_effect.PixelationConfigGeneratorConfig),
     'glass_blur': (P_blur.GlassBlurConfigGenerator, P_blur.GlassBlurConfigGeneratorConfig),
     'boundary_equalization': (P_color.BoundaryEqualizationConfigGenerator,
                               P_color.BoundaryEqualizationConfigGeneratorConfig),
@@ -84,7 +85,7 @@ def test_policy_configs_match_reference_draw_for_draw(golden_dir):
         # the generator consumed exactly the reference's number of draws
         assert float(rng.random()) == rec['next_random']
         checked += 1
-    assert checked > 440
+    assert checked > 455
 
 
 def test_affine_states(golden_dir):

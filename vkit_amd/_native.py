@@ -161,6 +161,7 @@ for _sfx in ('', '_dev'):
                                                                          c_int, c_int]
     _SIGNATURES['vkx_fill_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [ctypes.POINTER(VkxLayer), c_int]
     _SIGNATURES['vkx_fill_f32' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, ctypes.POINTER(VkxLayerF32), c_int]
+    _SIGNATURES['vkx_resize_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_int, c_int, c_ssize, c_int]
     _SIGNATURES['vkx_resize_cubic_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_int, c_int, c_ssize]
     _SIGNATURES['vkx_resize_cubic_f32' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_void_p, c_int, c_int, c_ssize]
     _SIGNATURES['vkx_paint_polys' + _sfx] = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_ssize, c_void_p,
@@ -656,6 +657,19 @@ def fill_poly_mask(shape, pts, ctx=None):
     mask = np.empty((h, w), np.uint8)
     check(lib().vkx_fill_poly_mask_u8(ctx.handle, _ptr(pts), int(pts.shape[0]), _ptr(mask), h, w, w))
     return mask
+
+
+INTER_NEAREST, INTER_LINEAR, INTER_CUBIC = 0, 1, 2
+
+
+def resize(src, dsize_hw, interpolation, ctx=None):
+    """cv.resize(src, (dw, dh), interpolation=...) on uint8 arrays for NEAREST / LINEAR / CUBIC."""
+    ctx = ctx or default_ctx()
+    dh, dw = int(dsize_hw[0]), int(dsize_hw[1])
+    src, sh, sw, cn, stride = _u8_plane(src)
+    dst = np.empty((dh, dw) + src.shape[2:], np.uint8)
+    check(lib().vkx_resize_u8(ctx.handle, _ptr(src), sh, sw, cn, stride, _ptr(dst), dh, dw, dw * cn, int(interpolation)))
+    return dst
 
 
 def resize_cubic(src, dsize_hw, ctx=None):

@@ -488,3 +488,17 @@ VKX_EXPORT int vkx_gather_u8(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, i
     return st.finish();
 }
 
+VKX_EXPORT int vkx_resize_u8(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t src_stride, uint8_t *dst,
+                             int dh, int dw, ptrdiff_t dst_stride, int interpolation)
+{
+    VKX_REQUIRE(ctx && src && dst, "NULL argument");
+    VKX_REQUIRE(sh > 0 && sw > 0 && dh > 0 && dw > 0 && cn > 0, "bad shape");
+    HostStage st(ctx);
+    const int s = st.add(src, nullptr, (size_t)sw * cn, sh, src_stride);
+    const int d = st.add(nullptr, dst, (size_t)dw * cn, dh, dst_stride);
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_resize_u8_dev(ctx, st.dev<uint8_t>(s), sh, sw, cn, (ptrdiff_t)sw * cn, st.dev<uint8_t>(d), dh, dw,
+                              (ptrdiff_t)dw * cn, interpolation));
+    return st.finish();
+}
+

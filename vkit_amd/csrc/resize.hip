@@ -111,6 +111,81 @@ __global__ void __launch_bounds__(256) k_resize_cubic_f32(const float *__restric
     dst[(ptrdiff_t)dy * dstride + dx] = v;
 }
 
+// INTER_LINEAR (uint8): 2 x 2 taps, horizontal pass in int32 with 11-bit coefficients, OpenCV's vertical rounding
+// uchar((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2); tables as for the cubic kernel (2 entries).
+template <int CN>
+__global__ void __launch_bounds__(256) k_resize_linear_u8(const uint8_t *__restrict__ src, int sh, int sw, ptrdiff_t sstride,
+                                                          uint8_t *__restrict__ dst, int dh, int dw, ptrdiff_t dstride,
+                                                          const int *__restrict__ xofs, const short *__restrict__ xa,
+                                                          const int *__restrict__ yofs, const short *__restrict__ yb)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dw || dy >= dh) return;
+    const int sx0 = xofs[dx] * CN, sx1 = clip_index(xofs[dx] + 1, sw) * CN;
+    const int a0 = xa[dx * 2], a1 = xa[dx * 2 + 1];
+    const int b0 = yb[dy * 2], b1 = yb[dy * 2 + 1];
+    const uint8_t *r0 = src + (ptrdiff_t)clip_index(yofs[dy], sh) * sstride;
+    const uint8_t *r1 = src + (ptrdiff_t)clip_index(yofs[dy] + 1, sh) * sstride;
+    uint8_t *out = dst + (ptrdiff_t)dy * dstride + (ptrdiff_t)dx * CN;
+#pragma unroll
+    for (int c = 0; c < CN; c++) {
+        const int h0 = r0[sx0 + c] * a0 + r0[sx1 + c] * a1;
+        const int h1 = r1[sx0 + c] * a0 + r1[sx1 + c] * a1;
+        out[c] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
+// the exact 2 x 2 shrink cv.resize routes to INTER_AREA
+template <int CN>
+__global__ void __launch_bounds__(256) k_resize_half_u8(const uint8_t *__restrict__ src, ptrdiff_t sstride,
+                                                        uint8_t *__restrict__ dst, int dh, int dw, ptrdiff_t dstride)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dw || dy >= dh) return;
+    const uint8_t *p = src + (ptrdiff_t)(2 * dy) * sstride + (ptrdiff_t)(2 * dx) * CN;
+#pragma unroll
+    for (int c = 0; c < CN; c++)
+        dst[(ptrdiff_t)dy * dstride + (ptrdiff_t)dx * CN + c] = (uint8_t)((p[c] + p[CN + c] + p[sstride + c] + p[sstride + CN + c] + 2) >> 2);
+}
+
+// INTER_NEAREST: source index min(floor(d * scale), size - 1), scale in double
+template <int CN>
+__global__ void __launch_bounds__(256) k_resize_nearest_u8(const uint8_t *__restrict__ src, int sh, int sw, ptrdiff_t sstride,
+                                                           uint8_t *__restrict__ dst, int dh, int dw, ptrdiff_t dstride,
+                                                           double ifx, double ify)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dw || dy >= dh) return;
+    const int sx = min((int)floor(dx * ifx), sw - 1), sy = min((int)floor(dy * ify), sh - 1);
+    const uint8_t *p = src + (ptrdiff_t)sy * sstride + (ptrdiff_t)sx * CN;
+#pragma unroll
+    for (int c = 0; c < CN; c++) dst[(ptrdiff_t)dy * dstride + (ptrdiff_t)dx * CN + c] = p[c];
+}
+
+void build_linear_axis(int ssize, int dsize, bool horizontal, std::vector<int> *ofs, std::vector<short> *coef)
+{
+    ofs->resize(dsize); coef->resize((size_t)dsize * 2);
+    const double inv_scale = (double)dsize / ssize, scale = 1. / inv_scale;
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s0 = (int)std::floor(f);
+        f -= s0;
+        if (horizontal) {
+            if (s0 < 0) { f = 0; s0 = 0; }
+            if (s0 >= ssize - 1) { f = 0; s0 = ssize - 1; }
+        }
+        (*ofs)[d] = s0;
+        const float c[2] = {1.f - f, f};
+        for (int k = 0; k < 2; k++) {
+            const int r = (int)std::nearbyint((double)(c[k] * 2048.f));
+            (*coef)[(size_t)d * 2 + k] = (short)(r < -32768 ? -32768 : (r > 32767 ? 32767 : r));
+        }
+    }
+}
+
 // Stages the four tables in ctx->misc; returns device pointers.
 int stage_tables(vkx_ctx *ctx, int sh, int sw, int dh, int dw, bool fixed, const int **xofs, const void **xcoef,
                  const int **yofs, const void **ycoef)
@@ -178,3 +253,63 @@ VKX_EXPORT int vkx_resize_cubic_f32_dev(vkx_ctx *ctx, const float *src, int sh, 
     VKX_LAUNCH_CHECK();
     return VKX_OK;
 }
+
+VKX_EXPORT int vkx_resize_u8_dev(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t src_stride, uint8_t *dst,
+                                 int dh, int dw, ptrdiff_t dst_stride, int interpolation)
+{
+    if (interpolation == VKX_INTER_CUBIC) return vkx_resize_cubic_u8_dev(ctx, src, sh, sw, cn, src_stride, dst, dh, dw, dst_stride);
+    VKX_REQUIRE(ctx && src && dst, "NULL argument");
+    VKX_REQUIRE(sh > 0 && sw > 0 && dh > 0 && dw > 0, "bad shape");
+    VKX_REQUIRE(cn == 1 || cn == 3 || cn == 4, "1, 3 or 4 channels");
+    dim3 grid(vkx_blocks(dw, 64), vkx_blocks(dh, 4));
+    if (interpolation == VKX_INTER_NEAREST) {
+        const double ifx = 1. / ((double)dw / sw), ify = 1. / ((double)dh / sh);
+        VKX_TIMED(ctx, "k_resize_nearest");
+        switch (cn) {
+        case 1: k_resize_nearest_u8<1><<<grid, 256, 0, ctx->stream>>>(src, sh, sw, src_stride, dst, dh, dw, dst_stride, ifx, ify); break;
+        case 3: k_resize_nearest_u8<3><<<grid, 256, 0, ctx->stream>>>(src, sh, sw, src_stride, dst, dh, dw, dst_stride, ifx, ify); break;
+        default: k_resize_nearest_u8<4><<<grid, 256, 0, ctx->stream>>>(src, sh, sw, src_stride, dst, dh, dw, dst_stride, ifx, ify); break;
+        }
+        VKX_LAUNCH_CHECK();
+        return VKX_OK;
+    }
+    if (interpolation != VKX_INTER_LINEAR) {
+        vkx_set_error("interpolation %d is not implemented (NEAREST, LINEAR, CUBIC are)", interpolation);
+        return VKX_ERR_UNSUPPORTED;
+    }
+    if (sw == 2 * dw && sh == 2 * dh) {
+        VKX_TIMED(ctx, "k_resize_half");
+        switch (cn) {
+        case 1: k_resize_half_u8<1><<<grid, 256, 0, ctx->stream>>>(src, src_stride, dst, dh, dw, dst_stride); break;
+        case 3: k_resize_half_u8<3><<<grid, 256, 0, ctx->stream>>>(src, src_stride, dst, dh, dw, dst_stride); break;
+        default: k_resize_half_u8<4><<<grid, 256, 0, ctx->stream>>>(src, src_stride, dst, dh, dw, dst_stride); break;
+        }
+        VKX_LAUNCH_CHECK();
+        return VKX_OK;
+    }
+    std::vector<int> xo, yo;
+    std::vector<short> xa, yb;
+    build_linear_axis(sw, dw, true, &xo, &xa);
+    build_linear_axis(sh, dh, false, &yo, &yb);
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o0 = 0, o1 = o0 + up(sizeof(int) * dw), o2 = o1 + up(sizeof(short) * 2 * dw), o3 = o2 + up(sizeof(int) * dh);
+    int rc = vkx_scratch_reserve(ctx, &ctx->misc, o3 + up(sizeof(short) * 2 * dh));
+    if (rc) return rc;
+    unsigned char *base = (unsigned char *)ctx->misc.ptr;
+    VKX_HIP(hipMemcpyAsync(base + o0, xo.data(), sizeof(int) * dw, hipMemcpyHostToDevice, ctx->stream));
+    VKX_HIP(hipMemcpyAsync(base + o1, xa.data(), sizeof(short) * 2 * dw, hipMemcpyHostToDevice, ctx->stream));
+    VKX_HIP(hipMemcpyAsync(base + o2, yo.data(), sizeof(int) * dh, hipMemcpyHostToDevice, ctx->stream));
+    VKX_HIP(hipMemcpyAsync(base + o3, yb.data(), sizeof(short) * 2 * dh, hipMemcpyHostToDevice, ctx->stream));
+    VKX_HIP(hipStreamSynchronize(ctx->stream));
+    const int *dxo = (const int *)(base + o0), *dyo = (const int *)(base + o2);
+    const short *dxa = (const short *)(base + o1), *dyb = (const short *)(base + o3);
+    VKX_TIMED(ctx, "k_resize_linear");
+    switch (cn) {
+    case 1: k_resize_linear_u8<1><<<grid, 256, 0, ctx->stream>>>(src, sh, sw, src_stride, dst, dh, dw, dst_stride, dxo, dxa, dyo, dyb); break;
+    case 3: k_resize_linear_u8<3><<<grid, 256, 0, ctx->stream>>>(src, sh, sw, src_stride, dst, dh, dw, dst_stride, dxo, dxa, dyo, dyb); break;
+    default: k_resize_linear_u8<4><<<grid, 256, 0, ctx->stream>>>(src, sh, sw, src_stride, dst, dh, dw, dst_stride, dxo, dxa, dyo, dyb); break;
+    }
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+

@@ -180,16 +180,16 @@ class Image(Shapable):
 
     def to_resized_image(self, resized_height: Optional[int] = None, resized_width: Optional[int] = None,
                          cv_resize_interpolation: int = 2):
-        """cv.resize(mat, (w, h), INTER_CUBIC) on the GPU (reference image.py:836-852).  Only the default
-        interpolation (cv.INTER_CUBIC == 2) is on the accelerated path."""
+        """cv.resize(mat, (w, h), interpolation) on the GPU (reference image.py:836-852) for cv.INTER_NEAREST (0),
+        cv.INTER_LINEAR (1) and the default cv.INTER_CUBIC (2)."""
         from vkit_amd import _native
-        if cv_resize_interpolation != 2:
-            raise NotImplementedError('only cv.INTER_CUBIC resizing is on the accelerated path')
+        if cv_resize_interpolation not in (0, 1, 2):
+            raise NotImplementedError('cv.INTER_NEAREST / LINEAR / CUBIC resizing are on the accelerated path')
         if self.mat.dtype != np.uint8:
             raise NotImplementedError('float32 image modes are outside the accelerated path')
         _, _, resized_height, resized_width = generate_shape_and_resized_shape(
             shapable_or_shape=self, resized_height=resized_height, resized_width=resized_width)
-        return attrs.evolve(self, mat=_native.resize_cubic(self.mat, (resized_height, resized_width)))
+        return attrs.evolve(self, mat=_native.resize(self.mat, (resized_height, resized_width), cv_resize_interpolation))
 
     def to_conducted_resized_image(self, shapable_or_shape, resized_height: Optional[int] = None,
                                    resized_width: Optional[int] = None, cv_resize_interpolation: int = 2):

@@ -40,7 +40,7 @@ from .photometric.noise import (
     SpeckleNoiseConfig,
     speckle_noise,
 )
-from .photometric.effect import FogConfig, fog
+from .photometric.effect import FogConfig, fog, PixelationConfig, pixelation
 from .photometric.streak import LineStreakConfig, line_streak, RectangleStreakConfig, rectangle_streak
 
 # geometric

@@ -1,8 +1,9 @@
 """``fog`` (reference: photometric/effect.py:89-216).  The fog density field is a diamond-square fractal drawn from the
 caller-visible numpy Generator stream on the host (like every random plane of the path); the per-pixel work -- blend
 every pixel towards the fog colour with the field as float32 alpha, ``uint8(clip((1 - a) * px + a * fog))`` -- is the
-alpha composite ``vkx_fill_u8`` with one page-sized layer.  ``jpeg_quality`` and ``pixelation`` of the same reference
-module are outside the path (an encoder round trip; INTER_LINEAR / INTER_NEAREST resizing)."""
+alpha composite ``vkx_fill_u8`` with one page-sized layer.  ``pixelation`` (:56-86) shrinks with ``cv.resize``
+INTER_LINEAR and grows back with INTER_NEAREST (``vkx_resize_u8``).  ``jpeg_quality`` (an encoder round trip) is
+outside the path."""
 from typing import Any, Mapping, Optional, Tuple
 
 import attrs
@@ -12,6 +13,25 @@ from numpy.random import Generator as RandomGenerator
 from vkit_amd import _native
 from vkit_amd.element import Image, ImageMode
 from ..interface import Distortion, DistortionConfig, DistortionNopState
+
+
+@attrs.define
+class PixelationConfig(DistortionConfig):
+    ratio: float
+
+
+def pixelation_image(config: PixelationConfig, state, image: Image, rng: Optional[RandomGenerator]):
+    assert 0 < config.ratio < 1
+    small_shape = (round(image.height * config.ratio), round(image.width * config.ratio))
+    small = _native.resize(image.mat, small_shape, _native.INTER_LINEAR)
+    return attrs.evolve(image, mat=_native.resize(small, image.shape, _native.INTER_NEAREST))
+
+
+pixelation = Distortion(
+    config_cls=PixelationConfig,
+    state_cls=DistortionNopState[PixelationConfig],
+    func_image=pixelation_image,
+)
 
 
 def generate_diamond_square_mask(shape: Tuple[int, int], roughness: float, rng: RandomGenerator):

@@ -1,4 +1,4 @@
-"""Config generator of ``fog`` (reference: distortion_policy/photometric/effect.py:88-130)."""
+"""Config generators of ``pixelation`` and ``fog`` (reference: distortion_policy/photometric/effect.py:56-130)."""
 from typing import Tuple
 
 import attrs
@@ -26,3 +26,20 @@ class FogConfigGenerator(DistortionConfigGenerator[FogConfigGeneratorConfig, dis
 
 
 fog_policy_factory = DistortionPolicyFactory(distortion.fog, FogConfigGenerator)
+
+
+@attrs.define
+class PixelationConfigGeneratorConfig:
+    ratio_min: float = 0.3
+    ratio_max: float = 1.0
+
+
+class PixelationConfigGenerator(DistortionConfigGenerator[PixelationConfigGeneratorConfig, distortion.PixelationConfig]):
+
+    def __call__(self, shape: Tuple[int, int], rng: RandomGenerator):
+        return distortion.PixelationConfig(
+            ratio=sample_float(self.level, self.config.ratio_min, self.config.ratio_max, None, rng, inverse_level=True))
+
+
+pixelation_policy_factory = DistortionPolicyFactory(distortion.pixelation, PixelationConfigGenerator)
+
