@@ -221,6 +221,11 @@ int vkx_gather_u8(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrd
                   const int32_t *pos_y, const int32_t *pos_x, ptrdiff_t pos_stride_el, uint8_t *dst, int dh, int dw,
                   ptrdiff_t dst_stride);
 
+/* poisson_noise  photometric/noise.py:81-91: np.clip(samples, 0, 255).astype(uint8) of the int64 rng.poisson draws
+ * (the draws themselves are the caller's numpy Generator stream; n values, flat). */
+int vkx_saturate_i64_u8_dev(vkx_ctx *ctx, const int64_t *src, size_t n, uint8_t *dst);
+int vkx_saturate_i64_u8(vkx_ctx *ctx, const int64_t *src, size_t n, uint8_t *dst);
+
 /* impulse_noise  photometric/noise.py:125-150: selector uint8 [h, w] (0 keep, 1 salt = 255, 2 pepper = 0 on every
  * channel of the pixel), drawn by the caller's numpy Generator (rng.choice). */
 int vkx_impulse_noise_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,

@@ -259,6 +259,8 @@ def gen_pointwise_ops():
                                                          image=Image(mat=coords), rng=default_rng(seed)).image.mat[:, :, :2]
     out['glass_cases'] = np.asarray([(1, 1, 0), (1, 4, 1), (2, 5, 2), (3, 2, 3)])
     cv_stub.GaussianBlur = saved_blur
+    for seed in (0, 1):
+        out[f'poisson_{seed}'] = D.poisson_noise.distort(D.PoissonNoiseConfig(), image=img, rng=default_rng(seed)).image.mat
     gray = Image(mat=src[:, :, 0].copy())
     out['gray_complement_thr'] = D.complement.distort(D.ComplementConfig(threshold=128), image=gray).image.mat
     out['gray_impulse'] = D.impulse_noise.distort(D.ImpulseNoiseConfig(prob_salt=0.1, prob_pepper=0.1), image=gray,

@@ -223,3 +223,15 @@ def test_glass_blur_and_gather(P):
     big = rng.integers(0, 256, (2048, 2048, 3), dtype=np.uint8)
     pos_y, pos_x = glass_shuffle_planes((2048, 2048), 1, 2, default_rng(5))
     np.testing.assert_array_equal(N.gather(big, pos_y, pos_x), big[pos_y, pos_x])
+
+
+def test_poisson_noise_reproduces_reference_outputs(P):
+    from vkit_amd import _native as N
+    from vkit_amd.element import Image
+    from vkit_amd.mechanism import distortion as D
+    img = Image(mat=P['src'])
+    for seed in (0, 1):
+        out = D.poisson_noise.distort({}, image=img, rng=default_rng(seed)).image
+        np.testing.assert_array_equal(out.mat, P[f'poisson_{seed}'])
+    samples = default_rng(3).integers(-500, 900, (123, 77, 3))
+    np.testing.assert_array_equal(N.saturate_i64(samples), np.clip(samples, 0, 255).astype(np.uint8))

@@ -131,6 +131,7 @@ _SIGNATURES = {
     'vkx_ctx_reset_timings': [c_void_p],
 }
 for _sfx in ('', '_dev'):
+    _SIGNATURES['vkx_saturate_i64_u8' + _sfx] = [c_void_p, c_void_p, c_size, c_void_p]
     _SIGNATURES['vkx_remap_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_void_p, c_ssize, c_void_p, c_int, c_int, c_ssize]
     _SIGNATURES['vkx_remap_f32' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_void_p, c_void_p, c_ssize,
                                            c_void_p, c_int, c_int, c_ssize]
@@ -601,6 +602,15 @@ def gather(img, pos_y, pos_x, ctx=None):
     dst = np.empty((dh, dw) + img.shape[2:], np.uint8)
     check(lib().vkx_gather_u8(ctx.handle, _ptr(img), h, w, cn, stride, _ptr(pos_y), _ptr(pos_x), dw, _ptr(dst), dh, dw,
                               dw * cn))
+    return dst
+
+
+def saturate_i64(samples, ctx=None):
+    """np.clip(samples, 0, 255).astype(np.uint8) for an int64 array."""
+    ctx = ctx or default_ctx()
+    samples = np.ascontiguousarray(samples, dtype=np.int64)
+    dst = np.empty(samples.shape, np.uint8)
+    check(lib().vkx_saturate_i64_u8(ctx.handle, _ptr(samples), samples.size, _ptr(dst)))
     return dst
 
 

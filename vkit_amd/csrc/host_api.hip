@@ -502,3 +502,15 @@ VKX_EXPORT int vkx_resize_u8(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, i
     return st.finish();
 }
 
+VKX_EXPORT int vkx_saturate_i64_u8(vkx_ctx *ctx, const int64_t *src, size_t n, uint8_t *dst)
+{
+    VKX_REQUIRE(ctx && (n == 0 || (src && dst)), "NULL argument");
+    if (n == 0) return VKX_OK;
+    HostStage st(ctx);
+    const int s = st.add(src, nullptr, n * 8, 1, (ptrdiff_t)(n * 8));
+    const int d = st.add(nullptr, dst, n, 1, (ptrdiff_t)n);
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_saturate_i64_u8_dev(ctx, st.dev<int64_t>(s), n, st.dev<uint8_t>(d)));
+    return st.finish();
+}
+

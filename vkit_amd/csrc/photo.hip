@@ -414,6 +414,16 @@ __global__ void __launch_bounds__(256) k_gather(const uint8_t *__restrict__ src,
     for (int c = 0; c < CN; c++) d[c] = p[c];
 }
 
+// np.clip(int64 samples, 0, 255).astype(uint8): the tail of poisson_noise (photometric/noise.py:81-91); the samples
+// themselves are rng.poisson draws of the caller's numpy Generator.
+__global__ void __launch_bounds__(256) k_saturate_i64(const long long *__restrict__ src, size_t n, uint8_t *__restrict__ dst)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long v = src[i];
+    dst[i] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
 // fill_np_array blend of one value: trunc(fl32(fl32(1 - a) * dst) + fl32(a * val)), products rounded separately.
 __device__ __forceinline__ uint8_t blend_u8(uint8_t d, uint8_t v, float w1)
 {
@@ -719,6 +729,15 @@ VKX_EXPORT int vkx_gather_u8_dev(vkx_ctx *ctx, const uint8_t *src, int sh, int s
         vkx_set_error("gather index outside the %dx%d source", sh, sw);
         return VKX_ERR_INVALID;
     }
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_saturate_i64_u8_dev(vkx_ctx *ctx, const int64_t *src, size_t n, uint8_t *dst)
+{
+    VKX_REQUIRE(ctx && (n == 0 || (src && dst)), "NULL argument");
+    if (n == 0) return VKX_OK;
+    { VKX_TIMED(ctx, "k_saturate_i64"); k_saturate_i64<<<vkx_blocks(n, 256), 256, 0, ctx->stream>>>((const long long *)src, n, dst); }
+    VKX_LAUNCH_CHECK();
     return VKX_OK;
 }
 

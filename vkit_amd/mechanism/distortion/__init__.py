@@ -39,6 +39,8 @@ from .photometric.noise import (
     impulse_noise,
     SpeckleNoiseConfig,
     speckle_noise,
+    PoissonNoiseConfig,
+    poisson_noise,
 )
 from .photometric.effect import FogConfig, fog, PixelationConfig, pixelation
 from .photometric.streak import LineStreakConfig, line_streak, RectangleStreakConfig, rectangle_streak

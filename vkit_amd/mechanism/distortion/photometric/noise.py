@@ -1,6 +1,6 @@
 """``gaussion_noise`` (sic, reference: photometric/noise.py:25-61), ``impulse_noise`` (:100-157) and
-``speckle_noise`` (:160-190).  ``poisson_noise`` is one ``rng.poisson`` call plus a clip -- all of it random-number
-generation on the caller's stream -- and stays outside the path.
+``speckle_noise`` (:160-190) and ``poisson_noise`` (:64-98), which is one ``rng.poisson`` call on the caller's stream
+plus a saturating narrow on the GPU.
 
 The samples come from the caller-visible numpy Generator stream -- ``np.round(rng.normal(0, std, shape))`` in C
 order, one draw per channel value -- so that a stored ``config.rng_state`` reproduces the same pixels; the add
@@ -122,3 +122,35 @@ speckle_noise = Distortion(
     state_cls=DistortionNopState[SpeckleNoiseConfig],
     func_image=speckle_noise_image,
 )
+
+
+@attrs.define
+class PoissonNoiseConfig(DistortionConfig):
+    _rng_state: Optional[Mapping[str, Any]] = None
+
+    @property
+    def supports_rng_state(self) -> bool:
+        return True
+
+    @property
+    def rng_state(self) -> Optional[Mapping[str, Any]]:
+        return self._rng_state
+
+    @rng_state.setter
+    def rng_state(self, val: Mapping[str, Any]):
+        self._rng_state = val
+
+
+def poisson_noise_image(config: PoissonNoiseConfig, state, image: Image, rng: Optional[RandomGenerator]):
+    """Every value is replaced by a Poisson draw with that value as its mean (float32 rates, C order)."""
+    assert rng
+    samples = rng.poisson(image.mat.astype(np.float32))
+    return Image(mat=_native.saturate_i64(samples))
+
+
+poisson_noise = Distortion(
+    config_cls=PoissonNoiseConfig,
+    state_cls=DistortionNopState[PoissonNoiseConfig],
+    func_image=poisson_noise_image,
+)
+

@@ -64,3 +64,19 @@ class SpeckleNoiseConfigGenerator(
 
 
 speckle_noise_policy_factory = DistortionPolicyFactory(distortion.speckle_noise, SpeckleNoiseConfigGenerator)
+
+
+@attrs.define
+class PoissonNoiseConfigGeneratorConfig:
+    pass
+
+
+class PoissonNoiseConfigGenerator(
+        DistortionConfigGenerator[PoissonNoiseConfigGeneratorConfig, distortion.PoissonNoiseConfig]):
+
+    def __call__(self, shape: Tuple[int, int], rng: RandomGenerator):
+        return distortion.PoissonNoiseConfig()
+
+
+poisson_noise_policy_factory = DistortionPolicyFactory(distortion.poisson_noise, PoissonNoiseConfigGenerator)
+

@@ -50,7 +50,7 @@ class _UnsupportedPolicyFactory:
 
 UNSUPPORTED_POLICY_NAMES = (
     'std_shift',
-    'defocus_blur', 'motion_blur', 'zoom_in_blur', 'poisson_noise', 'jpeg_quality',
+    'defocus_blur', 'motion_blur', 'zoom_in_blur', 'jpeg_quality',
     'ellipse_streak',
 )
 _U = _UnsupportedPolicyFactory
@@ -273,7 +273,7 @@ _PHOTOMETRIC_POLICY_FACTORIES_AND_DEFAULT_WEIGHTS_SUM_PAIRS = (
       color.posterization_policy_factory, color.color_balance_policy_factory, color.channel_permutation_policy_factory), 10.0),
     ((blur.gaussian_blur_policy_factory, _U('defocus_blur'), _U('motion_blur'), blur.glass_blur_policy_factory,
       _U('zoom_in_blur')), 1.0),
-    ((noise.gaussion_noise_policy_factory, _U('poisson_noise'), noise.impulse_noise_policy_factory,
+    ((noise.gaussion_noise_policy_factory, noise.poisson_noise_policy_factory, noise.impulse_noise_policy_factory,
       noise.speckle_noise_policy_factory), 3.0),
     ((_U('jpeg_quality'), effect.pixelation_policy_factory, effect.fog_policy_factory), 1.0),
     ((streak.line_streak_policy_factory, streak.rectangle_streak_policy_factory, _U('ellipse_streak')), 1.0),
