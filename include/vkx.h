@@ -312,6 +312,14 @@ int vkx_resize_u8_dev(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, 
 int vkx_resize_u8(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t src_stride,
                   uint8_t *dst, int dh, int dw, ptrdiff_t dst_stride, int interpolation);
 
+/* zoom_in_blur  photometric/blur.py:264-316: the image plus the centred crops of its INTER_CUBIC enlargements to the
+ * sizes of sizes_hw_host (HOST int32 [n, 2] as (height, width), every size >= the image) are summed in uint16, then
+ * dst = uint8(clip((1 - alpha) * px + alpha * rint(sum / (n + 1)))) in float64. */
+int vkx_zoom_in_blur_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                            const int32_t *sizes_hw_host, int n_sizes, double alpha, uint8_t *dst, ptrdiff_t dst_stride);
+int vkx_zoom_in_blur_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                        const int32_t *sizes_hw_host, int n_sizes, double alpha, uint8_t *dst, ptrdiff_t dst_stride);
+
 /* ---- polygon rasterisation -----------------------------------------------------------
  * cv.fillPoly(zeros((h, w), uint8), [pts], 1): PolygonInternals.np_mask element/polygon.py:70-77
  * (Bresenham LINE_8 outline + even-odd scanline spans).  pts: HOST int32 [npts, 2] as (x, y), all

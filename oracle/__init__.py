@@ -396,6 +396,22 @@ def pixelation(img, ratio):
     return resize_nearest(small, (h, w))
 
 
+def zoom_in_blur(img, ratio, step, alpha):
+    """zoom_in_blur_image -- photometric/blur.py:264-316, numpy statements of the reference around resize_cubic."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape[:2]
+    acc = img.astype(np.uint16)
+    count = 1
+    for factor in np.arange(1 + step, 1 + ratio + step, step):
+        rh, rw = round(h * factor), round(w * factor)
+        big = resize_cubic(img, (rh, rw))
+        up, left = (rh - h) // 2, (rw - w) // 2
+        acc += big[up:up + h, left:left + w]
+        count += 1
+    out = (1 - alpha) * img + alpha * np.round(acc / count)
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
 def _select(img, channels):
     return img[:, :, list(channels)] if channels else img
 

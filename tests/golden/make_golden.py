@@ -261,6 +261,15 @@ def gen_pointwise_ops():
     cv_stub.GaussianBlur = saved_blur
     for seed in (0, 1):
         out[f'poisson_{seed}'] = D.poisson_noise.distort(D.PoissonNoiseConfig(), image=img, rng=default_rng(seed)).image.mat
+    # zoom_in_blur: cv.resize is substituted by the oracle's bicubic restatement (oracle_patched: a structure check of
+    # the numpy part -- step list, uint16 accumulation, float64 blend and rounding)
+    saved_resize = cv_stub.resize
+    cv_stub.resize = lambda mat, dsize, interpolation=None: O.resize_cubic(mat, (dsize[1], dsize[0]))
+    for i, (ratio, step, alpha) in enumerate([(0.1, 0.01, 0.5), (0.05, 0.02, 0.7), (0.033, 0.004, 0.61)]):
+        out[f'zoom_oracle_patched_{i}'] = D.zoom_in_blur.distort(D.ZoomInBlurConfig(ratio=ratio, step=step, alpha=alpha),
+                                                                 image=img).image.mat
+    out['zoom_cases'] = np.asarray([(0.1, 0.01, 0.5), (0.05, 0.02, 0.7), (0.033, 0.004, 0.61)])
+    cv_stub.resize = saved_resize
     gray = Image(mat=src[:, :, 0].copy())
     out['gray_complement_thr'] = D.complement.distort(D.ComplementConfig(threshold=128), image=gray).image.mat
     out['gray_impulse'] = D.impulse_noise.distort(D.ImpulseNoiseConfig(prob_salt=0.1, prob_pepper=0.1), image=gray,
@@ -347,6 +356,7 @@ def gen_policy_configs():
         'speckle_noise': (P_noise.SpeckleNoiseConfigGenerator, P_noise.SpeckleNoiseConfigGeneratorConfig),
         'complement': (P_color.ComplementConfigGenerator, P_color.ComplementConfigGeneratorConfig),
         'glass_blur': (P_blur.GlassBlurConfigGenerator, P_blur.GlassBlurConfigGeneratorConfig),
+        'zoom_in_blur': (P_blur.ZoomInBlurConfigGenerator, P_blur.ZoomInBlurConfigGeneratorConfig),
         'fog': (P_effect.FogConfigGenerator, P_effect.FogConfigGeneratorConfig),
         'pixelation': (P_effect.PixelationConfigGenerator, P_effect.PixelationConfigGeneratorConfig),
         'boundary_equalization': (P_color.BoundaryEqualizationConfigGenerator,

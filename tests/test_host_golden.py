@@ -56,6 +56,7 @@ GENERATORS = {
     'fog': (P_effect.FogConfigGenerator, P_effect.FogConfigGeneratorConfig),
     'pixelation': (P_effect.PixelationConfigGenerator, P_effect.PixelationConfigGeneratorConfig),
     'glass_blur': (P_blur.GlassBlurConfigGenerator, P_blur.GlassBlurConfigGeneratorConfig),
+    'zoom_in_blur': (P_blur.ZoomInBlurConfigGenerator, P_blur.ZoomInBlurConfigGeneratorConfig),
     'boundary_equalization': (P_color.BoundaryEqualizationConfigGenerator,
                               P_color.BoundaryEqualizationConfigGeneratorConfig),
     'histogram_equalization': (P_color.HistogramEqualizationConfigGenerator,
@@ -85,7 +86,7 @@ def test_policy_configs_match_reference_draw_for_draw(golden_dir):
         # the generator consumed exactly the reference's number of draws
         assert float(rng.random()) == rec['next_random']
         checked += 1
-    assert checked > 455
+    assert checked > 470
 
 
 def test_affine_states(golden_dir):

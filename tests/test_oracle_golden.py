@@ -103,6 +103,14 @@ def test_pointwise_ops_against_reference(golden_dir):
     assert (O.speckle_noise(gray, default_rng(6).normal(0, 0.2, gray.shape)) == P['gray_speckle']).all()
 
 
+def test_zoom_in_blur_structure(golden_dir):
+    """The numpy half of zoom_in_blur (factor list, uint16 sums, float64 blend) against the reference run with cv.resize
+    substituted by this oracle's bicubic restatement: a structure check, not an independent pin of the resize."""
+    P = np.load(os.path.join(golden_dir, 'pointwise_ops.npz'))
+    for i, (ratio, step, alpha) in enumerate(P['zoom_cases']):
+        assert (O.zoom_in_blur(P['src'], float(ratio), float(step), float(alpha)) == P[f'zoom_oracle_patched_{i}']).all()
+
+
 def test_colour_conversion_known_answers():
     """Primaries through the [cv2] colour conversions: hrange 256 for the *_FULL codes (240 deg -> 171, 60 deg -> 43),
     lightness / saturation of pure colours, BT.601 grey weights (76 / 150 / 29)."""

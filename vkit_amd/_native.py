@@ -163,6 +163,7 @@ for _sfx in ('', '_dev'):
     _SIGNATURES['vkx_fill_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [ctypes.POINTER(VkxLayer), c_int]
     _SIGNATURES['vkx_fill_f32' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, ctypes.POINTER(VkxLayerF32), c_int]
     _SIGNATURES['vkx_resize_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_int, c_int, c_ssize, c_int]
+    _SIGNATURES['vkx_zoom_in_blur_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_int, c_double, c_void_p, c_ssize]
     _SIGNATURES['vkx_resize_cubic_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_int, c_int, c_ssize]
     _SIGNATURES['vkx_resize_cubic_f32' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_void_p, c_int, c_int, c_ssize]
     _SIGNATURES['vkx_paint_polys' + _sfx] = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_ssize, c_void_p,
@@ -679,6 +680,17 @@ def resize(src, dsize_hw, interpolation, ctx=None):
     src, sh, sw, cn, stride = _u8_plane(src)
     dst = np.empty((dh, dw) + src.shape[2:], np.uint8)
     check(lib().vkx_resize_u8(ctx.handle, _ptr(src), sh, sw, cn, stride, _ptr(dst), dh, dw, dw * cn, int(interpolation)))
+    return dst
+
+
+def zoom_in_blur(img, sizes_hw, alpha, ctx=None):
+    """include/vkx.h vkx_zoom_in_blur_u8: sizes_hw = [(height, width), ...] of the enlarged copies."""
+    ctx = ctx or default_ctx()
+    img, h, w, cn, stride = _u8_plane(img)
+    sizes = np.ascontiguousarray(np.asarray(sizes_hw, dtype=np.int32).reshape(-1, 2))
+    dst = np.empty_like(img)
+    check(lib().vkx_zoom_in_blur_u8(ctx.handle, _ptr(img), h, w, cn, stride, _ptr(sizes), int(sizes.shape[0]), float(alpha),
+                                    _ptr(dst), stride))
     return dst
 
 

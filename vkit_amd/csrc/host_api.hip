@@ -514,3 +514,17 @@ VKX_EXPORT int vkx_saturate_i64_u8(vkx_ctx *ctx, const int64_t *src, size_t n, u
     return st.finish();
 }
 
+VKX_EXPORT int vkx_zoom_in_blur_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                                   const int32_t *sizes_hw_host, int n_sizes, double alpha, uint8_t *dst, ptrdiff_t dst_stride)
+{
+    VKX_REQUIRE(ctx && src && dst, "NULL argument");
+    VKX_REQUIRE(h > 0 && w > 0 && cn > 0, "bad shape");
+    HostStage st(ctx);
+    const int s = st.add(src, nullptr, (size_t)w * cn, h, src_stride);
+    const int d = st.add(nullptr, dst, (size_t)w * cn, h, dst_stride);
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_zoom_in_blur_u8_dev(ctx, st.dev<uint8_t>(s), h, w, cn, (ptrdiff_t)w * cn, sizes_hw_host, n_sizes, alpha,
+                                    st.dev<uint8_t>(d), (ptrdiff_t)w * cn));
+    return st.finish();
+}
+

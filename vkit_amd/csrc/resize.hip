@@ -9,6 +9,7 @@
 // sums for float32.  Bound by HBM/L2 reads of the source (each source row is reused by ~4/scale destination rows).
 #include "vkx_internal.h"
 
+#include <algorithm>
 #include <cmath>
 
 namespace {
@@ -186,6 +187,34 @@ void build_linear_axis(int ssize, int dsize, bool horizontal, std::vector<int> *
     }
 }
 
+// zoom_in_blur (photometric/blur.py:264-316): uint16 accumulation of centred crops of enlarged copies, then
+// uint8(clip((1 - alpha) * px + alpha * rint(acc / count))) in float64.
+__global__ void __launch_bounds__(256) k_accumulate_crop(const uint8_t *__restrict__ src, ptrdiff_t sstride, int up, int left,
+                                                         uint16_t *__restrict__ acc, int h, int wc, int cn, int init)
+{
+    const int xe = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (xe >= wc || y >= h) return;
+    const uint16_t v = src[(ptrdiff_t)(up + y) * sstride + (ptrdiff_t)left * cn + xe];
+    uint16_t *a = acc + (size_t)y * wc + xe;
+    *a = init ? v : (uint16_t)(*a + v);      // numpy uint16 arithmetic wraps
+}
+
+__global__ void __launch_bounds__(256) k_zoom_finish(const uint8_t *__restrict__ src, ptrdiff_t sstride,
+                                                     const uint16_t *__restrict__ acc, int h, int wc, int count, double w0,
+                                                     double w1, uint8_t *__restrict__ dst, ptrdiff_t dstride)
+{
+    const int xe = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (xe >= wc || y >= h) return;
+    const double t0 = w0 * (double)src[(ptrdiff_t)y * sstride + xe];
+    const double mean = rint((double)acc[(size_t)y * wc + xe] / (double)count);   // np.round: half to even
+    const double t1 = w1 * mean;
+    double v = t0 + t1;
+    v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+    dst[(ptrdiff_t)y * dstride + xe] = (uint8_t)v;
+}
+
 // Stages the four tables in ctx->misc; returns device pointers.
 int stage_tables(vkx_ctx *ctx, int sh, int sw, int dh, int dw, bool fixed, const int **xofs, const void **xcoef,
                  const int **yofs, const void **ycoef)
@@ -309,6 +338,42 @@ VKX_EXPORT int vkx_resize_u8_dev(vkx_ctx *ctx, const uint8_t *src, int sh, int s
     case 3: k_resize_linear_u8<3><<<grid, 256, 0, ctx->stream>>>(src, sh, sw, src_stride, dst, dh, dw, dst_stride, dxo, dxa, dyo, dyb); break;
     default: k_resize_linear_u8<4><<<grid, 256, 0, ctx->stream>>>(src, sh, sw, src_stride, dst, dh, dw, dst_stride, dxo, dxa, dyo, dyb); break;
     }
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_zoom_in_blur_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                                       const int32_t *sizes_hw_host, int n_sizes, double alpha, uint8_t *dst,
+                                       ptrdiff_t dst_stride)
+{
+    VKX_REQUIRE(ctx && src && dst && (n_sizes == 0 || sizes_hw_host), "NULL argument");
+    VKX_REQUIRE(h > 0 && w > 0 && n_sizes >= 0, "bad shape");
+    VKX_REQUIRE(cn == 1 || cn == 3 || cn == 4, "1, 3 or 4 channels");
+    VKX_REQUIRE(n_sizes < 256, "too many zoom steps for a uint16 accumulator");
+    size_t max_plane = 0;
+    for (int i = 0; i < n_sizes; i++) {
+        const int rh = sizes_hw_host[2 * i], rw = sizes_hw_host[2 * i + 1];
+        VKX_REQUIRE(rh >= h && rw >= w, "zoom steps must not shrink the image");
+        max_plane = std::max(max_plane, (size_t)rh * rw * cn);
+    }
+    const int wc = w * cn;
+    int rc = vkx_scratch_reserve(ctx, &ctx->chain[0], max_plane + 256);
+    if (rc) return rc;
+    rc = vkx_scratch_reserve(ctx, &ctx->chain[1], (size_t)h * wc * sizeof(uint16_t));
+    if (rc) return rc;
+    uint8_t *big = (uint8_t *)ctx->chain[0].ptr;
+    uint16_t *acc = (uint16_t *)ctx->chain[1].ptr;
+    dim3 grid(vkx_blocks(wc, 64), vkx_blocks(h, 4));
+    { VKX_TIMED(ctx, "k_accumulate_crop"); k_accumulate_crop<<<grid, 256, 0, ctx->stream>>>(src, src_stride, 0, 0, acc, h, wc, cn, 1); }
+    VKX_LAUNCH_CHECK();
+    for (int i = 0; i < n_sizes; i++) {
+        const int rh = sizes_hw_host[2 * i], rw = sizes_hw_host[2 * i + 1];
+        rc = vkx_resize_cubic_u8_dev(ctx, src, h, w, cn, src_stride, big, rh, rw, (ptrdiff_t)rw * cn);
+        if (rc) return rc;
+        { VKX_TIMED(ctx, "k_accumulate_crop"); k_accumulate_crop<<<grid, 256, 0, ctx->stream>>>(big, (ptrdiff_t)rw * cn, (rh - h) / 2, (rw - w) / 2, acc, h, wc, cn, 0); }
+        VKX_LAUNCH_CHECK();
+    }
+    { VKX_TIMED(ctx, "k_zoom_finish"); k_zoom_finish<<<grid, 256, 0, ctx->stream>>>(src, src_stride, acc, h, wc, n_sizes + 1, 1 - alpha, alpha, dst, dst_stride); }
     VKX_LAUNCH_CHECK();
     return VKX_OK;
 }

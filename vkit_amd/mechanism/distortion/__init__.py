@@ -31,7 +31,14 @@ from .photometric.color import (
     HistogramEqualizationConfig,
     histogram_equalization,
 )
-from .photometric.blur import GaussianBlurConfig, gaussian_blur, GlassBlurConfig, glass_blur
+from .photometric.blur import (
+    GaussianBlurConfig,
+    gaussian_blur,
+    GlassBlurConfig,
+    glass_blur,
+    ZoomInBlurConfig,
+    zoom_in_blur,
+)
 from .photometric.noise import (
     GaussionNoiseConfig,
     gaussion_noise,

@@ -2,7 +2,8 @@
 ``cv.GaussianBlur(mat, (k, k), sigma)`` -- OpenCV's bit-exact 8.8 fixed-point separable kernel restated in HIP --
 and ``glass_blur`` (:186-258): that blur followed by a random local pixel shuffle.  ``defocus_blur`` / ``motion_blur``
 run ``cv.filter2D`` with kernels of 50+ taps, which OpenCV evaluates through a DFT: not reproducible bit for bit, so
-they stay outside the path, as does ``zoom_in_blur``."""
+they stay outside the path.  ``zoom_in_blur`` (:264-323) averages the image with centred crops of its bicubic
+enlargements (``vkx_zoom_in_blur_u8``)."""
 from typing import Any, Mapping, Optional
 
 import attrs
@@ -95,5 +96,29 @@ glass_blur = Distortion(
     config_cls=GlassBlurConfig,
     state_cls=DistortionNopState[GlassBlurConfig],
     func_image=glass_blur_image,
+)
+
+
+@attrs.define
+class ZoomInBlurConfig(DistortionConfig):
+    ratio: float = 0.1
+    step: float = 0.01
+    alpha: float = 0.5
+
+
+def zoom_in_blur_image(config: ZoomInBlurConfig, state, image: Image, rng: Optional[RandomGenerator]):
+    mode = image.mode
+    image = to_rgb_image(image, mode)
+    # the enlargement factors 1 + step, 1 + 2 step, ... up to 1 + ratio (numpy's float arange, like the reference)
+    sizes = [(round(image.height * factor), round(image.width * factor))
+             for factor in np.arange(1 + config.step, 1 + config.ratio + config.step, config.step)]
+    mat = _native.zoom_in_blur(image.mat, sizes, config.alpha)
+    return to_original_image(attrs.evolve(image, mat=mat), mode)
+
+
+zoom_in_blur = Distortion(
+    config_cls=ZoomInBlurConfig,
+    state_cls=DistortionNopState[ZoomInBlurConfig],
+    func_image=zoom_in_blur_image,
 )
 

@@ -1,5 +1,5 @@
-"""Config generators of ``gaussian_blur`` and ``glass_blur`` (reference: distortion_policy/photometric/blur.py:25-53,
-121-170)."""
+"""Config generators of ``gaussian_blur``, ``glass_blur`` and ``zoom_in_blur`` (reference:
+distortion_policy/photometric/blur.py:25-53, 121-219)."""
 from typing import Tuple
 
 import attrs
@@ -48,4 +48,27 @@ class GlassBlurConfigGenerator(DistortionConfigGenerator[GlassBlurConfigGenerato
 
 
 glass_blur_policy_factory = DistortionPolicyFactory(distortion.glass_blur, GlassBlurConfigGenerator)
+
+
+@attrs.define
+class ZoomInBlurConfigGeneratorConfig:
+    ratio_min: float = 0.01
+    ratio_max: float = 0.1
+    step_min: float = 0.002
+    step_max: float = 0.02
+    alpha_min: float = 0.5
+    alpha_max: float = 0.7
+
+
+class ZoomInBlurConfigGenerator(DistortionConfigGenerator[ZoomInBlurConfigGeneratorConfig, distortion.ZoomInBlurConfig]):
+
+    def __call__(self, shape: Tuple[int, int], rng: RandomGenerator):
+        cfg = self.config
+        ratio = sample_float(self.level, cfg.ratio_min, cfg.ratio_max, None, rng)
+        step = sample_float(self.level, cfg.step_min, cfg.step_max, None, rng)
+        alpha = rng.uniform(cfg.alpha_min, cfg.alpha_max)
+        return distortion.ZoomInBlurConfig(ratio=ratio, step=step, alpha=alpha)
+
+
+zoom_in_blur_policy_factory = DistortionPolicyFactory(distortion.zoom_in_blur, ZoomInBlurConfigGenerator)
 

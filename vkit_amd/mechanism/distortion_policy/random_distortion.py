@@ -50,7 +50,7 @@ class _UnsupportedPolicyFactory:
 
 UNSUPPORTED_POLICY_NAMES = (
     'std_shift',
-    'defocus_blur', 'motion_blur', 'zoom_in_blur', 'jpeg_quality',
+    'defocus_blur', 'motion_blur', 'jpeg_quality',
     'ellipse_streak',
 )
 _U = _UnsupportedPolicyFactory
@@ -272,7 +272,7 @@ _PHOTOMETRIC_POLICY_FACTORIES_AND_DEFAULT_WEIGHTS_SUM_PAIRS = (
       color.boundary_equalization_policy_factory, color.histogram_equalization_policy_factory, color.complement_policy_factory,
       color.posterization_policy_factory, color.color_balance_policy_factory, color.channel_permutation_policy_factory), 10.0),
     ((blur.gaussian_blur_policy_factory, _U('defocus_blur'), _U('motion_blur'), blur.glass_blur_policy_factory,
-      _U('zoom_in_blur')), 1.0),
+      blur.zoom_in_blur_policy_factory), 1.0),
     ((noise.gaussion_noise_policy_factory, noise.poisson_noise_policy_factory, noise.impulse_noise_policy_factory,
       noise.speckle_noise_policy_factory), 3.0),
     ((_U('jpeg_quality'), effect.pixelation_policy_factory, effect.fog_policy_factory), 1.0),
