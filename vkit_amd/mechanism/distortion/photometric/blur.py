@@ -1,8 +1,9 @@
 """``gaussian_blur`` (reference: photometric/blur.py:26-69): ksize = max(3, round(3 sigma) + 1) forced odd,
 ``cv.GaussianBlur(mat, (k, k), sigma)`` -- OpenCV's bit-exact 8.8 fixed-point separable kernel restated in HIP --
 and ``glass_blur`` (:186-258): that blur followed by a random local pixel shuffle.  ``defocus_blur`` / ``motion_blur``
-run ``cv.filter2D`` with kernels of 50+ taps, which OpenCV evaluates through a DFT: not reproducible bit for bit, so
-they stay outside the path.  ``zoom_in_blur`` (:264-323) averages the image with centred crops of its bicubic
+run ``cv.filter2D`` with float kernels built by float ``cv.GaussianBlur`` / ``cv.warpAffine`` (fused vs unfused
+multiply-adds differ between SIMD body and scalar tail inside one cv2 build; a DFT from 50 taps on): there is no single
+bit pattern to reproduce, so they stay outside the path.  ``zoom_in_blur`` (:264-323) averages the image with centred crops of its bicubic
 enlargements (``vkx_zoom_in_blur_u8``)."""
 from typing import Any, Mapping, Optional
 
