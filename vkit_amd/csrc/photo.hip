@@ -91,6 +91,62 @@ __global__ void __launch_bounds__(256) k_gaussian_blur(const uint8_t *__restrict
     for (int c = 0; c < CN; c++) d[c] = (uint8_t)vkd::clamp_u8((int)((acc[c] + 32768u) >> 16));
 }
 
+// The same arithmetic as k_gaussian_blur for kernels up to 7 x 7, tiled: a workgroup of 4 wavefronts owns a window of
+// 64 columns (lane = column, the middle 64 - 2 rx are outputs) x 32 + 2 ry rows.  Every pixel is loaded once (row
+// coalesced), the horizontal pass runs on wavefront shuffles, its 8.8 sums go through LDS, the vertical pass reads
+// them at lane stride 1 -- the standalone form of phases D / E of the fused chain kernel.
+constexpr int kBlurTileH = 32, kBlurRMax = 3;
+
+template <int CN>
+__global__ void __launch_bounds__(256) k_gaussian_blur_tiled(const uint8_t *__restrict__ src, int h, int w, ptrdiff_t sstride,
+                                                             uint8_t *__restrict__ dst, ptrdiff_t dstride, BlurKernel K)
+{
+    __shared__ uint16_t hs[(kBlurTileH + 2 * kBlurRMax) * 64 * CN];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = K.kw / 2;                       // kw == kh here
+    const int tw = 64 - 2 * r;
+    const int x0 = blockIdx.x * tw, y0 = blockIdx.y * kBlurTileH;
+    const int gx = reflect101(x0 - r + lane, w);   // the column this lane holds during the horizontal pass
+    const int rows = min(kBlurTileH, h - y0) + 2 * r;
+    uint32_t kq[2 * kBlurRMax + 1];
+#pragma unroll
+    for (int i = 0; i < 2 * kBlurRMax + 1; i++) kq[i] = i < K.kw ? K.k[i] : 0;
+    for (int row = wave; row < rows; row += 4) {
+        const uint8_t *p = src + (ptrdiff_t)reflect101(y0 - r + row, h) * sstride + (ptrdiff_t)gx * CN;
+        uint32_t px[CN], acc[CN];
+#pragma unroll
+        for (int c = 0; c < CN; c++) { px[c] = p[c]; acc[c] = 0; }
+#pragma unroll
+        for (int i = 0; i < 2 * kBlurRMax + 1; i++) {
+            if (i < K.kw) {
+                const int from = min(max(lane + i - r, 0), 63);
+#pragma unroll
+                for (int c = 0; c < CN; c++) acc[c] += kq[i] * (uint32_t)__shfl((int)px[c], from, 64);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CN; c++) hs[(row * 64 + lane) * CN + c] = (uint16_t)min(acc[c], 65535u);
+    }
+    __syncthreads();
+    const int ox = lane - r, x = x0 + ox;
+    if (ox < 0 || ox >= tw || x >= w) return;
+    for (int orow = wave; orow < rows - 2 * r; orow += 4) {
+        uint32_t acc[CN];
+#pragma unroll
+        for (int c = 0; c < CN; c++) acc[c] = 0;
+#pragma unroll
+        for (int j = 0; j < 2 * kBlurRMax + 1; j++) {
+            if (j < K.kh) {
+#pragma unroll
+                for (int c = 0; c < CN; c++) acc[c] += kq[j] * hs[((orow + j) * 64 + lane) * CN + c];
+            }
+        }
+        uint8_t *d = dst + (ptrdiff_t)(y0 + orow) * dstride + (ptrdiff_t)x * CN;
+#pragma unroll
+        for (int c = 0; c < CN; c++) d[c] = (uint8_t)vkd::clamp_u8((int)((acc[c] + 32768u) >> 16));
+    }
+}
+
 // ---- cvtColor RGB <-> HSV_FULL (uint8) -----------------------------------------------------------------------
 // RGB->HSV is OpenCV's integer LUT division; the two 256-entry tables (cvRound of doubles) are built on the
 // host once and passed in device memory.
@@ -492,6 +548,18 @@ VKX_EXPORT int vkx_gaussian_blur_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h,
                           kMaxKsize);
             return VKX_ERR_UNSUPPORTED;
         }
+    }
+    if (K.kw == K.kh && K.kw > 1 && K.kw <= 2 * kBlurRMax + 1 && (cn == 1 || cn == 3 || cn == 4)) {
+        const int tw = 64 - 2 * (K.kw / 2);
+        dim3 tgrid(vkx_blocks(w, tw), vkx_blocks(h, kBlurTileH));
+        VKX_TIMED(ctx, "k_gaussian_blur");
+        switch (cn) {
+        case 1: k_gaussian_blur_tiled<1><<<tgrid, 256, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K); break;
+        case 3: k_gaussian_blur_tiled<3><<<tgrid, 256, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K); break;
+        default: k_gaussian_blur_tiled<4><<<tgrid, 256, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K); break;
+        }
+        VKX_LAUNCH_CHECK();
+        return VKX_OK;
     }
     dim3 block(64, 4), grid(vkx_blocks(w, 64), vkx_blocks(h, 4));
     switch (cn) {
