@@ -88,3 +88,33 @@ def test_large_mask_fill_and_paint(N):
     N.fill(mask, [layer, layer2])
     assert (mask[h - 10:, w - 10:] == 7).all() and (mask[:2, :2] == 9).all()
     assert int(mask.sum()) == 60 * 50 - 100 + 27 * 38 + 700 + 36
+
+
+def test_torch_device_memory_and_stream_interop(N):
+    """The *_dev entry points take any device pointer and enqueue on a borrowed stream: tensors and the current stream
+    of PyTorch-ROCm (same HIP runtime in the process) work without a copy through the host."""
+    torch = pytest.importorskip('torch')
+    if not torch.cuda.is_available():
+        pytest.skip('torch sees no GPU')
+    rng = default_rng(5)
+    img = rng.integers(0, 256, (300, 420, 3), dtype=np.uint8)
+    noise = rng.integers(-40, 40, img.shape).astype(np.int16)
+    t_src = torch.from_numpy(img).cuda()
+    t_noise = torch.from_numpy(noise).cuda()
+    t_mid = torch.empty_like(t_src)
+    t_dst = torch.empty_like(t_src)
+    ctx = N.Context(0)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        lib = N.lib()
+        N.check(lib.vkx_color_shift_rgb_dev(ctx.handle, t_src.data_ptr(), 300, 420, 420 * 3, 91, t_mid.data_ptr(), 420 * 3))
+        N.check(lib.vkx_add_noise_i16_dev(ctx.handle, t_mid.data_ptr(), 300, 420, 3, 420 * 3, t_noise.data_ptr(), 420 * 3,
+                                          t_dst.data_ptr(), 420 * 3))
+        doubled = t_dst.to(torch.int32) * 2          # a torch op ordered after the kernels on the same stream
+    side.synchronize()
+    ctx.set_stream(None)
+    want = O.add_noise_i16(O.color_shift_rgb(img, 91), noise)
+    np.testing.assert_array_equal(t_dst.cpu().numpy(), want)
+    np.testing.assert_array_equal(doubled.cpu().numpy(), want.astype(np.int32) * 2)
+    ctx.close()
