@@ -20,6 +20,7 @@
 // implementation inside the library and serve every shape this kernel does not take.
 #include "vkx_internal.h"
 #include "vkx_cell.h"
+#include "vkx_color.h"
 
 #include <float.h>
 #include <stdlib.h>
@@ -173,40 +174,10 @@ struct HsvLut {
 
 __device__ __forceinline__ void hue_shift_px(const int *sdiv, const int *hdiv, int delta, int &r, int &g, int &b)
 {
-    // RGB -> HSV_FULL (integer LUT division)
-    const int v = max(b, max(g, r)), vmin = min(b, min(g, r));
-    const int diff = v - vmin;
-    const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
-    // table entries are < 2^24 (255 << 12, 256 << 12 / 6), diff and hh < 2^11: 24-bit multiplies (full rate) are exact
-    const int S = (__mul24(diff, sdiv[v]) + (1 << 11)) >> 12;
-    int hh = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
-    hh = (__mul24(hh, hdiv[diff]) + (1 << 11)) >> 12;
-    hh += hh < 0 ? 256 : 0;
-    int H = vkd::clamp_u8(hh);
+    int H, S, V;
+    vkd::rgb2hsv_full(sdiv, hdiv, r, g, b, H, S, V);
     H = (H + delta) & 255;   // python modulo 256 of a sum that may be negative
-    // HSV_FULL -> RGB (float32 scalar formula, no FMA).  Branch free: with s == 0 every candidate below is
-    // fv * 1.0f == fv, which is the reference's grey shortcut; H < 256 keeps the sector in 0..5.
-    const float s = S * (1.0f / 255.0f);
-    const float fv = v * (1.0f / 255.0f);
-    float h = (float)H * (6.0f / 256);
-    const int sector = (int)h;                 // h >= 0: truncation == floor
-    h -= (float)sector;
-    const float t0 = fv;
-    const float t1 = fv * (1.f - s);
-    const float t2 = fv * (1.f - s * h);
-    const float t3 = fv * (1.f - s * (1.f - h));
-    // sector table (b, g, r): 0 (t1,t3,t0) 1 (t1,t0,t2) 2 (t3,t0,t1) 3 (t0,t2,t1) 4 (t0,t1,t3) 5 (t2,t1,t0)
-    //   = (t1, odd ? t0 : t3, odd ? t2 : t0) rotated left by sector / 2
-    const bool odd = sector & 1;
-    const int rot = sector >> 1;
-    const float u0 = t1, u1 = odd ? t0 : t3, u2 = odd ? t2 : t0;
-    const float fb = rot == 0 ? u0 : (rot == 1 ? u1 : u2);
-    const float fg = rot == 0 ? u1 : (rot == 1 ? u2 : u0);
-    const float fr = rot == 0 ? u2 : (rot == 1 ? u0 : u1);
-    // 0 <= f <= 1, so round-half-even needs neither the cvRound range check nor the saturate_cast clamp
-    r = __float2int_rn(fr * 255.0f);
-    g = __float2int_rn(fg * 255.0f);
-    b = __float2int_rn(fb * 255.0f);
+    vkd::hsv2rgb_full(H, S, V, r, g, b);
 }
 
 constexpr size_t kLdsOwn = sizeof(uint32_t) * W * W;            // owner tags, then (r | g << 16) horizontal sums

@@ -1,6 +1,7 @@
 // Photometric members of the distortion chain on gfx950 (per-pixel integer / float32 work, HBM bound).
 // Arithmetic specification and reference citations: oracle/vkx_oracle.c.
 #include "vkx_internal.h"
+#include "vkx_color.h"
 
 #include <algorithm>
 
@@ -158,50 +159,10 @@ struct HsvTables {
 __device__ __forceinline__ void rgb2hsv_px(const int *__restrict__ sdiv, const int *__restrict__ hdiv, int r, int g, int b,
                                            int &H, int &S, int &V)
 {
-    int v = max(b, max(g, r)), vmin = min(b, min(g, r));
-    const int diff = v - vmin;
-    const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
-    S = (diff * sdiv[v] + (1 << 11)) >> 12;
-    int hh = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
-    hh = (hh * hdiv[diff] + (1 << 11)) >> 12;
-    hh += hh < 0 ? 256 : 0;
-    H = vkd::clamp_u8(hh);
-    V = v;
+    vkd::rgb2hsv_full(sdiv, hdiv, r, g, b, H, S, V);
 }
 
-// HSV2RGB_native (float32, scalar path of color_hsv.simd.hpp), no FMA.
-__device__ __forceinline__ void hsv2rgb_px(int H, int S, int V, int &r, int &g, int &b)
-{
-    const float hscale = 6.0f / 256;
-    float h = (float)H;
-    const float s = S * (1.0f / 255.0f);
-    const float v = V * (1.0f / 255.0f);
-    float fb, fg, fr;
-    if (s == 0) {
-        fb = fg = fr = v;
-    } else {
-        h *= hscale;              // < 6 for every 8-bit hue: the fmod(h, 6) of the reference is the identity
-        int sector = (int)floorf(h);
-        h -= sector;
-        if ((unsigned)sector >= 6u) { sector = 0; h = 0.f; }
-        const float t0 = v;
-        const float t1 = v * (1.f - s);
-        const float t2 = v * (1.f - s * h);
-        const float t3 = v * (1.f - s * (1.f - h));
-        // sector_data = {1,3,0}, {1,0,2}, {3,0,1}, {0,2,1}, {0,1,3}, {2,1,0}  (b, g, r)
-        switch (sector) {
-        case 0: fb = t1; fg = t3; fr = t0; break;
-        case 1: fb = t1; fg = t0; fr = t2; break;
-        case 2: fb = t3; fg = t0; fr = t1; break;
-        case 3: fb = t0; fg = t2; fr = t1; break;
-        case 4: fb = t0; fg = t1; fr = t3; break;
-        default: fb = t2; fg = t1; fr = t0; break;
-        }
-    }
-    r = vkd::clamp_u8(vkd::cv_round(fr * 255.0f));
-    g = vkd::clamp_u8(vkd::cv_round(fg * 255.0f));
-    b = vkd::clamp_u8(vkd::cv_round(fb * 255.0f));
-}
+__device__ __forceinline__ void hsv2rgb_px(int H, int S, int V, int &r, int &g, int &b) { vkd::hsv2rgb_full(H, S, V, r, g, b); }
 
 // mode 0: color_shift (RGB -> HSV, H += delta mod 256, HSV -> RGB); 1: RGB -> HSV; 2: HSV -> RGB
 template <int MODE>

@@ -1,0 +1,54 @@
+// cv.cvtColor RGB <-> HSV_FULL on uint8 (element/image.py:188-202,771-814; photometric/color.py:93-116), shared by the
+// single-stage kernels (photo.hip) and the fused chain kernel (fused.hip).  Must agree bit for bit with
+// oracle/vkx_oracle.c: integer LUT division forwards, the scalar float32 HSV2RGB_native formula (no FMA) backwards.
+#ifndef VKX_COLOR_H_
+#define VKX_COLOR_H_
+
+#include "vkx_internal.h"
+
+namespace vkd {
+
+// sdiv[i] = cvRound((255 << 12) / i), hdiv[i] = cvRound((256 << 12) / (6 i)): both < 2^24, and diff, |hh| < 2^11, so the
+// 24-bit multiplies (full rate) are exact.
+__device__ __forceinline__ void rgb2hsv_full(const int *sdiv, const int *hdiv, int r, int g, int b, int &H, int &S, int &V)
+{
+    const int v = max(b, max(g, r)), vmin = min(b, min(g, r));
+    const int diff = v - vmin;
+    const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
+    S = (__mul24(diff, sdiv[v]) + (1 << 11)) >> 12;
+    int hh = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+    hh = (__mul24(hh, hdiv[diff]) + (1 << 11)) >> 12;
+    hh += hh < 0 ? 256 : 0;
+    H = clamp_u8(hh);
+    V = v;
+}
+
+// Branch free: with s == 0 every candidate below is fv * 1.0f == fv, which is the reference's grey shortcut; H < 256
+// keeps the sector in 0..5.  sector table (b, g, r): 0 (t1,t3,t0) 1 (t1,t0,t2) 2 (t3,t0,t1) 3 (t0,t2,t1) 4 (t0,t1,t3)
+// 5 (t2,t1,t0) = (t1, odd ? t0 : t3, odd ? t2 : t0) rotated left by sector / 2.
+__device__ __forceinline__ void hsv2rgb_full(int H, int S, int V, int &r, int &g, int &b)
+{
+    const float s = S * (1.0f / 255.0f);
+    const float fv = V * (1.0f / 255.0f);
+    float h = (float)H * (6.0f / 256);
+    const int sector = (int)h;                 // h >= 0: truncation == floor
+    h -= (float)sector;
+    const float t0 = fv;
+    const float t1 = fv * (1.f - s);
+    const float t2 = fv * (1.f - s * h);
+    const float t3 = fv * (1.f - s * (1.f - h));
+    const bool odd = sector & 1;
+    const int rot = sector >> 1;
+    const float u0 = t1, u1 = odd ? t0 : t3, u2 = odd ? t2 : t0;
+    const float fb = rot == 0 ? u0 : (rot == 1 ? u1 : u2);
+    const float fg = rot == 0 ? u1 : (rot == 1 ? u2 : u0);
+    const float fr = rot == 0 ? u2 : (rot == 1 ? u0 : u1);
+    // 0 <= f <= 1, so round-half-even needs neither the cvRound range check nor the saturate_cast clamp
+    r = __float2int_rn(fr * 255.0f);
+    g = __float2int_rn(fg * 255.0f);
+    b = __float2int_rn(fb * 255.0f);
+}
+
+} // namespace vkd
+
+#endif // VKX_COLOR_H_
