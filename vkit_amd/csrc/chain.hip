@@ -3,8 +3,9 @@
 // i.e. BASELINE config 3.  Every item is an independent image with its own grid, destination size and
 // parameters (ragged batch); stages with a disabled parameter are skipped.
 //
-// Round-1 implementation: the stages run as the individual kernels of grid.hip / photo.hip, ping-ponging through
-// two ctx-owned planes so only the final stage writes the caller's destination.
+// Two implementations with identical pixels: the tile-fused kernel of fused.hip (preferred) and, for shapes it
+// declines or under VKX_CHAIN_STAGED=1, the individual kernels of grid.hip / photo.hip below, ping-ponging through two
+// ctx-owned planes so that only the final stage writes the caller's destination.
 #include "vkx_internal.h"
 
 #include <stdlib.h>
