@@ -1,10 +1,11 @@
 // The fused geometric + photometric chain on gfx950: ONE launch for a ragged batch of independent RGB images.
 //
-//   k_chain_setup   one lane per grid cell of every image: inverse homography, cv.fillPoly edge table, and the
-//                   binning of the cell into the destination tiles its bounding box (+ blur halo) touches.
-//   k_chain_fused   one 512-lane workgroup (8 wavefronts) per destination tile.  The tile's WINDOW is 64 x 64
-//                   pixels -- one wavefront spans a window row, lane = column -- and holds the tile proper
-//                   ((64 - 2R)^2 pixels, R = blur radius) plus its halo:
+//   k_chain_setup      one lane per grid cell of every image: closed-form inverse homography, cv.fillPoly edge table, and
+//                      the binning of the cell into the destination tiles its bounding box (+ blur halo) touches.
+//   k_chain_setup_svd  the few cells whose homography needs the Jacobi-SVD least squares (workspace in LDS).
+//   k_chain_fused      one 512-lane workgroup (8 wavefronts) per destination tile.  The tile's WINDOW is 64 x 64
+//                      pixels -- one wavefront spans a window row, lane = column -- and holds the tile proper
+//                      (((64 - 2R) & ~3)^2 pixels, R = blur radius) plus its halo:
 //      A  the tile's candidate cells are pulled into LDS and rasterised into an LDS ownership plane with
 //         ds_max ("the later cell in row-major order wins", grid_rendering/type.py:222-256);
 //      C  per window row: inv_H * (x, y, 1) in double (the FMA chain of the reference's dgemm), 1/32-px
@@ -12,12 +13,17 @@
 //      D  horizontal 8.8 fixed-point Gaussian pass with wavefront shuffles (the remapped pixel never leaves
 //         its register), result to LDS in place of the ownership tags;
 //      E  vertical pass out of LDS (lane stride 1, conflict free), RGB -> HSV_FULL -> hue shift -> RGB,
-//         + int16 noise, clip; neighbouring lanes pack 4 pixels into 3 dwords with one shuffle and store.
+//         + int16 noise, clip, optional line_streak blends; neighbouring lanes pack 4 pixels into 3 dwords with one
+//         shuffle and store.
+//      Variants of the tile body (template KIND): interior windows (border logic compiled out), empty tiles (no cell
+//      reaches the window: constant colour), and the element mode of k_tile_remap.
+//   k_tile_remap       the same tile machinery for vkx_grid_remap: 1-4 elements of any supported type (uint8 x 1 / 3 / 4
+//                      channels, float32) gathered through one lattice, no photometric stage.
 //   The dense float map, the remapped image and the blurred image never exist in HBM: the kernel reads the
 //   source image (and the noise plane, an API input) once and writes the result once.
 //
 // Arithmetic is identical to the single-purpose kernels in grid.hip / photo.hip, which stay the reference
-// implementation inside the library and serve every shape this kernel does not take.
+// implementation inside the library and serve every shape these kernels do not take.
 #include "vkx_internal.h"
 #include "vkx_cell.h"
 #include "vkx_color.h"
