@@ -162,6 +162,13 @@ __global__ void __launch_bounds__(64) k_chain_setup_svd(const ItemDev *__restric
     }
 }
 
+// a wave-uniform 64-bit value, moved into SGPRs
+__device__ __forceinline__ uint64_t uniform64(uint64_t v)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
 __device__ __forceinline__ int reflect101(int p, int len)
 {
     if ((unsigned)p < (unsigned)len) return p;
@@ -186,8 +193,10 @@ __device__ __forceinline__ void hue_shift_px(const int *sdiv, const int *hdiv, i
     vkd::hsv2rgb_full(H, S, V, r, g, b);
 }
 
-constexpr size_t kLdsOwn = sizeof(uint32_t) * W * W;            // owner tags, then (r | g << 16) horizontal sums
-constexpr size_t kLdsHbB = sizeof(uint16_t) * W * W;            // b horizontal sums
+constexpr int P = W + 1;        // dword pitch of the ownership plane: the raster walks columns AND rows, an odd pitch keeps both off
+                               // a single LDS bank
+constexpr size_t kLdsOwn = sizeof(uint32_t) * W * P;            // owner tags, then (r | b << 16) horizontal sums
+constexpr size_t kLdsHbB = sizeof(uint16_t) * W * W;            // g horizontal sums
 constexpr size_t kLdsCellR = sizeof(CellR) * NLDSCELL;
 constexpr size_t kLdsCellH = sizeof(double) * 9 * NLDSCELL;     // 72-byte pitch keeps same-index reads of different
                                                                 // cells on different LDS banks
@@ -198,15 +207,16 @@ constexpr size_t kFusedLds = kLdsOwn + kLdsHbB + kLdsCellR + kLdsCellH + kLdsLut
 // case (about 89 % of the tiles of a 2048^2 page).  Border handling (row / column validity, BORDER_REFLECT_101 lane tables,
 // the global-memory fallback for candidates beyond the chunk) compiles away; the arithmetic is the same.
 // STREAK: the line_streak stage is compiled in (its own kernel instance, so batches without it keep the lean one)
-template <int KIND, bool STREAK = false>   // 0 generic, 1 interior, 2 empty, 3 element remap (any element types)
+// RC: the blur radius as a compile-time constant (0..RMAX), or -1 = read it from the item.  With RC fixed the tap
+// loops of phases D / E unroll to exactly K taps and the tile geometry folds into immediates.
+template <int KIND, bool STREAK = false, int RC = -1>   // 0 generic, 1 interior, 2 empty, 3 element remap (any element types)
 __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, const int tile_id,
                                            const vkc::CellC *__restrict__ cells, const TileBin &bin,
                                            const HsvLut *__restrict__ lut, int phase_limit)
 {
     constexpr bool INTERIOR = KIND == 1, EMPTY = KIND == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // `own` holds owner tags during phases A / C with a row-dependent column rotation ((x + row) & 63, against
-    // bank conflicts of the raster), then the horizontal sums / packed pixels of phases D / E unrotated.
+    // `own` holds owner tags during phases A / C, then the horizontal sums / packed pixels of phases D / E; row pitch P.
     uint32_t *own = (uint32_t *)smem;
     uint16_t *hbB = (uint16_t *)(smem + kLdsOwn);
     CellR *lcr = (CellR *)(smem + kLdsOwn + kLdsHbB);
@@ -218,7 +228,7 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
     // derived from it is scalar arithmetic instead of per-lane (64-bit, quarter-rate) multiplies
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ty = tl / it.tiles_x, tx = tl - ty * it.tiles_x;
-    const int R = it.R, K = 2 * R + 1, Tw = tile_side(R);
+    const int R = RC >= 0 ? RC : it.R, K = 2 * R + 1, Tw = tile_side(R);
     const int dw = it.dw, dh = it.dh;
     const int x0 = tx * Tw, y0 = ty * Tw;                         // the tile proper
     const int tw = INTERIOR ? Tw : min(Tw, dw - x0), th = INTERIOR ? Tw : min(Tw, dh - y0);
@@ -227,9 +237,7 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
     const int cy0 = INTERIOR ? wy0 : max(wy0, 0), cy1 = INTERIOR ? wy0 + W : min(wy0 + W, dh);
 
     const gsrc_t src = (gsrc_t)it.src;
-    const gdst_t dst = (gdst_t)it.dst;
-    const int16_t VKX_GLOBAL *noise = (const int16_t VKX_GLOBAL *)it.noise;
-    const ptrdiff_t sstride = it.sstride, dstride = it.dstride, nstride = it.nstride;
+    const ptrdiff_t sstride = it.sstride;
     const int sh = it.sh, sw = it.sw;
 
     const int ocx = lane - R;                                     // output column inside the tile (phase E)
@@ -256,11 +264,12 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
 
     uint32_t kq[2 * RMAX + 1];
 #pragma unroll
-    for (int i = 0; i < 2 * RMAX + 1; i++) kq[i] = (R > 0 && i < K) ? it.kq[i] : 0;
+    for (int i = 0; i < 2 * RMAX + 1; i++) kq[i] = (R > 0 && i < K) ? it.kq[i < K - 1 - i ? i : K - 1 - i] : 0;   // symmetric (checked on the host)
     if constexpr (!EMPTY) {
         // ---- A: clear the ownership plane, then rasterise the candidates chunk by chunk out of LDS
 #pragma unroll
-        for (int i = 0; i < W * W / NTHREADS / 4; i++) ((uint4 *)own)[tid + i * NTHREADS] = make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < (W * P / 4 + NTHREADS - 1) / NTHREADS; i++)
+            if (tid + i * NTHREADS < W * P / 4) ((uint4 *)own)[tid + i * NTHREADS] = make_uint4(0, 0, 0, 0);
         if (it.hue_on) {
             if (tid < 256) lsdiv[tid] = lut->sdiv[tid];
             else lhdiv[tid - 256] = lut->hdiv[tid - 256];
@@ -327,13 +336,17 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
                 }
                 const bool check = c.flags & 1;
                 const double h6 = check ? lch[kk * 9 + 6] : 0.0, h7 = check ? lch[kk * 9 + 7] : 0.0;
-                uint32_t *o = own + row * W;
+                uint32_t *o = own + row * P - wx0;       // o[x]
                 for (int a = 0; a + 1 < n; a += 2) {
                     const int x1 = max(max((xs[a] + 65535) >> 16, xmin), cx0);
                     const int x2 = min(min(xs[a + 1] >> 16, xmax), cx1 - 1);
-                    for (int x = x1; x <= x2; x++) {
-                        if (check && fma(1.0, 1.0, fma(h7, (double)y, h6 * (double)x)) == 0) continue;
-                        atomicMax(o + ((x - wx0 + row) & 63), tag);   // swizzled column, see the note at `own`
+                    if (!check) {
+                        for (int x = x1; x <= x2; x++) atomicMax(o + x, tag);
+                    } else {
+                        for (int x = x1; x <= x2; x++) {
+                            if (fma(1.0, 1.0, fma(h7, (double)y, h6 * (double)x)) == 0) continue;
+                            atomicMax(o + x, tag);
+                        }
                     }
                 }
             }
@@ -367,7 +380,7 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
                     const int y = ymajor ? ly + sy * s : ly + sy * m;
                     if (x >= cx0 && x < cx1 && y >= cy0 && y < cy1 &&
                         !(check && fma(1.0, 1.0, fma(h7, (double)y, h6 * (double)x)) == 0))
-                        atomicMax(own + (y - wy0) * W + ((x - wx0 + y - wy0) & 63), tag);
+                        atomicMax(own + (y - wy0) * P + (x - wx0), tag);
                     const bool step = err < 0;
                     err += -2LL * dmin + (step ? 2LL * dmaj : 0LL);
                     m += step ? 1 : 0;
@@ -387,11 +400,11 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
         //      and the gathers of several rows overlap.  Lane = window column.
         const int gx = wx0 + lane;
         const bool colok = INTERIOR || (gx >= cx0 && gx < cx1);
-        int srcl[2 * RMAX + 1];   // lane holding tap i of this lane's horizontal stencil (BORDER_REFLECT_101)
+        int srcl[2 * RMAX + 1];   // lane (x 4) holding tap i of this lane's horizontal stencil (BORDER_REFLECT_101)
 #pragma unroll
         for (int i = 0; i < 2 * RMAX + 1; i++) {
             int s = (R > 0 && i < K) ? (INTERIOR ? lane + i - R : reflect101(gx + i - R, dw) - wx0) : lane;
-            srcl[i] = min(max(s, 0), W - 1);
+            srcl[i] = min(max(s, 0), W - 1) << 2;   // ds_bpermute takes the source lane as a byte address
         }
         for (int g0 = 0; g0 < ROWS_PER_WAVE; g0 += CGROUP) {
             int X[CGROUP], Y[CGROUP];
@@ -403,13 +416,13 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
                 rowok[u] = INTERIOR || (gy >= cy0 && gy < cy1);
                 X[u] = 0; Y[u] = 0;
                 if (rowok[u] && colok) {
-                    const uint32_t o = own[ly * W + ((lane + ly) & 63)];
+                    const uint32_t o = own[ly * P + lane];
                     if (o != 0) {
                         const int k = (int)o - 1;
                         double h[8];
                         if (INTERIOR || k < NLDSCELL) {
 #pragma unroll
-                            for (int j = 0; j < 8; j++) h[j] = lch[k * 9 + j];
+                            for (int j = 0; j < 8; j++) h[j] = lch[__umul24(k, 9) + j];
                         } else {
                             const vkc::CellC VKX_GLOBAL *gc =
                                 (const vkc::CellC VKX_GLOBAL *)(gcell + (r0 + k / ncol) * cw + (c0 + k % ncol));
@@ -465,9 +478,11 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
                 ta[u] = 0; tb[u] = 0;
                 if (fast[u]) {
                     // interior: the two 6-byte tap pairs come in as two unaligned 8-byte loads (3 sx + 8 <= 3 sw)
-                    const gsrc_t q0 = src + (ptrdiff_t)sy * sstride + (ptrdiff_t)sx * 3;
-                    ta[u] = *(const u64_u1 VKX_GLOBAL *)q0;
-                    tb[u] = *(const u64_u1 VKX_GLOBAL *)(q0 + sstride);
+                    // sy < 2^15, sstride < 2^24 and sh * sstride < 2^32 (checked on the host): full-rate 24-bit multiplies
+                    // and a 32-bit lane offset on the uniform base pointer
+                    const uint32_t o0 = __umul24((uint32_t)sy, (uint32_t)sstride) + __umul24((uint32_t)sx, 3u);
+                    ta[u] = *(const u64_u1 VKX_GLOBAL *)(src + (size_t)o0);
+                    tb[u] = *(const u64_u1 VKX_GLOBAL *)(src + (size_t)(o0 + (uint32_t)sstride));
                 }
             }
 #pragma unroll
@@ -492,21 +507,26 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
                     }
                 }
                 if (R > 0) {
-                    // D: horizontal u8 x 8.8 pass; tap i of lane l lives in lane srcl[i]
-                    uint32_t a0 = 0, a1 = 0, a2 = 0;
+                    // D: horizontal u8 x 8.8 pass; tap i of lane l lives in lane srcl[i].  r and b travel as the two
+                    // 16-bit halves of one dword (255 * 256 < 2^16: the halves never carry into each other)
+                    const uint32_t prb = px & 0x00ff00ffu, pg = (px >> 8) & 0xffu;
+                    uint32_t arb = 0, ag = 0;
 #pragma unroll
                     for (int i = 0; i < 2 * RMAX + 1; i++) {
                         if (i < K) {
-                            const uint32_t v = (uint32_t)__shfl((int)px, srcl[i], 64);
-                            a0 += kq[i] * (v & 0xff);
-                            a1 += kq[i] * ((v >> 8) & 0xff);
-                            a2 += kq[i] * ((v >> 16) & 0xff);
+                            uint32_t vrb = prb, vg = pg;
+                            if (!(INTERIOR && RC >= 0 && i == RC)) {      // the centre tap of an interior window is the lane's own pixel
+                                vrb = (uint32_t)__builtin_amdgcn_ds_bpermute(srcl[i], (int)prb);
+                                vg = (uint32_t)__builtin_amdgcn_ds_bpermute(srcl[i], (int)pg);
+                            }
+                            arb += __umul24(kq[i], vrb);
+                            ag += __umul24(kq[i], vg);
                         }
                     }
-                    own[ly * W + lane] = a0 | (a1 << 16);
-                    hbB[ly * W + lane] = (uint16_t)a2;
+                    own[ly * P + lane] = arb;
+                    hbB[ly * W + lane] = (uint16_t)ag;
                 } else {
-                    own[ly * W + lane] = px;
+                    own[ly * P + lane] = px;
                 }
             }
         }
@@ -520,6 +540,15 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
     // This wavefront's output rows are cy = wave + 8 i, column = lane - R.  All their noise (exactly 6 bytes per
     // pixel: a dword + a short) is requested up front, so eight rows of HBM latency overlap; asking earlier (before
     // phase A) would pin 16 VGPRs through the register-heavy phases and spill.
+    // The descriptor fields only this phase needs are read here, through a pointer the optimiser cannot trace back:
+    // hoisted to the top of the kernel they would sit in SGPRs through phases A - D and spill.
+    const ItemDev *ite_ = &it;
+    asm volatile("" : "+s"(ite_));
+    const ItemDev &ite = *ite_;
+    // (such loads come back in VGPRs; the row address arithmetic wants them scalar)
+    const gdst_t dst = (gdst_t)uniform64((uint64_t)ite.dst);
+    const int16_t VKX_GLOBAL *noise = (const int16_t VKX_GLOBAL *)uniform64((uint64_t)ite.noise);
+    const ptrdiff_t dstride = (ptrdiff_t)uniform64((uint64_t)ite.dstride), nstride = (ptrdiff_t)uniform64((uint64_t)ite.nstride);
     uint32_t nzA[ROWS_PER_WAVE];
     uint32_t nzB[ROWS_PER_WAVE];
 #pragma unroll
@@ -532,12 +561,13 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
             nzB[i] = *(const u16_u1 VKX_GLOBAL *)(np_ + 2);
         }
     }
-    const bool hue_on = it.hue_on != 0;
-    const int hue_delta = it.hue_delta;
+    const bool hue_on = __builtin_amdgcn_readfirstlane(ite.hue_on) != 0;
+    const int hue_delta = __builtin_amdgcn_readfirstlane(ite.hue_delta);
+    const int right4 = min(lane + 1, 63) << 2;       // ds_bpermute address of the right-hand neighbour
     const int full4 = (tw >> 2) << 2;          // columns covered by whole 4-pixel (12-byte) groups
-    const bool streak_on = STREAK && it.streak_on != 0;
-    const int sxm = streak_on ? (x0 + ocx) % it.streak_step : 0;        // this lane's column phase in the stripe period
-    const int sxd = streak_on ? (x0 + ocx) % it.streak_dash_step : 0;
+    const bool streak_on = STREAK && ite.streak_on != 0;
+    const int sxm = streak_on ? (x0 + ocx) % ite.streak_step : 0;        // this lane's column phase in the stripe period
+    const int sxd = streak_on ? (x0 + ocx) % ite.streak_dash_step : 0;
     // EMPTY: no lattice cell reaches the window, so every pixel of it maps to (0, 0) (the reference's unfilled map
     // entries) = the source's first pixel; the blur of a constant is that constant (kernel taps sum to 256), and the
     // hue shift is evaluated once per lane instead of once per pixel.
@@ -559,18 +589,17 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
             for (int j = 0; j < 2 * RMAX + 1; j++) {
                 if (j < K) {
                     const int yy = INTERIOR ? cy + j : reflect101(gy + j - R, dh) - wy0;
-                    const uint32_t hA = own[yy * W + lane];
-                    const uint32_t hB = hbB[yy * W + lane];
-                    a0 += kq[j] * (hA & 0xffff);
-                    a1 += kq[j] * (hA >> 16);
-                    a2 += kq[j] * hB;
+                    const uint16_t *hRB = (const uint16_t *)(own + yy * P + lane);
+                    a0 += __umul24(kq[j], (uint32_t)hRB[0]);
+                    a2 += __umul24(kq[j], (uint32_t)hRB[1]);
+                    a1 += __umul24(kq[j], (uint32_t)hbB[yy * W + lane]);
                 }
             }
             r = (int)((a0 + 32768u) >> 16);
             g = (int)((a1 + 32768u) >> 16);
             b = (int)((a2 + 32768u) >> 16);
         } else {
-            const uint32_t v = own[(cy + R) * W + lane];
+            const uint32_t v = own[(cy + R) * P + lane];
             r = v & 0xff; g = (v >> 8) & 0xff; b = (v >> 16) & 0xff;
         }
         if (hue_on) hue_shift_px(lsdiv, lhdiv, hue_delta, r, g, b);
@@ -583,28 +612,28 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
         if (STREAK && streak_on) {
             // stripe masks: vertical x % (t + g) < t, horizontal y % (t + g) < t, dash gaps cut them; vertical stripes
             // are blended first, then horizontal ones (crossings twice); trunc(fl32(1 - a) * v + a * c)
-            const int ym = gy % it.streak_step, yd = gy % it.streak_dash_step;
-            bool mv = it.streak_vert && sxm < it.streak_thickness;
-            bool mh = it.streak_hori && ym < it.streak_thickness;
-            if (it.streak_dash) {
-                if (yd < it.streak_dash_gap) mv = false;
-                if (sxd < it.streak_dash_gap) mh = false;
+            const int ym = gy % ite.streak_step, yd = gy % ite.streak_dash_step;
+            bool mv = ite.streak_vert && sxm < ite.streak_thickness;
+            bool mh = ite.streak_hori && ym < ite.streak_thickness;
+            if (ite.streak_dash) {
+                if (yd < ite.streak_dash_gap) mv = false;
+                if (sxd < ite.streak_dash_gap) mh = false;
             }
-            const float w1 = it.streak_alpha, w0 = 1.0f - w1;
+            const float w1 = ite.streak_alpha, w0 = 1.0f - w1;
             int *ch[3] = {&r, &g, &b};
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 int v = *ch[c];
-                const int col = it.streak_color[c];
-                if (mv) { const float t0 = w0 * (float)v, t1 = w1 * (float)col; v = it.streak_copy ? col : (int)(uint8_t)(t0 + t1); }
-                if (mh) { const float t0 = w0 * (float)v, t1 = w1 * (float)col; v = it.streak_copy ? col : (int)(uint8_t)(t0 + t1); }
+                const int col = ite.streak_color[c];
+                if (mv) { const float t0 = w0 * (float)v, t1 = w1 * (float)col; v = ite.streak_copy ? col : (int)(uint8_t)(t0 + t1); }
+                if (mh) { const float t0 = w0 * (float)v, t1 = w1 * (float)col; v = ite.streak_copy ? col : (int)(uint8_t)(t0 + t1); }
                 *ch[c] = v;
             }
         }
         // 4 adjacent pixels = 12 bytes = 3 dwords: lanes with (column & 3) = 0, 1, 2 each build one dword from
         // their own pixel and their right neighbour's
         const uint32_t P = (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16);
-        const uint32_t Pn = (uint32_t)__shfl_down((int)P, 1, 64);
+        const uint32_t Pn = (uint32_t)__builtin_amdgcn_ds_bpermute(right4, (int)P);
         gdst_t drow = dst + (ptrdiff_t)gy * dstride + (ptrdiff_t)x0 * 3;
         if (ocol) {
             const int m = ocx & 3;
@@ -647,8 +676,15 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
     const int nc = bin.rmax1 > 0 ? max(0, bin.rmax1 - bin.rmin) * max(0, bin.cmax1 - bin.cmin) : 0;
     const bool interior = wx0 >= 0 && wy0 >= 0 && wx0 + W <= it.dw && wy0 + W <= it.dh && nc <= NLDSCELL && phase_limit != 3;
     if (nc == 0) chain_tile<2, STREAK>(it, tl, tile_id, cells, bin, lut, phase_limit);
-    else if (interior) chain_tile<1, STREAK>(it, tl, tile_id, cells, bin, lut, phase_limit);
-    else chain_tile<0, STREAK>(it, tl, tile_id, cells, bin, lut, phase_limit);
+    else if (interior) {
+        // the common case gets the blur radius as a compile-time constant
+        switch (it.R) {
+        case 0: chain_tile<1, STREAK, 0>(it, tl, tile_id, cells, bin, lut, phase_limit); break;
+        case 1: chain_tile<1, STREAK, 1>(it, tl, tile_id, cells, bin, lut, phase_limit); break;
+        case 2: chain_tile<1, STREAK, 2>(it, tl, tile_id, cells, bin, lut, phase_limit); break;
+        default: chain_tile<1, STREAK, 3>(it, tl, tile_id, cells, bin, lut, phase_limit); break;
+        }
+    } else chain_tile<0, STREAK>(it, tl, tile_id, cells, bin, lut, phase_limit);
 }
 
 // Element mode of the same tile machinery: Image / Mask / ScoreMap (uint8 x 1, 3, 4 channels, float32) of one call
@@ -763,6 +799,10 @@ int vkx_chain_fused_try(vkx_ctx *ctx, const vkx_chain_item *items, int n_items)
         }
         for (int k = 0; k < 8; k++) d.kq[k] = 0;
         if (d.R > 0 && vkx_gaussian_kernel_q8_host(it.blur_ksize, it.blur_sigma, d.kq)) return VKX_ERR_UNSUPPORTED;
+        for (int k = 0; k < d.R; k++)
+            if (d.kq[k] != d.kq[2 * d.R - k]) return VKX_ERR_UNSUPPORTED;    // the kernel reads one half of the taps
+        // 24-bit row multiply, 32-bit byte offsets inside the source plane
+        if (it.src_stride <= 0 || it.src_stride >= (1 << 24) || (long long)it.sh * it.src_stride + 8 > 0xffffffffLL) return VKX_ERR_UNSUPPORTED;
         cell_prefix[i] = (int)ncells;
         tiles += (long long)d.tiles_x * d.tiles_y;
         if (d.tiles_x * d.tiles_y > max_tiles) max_tiles = d.tiles_x * d.tiles_y;

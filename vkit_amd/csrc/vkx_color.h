@@ -17,7 +17,10 @@ __device__ __forceinline__ void rgb2hsv_full(const int *sdiv, const int *hdiv, i
     const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
     S = (__mul24(diff, sdiv[v]) + (1 << 11)) >> 12;
     int hh = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
-    hh = (__mul24(hh, hdiv[diff]) + (1 << 11)) >> 12;
+    // |hh| < 2^11 and hdiv < 2^24: the signed 24-bit multiply-add is exact (spelled out -- left to the compiler this
+    // product became a quarter-rate 64-bit multiply)
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(hh) : "v"(hh), "v"(hdiv[diff]), "s"(1 << 11));
+    hh >>= 12;
     hh += hh < 0 ? 256 : 0;
     H = clamp_u8(hh);
     V = v;
@@ -33,13 +36,13 @@ __device__ __forceinline__ void hsv2rgb_full(int H, int S, int V, int &r, int &g
     float h = (float)H * (6.0f / 256);
     const int sector = (int)h;                 // h >= 0: truncation == floor
     h -= (float)sector;
-    const float t0 = fv;
-    const float t1 = fv * (1.f - s);
-    const float t2 = fv * (1.f - s * h);
-    const float t3 = fv * (1.f - s * (1.f - h));
     const bool odd = sector & 1;
     const int rot = sector >> 1;
-    const float u0 = t1, u1 = odd ? t0 : t3, u2 = odd ? t2 : t0;
+    // t2 = fv (1 - s h) serves the odd sectors, t3 = fv (1 - s (1 - h)) the even ones: only the one in use is evaluated
+    const float t0 = fv;
+    const float t1 = fv * (1.f - s);
+    const float tt = fv * (1.f - s * (odd ? h : 1.f - h));
+    const float u0 = t1, u1 = odd ? t0 : tt, u2 = odd ? tt : t0;
     const float fb = rot == 0 ? u0 : (rot == 1 ? u1 : u2);
     const float fg = rot == 0 ? u1 : (rot == 1 ? u2 : u0);
     const float fr = rot == 0 ? u2 : (rot == 1 ? u0 : u1);

@@ -94,7 +94,7 @@ namespace vkd {
 // OpenCV cvRound on x86: round-half-even, "integer indefinite" outside int32 / NaN.
 __device__ __forceinline__ int cv_round(float v)
 {
-    if (!(v >= -2147483648.f && v < 2147483648.f)) return INT_MIN;
+    if (!(fabsf(v) < 2147483648.f)) return INT_MIN;   // -2^31 itself converts to INT_MIN either way
     return __float2int_rn(v);
 }
 __device__ __forceinline__ int cv_round(double v)
