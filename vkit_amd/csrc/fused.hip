@@ -684,7 +684,14 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
         case 2: chain_tile<1, STREAK, 2>(it, tl, tile_id, cells, bin, lut, phase_limit); break;
         default: chain_tile<1, STREAK, 3>(it, tl, tile_id, cells, bin, lut, phase_limit); break;
         }
-    } else chain_tile<0, STREAK>(it, tl, tile_id, cells, bin, lut, phase_limit);
+    } else {
+        switch (it.R) {
+        case 0: chain_tile<0, STREAK, 0>(it, tl, tile_id, cells, bin, lut, phase_limit); break;
+        case 1: chain_tile<0, STREAK, 1>(it, tl, tile_id, cells, bin, lut, phase_limit); break;
+        case 2: chain_tile<0, STREAK, 2>(it, tl, tile_id, cells, bin, lut, phase_limit); break;
+        default: chain_tile<0, STREAK, 3>(it, tl, tile_id, cells, bin, lut, phase_limit); break;
+        }
+    }
 }
 
 // Element mode of the same tile machinery: Image / Mask / ScoreMap (uint8 x 1, 3, 4 channels, float32) of one call
