@@ -320,6 +320,17 @@ int vkx_zoom_in_blur_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int 
 int vkx_zoom_in_blur_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
                         const int32_t *sizes_hw_host, int n_sizes, double alpha, uint8_t *dst, ptrdiff_t dst_stride);
 
+/* ---- point projection through the lattice ------------------------------------------------
+ * FuncImageGridBased.func_point, grid_rendering/interface.py:194-216, for a batch of points (the reference loops
+ * point by point, distortion/interface.py:638-661): cell = (y // grid_size, x // grid_size) of the ROUNDED point,
+ * trans_mat = cv.getPerspectiveTransform(src quad, dst quad) of that cell (grid_rendering/type.py:166-180),
+ * (x', y') = trans_mat . (smooth_x, smooth_y, 1) dehomogenised, all in float64.  Everything is HOST memory:
+ * src_vertices / dst_vertices int32 [rows, cols, 2] (x, y); pts_xy int32 [n, 2] rounded (x, y); pts_smooth_xy
+ * float64 [n, 2]; out_xy float64 [n, 2].  A point whose cell index falls outside the (rows-1) x (cols-1) cells is an
+ * error (VKX_ERR_INVALID; the reference raises IndexError there). */
+int vkx_grid_project_points(vkx_ctx *ctx, const int32_t *src_vertices, const int32_t *dst_vertices, int rows, int cols,
+                            int grid_size, const int32_t *pts_xy, const double *pts_smooth_xy, int n, double *out_xy);
+
 /* ---- polygon rasterisation -----------------------------------------------------------
  * cv.fillPoly(zeros((h, w), uint8), [pts], 1): PolygonInternals.np_mask element/polygon.py:70-77
  * (Bresenham LINE_8 outline + even-odd scanline spans).  pts: HOST int32 [npts, 2] as (x, y), all

@@ -158,6 +158,26 @@ def grid_to_map(src_vertices, dst_vertices, dst_shape, solver=SOLVER_HYBRID, wan
     return (mx, my, owner) if want_owner else (mx, my)
 
 
+def grid_project_points(src_vertices, dst_vertices, grid_size, points_xy, smooth_xy):
+    """FuncImageGridBased.func_point (grid_rendering/interface.py:194-216) point by point, as the reference loops
+    (distortion/interface.py:638-661): cell of the rounded point, get_trans_mat (grid_rendering/type.py:166-180),
+    np.matmul(trans_mat, (smooth_x, smooth_y, 1.0)) and the two float64 divisions."""
+    sv = np.asarray(src_vertices)
+    dv = np.asarray(dst_vertices)
+    out = np.empty((len(points_xy), 2), np.float64)
+    cache = {}
+    for i, ((x, y), (fx, fy)) in enumerate(zip(points_xy, smooth_xy)):
+        r, c = int(y) // int(grid_size), int(x) // int(grid_size)
+        if not (0 <= r < sv.shape[0] - 1 and 0 <= c < sv.shape[1] - 1):
+            raise IndexError('list index out of range')
+        if (r, c) not in cache:
+            quad = lambda v: np.asarray([v[r, c], v[r, c + 1], v[r + 1, c + 1], v[r + 1, c]], np.float32)
+            cache[(r, c)] = get_perspective_transform(quad(sv), quad(dv))
+        tx, ty, t = np.matmul(cache[(r, c)], (float(fx), float(fy), 1.0))
+        out[i] = (float(tx / t), float(ty / t))
+    return out
+
+
 def gaussian_kernel_q8(ksize, sigma):
     k = np.zeros(ksize, np.uint16)
     assert lib().vko_gaussian_kernel_q8(int(ksize), ctypes.c_double(sigma), _p(k)) == 0

@@ -454,3 +454,54 @@ def test_chain_batch_staged_path_subprocess(N):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and 'ok' in out.stdout, out.stdout + out.stderr
+
+
+def test_grid_project_points_matches_oracle(N):
+    """vkx_grid_project_points against the point-by-point restatement: float64 results within 4 ulp (the reference's
+    np.matmul is a BLAS dgemv whose accumulation order is build dependent), rounded pixel positions identical."""
+    rng = default_rng(77)
+    for h, w, gs, amp in [(300, 420, 20, 6.0), (97, 64, 15, 3.0), (512, 512, 50, 12.0)]:
+        sv, dv, ds = synthetic_grid(h, w, gs, amp, seed=int(rng.integers(1 << 30)))
+        n = 500
+        xs = rng.integers(0, (sv.shape[1] - 1) * gs, n)
+        ys = rng.integers(0, (sv.shape[0] - 1) * gs, n)
+        pts = np.stack([xs, ys], axis=1).astype(np.int32)
+        smooth = pts + rng.uniform(-0.5, 0.5, pts.shape)
+        smooth[:50] = pts[:50]                     # exact lattice-aligned points too
+        got = N.project_points(sv, dv, gs, pts, smooth)
+        want = O.grid_project_points(sv, dv, gs, pts, smooth)
+        assert got.shape == want.shape == (n, 2)
+        ulp = np.spacing(np.abs(want))
+        assert (np.abs(got - want) <= 4 * ulp).all()
+        off_tie = np.abs(want - np.floor(want) - 0.5) > 1e-9
+        assert (np.rint(got)[off_tie] == np.rint(want)[off_tie]).all()
+    # a point past the last cell is an IndexError, like the reference's cell table
+    with pytest.raises(IndexError):
+        N.project_points(sv, dv, gs, [[(sv.shape[1] - 1) * gs, 3]], [[float((sv.shape[1] - 1) * gs), 3.0]])
+    assert N.project_points(sv, dv, gs, np.zeros((0, 2), np.int32), np.zeros((0, 2))).shape == (0, 2)
+
+
+def test_grid_distortion_points_and_polygons_batch(N):
+    """Distortion.distort(points=, polygons=) of a grid-based op runs the batch hooks and agrees with func_point."""
+    import vkit_amd.mechanism.distortion as D
+    from vkit_amd.element import Point, PointList, Polygon
+    from vkit_amd.mechanism.distortion.geometric.grid_rendering.interface import FuncImageGridBased
+    cfg = D.CameraCubicCurveConfig(curve_alpha=40.0, curve_beta=-25.0, curve_direction=30.0, curve_scale=1.0,
+                                   camera_model_config=D.CameraModelConfig(rotation_unit_vec=[1.0, 0.5, 0.1], rotation_theta=20.0),
+                                   grid_size=16)
+    shape = (200, 260)
+    pts = PointList(Point.create(y=y, x=x) for y, x in [(0, 0), (10.25, 33.5), (199, 259), (100, 100), (57.75, 201.125)])
+    polys = [Polygon.create(points=[Point.create(y=5, x=5), Point.create(y=5, x=90), Point.create(y=60, x=90)]),
+             Polygon.create(points=[Point.create(y=150, x=20), Point.create(y=190, x=200), Point.create(y=120, x=250),
+                                    Point.create(y=100, x=30)])]
+    res = D.camera_cubic_curve.distort(cfg, shape, points=pts, polygons=polys, get_state=True)
+    st = res.state
+    for p, q in zip(pts, res.points):
+        ref = FuncImageGridBased.func_point(cfg, st, shape, p, None)
+        assert (q.y, q.x) == (ref.y, ref.x)
+        assert abs(q.smooth_y - ref.smooth_y) < 1e-9 and abs(q.smooth_x - ref.smooth_x) < 1e-9
+    assert [len(p.points) for p in res.polygons] == [3, 4]
+    for poly, out in zip(polys, res.polygons):
+        for p, q in zip(poly.points, out.points):
+            ref = FuncImageGridBased.func_point(cfg, st, shape, p, None)
+            assert (q.y, q.x) == (ref.y, ref.x)

@@ -144,6 +144,8 @@ for _sfx in ('', '_dev'):
     _SIGNATURES['vkx_grid_remap' + _sfx] = [c_void_p, ctypes.POINTER(VkxElem), c_int, c_int, c_int, c_void_p, c_void_p,
                                             c_int, c_int, c_int, c_int]
     _SIGNATURES['vkx_gaussian_blur_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_int, c_double, c_void_p, c_ssize]
+    _SIGNATURES['vkx_grid_project_points'] = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
+                                              c_void_p]
     _SIGNATURES['vkx_color_shift_rgb' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_int, c_void_p, c_ssize]
     _SIGNATURES['vkx_cvt_rgb_hsv_u8' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_int, c_void_p, c_ssize]
     _SIGNATURES['vkx_mean_shift_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_int, c_int, c_int, c_int, c_uint, c_void_p,
@@ -463,6 +465,25 @@ def grid_remap(mats, src_vertices, dst_vertices, dst_shape, ctx=None):
         check(lib().vkx_grid_remap(ctx.handle, arr, len(chunk), sh, sw, _ptr(sv), _ptr(dv), rows, cols, dh, dw))
         outs.extend(chunk_out)
     return outs
+
+
+def project_points(src_vertices, dst_vertices, grid_size, points_xy, smooth_xy, ctx=None):
+    """FuncImageGridBased.func_point for a batch: ``points_xy`` int [n, 2] rounded (x, y), ``smooth_xy`` float64 [n, 2];
+    returns float64 [n, 2] (x', y').  IndexError for a point outside the lattice cells, like the reference."""
+    ctx = ctx or default_ctx()
+    sv, dv = _vertices(src_vertices), _vertices(dst_vertices)
+    rows, cols = sv.shape[:2]
+    pi = np.ascontiguousarray(points_xy, dtype=np.int32).reshape(-1, 2)
+    ps = np.ascontiguousarray(smooth_xy, dtype=np.float64).reshape(-1, 2)
+    if pi.shape != ps.shape:
+        raise ValueError('points_xy and smooth_xy must have the same length')
+    out = np.empty_like(ps)
+    rc = lib().vkx_grid_project_points(ctx.handle, _ptr(sv), _ptr(dv), rows, cols, int(grid_size), _ptr(pi), _ptr(ps),
+                                       pi.shape[0], _ptr(out))
+    if rc == -1 and 'outside the lattice cells' in last_error():
+        raise IndexError(last_error())
+    check(rc)
+    return out
 
 
 def gaussian_blur(img, ksize, sigma, ctx=None):

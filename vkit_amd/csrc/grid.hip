@@ -166,7 +166,81 @@ int build_owner(vkx_ctx *ctx, const int32_t *src_v, const int32_t *dst_v, int ro
     return VKX_OK;
 }
 
+
+// func_point of the grid-based distortions (grid_rendering/interface.py:194-216), one lane per point: the cell is
+// (y // grid_size, x // grid_size) of the ROUNDED point, its forward homography src quad -> dst quad is solved like
+// get_trans_mat (grid_rendering/type.py:166-180), and the SMOOTH point goes through it in double.  The three
+// accumulations follow the reference's np.matmul(trans_mat, (x, y, 1.0)) as OpenBLAS' dgemv evaluates a length-3 row:
+// fma(h2, 1.0, fma(h0, x, h1 * y)).
+__global__ void __launch_bounds__(64) k_project_points(const int32_t *__restrict__ src_v, const int32_t *__restrict__ dst_v,
+                                                       int rows, int cols, int grid_size, const int32_t *__restrict__ pts_i,
+                                                       const double *__restrict__ pts_s, int n, double *__restrict__ out,
+                                                       int *__restrict__ bad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int px = pts_i[2 * i], py = pts_i[2 * i + 1];
+    // python floor division
+    int r = py / grid_size, c = px / grid_size;
+    if (py % grid_size != 0 && (py < 0) != (grid_size < 0)) r--;
+    if (px % grid_size != 0 && (px < 0) != (grid_size < 0)) c--;
+    if (r < 0 || c < 0 || r >= rows - 1 || c >= cols - 1) {      // the reference indexes out of its cell table here
+        atomicExch(bad, i + 1);
+        out[2 * i] = 0.0; out[2 * i + 1] = 0.0;
+        return;
+    }
+    const int idx[4] = {r * cols + c, r * cols + c + 1, (r + 1) * cols + c + 1, (r + 1) * cols + c};
+    float from[8], to[8];
+    double qf[8], qt[8], H[9];
+    for (int k = 0; k < 4; k++) {
+        from[2 * k] = (float)src_v[2 * idx[k]]; from[2 * k + 1] = (float)src_v[2 * idx[k] + 1];
+        to[2 * k] = (float)dst_v[2 * idx[k]]; to[2 * k + 1] = (float)dst_v[2 * idx[k] + 1];
+        qf[2 * k] = from[2 * k]; qf[2 * k + 1] = from[2 * k + 1];
+        qt[2 * k] = to[2 * k]; qt[2 * k + 1] = to[2 * k + 1];
+    }
+    if (!vkc::homography_direct(qf, qt, H)) vkc::homography_jacobi(from, to, H);
+    const double sx = pts_s[2 * i], sy = pts_s[2 * i + 1];
+    const double tx = fma(H[2], 1.0, fma(H[0], sx, H[1] * sy));
+    const double ty = fma(H[5], 1.0, fma(H[3], sx, H[4] * sy));
+    const double t = fma(H[8], 1.0, fma(H[6], sx, H[7] * sy));
+    out[2 * i] = tx / t;
+    out[2 * i + 1] = ty / t;
+}
+
 } // namespace
+
+VKX_EXPORT int vkx_grid_project_points(vkx_ctx *ctx, const int32_t *src_vertices_host, const int32_t *dst_vertices_host,
+                                       int rows, int cols, int grid_size, const int32_t *pts_xy_host,
+                                       const double *pts_smooth_xy_host, int n, double *out_xy_host)
+{
+    VKX_REQUIRE(ctx && src_vertices_host && dst_vertices_host, "NULL argument");
+    VKX_REQUIRE(rows >= 2 && cols >= 2 && grid_size > 0 && n >= 0, "bad lattice");
+    if (n == 0) return VKX_OK;
+    VKX_REQUIRE(pts_xy_host && pts_smooth_xy_host && out_xy_host, "NULL argument");
+    const size_t vbytes = sizeof(int32_t) * 2 * (size_t)rows * cols;
+    const size_t ibytes = sizeof(int32_t) * 2 * (size_t)n, dbytes = sizeof(double) * 2 * (size_t)n;
+    const size_t off_dv = (vbytes + 255) & ~(size_t)255, off_pi = off_dv * 2, off_ps = off_pi + ((ibytes + 255) & ~(size_t)255);
+    const size_t off_out = off_ps + ((dbytes + 255) & ~(size_t)255), off_bad = off_out + ((dbytes + 255) & ~(size_t)255);
+    int rc = vkx_scratch_reserve(ctx, &ctx->stage[0], off_bad + 256);
+    if (rc) return rc;
+    uint8_t *base = (uint8_t *)ctx->stage[0].ptr;
+    VKX_HIP(hipMemcpyAsync(base, src_vertices_host, vbytes, hipMemcpyHostToDevice, ctx->stream));
+    VKX_HIP(hipMemcpyAsync(base + off_dv, dst_vertices_host, vbytes, hipMemcpyHostToDevice, ctx->stream));
+    VKX_HIP(hipMemcpyAsync(base + off_pi, pts_xy_host, ibytes, hipMemcpyHostToDevice, ctx->stream));
+    VKX_HIP(hipMemcpyAsync(base + off_ps, pts_smooth_xy_host, dbytes, hipMemcpyHostToDevice, ctx->stream));
+    VKX_HIP(hipMemsetAsync(base + off_bad, 0, sizeof(int), ctx->stream));
+    { VKX_TIMED(ctx, "k_project_points"); k_project_points<<<vkx_blocks((size_t)n, 64), 64, 0, ctx->stream>>>((const int32_t *)base, (const int32_t *)(base + off_dv), rows, cols, grid_size, (const int32_t *)(base + off_pi), (const double *)(base + off_ps), n, (double *)(base + off_out), (int *)(base + off_bad)); }
+    VKX_LAUNCH_CHECK();
+    int bad = 0;
+    VKX_HIP(hipMemcpyAsync(out_xy_host, base + off_out, dbytes, hipMemcpyDeviceToHost, ctx->stream));
+    VKX_HIP(hipMemcpyAsync(&bad, base + off_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    VKX_HIP(hipStreamSynchronize(ctx->stream));
+    if (bad) {
+        vkx_set_error("point %d lies outside the lattice cells", bad - 1);
+        return VKX_ERR_INVALID;
+    }
+    return VKX_OK;
+}
 
 VKX_EXPORT int vkx_grid_to_map_dev(vkx_ctx *ctx, const int32_t *src_vertices, const int32_t *dst_vertices, int rows,
                                    int cols, int dh, int dw, float *map_x, float *map_y, ptrdiff_t map_stride_el,

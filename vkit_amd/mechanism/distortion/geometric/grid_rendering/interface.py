@@ -2,15 +2,15 @@
 
 ``DistortionStateImageGridBased`` owns a source / destination ``ImageGrid`` pair; ``FuncImageGridBased`` blends
 Image / Mask / ScoreMap through ONE device-side grid (cell homographies + exact cv.fillPoly ownership + bilinear
-gather, csrc/grid.hip) and projects points on the host with the per-cell homography of the containing source
-cell."""
+gather, csrc/grid.hip).  Point and polygon LISTS go through the lattice in one device launch
+(``vkx_grid_project_points``); a single ``func_point`` call solves its cell on the host."""
 from typing import Generic, Optional, Tuple, Type, TypeVar
 
 import numpy as np
 from numpy.random import Generator as RandomGenerator
 
 from vkit_amd import _native
-from vkit_amd.element import Image, Mask, Point, ScoreMap
+from vkit_amd.element import Image, Mask, Point, PointTuple, Polygon, ScoreMap
 from ...interface import Distortion, DistortionConfig, DistortionState
 from .grid_creator import create_dst_image_grid_and_shift_amounts_and_resize_ratios
 from .image_grid import ImageGrid
@@ -95,6 +95,37 @@ class FuncImageGridBased(Generic[_T_CONFIG, _T_STATE]):
         return Point.create(y=float(ty / t), x=float(tx / t))
 
 
+    @classmethod
+    def _project(cls, state, points):
+        """All points of one call through the lattice in ONE device launch (the reference loops point by point,
+        distortion/interface.py:638-661)."""
+        src_grid, dst_grid = state.src_image_grid, state.dst_image_grid
+        assert src_grid.grid_size
+        points = list(points)
+        if not points:
+            return []
+        out = _native.project_points(src_grid.vertices, dst_grid.vertices, src_grid.grid_size,
+                                     [(p.x, p.y) for p in points], [(p.smooth_x, p.smooth_y) for p in points])
+        return [Point.create(y=float(y), x=float(x)) for x, y in out]
+
+    @classmethod
+    def func_points(cls, config, state, shape: Tuple[int, int], points, rng: Optional[RandomGenerator]):
+        assert state
+        return PointTuple(cls._project(state, points))
+
+    @classmethod
+    def func_polygons(cls, config, state, shape: Tuple[int, int], polygons, rng: Optional[RandomGenerator]):
+        assert state
+        polygons = list(polygons)
+        flat = cls._project(state, [p for polygon in polygons for p in polygon.points])
+        out, k = [], 0
+        for polygon in polygons:
+            n = len(polygon.points)
+            out.append(Polygon.create(points=flat[k:k + n]))
+            k += n
+        return out
+
+
 class DistortionImageGridBased(Distortion[_T_CONFIG, _T_STATE]):
 
     def __init__(self, config_cls: Type[_T_CONFIG], state_cls: Type[_T_STATE]):
@@ -107,6 +138,8 @@ class DistortionImageGridBased(Distortion[_T_CONFIG, _T_STATE]):
             func_score_map=funcs.func_score_map,
             func_active_mask=funcs.func_active_mask,
             func_point=funcs.func_point,
+            func_points=funcs.func_points,
+            func_polygons=funcs.func_polygons,
         )
 
     def distort(self, config_or_config_generator, shapable_or_shape=None, image=None, mask=None, score_map=None,
