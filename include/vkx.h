@@ -307,10 +307,25 @@ int vkx_resize_cubic_f32(vkx_ctx *ctx, const float *src, int sh, int sw, ptrdiff
 #define VKX_INTER_NEAREST 0
 #define VKX_INTER_LINEAR 1
 #define VKX_INTER_CUBIC 2
+/* ... and the interpolations PageResizingStep samples for the page Image, Masks and ScoreMaps
+ * (pipeline/text_detection/page_resizing.py:110-181, sample_cv_resize_interpolation utility/opt.py:125-148):
+ * LANCZOS4 (8 x 8 taps, 11-bit coefficients / float32), LINEAR_EXACT (8.8 fixed point on uint8; float32 has no
+ * bit-exact path in cv.resize and falls back to LINEAR), NEAREST_EXACT (16.16 index steps), AREA (shrinking only: box
+ * sums for integer factors, fractional cell weights in float32 otherwise). */
+#define VKX_INTER_AREA 3
+#define VKX_INTER_LANCZOS4 4
+#define VKX_INTER_LINEAR_EXACT 5
+#define VKX_INTER_NEAREST_EXACT 6
 int vkx_resize_u8_dev(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t src_stride,
                       uint8_t *dst, int dh, int dw, ptrdiff_t dst_stride, int interpolation);
 int vkx_resize_u8(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t src_stride,
                   uint8_t *dst, int dh, int dw, ptrdiff_t dst_stride, int interpolation);
+
+/* the same on a float32 plane (ScoreMap.to_resized_score_map element/score_map.py:616-640); strides in elements */
+int vkx_resize_f32_dev(vkx_ctx *ctx, const float *src, int sh, int sw, ptrdiff_t src_stride_el, float *dst, int dh, int dw,
+                       ptrdiff_t dst_stride_el, int interpolation);
+int vkx_resize_f32(vkx_ctx *ctx, const float *src, int sh, int sw, ptrdiff_t src_stride_el, float *dst, int dh, int dw,
+                   ptrdiff_t dst_stride_el, int interpolation);
 
 /* zoom_in_blur  photometric/blur.py:264-316: the image plus the centred crops of its INTER_CUBIC enlargements to the
  * sizes of sizes_hw_host (HOST int32 [n, 2] as (height, width), every size >= the image) are summed in uint16, then

@@ -514,6 +514,48 @@ def resize_cubic(src, dsize_hw):
     return dst
 
 
+INTER_NEAREST, INTER_LINEAR, INTER_CUBIC, INTER_AREA, INTER_LANCZOS4, INTER_LINEAR_EXACT, INTER_NEAREST_EXACT = range(7)
+
+
+def resize(src, dsize_hw, interpolation):
+    """cv.resize(src, (dw, dh), interpolation=<cv2 code>) for uint8 HxW[xC] or float32 HxW: the interpolations
+    PageResizingStep samples (utility/opt.py:125-148) plus the plain NEAREST / LINEAR."""
+    dh, dw = int(dsize_hw[0]), int(dsize_hw[1])
+    src = np.ascontiguousarray(src)
+    L = lib()
+    if interpolation == INTER_CUBIC:
+        return resize_cubic(src, dsize_hw)
+    if src.dtype == np.float32:
+        assert src.ndim == 2
+        sh, sw = src.shape
+        dst = np.empty((dh, dw), np.float32)
+        if interpolation in (INTER_NEAREST, INTER_NEAREST_EXACT):
+            fn = L.vko_resize_nearest_u8 if interpolation == INTER_NEAREST else L.vko_resize_nearest_exact_u8
+            rc = fn(_p(src), sh, sw, 4, _ss(sw * 4), _p(dst), dh, dw, _ss(dw * 4))
+        elif interpolation in (INTER_LINEAR, INTER_LINEAR_EXACT):     # no bit-exact float32 path: falls back to LINEAR
+            rc = L.vko_resize_linear_f32(_p(src), sh, sw, _ss(sw), _p(dst), dh, dw, _ss(dw))
+        elif interpolation == INTER_LANCZOS4:
+            rc = L.vko_resize_lanczos4_f32(_p(src), sh, sw, _ss(sw), _p(dst), dh, dw, _ss(dw))
+        elif interpolation == INTER_AREA:
+            rc = L.vko_resize_area(_p(src), sh, sw, 1, _ss(sw), _p(dst), dh, dw, _ss(dw), 1)
+        else:
+            raise ValueError(interpolation)
+        assert rc == 0, rc
+        return dst
+    assert src.dtype == np.uint8
+    if interpolation == INTER_AREA:
+        s3, squeeze = _as3(src)
+        sh, sw, cn = s3.shape
+        dst = np.empty((dh, dw, cn), np.uint8)
+        rc = L.vko_resize_area(_p(s3), sh, sw, cn, _ss(sw * cn), _p(dst), dh, dw, _ss(dw * cn), 0)
+        assert rc == 0, rc
+        return dst[:, :, 0] if squeeze else dst
+    fn = {INTER_NEAREST: L.vko_resize_nearest_u8, INTER_LINEAR: L.vko_resize_linear_u8,
+          INTER_LANCZOS4: L.vko_resize_lanczos4_u8, INTER_LINEAR_EXACT: L.vko_resize_linear_exact_u8,
+          INTER_NEAREST_EXACT: L.vko_resize_nearest_exact_u8}[interpolation]
+    return _resize_u8(fn, src, dsize_hw)
+
+
 def line_streak(img, thickness=1, gap=4, dash_thickness=0, dash_gap=0, color=(0, 0, 0), alpha=1.0,
                 enable_vert=True, enable_hori=True):
     out = np.array(img, dtype=np.uint8, order='C')

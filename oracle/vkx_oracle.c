@@ -1455,6 +1455,390 @@ VKO_API int vko_resize_nearest_u8(const uint8_t *src, int sh, int sw, int cn, pt
 }
 
 /* ------------------------------------------------------------------------------------
+ * [cv2] the other interpolations PageResizingStep samples (pipeline/text_detection/page_resizing.py:110-181 through
+ * utility/opt.py:125-148: INTER_NEAREST_EXACT, INTER_LINEAR_EXACT, INTER_CUBIC, INTER_LANCZOS4, and INTER_AREA when
+ * shrinking), applied to the page Image (uint8 x 3), its Masks (uint8) and ScoreMaps (float32).  imgproc/resize.cpp.
+ *
+ * LANCZOS4: the generic path of INTER_CUBIC with 8 taps s-3 .. s+4 and interpolateLanczos4's coefficients
+ *   (sin / cos of -(x + 3 - i) pi / 4 by angle addition from one sin / cos pair, divided by y^2, normalised in float32;
+ *   x < FLT_EPSILON -> the unit tap 3); uint8 through 11-bit coefficients, int32 sums and (sum + 2^21) >> 22;
+ *   float32 sums left to right.
+ * NEAREST_EXACT: resizeNN_bitexact -- 16.16 steps ifx = ((ssize << 16) + dsize / 2) / dsize, start ifx / 2 - ssize % 2,
+ *   index min((ifx * d + ifx0) >> 16, ssize - 1).
+ * LINEAR_EXACT on uint8: resize_bitExact<uchar, interpolationLinear> -- coordinates in double ("softdouble"),
+ *   8.8 fixed-point weights (cvRound(frac * 256), 256 - that), destination pixels left / right of the first / last
+ *   source sample copy it, horizontal pass ufixedpoint16, vertical pass 16.16 with (sum + 2^15) >> 16, rows outside
+ *   round one horizontal row with (v + 128) >> 8; an exact 2 x 2 shrink is the INTER_AREA box.  On float32 the
+ *   bit-exact table has no entry and cv.resize falls back to INTER_LINEAR: float32 weights (1 - f, f), s < 0 ->
+ *   (0, f = 0), s >= size - 1 -> (size - 1, f = 0) on both axes, S0 * a0 + S1 * a1 per pass.
+ * AREA (shrinking): integer scale factors -> ResizeAreaFast: box sum (int32 / float32) times 1.f / area, cvRound for
+ *   uint8; the 2 x 2 box follows its vector body: (sum + 2) >> 2 on uint8, ((a + b) + (c + d)) * 0.25f on float32 (the
+ *   scalar tail of a cv2 build rounds the last few columns differently); otherwise ResizeArea with computeResizeAreaTab's fractional cell weights,
+ *   float32 accumulation in table order.
+ * ---------------------------------------------------------------------------------- */
+#define VKO_PI 3.1415926535897932384626433832795   /* CV_PI */
+static void vko_lanczos4_coeffs(float x, float c[8])
+{
+    static const double s45 = 0.70710678118654752440084436210485;
+    static const double cs[8][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+    if (x < FLT_EPSILON) {
+        for (int i = 0; i < 8; i++) c[i] = 0;
+        c[3] = 1;
+        return;
+    }
+    float sum = 0;
+    double y0 = -(x + 3) * VKO_PI * 0.25, s0 = sin(y0), c0 = cos(y0);
+    for (int i = 0; i < 8; i++) {
+        double y = -(x + 3 - i) * VKO_PI * 0.25;
+        c[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+        sum += c[i];
+    }
+    sum = 1.f / sum;
+    for (int i = 0; i < 8; i++) c[i] *= sum;
+}
+
+static void vko_lanczos_axis(int ssize, int dsize, int *ofs, float *coef /* [dsize][8] */)
+{
+    double inv_scale = (double)dsize / ssize;
+    double scale = 1. / inv_scale;
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s0 = (int)floorf(f);
+        f -= s0;
+        ofs[d] = s0;
+        vko_lanczos4_coeffs(f, coef + 8 * d);
+    }
+}
+
+VKO_API int vko_resize_lanczos4_u8(const uint8_t *src, int sh, int sw, int cn, ptrdiff_t sstep,
+                                   uint8_t *dst, int dh, int dw, ptrdiff_t dstep)
+{
+    if (sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || cn <= 0) return -1;
+    int *xofs = (int *)malloc(sizeof(int) * dw), *yofs = (int *)malloc(sizeof(int) * dh);
+    float *xc = (float *)malloc(sizeof(float) * 8 * dw), *yc = (float *)malloc(sizeof(float) * 8 * dh);
+    short *xa = (short *)malloc(sizeof(short) * 8 * dw), *yb = (short *)malloc(sizeof(short) * 8 * dh);
+    int32_t *rows = (int32_t *)malloc(sizeof(int32_t) * 8 * (size_t)dw * cn);
+    if (!xofs || !yofs || !xc || !yc || !xa || !yb || !rows) return -2;
+    vko_lanczos_axis(sw, dw, xofs, xc);
+    vko_lanczos_axis(sh, dh, yofs, yc);
+    for (int i = 0; i < 8 * dw; i++) xa[i] = (short)sat_short(cv_round_f(xc[i] * 2048.f));
+    for (int i = 0; i < 8 * dh; i++) yb[i] = (short)sat_short(cv_round_f(yc[i] * 2048.f));
+    for (int dy = 0; dy < dh; dy++) {
+        for (int k = 0; k < 8; k++) {
+            const uint8_t *S = src + (ptrdiff_t)vko_clip_index(yofs[dy] - 3 + k, sh) * sstep;
+            int32_t *D = rows + (size_t)k * dw * cn;
+            for (int dx = 0; dx < dw; dx++)
+                for (int c = 0; c < cn; c++) {
+                    uint32_t v = 0;
+                    for (int j = 0; j < 8; j++) {
+                        int sx = vko_clip_index(xofs[dx] - 3 + j, sw);
+                        v += (uint32_t)((int32_t)S[sx * cn + c] * (int32_t)xa[8 * dx + j]);
+                    }
+                    D[dx * cn + c] = (int32_t)v;
+                }
+        }
+        uint8_t *out = dst + (ptrdiff_t)dy * dstep;
+        for (int x = 0; x < dw * cn; x++) {
+            uint32_t v = 0;
+            for (int k = 0; k < 8; k++)
+                v += (uint32_t)rows[(size_t)k * dw * cn + x] * (uint32_t)(int32_t)yb[8 * dy + k];
+            int32_t r = ((int32_t)(v + (1u << 21))) >> 22;
+            out[x] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+        }
+    }
+    free(xofs); free(yofs); free(xc); free(yc); free(xa); free(yb); free(rows);
+    return 0;
+}
+
+VKO_API int vko_resize_lanczos4_f32(const float *src, int sh, int sw, ptrdiff_t sstep_el, float *dst, int dh,
+                                    int dw, ptrdiff_t dstep_el)
+{
+    if (sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0) return -1;
+    int *xofs = (int *)malloc(sizeof(int) * dw), *yofs = (int *)malloc(sizeof(int) * dh);
+    float *xc = (float *)malloc(sizeof(float) * 8 * dw), *yc = (float *)malloc(sizeof(float) * 8 * dh);
+    float *rows = (float *)malloc(sizeof(float) * 8 * (size_t)dw);
+    if (!xofs || !yofs || !xc || !yc || !rows) return -2;
+    vko_lanczos_axis(sw, dw, xofs, xc);
+    vko_lanczos_axis(sh, dh, yofs, yc);
+    for (int dy = 0; dy < dh; dy++) {
+        for (int k = 0; k < 8; k++) {
+            const float *S = src + (ptrdiff_t)vko_clip_index(yofs[dy] - 3 + k, sh) * sstep_el;
+            for (int dx = 0; dx < dw; dx++) {
+                const float *a = xc + 8 * dx;
+                float v = S[vko_clip_index(xofs[dx] - 3, sw)] * a[0];
+                for (int j = 1; j < 8; j++) {
+                    float t = S[vko_clip_index(xofs[dx] - 3 + j, sw)] * a[j];
+                    v = v + t;
+                }
+                rows[(size_t)k * dw + dx] = v;
+            }
+        }
+        const float *b = yc + 8 * dy;
+        for (int x = 0; x < dw; x++) {
+            float v = rows[x] * b[0];
+            for (int k = 1; k < 8; k++) {
+                float t = rows[(size_t)k * dw + x] * b[k];
+                v = v + t;
+            }
+            dst[(ptrdiff_t)dy * dstep_el + x] = v;
+        }
+    }
+    free(xofs); free(yofs); free(xc); free(yc); free(rows);
+    return 0;
+}
+
+/* element size in bytes: 1 / 3 / 4 (a float32 plane is 4-byte elements) */
+VKO_API int vko_resize_nearest_exact_u8(const uint8_t *src, int sh, int sw, int cn, ptrdiff_t sstep, uint8_t *dst,
+                                        int dh, int dw, ptrdiff_t dstep)
+{
+    if (sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || cn <= 0) return -1;
+    int ifx = (int)((((int64_t)sw << 16) + dw / 2) / dw), ifx0 = ifx / 2 - sw % 2;
+    int ify = (int)((((int64_t)sh << 16) + dh / 2) / dh), ify0 = ify / 2 - sh % 2;
+    for (int y = 0; y < dh; y++) {
+        int sy = (int)(((int64_t)ify * y + ify0) >> 16);
+        if (sy > sh - 1) sy = sh - 1;
+        for (int x = 0; x < dw; x++) {
+            int sx = (int)(((int64_t)ifx * x + ifx0) >> 16);
+            if (sx > sw - 1) sx = sw - 1;
+            for (int c = 0; c < cn; c++) dst[(ptrdiff_t)y * dstep + x * cn + c] = src[(ptrdiff_t)sy * sstep + sx * cn + c];
+        }
+    }
+    return 0;
+}
+
+/* interpolationLinear: offsets, 8.8 weight of the right / lower sample, and the [min, max) range of destination
+ * indices that interpolate */
+static void vko_linear_exact_axis(int ssize, int dsize, int *ofs, int *w1, int *dmin, int *dmax)
+{
+    double inv_scale = (double)dsize / ssize, scale = 1.0 / inv_scale;
+    int mn = 0, mx = dsize;
+    for (int d = 0; d < dsize; d++) {
+        double fval = scale * ((double)d + 0.5) - 0.5;
+        int ival = (int)floor(fval);
+        w1[d] = 0;
+        if (ival >= 0 && ssize > 1) {
+            if (ival < ssize - 1) {
+                w1[d] = (int)nearbyint((fval - (double)ival) * 256.0);
+            } else {
+                ival = ssize - 1;
+                if (d < mx) mx = d;
+            }
+        } else {
+            if (d + 1 > mn) mn = d + 1;
+            ival = 0;
+        }
+        ofs[d] = ival;
+    }
+    if (mx < mn) mx = mn;
+    *dmin = mn; *dmax = mx;
+}
+
+VKO_API int vko_resize_linear_exact_u8(const uint8_t *src, int sh, int sw, int cn, ptrdiff_t sstep, uint8_t *dst,
+                                       int dh, int dw, ptrdiff_t dstep)
+{
+    if (sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || cn <= 0) return -1;
+    if (sw == 2 * dw && sh == 2 * dh && cn != 2)
+        return vko_resize_linear_u8(src, sh, sw, cn, sstep, dst, dh, dw, dstep);   /* the INTER_AREA 2 x 2 box */
+    int *xofs = (int *)malloc(sizeof(int) * dw), *yofs = (int *)malloc(sizeof(int) * dh);
+    int *xw = (int *)malloc(sizeof(int) * dw), *yw = (int *)malloc(sizeof(int) * dh);
+    uint32_t *h0 = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)dw * cn), *h1 = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)dw * cn);
+    if (!xofs || !yofs || !xw || !yw || !h0 || !h1) return -2;
+    int xmin, xmax, ymin, ymax;
+    vko_linear_exact_axis(sw, dw, xofs, xw, &xmin, &xmax);
+    vko_linear_exact_axis(sh, dh, yofs, yw, &ymin, &ymax);
+    const int xlast = xofs[dw - 1], ylast = yofs[dh - 1];
+    for (int dy = 0; dy < dh; dy++) {
+        int r0, r1, two = 0;
+        if (dy < ymin) r0 = r1 = 0;
+        else if (dy >= ymax) r0 = r1 = ylast;
+        else { r0 = yofs[dy]; r1 = r0 + 1; two = 1; }
+        for (int pass = 0; pass < 1 + two; pass++) {
+            const uint8_t *S = src + (ptrdiff_t)(pass ? r1 : r0) * sstep;
+            uint32_t *H = pass ? h1 : h0;
+            for (int dx = 0; dx < dw; dx++)
+                for (int c = 0; c < cn; c++) {
+                    uint32_t v;
+                    if (dx < xmin) v = (uint32_t)S[c] << 8;
+                    else if (dx >= xmax) v = (uint32_t)S[xlast * cn + c] << 8;
+                    else v = (uint32_t)(256 - xw[dx]) * S[xofs[dx] * cn + c] + (uint32_t)xw[dx] * S[(xofs[dx] + 1) * cn + c];
+                    H[dx * cn + c] = v;     /* ufixedpoint16: never above 255 << 8 */
+                }
+        }
+        uint8_t *out = dst + (ptrdiff_t)dy * dstep;
+        for (int x = 0; x < dw * cn; x++) {
+            uint32_t r;
+            if (!two) r = (h0[x] + 128u) >> 8;
+            else r = (h0[x] * (uint32_t)(256 - yw[dy]) + h1[x] * (uint32_t)yw[dy] + (1u << 15)) >> 16;
+            out[x] = (uint8_t)(r > 255 ? 255 : r);
+        }
+    }
+    free(xofs); free(yofs); free(xw); free(yw); free(h0); free(h1);
+    return 0;
+}
+
+VKO_API int vko_resize_linear_f32(const float *src, int sh, int sw, ptrdiff_t sstep_el, float *dst, int dh, int dw,
+                                  ptrdiff_t dstep_el)
+{
+    if (sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0) return -1;
+    if (sw == 2 * dw && sh == 2 * dh) {   /* is_area_fast with iscale 2: ResizeAreaFast on float32 */
+        for (int y = 0; y < dh; y++)
+            for (int x = 0; x < dw; x++) {
+                const float *p = src + (ptrdiff_t)(2 * y) * sstep_el + 2 * x;
+                float top = p[0] + p[1], bottom = p[sstep_el] + p[sstep_el + 1];   /* ResizeAreaFastVec_SIMD_32f's pairing */
+                float sum = top + bottom;
+                dst[(ptrdiff_t)y * dstep_el + x] = sum * 0.25f;
+            }
+        return 0;
+    }
+    const double sx_ = 1. / ((double)dw / sw), sy_ = 1. / ((double)dh / sh);
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * sy_ - 0.5);
+        int y0 = (int)floorf(fy);
+        fy -= y0;
+        if (y0 < 0) { y0 = 0; fy = 0; }
+        if (y0 >= sh - 1) { y0 = sh - 1; fy = 0; }
+        const float *S0 = src + (ptrdiff_t)y0 * sstep_el, *S1 = src + (ptrdiff_t)vko_clip_index(y0 + 1, sh) * sstep_el;
+        const float b0 = 1.f - fy, b1 = fy;
+        for (int dx = 0; dx < dw; dx++) {
+            float fx = (float)((dx + 0.5) * sx_ - 0.5);
+            int x0 = (int)floorf(fx);
+            fx -= x0;
+            if (x0 < 0) { x0 = 0; fx = 0; }
+            if (x0 >= sw - 1) { x0 = sw - 1; fx = 0; }
+            const int x1 = vko_clip_index(x0 + 1, sw);
+            const float a0 = 1.f - fx, a1 = fx;
+            float p0 = S0[x0] * a0, p1 = S0[x1] * a1, q0 = S1[x0] * a0, q1 = S1[x1] * a1;
+            float h0 = p0 + p1, h1 = q0 + q1;
+            float t0 = h0 * b0, t1 = h1 * b1;
+            dst[(ptrdiff_t)dy * dstep_el + dx] = t0 + t1;
+        }
+    }
+    return 0;
+}
+
+/* computeResizeAreaTab: (destination index, source index, weight) triples of one axis, in order */
+typedef struct { int di, si; float alpha; } vko_dec_alpha;
+
+static int vko_area_tab(int ssize, int dsize, double scale, vko_dec_alpha *tab)
+{
+    int k = 0;
+    for (int dx = 0; dx < dsize; dx++) {
+        double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        double cell = scale < ssize - fsx1 ? scale : ssize - fsx1;
+        int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+        if (sx2 > ssize - 1) sx2 = ssize - 1;
+        if (sx1 > sx2) sx1 = sx2;
+        if (sx1 - fsx1 > 1e-3) {
+            tab[k].di = dx; tab[k].si = sx1 - 1;
+            tab[k++].alpha = (float)((sx1 - fsx1) / cell);
+        }
+        for (int sx = sx1; sx < sx2; sx++) {
+            tab[k].di = dx; tab[k].si = sx;
+            tab[k++].alpha = (float)(1.0 / cell);
+        }
+        if (fsx2 - sx2 > 1e-3) {
+            double w = fsx2 - sx2;
+            if (w > 1.) w = 1.;
+            if (w > cell) w = cell;
+            tab[k].di = dx; tab[k].si = sx2;
+            tab[k++].alpha = (float)(w / cell);
+        }
+    }
+    return k;
+}
+
+/* INTER_AREA for a shrink on both axes (dw <= sw, dh <= sh); is_f32 selects float32 planes (cn = 1) */
+VKO_API int vko_resize_area(const void *src_, int sh, int sw, int cn, ptrdiff_t sstep_el, void *dst_, int dh, int dw,
+                            ptrdiff_t dstep_el, int is_f32)
+{
+    if (sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || cn <= 0 || dw > sw || dh > sh) return -1;
+    const uint8_t *s8 = (const uint8_t *)src_;
+    const float *sf = (const float *)src_;
+    uint8_t *d8 = (uint8_t *)dst_;
+    float *df = (float *)dst_;
+    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    const int iscale_x = (int)(scale_x > 2147483647. ? 2147483647. : nearbyint(scale_x));
+    const int iscale_y = (int)(scale_y > 2147483647. ? 2147483647. : nearbyint(scale_y));
+    const int fast = fabs(scale_x - iscale_x) < DBL_EPSILON && fabs(scale_y - iscale_y) < DBL_EPSILON;
+    if (fast) {
+        const int area = iscale_x * iscale_y;
+        const float scale = 1.f / area;
+        for (int y = 0; y < dh; y++)
+            for (int x = 0; x < dw; x++)
+                for (int c = 0; c < cn; c++) {
+                    if (is_f32 && iscale_x == 2 && iscale_y == 2) {
+                        /* the vector body of the 2 x 2 case pairs the rows: (a + b) + (c + d) */
+                        const float *S = sf + (ptrdiff_t)(y * 2) * sstep_el + (ptrdiff_t)(x * 2) * cn + c;
+                        float top = S[0] + S[cn], bottom = S[sstep_el] + S[sstep_el + cn];
+                        float sum = top + bottom;
+                        df[(ptrdiff_t)y * dstep_el + x * cn + c] = sum * 0.25f;
+                    } else if (is_f32) {
+                        float sum = 0;
+                        int k = 0;
+                        const float *S = sf + (ptrdiff_t)(y * iscale_y) * sstep_el + (ptrdiff_t)(x * iscale_x) * cn + c;
+                        /* ofs[k] runs row-major over the box; summed in groups of four, then one by one */
+                        for (; k <= area - 4; k += 4) {
+                            float a0 = S[(k / iscale_x) * sstep_el + (k % iscale_x) * cn];
+                            float a1 = S[((k + 1) / iscale_x) * sstep_el + ((k + 1) % iscale_x) * cn];
+                            float a2 = S[((k + 2) / iscale_x) * sstep_el + ((k + 2) % iscale_x) * cn];
+                            float a3 = S[((k + 3) / iscale_x) * sstep_el + ((k + 3) % iscale_x) * cn];
+                            float g = a0 + a1;
+                            g = g + a2;
+                            g = g + a3;
+                            sum = sum + g;
+                        }
+                        for (; k < area; k++) sum = sum + S[(k / iscale_x) * sstep_el + (k % iscale_x) * cn];
+                        df[(ptrdiff_t)y * dstep_el + x * cn + c] = sum * scale;
+                    } else {
+                        int sum = 0;
+                        const uint8_t *S = s8 + (ptrdiff_t)(y * iscale_y) * sstep_el + (ptrdiff_t)(x * iscale_x) * cn + c;
+                        for (int k = 0; k < area; k++) sum += S[(k / iscale_x) * sstep_el + (k % iscale_x) * cn];
+                        int r = (iscale_x == 2 && iscale_y == 2) ? (sum + 2) >> 2 : cv_round_f((float)sum * scale);
+                        d8[(ptrdiff_t)y * dstep_el + x * cn + c] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+                    }
+                }
+        return 0;
+    }
+    vko_dec_alpha *xtab = (vko_dec_alpha *)malloc(sizeof(vko_dec_alpha) * ((size_t)sw + 2 * (size_t)dw + 2));
+    vko_dec_alpha *ytab = (vko_dec_alpha *)malloc(sizeof(vko_dec_alpha) * ((size_t)sh + 2 * (size_t)dh + 2));
+    float *buf = (float *)malloc(sizeof(float) * (size_t)dw * cn), *sum = (float *)malloc(sizeof(float) * (size_t)dw * cn);
+    if (!xtab || !ytab || !buf || !sum) return -2;
+    const int xn = vko_area_tab(sw, dw, scale_x, xtab), yn = vko_area_tab(sh, dh, scale_y, ytab);
+    int prev_dy = ytab[0].di;
+    for (int i = 0; i < dw * cn; i++) sum[i] = 0;
+    for (int j = 0; j < yn; j++) {
+        const float beta = ytab[j].alpha;
+        const int dy = ytab[j].di, sy = ytab[j].si;
+        for (int i = 0; i < dw * cn; i++) buf[i] = 0;
+        for (int k = 0; k < xn; k++) {
+            const float alpha = xtab[k].alpha;
+            for (int c = 0; c < cn; c++) {
+                float v = is_f32 ? sf[(ptrdiff_t)sy * sstep_el + xtab[k].si * cn + c]
+                                 : (float)s8[(ptrdiff_t)sy * sstep_el + xtab[k].si * cn + c];
+                float t = v * alpha;
+                buf[xtab[k].di * cn + c] = buf[xtab[k].di * cn + c] + t;
+            }
+        }
+        if (dy != prev_dy) {
+            for (int i = 0; i < dw * cn; i++) {
+                if (is_f32) df[(ptrdiff_t)prev_dy * dstep_el + i] = sum[i];
+                else { int r = cv_round_f(sum[i]); d8[(ptrdiff_t)prev_dy * dstep_el + i] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r)); }
+                sum[i] = beta * buf[i];
+            }
+            prev_dy = dy;
+        } else {
+            for (int i = 0; i < dw * cn; i++) { float t = beta * buf[i]; sum[i] = sum[i] + t; }
+        }
+    }
+    for (int i = 0; i < dw * cn; i++) {
+        if (is_f32) df[(ptrdiff_t)prev_dy * dstep_el + i] = sum[i];
+        else { int r = cv_round_f(sum[i]); d8[(ptrdiff_t)prev_dy * dstep_el + i] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r)); }
+    }
+    free(xtab); free(ytab); free(buf); free(sum);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
  * [cv2] cv.Rodrigues(rvec) (double internals) and cv.projectPoints with zero distortion
  * -- geometric/camera.py:96, :189-195.  calib3d/calibration.cpp cvRodrigues2 /
  * cvProjectPoints2Internal.

@@ -25,8 +25,12 @@ sys.path.insert(0, REPO)
 
 for _m in ['cv2', 'iolite', 'shapely', 'shapely.geometry', 'shapely.strtree', 'shapely.validation', 'shapely.ops',
            'pyclipper', 'cattrs', 'cattrs.errors', 'cattrs.gen', 'intervaltree', 'faker', 'freetype', 'barcode',
-           'rectpack', 'vkit_collect_usage_information', 'fireball']:
+           'rectpack', 'vkit_collect_usage_information', 'fireball', 'barcode.writer']:
     sys.modules[_m] = MagicMock(name=_m)
+# the interpolation codes are data the reference passes around (utility/opt.py:125-148): give the stub cv2's integers
+(sys.modules['cv2'].INTER_NEAREST, sys.modules['cv2'].INTER_LINEAR, sys.modules['cv2'].INTER_CUBIC,
+ sys.modules['cv2'].INTER_AREA, sys.modules['cv2'].INTER_LANCZOS4, sys.modules['cv2'].INTER_LINEAR_EXACT,
+ sys.modules['cv2'].INTER_NEAREST_EXACT) = range(7)
 sys.path.insert(0, '/root/reference')
 
 import attrs  # noqa: E402
@@ -441,6 +445,52 @@ def gen_random_distortion_sampling():
 
 
 # --------------------------------------------------------------------------------------------
+def gen_page_resizing():
+    """PageResizingStep.run of the reference on recording stand-ins for the page elements: which size and which
+    interpolation every element is asked to take, for seeded rngs (pipeline/text_detection/page_resizing.py:86-181)."""
+    from vkit.pipeline.text_detection import page_resizing as PR
+    from vkit.utility.opt import sample_cv_resize_interpolation
+    fields = ['page_image', 'page_active_mask', 'page_char_mask', 'page_seal_impression_char_mask',
+              'page_char_height_score_map', 'page_text_line_mask', 'page_text_line_height_score_map']
+
+    class Recorder:
+        def __init__(self, name, shape, log):
+            self.name, self.shape, self.log = name, shape, log
+            self.mat = 1.0
+
+        def _resized(self, **kwargs):
+            self.log.append([self.name, kwargs['resized_height'], kwargs['resized_width'], kwargs['cv_resize_interpolation']])
+            return Recorder(self.name, (kwargs['resized_height'], kwargs['resized_width']), self.log)
+
+        to_resized_image = to_resized_mask = to_resized_score_map = _resized
+
+        def assign_mat(self, mat):
+            self.log.append([self.name + '.scale', float(mat)])
+
+    cases = []
+    rng = default_rng(99)
+    for seed in range(40):
+        shape = (int(rng.integers(200, 1500)), int(rng.integers(200, 1500)))
+        heights = [float(v) for v in rng.uniform(0.2, 60.0, int(rng.integers(3, 40)))]
+        if seed % 5 == 0:
+            heights.append(400.0)          # an outlier the median filter drops
+        cfg = PR.PageResizingStepConfig(resized_text_line_height_min=3.0 + seed % 4, resized_text_line_height_max=10.0 + seed)
+        step = PR.PageResizingStep(cfg)
+        log = []
+        page = MagicMock()
+        for name in fields:
+            setattr(page, name, Recorder(name, shape, log))
+        page.page_text_line_heights = heights
+        step.run(PR.PageResizingStepInput(page_distortion_step_output=page), default_rng(seed))
+        cases.append({'seed': seed, 'shape': list(shape), 'heights': heights,
+                      'config': [cfg.resized_text_line_height_min, cfg.resized_text_line_height_max,
+                                 cfg.text_line_heights_filtering_thr],
+                      'heights_min': step.get_text_line_heights_min(heights), 'calls': log})
+    draws = [[int(sample_cv_resize_interpolation(default_rng(s), bool(a))) for a in (0, 1)] for s in range(64)]
+    with open(os.path.join(HERE, 'page_resizing.json'), 'w') as f:
+        json.dump({'cases': cases, 'interpolation_draws': draws}, f)
+
+
 def _patch_cv2_with_oracle():
     def gpt(a, b, flag=None):
         return O.get_perspective_transform(a, b, O.SOLVER_HYBRID)
@@ -522,5 +572,6 @@ if __name__ == '__main__':
     gen_operator_semantics()
     gen_random_distortion_sampling()
     gen_structure_oracle_patched()
+    gen_page_resizing()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

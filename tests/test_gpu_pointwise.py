@@ -247,3 +247,88 @@ def test_zoom_in_blur(P):
     big = Image(mat=default_rng(23).integers(0, 256, (1024, 1024, 3), dtype=np.uint8))
     out = D.zoom_in_blur.distort({'ratio': 0.04, 'step': 0.01, 'alpha': 0.6}, image=big).image
     np.testing.assert_array_equal(out.mat, O.zoom_in_blur(big.mat, 0.04, 0.01, 0.6))
+
+
+@pytest.mark.gpu
+def test_resize_every_sampled_interpolation_matches_oracle():
+    """cv.resize codes 0..6 (NEAREST, LINEAR, CUBIC, AREA, LANCZOS4, LINEAR_EXACT, NEAREST_EXACT) on uint8 x 1 / 3 / 4
+    channels and float32 planes -- what PageResizingStep applies to the page Image, Masks and ScoreMaps.  uint8 bit-exact;
+    float32 bit-exact too (same operation order, no fused multiply-add on either side)."""
+    from vkit_amd import _native as N
+    import oracle as O
+    rng = np.random.default_rng(2024)
+    shapes = [((37, 53), (20, 31)), ((37, 53), (80, 99)), ((64, 64), (32, 32)), ((60, 90), (20, 30)), ((1, 9), (4, 3)),
+              ((9, 1), (3, 1)), ((50, 70), (50, 70)), ((33, 21), (32, 20)), ((128, 96), (31, 17)), ((5, 7), (11, 29))]
+    for (sh, sw), (dh, dw) in shapes:
+        planes = [rng.integers(0, 256, (sh, sw), dtype=np.uint8), rng.integers(0, 256, (sh, sw, 3), dtype=np.uint8),
+                  rng.integers(0, 256, (sh, sw, 4), dtype=np.uint8), (rng.random((sh, sw)) < 0.5).astype(np.uint8),
+                  rng.random((sh, sw), dtype=np.float32) * 40.0]
+        for inter in range(7):
+            if inter == O.INTER_AREA and (dh > sh or dw > sw):
+                continue        # the reference samples INTER_AREA only when shrinking
+            for src in planes:
+                got = N.resize(src, (dh, dw), inter)
+                want = O.resize(src, (dh, dw), inter)
+                assert got.dtype == want.dtype and got.shape == want.shape
+                assert (got == want).all(), (inter, src.shape, src.dtype, (dh, dw))
+    with pytest.raises(N.VkxError):
+        N.resize(planes[0], (sh * 2, sw * 2), O.INTER_AREA)
+
+
+@pytest.mark.gpu
+def test_resize_large_planes_properties():
+    """Page-sized planes: identity size is a copy, constants stay constant, AREA keeps the mean."""
+    from vkit_amd import _native as N
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (1024, 768, 3), dtype=np.uint8)
+    mask = (rng.random((1024, 768)) < 0.3).astype(np.uint8)
+    score = rng.random((1024, 768), dtype=np.float32)
+    for inter in range(7):
+        assert (N.resize(img, (1024, 768), inter) == img).all()
+        assert (N.resize(score, (1024, 768), inter) == score).all()
+        assert N.resize(mask, (700, 500), inter).shape == (700, 500)
+        const = np.full((300, 200, 3), 77, np.uint8)
+        assert (N.resize(const, (123, 97), inter) == 77).all()
+    small = N.resize(score, (256, 192), 3)
+    assert abs(float(small.mean()) - float(score.mean())) < 1e-4
+
+
+@pytest.mark.gpu
+def test_page_resizing_step_elements_match_oracle():
+    """PageResizingStep.run on real elements: every output equals the oracle's cv.resize restatement applied the way
+    the reference's element methods do (mask x 255 -> resize -> > 0; score map resize then x ratio)."""
+    from types import SimpleNamespace
+    import oracle as O
+    from vkit_amd.element import Image, Mask, ScoreMap
+    from vkit_amd.pipeline.text_detection import PageResizingStep, PageResizingStepConfig, PageResizingStepInput
+    from vkit_amd.utility import sample_cv_resize_interpolation
+    rng = np.random.default_rng(11)
+    h, w = 240, 320
+    used = set()
+    for seed in range(12):
+        page = SimpleNamespace(
+            page_image=Image(mat=rng.integers(0, 256, (h, w, 3), dtype=np.uint8)),
+            page_active_mask=Mask(mat=(rng.random((h, w)) < 0.9).astype(np.uint8)),
+            page_char_mask=Mask(mat=(rng.random((h, w)) < 0.2).astype(np.uint8)),
+            page_seal_impression_char_mask=Mask(mat=(rng.random((h, w)) < 0.05).astype(np.uint8)),
+            page_char_height_score_map=ScoreMap(mat=(rng.random((h, w), dtype=np.float32) * 30).astype(np.float32), is_prob=False),
+            page_text_line_mask=Mask(mat=(rng.random((h, w)) < 0.4).astype(np.uint8)),
+            page_text_line_height_score_map=ScoreMap(mat=(rng.random((h, w), dtype=np.float32) * 30).astype(np.float32), is_prob=False),
+            page_text_line_heights=[float(v) for v in rng.uniform(4.0, 30.0, 12)])
+        step = PageResizingStep(PageResizingStepConfig(resized_text_line_height_min=3.0, resized_text_line_height_max=24.0))
+        out = step.run(PageResizingStepInput(page_distortion_step_output=page), np.random.default_rng(seed))
+        # replay the two draws
+        r = np.random.default_rng(seed)
+        ratio = r.uniform(3.0, 24.0) / step.get_text_line_heights_min(page.page_text_line_heights)
+        size = (round(ratio * h), round(ratio * w))
+        inter = sample_cv_resize_interpolation(r, include_cv_inter_area=(ratio < 1.0))
+        used.add(inter)
+        assert out.page_image.shape == size
+        assert (out.page_image.mat == O.resize(page.page_image.mat, size, inter)).all()
+        for name in ('page_active_mask', 'page_char_mask', 'page_seal_impression_char_mask', 'page_text_line_mask'):
+            want = (O.resize(getattr(page, name).mat * 255, size, inter) > 0).astype(np.uint8)
+            assert (getattr(out, name).mat == want).all(), (name, inter)
+        for name in ('page_char_height_score_map', 'page_text_line_height_score_map'):
+            want = O.resize(getattr(page, name).mat, size, inter) * ratio
+            assert (getattr(out, name).mat == want).all(), (name, inter)
+    assert len(used) >= 4

@@ -325,3 +325,47 @@ def test_element_basics():
     assert Mask.from_shape((3, 3), value=1).to_inverted_mask().mat.sum() == 0
     from vkit_amd.mechanism.distortion.photometric.blur import _estimate_gaussian_kernel_size as ks
     assert [ks(s) for s in (0.5, 0.83, 0.84, 1.0, 2.0)] == [3, 3, 5, 5, 7]
+
+
+def test_page_resizing_step_decisions(golden_dir):
+    """PageResizingStep against the reference's own run on recording stand-ins (tests/golden/make_golden.py
+    gen_page_resizing): text-line height floor, rng order, target size, interpolation, element order, score scaling."""
+    from types import SimpleNamespace
+    from vkit_amd.pipeline.text_detection import PageResizingStep, PageResizingStepConfig, PageResizingStepInput
+    from vkit_amd.utility import sample_cv_resize_interpolation
+    with open(os.path.join(golden_dir, 'page_resizing.json')) as f:
+        G = json.load(f)
+    for s, (plain, with_area) in enumerate(G['interpolation_draws']):
+        assert sample_cv_resize_interpolation(default_rng(s), False) == plain
+        assert sample_cv_resize_interpolation(default_rng(s), True) == with_area
+
+    class Recorder:
+        def __init__(self, name, shape, log):
+            self.name, self.shape, self.log, self.mat = name, shape, log, 1.0
+
+        def _resized(self, **kwargs):
+            self.log.append([self.name, kwargs['resized_height'], kwargs['resized_width'], kwargs['cv_resize_interpolation']])
+            return Recorder(self.name, (kwargs['resized_height'], kwargs['resized_width']), self.log)
+
+        to_resized_image = to_resized_mask = to_resized_score_map = _resized
+
+        def assign_mat(self, mat):
+            self.log.append([self.name + '.scale', float(mat)])
+
+    assert len(G['cases']) == 40
+    seen = set()
+    for case in G['cases']:
+        lo, hi, thr = case['config']
+        step = PageResizingStep(PageResizingStepConfig(resized_text_line_height_min=lo, resized_text_line_height_max=hi,
+                                                       text_line_heights_filtering_thr=thr))
+        assert step.get_text_line_heights_min(case['heights']) == case['heights_min']
+        log = []
+        page = SimpleNamespace(page_text_line_heights=case['heights'])
+        for name in ('page_image', 'page_active_mask', 'page_char_mask', 'page_seal_impression_char_mask',
+                     'page_char_height_score_map', 'page_text_line_mask', 'page_text_line_height_score_map'):
+            setattr(page, name, Recorder(name, tuple(case['shape']), log))
+        out = step.run(PageResizingStepInput(page_distortion_step_output=page), default_rng(case['seed']))
+        assert log == case['calls'], case['seed']
+        assert out.page_image.shape == (case['calls'][0][1], case['calls'][0][2])
+        seen.add(case['calls'][0][3])
+    assert seen == {2, 3, 4, 5, 6}      # every interpolation the step can draw shows up in the fixture

@@ -168,6 +168,7 @@ for _sfx in ('', '_dev'):
     _SIGNATURES['vkx_zoom_in_blur_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_int, c_double, c_void_p, c_ssize]
     _SIGNATURES['vkx_resize_cubic_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_int, c_int, c_ssize]
     _SIGNATURES['vkx_resize_cubic_f32' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_void_p, c_int, c_int, c_ssize]
+    _SIGNATURES['vkx_resize_f32' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_void_p, c_int, c_int, c_ssize, c_int]
     _SIGNATURES['vkx_paint_polys' + _sfx] = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_ssize, c_void_p,
                                              c_ssize, c_int, c_int]
     _SIGNATURES['vkx_fill_poly_mask_u8' + _sfx] = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_ssize]
@@ -694,10 +695,21 @@ def fill_poly_mask(shape, pts, ctx=None):
 INTER_NEAREST, INTER_LINEAR, INTER_CUBIC = 0, 1, 2
 
 
+INTER_NEAREST, INTER_LINEAR, INTER_CUBIC, INTER_AREA, INTER_LANCZOS4, INTER_LINEAR_EXACT, INTER_NEAREST_EXACT = range(7)
+
+
 def resize(src, dsize_hw, interpolation, ctx=None):
-    """cv.resize(src, (dw, dh), interpolation=...) on uint8 arrays for NEAREST / LINEAR / CUBIC."""
+    """cv.resize(src, (dw, dh), interpolation=<cv2 code 0..6>) for uint8 HxW[xC] or float32 HxW arrays."""
     ctx = ctx or default_ctx()
     dh, dw = int(dsize_hw[0]), int(dsize_hw[1])
+    if src.dtype == np.float32:
+        src = np.ascontiguousarray(src)
+        if src.ndim != 2:
+            raise ValueError('float32 planes are HxW')
+        sh, sw = src.shape
+        dst = np.empty((dh, dw), np.float32)
+        check(lib().vkx_resize_f32(ctx.handle, _ptr(src), sh, sw, sw, _ptr(dst), dh, dw, dw, int(interpolation)))
+        return dst
     src, sh, sw, cn, stride = _u8_plane(src)
     dst = np.empty((dh, dw) + src.shape[2:], np.uint8)
     check(lib().vkx_resize_u8(ctx.handle, _ptr(src), sh, sw, cn, stride, _ptr(dst), dh, dw, dw * cn, int(interpolation)))

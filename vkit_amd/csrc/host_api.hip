@@ -358,6 +358,19 @@ VKX_EXPORT int vkx_resize_cubic_f32(vkx_ctx *ctx, const float *src, int sh, int 
     return st.finish();
 }
 
+VKX_EXPORT int vkx_resize_f32(vkx_ctx *ctx, const float *src, int sh, int sw, ptrdiff_t src_stride_el, float *dst, int dh, int dw,
+                              ptrdiff_t dst_stride_el, int interpolation)
+{
+    VKX_REQUIRE(ctx && src && dst, "NULL argument");
+    VKX_REQUIRE(sh > 0 && sw > 0 && dh > 0 && dw > 0, "bad shape");
+    HostStage st(ctx);
+    const int s = st.add(src, nullptr, (size_t)sw * 4, sh, src_stride_el * 4);
+    const int d = st.add(nullptr, dst, (size_t)dw * 4, dh, dst_stride_el * 4);
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_resize_f32_dev(ctx, st.dev<float>(s), sh, sw, sw, st.dev<float>(d), dh, dw, dw, interpolation));
+    return st.finish();
+}
+
 VKX_EXPORT int vkx_pointwise_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride, int op, int p0,
                                 int p1, unsigned channel_mask, uint8_t *dst, ptrdiff_t dst_stride)
 {

@@ -10,7 +10,9 @@
 #include "vkx_internal.h"
 
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
+#include <utility>
 
 namespace {
 
@@ -215,6 +217,404 @@ __global__ void __launch_bounds__(256) k_zoom_finish(const uint8_t *__restrict__
     dst[(ptrdiff_t)y * dstride + xe] = (uint8_t)v;
 }
 
+
+// ---- the other interpolations PageResizingStep samples (pipeline/text_detection/page_resizing.py:110-181 via
+// utility/opt.py:125-148); arithmetic as restated in oracle/vkx_oracle.c.
+
+// interpolateLanczos4 (imgproc): 8 taps s-3 .. s+4
+void lanczos4_coeffs(float x, float c[8])
+{
+    static const double s45 = 0.70710678118654752440084436210485;
+    static const double cs[8][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+    const double pi = 3.1415926535897932384626433832795;
+    if (x < FLT_EPSILON) {
+        for (int i = 0; i < 8; i++) c[i] = 0;
+        c[3] = 1;
+        return;
+    }
+    float sum = 0;
+    const double y0 = -(x + 3) * pi * 0.25, s0 = std::sin(y0), c0 = std::cos(y0);
+    for (int i = 0; i < 8; i++) {
+        const double y = -(x + 3 - i) * pi * 0.25;
+        c[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+        sum += c[i];
+    }
+    sum = 1.f / sum;
+    for (int i = 0; i < 8; i++) c[i] *= sum;
+}
+
+struct AxisTable8 {
+    std::vector<int> ofs;
+    std::vector<float> coef;   // [n][8]
+    std::vector<short> icoef;
+};
+
+void build_axis8(int ssize, int dsize, AxisTable8 *t)
+{
+    t->ofs.resize(dsize); t->coef.resize((size_t)dsize * 8); t->icoef.resize((size_t)dsize * 8);
+    const double inv_scale = (double)dsize / ssize, scale = 1. / inv_scale;
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        const int s0 = (int)std::floor(f);
+        f -= s0;
+        t->ofs[d] = s0;
+        lanczos4_coeffs(f, &t->coef[(size_t)d * 8]);
+        for (int k = 0; k < 8; k++) {
+            const int r = (int)std::nearbyint((double)(t->coef[(size_t)d * 8 + k] * 2048.f));
+            t->icoef[(size_t)d * 8 + k] = (short)(r < -32768 ? -32768 : (r > 32767 ? 32767 : r));
+        }
+    }
+}
+
+template <int CN>
+__global__ void __launch_bounds__(256) k_resize_lanczos4_u8(const uint8_t *__restrict__ src, int sh, int sw, ptrdiff_t sstride,
+                                                            uint8_t *__restrict__ dst, int dh, int dw, ptrdiff_t dstride,
+                                                            const int *__restrict__ xofs, const short *__restrict__ xa,
+                                                            const int *__restrict__ yofs, const short *__restrict__ yb)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dw || dy >= dh) return;
+    const int x0 = xofs[dx], y0 = yofs[dy];
+    int sx[8], ax[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { sx[j] = clip_index(x0 - 3 + j, sw) * CN; ax[j] = xa[dx * 8 + j]; }
+    unsigned acc[CN];
+#pragma unroll
+    for (int c = 0; c < CN; c++) acc[c] = 0;
+    for (int k = 0; k < 8; k++) {
+        const uint8_t *row = src + (ptrdiff_t)clip_index(y0 - 3 + k, sh) * sstride;
+        const int b = yb[dy * 8 + k];
+#pragma unroll
+        for (int c = 0; c < CN; c++) {
+            unsigned hsum = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) hsum += (unsigned)((int)row[sx[j] + c] * ax[j]);
+            acc[c] += hsum * (unsigned)b;
+        }
+    }
+    uint8_t *out = dst + (ptrdiff_t)dy * dstride + (ptrdiff_t)dx * CN;
+#pragma unroll
+    for (int c = 0; c < CN; c++) {
+        const int r = ((int)(acc[c] + (1u << 21))) >> 22;
+        out[c] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+    }
+}
+
+__global__ void __launch_bounds__(256) k_resize_lanczos4_f32(const float *__restrict__ src, int sh, int sw, ptrdiff_t sstride,
+                                                             float *__restrict__ dst, int dh, int dw, ptrdiff_t dstride,
+                                                             const int *__restrict__ xofs, const float *__restrict__ xc,
+                                                             const int *__restrict__ yofs, const float *__restrict__ yc)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dw || dy >= dh) return;
+    const int x0 = xofs[dx], y0 = yofs[dy];
+    int sx[8];
+    float ax[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { sx[j] = clip_index(x0 - 3 + j, sw); ax[j] = xc[dx * 8 + j]; }
+    float v = 0.f;
+    for (int k = 0; k < 8; k++) {
+        const float *row = src + (ptrdiff_t)clip_index(y0 - 3 + k, sh) * sstride;
+        float hsum = row[sx[0]] * ax[0];
+#pragma unroll
+        for (int j = 1; j < 8; j++) { const float t = row[sx[j]] * ax[j]; hsum = hsum + t; }
+        const float term = hsum * yc[dy * 8 + k];
+        v = k == 0 ? term : v + term;
+    }
+    dst[(ptrdiff_t)dy * dstride + dx] = v;
+}
+
+// INTER_NEAREST_EXACT (resizeNN_bitexact): 16.16 index arithmetic; CN = bytes per element (4 = one float32)
+template <int CN>
+__global__ void __launch_bounds__(256) k_resize_nearest_exact(const uint8_t *__restrict__ src, int sh, int sw, ptrdiff_t sstride,
+                                                              uint8_t *__restrict__ dst, int dh, int dw, ptrdiff_t dstride,
+                                                              int ifx, int ifx0, int ify, int ify0)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dw || dy >= dh) return;
+    const int sx = min((int)(((long long)ifx * dx + ifx0) >> 16), sw - 1);
+    const int sy = min((int)(((long long)ify * dy + ify0) >> 16), sh - 1);
+    const uint8_t *p = src + (ptrdiff_t)sy * sstride + (ptrdiff_t)sx * CN;
+#pragma unroll
+    for (int c = 0; c < CN; c++) dst[(ptrdiff_t)dy * dstride + (ptrdiff_t)dx * CN + c] = p[c];
+}
+
+// INTER_LINEAR_EXACT on uint8 (resize_bitExact): per axis (offset, 8.8 weight of the second sample) and the range
+// [mn, mx) of destination indices that interpolate; outside it the first / last source sample is copied
+void build_linear_exact_axis(int ssize, int dsize, std::vector<int> *ofs, std::vector<int> *w1, int *dmin, int *dmax)
+{
+    ofs->resize(dsize); w1->resize(dsize);
+    const double inv_scale = (double)dsize / ssize, scale = 1.0 / inv_scale;
+    int mn = 0, mx = dsize;
+    for (int d = 0; d < dsize; d++) {
+        const double fval = scale * ((double)d + 0.5) - 0.5;
+        int ival = (int)std::floor(fval);
+        (*w1)[d] = 0;
+        if (ival >= 0 && ssize > 1) {
+            if (ival < ssize - 1) (*w1)[d] = (int)std::nearbyint((fval - (double)ival) * 256.0);
+            else { ival = ssize - 1; mx = std::min(mx, d); }
+        } else { mn = std::max(mn, d + 1); ival = 0; }
+        (*ofs)[d] = ival;
+    }
+    if (mx < mn) mx = mn;
+    *dmin = mn; *dmax = mx;
+}
+
+template <int CN>
+__global__ void __launch_bounds__(256) k_resize_linear_exact_u8(const uint8_t *__restrict__ src, ptrdiff_t sstride,
+                                                                uint8_t *__restrict__ dst, int dh, int dw, ptrdiff_t dstride,
+                                                                const int *__restrict__ xofs, const int *__restrict__ xw,
+                                                                const int *__restrict__ yofs, const int *__restrict__ yw,
+                                                                int xmin, int xmax, int ymin, int ymax)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dw || dy >= dh) return;
+    const bool two = dy >= ymin && dy < ymax;
+    const int r0 = dy < ymin ? 0 : (dy >= ymax ? yofs[dh - 1] : yofs[dy]);
+    const uint8_t *S0 = src + (ptrdiff_t)r0 * sstride, *S1 = S0 + (two ? sstride : 0);
+    // horizontal taps: both on the first / last sample outside [xmin, xmax)
+    const int xa = dx < xmin ? 0 : (dx >= xmax ? xofs[dw - 1] : xofs[dx]);
+    const bool xin = dx >= xmin && dx < xmax;
+    const unsigned w1 = xin ? (unsigned)xw[dx] : 0u, w0 = 256u - w1;
+    const int xb = xin ? xa + 1 : xa;
+    const unsigned b1 = two ? (unsigned)yw[dy] : 0u, b0 = 256u - b1;
+    uint8_t *out = dst + (ptrdiff_t)dy * dstride + (ptrdiff_t)dx * CN;
+#pragma unroll
+    for (int c = 0; c < CN; c++) {
+        const unsigned h0 = w0 * S0[xa * CN + c] + w1 * S0[xb * CN + c];
+        unsigned r;
+        if (two) {
+            const unsigned h1 = w0 * S1[xa * CN + c] + w1 * S1[xb * CN + c];
+            r = (h0 * b0 + h1 * b1 + (1u << 15)) >> 16;
+        } else {
+            r = (h0 + 128u) >> 8;
+        }
+        out[c] = (uint8_t)(r > 255u ? 255u : r);
+    }
+}
+
+// INTER_LINEAR on float32 (what INTER_LINEAR_EXACT falls back to for a ScoreMap)
+__global__ void __launch_bounds__(256) k_resize_linear_f32(const float *__restrict__ src, int sh, int sw, ptrdiff_t sstride,
+                                                           float *__restrict__ dst, int dh, int dw, ptrdiff_t dstride,
+                                                           double scale_x, double scale_y)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dw || dy >= dh) return;
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int y0 = (int)floorf(fy);
+    fy -= y0;
+    if (y0 < 0) { y0 = 0; fy = 0; }
+    if (y0 >= sh - 1) { y0 = sh - 1; fy = 0; }
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int x0 = (int)floorf(fx);
+    fx -= x0;
+    if (x0 < 0) { x0 = 0; fx = 0; }
+    if (x0 >= sw - 1) { x0 = sw - 1; fx = 0; }
+    const int x1 = clip_index(x0 + 1, sw);
+    const float *S0 = src + (ptrdiff_t)y0 * sstride, *S1 = src + (ptrdiff_t)clip_index(y0 + 1, sh) * sstride;
+    const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+    const float p0 = S0[x0] * a0, p1 = S0[x1] * a1, q0 = S1[x0] * a0, q1 = S1[x1] * a1;
+    const float h0 = p0 + p1, h1 = q0 + q1;
+    const float t0 = h0 * b0, t1 = h1 * b1;
+    dst[(ptrdiff_t)dy * dstride + dx] = t0 + t1;
+}
+
+// INTER_AREA, integer scale factors (ResizeAreaFast): box sums, then * (1.f / area)
+template <int CN, bool F32>
+__global__ void __launch_bounds__(256) k_resize_area_fast(const void *__restrict__ src_, ptrdiff_t sstride, void *__restrict__ dst_,
+                                                          int dh, int dw, ptrdiff_t dstride, int isx, int isy)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dw || dy >= dh) return;
+    const int area = isx * isy;
+    const float scale = 1.f / area;
+    if (F32) {
+        const float *S = (const float *)src_ + (ptrdiff_t)(dy * isy) * sstride + (ptrdiff_t)(dx * isx);
+        if (isx == 2 && isy == 2) {          // the vector body of the 2 x 2 case pairs the rows
+            const float top = S[0] + S[1], bottom = S[sstride] + S[sstride + 1];
+            const float s4 = top + bottom;
+            ((float *)dst_)[(ptrdiff_t)dy * dstride + dx] = s4 * 0.25f;
+            return;
+        }
+        float sum = 0;
+        int k = 0;
+        for (; k <= area - 4; k += 4) {      // the reference sums the row-major box four samples at a time
+            const float a0 = S[(k / isx) * sstride + (k % isx)], a1 = S[((k + 1) / isx) * sstride + ((k + 1) % isx)];
+            const float a2 = S[((k + 2) / isx) * sstride + ((k + 2) % isx)], a3 = S[((k + 3) / isx) * sstride + ((k + 3) % isx)];
+            float g = a0 + a1;
+            g = g + a2;
+            g = g + a3;
+            sum = sum + g;
+        }
+        for (; k < area; k++) sum = sum + S[(k / isx) * sstride + (k % isx)];
+        ((float *)dst_)[(ptrdiff_t)dy * dstride + dx] = sum * scale;
+    } else {
+        const uint8_t *S = (const uint8_t *)src_ + (ptrdiff_t)(dy * isy) * sstride + (ptrdiff_t)(dx * isx) * CN;
+        uint8_t *out = (uint8_t *)dst_ + (ptrdiff_t)dy * dstride + (ptrdiff_t)dx * CN;
+#pragma unroll
+        for (int c = 0; c < CN; c++) {
+            int sum = 0;
+            for (int y = 0; y < isy; y++)
+                for (int x = 0; x < isx; x++) sum += S[(ptrdiff_t)y * sstride + x * CN + c];
+            const int r = (isx == 2 && isy == 2) ? (sum + 2) >> 2 : vkd::cv_round((float)sum * scale);
+            out[c] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+        }
+    }
+}
+
+// INTER_AREA, fractional scale (ResizeArea): computeResizeAreaTab's (source index, weight) runs per destination index
+struct AreaTab {
+    std::vector<int> start;    // [dsize + 1] first entry of every destination index
+    std::vector<int> si;
+    std::vector<float> alpha;
+};
+
+void build_area_tab(int ssize, int dsize, double scale, AreaTab *t)
+{
+    t->start.assign(dsize + 1, 0); t->si.clear(); t->alpha.clear();
+    for (int dx = 0; dx < dsize; dx++) {
+        t->start[dx] = (int)t->si.size();
+        const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+        const double cell = std::min(scale, ssize - fsx1);
+        int sx1 = (int)std::ceil(fsx1), sx2 = (int)std::floor(fsx2);
+        sx2 = std::min(sx2, ssize - 1);
+        sx1 = std::min(sx1, sx2);
+        if (sx1 - fsx1 > 1e-3) { t->si.push_back(sx1 - 1); t->alpha.push_back((float)((sx1 - fsx1) / cell)); }
+        for (int sx = sx1; sx < sx2; sx++) { t->si.push_back(sx); t->alpha.push_back((float)(1.0 / cell)); }
+        if (fsx2 - sx2 > 1e-3) { t->si.push_back(sx2); t->alpha.push_back((float)(std::min(std::min(fsx2 - sx2, 1.), cell) / cell)); }
+    }
+    t->start[dsize] = (int)t->si.size();
+}
+
+template <int CN, bool F32>
+__global__ void __launch_bounds__(256) k_resize_area(const void *__restrict__ src_, ptrdiff_t sstride, void *__restrict__ dst_, int dh,
+                                                     int dw, ptrdiff_t dstride, const int *__restrict__ xstart,
+                                                     const int *__restrict__ xsi, const float *__restrict__ xal,
+                                                     const int *__restrict__ ystart, const int *__restrict__ ysi,
+                                                     const float *__restrict__ yal)
+{
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dw || dy >= dh) return;
+    const int x0 = xstart[dx], x1 = xstart[dx + 1], y0 = ystart[dy], y1 = ystart[dy + 1];
+    float sum[CN];
+#pragma unroll
+    for (int c = 0; c < CN; c++) sum[c] = 0.f;
+    for (int j = y0; j < y1; j++) {
+        const float beta = yal[j];
+        float buf[CN];
+#pragma unroll
+        for (int c = 0; c < CN; c++) buf[c] = 0.f;
+        for (int k = x0; k < x1; k++) {
+            const float alpha = xal[k];
+#pragma unroll
+            for (int c = 0; c < CN; c++) {
+                const float v = F32 ? ((const float *)src_)[(ptrdiff_t)ysi[j] * sstride + xsi[k]]
+                                    : (float)((const uint8_t *)src_)[(ptrdiff_t)ysi[j] * sstride + xsi[k] * CN + c];
+                const float t = v * alpha;
+                buf[c] = buf[c] + t;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CN; c++) {
+            const float t = beta * buf[c];
+            sum[c] = j == y0 ? t : sum[c] + t;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CN; c++) {
+        if (F32) ((float *)dst_)[(ptrdiff_t)dy * dstride + dx] = sum[c];
+        else {
+            const int r = vkd::cv_round(sum[c]);
+            ((uint8_t *)dst_)[(ptrdiff_t)dy * dstride + (ptrdiff_t)dx * CN + c] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+        }
+    }
+}
+
+// uploads a list of host arrays into ctx->misc (256-byte aligned slots); ptrs[i] receives the device address
+int stage_arrays(vkx_ctx *ctx, const std::vector<std::pair<const void *, size_t>> &arrays, std::vector<const void *> *ptrs)
+{
+    size_t total = 0;
+    std::vector<size_t> off;
+    for (auto &a : arrays) { off.push_back(total); total += (a.second + 255) & ~(size_t)255; }
+    int rc = vkx_scratch_reserve(ctx, &ctx->misc, total ? total : 256);
+    if (rc) return rc;
+    unsigned char *base = (unsigned char *)ctx->misc.ptr;
+    ptrs->clear();
+    for (size_t i = 0; i < arrays.size(); i++) {
+        if (arrays[i].second) VKX_HIP(hipMemcpyAsync(base + off[i], arrays[i].first, arrays[i].second, hipMemcpyHostToDevice, ctx->stream));
+        ptrs->push_back(base + off[i]);
+    }
+    VKX_HIP(hipStreamSynchronize(ctx->stream));   // the host arrays live on the caller's frame
+    return VKX_OK;
+}
+
+#define VKX_CN_SWITCH(cn, KERNEL, ...)                                      \
+    switch (cn) {                                                           \
+    case 1: KERNEL<1><<<grid, 256, 0, ctx->stream>>>(__VA_ARGS__); break;   \
+    case 3: KERNEL<3><<<grid, 256, 0, ctx->stream>>>(__VA_ARGS__); break;   \
+    default: KERNEL<4><<<grid, 256, 0, ctx->stream>>>(__VA_ARGS__); break;  \
+    }
+
+// interpolations shared by the uint8 and float32 entry points; elem = bytes per element for the nearest kernels
+int resize_nearest_exact(vkx_ctx *ctx, const void *src, int sh, int sw, int elem, ptrdiff_t sstride_b, void *dst, int dh, int dw,
+                         ptrdiff_t dstride_b)
+{
+    const int ifx = (int)((((long long)sw << 16) + dw / 2) / dw), ifx0 = ifx / 2 - sw % 2;
+    const int ify = (int)((((long long)sh << 16) + dh / 2) / dh), ify0 = ify / 2 - sh % 2;
+    dim3 grid(vkx_blocks(dw, 64), vkx_blocks(dh, 4));
+    VKX_TIMED(ctx, "k_resize_nearest_exact");
+    VKX_CN_SWITCH(elem, k_resize_nearest_exact, (const uint8_t *)src, sh, sw, sstride_b, (uint8_t *)dst, dh, dw, dstride_b, ifx, ifx0, ify, ify0)
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
+template <bool F32>
+int resize_area(vkx_ctx *ctx, const void *src, int sh, int sw, int cn, ptrdiff_t sstride, void *dst, int dh, int dw, ptrdiff_t dstride)
+{
+    if (dw > sw || dh > sh) {
+        vkx_set_error("INTER_AREA is implemented for shrinking only (the reference samples it only then)");
+        return VKX_ERR_UNSUPPORTED;
+    }
+    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    const int isx = (int)std::nearbyint(scale_x), isy = (int)std::nearbyint(scale_y);
+    dim3 grid(vkx_blocks(dw, 64), vkx_blocks(dh, 4));
+    if (std::fabs(scale_x - isx) < DBL_EPSILON && std::fabs(scale_y - isy) < DBL_EPSILON) {
+        VKX_TIMED(ctx, "k_resize_area_fast");
+        switch (cn) {
+        case 1: k_resize_area_fast<1, F32><<<grid, 256, 0, ctx->stream>>>(src, sstride, dst, dh, dw, dstride, isx, isy); break;
+        case 3: k_resize_area_fast<3, F32><<<grid, 256, 0, ctx->stream>>>(src, sstride, dst, dh, dw, dstride, isx, isy); break;
+        default: k_resize_area_fast<4, F32><<<grid, 256, 0, ctx->stream>>>(src, sstride, dst, dh, dw, dstride, isx, isy); break;
+        }
+        VKX_LAUNCH_CHECK();
+        return VKX_OK;
+    }
+    AreaTab tx, ty;
+    build_area_tab(sw, dw, scale_x, &tx);
+    build_area_tab(sh, dh, scale_y, &ty);
+    std::vector<const void *> p;
+    int rc = stage_arrays(ctx, {{tx.start.data(), sizeof(int) * tx.start.size()}, {tx.si.data(), sizeof(int) * tx.si.size()},
+                                {tx.alpha.data(), sizeof(float) * tx.alpha.size()}, {ty.start.data(), sizeof(int) * ty.start.size()},
+                                {ty.si.data(), sizeof(int) * ty.si.size()}, {ty.alpha.data(), sizeof(float) * ty.alpha.size()}}, &p);
+    if (rc) return rc;
+    VKX_TIMED(ctx, "k_resize_area");
+#define VKX_AREA_ARGS src, sstride, dst, dh, dw, dstride, (const int *)p[0], (const int *)p[1], (const float *)p[2], (const int *)p[3], (const int *)p[4], (const float *)p[5]
+    switch (cn) {
+    case 1: k_resize_area<1, F32><<<grid, 256, 0, ctx->stream>>>(VKX_AREA_ARGS); break;
+    case 3: k_resize_area<3, F32><<<grid, 256, 0, ctx->stream>>>(VKX_AREA_ARGS); break;
+    default: k_resize_area<4, F32><<<grid, 256, 0, ctx->stream>>>(VKX_AREA_ARGS); break;
+    }
+#undef VKX_AREA_ARGS
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
 // Stages the four tables in ctx->misc; returns device pointers.
 int stage_tables(vkx_ctx *ctx, int sh, int sw, int dh, int dw, bool fixed, const int **xofs, const void **xcoef,
                  const int **yofs, const void **ycoef)
@@ -302,8 +702,38 @@ VKX_EXPORT int vkx_resize_u8_dev(vkx_ctx *ctx, const uint8_t *src, int sh, int s
         VKX_LAUNCH_CHECK();
         return VKX_OK;
     }
-    if (interpolation != VKX_INTER_LINEAR) {
-        vkx_set_error("interpolation %d is not implemented (NEAREST, LINEAR, CUBIC are)", interpolation);
+    if (interpolation == VKX_INTER_NEAREST_EXACT)
+        return resize_nearest_exact(ctx, src, sh, sw, cn, src_stride, dst, dh, dw, dst_stride);
+    if (interpolation == VKX_INTER_AREA) return resize_area<false>(ctx, src, sh, sw, cn, src_stride, dst, dh, dw, dst_stride);
+    if (interpolation == VKX_INTER_LANCZOS4) {
+        AxisTable8 tx, ty;
+        build_axis8(sw, dw, &tx);
+        build_axis8(sh, dh, &ty);
+        std::vector<const void *> p;
+        int rc = stage_arrays(ctx, {{tx.ofs.data(), sizeof(int) * dw}, {tx.icoef.data(), sizeof(short) * 8 * dw},
+                                    {ty.ofs.data(), sizeof(int) * dh}, {ty.icoef.data(), sizeof(short) * 8 * dh}}, &p);
+        if (rc) return rc;
+        VKX_TIMED(ctx, "k_resize_lanczos4");
+        VKX_CN_SWITCH(cn, k_resize_lanczos4_u8, src, sh, sw, src_stride, dst, dh, dw, dst_stride, (const int *)p[0], (const short *)p[1], (const int *)p[2], (const short *)p[3])
+        VKX_LAUNCH_CHECK();
+        return VKX_OK;
+    }
+    if (interpolation == VKX_INTER_LINEAR_EXACT && !(sw == 2 * dw && sh == 2 * dh)) {
+        std::vector<int> xo, xw, yo, yw;
+        int xmin, xmax, ymin, ymax;
+        build_linear_exact_axis(sw, dw, &xo, &xw, &xmin, &xmax);
+        build_linear_exact_axis(sh, dh, &yo, &yw, &ymin, &ymax);
+        std::vector<const void *> p;
+        int rc = stage_arrays(ctx, {{xo.data(), sizeof(int) * dw}, {xw.data(), sizeof(int) * dw}, {yo.data(), sizeof(int) * dh},
+                                    {yw.data(), sizeof(int) * dh}}, &p);
+        if (rc) return rc;
+        VKX_TIMED(ctx, "k_resize_linear_exact");
+        VKX_CN_SWITCH(cn, k_resize_linear_exact_u8, src, src_stride, dst, dh, dw, dst_stride, (const int *)p[0], (const int *)p[1], (const int *)p[2], (const int *)p[3], xmin, xmax, ymin, ymax)
+        VKX_LAUNCH_CHECK();
+        return VKX_OK;
+    }
+    if (interpolation != VKX_INTER_LINEAR && interpolation != VKX_INTER_LINEAR_EXACT) {
+        vkx_set_error("unknown interpolation code %d", interpolation);
         return VKX_ERR_UNSUPPORTED;
     }
     if (sw == 2 * dw && sh == 2 * dh) {
@@ -340,6 +770,55 @@ VKX_EXPORT int vkx_resize_u8_dev(vkx_ctx *ctx, const uint8_t *src, int sh, int s
     }
     VKX_LAUNCH_CHECK();
     return VKX_OK;
+}
+
+VKX_EXPORT int vkx_resize_f32_dev(vkx_ctx *ctx, const float *src, int sh, int sw, ptrdiff_t src_stride_el, float *dst, int dh,
+                                  int dw, ptrdiff_t dst_stride_el, int interpolation)
+{
+    if (interpolation == VKX_INTER_CUBIC) return vkx_resize_cubic_f32_dev(ctx, src, sh, sw, src_stride_el, dst, dh, dw, dst_stride_el);
+    VKX_REQUIRE(ctx && src && dst, "NULL argument");
+    VKX_REQUIRE(sh > 0 && sw > 0 && dh > 0 && dw > 0, "bad shape");
+    dim3 grid(vkx_blocks(dw, 64), vkx_blocks(dh, 4));
+    switch (interpolation) {
+    case VKX_INTER_NEAREST: {
+        const double ifx = 1. / ((double)dw / sw), ify = 1. / ((double)dh / sh);
+        VKX_TIMED(ctx, "k_resize_nearest");
+        k_resize_nearest_u8<4><<<grid, 256, 0, ctx->stream>>>((const uint8_t *)src, sh, sw, src_stride_el * 4, (uint8_t *)dst, dh, dw,
+                                                              dst_stride_el * 4, ifx, ify);
+        VKX_LAUNCH_CHECK();
+        return VKX_OK;
+    }
+    case VKX_INTER_NEAREST_EXACT:
+        return resize_nearest_exact(ctx, src, sh, sw, 4, src_stride_el * 4, dst, dh, dw, dst_stride_el * 4);
+    case VKX_INTER_AREA:
+        return resize_area<true>(ctx, src, sh, sw, 1, src_stride_el, dst, dh, dw, dst_stride_el);
+    case VKX_INTER_LINEAR:
+    case VKX_INTER_LINEAR_EXACT: {     // no bit-exact float32 path in cv.resize: INTER_LINEAR_EXACT falls back to INTER_LINEAR
+        if (sw == 2 * dw && sh == 2 * dh) return resize_area<true>(ctx, src, sh, sw, 1, src_stride_el, dst, dh, dw, dst_stride_el);
+        VKX_TIMED(ctx, "k_resize_linear");
+        k_resize_linear_f32<<<grid, 256, 0, ctx->stream>>>(src, sh, sw, src_stride_el, dst, dh, dw, dst_stride_el,
+                                                           1. / ((double)dw / sw), 1. / ((double)dh / sh));
+        VKX_LAUNCH_CHECK();
+        return VKX_OK;
+    }
+    case VKX_INTER_LANCZOS4: {
+        AxisTable8 tx, ty;
+        build_axis8(sw, dw, &tx);
+        build_axis8(sh, dh, &ty);
+        std::vector<const void *> p;
+        int rc = stage_arrays(ctx, {{tx.ofs.data(), sizeof(int) * dw}, {tx.coef.data(), sizeof(float) * 8 * dw},
+                                    {ty.ofs.data(), sizeof(int) * dh}, {ty.coef.data(), sizeof(float) * 8 * dh}}, &p);
+        if (rc) return rc;
+        VKX_TIMED(ctx, "k_resize_lanczos4");
+        k_resize_lanczos4_f32<<<grid, 256, 0, ctx->stream>>>(src, sh, sw, src_stride_el, dst, dh, dw, dst_stride_el, (const int *)p[0],
+                                                             (const float *)p[1], (const int *)p[2], (const float *)p[3]);
+        VKX_LAUNCH_CHECK();
+        return VKX_OK;
+    }
+    default:
+        vkx_set_error("unknown interpolation code %d", interpolation);
+        return VKX_ERR_UNSUPPORTED;
+    }
 }
 
 VKX_EXPORT int vkx_zoom_in_blur_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,

@@ -183,8 +183,8 @@ class Image(Shapable):
         """cv.resize(mat, (w, h), interpolation) on the GPU (reference image.py:836-852) for cv.INTER_NEAREST (0),
         cv.INTER_LINEAR (1) and the default cv.INTER_CUBIC (2)."""
         from vkit_amd import _native
-        if cv_resize_interpolation not in (0, 1, 2):
-            raise NotImplementedError('cv.INTER_NEAREST / LINEAR / CUBIC resizing are on the accelerated path')
+        if cv_resize_interpolation not in range(7):
+            raise ValueError(f'unknown cv2 interpolation code {cv_resize_interpolation}')
         if self.mat.dtype != np.uint8:
             raise NotImplementedError('float32 image modes are outside the accelerated path')
         _, _, resized_height, resized_width = generate_shape_and_resized_shape(

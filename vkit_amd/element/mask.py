@@ -105,14 +105,14 @@ class Mask(Shapable):
 
     def to_resized_mask(self, resized_height: Optional[int] = None, resized_width: Optional[int] = None,
                         cv_resize_interpolation: int = 2, binarization_threshold: int = 0):
-        """Bicubic resize of the 0/255 plane, then ``> binarization_threshold`` (reference mask.py:454-479)."""
+        """cv.resize of the 0/255 plane (any cv2 code 0..6), then ``> binarization_threshold`` (reference mask.py:454-479)."""
         from vkit_amd import _native
         assert not self.box
-        if cv_resize_interpolation != 2:
-            raise NotImplementedError('only cv.INTER_CUBIC resizing is on the accelerated path')
+        if cv_resize_interpolation not in range(7):
+            raise ValueError(f'unknown cv2 interpolation code {cv_resize_interpolation}')
         resized_height, resized_width = generate_resized_shape(
             height=self.height, width=self.width, resized_height=resized_height, resized_width=resized_width)
-        mat = _native.resize_cubic(self.np_mask.astype(np.uint8) * 255, (resized_height, resized_width))
+        mat = _native.resize(self.np_mask.astype(np.uint8) * 255, (resized_height, resized_width), cv_resize_interpolation)
         return Mask(mat=(mat > binarization_threshold).astype(np.uint8))
 
     def to_conducted_resized_mask(self, shapable_or_shape, resized_height: Optional[int] = None,

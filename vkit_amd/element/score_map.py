@@ -71,14 +71,14 @@ class ScoreMap(Shapable):
 
     def to_resized_score_map(self, resized_height: Optional[int] = None, resized_width: Optional[int] = None,
                              cv_resize_interpolation: int = 2):
-        """Bicubic resize, clipped back to [0, 1] for probability maps (reference score_map.py:616-637)."""
+        """cv.resize (any cv2 code 0..6), clipped back to [0, 1] for probability maps (reference score_map.py:616-637)."""
         from vkit_amd import _native
         assert not self.box
-        if cv_resize_interpolation != 2:
-            raise NotImplementedError('only cv.INTER_CUBIC resizing is on the accelerated path')
+        if cv_resize_interpolation not in range(7):
+            raise ValueError(f'unknown cv2 interpolation code {cv_resize_interpolation}')
         _, _, resized_height, resized_width = generate_shape_and_resized_shape(
             shapable_or_shape=self.shape, resized_height=resized_height, resized_width=resized_width)
-        mat = _native.resize_cubic(self.mat, (resized_height, resized_width))
+        mat = _native.resize(self.mat, (resized_height, resized_width), cv_resize_interpolation)
         if self.is_prob:
             mat = np.clip(mat, 0.0, 1.0)
         return attrs.evolve(self, mat=mat)

@@ -8,3 +8,10 @@ from .page_distortion import (  # noqa: F401
     PageDistortionStepOutput,
     page_distortion_step_factory,
 )
+from .page_resizing import (  # noqa: F401
+    PageResizingStep,
+    PageResizingStepConfig,
+    PageResizingStepInput,
+    PageResizingStepOutput,
+    page_resizing_step_factory,
+)

@@ -7,4 +7,5 @@ from .opt import (
     rng_choice,
     rng_choice_with_size,
     rng_shuffle,
+    sample_cv_resize_interpolation,
 )

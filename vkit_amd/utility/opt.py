@@ -102,6 +102,17 @@ def rng_shuffle(rng: RandomGenerator, items: Sequence[_T]) -> Sequence[_T]:
     return tuple(items[idx] for idx in indices)
 
 
+# cv2 interpolation codes PageResizingStep draws from (reference utility/opt.py:125-148): the bit-exact variants of
+# NEAREST / LINEAR, CUBIC and LANCZOS4; INTER_AREA joins the list only for a shrink
+_CV_INTER_FLAGS = (6, 5, 2, 4)       # NEAREST_EXACT, LINEAR_EXACT, CUBIC, LANCZOS4
+_CV_INTER_AREA = 3
+
+
+def sample_cv_resize_interpolation(rng: RandomGenerator, include_cv_inter_area: bool = False) -> int:
+    flags = _CV_INTER_FLAGS + ((_CV_INTER_AREA,) if include_cv_inter_area else ())
+    return rng_choice(rng, flags)
+
+
 def normalize_to_probs(weights: Sequence[float]):
     total = sum(weights)
     return [weight / total for weight in weights]
