@@ -391,3 +391,36 @@ def test_policy_fixture_known_answer(golden_dir):
     assert abs(rec['curve_alpha'] + 12.7058) < 1e-4 and abs(rec['curve_beta'] + 34.3899) < 1e-4
     assert abs(rec['curve_direction'] - 146.3886) < 1e-4 and rec['grid_size'] == 20
     assert rec['camera_model_config']['rotation_theta'] == 8
+
+
+def test_resize_restatements_known_answers():
+    """The cv.resize restatements page resizing uses: closed-form cases whose answers follow from the definitions."""
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, (24, 36, 3), dtype=np.uint8)
+    plane = rng.random((24, 36), dtype=np.float32)
+    for inter in range(7):
+        assert (O.resize(img, (24, 36), inter) == img).all()
+        assert (O.resize(plane, (24, 36), inter) == plane).all()
+        assert (O.resize(np.full((9, 7), 131, np.uint8), (5, 4), inter) == 131).all()
+    # NEAREST_EXACT doubles every sample on an exact 2x enlargement (16.16 centre rule), even and odd sizes
+    for n in (4, 5):
+        row = np.arange(n, dtype=np.uint8).reshape(1, n)
+        assert O.resize(row, (1, 2 * n), O.INTER_NEAREST_EXACT).tolist() == [[i // 2 for i in range(2 * n)]]
+    # AREA with integer factors is the rounded block mean (2 x 2: round half up; 3 x 3: cvRound of sum / 9)
+    a2 = O.resize(img, (12, 18), O.INTER_AREA).astype(int)
+    blocks = img.reshape(12, 2, 18, 2, 3).astype(int).sum(axis=(1, 3))
+    assert (a2 == (blocks + 2) // 4).all()
+    a3 = O.resize(img, (8, 12), O.INTER_AREA).astype(int)
+    s9 = img.reshape(8, 3, 12, 3, 3).astype(int).sum(axis=(1, 3))
+    assert (np.abs(a3 - s9 / 9.0) <= 0.5 + 1e-6).all()
+    # fractional AREA preserves the mean of a float plane; LINEAR_EXACT on an exact half is that same box
+    assert abs(float(O.resize(plane, (10, 15), O.INTER_AREA).mean()) - float(plane.mean())) < 1e-3
+    assert (O.resize(img, (12, 18), O.INTER_LINEAR_EXACT) == O.resize(img, (12, 18), O.INTER_AREA)).all()
+    # LINEAR_EXACT 1 -> 2 enlargement of a step: 8.8 weights 0.25 / 0.75 with round-half-up at the end
+    step = np.array([[0, 200]], np.uint8)
+    assert O.resize(step, (1, 4), O.INTER_LINEAR_EXACT).tolist() == [[0, 50, 150, 200]]
+    # LANCZOS4: a smooth ramp is reproduced to within rounding away from the borders
+    ramp = np.tile(np.arange(0, 144, 4, dtype=np.uint8), (8, 1))
+    up = O.resize(ramp, (8, 72), O.INTER_LANCZOS4).astype(int)
+    ideal = (np.arange(72) + 0.5) / 2 - 0.5
+    assert (np.abs(up[:, 8:-8] - 4 * ideal[8:-8]) <= 1.0).all()
