@@ -111,36 +111,74 @@ __device__ __forceinline__ int find_item(const int *__restrict__ prefix, int n, 
     return lo;
 }
 
+constexpr int kLocalBins = 1024;   // tile bins a setup block aggregates in LDS before touching the global ones
+
 __global__ void __launch_bounds__(256) k_chain_setup(const ItemDev *__restrict__ items, const int *__restrict__ cell_prefix,
                                                      int n_items, int total_cells, int slots,
                                                      vkc::CellC *__restrict__ cells, TileBin *__restrict__ bins,
                                                      int *__restrict__ deferred /* [0] = count, then cell ids */)
 {
+    // Device-scope atomics are the cost of this kernel (every cell updates the candidate rectangle of the 1 - 4 tiles it
+    // touches, and neighbouring cells hit the same bins).  A block's 256 consecutive cells cover a few tile rows of one
+    // image: their updates meet in LDS first and every touched bin is flushed once.
+    __shared__ int lbins[kLocalBins * 4];
+    __shared__ int s_item, s_tiles_x, s_ty_min, s_ty_max;
     const int gid = blockIdx.x * 256 + threadIdx.x;
-    if (gid >= total_cells) return;
-    const int ii = find_item(cell_prefix, n_items, gid);
-    const ItemDev &it = items[ii];
-    const int cell = gid - it.cell_base;
-    vkc::CellC rec;
-    int xmin, xmax, ymin, ymax;
-    // closed-form homography here; cells whose quads have collinear vertices go to k_chain_setup_svd
-    if (vkc::build_cell<vkc::kCellDirectOnly>(it.sv, it.dv, it.rows, it.cols, cell, rec, xmin, xmax, ymin, ymax)) cells[gid] = rec;
-    else deferred[1 + atomicAdd(&deferred[0], 1)] = gid;
-    // bin into every tile whose window [t*Tw - R, t*Tw + Tw + R) meets the cell's bounding box
-    const int r = cell / (it.cols - 1), c = cell - r * (it.cols - 1);
-    const int Tw = tile_side(it.R);
-    int tx0 = (xmin - it.R) / Tw, tx1 = (xmax + it.R) / Tw, ty0 = (ymin - it.R) / Tw, ty1 = (ymax + it.R) / Tw;
-    if (xmin - it.R < 0) tx0 = 0;
-    if (ymin - it.R < 0) ty0 = 0;
-    tx1 = min(tx1, it.tiles_x - 1);
-    ty1 = min(ty1, it.tiles_y - 1);
+    const bool active = gid < total_cells;
+    int ii = -1, r = 0, c = 0, tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1, tiles_x = 1;
+    if (active) {
+        ii = find_item(cell_prefix, n_items, gid);
+        const ItemDev &it = items[ii];
+        const int cell = gid - it.cell_base;
+        vkc::CellC rec;
+        int xmin, xmax, ymin, ymax;
+        // closed-form homography here; cells whose quads have collinear vertices go to k_chain_setup_svd
+        if (vkc::build_cell<vkc::kCellDirectOnly>(it.sv, it.dv, it.rows, it.cols, cell, rec, xmin, xmax, ymin, ymax)) cells[gid] = rec;
+        else deferred[1 + atomicAdd(&deferred[0], 1)] = gid;
+        // the cell belongs to every tile whose window [t*Tw - R, t*Tw + Tw + R) meets its bounding box
+        r = cell / (it.cols - 1); c = cell - r * (it.cols - 1);
+        const int Tw = tile_side(it.R);
+        tx0 = (xmin - it.R) / Tw; tx1 = (xmax + it.R) / Tw; ty0 = (ymin - it.R) / Tw; ty1 = (ymax + it.R) / Tw;
+        if (xmin - it.R < 0) tx0 = 0;
+        if (ymin - it.R < 0) ty0 = 0;
+        tiles_x = it.tiles_x;
+        tx1 = min(tx1, tiles_x - 1);
+        ty1 = min(ty1, it.tiles_y - 1);
+    }
+    if (threadIdx.x == 0) { s_item = ii; s_tiles_x = tiles_x; s_ty_min = INT_MAX; s_ty_max = -1; }
+    __syncthreads();
+    const bool local = active && ii == s_item && ty0 <= ty1 && tx0 <= tx1;   // cells of the block's first image
+    if (local) { atomicMin(&s_ty_min, ty0); atomicMax(&s_ty_max, ty1); }
+    __syncthreads();
+    const int tymin = s_ty_min, nb = s_ty_max >= tymin ? (s_ty_max - tymin + 1) * s_tiles_x : 0;
+    const bool use_lds = nb > 0 && nb <= kLocalBins;
+    if (use_lds)
+        for (int i = threadIdx.x; i < nb; i += 256) {
+            lbins[4 * i] = 0x7f7f7f7f; lbins[4 * i + 1] = 0x7f7f7f7f; lbins[4 * i + 2] = 0; lbins[4 * i + 3] = 0;
+        }
+    __syncthreads();
     for (int ty = ty0; ty <= ty1; ty++)
         for (int tx = tx0; tx <= tx1; tx++) {
-            TileBin *b = bins + (size_t)ii * slots + ty * it.tiles_x + tx;
-            atomicMin(&b->rmin, r);
-            atomicMin(&b->cmin, c);
-            atomicMax(&b->rmax1, r + 1);
-            atomicMax(&b->cmax1, c + 1);
+            if (local && use_lds) {
+                int *b = lbins + 4 * ((ty - tymin) * tiles_x + tx);
+                atomicMin(b, r); atomicMin(b + 1, c); atomicMax(b + 2, r + 1); atomicMax(b + 3, c + 1);
+            } else {
+                TileBin *b = bins + (size_t)ii * slots + ty * tiles_x + tx;
+                atomicMin(&b->rmin, r);
+                atomicMin(&b->cmin, c);
+                atomicMax(&b->rmax1, r + 1);
+                atomicMax(&b->cmax1, c + 1);
+            }
+        }
+    __syncthreads();
+    if (use_lds)
+        for (int i = threadIdx.x; i < nb; i += 256) {
+            if (lbins[4 * i + 2] == 0) continue;       // no cell of this block reached the tile
+            TileBin *b = bins + (size_t)s_item * slots + tymin * s_tiles_x + i;
+            atomicMin(&b->rmin, lbins[4 * i]);
+            atomicMin(&b->cmin, lbins[4 * i + 1]);
+            atomicMax(&b->rmax1, lbins[4 * i + 2]);
+            atomicMax(&b->cmax1, lbins[4 * i + 3]);
         }
 }
 
@@ -406,6 +444,7 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
             int s = (R > 0 && i < K) ? (INTERIOR ? lane + i - R : reflect101(gx + i - R, dw) - wx0) : lane;
             srcl[i] = min(max(s, 0), W - 1) << 2;   // ds_bpermute takes the source lane as a byte address
         }
+        const unsigned fast_xlim = (unsigned)max(sw - 2, 0), fast_ylim = (unsigned)max(sh - 1, 0);
         for (int g0 = 0; g0 < ROWS_PER_WAVE; g0 += CGROUP) {
             int X[CGROUP], Y[CGROUP];
             bool rowok[CGROUP];
@@ -473,8 +512,10 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
             bool fast[CGROUP];
 #pragma unroll
             for (int u = 0; u < CGROUP; u++) {
-                const int sx = vkd::sat_short(X[u] >> 5), sy = vkd::sat_short(Y[u] >> 5);
-                fast[u] = rowok[u] && colok && sx >= 0 && sx + 2 < sw && sy >= 0 && sy + 1 < sh;
+                // 0 <= sx, sx + 2 < sw, 0 <= sy, sy + 1 < sh as two unsigned compares; cv.remap's int16 saturation of the
+                // integer coordinate cannot change the verdict (sw, sh <= 32767) and only matters on the slow path
+                const int sx = X[u] >> 5, sy = Y[u] >> 5;
+                fast[u] = rowok[u] && colok && (unsigned)sx < fast_xlim && (unsigned)sy < fast_ylim;
                 ta[u] = 0; tb[u] = 0;
                 if (fast[u]) {
                     // interior: the two 6-byte tap pairs come in as two unaligned 8-byte loads (3 sx + 8 <= 3 sw)
