@@ -207,6 +207,33 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v)
     return ((uint64_t)hi << 32) | lo;
 }
 
+// nx / de and ny / de, both correctly rounded: the instruction sequence the compiler emits for an IEEE double division
+// (v_div_scale, v_rcp + two Newton steps, v_div_fmas, v_div_fixup), with the refined reciprocal of the scaled denominator
+// computed once when both quotients scale the denominator identically -- the normal case; any lane that disagrees sends
+// the wavefront through the two independent divisions.  Bit for bit the same quotients either way.
+__device__ __forceinline__ void div_pair(double nx, double ny, double de, double &qx, double &qy)
+{
+    bool fdx, fdy, fnx, fny;
+    const double sdx = __builtin_amdgcn_div_scale(nx, de, false, &fdx);
+    const double sdy = __builtin_amdgcn_div_scale(ny, de, false, &fdy);
+    if (__builtin_amdgcn_ballot_w64(__double_as_longlong(sdx) != __double_as_longlong(sdy)) != 0) {
+        qx = nx / de;
+        qy = ny / de;
+        return;
+    }
+    double r = __builtin_amdgcn_rcp(sdx);
+    double e = fma(-sdx, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-sdx, r, 1.0);
+    r = fma(r, e, r);
+    const double snx = __builtin_amdgcn_div_scale(nx, de, true, &fnx);
+    const double sny = __builtin_amdgcn_div_scale(ny, de, true, &fny);
+    const double px = snx * r, py = sny * r;
+    const double ex = fma(-sdx, px, snx), ey = fma(-sdx, py, sny);
+    qx = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(ex, r, px, fnx), de, nx);
+    qy = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(ey, r, py, fny), de, ny);
+}
+
 __device__ __forceinline__ int reflect101(int p, int len)
 {
     if ((unsigned)p < (unsigned)len) return p;
@@ -472,8 +499,10 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
                         const double nx = fma(h[2], 1.0, fma(h[1], fy, h[0] * fx));
                         const double ny = fma(h[5], 1.0, fma(h[4], fy, h[3] * fx));
                         const double de = fma(1.0, 1.0, fma(h[7], fy, h[6] * fx));
-                        X[u] = vkd::cv_round((float)(nx / de) * 32.f);
-                        Y[u] = vkd::cv_round((float)(ny / de) * 32.f);
+                        double qx, qy;
+                        div_pair(nx, ny, de, qx, qy);
+                        X[u] = vkd::cv_round((float)qx * 32.f);
+                        Y[u] = vkd::cv_round((float)qy * 32.f);
                     }
                 }
             }
