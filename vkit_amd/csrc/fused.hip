@@ -200,6 +200,14 @@ __global__ void __launch_bounds__(64) k_chain_setup_svd(const ItemDev *__restric
     }
 }
 
+// a * b + c on the low 24 bits of a and b (full rate)
+__device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // a wave-uniform 64-bit value, moved into SGPRs
 __device__ __forceinline__ uint64_t uniform64(uint64_t v)
 {
@@ -589,8 +597,10 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
                                 vrb = (uint32_t)__builtin_amdgcn_ds_bpermute(srcl[i], (int)prb);
                                 vg = (uint32_t)__builtin_amdgcn_ds_bpermute(srcl[i], (int)pg);
                             }
-                            arb += __umul24(kq[i], vrb);
-                            ag += __umul24(kq[i], vg);
+                            // spelled out: given the symmetric taps the compiler factors k (a + b) for the shuffled
+                            // values, whose sum it cannot bound, and pays a quarter-rate 32-bit multiply for it
+                            arb = mad_u24(kq[i], vrb, arb);
+                            ag = mad_u24(kq[i], vg, ag);
                         }
                     }
                     own[ly * P + lane] = arb;
@@ -634,6 +644,7 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
     const bool hue_on = __builtin_amdgcn_readfirstlane(ite.hue_on) != 0;
     const int hue_delta = __builtin_amdgcn_readfirstlane(ite.hue_delta);
     const int right4 = min(lane + 1, 63) << 2;       // ds_bpermute address of the right-hand neighbour
+    const uint32_t dcol4 = (uint32_t)(x0 * 3 + (ocx >> 2) * 12 + (ocx & 3) * 4);   // this lane's dword of a 4-pixel group
     const int full4 = (tw >> 2) << 2;          // columns covered by whole 4-pixel (12-byte) groups
     const bool streak_on = STREAK && ite.streak_on != 0;
     const int sxm = streak_on ? (x0 + ocx) % ite.streak_step : 0;        // this lane's column phase in the stripe period
@@ -710,7 +721,9 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
             if (INTERIOR || ocx < full4) {     // an interior tile is whole 4-pixel groups
                 if (m < 3) {
                     const uint32_t wv = (P >> (8 * m)) | (Pn << (24 - 8 * m));   // one store for all three lanes
-                    *(u32_u1 VKX_GLOBAL *)(drow + (ocx >> 2) * 12 + m * 4) = wv;
+                    // dh * dstride < 2^32 (checked on the host): scalar row offset + lane offset on the scalar base
+                    const uint32_t off = (uint32_t)gy * (uint32_t)dstride + dcol4;
+                    *(u32_u1 VKX_GLOBAL *)(dst + (size_t)off) = wv;
                 }
             } else {
                 gdst_t d = drow + ocx * 3;
@@ -880,6 +893,7 @@ int vkx_chain_fused_try(vkx_ctx *ctx, const vkx_chain_item *items, int n_items)
             if (d.kq[k] != d.kq[2 * d.R - k]) return VKX_ERR_UNSUPPORTED;    // the kernel reads one half of the taps
         // 24-bit row multiply, 32-bit byte offsets inside the source plane
         if (it.src_stride <= 0 || it.src_stride >= (1 << 24) || (long long)it.sh * it.src_stride + 8 > 0xffffffffLL) return VKX_ERR_UNSUPPORTED;
+        if (it.dst_stride <= 0 || (long long)it.dh * it.dst_stride > 0xffffffffLL) return VKX_ERR_UNSUPPORTED;
         cell_prefix[i] = (int)ncells;
         tiles += (long long)d.tiles_x * d.tiles_y;
         if (d.tiles_x * d.tiles_y > max_tiles) max_tiles = d.tiles_x * d.tiles_y;
