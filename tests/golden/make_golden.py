@@ -368,6 +368,7 @@ def gen_policy_configs():
         'histogram_equalization': (P_color.HistogramEqualizationConfigGenerator,
                                    P_color.HistogramEqualizationConfigGeneratorConfig),
         'brightness_shift': (P_color.BrightnessShiftConfigGenerator, P_color.BrightnessShiftConfigGeneratorConfig),
+        'std_shift': (P_color.StdShiftConfigGenerator, P_color.StdShiftConfigGeneratorConfig),
         'color_balance': (P_color.ColorBalanceConfigGenerator, P_color.ColorBalanceConfigGeneratorConfig),
         'posterization': (P_color.PosterizationConfigGenerator, P_color.PosterizationConfigGeneratorConfig),
         'channel_permutation': (P_color.ChannelPermutationConfigGenerator,
@@ -445,6 +446,36 @@ def gen_random_distortion_sampling():
 
 
 # --------------------------------------------------------------------------------------------
+def gen_std_shift():
+    """std_shift of the reference (photometric/color.py:165-210; numpy only): colour and grayscale images, channel
+    subsets, scales on both sides of 1, and a plane big enough for the float32 running sum to leave the exact range."""
+    out, cases = {}, []
+    rng = default_rng(321)
+    specs = [((37, 53, 3), 1.7, None), ((37, 53, 3), 0.45, [0, 2]), ((37, 53, 3), 2.5, [1]), ((64, 48), 1.3, None),
+             ((64, 48), 0.8, None), ((1, 1, 3), 2.0, None),
+             # formula-generated planes, large enough for the float32 running sums to leave the exact range
+             ((5000, 4000), 1.21, None), ((1200, 1000, 3), 1.9, None), ((1200, 1000, 3), 0.6, [0, 2])]
+    for i, (shape, scale, channels) in enumerate(specs):
+        if shape[0] >= 1000:
+            n = int(np.prod(shape))
+            mat = (np.arange(n, dtype=np.uint32) * np.uint32(2654435761) >> np.uint32(24)).astype(np.uint8).reshape(shape)
+            keep = None        # regenerated by the test from the same formula; only a digest of the output is kept
+        else:
+            mat = rng.integers(0, 256, shape, dtype=np.uint8)
+            keep = mat
+        res = D.std_shift.distort(D.StdShiftConfig(scale=scale, channels=channels), image=Image(mat=mat)).image.mat
+        cases.append({'shape': list(shape), 'scale': scale, 'channels': channels})
+        if keep is not None:
+            out[f'in_{i}'] = keep
+            out[f'out_{i}'] = res
+        else:
+            hist = np.bincount(res.reshape(-1), minlength=256)
+            out[f'out_hist_{i}'] = hist
+            out[f'out_head_{i}'] = res.reshape(-1)[:4096].copy()
+    out['cases_json'] = np.frombuffer(json.dumps(cases).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, 'std_shift.npz'), **out)
+
+
 def gen_page_resizing():
     """PageResizingStep.run of the reference on recording stand-ins for the page elements: which size and which
     interpolation every element is asked to take, for seeded rngs (pipeline/text_detection/page_resizing.py:86-181)."""
@@ -573,5 +604,6 @@ if __name__ == '__main__':
     gen_random_distortion_sampling()
     gen_structure_oracle_patched()
     gen_page_resizing()
+    gen_std_shift()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -332,3 +332,23 @@ def test_page_resizing_step_elements_match_oracle():
             want = O.resize(getattr(page, name).mat, size, inter) * ratio
             assert (getattr(out, name).mat == want).all(), (name, inter)
     assert len(used) >= 4
+
+
+@pytest.mark.gpu
+def test_std_shift_matches_reference_goldens(golden_dir):
+    """std_shift end to end (host numpy mean, device table pass) against outputs of the reference itself."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_host_golden import _std_shift_cases
+    import vkit_amd.mechanism.distortion as D
+    from vkit_amd.element import Image
+    n = 0
+    for case, mat, want, hist, head in _std_shift_cases(golden_dir):
+        got = D.std_shift.distort(D.StdShiftConfig(scale=case['scale'], channels=case['channels']), image=Image(mat=mat)).image.mat
+        if want is not None:
+            assert (got == want).all(), case
+        else:
+            assert (np.bincount(got.reshape(-1), minlength=256) == hist).all(), case
+            assert (got.reshape(-1)[:4096] == head).all(), case
+        n += 1
+    assert n == 9

@@ -42,6 +42,7 @@ GENERATORS = {
     'camera_plane_line_fold': (P_cam.CameraPlaneLineFoldConfigGenerator, P_cam.CameraPlaneLineFoldConfigGeneratorConfig),
     'camera_plane_line_curve': (P_cam.CameraPlaneLineCurveConfigGenerator, P_cam.CameraPlaneLineCurveConfigGeneratorConfig),
     'shear_hori': (P_aff.ShearHoriConfigGenerator, P_aff.ShearHoriConfigGeneratorConfig),
+    'std_shift': (P_color.StdShiftConfigGenerator, P_color.StdShiftConfigGeneratorConfig),
     'shear_vert': (P_aff.ShearVertConfigGenerator, P_aff.ShearVertConfigGeneratorConfig),
     'rotate': (P_aff.RotateConfigGenerator, P_aff.RotateConfigGeneratorConfig),
     'skew_hori': (P_aff.SkewHoriConfigGenerator, P_aff.SkewHoriConfigGeneratorConfig),
@@ -86,7 +87,7 @@ def test_policy_configs_match_reference_draw_for_draw(golden_dir):
         # the generator consumed exactly the reference's number of draws
         assert float(rng.random()) == rec['next_random']
         checked += 1
-    assert checked > 470
+    assert checked > 480
 
 
 def test_affine_states(golden_dir):
@@ -369,3 +370,41 @@ def test_page_resizing_step_decisions(golden_dir):
         assert out.page_image.shape == (case['calls'][0][1], case['calls'][0][2])
         seen.add(case['calls'][0][3])
     assert seen == {2, 3, 4, 5, 6}      # every interpolation the step can draw shows up in the fixture
+
+
+def _std_shift_cases(golden_dir):
+    Z = np.load(os.path.join(golden_dir, 'std_shift.npz'))
+    cases = json.loads(bytes(Z['cases_json']))
+    for i, case in enumerate(cases):
+        shape = tuple(case['shape'])
+        if f'in_{i}' in Z.files:
+            yield case, Z[f'in_{i}'], Z[f'out_{i}'], None, None
+        else:
+            n = int(np.prod(shape))
+            mat = (np.arange(n, dtype=np.uint32) * np.uint32(2654435761) >> np.uint32(24)).astype(np.uint8).reshape(shape)
+            yield case, mat, None, Z[f'out_hist_{i}'], Z[f'out_head_{i}']
+
+
+def test_std_shift_tables_match_reference(golden_dir, monkeypatch):
+    """std_shift's host half (numpy mean + the 256-level float32 expression) against the reference's outputs; the table
+    pass itself is replaced by numpy indexing here and runs on the GPU in tests/test_gpu_pointwise.py."""
+    from vkit_amd import _native
+
+    def lut_on_host(img, lut, channels=None, ctx=None):
+        out = img.copy()
+        planes = out.reshape(out.shape[0], out.shape[1], -1)
+        for c in (channels if channels is not None else range(planes.shape[2])):
+            planes[:, :, c] = lut[c][planes[:, :, c]]
+        return out
+
+    monkeypatch.setattr(_native, 'apply_lut', lut_on_host)
+    n = 0
+    for case, mat, want, hist, head in _std_shift_cases(golden_dir):
+        got = D.std_shift.distort(D.StdShiftConfig(scale=case['scale'], channels=case['channels']), image=Image(mat=mat)).image.mat
+        if want is not None:
+            assert (got == want).all(), case
+        else:
+            assert (np.bincount(got.reshape(-1), minlength=256) == hist).all(), case
+            assert (got.reshape(-1)[:4096] == head).all(), case
+        n += 1
+    assert n == 9

@@ -24,6 +24,8 @@ from .photometric.color import (
     channel_permutation,
     BrightnessShiftConfig,
     brightness_shift,
+    StdShiftConfig,
+    std_shift,
     ColorBalanceConfig,
     color_balance,
     BoundaryEqualizationConfig,

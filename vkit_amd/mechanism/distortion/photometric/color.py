@@ -2,8 +2,9 @@
 photometric/color.py:32-116) and the integer per-value members ``complement``, ``posterization``,
 ``channel_permutation`` (:299-357, :400-432), ``brightness_shift`` (:125-160), ``color_balance`` (:360-397) and the two
 equalisations (:205-285): a per-channel histogram on the GPU (exact integer reduction), a 256-entry table per channel
-built on the host with the reference's arithmetic, and a table pass on the GPU.  ``std_shift`` needs a float32 mean in
-numpy's sequential summation order and is not on the path."""
+built on the host with the reference's arithmetic, and a table pass on the GPU.  ``std_shift`` (:165-210) takes its
+per-channel float32 mean from numpy on the host -- an order-dependent float32 reduction, evaluated by the same numpy call
+as the reference -- and then is a table pass like the others."""
 from typing import Any, Mapping, Optional, Sequence
 
 import attrs
@@ -200,6 +201,48 @@ color_balance = Distortion(
     config_cls=ColorBalanceConfig,
     state_cls=DistortionNopState[ColorBalanceConfig],
     func_image=color_balance_image,
+)
+
+
+@attrs.define
+class StdShiftConfig(DistortionConfig):
+    scale: float
+    channels: Optional[Sequence[int]] = None
+
+
+def std_shift_image(config: StdShiftConfig, state, image: Image, rng: Optional[RandomGenerator]):
+    """``round(v * scale - mean * (scale - 1))`` clipped to uint8, per selected channel (reference color.py:165-203).
+
+    The mean is the reference's own expression on the host array: ``np.mean`` of the float32 copy, over the flattened
+    pixels with ``axis=0`` for colour images -- a float32 accumulation whose value depends on the summation order, so it
+    is left to numpy.  Everything per pixel depends on the grey level and the channel only: the float32 expression is
+    evaluated for the 256 levels and applied as a table on the GPU."""
+    assert config.scale > 0
+    mat = image.mat[:, :, list(config.channels)] if config.channels else image.mat
+    mat = mat.astype(np.float32)
+    if mat.ndim == 2:
+        mean = np.mean(mat)
+    elif mat.ndim == 3:
+        mean = np.mean(mat.reshape(-1, mat.shape[-1]), axis=0)
+    else:
+        raise NotImplementedError()
+    selected = _selected_channels(image, config.channels)
+    levels = np.arange(256, dtype=np.float32)
+    if mat.ndim == 3:
+        values = levels.reshape(-1, 1) * config.scale - mean * (config.scale - 1)       # (256, k), float32
+    else:
+        values = (levels * config.scale - mean * (config.scale - 1)).reshape(-1, 1)
+    table = np.clip(np.round(values), 0, 255).astype(np.uint8)
+    lut = np.tile(np.arange(256, dtype=np.uint8), (max(image.num_channels, 1), 1))
+    for k, c in enumerate(selected):
+        lut[c] = table[:, k]
+    return attrs.evolve(image, mat=_native.apply_lut(image.mat, lut, channels=selected))
+
+
+std_shift = Distortion(
+    config_cls=StdShiftConfig,
+    state_cls=DistortionNopState[StdShiftConfig],
+    func_image=std_shift_image,
 )
 
 

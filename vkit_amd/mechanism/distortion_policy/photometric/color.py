@@ -126,6 +126,23 @@ brightness_shift_policy_factory = DistortionPolicyFactory(distortion.brightness_
 
 
 @attrs.define
+class StdShiftConfigGeneratorConfig:
+    scale_min: float = 1.0
+    scale_max: float = 2.5
+    prob_reciprocal: float = 0.5
+
+
+class StdShiftConfigGenerator(DistortionConfigGenerator[StdShiftConfigGeneratorConfig, distortion.StdShiftConfig]):
+
+    def __call__(self, shape: Tuple[int, int], rng: RandomGenerator):
+        scale = sample_float(self.level, self.config.scale_min, self.config.scale_max, self.config.prob_reciprocal, rng)
+        return distortion.StdShiftConfig(scale=scale, channels=sample_channels(rng))
+
+
+std_shift_policy_factory = DistortionPolicyFactory(distortion.std_shift, StdShiftConfigGenerator)
+
+
+@attrs.define
 class ColorBalanceConfigGeneratorConfig:
     ratio_min: float = 0.0
     ratio_max: float = 1.0

@@ -49,7 +49,6 @@ class _UnsupportedPolicyFactory:
 
 
 UNSUPPORTED_POLICY_NAMES = (
-    'std_shift',
     'defocus_blur', 'motion_blur', 'jpeg_quality',
     'ellipse_streak',
 )
@@ -268,7 +267,7 @@ class RandomDistortionFactoryConfig:
 
 # (policy factories of one family, summed weight of the family); order is the reference's.
 _PHOTOMETRIC_POLICY_FACTORIES_AND_DEFAULT_WEIGHTS_SUM_PAIRS = (
-    ((color.mean_shift_policy_factory, color.color_shift_policy_factory, color.brightness_shift_policy_factory, _U('std_shift'),
+    ((color.mean_shift_policy_factory, color.color_shift_policy_factory, color.brightness_shift_policy_factory, color.std_shift_policy_factory,
       color.boundary_equalization_policy_factory, color.histogram_equalization_policy_factory, color.complement_policy_factory,
       color.posterization_policy_factory, color.color_balance_policy_factory, color.channel_permutation_policy_factory), 10.0),
     ((blur.gaussian_blur_policy_factory, _U('defocus_blur'), _U('motion_blur'), blur.glass_blur_policy_factory,
