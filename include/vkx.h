@@ -321,6 +321,15 @@ int vkx_resize_u8_dev(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, 
 int vkx_resize_u8(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t src_stride,
                   uint8_t *dst, int dh, int dw, ptrdiff_t dst_stride, int interpolation);
 
+/* cv.filter2D(image, -1, kernel) on uint8 with a float32 kernel of up to 15 x 15 taps (HOST pointer, row-major):
+ * defocus_blur / motion_blur  photometric/blur.py:85-192.  Correlation anchored at the kernel centre,
+ * BORDER_REFLECT_101, the non-zero taps in row-major order accumulated in float32 (products and sums rounded
+ * separately), cvRound + saturate. */
+int vkx_filter2d_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                        const float *kernel_host, int kh, int kw, uint8_t *dst, ptrdiff_t dst_stride);
+int vkx_filter2d_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                    const float *kernel_host, int kh, int kw, uint8_t *dst, ptrdiff_t dst_stride);
+
 /* the same on a float32 plane (ScoreMap.to_resized_score_map element/score_map.py:616-640); strides in elements */
 int vkx_resize_f32_dev(vkx_ctx *ctx, const float *src, int sh, int sw, ptrdiff_t src_stride_el, float *dst, int dh, int dw,
                        ptrdiff_t dst_stride_el, int interpolation);

@@ -556,6 +556,77 @@ def resize(src, dsize_hw, interpolation):
     return _resize_u8(fn, src, dsize_hw)
 
 
+def gaussian_blur_f32(mat, ksize, sigma):
+    """cv.GaussianBlur(float32 HxW, (ksize, ksize), sigma) -- the kernel smoothing of blur.py:41-46."""
+    mat = np.ascontiguousarray(mat, dtype=np.float32)
+    h, w = mat.shape
+    dst = np.empty_like(mat)
+    assert lib().vko_gaussian_blur_f32(_p(mat), h, w, _ss(w), int(ksize), ctypes.c_double(sigma), _p(dst), _ss(w)) == 0
+    return dst
+
+
+def filter2d(img, kernel):
+    """cv.filter2D(uint8 image, -1, float32 kernel)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    kernel = np.ascontiguousarray(kernel, dtype=np.float32)
+    s3, squeeze = _as3(img)
+    h, w, cn = s3.shape
+    dst = np.empty_like(s3)
+    rc = lib().vko_filter2d_u8(_p(s3), h, w, cn, _ss(w * cn), _p(kernel), kernel.shape[0], kernel.shape[1], _p(dst), _ss(w * cn))
+    assert rc == 0, rc
+    return dst[:, :, 0] if squeeze else dst
+
+
+def _estimate_gaussian_kernel_size(sigma):
+    kernel_size = max(3, round(3 * sigma) + 1)
+    return kernel_size + 1 if kernel_size % 2 == 0 else kernel_size
+
+
+def defocus_kernel(radius, anti_aliasing_sigma=0.5):
+    """The disc kernel of defocus_blur_image (blur.py:85-112)."""
+    aa = _estimate_gaussian_kernel_size(anti_aliasing_sigma)
+    kernel_size = 2 * radius + 1 + aa // 2 * 2
+    begin = -(kernel_size // 2)
+    coords = np.arange(begin, begin + kernel_size)
+    x, y = np.meshgrid(coords, coords)
+    kernel = ((x ** 2 + y ** 2) <= radius ** 2).astype(np.float32)
+    kernel /= kernel.sum()
+    return gaussian_blur_f32(kernel, aa, anti_aliasing_sigma)
+
+
+def rotation_matrix_2d(center, angle, scale):
+    """cv.getRotationMatrix2D (imgproc/imgwarp.cpp): angle in degrees, counter-clockwise, float64."""
+    angle = angle * np.pi / 180
+    alpha, beta = np.cos(angle) * scale, np.sin(angle) * scale
+    return np.asarray([[alpha, beta, (1 - alpha) * center[0] - beta * center[1]],
+                       [-beta, alpha, beta * center[0] + (1 - alpha) * center[1]]], np.float64)
+
+
+def motion_kernel(radius, angle, anti_aliasing_sigma=0.5):
+    """The rotated line kernel of motion_blur_image (blur.py:135-176)."""
+    aa = _estimate_gaussian_kernel_size(anti_aliasing_sigma)
+    padding = aa // 2 * 2
+    kernel_size = 2 * radius + 1
+    half = padding // 2
+    center, left = radius + half, half
+    right = left + kernel_size - 1
+    kernel_size += padding
+    kernel = np.zeros((kernel_size, kernel_size), np.float32)
+    kernel[center, left:right + 1] = 1.0
+    trans_mat = rotation_matrix_2d((center, center), 360 - (angle % 360), 1.0)
+    kernel = warp_affine(kernel, trans_mat, kernel.shape)
+    kernel /= kernel.sum()
+    return gaussian_blur_f32(kernel, aa, anti_aliasing_sigma)
+
+
+def defocus_blur(img, radius, anti_aliasing_sigma=0.5):
+    return filter2d(img, defocus_kernel(radius, anti_aliasing_sigma))
+
+
+def motion_blur(img, radius, angle, anti_aliasing_sigma=0.5):
+    return filter2d(img, motion_kernel(radius, angle, anti_aliasing_sigma))
+
+
 def line_streak(img, thickness=1, gap=4, dash_thickness=0, dash_gap=0, color=(0, 0, 0), alpha=1.0,
                 enable_vert=True, enable_hori=True):
     out = np.array(img, dtype=np.uint8, order='C')

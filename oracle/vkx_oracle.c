@@ -1839,6 +1839,93 @@ VKO_API int vko_resize_area(const void *src_, int sh, int sw, int cn, ptrdiff_t 
 }
 
 /* ------------------------------------------------------------------------------------
+ * [cv2] defocus_blur / motion_blur -- photometric/blur.py:85-192: a small float32 kernel (a disc, or a rotated line,
+ * normalised) is smoothed with cv.GaussianBlur and applied with cv.filter2D(image, -1, kernel).
+ *   cv.GaussianBlur on float32: getGaussianKernel(ksize, sigma, CV_32F) = the bit-exact double kernel cast to float32,
+ *     then sepFilter2D: rows first, then columns, symmetric form s = x0 k0 + (x-1 + x+1) k1 + (x-2 + x+2) k2 ...,
+ *     float32, BORDER_REFLECT_101.
+ *   cv.filter2D, uint8 -> uint8, float32 kernel below the DFT threshold: correlation anchored at the kernel centre,
+ *     BORDER_REFLECT_101, the non-zero taps in row-major order, s += k * float(px) in float32, cvRound + saturate.
+ * A cv2 build may fuse the multiply-adds of its vector body or hand the filter to IPP; the scalar C++ code is what is
+ * restated here (parity unpinned, like every cv2 call).
+ * ---------------------------------------------------------------------------------- */
+VKO_API int vko_gaussian_kernel_f32(int n, double sigma, float *kf)
+{
+    if (n <= 0 || (n & 1) == 0 || n > 255 || sigma <= 0) return -1;
+    double scale2X = -0.125 / (sigma * sigma);
+    int n2 = (n - 1) / 2;
+    double values[128];
+    double sum = 0;
+    for (int i = 0, x = 1 - n; i < n2; i++, x += 2) {
+        double t = exp((double)(x * x) * scale2X);
+        values[i] = t;
+        sum += t;
+    }
+    sum *= 2;
+    sum += 1;
+    double mul1 = 1. / sum;
+    for (int i = 0; i < n2; i++) { double t = values[i] * mul1; kf[i] = (float)t; kf[n - 1 - i] = (float)t; }
+    kf[n2] = (float)(1. * mul1);
+    return 0;
+}
+
+VKO_API int vko_gaussian_blur_f32(const float *src, int h, int w, ptrdiff_t sstep_el, int ksize, double sigma, float *dst,
+                                  ptrdiff_t dstep_el)
+{
+    float k[255];
+    if (h <= 0 || w <= 0 || vko_gaussian_kernel_f32(ksize, sigma, k)) return -1;
+    const int r = ksize / 2;
+    float *tmp = (float *)malloc(sizeof(float) * (size_t)h * w);
+    if (!tmp) return -2;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const float *S = src + (ptrdiff_t)y * sstep_el;
+            float s0 = S[x] * k[r];
+            for (int j = 1; j <= r; j++) {
+                float pair = S[reflect101(x - j, w)] + S[reflect101(x + j, w)];
+                float t = pair * k[r + j];
+                s0 = s0 + t;
+            }
+            tmp[(size_t)y * w + x] = s0;
+        }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            float s0 = k[r] * tmp[(size_t)y * w + x];
+            for (int j = 1; j <= r; j++) {
+                float pair = tmp[(size_t)reflect101(y + j, h) * w + x] + tmp[(size_t)reflect101(y - j, h) * w + x];
+                float t = k[r + j] * pair;
+                s0 = s0 + t;
+            }
+            dst[(ptrdiff_t)y * dstep_el + x] = s0;
+        }
+    free(tmp);
+    return 0;
+}
+
+VKO_API int vko_filter2d_u8(const uint8_t *src, int h, int w, int cn, ptrdiff_t sstep, const float *kernel, int kh, int kw,
+                            uint8_t *dst, ptrdiff_t dstep)
+{
+    if (h <= 0 || w <= 0 || cn <= 0 || kh <= 0 || kw <= 0) return -1;
+    const int ay = kh / 2, ax = kw / 2;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            for (int c = 0; c < cn; c++) {
+                float s0 = 0.f;
+                for (int ky = 0; ky < kh; ky++)
+                    for (int kx = 0; kx < kw; kx++) {
+                        const float f = kernel[ky * kw + kx];
+                        if (f == 0) continue;
+                        const int sy = reflect101(y + ky - ay, h), sx = reflect101(x + kx - ax, w);
+                        const float t = f * (float)src[(ptrdiff_t)sy * sstep + sx * cn + c];
+                        s0 = s0 + t;
+                    }
+                int r = cv_round_f(s0);
+                dst[(ptrdiff_t)y * dstep + x * cn + c] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+            }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------
  * [cv2] cv.Rodrigues(rvec) (double internals) and cv.projectPoints with zero distortion
  * -- geometric/camera.py:96, :189-195.  calib3d/calibration.cpp cvRodrigues2 /
  * cvProjectPoints2Internal.

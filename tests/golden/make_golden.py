@@ -353,6 +353,8 @@ def gen_policy_configs():
         'skew_hori': (P_aff.SkewHoriConfigGenerator, P_aff.SkewHoriConfigGeneratorConfig),
         'skew_vert': (P_aff.SkewVertConfigGenerator, P_aff.SkewVertConfigGeneratorConfig),
         'gaussian_blur': (P_blur.GaussianBlurConfigGenerator, P_blur.GaussianBlurConfigGeneratorConfig),
+        'defocus_blur': (P_blur.DefocusBlurConfigGenerator, P_blur.DefocusBlurConfigGeneratorConfig),
+        'motion_blur': (P_blur.MotionBlurConfigGenerator, P_blur.MotionBlurConfigGeneratorConfig),
         'mean_shift': (P_color.MeanShiftConfigGenerator, P_color.MeanShiftConfigGeneratorConfig),
         'color_shift': (P_color.ColorShiftConfigGenerator, P_color.ColorShiftConfigGeneratorConfig),
         'gaussion_noise': (P_noise.GaussionNoiseConfigGenerator, P_noise.GaussionNoiseConfigGeneratorConfig),

@@ -352,3 +352,50 @@ def test_std_shift_matches_reference_goldens(golden_dir):
             assert (got.reshape(-1)[:4096] == head).all(), case
         n += 1
     assert n == 9
+
+
+@pytest.mark.gpu
+def test_filter2d_matches_oracle():
+    """vkx_filter2d_u8 against the restatement of cv.filter2D: odd and even kernel sizes up to 15 x 15, zero taps,
+    negative taps (saturation both ways), 1 / 3 / 4 channels, images smaller than the kernel, ragged sizes."""
+    from vkit_amd import _native as N
+    import oracle as O
+    rng = np.random.default_rng(42)
+    for shape in [(37, 53, 3), (64, 64), (1, 9, 3), (9, 1), (130, 70, 4), (3, 3, 3), (200, 333, 3)]:
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        for kh, kw in [(1, 1), (3, 3), (5, 5), (7, 7), (15, 15), (3, 7), (4, 4), (2, 5)]:
+            kernel = rng.random((kh, kw)).astype(np.float32)
+            kernel[rng.random((kh, kw)) < 0.3] = 0
+            kernel /= max(kernel.sum(), np.float32(1e-3))
+            if (kh + kw) % 3 == 0:
+                kernel = (kernel * 3 - np.float32(0.2)).astype(np.float32)       # overshoot and negatives
+            got = N.filter2d(img, kernel)
+            assert (got == O.filter2d(img, kernel)).all(), (shape, kh, kw)
+    with pytest.raises(N.VkxError):
+        N.filter2d(img, np.ones((16, 16), np.float32))
+
+
+@pytest.mark.gpu
+def test_defocus_and_motion_blur_match_oracle():
+    """defocus_blur / motion_blur end to end (host kernel construction incl. the device warpAffine of the motion line,
+    device filter2D) against the oracle pipeline, for every radius / a sweep of angles, RGB and grayscale."""
+    from vkit_amd import _native as N
+    import oracle as O
+    import vkit_amd.mechanism.distortion as D
+    from vkit_amd.element import Image
+    from vkit_amd.mechanism.distortion.photometric import blur as B
+    rng = np.random.default_rng(3)
+    rgb = rng.integers(0, 256, (90, 120, 3), dtype=np.uint8)
+    gray = rng.integers(0, 256, (77, 41), dtype=np.uint8)
+    for radius in (1, 2, 3):
+        for mat in (rgb, gray):
+            got = D.defocus_blur.distort(D.DefocusBlurConfig(radius=radius), image=Image(mat=mat)).image.mat
+            assert (got == O.defocus_blur(mat, radius)).all()
+        for angle in (0, 17, 45, 90, 133, 180, 271, 306, 359, 360, 725):
+            k = B.motion_kernel(radius, angle, 0.5)
+            assert (k == O.motion_kernel(radius, angle, 0.5)).all(), (radius, angle)
+            got = D.motion_blur.distort(D.MotionBlurConfig(radius=radius, angle=angle), image=Image(mat=rgb)).image.mat
+            assert (got == O.motion_blur(rgb, radius, angle)).all(), (radius, angle)
+    # a horizontal line at angle 0 only blurs along x (plus the anti-aliasing spread)
+    k0 = B.motion_kernel(2, 0, 0.5)
+    assert k0[3].sum() > 0.75 * k0.sum()

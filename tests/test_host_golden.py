@@ -43,6 +43,8 @@ GENERATORS = {
     'camera_plane_line_curve': (P_cam.CameraPlaneLineCurveConfigGenerator, P_cam.CameraPlaneLineCurveConfigGeneratorConfig),
     'shear_hori': (P_aff.ShearHoriConfigGenerator, P_aff.ShearHoriConfigGeneratorConfig),
     'std_shift': (P_color.StdShiftConfigGenerator, P_color.StdShiftConfigGeneratorConfig),
+    'defocus_blur': (P_blur.DefocusBlurConfigGenerator, P_blur.DefocusBlurConfigGeneratorConfig),
+    'motion_blur': (P_blur.MotionBlurConfigGenerator, P_blur.MotionBlurConfigGeneratorConfig),
     'shear_vert': (P_aff.ShearVertConfigGenerator, P_aff.ShearVertConfigGeneratorConfig),
     'rotate': (P_aff.RotateConfigGenerator, P_aff.RotateConfigGeneratorConfig),
     'skew_hori': (P_aff.SkewHoriConfigGenerator, P_aff.SkewHoriConfigGeneratorConfig),
@@ -87,7 +89,7 @@ def test_policy_configs_match_reference_draw_for_draw(golden_dir):
         # the generator consumed exactly the reference's number of draws
         assert float(rng.random()) == rec['next_random']
         checked += 1
-    assert checked > 480
+    assert checked > 510
 
 
 def test_affine_states(golden_dir):

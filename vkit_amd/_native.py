@@ -168,6 +168,7 @@ for _sfx in ('', '_dev'):
     _SIGNATURES['vkx_zoom_in_blur_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_int, c_double, c_void_p, c_ssize]
     _SIGNATURES['vkx_resize_cubic_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_int, c_int, c_ssize]
     _SIGNATURES['vkx_resize_cubic_f32' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_void_p, c_int, c_int, c_ssize]
+    _SIGNATURES['vkx_filter2d_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_int, c_int, c_void_p, c_ssize]
     _SIGNATURES['vkx_resize_f32' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_void_p, c_int, c_int, c_ssize, c_int]
     _SIGNATURES['vkx_paint_polys' + _sfx] = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_ssize, c_void_p,
                                              c_ssize, c_int, c_int]
@@ -598,6 +599,19 @@ def histogram(img, ctx=None):
     hist = np.zeros((cn, 256), np.int32)
     check(lib().vkx_histogram_u8(ctx.handle, _ptr(img), h, w, cn, stride, _ptr(hist)))
     return hist
+
+
+def filter2d(img, kernel, ctx=None):
+    """cv.filter2D(img, -1, kernel) for uint8 images and float32 kernels of up to 15 x 15 taps."""
+    ctx = ctx or default_ctx()
+    img, h, w, cn, stride = _u8_plane(img)
+    kernel = np.ascontiguousarray(kernel, dtype=np.float32)
+    if kernel.ndim != 2:
+        raise ValueError('kernel must be 2-D')
+    dst = np.empty_like(img)
+    check(lib().vkx_filter2d_u8(ctx.handle, _ptr(img), h, w, cn, stride, _ptr(kernel), kernel.shape[0], kernel.shape[1],
+                                _ptr(dst), stride))
+    return dst
 
 
 def apply_lut(img, lut, channels=None, ctx=None):

@@ -371,6 +371,20 @@ VKX_EXPORT int vkx_resize_f32(vkx_ctx *ctx, const float *src, int sh, int sw, pt
     return st.finish();
 }
 
+VKX_EXPORT int vkx_filter2d_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                               const float *kernel_host, int kh, int kw, uint8_t *dst, ptrdiff_t dst_stride)
+{
+    VKX_REQUIRE(ctx && src && dst, "NULL argument");
+    VKX_REQUIRE(h >= 0 && w >= 0 && cn > 0, "bad shape");
+    HostStage st(ctx);
+    const int s = st.add(src, nullptr, (size_t)w * cn, h, src_stride);
+    const int d = st.add(nullptr, dst, (size_t)w * cn, h, dst_stride);
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_filter2d_u8_dev(ctx, st.dev<uint8_t>(s), h, w, cn, (ptrdiff_t)w * cn, kernel_host, kh, kw, st.dev<uint8_t>(d),
+                                (ptrdiff_t)w * cn));
+    return st.finish();
+}
+
 VKX_EXPORT int vkx_pointwise_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride, int op, int p0,
                                 int p1, unsigned channel_mask, uint8_t *dst, ptrdiff_t dst_stride)
 {

@@ -148,6 +148,57 @@ __global__ void __launch_bounds__(256) k_gaussian_blur_tiled(const uint8_t *__re
     }
 }
 
+// ---- cv.filter2D(uint8 image, -1, float32 kernel) (defocus_blur / motion_blur, photometric/blur.py:85-192) -------
+// Correlation anchored at the kernel centre, BORDER_REFLECT_101; per pixel the non-zero taps in row-major order,
+// s += k * float(px) with separate roundings, then cvRound + saturate.  One workgroup = a 64 x 16 output tile: the
+// tile plus its halo is staged in LDS once (reflection resolved while staging), every lane walks the taps out of LDS.
+constexpr int kF2dMaxK = 15;                       // kernels up to 15 x 15
+constexpr int kF2dTileW = 64, kF2dTileH = 16;
+struct F2dKernel {
+    int kh, kw;
+    float k[kF2dMaxK * kF2dMaxK];
+};
+
+template <int CN>
+__global__ void __launch_bounds__(256) k_filter2d_u8(const uint8_t *__restrict__ src, int h, int w, ptrdiff_t sstride,
+                                                     uint8_t *__restrict__ dst, ptrdiff_t dstride, F2dKernel K)
+{
+    __shared__ uint8_t tile[(kF2dTileH + kF2dMaxK - 1) * (kF2dTileW + kF2dMaxK - 1) * CN];
+    const int ay = K.kh / 2, ax = K.kw / 2;
+    const int x0 = blockIdx.x * kF2dTileW, y0 = blockIdx.y * kF2dTileH;
+    const int tw = kF2dTileW + K.kw - 1, th = kF2dTileH + K.kh - 1;
+    for (int i = threadIdx.x; i < tw * th; i += 256) {
+        const int ty = i / tw, tx = i - ty * tw;
+        const uint8_t *p = src + (ptrdiff_t)reflect101(y0 + ty - ay, h) * sstride + (ptrdiff_t)reflect101(x0 + tx - ax, w) * CN;
+#pragma unroll
+        for (int c = 0; c < CN; c++) tile[i * CN + c] = p[c];
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63, x = x0 + lx;
+    if (x >= w) return;
+    for (int ly = threadIdx.x >> 6; ly < kF2dTileH; ly += 4) {
+        const int y = y0 + ly;
+        if (y >= h) break;
+        float acc[CN];
+#pragma unroll
+        for (int c = 0; c < CN; c++) acc[c] = 0.f;
+        for (int ky = 0; ky < K.kh; ky++)
+            for (int kx = 0; kx < K.kw; kx++) {
+                const float f = K.k[ky * K.kw + kx];
+                if (f == 0) continue;                       // uniform: the reference drops zero taps from its list
+                const uint8_t *t = tile + ((ly + ky) * tw + lx + kx) * CN;
+#pragma unroll
+                for (int c = 0; c < CN; c++) {
+                    const float term = f * (float)t[c];
+                    acc[c] = acc[c] + term;
+                }
+            }
+        uint8_t *d = dst + (ptrdiff_t)y * dstride + (ptrdiff_t)x * CN;
+#pragma unroll
+        for (int c = 0; c < CN; c++) d[c] = (uint8_t)vkd::clamp_u8(vkd::cv_round(acc[c]));
+    }
+}
+
 // ---- cvtColor RGB <-> HSV_FULL (uint8) -----------------------------------------------------------------------
 // RGB->HSV is OpenCV's integer LUT division; the two 256-entry tables (cvRound of doubles) are built on the
 // host once and passed in device memory.
@@ -528,6 +579,28 @@ VKX_EXPORT int vkx_gaussian_blur_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h,
     case 3: { VKX_TIMED(ctx, "k_gaussian_blur"); k_gaussian_blur<3><<<grid, block, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K); } break;
     case 4: { VKX_TIMED(ctx, "k_gaussian_blur"); k_gaussian_blur<4><<<grid, block, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K); } break;
     default: vkx_set_error("unsupported channel count %d", cn); return VKX_ERR_UNSUPPORTED;
+    }
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_filter2d_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
+                                   const float *kernel_host, int kh, int kw, uint8_t *dst, ptrdiff_t dst_stride)
+{
+    int rc = check_plane(ctx, src, dst, h, w);
+    if (rc) return rc;
+    VKX_REQUIRE(kernel_host && kh >= 1 && kw >= 1 && kh <= kF2dMaxK && kw <= kF2dMaxK, "kernel of 1..15 rows and columns");
+    VKX_REQUIRE(cn == 1 || cn == 3 || cn == 4, "1, 3 or 4 channels");
+    if (h == 0 || w == 0) return VKX_OK;
+    F2dKernel K;
+    K.kh = kh; K.kw = kw;
+    for (int i = 0; i < kF2dMaxK * kF2dMaxK; i++) K.k[i] = i < kh * kw ? kernel_host[i] : 0.f;
+    dim3 grid(vkx_blocks(w, kF2dTileW), vkx_blocks(h, kF2dTileH));
+    VKX_TIMED(ctx, "k_filter2d");
+    switch (cn) {
+    case 1: k_filter2d_u8<1><<<grid, 256, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K); break;
+    case 3: k_filter2d_u8<3><<<grid, 256, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K); break;
+    default: k_filter2d_u8<4><<<grid, 256, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K); break;
     }
     VKX_LAUNCH_CHECK();
     return VKX_OK;

@@ -36,6 +36,10 @@ from .photometric.color import (
 from .photometric.blur import (
     GaussianBlurConfig,
     gaussian_blur,
+    DefocusBlurConfig,
+    defocus_blur,
+    MotionBlurConfig,
+    motion_blur,
     GlassBlurConfig,
     glass_blur,
     ZoomInBlurConfig,

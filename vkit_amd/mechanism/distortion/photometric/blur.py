@@ -1,10 +1,12 @@
 """``gaussian_blur`` (reference: photometric/blur.py:26-69): ksize = max(3, round(3 sigma) + 1) forced odd,
 ``cv.GaussianBlur(mat, (k, k), sigma)`` -- OpenCV's bit-exact 8.8 fixed-point separable kernel restated in HIP --
 and ``glass_blur`` (:186-258): that blur followed by a random local pixel shuffle.  ``defocus_blur`` / ``motion_blur``
-run ``cv.filter2D`` with float kernels built by float ``cv.GaussianBlur`` / ``cv.warpAffine`` (fused vs unfused
-multiply-adds differ between SIMD body and scalar tail inside one cv2 build; a DFT from 50 taps on): there is no single
-bit pattern to reproduce, so they stay outside the path.  ``zoom_in_blur`` (:264-323) averages the image with centred crops of its bicubic
+(:85-192) build a small float32 kernel on the host -- a normalised disc, or a line rotated with ``cv.warpAffine``
+(``vkx_warp_affine_f32``), smoothed with a float32 ``cv.GaussianBlur`` restated in numpy below -- and apply it with
+``cv.filter2D`` on the GPU (``vkx_filter2d_u8``; the scalar C++ arithmetic of cv2: float32 accumulation in tap order,
+no fused multiply-add).  ``zoom_in_blur`` (:264-323) averages the image with centred crops of its bicubic
 enlargements (``vkx_zoom_in_blur_u8``)."""
+import math
 from typing import Any, Mapping, Optional
 
 import attrs
@@ -38,6 +40,135 @@ gaussian_blur = Distortion(
     config_cls=GaussianBlurConfig,
     state_cls=DistortionNopState[GaussianBlurConfig],
     func_image=gaussian_blur_image,
+)
+
+
+def _gaussian_kernel_f32(ksize: int, sigma: float) -> np.ndarray:
+    """cv.getGaussianKernel(ksize, sigma, CV_32F) for sigma > 0: the bit-exact double kernel (weights exp(-x^2 / 2 sigma^2)
+    evaluated on doubled integer offsets, normalised by the reciprocal of their sum), cast to float32."""
+    assert ksize % 2 == 1 and sigma > 0
+    scale2x = -0.125 / (sigma * sigma)
+    half = (ksize - 1) // 2
+    values = [math.exp(float(x * x) * scale2x) for x in range(1 - ksize, 0, 2)]
+    total = 0.0
+    for v in values:
+        total += v
+    total *= 2
+    total += 1
+    mul1 = 1.0 / total
+    kernel = np.empty(ksize, np.float32)
+    for i, v in enumerate(values):
+        kernel[i] = kernel[ksize - 1 - i] = np.float32(v * mul1)
+    kernel[half] = np.float32(1.0 * mul1)
+    return kernel
+
+
+def _reflect101(idx: np.ndarray, size: int) -> np.ndarray:
+    if size == 1:
+        return np.zeros_like(idx)
+    idx = np.abs(idx)
+    period = 2 * (size - 1)
+    idx = idx % period
+    return np.where(idx >= size, period - idx, idx)
+
+
+def _gaussian_blur_f32(mat: np.ndarray, ksize: int, sigma: float) -> np.ndarray:
+    """cv.GaussianBlur on a small float32 matrix (the kernels below): separable, rows then columns, the symmetric form
+    ``x0 k0 + (x-1 + x+1) k1 + ...`` in float32, BORDER_REFLECT_101."""
+    kernel = _gaussian_kernel_f32(ksize, sigma)
+    r = ksize // 2
+    out = mat.astype(np.float32)
+    for axis in (1, 0):
+        n = out.shape[axis]
+        base = np.arange(n)
+        acc = out * kernel[r]
+        for j in range(1, r + 1):
+            pair = np.take(out, _reflect101(base - j, n), axis=axis) + np.take(out, _reflect101(base + j, n), axis=axis)
+            acc = acc + pair * kernel[r + j]
+        out = acc.astype(np.float32)
+    return out
+
+
+def _anti_aliasing_ksize_and_padding(anti_aliasing_sigma: float):
+    kernel_size = _estimate_gaussian_kernel_size(anti_aliasing_sigma)
+    return kernel_size, kernel_size // 2 * 2
+
+
+def _filter2d_image(image: Image, kernel: np.ndarray):
+    mode = image.mode
+    image = to_rgb_image(image, mode)
+    return to_original_image(attrs.evolve(image, mat=_native.filter2d(image.mat, kernel)), mode)
+
+
+@attrs.define
+class DefocusBlurConfig(DistortionConfig):
+    radius: int
+    anti_aliasing_sigma: float = 0.5
+
+
+def defocus_kernel(radius: int, anti_aliasing_sigma: float) -> np.ndarray:
+    """Normalised disc of the given radius with a zero margin, smoothed by the anti-aliasing Gaussian (reference :90-112)."""
+    assert 0 < radius
+    aa_ksize, padding = _anti_aliasing_ksize_and_padding(anti_aliasing_sigma)
+    kernel_size = 2 * radius + 1 + padding
+    begin = -(kernel_size // 2)
+    coords = np.arange(begin, begin + kernel_size)
+    x, y = np.meshgrid(coords, coords)
+    kernel = ((x ** 2 + y ** 2) <= radius ** 2).astype(np.float32)
+    kernel /= kernel.sum()
+    return _gaussian_blur_f32(kernel, aa_ksize, anti_aliasing_sigma)
+
+
+def defocus_blur_image(config: DefocusBlurConfig, state, image: Image, rng: Optional[RandomGenerator]):
+    return _filter2d_image(image, defocus_kernel(config.radius, config.anti_aliasing_sigma))
+
+
+defocus_blur = Distortion(
+    config_cls=DefocusBlurConfig,
+    state_cls=DistortionNopState[DefocusBlurConfig],
+    func_image=defocus_blur_image,
+)
+
+
+@attrs.define
+class MotionBlurConfig(DistortionConfig):
+    radius: int
+    angle: int
+    anti_aliasing_sigma: float = 0.5
+
+
+def _rotation_matrix_2d(center, angle: float, scale: float) -> np.ndarray:
+    """cv.getRotationMatrix2D: degrees, counter-clockwise, float64."""
+    angle = angle * np.pi / 180
+    alpha, beta = np.cos(angle) * scale, np.sin(angle) * scale
+    return np.asarray([[alpha, beta, (1 - alpha) * center[0] - beta * center[1]],
+                       [-beta, alpha, beta * center[0] + (1 - alpha) * center[1]]], np.float64)
+
+
+def motion_kernel(radius: int, angle: int, anti_aliasing_sigma: float) -> np.ndarray:
+    """A horizontal line of 2 radius + 1 taps in a zero margin, rotated clockwise by ``angle`` degrees with a bilinear
+    warpAffine, normalised, smoothed (reference :135-176)."""
+    aa_ksize, padding = _anti_aliasing_ksize_and_padding(anti_aliasing_sigma)
+    half = padding // 2
+    center, left = radius + half, half
+    length = 2 * radius + 1
+    kernel_size = length + padding
+    kernel = np.zeros((kernel_size, kernel_size), np.float32)
+    kernel[center, left:left + length] = 1.0
+    trans_mat = _rotation_matrix_2d((center, center), 360 - (int(angle) % 360), 1.0)
+    kernel = _native.warp_affine(kernel, trans_mat, kernel.shape)
+    kernel /= kernel.sum()
+    return _gaussian_blur_f32(kernel, aa_ksize, anti_aliasing_sigma)
+
+
+def motion_blur_image(config: MotionBlurConfig, state, image: Image, rng: Optional[RandomGenerator]):
+    return _filter2d_image(image, motion_kernel(config.radius, config.angle, config.anti_aliasing_sigma))
+
+
+motion_blur = Distortion(
+    config_cls=MotionBlurConfig,
+    state_cls=DistortionNopState[MotionBlurConfig],
+    func_image=motion_blur_image,
 )
 
 

@@ -28,6 +28,40 @@ gaussian_blur_policy_factory = DistortionPolicyFactory(distortion.gaussian_blur,
 
 
 @attrs.define
+class DefocusBlurConfigGeneratorConfig:
+    radius_min: int = 1
+    radius_max: int = 2
+
+
+class DefocusBlurConfigGenerator(
+        DistortionConfigGenerator[DefocusBlurConfigGeneratorConfig, distortion.DefocusBlurConfig]):
+
+    def __call__(self, shape: Tuple[int, int], rng: RandomGenerator):
+        return distortion.DefocusBlurConfig(
+            radius=sample_int(self.level, self.config.radius_min, self.config.radius_max, None, rng))
+
+
+defocus_blur_policy_factory = DistortionPolicyFactory(distortion.defocus_blur, DefocusBlurConfigGenerator)
+
+
+@attrs.define
+class MotionBlurConfigGeneratorConfig:
+    radius_min: int = 1
+    radius_max: int = 2
+
+
+class MotionBlurConfigGenerator(
+        DistortionConfigGenerator[MotionBlurConfigGeneratorConfig, distortion.MotionBlurConfig]):
+
+    def __call__(self, shape: Tuple[int, int], rng: RandomGenerator):
+        radius = sample_int(self.level, self.config.radius_min, self.config.radius_max, None, rng)
+        return distortion.MotionBlurConfig(radius=radius, angle=rng.integers(0, 360))
+
+
+motion_blur_policy_factory = DistortionPolicyFactory(distortion.motion_blur, MotionBlurConfigGenerator)
+
+
+@attrs.define
 class GlassBlurConfigGeneratorConfig:
     sigma_min: float = 0.5
     sigma_max: float = 1.0

@@ -49,7 +49,7 @@ class _UnsupportedPolicyFactory:
 
 
 UNSUPPORTED_POLICY_NAMES = (
-    'defocus_blur', 'motion_blur', 'jpeg_quality',
+    'jpeg_quality',
     'ellipse_streak',
 )
 _U = _UnsupportedPolicyFactory
@@ -270,7 +270,8 @@ _PHOTOMETRIC_POLICY_FACTORIES_AND_DEFAULT_WEIGHTS_SUM_PAIRS = (
     ((color.mean_shift_policy_factory, color.color_shift_policy_factory, color.brightness_shift_policy_factory, color.std_shift_policy_factory,
       color.boundary_equalization_policy_factory, color.histogram_equalization_policy_factory, color.complement_policy_factory,
       color.posterization_policy_factory, color.color_balance_policy_factory, color.channel_permutation_policy_factory), 10.0),
-    ((blur.gaussian_blur_policy_factory, _U('defocus_blur'), _U('motion_blur'), blur.glass_blur_policy_factory,
+    ((blur.gaussian_blur_policy_factory, blur.defocus_blur_policy_factory, blur.motion_blur_policy_factory,
+      blur.glass_blur_policy_factory,
       blur.zoom_in_blur_policy_factory), 1.0),
     ((noise.gaussion_noise_policy_factory, noise.poisson_noise_policy_factory, noise.impulse_noise_policy_factory,
       noise.speckle_noise_policy_factory), 3.0),
