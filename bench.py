@@ -245,12 +245,12 @@ def main():
     # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), measured in separate
     # rocprofv3 --pmc passes (profiles/) on the same workload and scaled by the number of images of this launch.
     traffic, traffic_source = None, None
-    tpath = os.path.join(ROOT, 'profiles', 'r1k_traffic.json')
+    tpath = os.path.join(ROOT, 'profiles', 'r1l_traffic.json')
     if dominant == 'k_chain_fused' and size == 2048 and os.path.exists(tpath):
         with open(tpath) as fin:
             tj = json.load(fin)
         traffic = tj['hbm_bytes_per_image'] * B
-        traffic_source = 'profiles/r1k_traffic.json'
+        traffic_source = 'profiles/r1l_traffic.json'
     kernel_sum_s = sum(v[0] for v in kernel_times.values()) / 1e3 / args.steps
     result = {
         'metric': 'Mpixels/s (2048^2 RGB, geo+photo chain)',
