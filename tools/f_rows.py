@@ -38,8 +38,15 @@ for D in (1229, 2458):
         ts = []
         for _ in range(5):
             ctx.sync(); t0 = time.perf_counter(); run(); ctx.sync(); ts.append(time.perf_counter() - t0)
+        ctx.set_timing(True); ctx.reset_timings()
+        for _ in range(3):
+            run()
+        ctx.sync()
+        kern = sum(v[0] for v in ctx.timings().values()) / 3
+        ctx.set_timing(False); ctx.reset_timings()
         bytes_moved = (S * S + D * D) * (3 + 1 + 4)
         res['resize_2048_page'][f'{names[inter]}_to_{D}'] = {'ms_image_mask_score': round(min(ts) * 1e3, 3),
+                                                            'kernels_ms': round(kern, 3),
                                                             'GBps_on_S_plus_D': round(bytes_moved / min(ts) / 1e9)}
 # point projection
 import vkit_amd.mechanism.distortion as Dm

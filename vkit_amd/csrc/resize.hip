@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <utility>
 
 namespace {
@@ -537,21 +538,42 @@ __global__ void __launch_bounds__(256) k_resize_area(const void *__restrict__ sr
     }
 }
 
-// uploads a list of host arrays into ctx->misc (256-byte aligned slots); ptrs[i] receives the device address
-int stage_arrays(vkx_ctx *ctx, const std::vector<std::pair<const void *, size_t>> &arrays, std::vector<const void *> *ptrs)
+// Host-built tables of one resize geometry in device memory, from the ctx cache when the geometry was seen recently.
+// `build` fills the host arrays (kept alive until the upload has completed) and the metadata on a miss only.
+template <class Build>
+int cached_tables(vkx_ctx *ctx, const int key[6], Build build, std::vector<const void *> *ptrs, const std::vector<int> **meta)
 {
-    size_t total = 0;
-    std::vector<size_t> off;
-    for (auto &a : arrays) { off.push_back(total); total += (a.second + 255) & ~(size_t)255; }
-    int rc = vkx_scratch_reserve(ctx, &ctx->misc, total ? total : 256);
-    if (rc) return rc;
-    unsigned char *base = (unsigned char *)ctx->misc.ptr;
-    ptrs->clear();
-    for (size_t i = 0; i < arrays.size(); i++) {
-        if (arrays[i].second) VKX_HIP(hipMemcpyAsync(base + off[i], arrays[i].first, arrays[i].second, hipMemcpyHostToDevice, ctx->stream));
-        ptrs->push_back(base + off[i]);
+    vkx_ctx::ResizeTabs *slot = nullptr;
+    for (auto &t : ctx->resize_tabs)
+        if (std::equal(key, key + 6, t.key)) slot = &t;
+    int n = 0;
+    if (!slot) {
+        slot = &ctx->resize_tabs[0];
+        for (auto &t : ctx->resize_tabs)
+            if (t.stamp < slot->stamp) slot = &t;
+        std::vector<std::pair<const void *, size_t>> arrays;
+        std::vector<int> m;
+        build(&arrays, &m);
+        if (arrays.size() > 7) return VKX_ERR_INVALID;
+        size_t total = 0;
+        for (size_t i = 0; i < arrays.size(); i++) { slot->off[i] = total; total += (arrays[i].second + 255) & ~(size_t)255; }
+        slot->off[7] = arrays.size();
+        slot->key[0] = -1;
+        int rc = vkx_scratch_reserve(ctx, &slot->buf, total ? total : 256);
+        if (rc) return rc;
+        for (size_t i = 0; i < arrays.size(); i++)
+            if (arrays[i].second)
+                VKX_HIP(hipMemcpyAsync((unsigned char *)slot->buf.ptr + slot->off[i], arrays[i].first, arrays[i].second,
+                                       hipMemcpyHostToDevice, ctx->stream));
+        VKX_HIP(hipStreamSynchronize(ctx->stream));
+        slot->yofs.swap(m);
+        std::copy(key, key + 6, slot->key);
     }
-    VKX_HIP(hipStreamSynchronize(ctx->stream));   // the host arrays live on the caller's frame
+    n = (int)slot->off[7];
+    slot->stamp = ++ctx->resize_clock;
+    ptrs->clear();
+    for (int i = 0; i < n; i++) ptrs->push_back((unsigned char *)slot->buf.ptr + slot->off[i]);
+    *meta = &slot->yofs;
     return VKX_OK;
 }
 
@@ -595,13 +617,17 @@ int resize_area(vkx_ctx *ctx, const void *src, int sh, int sw, int cn, ptrdiff_t
         VKX_LAUNCH_CHECK();
         return VKX_OK;
     }
-    AreaTab tx, ty;
-    build_area_tab(sw, dw, scale_x, &tx);
-    build_area_tab(sh, dh, scale_y, &ty);
+    AreaTab tx, ty;     // filled on a cache miss only
     std::vector<const void *> p;
-    int rc = stage_arrays(ctx, {{tx.start.data(), sizeof(int) * tx.start.size()}, {tx.si.data(), sizeof(int) * tx.si.size()},
-                                {tx.alpha.data(), sizeof(float) * tx.alpha.size()}, {ty.start.data(), sizeof(int) * ty.start.size()},
-                                {ty.si.data(), sizeof(int) * ty.si.size()}, {ty.alpha.data(), sizeof(float) * ty.alpha.size()}}, &p);
+    const std::vector<int> *meta;
+    const int key[6] = {103, 0, sh, sw, dh, dw};
+    int rc = cached_tables(ctx, key, [&](std::vector<std::pair<const void *, size_t>> *arrays, std::vector<int> *) {
+        build_area_tab(sw, dw, scale_x, &tx);
+        build_area_tab(sh, dh, scale_y, &ty);
+        *arrays = {{tx.start.data(), sizeof(int) * tx.start.size()}, {tx.si.data(), sizeof(int) * tx.si.size()},
+                   {tx.alpha.data(), sizeof(float) * tx.alpha.size()}, {ty.start.data(), sizeof(int) * ty.start.size()},
+                   {ty.si.data(), sizeof(int) * ty.si.size()}, {ty.alpha.data(), sizeof(float) * ty.alpha.size()}};
+    }, &p, &meta);
     if (rc) return rc;
     VKX_TIMED(ctx, "k_resize_area");
 #define VKX_AREA_ARGS src, sstride, dst, dh, dw, dstride, (const int *)p[0], (const int *)p[1], (const float *)p[2], (const int *)p[3], (const int *)p[4], (const float *)p[5]
@@ -615,31 +641,163 @@ int resize_area(vkx_ctx *ctx, const void *src, int sh, int sw, int cn, ptrdiff_t
     return VKX_OK;
 }
 
-// Stages the four tables in ctx->misc; returns device pointers.
-int stage_tables(vkx_ctx *ctx, int sh, int sw, int dh, int dw, bool fixed, const int **xofs, const void **xcoef,
-                 const int **yofs, const void **ycoef)
+
+// ---- separable form of the CUBIC / LANCZOS4 gathers ------------------------------------------------------------------
+// One workgroup = a 64 x 16 destination tile.  The source rows the tile's 16 destination rows reach (clipped to the
+// image like the taps themselves) get their horizontal pass once, into LDS; the vertical pass reads them back.  The
+// sums are the ones of the direct kernels above -- the horizontal sum of a source row does not depend on the
+// destination row it is used for -- with K (rows / 16 + 1) multiply-adds per sample instead of K^2.  A tile that would
+// need more than kSepRows source rows (a shrink by more than ~2x) is left to the direct kernels.
+constexpr int kSepTileW = 64, kSepTileH = 16, kSepRows = 40;
+
+template <typename T, typename CT, typename AT, int CN, int KS>
+__global__ void __launch_bounds__(256) k_resize_sep(const T *__restrict__ src, int sh, int sw, ptrdiff_t sstride,
+                                                    T *__restrict__ dst, int dh, int dw, ptrdiff_t dstride,
+                                                    const int *__restrict__ xofs, const CT *__restrict__ xa,
+                                                    const int *__restrict__ yofs, const CT *__restrict__ yb)
 {
-    AxisTable tx, ty;
-    build_axis(sw, dw, &tx);
-    build_axis(sh, dh, &ty);
-    const size_t csz = fixed ? sizeof(short) : sizeof(float);
-    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    const size_t o0 = 0, o1 = o0 + up(sizeof(int) * dw), o2 = o1 + up(csz * 4 * dw), o3 = o2 + up(sizeof(int) * dh);
-    const size_t total = o3 + up(csz * 4 * dh);
-    int rc = vkx_scratch_reserve(ctx, &ctx->misc, total);
-    if (rc) return rc;
-    unsigned char *base = (unsigned char *)ctx->misc.ptr;
-    VKX_HIP(hipMemcpyAsync(base + o0, tx.ofs.data(), sizeof(int) * dw, hipMemcpyHostToDevice, ctx->stream));
-    VKX_HIP(hipMemcpyAsync(base + o2, ty.ofs.data(), sizeof(int) * dh, hipMemcpyHostToDevice, ctx->stream));
-    if (fixed) {
-        VKX_HIP(hipMemcpyAsync(base + o1, tx.icoef.data(), csz * 4 * dw, hipMemcpyHostToDevice, ctx->stream));
-        VKX_HIP(hipMemcpyAsync(base + o3, ty.icoef.data(), csz * 4 * dh, hipMemcpyHostToDevice, ctx->stream));
-    } else {
-        VKX_HIP(hipMemcpyAsync(base + o1, tx.coef.data(), csz * 4 * dw, hipMemcpyHostToDevice, ctx->stream));
-        VKX_HIP(hipMemcpyAsync(base + o3, ty.coef.data(), csz * 4 * dh, hipMemcpyHostToDevice, ctx->stream));
+    __shared__ AT hbuf[kSepRows * kSepTileW * CN];
+    constexpr int LEFT = KS / 2 - 1;          // taps s - LEFT .. s + KS / 2
+    const int x0 = blockIdx.x * kSepTileW, y0 = blockIdx.y * kSepTileH;
+    const int ylast = min(y0 + kSepTileH, dh) - 1;
+    const int rmin = clip_index(yofs[y0] - LEFT, sh), rmax = clip_index(yofs[ylast] + KS / 2, sh);
+    const int nrows = rmax - rmin + 1;
+    for (int idx = threadIdx.x; idx < nrows * kSepTileW; idx += 256) {
+        const int r = idx / kSepTileW, lx = idx - r * kSepTileW, dx = x0 + lx;
+        if (dx >= dw) continue;
+        const T *row = src + (ptrdiff_t)(rmin + r) * sstride;
+        const int s0 = xofs[dx] - LEFT;
+        AT hsum[CN];
+#pragma unroll
+        for (int j = 0; j < KS; j++) {
+            const int sx = clip_index(s0 + j, sw) * CN;
+            const CT a = xa[dx * KS + j];
+#pragma unroll
+            for (int c = 0; c < CN; c++) {
+                if constexpr (sizeof(T) == 1) {
+                    const AT term = (AT)((int)row[sx + c] * (int)a);
+                    hsum[c] = j == 0 ? term : hsum[c] + term;
+                } else {
+                    const AT term = row[sx + c] * a;
+                    hsum[c] = j == 0 ? term : hsum[c] + term;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CN; c++) hbuf[(r * kSepTileW + lx) * CN + c] = hsum[c];
     }
-    VKX_HIP(hipStreamSynchronize(ctx->stream)); // the tables live on this frame
-    *xofs = (const int *)(base + o0); *xcoef = base + o1; *yofs = (const int *)(base + o2); *ycoef = base + o3;
+    __syncthreads();
+    const int lx = threadIdx.x & 63, dx = x0 + lx;
+    if (dx >= dw) return;
+    for (int y = y0 + (threadIdx.x >> 6); y <= ylast; y += 4) {
+        const int t0 = yofs[y] - LEFT;
+        AT acc[CN];
+#pragma unroll
+        for (int k = 0; k < KS; k++) {
+            const AT *h = hbuf + ((clip_index(t0 + k, sh) - rmin) * kSepTileW + lx) * CN;
+            const CT b = yb[y * KS + k];
+#pragma unroll
+            for (int c = 0; c < CN; c++) {
+                if constexpr (sizeof(T) == 1) {
+                    const AT term = h[c] * (AT)(int)b;
+                    acc[c] = k == 0 ? term : acc[c] + term;
+                } else {
+                    const AT term = h[c] * b;
+                    acc[c] = k == 0 ? term : acc[c] + term;
+                }
+            }
+        }
+        T *out = dst + (ptrdiff_t)y * dstride + (ptrdiff_t)dx * CN;
+#pragma unroll
+        for (int c = 0; c < CN; c++) {
+            if constexpr (sizeof(T) == 1) {
+                const int r = ((int)(acc[c] + (1u << 21))) >> 22;
+                out[c] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+            } else {
+                out[c] = acc[c];
+            }
+        }
+    }
+}
+
+// can every 16-row destination tile keep its source rows in LDS?
+bool separable_fits(const std::vector<int> &yofs, int sh, int dh, int ks)
+{
+    static const bool force_direct = getenv("VKX_RESIZE_DIRECT") != nullptr;   // parity aid: the two forms must agree
+    if (force_direct) return false;
+    const int left = ks / 2 - 1;
+    auto clip = [sh](int v) { return v < 0 ? 0 : (v >= sh ? sh - 1 : v); };
+    for (int y0 = 0; y0 < dh; y0 += kSepTileH) {
+        const int ylast = std::min(y0 + kSepTileH, dh) - 1;
+        if (clip(yofs[ylast] + ks / 2) - clip(yofs[y0] - left) + 1 > kSepRows) return false;
+    }
+    return true;
+}
+
+template <int KS>
+void launch_sep_u8(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t sstride, uint8_t *dst, int dh, int dw,
+                   ptrdiff_t dstride, const int *xofs, const short *xa, const int *yofs, const short *yb)
+{
+    dim3 grid(vkx_blocks(dw, kSepTileW), vkx_blocks(dh, kSepTileH));
+    switch (cn) {
+    case 1: k_resize_sep<uint8_t, short, unsigned, 1, KS><<<grid, 256, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, xofs, xa, yofs, yb); break;
+    case 3: k_resize_sep<uint8_t, short, unsigned, 3, KS><<<grid, 256, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, xofs, xa, yofs, yb); break;
+    default: k_resize_sep<uint8_t, short, unsigned, 4, KS><<<grid, 256, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, xofs, xa, yofs, yb); break;
+    }
+}
+
+// The four tables (column offsets + coefficients, row offsets + coefficients) of a CUBIC (taps = 4) or LANCZOS4
+// (taps = 8) resize in device memory, from the ctx cache when the geometry was seen recently.
+int resize_tables(vkx_ctx *ctx, int taps, bool fixed, int sh, int sw, int dh, int dw, const int **xofs, const void **xcoef,
+                  const int **yofs, const void **ycoef, const std::vector<int> **yofs_host)
+{
+    const int key[6] = {taps, fixed ? 1 : 0, sh, sw, dh, dw};
+    vkx_ctx::ResizeTabs *slot = nullptr;
+    for (auto &t : ctx->resize_tabs)
+        if (std::equal(key, key + 6, t.key)) slot = &t;
+    if (!slot) {
+        slot = &ctx->resize_tabs[0];
+        for (auto &t : ctx->resize_tabs)
+            if (t.stamp < slot->stamp) slot = &t;
+        std::vector<int> xo, yo;
+        std::vector<float> xc, yc;
+        std::vector<short> xi, yi;
+        if (taps == 4) {
+            AxisTable tx, ty;
+            build_axis(sw, dw, &tx);
+            build_axis(sh, dh, &ty);
+            xo.swap(tx.ofs); yo.swap(ty.ofs); xc.swap(tx.coef); yc.swap(ty.coef); xi.swap(tx.icoef); yi.swap(ty.icoef);
+        } else {
+            AxisTable8 tx, ty;
+            build_axis8(sw, dw, &tx);
+            build_axis8(sh, dh, &ty);
+            xo.swap(tx.ofs); yo.swap(ty.ofs); xc.swap(tx.coef); yc.swap(ty.coef); xi.swap(tx.icoef); yi.swap(ty.icoef);
+        }
+        const size_t csz = fixed ? sizeof(short) : sizeof(float);
+        auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        slot->off[0] = 0;
+        slot->off[1] = slot->off[0] + up(sizeof(int) * dw);
+        slot->off[2] = slot->off[1] + up(csz * taps * dw);
+        slot->off[3] = slot->off[2] + up(sizeof(int) * dh);
+        slot->key[0] = -1;                        // invalid until the upload below has succeeded
+        int rc = vkx_scratch_reserve(ctx, &slot->buf, slot->off[3] + up(csz * taps * dh));
+        if (rc) return rc;
+        unsigned char *base = (unsigned char *)slot->buf.ptr;
+        VKX_HIP(hipMemcpyAsync(base + slot->off[0], xo.data(), sizeof(int) * dw, hipMemcpyHostToDevice, ctx->stream));
+        VKX_HIP(hipMemcpyAsync(base + slot->off[2], yo.data(), sizeof(int) * dh, hipMemcpyHostToDevice, ctx->stream));
+        const void *xsrc = fixed ? (const void *)xi.data() : (const void *)xc.data();
+        const void *ysrc = fixed ? (const void *)yi.data() : (const void *)yc.data();
+        VKX_HIP(hipMemcpyAsync(base + slot->off[1], xsrc, csz * taps * dw, hipMemcpyHostToDevice, ctx->stream));
+        VKX_HIP(hipMemcpyAsync(base + slot->off[3], ysrc, csz * taps * dh, hipMemcpyHostToDevice, ctx->stream));
+        VKX_HIP(hipStreamSynchronize(ctx->stream)); // the host tables live on this frame
+        slot->yofs.swap(yo);
+        std::copy(key, key + 6, slot->key);
+    }
+    slot->stamp = ++ctx->resize_clock;
+    unsigned char *base = (unsigned char *)slot->buf.ptr;
+    *xofs = (const int *)(base + slot->off[0]); *xcoef = base + slot->off[1];
+    *yofs = (const int *)(base + slot->off[2]); *ycoef = base + slot->off[3];
+    *yofs_host = &slot->yofs;
     return VKX_OK;
 }
 
@@ -653,10 +811,16 @@ VKX_EXPORT int vkx_resize_cubic_u8_dev(vkx_ctx *ctx, const uint8_t *src, int sh,
     VKX_REQUIRE(cn == 1 || cn == 3 || cn == 4, "1, 3 or 4 channels");
     const int *xofs, *yofs;
     const void *xa, *yb;
-    int rc = stage_tables(ctx, sh, sw, dh, dw, true, &xofs, &xa, &yofs, &yb);
+    const std::vector<int> *yh;
+    int rc = resize_tables(ctx, 4, true, sh, sw, dh, dw, &xofs, &xa, &yofs, &yb, &yh);
     if (rc) return rc;
     dim3 grid(vkx_blocks(dw, 64), vkx_blocks(dh, 4));
     VKX_TIMED(ctx, "k_resize_cubic");
+    if (separable_fits(*yh, sh, dh, 4)) {
+        launch_sep_u8<4>(ctx, src, sh, sw, cn, src_stride, dst, dh, dw, dst_stride, xofs, (const short *)xa, yofs, (const short *)yb);
+        VKX_LAUNCH_CHECK();
+        return VKX_OK;
+    }
     switch (cn) {
     case 1: k_resize_cubic_u8<1><<<grid, 256, 0, ctx->stream>>>(src, sh, sw, src_stride, dst, dh, dw, dst_stride, xofs, (const short *)xa, yofs, (const short *)yb); break;
     case 3: k_resize_cubic_u8<3><<<grid, 256, 0, ctx->stream>>>(src, sh, sw, src_stride, dst, dh, dw, dst_stride, xofs, (const short *)xa, yofs, (const short *)yb); break;
@@ -673,10 +837,18 @@ VKX_EXPORT int vkx_resize_cubic_f32_dev(vkx_ctx *ctx, const float *src, int sh, 
     VKX_REQUIRE(sh > 0 && sw > 0 && dh > 0 && dw > 0, "bad shape");
     const int *xofs, *yofs;
     const void *xc, *yc;
-    int rc = stage_tables(ctx, sh, sw, dh, dw, false, &xofs, &xc, &yofs, &yc);
+    const std::vector<int> *yh;
+    int rc = resize_tables(ctx, 4, false, sh, sw, dh, dw, &xofs, &xc, &yofs, &yc, &yh);
     if (rc) return rc;
     dim3 grid(vkx_blocks(dw, 64), vkx_blocks(dh, 4));
     VKX_TIMED(ctx, "k_resize_cubic");
+    if (separable_fits(*yh, sh, dh, 4)) {
+        dim3 sgrid(vkx_blocks(dw, kSepTileW), vkx_blocks(dh, kSepTileH));
+        k_resize_sep<float, float, float, 1, 4><<<sgrid, 256, 0, ctx->stream>>>(src, sh, sw, src_stride_el, dst, dh, dw, dst_stride_el,
+                                                                                 xofs, (const float *)xc, yofs, (const float *)yc);
+        VKX_LAUNCH_CHECK();
+        return VKX_OK;
+    }
     k_resize_cubic_f32<<<grid, 256, 0, ctx->stream>>>(src, sh, sw, src_stride_el, dst, dh, dw, dst_stride_el, xofs,
                                                       (const float *)xc, yofs, (const float *)yc);
     VKX_LAUNCH_CHECK();
@@ -706,27 +878,36 @@ VKX_EXPORT int vkx_resize_u8_dev(vkx_ctx *ctx, const uint8_t *src, int sh, int s
         return resize_nearest_exact(ctx, src, sh, sw, cn, src_stride, dst, dh, dw, dst_stride);
     if (interpolation == VKX_INTER_AREA) return resize_area<false>(ctx, src, sh, sw, cn, src_stride, dst, dh, dw, dst_stride);
     if (interpolation == VKX_INTER_LANCZOS4) {
-        AxisTable8 tx, ty;
-        build_axis8(sw, dw, &tx);
-        build_axis8(sh, dh, &ty);
-        std::vector<const void *> p;
-        int rc = stage_arrays(ctx, {{tx.ofs.data(), sizeof(int) * dw}, {tx.icoef.data(), sizeof(short) * 8 * dw},
-                                    {ty.ofs.data(), sizeof(int) * dh}, {ty.icoef.data(), sizeof(short) * 8 * dh}}, &p);
+        const int *xofs, *yofs;
+        const void *xa, *yb;
+        const std::vector<int> *yh;
+        int rc = resize_tables(ctx, 8, true, sh, sw, dh, dw, &xofs, &xa, &yofs, &yb, &yh);
         if (rc) return rc;
         VKX_TIMED(ctx, "k_resize_lanczos4");
-        VKX_CN_SWITCH(cn, k_resize_lanczos4_u8, src, sh, sw, src_stride, dst, dh, dw, dst_stride, (const int *)p[0], (const short *)p[1], (const int *)p[2], (const short *)p[3])
+        if (separable_fits(*yh, sh, dh, 8)) {
+            launch_sep_u8<8>(ctx, src, sh, sw, cn, src_stride, dst, dh, dw, dst_stride, xofs, (const short *)xa, yofs, (const short *)yb);
+            VKX_LAUNCH_CHECK();
+            return VKX_OK;
+        }
+        VKX_CN_SWITCH(cn, k_resize_lanczos4_u8, src, sh, sw, src_stride, dst, dh, dw, dst_stride, xofs, (const short *)xa, yofs, (const short *)yb)
         VKX_LAUNCH_CHECK();
         return VKX_OK;
     }
     if (interpolation == VKX_INTER_LINEAR_EXACT && !(sw == 2 * dw && sh == 2 * dh)) {
-        std::vector<int> xo, xw, yo, yw;
-        int xmin, xmax, ymin, ymax;
-        build_linear_exact_axis(sw, dw, &xo, &xw, &xmin, &xmax);
-        build_linear_exact_axis(sh, dh, &yo, &yw, &ymin, &ymax);
+        std::vector<int> xo, xw, yo, yw;     // filled on a cache miss only
         std::vector<const void *> p;
-        int rc = stage_arrays(ctx, {{xo.data(), sizeof(int) * dw}, {xw.data(), sizeof(int) * dw}, {yo.data(), sizeof(int) * dh},
-                                    {yw.data(), sizeof(int) * dh}}, &p);
+        const std::vector<int> *meta;
+        const int key[6] = {105, 0, sh, sw, dh, dw};
+        int rc = cached_tables(ctx, key, [&](std::vector<std::pair<const void *, size_t>> *arrays, std::vector<int> *m) {
+            int xmin_, xmax_, ymin_, ymax_;
+            build_linear_exact_axis(sw, dw, &xo, &xw, &xmin_, &xmax_);
+            build_linear_exact_axis(sh, dh, &yo, &yw, &ymin_, &ymax_);
+            *arrays = {{xo.data(), sizeof(int) * dw}, {xw.data(), sizeof(int) * dw}, {yo.data(), sizeof(int) * dh},
+                       {yw.data(), sizeof(int) * dh}};
+            *m = {xmin_, xmax_, ymin_, ymax_};
+        }, &p, &meta);
         if (rc) return rc;
+        const int xmin = (*meta)[0], xmax = (*meta)[1], ymin = (*meta)[2], ymax = (*meta)[3];
         VKX_TIMED(ctx, "k_resize_linear_exact");
         VKX_CN_SWITCH(cn, k_resize_linear_exact_u8, src, src_stride, dst, dh, dw, dst_stride, (const int *)p[0], (const int *)p[1], (const int *)p[2], (const int *)p[3], xmin, xmax, ymin, ymax)
         VKX_LAUNCH_CHECK();
@@ -802,16 +983,21 @@ VKX_EXPORT int vkx_resize_f32_dev(vkx_ctx *ctx, const float *src, int sh, int sw
         return VKX_OK;
     }
     case VKX_INTER_LANCZOS4: {
-        AxisTable8 tx, ty;
-        build_axis8(sw, dw, &tx);
-        build_axis8(sh, dh, &ty);
-        std::vector<const void *> p;
-        int rc = stage_arrays(ctx, {{tx.ofs.data(), sizeof(int) * dw}, {tx.coef.data(), sizeof(float) * 8 * dw},
-                                    {ty.ofs.data(), sizeof(int) * dh}, {ty.coef.data(), sizeof(float) * 8 * dh}}, &p);
+        const int *xofs, *yofs;
+        const void *xc, *yc;
+        const std::vector<int> *yh;
+        int rc = resize_tables(ctx, 8, false, sh, sw, dh, dw, &xofs, &xc, &yofs, &yc, &yh);
         if (rc) return rc;
         VKX_TIMED(ctx, "k_resize_lanczos4");
-        k_resize_lanczos4_f32<<<grid, 256, 0, ctx->stream>>>(src, sh, sw, src_stride_el, dst, dh, dw, dst_stride_el, (const int *)p[0],
-                                                             (const float *)p[1], (const int *)p[2], (const float *)p[3]);
+        if (separable_fits(*yh, sh, dh, 8)) {
+            dim3 sgrid(vkx_blocks(dw, kSepTileW), vkx_blocks(dh, kSepTileH));
+            k_resize_sep<float, float, float, 1, 8><<<sgrid, 256, 0, ctx->stream>>>(src, sh, sw, src_stride_el, dst, dh, dw, dst_stride_el,
+                                                                                     xofs, (const float *)xc, yofs, (const float *)yc);
+            VKX_LAUNCH_CHECK();
+            return VKX_OK;
+        }
+        k_resize_lanczos4_f32<<<grid, 256, 0, ctx->stream>>>(src, sh, sw, src_stride_el, dst, dh, dw, dst_stride_el, xofs,
+                                                             (const float *)xc, yofs, (const float *)yc);
         VKX_LAUNCH_CHECK();
         return VKX_OK;
     }

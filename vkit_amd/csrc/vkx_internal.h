@@ -58,6 +58,18 @@ struct vkx_ctx {
     vkx_scratch stage[6]; // staging planes of the host-pointer entry points
     vkx_scratch chain[2]; // ping-pong planes of the batched chain entry point
 
+    // The tap tables of the last few CUBIC / LANCZOS4 resize geometries (PageResizingStep resizes seven elements with one
+    // geometry: the tables are built and uploaded for the first one only).
+    struct ResizeTabs {
+        int key[6] = {-1, -1, -1, -1, -1, -1};    // taps, fixed point?, sh, sw, dh, dw
+        vkx_scratch buf;
+        size_t off[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // the tables inside buf (xofs, xcoef, yofs, ycoef for the tap kernels)
+        std::vector<int> yofs;                    // host side: row offsets (tile planning) or other small metadata
+        unsigned long stamp = 0;
+    };
+    ResizeTabs resize_tabs[6];
+    unsigned long resize_clock = 0;
+
     // Optional per-kernel timing with HIP events recorded on the launch stream (vkx_ctx_set_timing).
     bool timing = false;
     struct TimedLaunch { int name_id; hipEvent_t start, stop; };
