@@ -244,13 +244,19 @@ def main():
     chain_bytes = (3 * S + 3 * D) * B       # the fully fused figure for the whole chain, per step
     # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), measured in separate
     # rocprofv3 --pmc passes (profiles/) on the same workload and scaled by the number of images of this launch.
-    traffic, traffic_source = None, None
+    traffic, traffic_source, valu_issue = None, None, None
     tpath = os.path.join(ROOT, 'profiles', 'r1l_traffic.json')
     if dominant == 'k_chain_fused' and size == 2048 and os.path.exists(tpath):
         with open(tpath) as fin:
             tj = json.load(fin)
         traffic = tj['hbm_bytes_per_image'] * B
         traffic_source = 'profiles/r1l_traffic.json'
+        if 'valu_insts_per_image' in tj and avg_s > 0:
+            # why the HBM fraction is what it is: wavefront VALU instructions (PMC, same profile) at one issue per 4 cycles
+            # on 1024 SIMDs (256 CUs x 4) at 2.4 GHz, against the measured launch time
+            floor_s = tj['valu_insts_per_image'] * B / 1024 * 4 / 2.4e9
+            valu_issue = {'insts_per_wavefront': round(tj['valu_insts_per_wavefront']), 'floor_ms': floor_s * 1e3,
+                          'frac_of_launch': floor_s / avg_s}
     kernel_sum_s = sum(v[0] for v in kernel_times.values()) / 1e3 / args.steps
     result = {
         'metric': 'Mpixels/s (2048^2 RGB, geo+photo chain)',
@@ -285,6 +291,7 @@ def main():
             'frac': achieved / HBM_PEAK_GBS,
             'traffic': traffic,
             'traffic_source': traffic_source,
+            'valu_issue': valu_issue,
             'avg_launch_ms': avg_s * 1e3,
             'algorithmic_bytes_per_launch': algorithmic.get(dominant, 0),
             'noise_input_bytes_per_launch': noise_input_bytes if dominant == 'k_chain_fused' else 0,

@@ -68,6 +68,9 @@ def main():
         fout.write('\n'.join(lines))
     if 'k_chain_fused' in traffic:
         t = traffic['k_chain_fused']
+        d = {c: sums['k_chain_fused'][c] / counts['k_chain_fused'][c] for c in sums['k_chain_fused']}
+        if 'SQ_INSTS_VALU' in d and 'SQ_WAVES' in d:
+            t.update(valu_insts_per_image=d['SQ_INSTS_VALU'] / images, valu_insts_per_wavefront=d['SQ_INSTS_VALU'] / d['SQ_WAVES'])
         t.update(source=f'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, batch {images} '
                         f'(profiles/{tag}_pmc_batch{images}.md); FETCH_SIZE doubled (gfx950), WRITE_SIZE as reported',
                  images=images)
