@@ -4,27 +4,24 @@ from typing import Tuple
 
 
 class Shapable:
-    """Anything with a (height, width)."""
+    """Mixin for everything that occupies ``height`` x ``width`` pixels; subclasses provide the two extents."""
 
-    @property
-    def height(self) -> int:
-        raise NotImplementedError()
-
-    @property
-    def width(self) -> int:
-        raise NotImplementedError()
-
-    @property
-    def area(self) -> int:
-        return self.height * self.width
+    height: int
+    width: int
 
     @property
     def shape(self) -> Tuple[int, int]:
-        return self.height, self.width
+        return (self.height, self.width)
+
+    @property
+    def area(self) -> int:
+        h, w = self.shape
+        return h * w
 
 
 @unique
 class ElementSetOperationMode(Enum):
-    UNION = 'union'          # covered by one or more elements
-    DISTINCT = 'distinct'    # covered by exactly one element
-    INTERSECT = 'intersect'  # covered by more than one element
+    """How overlapping elements combine: covered by any / by exactly one / by several of them."""
+    UNION = 'union'
+    DISTINCT = 'distinct'
+    INTERSECT = 'intersect'

@@ -1,9 +1,9 @@
 """``DistortionPolicy``: a distortion + a level-driven config generator (reference: distortion_policy/type.py)."""
-from typing import Any, Generic, Iterable, Mapping, Optional, Tuple, Type, TypeVar, Union
+from typing import Any, Generic, Mapping, Optional, Tuple, Type, TypeVar, Union
 
 from numpy.random import Generator as RandomGenerator
 
-from vkit_amd.element import Image, Mask, Point, PointList, PointTuple, Polygon, ScoreMap, Shapable
+from vkit_amd.element import Shapable
 from vkit_amd.utility import PathType, dyn_structure, get_generic_classes
 from ..distortion.interface import Distortion, DistortionConfig, DistortionState
 
@@ -40,37 +40,14 @@ class DistortionPolicy(Generic[_T_GENERATOR_CONFIG, _T_CONFIG, _T_STATE]):
         self.config_for_config_generator = config_for_config_generator
         self.config_generator_cls = config_generator_cls
 
-    def distort(
-        self,
-        level: int,
-        shapable_or_shape: Optional[Union[Shapable, Tuple[int, int]]] = None,
-        image: Optional[Image] = None,
-        mask: Optional[Mask] = None,
-        score_map: Optional[ScoreMap] = None,
-        point: Optional[Point] = None,
-        points: Optional[Union[PointList, PointTuple, Iterable[Point]]] = None,
-        corner_points: Optional[Union[PointList, PointTuple, Iterable[Point]]] = None,
-        polygon: Optional[Polygon] = None,
-        polygons: Optional[Iterable[Polygon]] = None,
-        rng: Optional[RandomGenerator] = None,
-        enable_debug: bool = False,
-    ):
-        generator = self.config_generator_cls(self.config_for_config_generator, level)
+    def distort(self, level: int, shapable_or_shape: Optional[Union[Shapable, Tuple[int, int]]] = None, *,
+                rng: Optional[RandomGenerator] = None, enable_debug: bool = False, **elements):
+        """Samples a config for ``level`` and applies the distortion to the given elements -- any of ``image``,
+        ``mask``, ``score_map``, ``point``, ``points``, ``corner_points``, ``polygon``, ``polygons``, passed through
+        to ``Distortion.distort`` (reference type.py:84-118); with ``enable_debug`` the result carries config and state."""
         return self.distortion.distort(
-            config_or_config_generator=generator,
-            shapable_or_shape=shapable_or_shape,
-            image=image,
-            mask=mask,
-            score_map=score_map,
-            point=point,
-            points=points,
-            corner_points=corner_points,
-            polygon=polygon,
-            polygons=polygons,
-            rng=rng,
-            get_config=enable_debug,
-            get_state=enable_debug,
-        )
+            self.config_generator_cls(self.config_for_config_generator, level), shapable_or_shape,
+            rng=rng, get_config=enable_debug, get_state=enable_debug, **elements)
 
     @property
     def name(self):
