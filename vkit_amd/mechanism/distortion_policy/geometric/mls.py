@@ -1,6 +1,7 @@
 """Config generator of ``similarity_mls`` (reference: distortion_policy/geometric/mls.py): a lattice of handle
 points whose spacings are shuffled, each handle displaced by a level-dependent integer radius."""
-from typing import List, Tuple
+import itertools
+from typing import Tuple
 
 import attrs
 from numpy.random import Generator as RandomGenerator
@@ -27,47 +28,40 @@ class SimilarityMlsConfigGenerator(
 
     @classmethod
     def generate_coord(cls, length: int, step: int, rng: RandomGenerator):
-        """0 .. length-1 split into shuffled segments of ``step`` (the remainder joins the last one)."""
+        """Cut positions of ``0 .. length - 1``: whole ``step`` segments (the remainder is added to one of them), in a
+        shuffled order.  One ``rng.shuffle`` of a Python list, like the reference (:48-64)."""
         end = length - 1
-        if end % step == 0:
-            steps = [step] * (end // step)
-        else:
-            steps = [step] * (end // step - 1)
-            steps.append(step + end % step)
-        assert sum(steps) == end
-        rng.shuffle(steps)
-        coord: List[int] = [0]
-        for seg in steps:
-            coord.append(coord[-1] + seg)
-        return coord
+        whole, rest = divmod(end, step)
+        segments = [step] * whole
+        if rest:
+            segments[-1] += rest
+        assert sum(segments) == end
+        rng.shuffle(segments)
+        return list(itertools.accumulate(segments, initial=0))
 
     def __call__(self, shape: Tuple[int, int], rng: RandomGenerator):
-        height, width = shape
-        short_side = min(shape)
-        num_segments = rng.integers(self.config.num_segments_min, self.config.num_segments_max + 1)
-        step = (short_side - 1) // num_segments
-        if step < self.config.step_min:
-            step = short_side - 1  # too dense: corners only
+        cfg = self.config
+        # draw order (the contract): segment count, row shuffle, column shuffle, radius ratio, then (dy, dx) per handle
+        num_segments = rng.integers(cfg.num_segments_min, cfg.num_segments_max + 1)
+        step = (min(shape) - 1) // num_segments
+        if step < cfg.step_min:
+            step = min(shape) - 1          # too dense for this page: only the corners stay
+        rows = self.generate_coord(shape[0], step, rng)
+        cols = self.generate_coord(shape[1], step, rng)
+        handles = PointList(Point.create(y=y, x=x) for y, x in itertools.product(rows, cols))
 
-        coord_y = self.generate_coord(height, step, rng)
-        coord_x = self.generate_coord(width, step, rng)
-        src_handle_points = PointList(Point.create(y=y, x=x) for y in coord_y for x in coord_x)
+        assert cfg.radius_max_ratio_max < 0.5       # neighbouring handles cannot cross
+        ratio = sample_float(self.level, cfg.radius_max_ratio_min, cfg.radius_max_ratio_max, None, rng,
+                             mode=SampleFloatMode.QUAD)
+        radius = int(ratio * step)
 
-        assert self.config.radius_max_ratio_max < 0.5
-        radius_max_ratio = sample_float(self.level, self.config.radius_max_ratio_min,
-                                        self.config.radius_max_ratio_max, None, rng, mode=SampleFloatMode.QUAD)
-        radius = int(radius_max_ratio * step)
-        dst_handle_points = PointList()
-        for point in src_handle_points:
-            delta_y = rng.integers(-radius, radius + 1)
-            delta_x = rng.integers(-radius, radius + 1)
-            dst_handle_points.append(Point.create(y=point.y + delta_y, x=point.x + delta_x))
+        def jitter(value: int) -> int:
+            return value + rng.integers(-radius, radius + 1)
 
+        moved = PointList(Point.create(y=jitter(p.y), x=jitter(p.x)) for p in handles)      # y is drawn before x
         return distortion.SimilarityMlsConfig(
-            src_handle_points=src_handle_points.to_point_tuple(),
-            dst_handle_points=dst_handle_points.to_point_tuple(),
-            grid_size=generate_grid_size(self.config.grid_size_min, self.config.grid_size_ratio, shape),
-        )
+            src_handle_points=handles.to_point_tuple(), dst_handle_points=moved.to_point_tuple(),
+            grid_size=generate_grid_size(cfg.grid_size_min, cfg.grid_size_ratio, shape))
 
 
 similarity_mls_policy_factory = DistortionPolicyFactory(distortion.similarity_mls, SimilarityMlsConfigGenerator)
