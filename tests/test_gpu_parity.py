@@ -505,3 +505,23 @@ def test_grid_distortion_points_and_polygons_batch(N):
         for p, q in zip(poly.points, out.points):
             ref = FuncImageGridBased.func_point(cfg, st, shape, p, None)
             assert (q.y, q.x) == (ref.y, ref.x)
+
+
+def test_fused_chain_hue_shift_whole_colour_cube(N):
+    """Every RGB triple through the fused chain kernel (identity lattice, hue shift only): its HSV round trip carries
+    the hue modulo 256 and takes floor / fraction of the sector in integers -- same bytes as the staged cvtColor pair."""
+    from types import SimpleNamespace
+    from vkit_amd.batch import ChainBatch
+    v = np.arange(256, dtype=np.uint8)
+    cube = np.ascontiguousarray(np.stack(np.meshgrid(v, v, v, indexing='ij'), -1).reshape(4096, 4096, 3))
+    coords = list(range(0, 4096, 64)) + [4095]
+    lattice = np.array([[(x, y) for x in coords] for y in coords], np.int32)
+    state = SimpleNamespace(result_shape=(4096, 4096), src_image_grid=SimpleNamespace(vertices=lattice),
+                            dst_image_grid=SimpleNamespace(vertices=lattice))
+    for delta in (37, -100, 255):
+        batch = ChainBatch()
+        batch.add(cube, state, blur_sigma=None, hue_delta=delta, noise=None)
+        batch.run()
+        got = batch.result(0)
+        batch.close()
+        assert (got == O.color_shift_rgb(cube, delta)).all(), delta

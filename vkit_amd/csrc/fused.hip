@@ -261,8 +261,8 @@ struct HsvLut {
 __device__ __forceinline__ void hue_shift_px(const int *sdiv, const int *hdiv, int delta, int &r, int &g, int &b)
 {
     int H, S, V;
-    vkd::rgb2hsv_full(sdiv, hdiv, r, g, b, H, S, V);
-    H = (H + delta) & 255;   // python modulo 256 of a sum that may be negative
+    vkd::rgb2hsv_full<true>(sdiv, hdiv, r, g, b, H, S, V);
+    H = (H + delta) & 255;   // python modulo 256 of a sum that may be negative (H itself is only valid modulo 256 here)
     vkd::hsv2rgb_full(H, S, V, r, g, b);
 }
 

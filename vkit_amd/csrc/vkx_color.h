@@ -10,6 +10,10 @@ namespace vkd {
 
 // sdiv[i] = cvRound((255 << 12) / i), hdiv[i] = cvRound((256 << 12) / (6 i)): both < 2^24, and diff, |hh| < 2^11, so the
 // 24-bit multiplies (full rate) are exact.
+// WRAP_H: leave the hue as computed, valid modulo 256 (callers that add a shift and reduce modulo 256 anyway).
+// Otherwise the negative half is moved up by 256; the quotient then lies in 0..255 by construction (|hh| <= 5 diff before
+// the division, so at most 213 after it, at least -43): saturate_cast has nothing to clamp.
+template <bool WRAP_H = false>
 __device__ __forceinline__ void rgb2hsv_full(const int *sdiv, const int *hdiv, int r, int g, int b, int &H, int &S, int &V)
 {
     const int v = max(b, max(g, r)), vmin = min(b, min(g, r));
@@ -21,8 +25,8 @@ __device__ __forceinline__ void rgb2hsv_full(const int *sdiv, const int *hdiv, i
     // product became a quarter-rate 64-bit multiply)
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(hh) : "v"(hh), "v"(hdiv[diff]), "s"(1 << 11));
     hh >>= 12;
-    hh += hh < 0 ? 256 : 0;
-    H = clamp_u8(hh);
+    if (!WRAP_H) hh += hh < 0 ? 256 : 0;
+    H = hh;
     V = v;
 }
 
@@ -33,9 +37,10 @@ __device__ __forceinline__ void hsv2rgb_full(int H, int S, int V, int &r, int &g
 {
     const float s = S * (1.0f / 255.0f);
     const float fv = V * (1.0f / 255.0f);
-    float h = (float)H * (6.0f / 256);
-    const int sector = (int)h;                 // h >= 0: truncation == floor
-    h -= (float)sector;
+    // h = H * 6 / 256 is exact in float32 (6 / 256 = 3 / 128, H * 6 < 2^11): its floor and fraction in integers
+    const int h6 = __mul24(H, 6);
+    const int sector = h6 >> 8;
+    const float h = (float)(h6 & 255) * (1.0f / 256);
     const bool odd = sector & 1;
     const int rot = sector >> 1;
     // t2 = fv (1 - s h) serves the odd sectors, t3 = fv (1 - s (1 - h)) the even ones: only the one in use is evaluated
