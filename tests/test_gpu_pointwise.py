@@ -399,3 +399,25 @@ def test_defocus_and_motion_blur_match_oracle():
     # a horizontal line at angle 0 only blurs along x (plus the anti-aliasing spread)
     k0 = B.motion_kernel(2, 0, 0.5)
     assert k0[3].sum() > 0.75 * k0.sum()
+
+
+@pytest.mark.gpu
+def test_resize_table_cache_survives_eviction():
+    """The context keeps the tap tables of the last few resize geometries: cycling through more geometries than slots,
+    interleaving interpolations and dtypes, must keep returning the oracle's planes (stale or mixed-up tables would not)."""
+    from vkit_amd import _native as N
+    import oracle as O
+    rng = np.random.default_rng(99)
+    img = rng.integers(0, 256, (61, 83, 3), dtype=np.uint8)
+    plane = rng.random((61, 83), dtype=np.float32)
+    sizes = [(40, 50), (90, 120), (61, 84), (30, 83), (122, 166), (45, 45), (100, 30), (64, 64), (40, 50), (90, 120)]
+    for rep in range(3):
+        for dh, dw in sizes:
+            for inter in (2, 4, 5, 3):
+                if inter == 3 and (dh > 61 or dw > 83):
+                    continue
+                assert (N.resize(img, (dh, dw), inter) == O.resize(img, (dh, dw), inter)).all(), (rep, dh, dw, inter)
+                assert (N.resize(plane, (dh, dw), inter) == O.resize(plane, (dh, dw), inter)).all(), (rep, dh, dw, inter)
+    # a different source with a cached geometry must not reuse anything but the tables
+    other = rng.integers(0, 256, (61, 83, 3), dtype=np.uint8)
+    assert (N.resize(other, (90, 120), 4) == O.resize(other, (90, 120), 4)).all()
