@@ -421,3 +421,22 @@ def test_resize_table_cache_survives_eviction():
     # a different source with a cached geometry must not reuse anything but the tables
     other = rng.integers(0, 256, (61, 83, 3), dtype=np.uint8)
     assert (N.resize(other, (90, 120), 4) == O.resize(other, (90, 120), 4)).all()
+
+
+@pytest.mark.gpu
+def test_resize_lanczos4_nan_coefficient_column():
+    """Found by tools/soak.py: when the float32 fraction of a destination index rounds up to exactly 1.0 (e.g. 4 -> 196
+    columns, index 24), interpolateLanczos4 divides 0 by 0 for one tap and the whole coefficient vector becomes
+    (0, 0, 0, 0, NaN, 0, 0, 0).  cv2 turns the NaN into -32768 through saturate_cast<short>(cvRound(NaN)) on uint8 and
+    carries it on float32; both must come out of the GPU path the same way."""
+    from vkit_amd import _native as N
+    import oracle as O
+    rng = np.random.default_rng(0)
+    for (sh, sw), (dh, dw) in (((146, 4), (64, 196)), ((127, 1), (202, 197)), ((4, 146), (196, 64))):
+        for cn in (1, 3, 4):
+            src = rng.integers(0, 256, (sh, sw) if cn == 1 else (sh, sw, cn), dtype=np.uint8)
+            assert (N.resize(src, (dh, dw), 4) == O.resize(src, (dh, dw), 4)).all()
+        plane = rng.random((sh, sw), dtype=np.float32)
+        got, want = N.resize(plane, (dh, dw), 4), O.resize(plane, (dh, dw), 4)
+        assert np.isnan(want).any()
+        assert ((got == want) | (np.isnan(got) & np.isnan(want))).all()

@@ -17,7 +17,7 @@ from vkit_amd import _native as N
 t0 = time.time()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 rng = default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 777)
-counts = dict(chain=0, resize=0, poly=0, fill=0, remap=0)
+counts = dict(chain=0, resize=0, poly=0, fill=0, remap=0, filter2d=0, points=0)
 while time.time() - t0 < budget:
     # fused chain, ragged batch
     grids, names = {}, []
@@ -49,7 +49,16 @@ while time.time() - t0 < budget:
         assert (N.resize(src, (dh, dw), 2) == O.resize_cubic(src, (dh, dw))).all()
         assert (N.resize(src, (dh, dw), 1) == O.resize_linear(src, (dh, dw))).all()
         assert (N.resize(src, (dh, dw), 0) == O.resize_nearest(src, (dh, dw))).all()
-        counts['resize'] += 3
+        for inter in (4, 5, 6):
+            assert (N.resize(src, (dh, dw), inter) == O.resize(src, (dh, dw), inter)).all()
+        if dh <= sh and dw <= sw:
+            assert (N.resize(src, (dh, dw), 3) == O.resize(src, (dh, dw), 3)).all()
+        if cn == 1:
+            plane = rng.random((sh, sw), dtype=np.float32)
+            for inter in (2, 4, 5, 6):
+                got, want = N.resize(plane, (dh, dw), inter), O.resize(plane, (dh, dw), inter)
+                assert ((got == want) | ((got != got) & (want != want))).all()      # NaN taps: see the regression test
+        counts['resize'] += 7
     # polygons
     for _ in range(40):
         h, w = int(rng.integers(1, 150)), int(rng.integers(1, 150))
@@ -57,6 +66,27 @@ while time.time() - t0 < budget:
         pts = np.stack([rng.integers(0, w, n), rng.integers(0, h, n)], axis=1)
         assert (N.fill_poly_mask((h, w), pts) == O.fill_poly((h, w), pts.astype(np.int32))).all()
         counts['poly'] += 1
+    # filter2D with random kernels
+    for _ in range(6):
+        h, w = int(rng.integers(1, 200)), int(rng.integers(1, 200))
+        cn = int(rng.choice([1, 3, 4]))
+        img = rng.integers(0, 256, (h, w) if cn == 1 else (h, w, cn), dtype=np.uint8)
+        kh, kw = int(rng.integers(1, 16)), int(rng.integers(1, 16))
+        kernel = (rng.random((kh, kw)) * (rng.random((kh, kw)) < 0.7)).astype(np.float32)
+        kernel /= max(float(kernel.sum()), 1e-3)
+        assert (N.filter2d(img, kernel) == O.filter2d(img, kernel)).all()
+        counts['filter2d'] += 1
+    # point projection through the first lattice
+    sv, dv, ds, (h, w) = grids['g0']
+    gs = int(sv[1, 0, 1] - sv[0, 0, 1]) if sv.shape[0] > 2 else max(h, w)
+    if sv.shape[0] > 2 and sv.shape[1] > 2:
+        n = 300
+        pts = np.stack([rng.integers(0, (sv.shape[1] - 1) * gs, n), rng.integers(0, (sv.shape[0] - 1) * gs, n)], axis=1)
+        smooth = pts + rng.uniform(-0.5, 0.5, pts.shape)
+        got = N.project_points(sv, dv, gs, pts, smooth)
+        want = O.grid_project_points(sv, dv, gs, pts, smooth)
+        assert (np.abs(got - want) <= 4 * np.spacing(np.abs(want)) + 1e-300).all()
+        counts['points'] += n
     # composite list
     page = rng.integers(0, 256, (150, 200, 3), dtype=np.uint8)
     want = page.copy()

@@ -11,11 +11,21 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <utility>
 
 namespace {
+
+// cvRound of a host float: ties to even, "integer indefinite" (INT_MIN) for NaN and out-of-range values -- a LANCZOS4
+// coefficient can be NaN (fraction rounding up to exactly 1.0f makes one tap 0 / 0), and saturate_cast<short> of that
+// is -32768 in cv2, not whatever a plain (int) cast of NaN yields.
+int cv_round_host(float v)
+{
+    if (!(v >= -2147483648.f && v < 2147483648.f)) return INT_MIN;
+    return (int)std::nearbyint((double)v);
+}
 
 struct AxisTable {
     std::vector<int> ofs;      // floor of the source coordinate
@@ -44,7 +54,7 @@ void build_axis(int ssize, int dsize, AxisTable *t)
         t->ofs[d] = s0;
         cubic_coeffs(f, &t->coef[(size_t)d * 4]);
         for (int k = 0; k < 4; k++) {
-            const int r = (int)std::nearbyint((double)(t->coef[(size_t)d * 4 + k] * 2048.f)); // cvRound: ties to even
+            const int r = cv_round_host(t->coef[(size_t)d * 4 + k] * 2048.f);
             t->icoef[(size_t)d * 4 + k] = (short)(r < -32768 ? -32768 : (r > 32767 ? 32767 : r));
         }
     }
@@ -184,7 +194,7 @@ void build_linear_axis(int ssize, int dsize, bool horizontal, std::vector<int> *
         (*ofs)[d] = s0;
         const float c[2] = {1.f - f, f};
         for (int k = 0; k < 2; k++) {
-            const int r = (int)std::nearbyint((double)(c[k] * 2048.f));
+            const int r = cv_round_host(c[k] * 2048.f);
             (*coef)[(size_t)d * 2 + k] = (short)(r < -32768 ? -32768 : (r > 32767 ? 32767 : r));
         }
     }
@@ -261,7 +271,7 @@ void build_axis8(int ssize, int dsize, AxisTable8 *t)
         t->ofs[d] = s0;
         lanczos4_coeffs(f, &t->coef[(size_t)d * 8]);
         for (int k = 0; k < 8; k++) {
-            const int r = (int)std::nearbyint((double)(t->coef[(size_t)d * 8 + k] * 2048.f));
+            const int r = cv_round_host(t->coef[(size_t)d * 8 + k] * 2048.f);
             t->icoef[(size_t)d * 8 + k] = (short)(r < -32768 ? -32768 : (r > 32767 ? 32767 : r));
         }
     }
