@@ -245,12 +245,12 @@ def main():
     # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), measured in separate
     # rocprofv3 --pmc passes (profiles/) on the same workload and scaled by the number of images of this launch.
     traffic, traffic_source, valu_issue = None, None, None
-    tpath = os.path.join(ROOT, 'profiles', 'r1l_traffic.json')
+    tpath = os.path.join(ROOT, 'profiles', 'r1m_traffic.json')
     if dominant == 'k_chain_fused' and size == 2048 and os.path.exists(tpath):
         with open(tpath) as fin:
             tj = json.load(fin)
         traffic = tj['hbm_bytes_per_image'] * B
-        traffic_source = 'profiles/r1l_traffic.json'
+        traffic_source = 'profiles/r1m_traffic.json'
         if 'valu_insts_per_image' in tj and avg_s > 0:
             # why the HBM fraction is what it is: wavefront VALU instructions (PMC, same profile) at one issue per 4 cycles
             # on 1024 SIMDs (256 CUs x 4) at 2.4 GHz, against the measured launch time
