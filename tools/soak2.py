@@ -106,6 +106,14 @@ while time.time() - t0 < budget:
     for c in range(cn):
         want[:, :, c] = lut[c][want[:, :, c]]
     same(N.apply_lut(src, lut), want.reshape(src.shape), ('apply_lut',))
+    py = rng.integers(0, h, (dh, dw)).astype(np.int32)
+    px = rng.integers(0, w, (dh, dw)).astype(np.int32)
+    same(N.gather(src, py, px), src[py, px], ('gather',))
+    big = rng.integers(-2 ** 40, 2 ** 40, src.shape) if rng.random() < 0.3 else rng.poisson(rng.uniform(0, 300), src.shape)
+    same(N.saturate_i64(big), np.clip(big, 0, 255).astype(np.uint8), ('saturate_i64',))
+    hist = N.histogram(src).reshape(cn, 256)
+    ref = np.stack([np.bincount(src.reshape(h, w, cn)[:, :, c].ravel(), minlength=256) for c in range(cn)])
+    same(hist.astype(np.int64), ref.astype(np.int64), ('histogram',))
     # the two filter2D operators end to end
     radius = int(rng.integers(1, 4))
     aa = float(rng.uniform(0.4, 1.2))
