@@ -44,4 +44,45 @@ while time.time() - t0 < budget:
     assert (mask == want_mask).all() and (score == want_score).all(), (h, w, len(polygons))
     n_polys += len(polygons)
     n_pages += 1
-print('soak3 ok', n_pages, 'planes', n_polys, 'polygons', round(time.time() - t0), 's')
+# composite layer lists on every destination type: uint8 x 1 / 3 / 4 channels and float32, plain / keep-max / keep-min,
+# scalar and plane alpha, masks, constant and plane values
+import oracle as O
+t1 = time.time()
+n_layers = 0
+while time.time() - t1 < budget / 2:
+    h, w = int(rng.integers(1, 200)), int(rng.integers(1, 260))
+    kind = int(rng.integers(0, 4))
+    if kind == 3:
+        page = (rng.random((h, w), dtype=np.float32) * 30).astype(np.float32)
+        cn, dtype = 1, np.float32
+    else:
+        cn = (1, 3, 4)[kind]
+        page = rng.integers(0, 256, (h, w) if cn == 1 else (h, w, cn), dtype=np.uint8)
+        dtype = np.uint8
+    want = page.copy()
+    layers = []
+    for _ in range(int(rng.integers(0, 40))):
+        bh, bw = int(rng.integers(1, h + 1)), int(rng.integers(1, w + 1))
+        up, left = int(rng.integers(0, h - bh + 1)), int(rng.integers(0, w - bw + 1))
+        mode = int(rng.choice([0, 0, 1, 2]))
+        shape = (bh, bw) if cn == 1 else (bh, bw, cn)
+        if rng.random() < 0.5:
+            value = (rng.random(shape, dtype=np.float32) * 40).astype(np.float32) if dtype == np.float32 \
+                else rng.integers(0, 256, shape, dtype=np.uint8)
+        elif dtype == np.float32:
+            value = float(rng.uniform(0, 40))
+        else:
+            value = tuple(int(v) for v in rng.integers(0, 256, cn)) if cn > 1 else int(rng.integers(0, 256))
+        mask = (rng.random((bh, bw)) < 0.6).astype(np.uint8) if rng.random() < 0.4 else None
+        if mask is None and rng.random() < 0.4:
+            alpha = (rng.random((bh, bw), dtype=np.float32) * (rng.random((bh, bw)) < 0.6)).astype(np.float32)
+        elif mask is not None and cn == 1 and dtype == np.uint8:
+            alpha = 1.0           # 2-D uint8 + mask + fractional scalar alpha raises in the reference
+        else:
+            alpha = float(rng.choice([1.0, 1.0, rng.random()]))
+        layers.append(N.make_layer((up, left, bh, bw), cn, value, mask=mask, alpha=alpha, mode=mode, dtype=dtype))
+        O.fill(want, (up, left, bh, bw), value, mask=mask, alpha=alpha, mode=mode)
+    N.fill(page, layers)
+    assert (page == want).all(), (h, w, cn, dtype, len(layers))
+    n_layers += len(layers)
+print('soak3 ok', n_pages, 'planes', n_polys, 'polygons', n_layers, 'composite layers', round(time.time() - t0), 's')
