@@ -520,23 +520,66 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
                 for (int u = 0; u < CGROUP; u++) {
                     const int gy = wy0 + wave * ROWS_PER_WAVE + g0 + u;
                     if (!(rowok[u] && colok)) continue;
+                    // all four taps inside the source (every pixel but a rim of the result): unpredicated loads, two
+                    // samples per load where they are adjacent in memory; the rim takes the generic samplers
+                    const int sx = X[u] >> 5, sy = Y[u] >> 5, fx = X[u] & 31, fy = Y[u] & 31;
+                    const bool inner = (unsigned)sx < fast_xlim && (unsigned)sy < fast_ylim;
+                    const int w00 = (32 - fy) * (32 - fx), w01 = (32 - fy) * fx, w10 = fy * (32 - fx), w11 = fy * fx;
                     for (int e = 0; e < it.n_elems; e++) {
                         const ItemDev::Elem &el = it.el[e];
                         if (el.is_f32) {
-                            ((float *)el.dst)[(ptrdiff_t)gy * el.dstride + gx] =
-                                vkd::sample_f32((const float *)el.src, sh, sw, el.sstride, X[u], Y[u]);
+                            float v;
+                            if (inner) {
+                                typedef float f32x2_u4 __attribute__((ext_vector_type(2), aligned(4)));
+                                const float *q0 = (const float *)el.src + (ptrdiff_t)sy * el.sstride + sx;
+                                const f32x2_u4 a = *(const f32x2_u4 *)q0, b = *(const f32x2_u4 *)(q0 + el.sstride);
+                                const float ax = fx * (1.f / 32), ay = fy * (1.f / 32), bx = 1.f - ax, by = 1.f - ay;
+                                const float p0 = a.x * (by * bx), p1 = a.y * (by * ax), p2 = b.x * (ay * bx), p3 = b.y * (ay * ax);
+                                v = ((p0 + p1) + p2) + p3;
+                            } else {
+                                v = vkd::sample_f32((const float *)el.src, sh, sw, el.sstride, X[u], Y[u]);
+                            }
+                            ((float *)el.dst)[(ptrdiff_t)gy * el.dstride + gx] = v;
                         } else {
                             uint8_t *d = (uint8_t *)el.dst + (ptrdiff_t)gy * el.dstride + (ptrdiff_t)gx * el.cn;
                             const uint8_t *sp = (const uint8_t *)el.src;
                             if (el.cn == 1) {
-                                vkd::sample_u8<1>(sp, sh, sw, el.sstride, X[u], Y[u], d);
+                                if (inner) {
+                                    const uint8_t *q0 = sp + (ptrdiff_t)sy * el.sstride + sx;
+                                    const uint32_t a = *(const u16_u1 *)q0, b = *(const u16_u1 *)(q0 + el.sstride);
+                                    d[0] = (uint8_t)(((a & 0xff) * w00 + (a >> 8) * w01 + (b & 0xff) * w10 + (b >> 8) * w11 + 512) >> 10);
+                                } else {
+                                    vkd::sample_u8<1>(sp, sh, sw, el.sstride, X[u], Y[u], d);
+                                }
                             } else if (el.cn == 3) {
                                 uint8_t p3[3];
-                                vkd::sample_u8<3>(sp, sh, sw, el.sstride, X[u], Y[u], p3);
+                                if (inner) {
+                                    const uint8_t *q0 = sp + (ptrdiff_t)sy * el.sstride + (ptrdiff_t)sx * 3;
+                                    const unsigned long long a = *(const u64_u1 *)q0, b = *(const u64_u1 *)(q0 + el.sstride);
+#pragma unroll
+                                    for (int k = 0; k < 3; k++) {
+                                        const int v0 = (int)((a >> (8 * k)) & 0xff), v1 = (int)((a >> (8 * (k + 3))) & 0xff);
+                                        const int v2 = (int)((b >> (8 * k)) & 0xff), v3 = (int)((b >> (8 * (k + 3))) & 0xff);
+                                        p3[k] = (uint8_t)((v0 * w00 + v1 * w01 + v2 * w10 + v3 * w11 + 512) >> 10);
+                                    }
+                                } else {
+                                    vkd::sample_u8<3>(sp, sh, sw, el.sstride, X[u], Y[u], p3);
+                                }
                                 d[0] = p3[0]; d[1] = p3[1]; d[2] = p3[2];
                             } else {
                                 uint8_t p4[4];
-                                vkd::sample_u8<4>(sp, sh, sw, el.sstride, X[u], Y[u], p4);
+                                if (inner) {
+                                    const uint8_t *q0 = sp + (ptrdiff_t)sy * el.sstride + (ptrdiff_t)sx * 4;
+                                    const unsigned long long a = *(const u64_u1 *)q0, b = *(const u64_u1 *)(q0 + el.sstride);
+#pragma unroll
+                                    for (int k = 0; k < 4; k++) {
+                                        const int v0 = (int)((a >> (8 * k)) & 0xff), v1 = (int)((a >> (8 * (k + 4))) & 0xff);
+                                        const int v2 = (int)((b >> (8 * k)) & 0xff), v3 = (int)((b >> (8 * (k + 4))) & 0xff);
+                                        p4[k] = (uint8_t)((v0 * w00 + v1 * w01 + v2 * w10 + v3 * w11 + 512) >> 10);
+                                    }
+                                } else {
+                                    vkd::sample_u8<4>(sp, sh, sw, el.sstride, X[u], Y[u], p4);
+                                }
                                 *(uint32_t *)d = (uint32_t)p4[0] | ((uint32_t)p4[1] << 8) | ((uint32_t)p4[2] << 16) |
                                                  ((uint32_t)p4[3] << 24);
                             }
