@@ -119,6 +119,12 @@ typedef struct vkx_elem {
 int vkx_grid_remap_dev(vkx_ctx *ctx, const vkx_elem *elems, int n_elems, int sh, int sw,
                        const int32_t *src_vertices, const int32_t *dst_vertices, int rows, int cols,
                        int dh, int dw);
+/* The same elements through an explicit dense map shared by all of them (cv.remap per element with one
+ * (map_x, map_y) pair, grid_blender.py:54-81 when the caller keeps the map of generate_remap_params). */
+int vkx_remap_multi_dev(vkx_ctx *ctx, const vkx_elem *elems, int n_elems, int sh, int sw, const float *map_x,
+                        const float *map_y, ptrdiff_t map_stride_el, int dh, int dw);
+int vkx_remap_multi(vkx_ctx *ctx, const vkx_elem *elems, int n_elems, int sh, int sw, const float *map_x,
+                    const float *map_y, ptrdiff_t map_stride_el, int dh, int dw);
 int vkx_grid_remap(vkx_ctx *ctx, const vkx_elem *elems, int n_elems, int sh, int sw,
                    const int32_t *src_vertices, const int32_t *dst_vertices, int rows, int cols,
                    int dh, int dw);

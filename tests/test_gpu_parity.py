@@ -525,3 +525,24 @@ def test_fused_chain_hue_shift_whole_colour_cube(N):
         got = batch.result(0)
         batch.close()
         assert (got == O.color_shift_rgb(cube, delta)).all(), delta
+
+
+def test_remap_multi_shared_map(N):
+    """vkx_remap_multi: Image + Mask + ScoreMap + a 4-channel plane through one explicit dense map, incl. out-of-range
+    and non-finite map entries -- equal to cv.remap element by element."""
+    rng = default_rng(17)
+    h, w, dh, dw = 93, 121, 80, 150
+    mats = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8), (rng.random((h, w)) < 0.5).astype(np.uint8),
+            rng.random((h, w), dtype=np.float32), rng.integers(0, 256, (h, w, 4), dtype=np.uint8)]
+    mx = rng.uniform(-5, w + 5, (dh, dw)).astype(np.float32)
+    my = rng.uniform(-5, h + 5, (dh, dw)).astype(np.float32)
+    mx[3, 4] = np.nan
+    my[5, 6] = np.inf
+    for got, m in zip(N.remap_multi(mats, mx, my), mats):
+        want = O.remap(m, mx, my)
+        assert got.dtype == want.dtype and (got == want).all()
+    # a lattice's own map reproduces vkx_grid_remap
+    sv, dv, ds = synthetic_grid(h, w, 15, 4.0, seed=3)
+    gx, gy = N.grid_to_map(sv, dv, ds)
+    for a, b in zip(N.remap_multi(mats, gx, gy), N.grid_remap(mats, sv, dv, ds)):
+        assert (a == b).all()

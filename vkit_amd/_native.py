@@ -143,6 +143,8 @@ for _sfx in ('', '_dev'):
                                              c_void_p, c_ssize, c_void_p]
     _SIGNATURES['vkx_grid_remap' + _sfx] = [c_void_p, ctypes.POINTER(VkxElem), c_int, c_int, c_int, c_void_p, c_void_p,
                                             c_int, c_int, c_int, c_int]
+    _SIGNATURES['vkx_remap_multi' + _sfx] = [c_void_p, ctypes.POINTER(VkxElem), c_int, c_int, c_int, c_void_p, c_void_p, c_ssize,
+                                             c_int, c_int]
     _SIGNATURES['vkx_gaussian_blur_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_int, c_double, c_void_p, c_ssize]
     _SIGNATURES['vkx_grid_project_points'] = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
                                               c_void_p]
@@ -465,6 +467,38 @@ def grid_remap(mats, src_vertices, dst_vertices, dst_shape, ctx=None):
                 raise TypeError(f'unsupported dtype {m.dtype}')
             chunk_out.append(out)
         check(lib().vkx_grid_remap(ctx.handle, arr, len(chunk), sh, sw, _ptr(sv), _ptr(dv), rows, cols, dh, dw))
+        outs.extend(chunk_out)
+    return outs
+
+
+def remap_multi(mats, map_x, map_y, ctx=None):
+    """cv.remap of every array of ``mats`` (uint8 HxW[xC] / float32 HxW, one source shape) through one dense map."""
+    ctx = ctx or default_ctx()
+    map_x = np.ascontiguousarray(map_x, dtype=np.float32)
+    map_y = np.ascontiguousarray(map_y, dtype=np.float32)
+    if map_x.shape != map_y.shape or map_x.ndim != 2:
+        raise ValueError('map_x / map_y must be 2-D and of one shape')
+    dh, dw = map_x.shape
+    outs = []
+    for i in range(0, len(mats), 8):
+        chunk = [np.ascontiguousarray(m) for m in mats[i:i + 8]]
+        sh, sw = chunk[0].shape[:2]
+        arr = (VkxElem * len(chunk))()
+        chunk_out = []
+        for j, m in enumerate(chunk):
+            if m.shape[:2] != (sh, sw):
+                raise ValueError('all elements of one call must share the source shape')
+            if m.dtype == np.float32 and m.ndim == 2:
+                out = np.empty((dh, dw), np.float32)
+                arr[j] = VkxElem(m.ctypes.data, out.ctypes.data, sw, dw, 1, 1)
+            elif m.dtype == np.uint8:
+                cn = 1 if m.ndim == 2 else m.shape[2]
+                out = _out_like(m, dh, dw)
+                arr[j] = VkxElem(m.ctypes.data, out.ctypes.data, sw * cn, dw * cn, cn, 0)
+            else:
+                raise TypeError(f'unsupported element {m.dtype} {m.shape}')
+            chunk_out.append(out)
+        check(lib().vkx_remap_multi(ctx.handle, arr, len(chunk), sh, sw, _ptr(map_x), _ptr(map_y), dw, dh, dw))
         outs.extend(chunk_out)
     return outs
 

@@ -184,6 +184,36 @@ VKX_EXPORT int vkx_grid_remap(vkx_ctx *ctx, const vkx_elem *elems, int n_elems, 
     return st.finish();
 }
 
+VKX_EXPORT int vkx_remap_multi(vkx_ctx *ctx, const vkx_elem *elems, int n_elems, int sh, int sw, const float *map_x,
+                               const float *map_y, ptrdiff_t map_stride_el, int dh, int dw)
+{
+    VKX_REQUIRE(ctx && elems && map_x && map_y, "NULL argument");
+    VKX_REQUIRE(n_elems >= 1 && n_elems <= 8, "1..8 elements per call");
+    VKX_REQUIRE(dh >= 0 && dw >= 0 && sh > 0 && sw > 0, "bad shape");
+    HostStage st(ctx);
+    const int mx = st.add(map_x, nullptr, (size_t)dw * 4, dh, map_stride_el * 4);
+    const int my = st.add(map_y, nullptr, (size_t)dw * 4, dh, map_stride_el * 4);
+    int sid[8], did[8];
+    for (int i = 0; i < n_elems; i++) {
+        const vkx_elem &e = elems[i];
+        VKX_REQUIRE(e.src && e.dst && e.cn >= 1 && e.cn <= 4, "bad element");
+        const size_t esz = e.is_f32 ? 4 : 1;
+        sid[i] = st.add(e.src, nullptr, (size_t)sw * e.cn * esz, sh, e.src_stride * (ptrdiff_t)esz);
+        did[i] = st.add(nullptr, e.dst, (size_t)dw * e.cn * esz, dh, e.dst_stride * (ptrdiff_t)esz);
+    }
+    VKX_TRY(st.commit());
+    vkx_elem de[8];
+    for (int i = 0; i < n_elems; i++) {
+        de[i] = elems[i];
+        de[i].src = st.dev<uint8_t>(sid[i]);
+        de[i].dst = st.dev<uint8_t>(did[i]);
+        de[i].src_stride = (ptrdiff_t)sw * elems[i].cn;
+        de[i].dst_stride = (ptrdiff_t)dw * elems[i].cn;
+    }
+    VKX_TRY(vkx_remap_multi_dev(ctx, de, n_elems, sh, sw, st.dev<float>(mx), st.dev<float>(my), dw, dh, dw));
+    return st.finish();
+}
+
 VKX_EXPORT int vkx_gaussian_blur_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
                                     int ksize, double sigma, uint8_t *dst, ptrdiff_t dst_stride)
 {

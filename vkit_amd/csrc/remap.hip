@@ -175,6 +175,27 @@ VKX_EXPORT int vkx_remap_f32_dev(vkx_ctx *ctx, const float *src, int sh, int sw,
                       CoordMap{map_x, map_y, map_stride_el});
 }
 
+VKX_EXPORT int vkx_remap_multi_dev(vkx_ctx *ctx, const vkx_elem *elems, int n_elems, int sh, int sw, const float *map_x,
+                                   const float *map_y, ptrdiff_t map_stride_el, int dh, int dw)
+{
+    VKX_REQUIRE(ctx && elems && map_x && map_y, "NULL argument");
+    VKX_REQUIRE(n_elems >= 1, "no elements");
+    const CoordMap map{map_x, map_y, map_stride_el};
+    for (int i = 0; i < n_elems; i++) {
+        const vkx_elem &e = elems[i];
+        VKX_REQUIRE(e.src && e.dst, "NULL element plane");
+        int rc;
+        if (e.is_f32) {
+            VKX_REQUIRE(e.cn == 1, "float32 elements are single channel");
+            rc = launch_f32(ctx, (const float *)e.src, sh, sw, e.src_stride, (float *)e.dst, dh, dw, e.dst_stride, map);
+        } else {
+            rc = launch_u8(ctx, (const uint8_t *)e.src, sh, sw, e.cn, e.src_stride, (uint8_t *)e.dst, dh, dw, e.dst_stride, map);
+        }
+        if (rc) return rc;
+    }
+    return VKX_OK;
+}
+
 VKX_EXPORT int vkx_warp_affine_u8_dev(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t src_stride,
                                       const double M[6], uint8_t *dst, int dh, int dw, ptrdiff_t dst_stride)
 {
