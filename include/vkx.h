@@ -34,6 +34,8 @@ extern "C" {
 #define VKX_ERR_HIP (-2)         /* HIP runtime failure (message has the hipError string) */
 #define VKX_ERR_NOMEM (-3)
 #define VKX_ERR_UNSUPPORTED (-4)
+#define VKX_ERR_OUT_OF_LATTICE (-5) /* a point falls outside the lattice cells (the reference raises IndexError there) */
+#define VKX_ERR_DIVIDE (-6)         /* a division by zero the reference raises FloatingPointError for */
 
 typedef struct vkx_ctx vkx_ctx;
 
@@ -357,9 +359,29 @@ int vkx_zoom_in_blur_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, 
  * (x', y') = trans_mat . (smooth_x, smooth_y, 1) dehomogenised, all in float64.  Everything is HOST memory:
  * src_vertices / dst_vertices int32 [rows, cols, 2] (x, y); pts_xy int32 [n, 2] rounded (x, y); pts_smooth_xy
  * float64 [n, 2]; out_xy float64 [n, 2].  A point whose cell index falls outside the (rows-1) x (cols-1) cells is an
- * error (VKX_ERR_INVALID; the reference raises IndexError there). */
+ * error (VKX_ERR_OUT_OF_LATTICE; the reference raises IndexError there). */
 int vkx_grid_project_points(vkx_ctx *ctx, const int32_t *src_vertices, const int32_t *dst_vertices, int rows, int cols,
                             int grid_size, const int32_t *pts_xy, const double *pts_smooth_xy, int n, double *out_xy);
+
+/* ---- similarity_mls lattice construction --------------------------------------------------
+ * SimilarityMlsPointProjector.project_point, geometric/mls.py:38-135, for every vertex of the source lattice in one
+ * launch (the reference projects vertex by vertex through create_dst_image_grid_and_shift_amounts_and_resize_ratios,
+ * grid_rendering/grid_creator.py:44-115).  float32 arithmetic in the reference's order of operations, including the
+ * accumulation orders of numpy's reductions and of np.matmul (csrc/mls.hip lists them).
+ *   src_handles / dst_handles                float32 [n_handles, 2] (x, y): the INTEGER handle positions
+ *                                            (PointTuple.to_smooth_np_array, element/point.py:251-252)
+ *   src_handles_smooth / dst_handles_smooth  float64 [n_handles, 2]: a vertex exactly on a source handle maps to that
+ *                                            handle's target (mls.py:57-61; the last duplicate wins like the dict)
+ *   vertices_xy, out_xy                      float64 [n_vertices, 2]
+ * n_handles <= 128.  VKX_ERR_DIVIDE where the reference's np.errstate(divide='raise') fires (a vertex on an integer
+ * handle position that is not an exact handle hit).  _dev: device pointers, `status` int32 (zeroed by the caller)
+ * receives 1 + the index of such a vertex. */
+int vkx_mls_project_dev(vkx_ctx *ctx, const float *src_handles, const float *dst_handles,
+                        const double *src_handles_smooth, const double *dst_handles_smooth, int n_handles,
+                        const double *vertices_xy, int n_vertices, double *out_xy, int32_t *status);
+int vkx_mls_project(vkx_ctx *ctx, const float *src_handles, const float *dst_handles,
+                    const double *src_handles_smooth, const double *dst_handles_smooth, int n_handles,
+                    const double *vertices_xy, int n_vertices, double *out_xy);
 
 /* ---- polygon rasterisation -----------------------------------------------------------
  * cv.fillPoly(zeros((h, w), uint8), [pts], 1): PolygonInternals.np_mask element/polygon.py:70-77

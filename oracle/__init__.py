@@ -715,3 +715,18 @@ def rectangle_streak(img, thickness=1, aspect_ratio=None, dash_thickness=0, dash
     fill(out, (0, 0, H, W), tuple(color), mask=vert, alpha=float(alpha))
     fill(out, (0, 0, H, W), tuple(color), mask=hori, alpha=float(alpha))
     return out
+
+
+def mls_project(src_handles_xy, dst_handles_xy, src_handles_smooth_xy, dst_handles_smooth_xy, vertices_xy):
+    """SimilarityMlsPointProjector.project_point for every vertex -- geometric/mls.py:38-135."""
+    p = np.ascontiguousarray(src_handles_xy, dtype=np.float32).reshape(-1, 2)
+    q = np.ascontiguousarray(dst_handles_xy, dtype=np.float32).reshape(-1, 2)
+    ps = np.ascontiguousarray(src_handles_smooth_xy, dtype=np.float64).reshape(-1, 2)
+    qs = np.ascontiguousarray(dst_handles_smooth_xy, dtype=np.float64).reshape(-1, 2)
+    v = np.ascontiguousarray(vertices_xy, dtype=np.float64).reshape(-1, 2)
+    out = np.zeros_like(v)
+    rc = lib().vko_mls_project(_p(p), _p(q), _p(ps), _p(qs), p.shape[0], _p(v), v.shape[0], _p(out))
+    if rc > 0:
+        raise FloatingPointError(f'vertex {rc - 1}: divide by zero')
+    assert rc == 0
+    return out

@@ -1968,3 +1968,90 @@ VKO_API int vko_project_points(const double *pts3, size_t n, const double rvec[3
 }
 
 VKO_API int vko_version(void) { return 1; }
+
+/* -----------------------------------------------------------------------------------------------------------------
+ * SimilarityMlsPointProjector.project_point -- vkit/mechanism/distortion/geometric/mls.py:38-135, all vertices.
+ * float32 numpy arithmetic in the reference's order of operations.  The accumulation orders are those numpy 2.2.6 +
+ * OpenBLAS 0.3.29 use for these shapes in the container the goldens were generated in (pinned by
+ * tests/golden/mls_states.npz / mls_lattices.npz, which come from the imported reference):
+ *   np.sum over a contiguous axis: numpy's pairwise sum (n < 8 sequential; else 8 running sums over whole blocks of 8,
+ *   ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the tail); np.sum(axis=0) of an (N, 2): row after row;
+ *   (N,) @ (N, 2): acc = fma(w_i, p_i, acc), for exactly four handles fma(w0,p0,w1 p1) + fma(w2,p2,w3 p3);
+ *   (N, 2) @ (2, 2) and (N,1,2) @ (N,2,2): fma(a1, b1, a0 b0).
+ * Returns 0, or 1 + the index of a vertex where np.errstate(divide='raise') fires (mls.py:72-74).
+ * ----------------------------------------------------------------------------------------------------------------- */
+static float vko_mls_weight(const float *p, int i, float vx, float vy)
+{
+    const float dx = p[2 * i] - vx, dy = p[2 * i + 1] - vy;
+    const float d2 = dx * dx + dy * dy;
+    return 1.f / d2;
+}
+
+static float vko_pairwise_sum_f32(const float *a, int n)
+{
+    if (n < 8) {
+        float res = a[0];
+        for (int i = 1; i < n; i++) res = res + a[i];
+        return res;
+    }
+    float r[8];
+    for (int j = 0; j < 8; j++) r[j] = a[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; j++) r[j] = r[j] + a[i + j];
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res = res + a[i];
+    return res;
+}
+
+VKO_API int vko_mls_project(const float *p, const float *q, const double *ps, const double *qs, int n,
+                            const double *vertices, int n_vertices, double *out)
+{
+    if (n < 1 || n > 128) return -1;
+    float w[128], t[128];
+    for (int v = 0; v < n_vertices; v++) {
+        const double vxd = vertices[2 * v], vyd = vertices[2 * v + 1];
+        int hit = -1;
+        for (int i = 0; i < n; i++)
+            if (ps[2 * i] == vxd && ps[2 * i + 1] == vyd) hit = i;      /* mls.py:57-61, dict: last duplicate wins */
+        if (hit >= 0) { out[2 * v] = qs[2 * hit]; out[2 * v + 1] = qs[2 * hit + 1]; continue; }
+        const float vx = (float)vxd, vy = (float)vyd;
+        for (int i = 0; i < n; i++) {
+            const float dx = p[2 * i] - vx, dy = p[2 * i + 1] - vy;
+            if (dx * dx + dy * dy == 0.f) return v + 1;
+            w[i] = vko_mls_weight(p, i, vx, vy);                        /* mls.py:64-74 */
+        }
+        const float sw = vko_pairwise_sum_f32(w, n);
+        float psx, psy, qsx, qsy;
+        if (n == 4) {
+            const float w0 = w[0] / sw, w1 = w[1] / sw, w2 = w[2] / sw, w3 = w[3] / sw;
+            psx = fmaf(w0, p[0], w1 * p[2]) + fmaf(w2, p[4], w3 * p[6]);
+            psy = fmaf(w0, p[1], w1 * p[3]) + fmaf(w2, p[5], w3 * p[7]);
+            qsx = fmaf(w0, q[0], w1 * q[2]) + fmaf(w2, q[4], w3 * q[6]);
+            qsy = fmaf(w0, q[1], w1 * q[3]) + fmaf(w2, q[5], w3 * q[7]);
+        } else {
+            psx = psy = qsx = qsy = 0.f;
+            for (int i = 0; i < n; i++) {                               /* mls.py:77-78 */
+                const float wn = w[i] / sw;
+                psx = fmaf(wn, p[2 * i], psx); psy = fmaf(wn, p[2 * i + 1], psy);
+                qsx = fmaf(wn, q[2 * i], qsx); qsy = fmaf(wn, q[2 * i + 1], qsy);
+            }
+        }
+        const float ax = vx - psx, ay = vy - psy;                       /* mls.py:89-106 */
+        float sx = 0.f, sy = 0.f;
+        for (int i = 0; i < n; i++) {
+            const float hx = p[2 * i] - psx, hy = p[2 * i + 1] - psy;   /* mls.py:81-86 */
+            const float gx = q[2 * i] - qsx, gy = q[2 * i + 1] - qsy;
+            t[i] = w[i] * (hx * hx + hy * hy);                          /* mls.py:130 */
+            const float t0 = fmaf(hy, ay, hx * ax), t1 = fmaf(hy, -ax, hx * ay);      /* mls.py:108 */
+            const float b0 = fmaf(-hx, ay, hy * ax), b1 = fmaf(-hx, -ax, hy * ay);    /* mls.py:109 */
+            const float a00 = w[i] * t0, a01 = w[i] * t1, a10 = w[i] * b0, a11 = w[i] * b1;   /* mls.py:111-114 */
+            const float e0 = fmaf(gy, a10, gx * a00), e1 = fmaf(gy, a11, gx * a01);           /* mls.py:118-129 */
+            if (i == 0) { sx = e0; sy = e1; } else { sx = sx + e0; sy = sy + e1; }
+        }
+        const float mu = vko_pairwise_sum_f32(t, n);
+        out[2 * v] = (double)(sx / mu + qsx);                           /* mls.py:131 */
+        out[2 * v + 1] = (double)(sy / mu + qsy);
+    }
+    return 0;
+}

@@ -314,6 +314,31 @@ def gen_mls_states():
     np.savez_compressed(os.path.join(HERE, 'mls_states.npz'), **out)
 
 
+def gen_mls_lattices():
+    """Full destination lattices of the real reference at the BASELINE sizes (C2 / C5: 2048^2, 4096^2) and the page
+    size of C4 (1024^2): handle points in, rounded + smooth lattice out.  The per-vertex reference loop takes ~0.8 s a
+    state here; the fixtures pin the device kernel (csrc/mls.hip) and the oracle restatement at those sizes."""
+    out = {}
+    meta = []
+    for (hw, seed, level) in ((1024, 0, 5), (1024, 3, 9), (2048, 0, 5), (2048, 1, 5), (2048, 2, 10), (4096, 0, 5),
+                              (4096, 1, 5)):
+        cfg = P_mls.SimilarityMlsConfigGenerator(P_mls.SimilarityMlsConfigGeneratorConfig(), level)((hw, hw), default_rng(seed))
+        st = SimilarityMlsState(cfg, (hw, hw), None)
+        key = f'{hw}_s{seed}_l{level}'
+        out[key + '_src_handles'] = np.asarray([[p.smooth_x, p.smooth_y] for p in cfg.src_handle_points])
+        out[key + '_dst_handles'] = np.asarray([[p.smooth_x, p.smooth_y] for p in cfg.dst_handle_points])
+        d_smooth, d_int = grid_to_arrays(st.dst_image_grid)
+        out[key + '_dst_grid'] = d_int.astype(np.int16)
+        # the smooth lattice is (float32 projection) - (integer shift): stored as the float32 projection, exactly
+        unshifted = d_smooth + np.asarray([st.shift_amount_x, st.shift_amount_y], dtype=np.float64)
+        out[key + '_projected'] = unshifted.astype(np.float32)
+        assert (out[key + '_projected'].astype(np.float64) - np.asarray([st.shift_amount_x, st.shift_amount_y]) == d_smooth).all()
+        meta.append(dict(key=key, h=hw, w=hw, seed=seed, level=level, grid_size=cfg.grid_size,
+                         result_shape=list(st.result_shape), shift=[st.shift_amount_y, st.shift_amount_x]))
+    out['meta_json'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, 'mls_lattices.npz'), **out)
+
+
 # --------------------------------------------------------------------------------------------
 def gen_affine_states():
     out = []
@@ -378,6 +403,7 @@ def gen_policy_configs():
         'line_streak': (P_streak.LineStreakConfigGenerator, P_streak.LineStreakConfigGeneratorConfig),
         'rectangle_streak': (P_streak.RectangleStreakConfigGenerator, P_streak.RectangleStreakConfigGeneratorConfig),
         'ellipse_streak': (P_streak.EllipseStreakConfigGenerator, P_streak.EllipseStreakConfigGeneratorConfig),
+        'jpeg_quality': (P_effect.JpegQualityConfigGenerator, P_effect.JpegQualityConfigGeneratorConfig),
     }
     out = []
     for name, (gen_cls, cfg_cls) in gens.items():
@@ -596,10 +622,15 @@ def gen_structure_oracle_patched():
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1:                      # regenerate only the named fixtures: make_golden.py gen_mls_lattices ...
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     gen_numpy_path()
     gen_fill_modes()
     gen_pointwise_ops()
     gen_mls_states()
+    gen_mls_lattices()
     gen_affine_states()
     gen_policy_configs()
     gen_operator_semantics()

@@ -1,0 +1,90 @@
+"""Test infrastructure: replays ONE distortion of the operator API through the CPU oracle, given the config and state the
+operator reported (``Distortion.distort(..., get_config=True, get_state=True)`` / ``DistortionPolicy.distort(...,
+enable_debug=True)`` / ``RandomDistortionDebug``).  Used by the ``-m gpu`` operator tests to compare every element the
+HIP path returns with the oracle evaluated on the same state."""
+import numpy as np
+from numpy.random import default_rng
+
+import oracle as O
+from vkit_amd.mechanism.distortion.photometric.opt import OutOfBoundBehavior
+
+GRID_BASED = ('similarity_mls', 'camera_plane_only', 'camera_cubic_curve', 'camera_plane_line_fold',
+              'camera_plane_line_curve')
+AFFINE = ('shear_hori', 'shear_vert', 'rotate', 'skew_hori', 'skew_vert')
+IDENTITY = ('jpeg_quality', 'ellipse_streak')     # out of the accelerated path: the image passes through
+
+
+def gaussian_ksize(sigma):
+    k = max(3, round(3 * sigma) + 1)
+    return k + 1 if k % 2 == 0 else k
+
+
+def _std_shift(mat, cfg):
+    sel = mat[:, :, list(cfg.channels)] if cfg.channels else mat
+    f = sel.astype(np.float32)
+    mean = np.mean(f.reshape(-1, f.shape[-1]), axis=0)
+    f = f * cfg.scale - mean * (cfg.scale - 1)
+    out = mat.copy()
+    res = np.clip(np.round(f), 0, 255).astype(np.uint8)
+    if cfg.channels:
+        out[:, :, list(cfg.channels)] = res
+    else:
+        out = res
+    return out
+
+
+def _private_rng(cfg):
+    rng = default_rng()
+    rng.bit_generator.state = cfg.rng_state
+    return rng
+
+
+def _gaussion_noise(mat, cfg):
+    noise = np.round(_private_rng(cfg).normal(0, cfg.std, mat.shape)).astype(np.int16)
+    return O.add_noise_i16(mat, noise)
+
+
+PHOTOMETRIC = {
+    'gaussian_blur': lambda m, c: O.gaussian_blur(m, gaussian_ksize(c.sigma), c.sigma),
+    'defocus_blur': lambda m, c: O.defocus_blur(m, c.radius, c.anti_aliasing_sigma),
+    'motion_blur': lambda m, c: O.motion_blur(m, c.radius, c.angle, c.anti_aliasing_sigma),
+    'zoom_in_blur': lambda m, c: O.zoom_in_blur(m, c.ratio, c.step, c.alpha),
+    'mean_shift': lambda m, c: O.mean_shift(m, c.delta, c.threshold, c.channels, c.oob_behavior == OutOfBoundBehavior.CYCLE),
+    'color_shift': lambda m, c: O.color_shift_rgb(m, c.delta),
+    'brightness_shift': lambda m, c: O.brightness_shift_rgb(m, c.delta),
+    'std_shift': _std_shift,
+    'boundary_equalization': lambda m, c: O.boundary_equalization(m, c.channels),
+    'histogram_equalization': lambda m, c: O.histogram_equalization(m, c.channels),
+    'complement': lambda m, c: O.complement(m, c.threshold, c.enable_threshold_lte, c.channels),
+    'posterization': lambda m, c: O.posterization(m, c.num_bits, c.channels),
+    'color_balance': lambda m, c: O.color_balance_rgb(m, c.ratio),
+    'pixelation': lambda m, c: O.pixelation(m, c.ratio),
+    'gaussion_noise': _gaussion_noise,
+    'line_streak': lambda m, c: O.line_streak(m, c.thickness, c.gap, c.dash_thickness, c.dash_gap, c.color, c.alpha,
+                                              c.enable_vert, c.enable_hori),
+    'rectangle_streak': lambda m, c: O.rectangle_streak(m, c.thickness, c.aspect_ratio, c.dash_thickness, c.dash_gap,
+                                                        c.short_side_min, c.short_side_step, c.color, c.alpha),
+}
+REPLAYABLE = tuple(PHOTOMETRIC) + GRID_BASED + AFFINE + IDENTITY
+
+
+def geometric_sampler(name, state):
+    """-> f(mat) applying the oracle's version of the state's dense resampling to one element plane."""
+    if name in GRID_BASED:
+        mx, my = O.grid_to_map(state.src_image_grid.vertices, state.dst_image_grid.vertices, state.result_shape)
+        return lambda mat: O.remap(mat, mx, my)
+    assert name in AFFINE, name
+    M, dsize = np.asarray(state.trans_mat, np.float64), state.dsize
+    warp = O.warp_affine if M.shape[0] == 2 else O.warp_perspective
+    return lambda mat: warp(mat, M, dsize)
+
+
+def replay(name, config, state, image=None, mask=None, score_map=None):
+    """Oracle outputs (image, mask, score_map) -- numpy arrays or None -- of one distortion step."""
+    if name in IDENTITY:
+        return image, mask, score_map
+    if name in PHOTOMETRIC:
+        # photometric distortions leave masks and score maps alone (distortion/interface.py:580-600)
+        return (PHOTOMETRIC[name](image, config) if image is not None else None), mask, score_map
+    f = geometric_sampler(name, state)
+    return tuple(f(m) if m is not None else None for m in (image, mask, score_map))

@@ -358,15 +358,22 @@ def test_page_assembler_layer_order(N):
 
 
 def test_page_distortion_step(N):
-    from vkit_amd.mechanism.distortion_policy import UNSUPPORTED_POLICY_NAMES, random_distortion_factory
+    from oracle_replay import REPLAYABLE, replay
+    from vkit_amd.mechanism.distortion_policy import random_distortion_factory
+    from vkit_amd.mechanism.distortion_policy.random_distortion import RandomDistortionDebug
     from vkit_amd.element import Mask, PointList
     from vkit_amd.pipeline import text_detection as T
     step_input = _synthetic_page_input(seed=9)
     page_output = T.page_assembler_step_factory.create().run(step_input, default_rng(0))
-    factory_config = {'disabled_policy_names': list(UNSUPPORTED_POLICY_NAMES), 'prob_geometric': 1.0}
+    # every policy the oracle can replay from (config, state) stays enabled -- the two pass-through members included;
+    # the members whose random planes are rebuilt elsewhere (test_gpu_pointwise.py) are switched off here
+    all_names = [p.name for st in random_distortion_factory.create().stages for p in st.config.distortion_policies]
+    factory_config = {'disabled_policy_names': sorted(set(all_names) - set(REPLAYABLE)), 'prob_geometric': 1.0,
+                      'num_photometric_min': 1}
     step = T.page_distortion_step_factory.create({'random_distortion_factory_config': factory_config})
     shapes = set()
-    for seed in range(4):
+    replayed = set()
+    for seed in range(6):
         out = step.run(T.PageDistortionStepInput(page_output), default_rng(seed))
         shapes.add(out.page_image.shape)
 
@@ -387,7 +394,22 @@ def test_page_distortion_step(N):
             image=page.image, mask=Mask(mat=active), polygons=flat_polygons, points=flat_points,
             rng=default_rng(seed))
         np.testing.assert_array_equal(out.page_active_mask.mat, result.mask.mat)
-        want = result.image.mat.copy()
+        # ... and the chain itself against the oracle: every distortion replayed from the config / state it reports
+        debug = RandomDistortionDebug()
+        again = random_distortion_factory.create(factory_config).distort(
+            image=page.image, mask=Mask(mat=active), polygons=flat_polygons, points=flat_points,
+            rng=default_rng(seed), debug=debug)
+        np.testing.assert_array_equal(again.image.mat, result.image.mat)
+        cur_image, cur_mask = page.image.mat, active
+        for k, name in enumerate(debug.distortion_names):
+            cur_image, cur_mask, _ = replay(name, debug.distortion_configs[k], debug.distortion_states[k], cur_image,
+                                            cur_mask)
+            np.testing.assert_array_equal(debug.distortion_images[k].mat, cur_image, err_msg=f'{seed} {k} {name}')
+            replayed.add(name)
+        # (the step injects no corner points, so nothing is trimmed after the last stage)
+        np.testing.assert_array_equal(result.image.mat, cur_image)
+        np.testing.assert_array_equal(result.mask.mat, cur_mask)
+        want = cur_image.copy()
         bottom = page.page_bottom_layer_image.mat
         if bottom.shape != want.shape:
             bottom = O.resize_cubic(bottom, want.shape[:2])
@@ -429,6 +451,7 @@ def test_page_distortion_step(N):
         assert out.page_char_heights == [float(v) for v in char_h]
         assert out.page_seal_impression_char_mask.mat.sum() > 0
     assert len(shapes) > 1  # geometric distortions did change the page shape, so the resize branch ran
+    assert len(replayed) >= 6, replayed
 
 
 @pytest.mark.parametrize('src_shape,dst_shape', [((20, 30), (33, 47)), ((64, 64), (32, 32)), ((97, 131), (40, 55)),

@@ -1,0 +1,280 @@
+"""Operator-level parity on the GPU: the reference's entry points -- ``Distortion.distort`` (vkit/mechanism/distortion/
+interface.py:824-912) and ``DistortionPolicy.distort`` (distortion_policy/type.py:69-114) -- on REAL reference states
+at the BASELINE sizes, every returned element against the oracle evaluated on the state / config the operator reports.
+
+  C1  rotate.distort({'angle': 30}, image = 512^2 RGB)                                      (+ mask, score map)
+  C2  similarity_mls, policy config (level 5, default_rng(i)), 2048^2 RGB
+  C3  camera_cubic_curve state (level 5, default_rng(0)) at 2048^2, then gaussian_blur, color_shift, gaussion_noise
+      through the operators one by one AND through the fused batch kernel
+  C5  one 4096^2 similarity_mls state, Image + Mask + ScoreMap in one call
+plus the photometric members (incl. rectangle_streak) and all ten geometric policies through DistortionPolicy.distort,
+and the device lattice construction (vkx_mls_project) against the reference's lattices.  Bit-exact everywhere."""
+import json
+import os
+
+import numpy as np
+import pytest
+from numpy.random import default_rng
+
+import oracle as O
+from oracle_replay import PHOTOMETRIC, gaussian_ksize, geometric_sampler, replay
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def N():
+    from vkit_amd import _native
+    _native.default_ctx()
+    return _native
+
+
+def _elements(h, w, seed):
+    from vkit_amd.element import Image, Mask, ScoreMap
+    image = Image(mat=default_rng(1000 + seed).integers(0, 256, (h, w, 3), dtype=np.uint8))
+    mask = Mask(mat=(default_rng(2000 + seed).random((h, w)) < 0.5).astype(np.uint8))
+    score = ScoreMap(mat=default_rng(3000 + seed).random((h, w), dtype=np.float32))
+    return image, mask, score
+
+
+def _same(got, want, what):
+    assert got.shape == want.shape and got.dtype == want.dtype, (what, got.shape, want.shape)
+    if got.dtype == np.float32:
+        assert (got.view(np.uint32) == want.view(np.uint32)).all(), what      # bit patterns, not values
+    else:
+        assert (got == want).all(), what
+
+
+# ---------------------------------------------------------------------------------------------- C1
+def test_c1_rotate_512(N):
+    from vkit_amd.mechanism import distortion as D
+    image, mask, score = _elements(512, 512, 0)
+    res = D.rotate.distort({'angle': 30}, image=image, mask=mask, score_map=score, get_state=True, get_active_mask=True)
+    state = res.state
+    # SURVEY 8(a) a9 known answer
+    assert np.asarray(state.trans_mat).tolist() == [[0.8660253882408142, -0.5, 256.0], [0.5, 0.8660253882408142, 0.0]]
+    assert state.dsize == (700, 700) and res.shape == (700, 700)
+    f = geometric_sampler('rotate', state)
+    _same(res.image.mat, f(image.mat), 'image')
+    _same(res.mask.mat, f(mask.mat), 'mask')
+    _same(res.score_map.mat, f(score.mat), 'score_map')
+    _same(res.active_mask.mat, f(np.ones((512, 512), np.uint8)), 'active_mask')
+    # the single-element conveniences agree with the operator entry
+    _same(D.rotate.distort_image({'angle': 30}, image).mat, res.image.mat, 'distort_image')
+
+
+# ---------------------------------------------------------------------------------------------- lattice construction
+def test_mls_lattices_on_device_match_reference(N, golden_dir):
+    """vkx_mls_project through SimilarityMlsState: the destination lattices of the imported reference, bit for bit
+    (five small states, 1024^2, and the C2 / C5 sizes 2048^2 and 4096^2)."""
+    from vkit_amd.element import Point, PointTuple
+    from vkit_amd.mechanism import distortion as D
+    os.environ.pop('VKX_MLS_HOST_PROJECTION', None)
+    checked = 0
+    for fname in ('mls_states.npz', 'mls_lattices.npz'):
+        M = np.load(os.path.join(golden_dir, fname))
+        for m in json.loads(bytes(M['meta_json'])):
+            k = m['key']
+            if k + '_src_handles' not in M.files:
+                continue
+            cfg = D.SimilarityMlsConfig(
+                src_handle_points=PointTuple(Point.create(y=y, x=x) for x, y in M[k + '_src_handles']),
+                dst_handle_points=PointTuple(Point.create(y=y, x=x) for x, y in M[k + '_dst_handles']),
+                grid_size=m['grid_size'])
+            st = D.similarity_mls.generate_state(cfg, (m['h'], m['w']))
+            assert st.result_shape == tuple(m['result_shape']), k
+            assert [st.shift_amount_y, st.shift_amount_x] == m['shift'], k
+            assert (st.dst_image_grid.vertices == M[k + '_dst_grid']).all(), k
+            if k + '_projected' in M.files:
+                shift = np.array([m['shift'][1], m['shift'][0]], np.float64)
+                assert (st.dst_image_grid.smooth + shift == M[k + '_projected'].astype(np.float64)).all(), k
+            else:
+                assert (st.dst_image_grid.smooth == M[k + '_dst_grid_smooth']).all(), k
+            checked += 1
+    assert checked == 12
+
+
+def test_mls_project_kernel_matches_oracle(N):
+    """Handle counts around numpy's reduction special cases, exact handle hits, the divide-by-zero error."""
+    rng = default_rng(21)
+    for n in (2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 24, 25, 31, 40, 128):
+        ps = rng.integers(0, 3000, (n, 2)).astype(np.float64) + 0.25 * (np.arange(n) % 3)[:, None]
+        qs = ps + rng.normal(0, 25, (n, 2))
+        p, q = np.rint(ps).astype(np.float32), np.rint(qs).astype(np.float32)
+        V = rng.integers(0, 3000, (5000, 2)).astype(np.float64) + 0.5
+        V[7] = ps[n - 1]
+        got = N.mls_project(p, q, ps, qs, V)
+        want = O.mls_project(p, q, ps, qs, V)
+        assert (got == want).all(), n
+        assert tuple(got[7]) == tuple(qs[n - 1])
+    on_integer = np.array([[float(p[1, 0]), float(p[1, 1])]])       # handle 1 sits at x + 0.25: no exact hit
+    with pytest.raises(FloatingPointError):
+        N.mls_project(p, q, ps, qs, on_integer)
+    with pytest.raises(N.VkxError):
+        N.mls_project(np.zeros((129, 2), np.float32), np.zeros((129, 2), np.float32), np.zeros((129, 2)), np.zeros((129, 2)), V)
+
+
+# ---------------------------------------------------------------------------------------------- C2 / C5
+@pytest.mark.parametrize('hw,seed', [(2048, 0), (2048, 1), (4096, 0)])
+def test_c2_c5_similarity_mls_reference_states(N, golden_dir, hw, seed):
+    from vkit_amd.mechanism import distortion as D
+    from vkit_amd.mechanism.distortion_policy.geometric import mls as P_mls
+    M = np.load(os.path.join(golden_dir, 'mls_lattices.npz'))
+    gen = P_mls.SimilarityMlsConfigGenerator(P_mls.SimilarityMlsConfigGeneratorConfig(), 5)
+    image, mask, score = _elements(hw, hw, seed)
+    res = D.similarity_mls.distort(gen, image=image, mask=mask, score_map=score, rng=default_rng(seed), get_state=True,
+                                   get_config=True, get_active_mask=(hw == 2048))
+    st = res.state
+    # the state is the reference's: the lattice golden of this very (size, seed, level)
+    assert (st.dst_image_grid.vertices == M[f'{hw}_s{seed}_l5_dst_grid']).all()
+    assert res.shape == st.result_shape and res.config.grid_size == max(15, int(0.01 * hw))
+    mx, my = O.grid_to_map(st.src_image_grid.vertices, st.dst_image_grid.vertices, st.result_shape)
+    _same(res.image.mat, O.remap(image.mat, mx, my), 'image')
+    _same(res.mask.mat, O.remap(mask.mat, mx, my), 'mask')
+    _same(res.score_map.mat, O.remap(score.mat, mx, my), 'score_map')
+    if hw == 2048:
+        # one element per call takes the same device path
+        _same(D.similarity_mls.distort(res.config, image=image).image.mat, res.image.mat, 'image alone')
+        border = st.dst_image_grid.generate_border_polygon()
+        pts = np.asarray([(p.x, p.y) for p in border.points], np.int32)
+        _same(res.active_mask.mat, O.fill_poly(st.result_shape, pts), 'active_mask')
+
+
+# ---------------------------------------------------------------------------------------------- C3
+def test_c3_camera_cubic_curve_chain_2048(N):
+    """The headline chain on a real camera_cubic_curve state: operator by operator, and through the fused batch kernel."""
+    from vkit_amd.batch import ChainBatch
+    from vkit_amd.mechanism import distortion as D
+    from vkit_amd.mechanism.distortion_policy.geometric import camera as P_cam
+    gen = P_cam.CameraCubicCurveConfigGenerator(P_cam.CameraCubicCurveConfigGeneratorConfig(), 5)
+    image, _, _ = _elements(2048, 2048, 0)
+    geo = D.camera_cubic_curve.distort(gen, image=image, rng=default_rng(0), get_state=True, get_config=True)
+    cfg, st = geo.config, geo.state
+    # seed 0 @2048^2
+    assert (round(cfg.curve_alpha, 4), round(cfg.curve_beta, 4), round(cfg.curve_direction, 4), cfg.grid_size) == \
+        (-12.7058, -34.3899, 146.3886, 20)
+    mx, my = O.grid_to_map(st.src_image_grid.vertices, st.dst_image_grid.vertices, st.result_shape)
+    want = O.remap(image.mat, mx, my)
+    _same(geo.image.mat, want, 'remap')
+    blur = D.gaussian_blur.distort({'sigma': 1.0}, image=geo.image)
+    want = O.gaussian_blur(want, 5, 1.0)
+    _same(blur.image.mat, want, 'gaussian_blur')
+    hue = D.color_shift.distort({'delta': 37}, image=blur.image)
+    want = O.color_shift_rgb(want, 37)
+    _same(hue.image.mat, want, 'color_shift')
+    noisy = D.gaussion_noise.distort({'std': 10.0}, image=hue.image, rng=default_rng(5000), get_config=True)
+    private = default_rng()
+    private.bit_generator.state = noisy.config.rng_state
+    noise = np.round(private.normal(0, 10.0, want.shape)).astype(np.int16)
+    want = O.add_noise_i16(want, noise)
+    _same(noisy.image.mat, want, 'gaussion_noise')
+    streak_cfg = D.LineStreakConfig(thickness=2, gap=20, alpha=0.5)
+    streak = D.line_streak.distort(streak_cfg, image=noisy.image)
+    want_streak = O.line_streak(want, 2, 20, 0, 0, (0, 0, 0), 0.5, True, True)
+    _same(streak.image.mat, want_streak, 'line_streak')
+
+    batch = ChainBatch()
+    batch.add(image.mat, st, blur_sigma=1.0, hue_delta=37, noise=noise)
+    batch.add(image.mat, st, blur_sigma=1.0, hue_delta=37, noise=noise, streak=streak_cfg)
+    batch.run()
+    _same(batch.result(0), want, 'fused chain')
+    _same(batch.result(1), want_streak, 'fused chain + streak')
+    batch.close()
+
+
+# ---------------------------------------------------------------------------------------------- photometric members
+def test_photometric_operators_through_distort_and_policy(N):
+    """gaussian_blur / color_shift / gaussion_noise / line_streak / rectangle_streak (and the other replayable members)
+    through ``Distortion.distort`` with explicit configs and through ``DistortionPolicy.distort`` with sampled ones."""
+    from vkit_amd.element import Image
+    from vkit_amd.mechanism import distortion as D
+    from vkit_amd.mechanism.distortion_policy.photometric import blur as P_blur, color as P_color, effect as P_effect, \
+        noise as P_noise, streak as P_streak
+    rng = default_rng(31)
+    mat = rng.integers(0, 256, (333, 407, 3), dtype=np.uint8)
+    image = Image(mat=mat)
+    explicit = [
+        (D.gaussian_blur, 'gaussian_blur', {'sigma': 0.7}), (D.gaussian_blur, 'gaussian_blur', {'sigma': 1.0}),
+        (D.gaussian_blur, 'gaussian_blur', {'sigma': 2.0}),
+        (D.color_shift, 'color_shift', {'delta': 37}), (D.color_shift, 'color_shift', {'delta': -200}),
+        (D.gaussion_noise, 'gaussion_noise', {'std': 10.0}),
+        (D.line_streak, 'line_streak', {'thickness': 2, 'gap': 20, 'alpha': 0.5}),
+        (D.line_streak, 'line_streak', {'thickness': 3, 'gap': 7, 'dash_thickness': 9, 'dash_gap': 4, 'alpha': 1.0,
+                                        'color': (200, 10, 60), 'enable_hori': False}),
+        (D.rectangle_streak, 'rectangle_streak', {'thickness': 2, 'alpha': 0.6, 'color': (10, 200, 30)}),
+        (D.rectangle_streak, 'rectangle_streak', {'thickness': 3, 'aspect_ratio': 0.7, 'dash_thickness': 11, 'dash_gap': 5,
+                                                  'short_side_min': 17, 'short_side_step': 23, 'alpha': 1.0}),
+    ]
+    for op, name, cfg in explicit:
+        res = op.distort(cfg, image=image, rng=default_rng(77), get_config=True)
+        _same(res.image.mat, PHOTOMETRIC[name](mat, res.config), (name, cfg))
+        assert res.shape == image.shape
+    factories = [P_blur.gaussian_blur_policy_factory, P_blur.defocus_blur_policy_factory, P_blur.motion_blur_policy_factory,
+                 P_blur.zoom_in_blur_policy_factory, P_color.mean_shift_policy_factory, P_color.color_shift_policy_factory,
+                 P_color.brightness_shift_policy_factory, P_color.std_shift_policy_factory,
+                 P_color.boundary_equalization_policy_factory, P_color.histogram_equalization_policy_factory,
+                 P_color.complement_policy_factory, P_color.posterization_policy_factory,
+                 P_color.color_balance_policy_factory, P_effect.pixelation_policy_factory,
+                 P_noise.gaussion_noise_policy_factory, P_streak.line_streak_policy_factory,
+                 P_streak.rectangle_streak_policy_factory]
+    for factory in factories:
+        policy = factory.create(None)
+        for level, seed in ((1, 0), (5, 1), (8, 2), (10, 3)):
+            res = policy.distort(level, image=image, rng=default_rng(seed), enable_debug=True)
+            _same(res.image.mat, PHOTOMETRIC[policy.name](mat, res.config), (policy.name, level, seed))
+
+
+def test_rectangle_streak_full_size(N):
+    from vkit_amd.element import Image
+    from vkit_amd.mechanism.distortion_policy.photometric import streak as P_streak
+    mat = default_rng(32).integers(0, 256, (2048, 2048, 3), dtype=np.uint8)
+    policy = P_streak.rectangle_streak_policy_factory.create(None)
+    for level, seed in ((3, 0), (9, 4)):
+        res = policy.distort(level, image=Image(mat=mat), rng=default_rng(seed), enable_debug=True)
+        _same(res.image.mat, PHOTOMETRIC['rectangle_streak'](mat, res.config), (level, seed))
+
+
+# ---------------------------------------------------------------------------------------------- geometric policies
+def test_geometric_policies_all_elements(N):
+    """The ten geometric policies, sampled configs, Image + Mask + ScoreMap + points in one call."""
+    from vkit_amd.element import Point, PointList
+    from vkit_amd.mechanism.distortion_policy.geometric import affine as P_aff, camera as P_cam, mls as P_mls
+    factories = [P_aff.shear_hori_policy_factory, P_aff.shear_vert_policy_factory, P_aff.rotate_policy_factory,
+                 P_aff.skew_hori_policy_factory, P_aff.skew_vert_policy_factory, P_mls.similarity_mls_policy_factory,
+                 P_cam.camera_plane_only_policy_factory, P_cam.camera_cubic_curve_policy_factory,
+                 P_cam.camera_plane_line_fold_policy_factory, P_cam.camera_plane_line_curve_policy_factory]
+    rng = default_rng(41)
+    ran = 0
+    for factory in factories:
+        policy = factory.create(None)
+        for level in (2, 6, 10):
+            h, w = int(rng.integers(90, 700)), int(rng.integers(90, 700))
+            image, mask, score = _elements(h, w, level)
+            pts = PointList(Point.create(y=int(y), x=int(x)) for y, x in zip(rng.integers(0, h - 1, 6), rng.integers(0, w - 1, 6)))
+            seed = int(rng.integers(1 << 30))
+            res = policy.distort(level, image=image, mask=mask, score_map=score, points=pts, rng=default_rng(seed),
+                                 enable_debug=True)
+            if res.state is None or res.image is image:
+                continue
+            wi, wm, ws = replay(policy.name, res.config, res.state, image.mat, mask.mat, score.mat)
+            _same(res.image.mat, wi, (policy.name, level, 'image'))
+            _same(res.mask.mat, wm, (policy.name, level, 'mask'))
+            _same(res.score_map.mat, ws, (policy.name, level, 'score_map'))
+            assert len(res.points) == 6 and res.shape == res.image.shape
+            ran += 1
+    assert ran >= 25
+
+
+def test_positional_reference_style_call(N):
+    """the grid-based override keeps the base signature -- elements passed positionally, as the reference's
+    callers may (interface.py:824-840)."""
+    from vkit_amd.mechanism import distortion as D
+    from vkit_amd.mechanism.distortion_policy.geometric import camera as P_cam
+    image, mask, score = _elements(160, 120, 3)
+    cfg = P_cam.CameraPlaneOnlyConfigGenerator(P_cam.CameraPlaneOnlyConfigGeneratorConfig(), 4)((160, 120), default_rng(2))
+    a = D.camera_plane_only.distort(cfg, None, image, mask, score)
+    b = D.camera_plane_only.distort(cfg, image=image, mask=mask, score_map=score)
+    _same(a.image.mat, b.image.mat, 'image')
+    _same(a.mask.mat, b.mask.mat, 'mask')
+    _same(a.score_map.mat, b.score_map.mat, 'score_map')
+    assert a.state is None and a.shape == a.image.shape

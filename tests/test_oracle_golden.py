@@ -424,3 +424,69 @@ def test_resize_restatements_known_answers():
     up = O.resize(ramp, (8, 72), O.INTER_LANCZOS4).astype(int)
     ideal = (np.arange(72) + 0.5) / 2 - 0.5
     assert (np.abs(up[:, 8:-8] - 4 * ideal[8:-8]) <= 1.0).all()
+
+
+def test_mls_project_matches_reference_lattices(golden_dir):
+    """The restatement of SimilarityMlsPointProjector.project_point (float32, numpy / OpenBLAS accumulation orders) against
+    lattices the imported reference produced: five small states and seven full-size ones (1024^2 - 4096^2)."""
+    import json
+
+    def src_lattice(h, w, gs):
+        ys = list(range(0, h, gs)) + ([h - 1] if (h - 1) % gs else [])
+        xs = list(range(0, w, gs)) + ([w - 1] if (w - 1) % gs else [])
+        return np.array([[(x, y) for x in xs] for y in ys], np.float64)
+
+    checked = 0
+    for fname in ('mls_states.npz', 'mls_lattices.npz'):
+        M = np.load(os.path.join(golden_dir, fname))
+        for m in json.loads(bytes(M['meta_json'])):
+            k = m['key']
+            if k + '_src_handles' not in M.files:
+                continue
+            ps, qs = M[k + '_src_handles'], M[k + '_dst_handles']
+            V = src_lattice(m['h'], m['w'], m['grid_size'])
+            got = O.mls_project(np.rint(ps).astype(np.float32), np.rint(qs).astype(np.float32), ps, qs, V.reshape(-1, 2))
+            got = got.reshape(V.shape)
+            shift = np.array([m['shift'][1], m['shift'][0]], np.float64)
+            rounded = np.rint(got)
+            assert [int(rounded[..., 1].min()), int(rounded[..., 0].min())] == m['shift']
+            if k + '_projected' in M.files:
+                assert (got == M[k + '_projected'].astype(np.float64)).all(), k
+            else:
+                assert (got - shift == M[k + '_dst_grid_smooth']).all(), k
+            assert (np.rint(got - shift).astype(np.int32) == M[k + '_dst_grid']).all(), k
+            checked += got.shape[0] * got.shape[1]
+    assert checked > 60000
+
+
+def test_mls_project_small_handle_counts_and_pins():
+    """Handle counts around numpy's reduction special cases (4 handles: the paired sgemv; < 8 / >= 8: the pairwise
+    sum) against the per-vertex numpy statement, pinned vertices and the divide-by-zero error."""
+    import os as _os
+    _os.environ['VKX_MLS_HOST_PROJECTION'] = '1'
+    try:
+        from vkit_amd.element import Point, PointTuple
+        from vkit_amd.mechanism.distortion.geometric.mls import SimilarityMlsPointProjector
+        from vkit_amd.mechanism.distortion.geometric.grid_rendering.point_projector import PointProjector
+        rng = default_rng(11)
+        for n in (2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 24, 25, 31, 40):
+            src = [(float(x) + 0.25 * (i % 3), float(y)) for i, (x, y) in enumerate(rng.integers(0, 300, (n, 2)))]
+            dst = [(x + float(rng.normal(0, 9)), y + float(rng.normal(0, 9))) for x, y in src]
+            sp = PointTuple(Point.create(y=y, x=x) for x, y in src)
+            dp = PointTuple(Point.create(y=y, x=x) for x, y in dst)
+            proj = SimilarityMlsPointProjector(sp, dp)
+            V = rng.integers(0, 300, (60, 2)).astype(np.float64) + 0.5     # never on an integer handle position
+            V[0] = src[-1]                                                  # an exact handle hit: identity
+            want = PointProjector.project_array(proj, V)
+            sm = lambda pts: np.asarray([(p.smooth_x, p.smooth_y) for p in pts], np.float64)   # noqa: E731
+            got = O.mls_project(proj.p, proj.q, sm(sp), sm(dp), V)
+            assert (got == want).all(), n
+            assert tuple(got[0]) == dst[-1]
+        # handle 1 sits at smooth x + 0.25: a vertex on its INTEGER position is no exact hit and divides by zero
+        on_integer = np.array([[float(proj.p[1, 0]), float(proj.p[1, 1])]])
+        with pytest.raises(FloatingPointError):
+            O.mls_project(proj.p, proj.q, sm(sp), sm(dp), on_integer)
+        with pytest.raises(FloatingPointError):
+            PointProjector.project_array(proj, on_integer)
+    finally:
+        _os.environ.pop('VKX_MLS_HOST_PROJECTION', None)

@@ -27,6 +27,10 @@ class VkxError(RuntimeError):
     pass
 
 
+# error codes of include/vkx.h
+ERR_INVALID, ERR_HIP, ERR_NOMEM, ERR_UNSUPPORTED, ERR_OUT_OF_LATTICE, ERR_DIVIDE = -1, -2, -3, -4, -5, -6
+
+
 class VkxElem(ctypes.Structure):
     _fields_ = [
         ('src', c_void_p),
@@ -148,6 +152,8 @@ for _sfx in ('', '_dev'):
     _SIGNATURES['vkx_gaussian_blur_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_int, c_double, c_void_p, c_ssize]
     _SIGNATURES['vkx_grid_project_points'] = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
                                               c_void_p]
+    _SIGNATURES['vkx_mls_project'] = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]
+    _SIGNATURES['vkx_mls_project_dev'] = _SIGNATURES['vkx_mls_project'] + [c_void_p]
     _SIGNATURES['vkx_color_shift_rgb' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_int, c_void_p, c_ssize]
     _SIGNATURES['vkx_cvt_rgb_hsv_u8' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_int, c_void_p, c_ssize]
     _SIGNATURES['vkx_mean_shift_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_int, c_int, c_int, c_int, c_uint, c_void_p,
@@ -443,6 +449,8 @@ def grid_remap(mats, src_vertices, dst_vertices, dst_shape, ctx=None):
     """Gathers every array of ``mats`` (uint8 HxW[xC] / float32 HxW, all of one source shape) through one grid."""
     ctx = ctx or default_ctx()
     sv, dv = _vertices(src_vertices), _vertices(dst_vertices)
+    if sv.shape != dv.shape:
+        raise ValueError('source / destination grids differ in shape')
     rows, cols = sv.shape[:2]
     dh, dw = int(dst_shape[0]), int(dst_shape[1])
     outs = []
@@ -516,8 +524,31 @@ def project_points(src_vertices, dst_vertices, grid_size, points_xy, smooth_xy, 
     out = np.empty_like(ps)
     rc = lib().vkx_grid_project_points(ctx.handle, _ptr(sv), _ptr(dv), rows, cols, int(grid_size), _ptr(pi), _ptr(ps),
                                        pi.shape[0], _ptr(out))
-    if rc == -1 and 'outside the lattice cells' in last_error():
+    if rc == ERR_OUT_OF_LATTICE:
         raise IndexError(last_error())
+    check(rc)
+    return out
+
+
+def mls_project(src_handles_xy, dst_handles_xy, src_handles_smooth_xy, dst_handles_smooth_xy, vertices_xy, ctx=None):
+    """SimilarityMlsPointProjector.project_point (geometric/mls.py:38-135) for every vertex in one launch.
+
+    ``src_handles_xy`` / ``dst_handles_xy``: float32 [n, 2], the integer handle positions the reference feeds its float32
+    arithmetic (``PointTuple.to_smooth_np_array``); ``*_smooth_xy``: float64 [n, 2], the handles' smooth positions (a
+    vertex exactly on a source handle maps to its target); ``vertices_xy``: float64 [m, 2].  Returns float64 [m, 2].
+    FloatingPointError where the reference's ``np.errstate(divide='raise')`` fires."""
+    ctx = ctx or default_ctx()
+    p = np.ascontiguousarray(src_handles_xy, dtype=np.float32).reshape(-1, 2)
+    q = np.ascontiguousarray(dst_handles_xy, dtype=np.float32).reshape(-1, 2)
+    ps = np.ascontiguousarray(src_handles_smooth_xy, dtype=np.float64).reshape(-1, 2)
+    qs = np.ascontiguousarray(dst_handles_smooth_xy, dtype=np.float64).reshape(-1, 2)
+    if not (p.shape == q.shape == ps.shape == qs.shape):
+        raise ValueError('handle arrays differ in length')
+    v = np.ascontiguousarray(vertices_xy, dtype=np.float64).reshape(-1, 2)
+    out = np.empty_like(v)
+    rc = lib().vkx_mls_project(ctx.handle, _ptr(p), _ptr(q), _ptr(ps), _ptr(qs), p.shape[0], _ptr(v), v.shape[0], _ptr(out))
+    if rc == ERR_DIVIDE:
+        raise FloatingPointError(last_error())
     check(rc)
     return out
 

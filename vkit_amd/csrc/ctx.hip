@@ -77,13 +77,34 @@ VKX_EXPORT int vkx_ctx_destroy(vkx_ctx *ctx)
 VKX_EXPORT int vkx_ctx_sync(vkx_ctx *ctx)
 {
     VKX_REQUIRE(ctx != nullptr, "ctx is NULL");
+    vkx_device_guard guard(ctx);
     VKX_HIP(hipStreamSynchronize(ctx->stream));
     return VKX_OK;
+}
+
+vkx_device_guard::vkx_device_guard(const vkx_ctx *ctx)
+{
+    if (!ctx || hipGetDevice(&prev) != hipSuccess || prev == ctx->device) return;
+    switched = hipSetDevice(ctx->device) == hipSuccess;
+}
+
+vkx_device_guard::~vkx_device_guard()
+{
+    if (switched) (void)hipSetDevice(prev);
 }
 
 VKX_EXPORT int vkx_ctx_set_stream(vkx_ctx *ctx, void *hip_stream)
 {
     VKX_REQUIRE(ctx != nullptr, "ctx is NULL");
+    if (hip_stream) {
+        // a borrowed stream must live on the ctx's device: its scratch and kernels do
+        hipDevice_t dev = -1;
+        vkx_device_guard guard(ctx);
+        if (hipStreamGetDevice((hipStream_t)hip_stream, &dev) == hipSuccess && (int)dev != ctx->device) {
+            vkx_set_error("vkx_ctx_set_stream: the stream belongs to device %d, the ctx to device %d", (int)dev, ctx->device);
+            return VKX_ERR_INVALID;
+        }
+    }
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return VKX_OK;
 }
@@ -93,7 +114,7 @@ VKX_EXPORT void *vkx_ctx_stream(vkx_ctx *ctx) { return ctx ? (void *)ctx->stream
 int vkx_scratch_reserve(vkx_ctx *ctx, vkx_scratch *s, size_t bytes)
 {
     if (bytes <= s->cap) return VKX_OK;
-    VKX_HIP(hipSetDevice(ctx->device));
+    vkx_device_guard guard(ctx);
     if (s->ptr) {
         // the old block may still be in use by work queued on the stream
         VKX_HIP(hipStreamSynchronize(ctx->stream));
@@ -115,7 +136,7 @@ int vkx_scratch_reserve(vkx_ctx *ctx, vkx_scratch *s, size_t bytes)
 VKX_EXPORT int vkx_malloc(vkx_ctx *ctx, size_t bytes, void **dptr)
 {
     VKX_REQUIRE(ctx && dptr, "NULL argument");
-    VKX_HIP(hipSetDevice(ctx->device));
+    vkx_device_guard guard(ctx);
     hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
     if (e != hipSuccess) {
         vkx_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
@@ -128,7 +149,7 @@ VKX_EXPORT int vkx_free(vkx_ctx *ctx, void *dptr)
 {
     VKX_REQUIRE(ctx != nullptr, "ctx is NULL");
     if (!dptr) return VKX_OK;
-    VKX_HIP(hipSetDevice(ctx->device));
+    vkx_device_guard guard(ctx);
     VKX_HIP(hipStreamSynchronize(ctx->stream));
     VKX_HIP(hipFree(dptr));
     return VKX_OK;
@@ -138,6 +159,7 @@ VKX_EXPORT int vkx_upload(vkx_ctx *ctx, void *dptr, const void *hptr, size_t byt
 {
     VKX_REQUIRE(ctx && (bytes == 0 || (dptr && hptr)), "NULL argument");
     if (!bytes) return VKX_OK;
+    vkx_device_guard guard(ctx);
     VKX_HIP(hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, ctx->stream));
     VKX_HIP(hipStreamSynchronize(ctx->stream));
     return VKX_OK;
@@ -147,6 +169,7 @@ VKX_EXPORT int vkx_download(vkx_ctx *ctx, void *hptr, const void *dptr, size_t b
 {
     VKX_REQUIRE(ctx && (bytes == 0 || (dptr && hptr)), "NULL argument");
     if (!bytes) return VKX_OK;
+    vkx_device_guard guard(ctx);
     VKX_HIP(hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
     VKX_HIP(hipStreamSynchronize(ctx->stream));
     return VKX_OK;
@@ -156,6 +179,7 @@ VKX_EXPORT int vkx_memset(vkx_ctx *ctx, void *dptr, int value, size_t bytes)
 {
     VKX_REQUIRE(ctx && (bytes == 0 || dptr), "NULL argument");
     if (!bytes) return VKX_OK;
+    vkx_device_guard guard(ctx);
     VKX_HIP(hipMemsetAsync(dptr, value, bytes, ctx->stream));
     return VKX_OK;
 }
@@ -173,7 +197,7 @@ static hipEvent_t take_event(vkx_ctx *ctx)
     return e;
 }
 
-vkx_timed::vkx_timed(vkx_ctx *c, const char *kernel_name) : ctx(c), slot(-1)
+vkx_timed::vkx_timed(vkx_ctx *c, const char *kernel_name) : guard(c), ctx(c), slot(-1)
 {
     if (!ctx || !ctx->timing) return;
     int id = -1;
@@ -208,6 +232,7 @@ VKX_EXPORT int vkx_ctx_set_timing(vkx_ctx *ctx, int enabled)
 VKX_EXPORT int vkx_ctx_collect_timings(vkx_ctx *ctx, int *n_kernels)
 {
     VKX_REQUIRE(ctx && n_kernels, "NULL argument");
+    vkx_device_guard guard(ctx);
     VKX_HIP(hipStreamSynchronize(ctx->stream));
     for (auto &l : ctx->launches) {
         float ms = 0.f;

@@ -237,7 +237,7 @@ VKX_EXPORT int vkx_grid_project_points(vkx_ctx *ctx, const int32_t *src_vertices
     VKX_HIP(hipStreamSynchronize(ctx->stream));
     if (bad) {
         vkx_set_error("point %d lies outside the lattice cells", bad - 1);
-        return VKX_ERR_INVALID;
+        return VKX_ERR_OUT_OF_LATTICE;
     }
     return VKX_OK;
 }

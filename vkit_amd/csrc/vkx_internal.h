@@ -80,8 +80,22 @@ struct vkx_ctx {
     std::vector<long long> timing_count;
 };
 
-// RAII scope around ONE kernel launch: records a start / stop event pair on the ctx stream when timing is on.
+// The current device is per-thread state: a ctx used from a thread other than its creator (or after the caller
+// switched devices, e.g. torch.cuda.set_device) must see its own device while it launches on ctx->stream.
+// Saves, sets and restores; free when the device is already current.
+struct vkx_device_guard {
+    int prev = -1;
+    bool switched = false;
+    explicit vkx_device_guard(const vkx_ctx *ctx);
+    ~vkx_device_guard();
+    vkx_device_guard(const vkx_device_guard &) = delete;
+    vkx_device_guard &operator=(const vkx_device_guard &) = delete;
+};
+
+// RAII scope around ONE kernel launch: binds the ctx device for the launch and records a start / stop event pair on
+// the ctx stream when timing is on.
 struct vkx_timed {
+    vkx_device_guard guard;
     vkx_ctx *ctx;
     int slot;
     vkx_timed(vkx_ctx *ctx, const char *kernel_name);

@@ -3,6 +3,7 @@
 ``fill_np_array`` keeps the reference's signature and semantics (vkit/element/opt.py:118-209) but the
 arithmetic runs in the ``k_fill`` HIP kernel through ``vkx_fill_u8``; there is no numpy fallback.
 """
+import threading
 from typing import Optional, Tuple, Union
 
 import numpy as np
@@ -62,12 +63,15 @@ class deferred_fill:
         return base is self.base
 
     def __enter__(self):
-        _DEFERRED.append(self)
+        _deferred_stack().append(self)
         return self
 
     def __exit__(self, exc_type, exc, tb):
-        popped = _DEFERRED.pop()
-        assert popped is self
+        stack = _deferred_stack()
+        if self in stack:
+            stack.remove(self)
+        # an exception inside the block abandons the recorded layers: the destination is left as it was, the
+        # exception propagates
         if exc_type is None and self.layers:
             from vkit_amd import _native
             writeable = self.base.flags.writeable
@@ -80,7 +84,16 @@ class deferred_fill:
         return False
 
 
-_DEFERRED = []
+# one stack per thread: contexts (streams, scratch) are per thread too (_native.default_ctx), and two threads
+# assembling pages at once must not see each other's open composites
+_DEFERRED_TLS = threading.local()
+
+
+def _deferred_stack():
+    stack = getattr(_DEFERRED_TLS, 'stack', None)
+    if stack is None:
+        stack = _DEFERRED_TLS.stack = []
+    return stack
 
 
 def fill_np_array(
@@ -132,8 +145,9 @@ def fill_np_array(
     if np_mask is not None:
         mask_u8 = np_mask.view(np.uint8) if np_mask.dtype == np.bool_ else (np_mask > 0).view(np.uint8)
     layer = _native.make_layer((up, left, bh, bw), cn, value, mask=mask_u8, alpha=alpha, mode=mode, dtype=mat.dtype)
-    if _DEFERRED and _DEFERRED[-1].accepts(base):
-        _DEFERRED[-1].layers.append(layer)
+    stack = _deferred_stack()
+    if stack and stack[-1].accepts(base):
+        stack[-1].layers.append(layer)
         return
     if base.flags.c_contiguous:
         _native.fill(base, [layer])

@@ -20,8 +20,10 @@ from .photometric.noise import (
     GaussionNoiseConfig, gaussion_noise, ImpulseNoiseConfig, impulse_noise, SpeckleNoiseConfig, speckle_noise,
     PoissonNoiseConfig, poisson_noise,
 )
-from .photometric.effect import FogConfig, fog, PixelationConfig, pixelation
-from .photometric.streak import LineStreakConfig, line_streak, RectangleStreakConfig, rectangle_streak
+from .photometric.effect import FogConfig, fog, JpegQualityConfig, jpeg_quality, PixelationConfig, pixelation
+from .photometric.streak import (
+    EllipseStreakConfig, ellipse_streak, LineStreakConfig, line_streak, RectangleStreakConfig, rectangle_streak,
+)
 
 # geometric
 from .geometric.affine import (

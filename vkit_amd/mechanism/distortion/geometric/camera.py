@@ -62,6 +62,10 @@ def project_points(np_3d_points: np.ndarray, rotation_vec: np.ndarray, translati
 class Point2dTo3dStrategy:
 
     def generate_np_3d_points(self, points: PointTuple) -> np.ndarray:
+        return self.lift(points.to_smooth_np_array())
+
+    def lift(self, np_2d_points: np.ndarray) -> np.ndarray:
+        """float32 [n, 2] page positions (the INTEGER positions, PointTuple.to_smooth_np_array) -> [n, 3]."""
         raise NotImplementedError()
 
 
@@ -155,6 +159,12 @@ class CameraPointProjector(PointProjector):
     def project_point(self, src_point: Point):
         return self.project_points(PointTuple.from_point(src_point))[0]
 
+    def project_array(self, smooth_xy: np.ndarray) -> np.ndarray:
+        # the strategies consume the rounded positions as float32 (PointTuple.to_smooth_np_array)
+        np_2d_points = np.rint(np.asarray(smooth_xy, dtype=np.float64)).astype(np.int64).astype(np.float32)
+        np_3d_points = self.point_2d_to_3d_strategy.lift(np_2d_points)
+        return np.asarray(self.camera_model.project_np_points_from_3d_to_2d(np_3d_points), dtype=np.float64)
+
 
 class DistortionStateCameraOperation(DistortionStateImageGridBased[_T_CONFIG]):
 
@@ -190,8 +200,7 @@ class CameraPlaneOnlyConfig(DistortionConfig):
 
 class CameraPlaneOnlyPoint2dTo3dStrategy(Point2dTo3dStrategy):
 
-    def generate_np_3d_points(self, points: PointTuple) -> np.ndarray:
-        np_2d_points = points.to_smooth_np_array()
+    def lift(self, np_2d_points: np.ndarray) -> np.ndarray:
         return np.hstack((np_2d_points, np.zeros((np_2d_points.shape[0], 1), dtype=np.float32)))
 
 
@@ -237,8 +246,7 @@ class CameraCubicCurvePoint2dTo3dStrategy(Point2dTo3dStrategy):
         self.plane_projection_range = along.max() - self.plane_projection_min
         self.curve_scale = curve_scale
 
-    def generate_np_3d_points(self, points: PointTuple) -> np.ndarray:
-        np_2d_points = points.to_smooth_np_array()
+    def lift(self, np_2d_points: np.ndarray) -> np.ndarray:
         along = np.matmul(self.rotation_mat, np_2d_points.transpose())[0]
         ratios = (along - self.plane_projection_min) / self.plane_projection_range
         poly = np.asarray([
@@ -289,8 +297,7 @@ class CameraPlaneLinePoint2dTo3dStrategy(Point2dTo3dStrategy):
         self.weights_func = weights_func
         self.perturb_vec = np.asarray(perturb_vec, dtype=np.float32)
 
-    def generate_np_3d_points(self, points: PointTuple) -> np.ndarray:
-        np_2d_points = points.to_smooth_np_array()
+    def lift(self, np_2d_points: np.ndarray) -> np.ndarray:
         distances = np.abs((np_2d_points * self.line_params_a_b).sum(axis=1) + self.line_param_c)
         weights = self.weights_func(distances / self.distance_max, self.alpha)
         np_3d_points = np.hstack((np_2d_points, np.zeros((np_2d_points.shape[0], 1), dtype=np.float32)))

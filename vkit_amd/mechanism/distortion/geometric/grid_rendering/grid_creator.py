@@ -27,9 +27,15 @@ def create_dst_image_grid_and_shift_amounts_and_resize_ratios(src_image_grid: Im
                                                               point_projector: PointProjector,
                                                               resize_as_src: bool = True):
     rows, cols = src_image_grid.shape
-    projected = point_projector.project_points(src_image_grid.flatten_points)
-    assert len(projected) == rows * cols
-    smooth = np.asarray([(p.smooth_x, p.smooth_y) for p in projected], dtype=np.float64).reshape(rows, cols, 2)
+    # the lattice stays an array from end to end (10 816 vertices at 2048^2: no per-vertex Point objects)
+    projected = np.asarray(point_projector.project_array(src_image_grid.smooth.reshape(-1, 2)), dtype=np.float64)
+    assert projected.shape == (rows * cols, 2)
+    if not np.isfinite(projected).all():
+        # the reference builds a Point per vertex and fails in its round() (element/point.py:31-47)
+        if np.isnan(projected).any():
+            raise ValueError('cannot convert float NaN to integer')
+        raise OverflowError('cannot convert float infinity to integer')
+    smooth = np.array(projected.reshape(rows, cols, 2))
 
     # the shift is the minimum of the ROUNDED positions (an integer), applied to the smooth positions
     rounded = np.rint(smooth)

@@ -143,26 +143,35 @@ class DistortionImageGridBased(Distortion[_T_CONFIG, _T_STATE]):
         )
 
     def distort(self, config_or_config_generator, shapable_or_shape=None, image=None, mask=None, score_map=None,
-                **kwargs):
-        """Same contract as ``Distortion.distort``; Image + Mask + ScoreMap of one call share ONE device pass
-        (one ownership raster, one homography evaluation per pixel, three gathers) instead of three."""
+                point=None, points=None, corner_points=None, polygon=None, polygons=None, get_active_mask=False,
+                get_config=False, get_state=False, disable_clip_result_elements=False, rng=None):
+        """Same signature and contract as ``Distortion.distort`` (distortion/interface.py:824-912); Image + Mask +
+        ScoreMap of one call share ONE device pass (one ownership raster, one homography evaluation per pixel, three
+        gathers) instead of three."""
         shared = [e for e in (image, mask, score_map) if e is not None]
         if len(shared) < 2:
-            return super().distort(config_or_config_generator, shapable_or_shape, image=image, mask=mask,
-                                   score_map=score_map, **kwargs)
-        result = super().distort(config_or_config_generator, shapable_or_shape or shared[0].shape, image=None,
-                                 mask=None, score_map=None, get_state=True,
-                                 **{k: v for k, v in kwargs.items() if k != 'get_state'})
+            return super().distort(config_or_config_generator, shapable_or_shape, image, mask, score_map, point, points,
+                                   corner_points, polygon, polygons, get_active_mask, get_config, get_state,
+                                   disable_clip_result_elements, rng)
+        if shapable_or_shape is None:
+            shapable_or_shape = shared[0]
+        # everything but the three pixel elements through the base operator (it also prepares config, rng and state)
+        result = super().distort(config_or_config_generator, shapable_or_shape, None, None, None, point, points,
+                                 corner_points, polygon, polygons, get_active_mask, get_config, True,
+                                 disable_clip_result_elements, rng)
         state = result.state
         outs = _native.grid_remap([e.mat for e in shared], state.src_image_grid.vertices,
                                   state.dst_image_grid.vertices, state.dst_image_grid.image_shape)
         it = iter(outs)
         if image is not None:
             result.image = Image(mat=next(it), mode=image.mode)
+            assert result.shape == result.image.shape
         if mask is not None:
             result.mask = Mask(mat=next(it))
+            assert result.shape == result.mask.shape
         if score_map is not None:
             result.score_map = ScoreMap(mat=next(it))
-        if not kwargs.get('get_state'):
+            assert result.shape == result.score_map.shape
+        if not get_state:
             result.state = None
         return result

@@ -2,6 +2,8 @@
 grid_rendering/point_projector.py)."""
 from typing import Iterable, Union
 
+import numpy as np
+
 from vkit_amd.element import Point, PointList, PointTuple
 
 
@@ -12,3 +14,11 @@ class PointProjector:
 
     def project_points(self, src_points: Union[PointList, PointTuple, Iterable[Point]]):
         return PointList(self.project_point(p) for p in src_points).to_point_tuple()
+
+    def project_array(self, smooth_xy: np.ndarray) -> np.ndarray:
+        """The whole lattice at once: float64 [n, 2] (x, y) in, float64 [n, 2] out -- the array form of what
+        ``create_dst_image_grid_and_shift_amounts_and_resize_ratios`` asks of a projector (grid_creator.py:44-60).
+        Subclasses override it with a vectorised / device path; this default walks ``project_point``."""
+        projected = self.project_points(Point.create(y=float(y), x=float(x)) for x, y in smooth_xy)
+        assert len(projected) == len(smooth_xy)
+        return np.asarray([(p.smooth_x, p.smooth_y) for p in projected], dtype=np.float64).reshape(-1, 2)

@@ -2,16 +2,23 @@
 vkit/mechanism/distortion/geometric/mls.py; Schaefer, McPhail, Warren, "Image deformation using moving least
 squares", 2006, section 2.2).
 
-Host side: every lattice vertex is projected with float32 numpy arithmetic in the reference's order of
-operations, because everything downstream only sees the ROUNDED vertex and a last-bit difference can flip a
-rounding.  Device side: the dense remap through the two integer lattices (grid_rendering).
+Everything downstream only sees the ROUNDED vertex, so a last-bit difference in the float32 arithmetic can flip a
+rounding: the lattice is projected with the reference's float32 operations in the reference's order, including the
+accumulation orders of numpy's reductions and of the BLAS kernels behind ``np.matmul``.  The whole lattice goes
+through ONE device launch (``vkx_mls_project``, csrc/mls.hip: 10 816 vertices x 25 handles at 2048^2 in a few
+microseconds instead of 0.3 - 0.8 s of per-vertex numpy calls); ``project_point`` keeps the reference's
+single-vertex numpy form.  ``VKX_MLS_HOST_PROJECTION=1`` routes the lattice through ``project_point`` vertex by
+vertex -- the reference's own path, for building states on a host without a GPU (the CPU tests); it is never
+selected implicitly.  Device side as well: the dense remap through the two integer lattices (grid_rendering).
 """
+import os
 from typing import Optional, Tuple
 
 import attrs
 import numpy as np
 from numpy.random import Generator as RandomGenerator
 
+from vkit_amd import _native
 from vkit_amd.element import Point, PointTuple
 from ..interface import DistortionConfig
 from .grid_rendering.grid_creator import create_src_image_grid
@@ -75,6 +82,13 @@ class SimilarityMlsPointProjector(PointProjector):
         mu = np.sum(w * np.sum(p_hat * p_hat, axis=1))
         fx, fy = np.sum(terms, axis=0) / mu + q_star
         return Point.create(y=float(fy), x=float(fx))
+
+    def project_array(self, smooth_xy: np.ndarray) -> np.ndarray:
+        if os.environ.get('VKX_MLS_HOST_PROJECTION', '') == '1':
+            return super().project_array(smooth_xy)
+        smooth = lambda pts: np.asarray([(p.smooth_x, p.smooth_y) for p in pts], dtype=np.float64)   # noqa: E731
+        return _native.mls_project(self.p, self.q, smooth(self.src_handle_points), smooth(self.dst_handle_points),
+                                   smooth_xy)
 
 
 class SimilarityMlsState(DistortionStateImageGridBased[SimilarityMlsConfig]):

@@ -2,8 +2,9 @@
 caller-visible numpy Generator stream on the host (like every random plane of the path); the per-pixel work -- blend
 every pixel towards the fog colour with the field as float32 alpha, ``uint8(clip((1 - a) * px + a * fog))`` -- is the
 alpha composite ``vkx_fill_u8`` with one page-sized layer.  ``pixelation`` (:56-86) shrinks with ``cv.resize``
-INTER_LINEAR and grows back with INTER_NEAREST (``vkx_resize_u8``).  ``jpeg_quality`` (an encoder round trip) is
-outside the path."""
+INTER_LINEAR and grows back with INTER_NEAREST (``vkx_resize_u8``).  ``jpeg_quality`` (:25-53, an encoder round trip
+through ``cv.imencode`` / ``cv.imdecode``) is outside the path: the operator exists with the reference's config so that
+policies sample it draw for draw, the image passes through (``photometric/opt.py: pass_through_out_of_path``)."""
 from typing import Any, Mapping, Optional, Tuple
 
 import attrs
@@ -13,6 +14,24 @@ from numpy.random import Generator as RandomGenerator
 from vkit_amd import _native
 from vkit_amd.element import Image, ImageMode
 from ..interface import Distortion, DistortionConfig, DistortionNopState
+from .opt import pass_through_out_of_path
+
+
+@attrs.define
+class JpegQualityConfig(DistortionConfig):
+    quality: int
+
+
+def jpeg_quality_image(config: JpegQualityConfig, state, image: Image, rng: Optional[RandomGenerator]):
+    assert 0 <= config.quality <= 100
+    return pass_through_out_of_path('jpeg_quality', image)
+
+
+jpeg_quality = Distortion(
+    config_cls=JpegQualityConfig,
+    state_cls=DistortionNopState[JpegQualityConfig],
+    func_image=jpeg_quality_image,
+)
 
 
 @attrs.define

@@ -11,6 +11,7 @@ from numpy.random import Generator as RandomGenerator
 from vkit_amd import _native
 from vkit_amd.element import Box, Image
 from ..interface import Distortion, DistortionConfig, DistortionNopState
+from .opt import pass_through_out_of_path
 
 
 @attrs.define
@@ -131,4 +132,28 @@ rectangle_streak = Distortion(
     config_cls=RectangleStreakConfig,
     state_cls=DistortionNopState[RectangleStreakConfig],
     func_image=rectangle_streak_image,
+)
+
+
+@attrs.define
+class EllipseStreakConfig(DistortionConfig):
+    thickness: int = 1
+    aspect_ratio: Optional[float] = None
+    short_side_min: int = 10
+    short_side_step: int = 10
+    color: Tuple[int, int, int] = (0, 0, 0)
+    alpha: float = 1.0
+
+
+def ellipse_streak_image(config: EllipseStreakConfig, state, image: Image, rng: Optional[RandomGenerator]):
+    """reference photometric/streak.py:283-337: concentric ``cv.ellipse`` outlines blended like the other streaks.  The
+    polygonal-arc + thick-polyline rasteriser of cv.ellipse is outside the path; see ``pass_through_out_of_path``."""
+    _check_color(image, config.color)
+    return pass_through_out_of_path('ellipse_streak', image)
+
+
+ellipse_streak = Distortion(
+    config_cls=EllipseStreakConfig,
+    state_cls=DistortionNopState[EllipseStreakConfig],
+    func_image=ellipse_streak_image,
 )

@@ -1,12 +1,29 @@
-"""Config generators of ``pixelation`` and ``fog`` (reference: distortion_policy/photometric/effect.py:56-130)."""
+"""Config generators of ``jpeg_quality``, ``pixelation`` and ``fog`` (reference:
+distortion_policy/photometric/effect.py:24-130)."""
 from typing import Tuple
 
 import attrs
 from numpy.random import Generator as RandomGenerator
 
 from vkit_amd.mechanism import distortion
-from ..opt import sample_float
+from ..opt import sample_float, sample_int
 from ..type import DistortionConfigGenerator, DistortionPolicyFactory
+
+
+@attrs.define
+class JpegQualityConfigGeneratorConfig:
+    quality_min: int = 1
+    quality_max: int = 50
+
+
+class JpegQualityConfigGenerator(DistortionConfigGenerator[JpegQualityConfigGeneratorConfig, distortion.JpegQualityConfig]):
+
+    def __call__(self, shape: Tuple[int, int], rng: RandomGenerator):
+        return distortion.JpegQualityConfig(
+            quality=sample_int(self.level, self.config.quality_min, self.config.quality_max, None, rng, inverse_level=True))
+
+
+jpeg_quality_policy_factory = DistortionPolicyFactory(distortion.jpeg_quality, JpegQualityConfigGenerator)
 
 
 @attrs.define

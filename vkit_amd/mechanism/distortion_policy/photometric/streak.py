@@ -123,3 +123,35 @@ class RectangleStreakConfigGenerator(
 
 
 rectangle_streak_policy_factory = DistortionPolicyFactory(distortion.rectangle_streak, RectangleStreakConfigGenerator)
+
+
+@attrs.define
+class EllipseStreakConfigGeneratorConfig:
+    thickness_min: int = 1
+    thickness_max: int = 3
+    aspect_ratio_min: float = 0.5
+    aspect_ratio_max: float = 1.5
+    short_side_min: int = 5
+    short_side_min_ratio_min: float = 0.01
+    short_side_min_ratio_max: float = 0.25
+    short_side_step_ratio_min: float = 0.8
+    short_side_step_ratio_max: float = 3.0
+    alpha_min: float = 0.2
+    alpha_max: float = 1.0
+
+
+class EllipseStreakConfigGenerator(
+        DistortionConfigGenerator[EllipseStreakConfigGeneratorConfig, distortion.EllipseStreakConfig]):
+
+    def __call__(self, shape: Tuple[int, int], rng: RandomGenerator):
+        cfg = self.config
+        thickness, aspect_ratio, short_side_min, short_side_step, alpha = \
+            sample_params_for_rectangle_and_ellipse_streak(
+                self.level, cfg.thickness_min, cfg.thickness_max, cfg.aspect_ratio_min, cfg.aspect_ratio_max,
+                cfg.short_side_min, cfg.short_side_min_ratio_min, cfg.short_side_min_ratio_max,
+                cfg.short_side_step_ratio_min, cfg.short_side_step_ratio_max, cfg.alpha_min, cfg.alpha_max, shape, rng)
+        return distortion.EllipseStreakConfig(thickness=thickness, aspect_ratio=aspect_ratio,
+                                              short_side_min=short_side_min, short_side_step=short_side_step, alpha=alpha)
+
+
+ellipse_streak_policy_factory = DistortionPolicyFactory(distortion.ellipse_streak, EllipseStreakConfigGenerator)

@@ -3,8 +3,8 @@ distortion_policy/random_distortion.py).
 
 Stage 0 draws 0..2 photometric policies, stage 1 (prob 0.75) exactly one geometric policy, optionally followed
 by a forced rotate stage.  The policy TABLE (names, order, weights) is the reference's, so that a given rng
-state selects the same policies; members that are not on the accelerated path are registered as placeholders
-that raise ``NotImplementedError`` if drawn -- list them in ``disabled_policy_names`` to exclude them.
+state selects the same policies.  Two members (``UNSUPPORTED_POLICY_NAMES``) sample their configs like the
+reference but leave the image unchanged: their pixel work is outside the accelerated path.
 """
 import logging
 from collections import defaultdict
@@ -24,35 +24,13 @@ from .type import DistortionPolicy
 logger = logging.getLogger(__name__)
 
 
-class _UnsupportedPolicy:
-    """Keeps the sampling table aligned with the reference; refuses to run."""
-
-    def __init__(self, name: str):
-        self.name = name
-
-    def distort(self, *args, **kwargs):
-        raise NotImplementedError(
-            f'distortion policy "{self.name}" is not part of the MI355X-accelerated path; add it to '
-            'RandomDistortionFactoryConfig.disabled_policy_names')
-
-    def __repr__(self):
-        return f'DistortionPolicy({self.name}, unsupported)'
-
-
-class _UnsupportedPolicyFactory:
-
-    def __init__(self, name: str):
-        self.name = name
-
-    def create(self, config=None):
-        return _UnsupportedPolicy(self.name)
-
-
+# Policies whose operator passes the image through unchanged (the pixel work is outside this path, see
+# distortion/photometric/opt.py: pass_through_out_of_path); their configs are sampled like the reference's, so the
+# table, the sampling and the rng stream are the reference's whether or not they are listed in disabled_policy_names.
 UNSUPPORTED_POLICY_NAMES = (
     'jpeg_quality',
     'ellipse_streak',
 )
-_U = _UnsupportedPolicyFactory
 
 
 @attrs.define
@@ -275,8 +253,9 @@ _PHOTOMETRIC_POLICY_FACTORIES_AND_DEFAULT_WEIGHTS_SUM_PAIRS = (
       blur.zoom_in_blur_policy_factory), 1.0),
     ((noise.gaussion_noise_policy_factory, noise.poisson_noise_policy_factory, noise.impulse_noise_policy_factory,
       noise.speckle_noise_policy_factory), 3.0),
-    ((_U('jpeg_quality'), effect.pixelation_policy_factory, effect.fog_policy_factory), 1.0),
-    ((streak.line_streak_policy_factory, streak.rectangle_streak_policy_factory, _U('ellipse_streak')), 1.0),
+    ((effect.jpeg_quality_policy_factory, effect.pixelation_policy_factory, effect.fog_policy_factory), 1.0),
+    ((streak.line_streak_policy_factory, streak.rectangle_streak_policy_factory,
+      streak.ellipse_streak_policy_factory), 1.0),
 )
 
 _GEOMETRIC_POLICY_FACTORIES_AND_DEFAULT_WEIGHTS_SUM_PAIRS = (
