@@ -27,6 +27,21 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+# HBM bytes per image from the PMC passes of the current kernel source.  tools/record.sh rewrites this file together
+# with the sha256 of the sources it profiled; a line measured on other sources reports traffic = null instead of a
+# stale figure.
+TRAFFIC_FILE = os.path.join('profiles', 'current_traffic.json')
+KERNEL_SOURCES = ('vkit_amd/csrc/fused.hip', 'vkit_amd/csrc/vkx_cell.h', 'vkit_amd/csrc/vkx_color.h',
+                  'vkit_amd/csrc/vkx_internal.h')
+
+
+def kernel_source_digest():
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 BLUR_SIGMA = 1.0
 HUE_DELTA = 37
@@ -120,14 +135,16 @@ def cpu_baseline_all_cores(size, n_procs, per_proc):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200,
+                    help='timed passes over the batch (the default keeps the timed region above 2 s)')
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=256, help='images per GPU')
     ap.add_argument('--size', type=int, default=2048)
     ap.add_argument('--cpu-sample', type=int, default=64, help='images timed on the CPU oracle (rank 0, N=1)')
     ap.add_argument('--cpu-procs', type=int, default=-1,
                     help='processes of the all-cores CPU leg (-1 = min(64, cores), 0 = skip)')
-    ap.add_argument('--verify', type=int, default=1, help='images of the batch checked against the oracle')
+    ap.add_argument('--verify', type=int, default=4,
+                    help='images of the batch checked against the oracle (spread over the batch, the last one included)')
     ap.add_argument('--noise-workers', type=int, default=-1,
                     help='processes generating the numpy noise planes (0 = in this process, e.g. under rocprofv3)')
     args = ap.parse_args()
@@ -199,7 +216,8 @@ def main():
     verified = 0
     if rank == 0 and args.verify > 0:
         import oracle as O
-        for j in range(min(args.verify, B)):
+        picks = sorted({int(round(k * (B - 1) / max(args.verify - 1, 1))) for k in range(min(args.verify, B))} | {B - 1})
+        for j in picks:
             st = states[j]
             img = np.random.default_rng(1000 + first + j).integers(0, 256, (size, size, 3), dtype=np.uint8)
             mx, my = O.grid_to_map(st.src_image_grid.vertices, st.dst_image_grid.vertices, st.result_shape)
@@ -245,12 +263,18 @@ def main():
     # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), measured in separate
     # rocprofv3 --pmc passes (profiles/) on the same workload and scaled by the number of images of this launch.
     traffic, traffic_source, valu_issue = None, None, None
-    tpath = os.path.join(ROOT, 'profiles', 'r1m_traffic.json')
+    tpath = os.path.join(ROOT, TRAFFIC_FILE)
+    tj = None
     if dominant == 'k_chain_fused' and size == 2048 and os.path.exists(tpath):
         with open(tpath) as fin:
             tj = json.load(fin)
+        if tj.get('kernel_source_digest') != kernel_source_digest():
+            traffic_source = (f'{TRAFFIC_FILE} was measured on other kernel sources (digest '
+                              f'{tj.get("kernel_source_digest")} != {kernel_source_digest()}): not used')
+            tj = None
+    if tj is not None:
         traffic = tj['hbm_bytes_per_image'] * B
-        traffic_source = 'profiles/r1m_traffic.json'
+        traffic_source = f'{TRAFFIC_FILE} <- {tj.get("profile", "?")}'
         if 'valu_insts_per_image' in tj and avg_s > 0:
             # why the HBM fraction is what it is: wavefront VALU instructions (PMC, same profile) at one issue per 4 cycles
             # on 1024 SIMDs (256 CUs x 4) at 2.4 GHz, against the measured launch time
@@ -280,6 +304,7 @@ def main():
             'mean_result_pixels': D,
             'sharding': f'{world} process(es), one per GPU, independent images, no collective',
             'verified_against_oracle': verified,
+            'kernel_source_digest': kernel_source_digest(),
             'setup_s': round(t_setup, 1),
         },
         'roofline': {
@@ -289,6 +314,10 @@ def main():
             'peak': HBM_PEAK_GBS,
             'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS,
+            # the north star words the target as "HBM-read roofline": the bytes the kernel must READ (source once, and the
+            # noise plane of this workload) over the same launch time
+            'read_frac': (3 * S * B) / avg_s / 1e9 / HBM_PEAK_GBS if avg_s > 0 else 0.0,
+            'read_frac_incl_noise_input': (3 * S + 6 * D) * B / avg_s / 1e9 / HBM_PEAK_GBS if avg_s > 0 else 0.0,
             'traffic': traffic,
             'traffic_source': traffic_source,
             'valu_issue': valu_issue,

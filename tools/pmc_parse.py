@@ -23,6 +23,9 @@ def main():
     stats = os.path.join(ROOT, 'gpurun_out', f'stats_{tag}', 'stats_kernel_stats.csv')
     if os.path.exists(stats):
         shutil.copy(stats, os.path.join(out_dir, f'{tag}_kernel_stats_batch64.csv'))
+    stats256 = os.path.join(ROOT, 'gpurun_out', f'stats256_{tag}', 'stats_kernel_stats.csv')
+    if os.path.exists(stats256):
+        shutil.copy(stats256, os.path.join(out_dir, f'{tag}_kernel_stats_batch256.csv'))
     sums = defaultdict(lambda: defaultdict(float))    # kernel -> counter -> sum over dispatches
     counts = defaultdict(lambda: defaultdict(int))
     for path in sorted(glob.glob(os.path.join(ROOT, 'gpurun_out', f'pmc_{tag}', 'p*', '*counter_collection.csv'))):
@@ -74,8 +77,15 @@ def main():
         t.update(source=f'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, batch {images} '
                         f'(profiles/{tag}_pmc_batch{images}.md); FETCH_SIZE doubled (gfx950), WRITE_SIZE as reported',
                  images=images)
+        # the digest of the kernel sources the GPU box profiled (tools/record.sh writes it next to the counters)
+        dpath = os.path.join(ROOT, 'gpurun_out', f'digest_{tag}.txt')
+        if os.path.exists(dpath):
+            t.update(kernel_source_digest=open(dpath).read().strip(), profile=f'profiles/{tag}_pmc_batch{images}.md')
         with open(os.path.join(out_dir, f'{tag}_traffic.json'), 'w') as fout:
             json.dump(t, fout, indent=1)
+        if 'kernel_source_digest' in t:        # what bench.py reads (bench.TRAFFIC_FILE)
+            with open(os.path.join(out_dir, 'current_traffic.json'), 'w') as fout:
+                json.dump(t, fout, indent=1)
     print('\n'.join(lines))
 
 

@@ -67,6 +67,44 @@ T = [
     ('v_mov_b32_dpp_wave_shr1', 'v_mov_b32_dpp {d}, {d} wave_shr:1 row_mask:0xf bank_mask:0xf', '32'),
     ('v_mul_u32_u24_dpp_wave_shr1', 'v_mul_u32_u24_dpp {d}, {d}, {a} wave_shr:1 row_mask:0xf bank_mask:0xf', '32'),
     ('v_add_u32_dpp_row_shr2', 'v_add_u32_dpp {d}, {d}, {a} row_shr:2 row_mask:0xf bank_mask:0xf', '32'),
+    ('v_sub_u32', 'v_sub_u32 {d}, {a}, {d}', '32'),
+    ('v_and_b32', 'v_and_b32 {d}, {a}, {d}', '32'),
+    ('v_or_b32', 'v_or_b32 {d}, {a}, {d}', '32'),
+    ('v_xor_b32', 'v_xor_b32 {d}, {a}, {d}', '32'),
+    ('v_lshlrev_b32', 'v_lshlrev_b32 {d}, 3, {d}', '32'),
+    ('v_lshrrev_b32', 'v_lshrrev_b32 {d}, 3, {d}', '32'),
+    ('v_ashrrev_i32', 'v_ashrrev_i32 {d}, 3, {d}', '32'),
+    ('v_lshlrev_b32_vshift', 'v_lshlrev_b32 {d}, {a}, {d}', '32'),
+    ('v_max_u32', 'v_max_u32 {d}, {a}, {d}', '32'),
+    ('v_min_i32', 'v_min_i32 {d}, {a}, {d}', '32'),
+    ('v_mov_b32', 'v_mov_b32 {d}, {a}', '32'),
+    ('v_add_f32', 'v_add_f32 {d}, {a}, {d}', '32'),
+    ('v_sub_f32', 'v_sub_f32 {d}, {a}, {d}', '32'),
+    ('v_max_f32', 'v_max_f32 {d}, {a}, {d}', '32'),
+    ('v_fmac_f32', 'v_fmac_f32 {d}, {a}, {b}', '32'),
+    ('v_mul_i32_i24', 'v_mul_i32_i24 {d}, {a}, {d}', '32'),
+    ('v_lshl_add_u32', 'v_lshl_add_u32 {d}, {d}, 3, {a}', '32'),
+    ('v_add_lshl_u32', 'v_add_lshl_u32 {d}, {d}, {a}, 3', '32'),
+    ('v_xad_u32', 'v_xad_u32 {d}, {d}, {a}, {b}', '32'),
+    ('v_or3_b32', 'v_or3_b32 {d}, {d}, {a}, {b}', '32'),
+    ('v_cndmask_b32_e64_sgpr', 'v_cndmask_b32_e64 {d}, {d}, {a}, s[20:21]', '32'),
+    ('v_cmp_lt_u32_e64_sgpr', 'v_cmp_lt_u32_e64 s[22:23], {d}, {a}', '32'),
+    ('v_cmp_then_cndmask_pair', 'v_cmp_lt_u32_e32 vcc, {d}, {a}\\n\\tv_cndmask_b32_e32 {d}, {d}, {b}, vcc', '32'),
+    ('v_add_co_u32', 'v_add_co_u32 {d}, vcc, {a}, {d}', '32'),
+    ('v_readlane_b32', 'v_readlane_b32 s20, {d}, 3', '32'),
+    ('v_readfirstlane_b32', 'v_readfirstlane_b32 s20, {d}', '32'),
+    ('v_sub_u32_sdwa_byte', 'v_sub_u32_sdwa {d}, {d}, {a} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD', '32'),
+    ('v_and_b32_dpp_row_shr1', 'v_and_b32_dpp {d}, {d}, {a} row_shr:1 row_mask:0xf bank_mask:0xf', '32'),
+    ('v_fma_f32_neg', 'v_fma_f32 {d}, -{a}, {b}, {d}', '32'),
+    ('v_mul_f32_dpp_row_shr1', 'v_mul_f32_dpp {d}, {d}, {a} row_shr:1 row_mask:0xf bank_mask:0xf', '32'),
+    ('v_cvt_u32_f32', 'v_cvt_u32_f32 {d}, {d}', '32'),
+    ('v_floor_f32', 'v_floor_f32 {d}, {d}', '32'),
+    ('v_fract_f32', 'v_fract_f32 {d}, {d}', '32'),
+    ('v_min3_u32', 'v_min3_u32 {d}, {d}, {a}, {b}', '32'),
+    ('v_pk_add_i16', 'v_pk_add_i16 {d}, {a}, {d}', '32'),
+    ('v_pk_min_i16', 'v_pk_min_i16 {d}, {a}, {d}', '32'),
+    ('v_pk_lshrrev_b16', 'v_pk_lshrrev_b16 {d}, 3, {d}', '32'),
+    ('v_fma_f32_x2_independent', 'v_fma_f32 {d}, {a}, {b}, {d}', '32'),
     ('v_permlane32_swap_b32', 'v_permlane32_swap_b32 {d}, {a}', '32'),
     ('ds_bpermute_b32', 'ds_bpermute_b32 {d}, {a}, {d}', '32lds'),
     ('ds_read_b32', 'ds_read_b32 {d}, {a}', '32lds'),
@@ -80,37 +118,25 @@ UNROLL = 32
 
 
 def kernel(idx, name, tmpl, kind):
+    """Operands: %0-%3 64-bit accumulators d, %4 / %5 64-bit sources a / b, %6-%9 32-bit accumulators, %10 / %11 32-bit
+    sources, %12 a 128-bit register (LDS reads).  A '32' kernel uses %6-%9 as d and %10 / %11 as a / b."""
     lds = kind.endswith('lds')
     base = kind.replace('lds', '')
     lines = []
     for u in range(UNROLL):
         k = u % 4
         if base == '32':
-            s = tmpl.format(d=f'%{k}', a='%4', b='%5', c='%5')
+            s = tmpl.format(d=f'%{6 + k}', a='%10', b='%11')
         elif base == '64':
-            s = tmpl.format(d=f'%{k}', a='%4', b='%5', d32=f'%{k}', a32='%6', b32='%7')
-            # 64-bit operands print as register pairs; *_32 forms use the separate 32-bit inputs
+            s = tmpl.format(d=f'%{k}', a='%4', b='%5', d32=f'%{6 + k}', a32='%10', b32='%11')
         else:
-            s = tmpl.format(q='%8', a32='%6')
+            s = tmpl.format(q='%12', a32='%10')
         lines.append(s)
     if lds:
         lines.append('s_waitcnt lgkmcnt(0)')
     body = '\\n\\t'.join(lines)
-    if base == '32':
-        decl = 'uint32_t d0 = t, d1 = t * 3u + 1u, d2 = t ^ 0x55u, d3 = t + 7u; uint32_t a = (t & 63u) * 4u, b = 0x01020304u;'
-        cons = '"+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(a), "v"(b)'
-        fin = 'out[gid] = d0 + d1 + d2 + d3;'
-    elif base == '64':
-        decl = ('double d0 = 1.0 + t * 1e-3, d1 = 1.5 + t * 1e-3, d2 = 2.0 + t * 1e-3, d3 = 2.5 + t * 1e-3; '
-                'double a = 1.0000001, b = 0.9999999; uint32_t a32 = (t & 63u) * 8u, b32 = 3u;')
-        cons = '"+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(a), "v"(b), "v"(a32), "v"(b32)'
-        fin = 'out[gid] = (uint32_t)__double_as_longlong(d0 + d1 + d2 + d3);'
-    else:
-        decl = ('double d0 = 0, d1 = 0, d2 = 0, d3 = 0, a = 0, b = 0; uint32_t a32 = (t & 63u) * 16u, b32 = 0; '
-                'typedef uint32_t u4 __attribute__((ext_vector_type(4))); u4 q = {0, 0, 0, 0};')
-        cons = '"+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(a), "v"(b), "v"(a32), "v"(b32), "v"(q)'
-        fin = 'out[gid] = q.x + q.y;'
-    clobber = ', "vcc"' if 'vcc' in tmpl else ''
+    scale = {'32': 4, '64': 8, '128': 16}[base]
+    clobber = (', "vcc"' if 'vcc' in tmpl else '') + (', "s20", "s21", "s22", "s23"' if 's2' in tmpl else '')
     return f'''
 __global__ void __launch_bounds__(512, 8) k{idx}(uint32_t *out, int iters)
 {{
@@ -118,10 +144,15 @@ __global__ void __launch_bounds__(512, 8) k{idx}(uint32_t *out, int iters)
     const uint32_t t = threadIdx.x, gid = blockIdx.x * 512 + t;
     lds[t] = t; lds[t + 512] = t;
     __syncthreads();
-    {decl}
+    double d0 = 1.0 + t * 1e-3, d1 = 1.5 + t * 1e-3, d2 = 2.0 + t * 1e-3, d3 = 2.5 + t * 1e-3, a = 1.0000001, b = 0.9999999;
+    uint32_t e0 = t, e1 = t * 3u + 1u, e2 = t ^ 0x55u, e3 = t + 7u, a32 = (t & 63u) * {scale}u, b32 = 0x01020304u;
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4 q = {{0, 0, 0, 0}};
     for (int i = 0; i < iters; i++)
-        asm volatile("{body}" : {cons} : "memory"{clobber});
-    {fin}
+        asm volatile("{body}"
+                     : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(a), "+v"(b), "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3),
+                       "+v"(a32), "+v"(b32), "+v"(q) : : "memory"{clobber});
+    out[gid] = (uint32_t)__double_as_longlong(d0 + d1 + d2 + d3) + e0 + e1 + e2 + e3 + q.x + q.y;
     if (iters < 0) out[0] = lds[t];
 }}
 '''

@@ -208,6 +208,20 @@ __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
     return r;
 }
 
+// the same with a wave-uniform multiplier / addend held in an SGPR (a VOP3 instruction reads one scalar operand for free)
+__device__ __forceinline__ uint32_t mad_u24_ks(uint32_t k_uniform, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "s"(k_uniform), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t mad_u24_cs(uint32_t a, uint32_t b, uint32_t c_uniform)
+{
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_uniform));
+    return r;
+}
+
 // a wave-uniform 64-bit value, moved into SGPRs
 __device__ __forceinline__ uint64_t uniform64(uint64_t v)
 {
@@ -242,6 +256,27 @@ __device__ __forceinline__ void div_pair(double nx, double ny, double de, double
     qy = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(ey, r, py, fny), de, ny);
 }
 
+// The two quotients as float32 (all the map keeps of them, grid_rendering/type.py:209-261 stores float32 and cv.remap reads
+// float32): nx * r and ny * r with r = 1 / de refined to full double precision are within a few ulp (2^-50 relative) of the
+// exact quotients, so they round to the same float32 unless they lie that close to a rounding midpoint of float32 -- the 29
+// significand bits a float32 drops within 2^-48 of 1000...0.  Returns false (wavefront-wide) when any active lane cannot
+// prove it; the caller then takes the exactly rounded division.  |de| >= 1e-6 and finite here (cells whose denominator may
+// vanish are flagged and never come this way), so no operand scaling is needed.
+__device__ __forceinline__ bool div_pair_f32_fast(double nx, double ny, double de, float &fx, float &fy)
+{
+    double r = __builtin_amdgcn_rcp(de);
+    double e = fma(-de, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-de, r, 1.0);
+    r = fma(r, e, r);
+    const double qx = nx * r, qy = ny * r;
+    const uint32_t lx = (uint32_t)__double_as_longlong(qx) & 0x1fffffffu, ly = (uint32_t)__double_as_longlong(qy) & 0x1fffffffu;
+    const bool danger = (lx - (0x10000000u - 16u)) < 32u || (ly - (0x10000000u - 16u)) < 32u;
+    fx = (float)qx;
+    fy = (float)qy;
+    return __builtin_amdgcn_ballot_w64(danger) == 0;
+}
+
 __device__ __forceinline__ int reflect101(int p, int len)
 {
     if ((unsigned)p < (unsigned)len) return p;
@@ -266,15 +301,26 @@ __device__ __forceinline__ void hue_shift_px(const int *sdiv, const int *hdiv, i
     vkd::hsv2rgb_full(H, S, V, r, g, b);
 }
 
-constexpr int P = W + 1;        // dword pitch of the ownership plane: the raster walks columns AND rows, an odd pitch keeps both off
+constexpr int P_ = W + 1;        // dword pitch of the ownership plane: the raster walks columns AND rows, an odd pitch keeps both off
                                // a single LDS bank
-constexpr size_t kLdsOwn = sizeof(uint32_t) * W * P;            // owner tags, then (r | b << 16) horizontal sums
+constexpr size_t kLdsOwn = sizeof(uint32_t) * W * P_;            // owner tags, then (r | b << 16) horizontal sums
 constexpr size_t kLdsHbB = sizeof(uint16_t) * W * W;            // g horizontal sums
 constexpr size_t kLdsCellR = sizeof(CellR) * NLDSCELL;
 constexpr size_t kLdsCellH = sizeof(double) * 9 * NLDSCELL;     // 72-byte pitch keeps same-index reads of different
                                                                 // cells on different LDS banks
 constexpr size_t kLdsLut = sizeof(int) * 512;
-constexpr size_t kFusedLds = kLdsOwn + kLdsHbB + kLdsCellR + kLdsCellH + kLdsLut;
+constexpr size_t kLdsSel = sizeof(uint32_t) * 8;              // byte-permute selectors of the six hue sectors, then one flag word
+constexpr size_t kFusedLds = kLdsOwn + kLdsHbB + kLdsCellR + kLdsCellH + kLdsLut + kLdsSel + 16;
+
+typedef const double __attribute__((address_space(3))) *lds_cdouble_t;
+
+// saturating float -> int32 convert of an already integral value (v_cvt_i32_f32: +-big -> INT_MAX / INT_MIN, NaN -> 0)
+__device__ __forceinline__ int cvt_i32_sat(float v)
+{
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
 
 // INTERIOR: the tile's whole 64 x 64 window lies inside the image and its candidates fit one LDS chunk -- the common
 // case (about 89 % of the tiles of a 2048^2 page).  Border handling (row / column validity, BORDER_REFLECT_101 lane tables,
@@ -296,6 +342,8 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
     double *lch = (double *)(smem + kLdsOwn + kLdsHbB + kLdsCellR);
     int *lsdiv = (int *)(smem + kLdsOwn + kLdsHbB + kLdsCellR + kLdsCellH);
     int *lhdiv = lsdiv + 256;
+    uint32_t *lsel = (uint32_t *)(lhdiv + 256);      // [8] hue sector selectors (vkd::kHsvSelectors)
+    int *lflag = (int *)(lsel + 8);                  // != 0: a candidate cell's projective denominator may vanish
 
     // the wavefront index is uniform: read it into an SGPR so that every row index, row address and row predicate
     // derived from it is scalar arithmetic instead of per-lane (64-bit, quarter-rate) multiplies
@@ -341,12 +389,14 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
     if constexpr (!EMPTY) {
         // ---- A: clear the ownership plane, then rasterise the candidates chunk by chunk out of LDS
 #pragma unroll
-        for (int i = 0; i < (W * P / 4 + NTHREADS - 1) / NTHREADS; i++)
-            if (tid + i * NTHREADS < W * P / 4) ((uint4 *)own)[tid + i * NTHREADS] = make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < (W * P_ / 4 + NTHREADS - 1) / NTHREADS; i++)
+            if (tid + i * NTHREADS < W * P_ / 4) ((uint4 *)own)[tid + i * NTHREADS] = make_uint4(0, 0, 0, 0);
         if (it.hue_on) {
             if (tid < 256) lsdiv[tid] = lut->sdiv[tid];
             else lhdiv[tid - 256] = lut->hdiv[tid - 256];
+            if (tid < 8) lsel[tid] = vkd::kHsvSelectors[tid];
         }
+        if (tid == 0) *lflag = 0;
         for (int base = 0; base < max(nc, 1); base += NLDSCELL) {
             const int cn_ = min(NLDSCELL, nc - base);
             if (base > 0) __syncthreads();            // the previous chunk is still being read
@@ -358,8 +408,10 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
             int *lylo = lpref + NLDSCELL + 1;        // [NLDSCELL] first window row of each candidate
             if (wave == 0) {
                 int hk = 0, ylo = 0;
+                bool flagged = false;
                 if (lane < cn_) {
                     const CellR &c = lcr[lane];
+                    flagged = c.flags & 1;
                     int vmin = INT_MAX, vmax = INT_MIN;
 #pragma unroll
                     for (int i = 0; i < 4; i++) { vmin = min(vmin, (int)c.vy[i]); vmax = max(vmax, (int)c.vy[i]); }
@@ -375,6 +427,7 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
                 lpref[lane + 1] = incl;
                 if (lane == 0) lpref[0] = 0;
                 lylo[lane] = ylo;
+                if (__builtin_amdgcn_ballot_w64(flagged) != 0 && lane == 0) *lflag = 1;
             }
             __syncthreads();
             const int nrows = lpref[NLDSCELL];
@@ -409,7 +462,7 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
                 }
                 const bool check = c.flags & 1;
                 const double h6 = check ? lch[kk * 9 + 6] : 0.0, h7 = check ? lch[kk * 9 + 7] : 0.0;
-                uint32_t *o = own + row * P - wx0;       // o[x]
+                uint32_t *o = own + row * P_ - wx0;       // o[x]
                 for (int a = 0; a + 1 < n; a += 2) {
                     const int x1 = max(max((xs[a] + 65535) >> 16, xmin), cx0);
                     const int x2 = min(min(xs[a + 1] >> 16, xmax), cx1 - 1);
@@ -425,7 +478,9 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
             }
             // A.2 outline: one (candidate, edge) pair per step; 8-connected Bresenham from the edge's left end,
             //     advanced incrementally (cv::LineIterator) over the part of the edge inside the window
-            for (int p = tid; p < cn_ * 4; p += NTHREADS) {
+            // (handed out from the LAST lane downwards: the span items above keep the first wavefronts busy, the outline
+            //  items go to the ones they leave idle, and the two kinds of work overlap instead of following each other)
+            for (int p = NTHREADS - 1 - tid; p < cn_ * 4; p += NTHREADS) {
                 const int kk = p >> 2, i = p & 3;
                 const CellR &c = lcr[kk];
                 const uint32_t tag = (uint32_t)(base + kk) + 1;
@@ -453,7 +508,7 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
                     const int y = ymajor ? ly + sy * s : ly + sy * m;
                     if (x >= cx0 && x < cx1 && y >= cy0 && y < cy1 &&
                         !(check && fma(1.0, 1.0, fma(h7, (double)y, h6 * (double)x)) == 0))
-                        atomicMax(own + (y - wy0) * P + (x - wx0), tag);
+                        atomicMax(own + (y - wy0) * P_ + (x - wx0), tag);
                     const bool step = err < 0;
                     err += -2LL * dmin + (step ? 2LL * dmaj : 0LL);
                     m += step ? 1 : 0;
@@ -480,6 +535,10 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
             srcl[i] = min(max(s, 0), W - 1) << 2;   // ds_bpermute takes the source lane as a byte address
         }
         const unsigned fast_xlim = (unsigned)max(sw - 2, 0), fast_ylim = (unsigned)max(sh - 1, 0);
+        const double fxd = (double)gx;               // the lane's column: the same for every row of the tile
+        // a candidate whose denominator may vanish sends the whole tile through the exactly rounded divisions (NaN / inf
+        // quotients must come out as the reference's)
+        const bool exact_div = __builtin_amdgcn_readfirstlane(*lflag) != 0;
         for (int g0 = 0; g0 < ROWS_PER_WAVE; g0 += CGROUP) {
             int X[CGROUP], Y[CGROUP];
             bool rowok[CGROUP];
@@ -490,27 +549,39 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
                 rowok[u] = INTERIOR || (gy >= cy0 && gy < cy1);
                 X[u] = 0; Y[u] = 0;
                 if (rowok[u] && colok) {
-                    const uint32_t o = own[ly * P + lane];
+                    const uint32_t o = own[ly * P_ + lane];
                     if (o != 0) {
                         const int k = (int)o - 1;
                         double h[8];
                         if (INTERIOR || k < NLDSCELL) {
+                            // one base register, the eight loads at immediate offsets
+                            lds_cdouble_t hp = (lds_cdouble_t)(lch + __umul24(k, 9));
+                            asm volatile("" : "+v"(hp));
 #pragma unroll
-                            for (int j = 0; j < 8; j++) h[j] = lch[__umul24(k, 9) + j];
+                            for (int j = 0; j < 8; j++) h[j] = hp[j];
                         } else {
                             const vkc::CellC VKX_GLOBAL *gc =
                                 (const vkc::CellC VKX_GLOBAL *)(gcell + (r0 + k / ncol) * cw + (c0 + k % ncol));
 #pragma unroll
                             for (int j = 0; j < 8; j++) h[j] = gc->H[j];
                         }
-                        const double fx = (double)gx, fy = (double)gy;
-                        const double nx = fma(h[2], 1.0, fma(h[1], fy, h[0] * fx));
-                        const double ny = fma(h[5], 1.0, fma(h[4], fy, h[3] * fx));
-                        const double de = fma(1.0, 1.0, fma(h[7], fy, h[6] * fx));
-                        double qx, qy;
-                        div_pair(nx, ny, de, qx, qy);
-                        X[u] = vkd::cv_round((float)qx * 32.f);
-                        Y[u] = vkd::cv_round((float)qy * 32.f);
+                        const double fy = (double)gy;
+                        const double nx = fma(h[2], 1.0, fma(h[1], fy, h[0] * fxd));
+                        const double ny = fma(h[5], 1.0, fma(h[4], fy, h[3] * fxd));
+                        const double de = fma(1.0, 1.0, fma(h[7], fy, h[6] * fxd));
+                        float qxf, qyf;
+                        if (exact_div || !div_pair_f32_fast(nx, ny, de, qxf, qyf)) {
+                            double qx, qy;
+                            div_pair(nx, ny, de, qx, qy);
+                            X[u] = vkd::cv_round((float)qx * 32.f);
+                            Y[u] = vkd::cv_round((float)qy * 32.f);
+                        } else {
+                            // finite quotients: beyond int32 the saturating convert lands outside the source on the
+                            // same side as cvRound's INT_MIN does after the int16 saturation of cv.remap -- border
+                            // pixels either way
+                            X[u] = cvt_i32_sat(rintf(qxf * 32.f));
+                            Y[u] = cvt_i32_sat(rintf(qyf * 32.f));
+                        }
                     }
                 }
             }
@@ -610,27 +681,37 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
             for (int u = 0; u < CGROUP; u++) {
                 const int ly = wave * ROWS_PER_WAVE + g0 + u;
                 if (!rowok[u]) continue;                     // uniform over the wavefront
-                uint32_t px = 0;
+                uint32_t prb = 0, pg = 0;                    // r | b << 16, g
                 if (colok) {
                     const int fx = X[u] & 31, fy = Y[u] & 31;
-                    const int w00 = (32 - fy) * (32 - fx), w01 = (32 - fy) * fx, w10 = fy * (32 - fx), w11 = fy * fx;
                     if (fast[u]) {
-#pragma unroll
-                        for (int k = 0; k < 3; k++) {
-                            const int v0 = (int)((ta[u] >> (8 * k)) & 0xff), v1 = (int)((ta[u] >> (8 * (k + 3))) & 0xff);
-                            const int v2 = (int)((tb[u] >> (8 * k)) & 0xff), v3 = (int)((tb[u] >> (8 * (k + 3))) & 0xff);
-                            px |= (uint32_t)((v0 * w00 + v1 * w01 + v2 * w10 + v3 * w11 + 512) >> 10) << (8 * k);
-                        }
+                        // (32 - fy) ((32 - fx) v00 + fx v01) + fy ((32 - fx) v10 + fx v11): the same integer as cv.remap's four
+                        // weighted taps.  Horizontal pairs with v_dot4_u32_u8 -- bytes 0 and 3 of a dword are one channel of
+                        // two neighbouring RGB pixels -- then the vertical pair with 24-bit multiply-adds.
+                        const uint32_t wx = (uint32_t)(32 - fx) | ((uint32_t)fx << 24);
+                        const uint32_t t0 = (uint32_t)ta[u], t1 = (uint32_t)(ta[u] >> 32), b0 = (uint32_t)tb[u], b1 = (uint32_t)(tb[u] >> 32);
+                        const uint32_t ar = __builtin_amdgcn_udot4(t0, wx, 0u, false);
+                        const uint32_t ag = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t1, t0, 1), wx, 0u, false);
+                        const uint32_t ab = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t1, t0, 2), wx, 0u, false);
+                        const uint32_t br = __builtin_amdgcn_udot4(b0, wx, 0u, false);
+                        const uint32_t bg = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b1, b0, 1), wx, 0u, false);
+                        const uint32_t bb = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b1, b0, 2), wx, 0u, false);
+                        const uint32_t wy0 = (uint32_t)(32 - fy), wy1 = (uint32_t)fy;
+                        const uint32_t r = mad_u24(br, wy1, mad_u24_cs(ar, wy0, 512u)) >> 10;
+                        const uint32_t g = mad_u24(bg, wy1, mad_u24_cs(ag, wy0, 512u)) >> 10;
+                        const uint32_t b = mad_u24(bb, wy1, mad_u24_cs(ab, wy0, 512u)) >> 10;
+                        prb = r | (b << 16);
+                        pg = g;
                     } else {
                         uint8_t p3[3];
                         vkd::sample_u8<3>(it.src, sh, sw, sstride, X[u], Y[u], p3);
-                        px = (uint32_t)p3[0] | ((uint32_t)p3[1] << 8) | ((uint32_t)p3[2] << 16);
+                        prb = (uint32_t)p3[0] | ((uint32_t)p3[2] << 16);
+                        pg = p3[1];
                     }
                 }
                 if (R > 0) {
                     // D: horizontal u8 x 8.8 pass; tap i of lane l lives in lane srcl[i].  r and b travel as the two
                     // 16-bit halves of one dword (255 * 256 < 2^16: the halves never carry into each other)
-                    const uint32_t prb = px & 0x00ff00ffu, pg = (px >> 8) & 0xffu;
                     uint32_t arb = 0, ag = 0;
 #pragma unroll
                     for (int i = 0; i < 2 * RMAX + 1; i++) {
@@ -641,15 +722,15 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
                                 vg = (uint32_t)__builtin_amdgcn_ds_bpermute(srcl[i], (int)pg);
                             }
                             // spelled out: given the symmetric taps the compiler factors k (a + b) for the shuffled
-                            // values, whose sum it cannot bound, and pays a quarter-rate 32-bit multiply for it
-                            arb = mad_u24(kq[i], vrb, arb);
-                            ag = mad_u24(kq[i], vg, ag);
+                            // values, whose sum it cannot bound
+                            arb = mad_u24_ks(kq[i], vrb, arb);
+                            ag = mad_u24_ks(kq[i], vg, ag);
                         }
                     }
-                    own[ly * P + lane] = arb;
+                    own[ly * P_ + lane] = arb;
                     hbB[ly * W + lane] = (uint16_t)ag;
                 } else {
-                    own[ly * P + lane] = px;
+                    own[ly * P_ + lane] = (prb & 0xffu) | (pg << 8) | (prb & 0xff0000u);
                 }
             }
         }
@@ -695,68 +776,72 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
     // EMPTY: no lattice cell reaches the window, so every pixel of it maps to (0, 0) (the reference's unfilled map
     // entries) = the source's first pixel; the blur of a constant is that constant (kernel taps sum to 256), and the
     // hue shift is evaluated once per lane instead of once per pixel.
-    int er = 0, eg = 0, eb = 0;
+    uint32_t epx = 0;                                 // r | g << 8 | b << 16
     if constexpr (EMPTY) {
-        er = src[0]; eg = src[1]; eb = src[2];
+        int er = src[0], eg = src[1], eb = src[2];
         if (hue_on) hue_shift_px(lut->sdiv, lut->hdiv, hue_delta, er, eg, eb);
+        epx = (uint32_t)er | ((uint32_t)eg << 8) | ((uint32_t)eb << 16);
     }
 #pragma unroll
     for (int i = 0; i < ROWS_PER_WAVE; i++) {
         const int cy = wave + NWAVES * i;
         if (cy >= th) continue;                 // uniform over the wavefront
         const int gy = y0 + cy;
-        int r = er, g = eg, b = eb;
+        uint32_t P = epx;                       // the pixel as r | g << 8 | b << 16
         if constexpr (!EMPTY) {
-        if (R > 0) {
-            uint32_t a0 = 0, a1 = 0, a2 = 0;
+            if (R > 0) {
+                uint32_t a0 = 0, a1 = 0, a2 = 0;
 #pragma unroll
-            for (int j = 0; j < 2 * RMAX + 1; j++) {
-                if (j < K) {
-                    const int yy = INTERIOR ? cy + j : reflect101(gy + j - R, dh) - wy0;
-                    const uint16_t *hRB = (const uint16_t *)(own + yy * P + lane);
-                    a0 += __umul24(kq[j], (uint32_t)hRB[0]);
-                    a2 += __umul24(kq[j], (uint32_t)hRB[1]);
-                    a1 += __umul24(kq[j], (uint32_t)hbB[yy * W + lane]);
+                for (int j = 0; j < 2 * RMAX + 1; j++) {
+                    if (j < K) {
+                        const int yy = INTERIOR ? cy + j : reflect101(gy + j - R, dh) - wy0;
+                        const uint16_t *hRB = (const uint16_t *)(own + yy * P_ + lane);
+                        a0 += __umul24(kq[j], (uint32_t)hRB[0]);
+                        a2 += __umul24(kq[j], (uint32_t)hRB[1]);
+                        a1 += __umul24(kq[j], (uint32_t)hbB[yy * W + lane]);
+                    }
+                }
+                const int r = (int)((a0 + 32768u) >> 16), g = (int)((a1 + 32768u) >> 16), b = (int)((a2 + 32768u) >> 16);
+                if (hue_on) P = vkd::hue_shift_packed(lsdiv, lhdiv, lsel, hue_delta, r, g, b);
+                else P = (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16);
+            } else {
+                P = own[(cy + R) * P_ + lane];
+                if (hue_on) P = vkd::hue_shift_packed(lsdiv, lhdiv, lsel, hue_delta, (int)(P & 0xff), (int)((P >> 8) & 0xff),
+                                                      (int)((P >> 16) & 0xff));
+            }
+        }
+        if (noise || (STREAK && streak_on)) {
+            int r = (int)(P & 0xff), g = (int)((P >> 8) & 0xff), b = (int)((P >> 16) & 0xff);
+            if (noise) {
+                r = vkd::clamp_u8(r + (int)(int16_t)(nzA[i] & 0xffff));
+                g = vkd::clamp_u8(g + (int)(int16_t)(nzA[i] >> 16));
+                b = vkd::clamp_u8(b + (int)(int16_t)(nzB[i] & 0xffff));
+            }
+            if (STREAK && streak_on) {
+                // stripe masks: vertical x % (t + g) < t, horizontal y % (t + g) < t, dash gaps cut them; vertical stripes
+                // are blended first, then horizontal ones (crossings twice); trunc(fl32(1 - a) * v + a * c)
+                const int ym = gy % ite.streak_step, yd = gy % ite.streak_dash_step;
+                bool mv = ite.streak_vert && sxm < ite.streak_thickness;
+                bool mh = ite.streak_hori && ym < ite.streak_thickness;
+                if (ite.streak_dash) {
+                    if (yd < ite.streak_dash_gap) mv = false;
+                    if (sxd < ite.streak_dash_gap) mh = false;
+                }
+                const float w1 = ite.streak_alpha, w0 = 1.0f - w1;
+                int *ch[3] = {&r, &g, &b};
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    int v = *ch[c];
+                    const int col = ite.streak_color[c];
+                    if (mv) { const float t0 = w0 * (float)v, t1 = w1 * (float)col; v = ite.streak_copy ? col : (int)(uint8_t)(t0 + t1); }
+                    if (mh) { const float t0 = w0 * (float)v, t1 = w1 * (float)col; v = ite.streak_copy ? col : (int)(uint8_t)(t0 + t1); }
+                    *ch[c] = v;
                 }
             }
-            r = (int)((a0 + 32768u) >> 16);
-            g = (int)((a1 + 32768u) >> 16);
-            b = (int)((a2 + 32768u) >> 16);
-        } else {
-            const uint32_t v = own[(cy + R) * P + lane];
-            r = v & 0xff; g = (v >> 8) & 0xff; b = (v >> 16) & 0xff;
-        }
-        if (hue_on) hue_shift_px(lsdiv, lhdiv, hue_delta, r, g, b);
-        }
-        if (noise) {
-            r = vkd::clamp_u8((int16_t)((int16_t)r + (int16_t)(nzA[i] & 0xffff)));
-            g = vkd::clamp_u8((int16_t)((int16_t)g + (int16_t)(nzA[i] >> 16)));
-            b = vkd::clamp_u8((int16_t)((int16_t)b + (int16_t)(nzB[i] & 0xffff)));
-        }
-        if (STREAK && streak_on) {
-            // stripe masks: vertical x % (t + g) < t, horizontal y % (t + g) < t, dash gaps cut them; vertical stripes
-            // are blended first, then horizontal ones (crossings twice); trunc(fl32(1 - a) * v + a * c)
-            const int ym = gy % ite.streak_step, yd = gy % ite.streak_dash_step;
-            bool mv = ite.streak_vert && sxm < ite.streak_thickness;
-            bool mh = ite.streak_hori && ym < ite.streak_thickness;
-            if (ite.streak_dash) {
-                if (yd < ite.streak_dash_gap) mv = false;
-                if (sxd < ite.streak_dash_gap) mh = false;
-            }
-            const float w1 = ite.streak_alpha, w0 = 1.0f - w1;
-            int *ch[3] = {&r, &g, &b};
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                int v = *ch[c];
-                const int col = ite.streak_color[c];
-                if (mv) { const float t0 = w0 * (float)v, t1 = w1 * (float)col; v = ite.streak_copy ? col : (int)(uint8_t)(t0 + t1); }
-                if (mh) { const float t0 = w0 * (float)v, t1 = w1 * (float)col; v = ite.streak_copy ? col : (int)(uint8_t)(t0 + t1); }
-                *ch[c] = v;
-            }
+            P = (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16);
         }
         // 4 adjacent pixels = 12 bytes = 3 dwords: lanes with (column & 3) = 0, 1, 2 each build one dword from
         // their own pixel and their right neighbour's
-        const uint32_t P = (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16);
         const uint32_t Pn = (uint32_t)__builtin_amdgcn_ds_bpermute(right4, (int)P);
         gdst_t drow = dst + (ptrdiff_t)gy * dstride + (ptrdiff_t)x0 * 3;
         if (ocol) {
@@ -770,7 +855,7 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
                 }
             } else {
                 gdst_t d = drow + ocx * 3;
-                d[0] = (uint8_t)r; d[1] = (uint8_t)g; d[2] = (uint8_t)b;
+                d[0] = (uint8_t)P; d[1] = (uint8_t)(P >> 8); d[2] = (uint8_t)(P >> 16);
             }
         }
     }
@@ -801,6 +886,12 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
     const int wx0 = tx * Tw - it.R, wy0 = ty * Tw - it.R;
     const int nc = bin.rmax1 > 0 ? max(0, bin.rmax1 - bin.rmin) * max(0, bin.cmax1 - bin.cmin) : 0;
     const bool interior = wx0 >= 0 && wy0 >= 0 && wx0 + W <= it.dw && wy0 + W <= it.dh && nc <= NLDSCELL && phase_limit != 3;
+#ifdef VKX_FUSED_CENSUS
+    // tools/isa_census.py: only the hot variant (interior window, 5-tap blur) so that its ISA can be read in isolation
+    (void)interior;
+    chain_tile<1, STREAK, 2>(it, tl, tile_id, cells, bin, lut, phase_limit);
+    return;
+#endif
     if (nc == 0) chain_tile<2, STREAK>(it, tl, tile_id, cells, bin, lut, phase_limit);
     else if (interior) {
         // the common case gets the blur radius as a compile-time constant

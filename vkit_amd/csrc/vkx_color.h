@@ -57,6 +57,37 @@ __device__ __forceinline__ void hsv2rgb_full(int H, int S, int V, int &r, int &g
     b = __float2int_rn(fb * 255.0f);
 }
 
+// The hue shift of the fused chain kernel: the same arithmetic as rgb2hsv_full + hsv2rgb_full with the shifted hue, arranged
+// for the instruction mix of gfx950 (simple integer / float32 adds and multiplies issue at twice the rate of converts,
+// compares, selects and 24-bit multiplies there):
+//   * t0 * 255 rounds to V itself (V / 255 is within one ulp of the quotient, times 255 within one ulp of V): not evaluated;
+//   * cvRound(t * 255) as  fl(fl(t * 255) + 1.5 * 2^23): the sum is rounded to an integer, ties to even, exactly like cvRound
+//     of the rounded product, and the integer sits in the low byte of the float's bit pattern;
+//   * the sector's channel assignment is ONE byte permute with a selector looked up by sector (`sel`, kHsvSelectors in LDS)
+//     instead of nine selects: sources are byte 0 = q/t, byte 1 = V (one dword) and byte 4 = p (the other).
+// Returns r | g << 8 | b << 16.
+//   sector table (b, g, r): 0 (p, t, V) 1 (p, V, q) 2 (t, V, p) 3 (V, q, p) 4 (V, p, t) 5 (q, p, V)
+__device__ constexpr uint32_t kHsvSelectors[8] = {0x0c040001u, 0x0c040100u, 0x0c000104u, 0x0c010004u,
+                                                  0x0c010400u, 0x0c000401u, 0x0c0c0c0cu, 0x0c0c0c0cu};
+
+__device__ __forceinline__ uint32_t hue_shift_packed(const int *sdiv, const int *hdiv, const uint32_t *sel, int delta,
+                                                     int r, int g, int b)
+{
+    int H, S, V;
+    rgb2hsv_full<true>(sdiv, hdiv, r, g, b, H, S, V);
+    const uint32_t h6 = __umul24((uint32_t)(H + delta) & 255u, 6u);   // python modulo 256, then h = H * 6 / 256 exactly
+    const float s = (float)S * (1.0f / 255.0f);
+    const float fv = (float)V * (1.0f / 255.0f);
+    const float h = (float)(h6 & 255u) * (1.0f / 256);
+    const float x = (h6 & 256u) ? h : 1.f - h;              // odd sectors interpolate with h, even ones with 1 - h
+    const float t1 = fv * (1.f - s);
+    const float tt = fv * (1.f - s * x);
+    const float m1 = t1 * 255.0f + 12582912.0f;             // products and sums round separately (-ffp-contract=off)
+    const float mt = tt * 255.0f + 12582912.0f;
+    const uint32_t lo = __float_as_uint(mt) | ((uint32_t)V << 8);   // byte 0 = q / t, byte 1 = V (bits 8..15 of mt are 0)
+    return __builtin_amdgcn_perm(__float_as_uint(m1), lo, sel[h6 >> 8]);
+}
+
 } // namespace vkd
 
 #endif // VKX_COLOR_H_
