@@ -410,6 +410,25 @@ def test_chain_batch_degenerate_grid(N):
     _chain_case(N, grids, ['deg'], 14, [1.0], [99], [True])
 
 
+def test_chain_batch_rim_stress(N):
+    """Border tiles whose pixels map outside the source (the per-tap rim sampler next to the paired fast loads), every
+    blur radius, the same batch issued repeatedly: a timing-dependent defect (a missed wait state, a stale register) shows
+    up as a run-to-run difference or a deviation from the oracle.  Round 2 found one this way in the 3-tap variant."""
+    rng = default_rng(77)
+    grids, names = {}, []
+    for i, (h, w, gs, amp) in enumerate([(200, 260, 15, 9.0), (130, 500, 15, 12.0), (333, 190, 20, 6.0)]):
+        sv, dv, dshape = synthetic_grid(h, w, gs, amp, seed=100 + i)
+        sv = sv.copy()
+        # pull the source lattice outwards: its rim samples the outside of the source image (cv.remap's zero border)
+        sv[0, :, 1] -= 3; sv[-1, :, 1] += 3; sv[:, 0, 0] -= 3; sv[:, -1, 0] += 3
+        for k, sigma in enumerate((0.7, 1.0, 2.0)):
+            name = f'rim{i}_{k}'
+            grids[name] = (sv, dv, dshape, (h, w))
+            names.append(name)
+    for round_ in range(8):
+        _chain_case(N, grids, names, 3000 + round_, [0.7, 1.0, 2.0], [None, 37, -5], [round_ % 2 == 0])
+
+
 def test_chain_batch_full_size(N):
     sv, dv, dshape = synthetic_grid(2048, 2048, 20, 18.0, seed=3)
     grids = {'big': (sv, dv, dshape, (2048, 2048))}

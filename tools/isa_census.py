@@ -17,7 +17,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, 'vkit_amd', 'csrc', 'fused.hip')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fvisibility=hidden',
-         '-Wno-unused-function', '-g1', '-DVKX_FUSED_CENSUS', '-S', '--cuda-device-only']
+         '-Wno-unused-function', '-g1', '-DVKX_FUSED_CENSUS=2', '-S', '--cuda-device-only']
 
 
 def phase_table():

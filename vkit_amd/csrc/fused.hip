@@ -208,18 +208,25 @@ __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
     return r;
 }
 
-// the same with a wave-uniform multiplier / addend held in an SGPR (a VOP3 instruction reads one scalar operand for free)
+// Multiply-adds with a wave-uniform operand (a blur weight, a rounding constant) are written with the compiler's own
+// intrinsics, never as inline assembly with an "s" operand: the compiler keeps such values in SGPRs, may spill them to VGPR
+// lanes and reload them with v_readlane right before the use, and gfx950 needs wait states between a VALU write of an SGPR
+// and a VALU read of it -- wait states the hazard recogniser inserts for its own instructions only, not for the text of an
+// asm statement (seen as sporadic wrong horizontal sums in the 3-tap variant).
 __device__ __forceinline__ uint32_t mad_u24_ks(uint32_t k_uniform, uint32_t b, uint32_t c)
 {
-    uint32_t r;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "s"(k_uniform), "v"(b), "v"(c));
-    return r;
+    return __umul24(k_uniform, b) + c;
 }
 __device__ __forceinline__ uint32_t mad_u24_cs(uint32_t a, uint32_t b, uint32_t c_uniform)
 {
-    uint32_t r;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c_uniform));
-    return r;
+    return __umul24(a, b) + c_uniform;
+}
+
+// c + a.lo * b.lo + a.hi * b.hi on unsigned 16-bit halves (v_dot2_u32_u16)
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t dot2_u16_ks(uint32_t k_uniform, uint32_t b, uint32_t c)
+{
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, k_uniform), __builtin_bit_cast(ushort2_t, b), c, false);
 }
 
 // a wave-uniform 64-bit value, moved into SGPRs
@@ -288,6 +295,32 @@ __device__ __forceinline__ int reflect101(int p, int len)
     return p;
 }
 
+// cv.remap's bilinear sample of an RGB pixel whose 2 x 2 taps are not all inside the source (the rim of the result and
+// everything that maps outside): vkd::sample_u8<3> on the kernel's global-address-space source pointer, every tap its own
+// predicated byte load.  Returns r | b << 16 and g.
+__device__ __forceinline__ void rim_sample_rgb(gsrc_t src, int sh, int sw, ptrdiff_t sstride, int X, int Y, uint32_t &prb, uint32_t &pg)
+{
+    const int sx = vkd::sat_short(X >> 5), sy = vkd::sat_short(Y >> 5);
+    const int fx = X & 31, fy = Y & 31;
+    prb = 0; pg = 0;
+    if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) return;
+    const bool x0 = sx >= 0, x1 = sx + 1 < sw, y0 = sy >= 0, y1 = sy + 1 < sh;
+    // (sy, sx) may be -1: offsets are formed in 64 bits from the row / column that exist
+    const gsrc_t r0 = src + (ptrdiff_t)sy * sstride + (ptrdiff_t)sx * 3, r1 = r0 + sstride;
+    const int w00 = (32 - fy) * (32 - fx), w01 = (32 - fy) * fx, w10 = fy * (32 - fx), w11 = fy * fx;
+    uint32_t c[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int v0 = (x0 && y0) ? r0[k] : 0;
+        const int v1 = (x1 && y0) ? r0[3 + k] : 0;
+        const int v2 = (x0 && y1) ? r1[k] : 0;
+        const int v3 = (x1 && y1) ? r1[3 + k] : 0;
+        c[k] = (uint32_t)(v0 * w00 + v1 * w01 + v2 * w10 + v3 * w11 + 512) >> 10;
+    }
+    prb = c[0] | (c[2] << 16);
+    pg = c[1];
+}
+
 struct HsvLut {
     int sdiv[256];
     int hdiv[256];
@@ -301,10 +334,14 @@ __device__ __forceinline__ void hue_shift_px(const int *sdiv, const int *hdiv, i
     vkd::hsv2rgb_full(H, S, V, r, g, b);
 }
 
-constexpr int P_ = W + 1;        // dword pitch of the ownership plane: the raster walks columns AND rows, an odd pitch keeps both off
-                               // a single LDS bank
-constexpr size_t kLdsOwn = sizeof(uint32_t) * W * P_;            // owner tags, then (r | b << 16) horizontal sums
-constexpr size_t kLdsHbB = sizeof(uint16_t) * W * W;            // g horizontal sums
+// Dword pitch of the ownership plane.  Odd: the raster walks columns AND rows, an odd pitch keeps both off a single LDS
+// bank.  97: once the tags of the window rows (2m, 2m + 1) are consumed, their 2 x 97 dwords take the horizontal sums of
+// that row pair -- three 64-dword planes R, G, B whose dwords hold (row 2m | row 2m + 1 << 16), the operand layout of the
+// vertical pass's v_dot2_u32_u16 -- written by the wavefront that read the tags.
+constexpr int P_ = 97;
+constexpr int kPairPitch = 2 * P_;  // dwords between the plane triples of consecutive row pairs
+constexpr size_t kLdsOwn = sizeof(uint32_t) * W * P_;
+constexpr size_t kLdsHbB = 1024;                                 // phase A's work-list prefix sums
 constexpr size_t kLdsCellR = sizeof(CellR) * NLDSCELL;
 constexpr size_t kLdsCellH = sizeof(double) * 9 * NLDSCELL;     // 72-byte pitch keeps same-index reads of different
                                                                 // cells on different LDS banks
@@ -369,18 +406,38 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
     const int cw = it.cols - 1;   // cells per lattice row
     const vkc::CellC *gcell = cells + it.cell_base;
 
-    // copies candidate records [base, base + cn) into the two LDS tables; 16 lanes x 8 B per 128-byte record
-    auto load_chunk = [&](int base, int cn_) {
-        for (int rec = tid >> 4; rec < cn_; rec += NTHREADS / 16) {
-            const int part = tid & 15;
-            const int k = base + rec;
-            const int rr = k / ncol, cc = k - rr * ncol;
-            const unsigned long long VKX_GLOBAL *s8 =
-                (const unsigned long long VKX_GLOBAL *)(gcell + (r0 + rr) * cw + (c0 + cc));
-            const unsigned long long v = s8[part];
-            if (part < 8) ((unsigned long long *)(lch + rec * 9))[part] = v;
-            else if (part < 15) ((unsigned long long *)(lcr + rec))[part - 8] = v;
+    // Candidate records [base, base + cn) go into the two LDS tables, 16 lanes x 8 B per 128-byte record and two records per
+    // lane (NLDSCELL = 2 x 32).  Fetch and store are split so that the first chunk's loads are in flight, together with the
+    // hue tables, while the ownership plane is being cleared: one memory round trip at the head of the tile instead of three.
+    static_assert(NLDSCELL == 2 * (NTHREADS / 16), "two records per lane and chunk");
+    auto chunk_fetch = [&](int base, int cn_, unsigned long long (&v)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int rec = (tid >> 4) + h * (NTHREADS / 16);
+            v[h] = 0;
+            if (rec < cn_) {
+                const int k = base + rec;
+                const int rr = k / ncol, cc = k - rr * ncol;
+                const unsigned long long VKX_GLOBAL *s8 =
+                    (const unsigned long long VKX_GLOBAL *)(gcell + (r0 + rr) * cw + (c0 + cc));
+                v[h] = s8[tid & 15];
+            }
         }
+    };
+    auto chunk_store = [&](int cn_, const unsigned long long (&v)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int rec = (tid >> 4) + h * (NTHREADS / 16), part = tid & 15;
+            if (rec < cn_) {
+                if (part < 8) ((unsigned long long *)(lch + rec * 9))[part] = v[h];
+                else if (part < 15) ((unsigned long long *)(lcr + rec))[part - 8] = v[h];
+            }
+        }
+    };
+    auto load_chunk = [&](int base, int cn_) {
+        unsigned long long v[2];
+        chunk_fetch(base, cn_, v);
+        chunk_store(cn_, v);
     };
 
     uint32_t kq[2 * RMAX + 1];
@@ -388,20 +445,32 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
     for (int i = 0; i < 2 * RMAX + 1; i++) kq[i] = (R > 0 && i < K) ? it.kq[i < K - 1 - i ? i : K - 1 - i] : 0;   // symmetric (checked on the host)
     if constexpr (!EMPTY) {
         // ---- A: clear the ownership plane, then rasterise the candidates chunk by chunk out of LDS
+        unsigned long long first[2];
+        chunk_fetch(0, min(NLDSCELL, nc), first);
+        int lutv = 0;
+        uint32_t selv = 0;
+        if (it.hue_on) {
+            lutv = tid < 256 ? lut->sdiv[tid] : lut->hdiv[tid - 256];
+            if (tid < 8) selv = vkd::kHsvSelectors[tid];
+        }
 #pragma unroll
         for (int i = 0; i < (W * P_ / 4 + NTHREADS - 1) / NTHREADS; i++)
             if (tid + i * NTHREADS < W * P_ / 4) ((uint4 *)own)[tid + i * NTHREADS] = make_uint4(0, 0, 0, 0);
         if (it.hue_on) {
-            if (tid < 256) lsdiv[tid] = lut->sdiv[tid];
-            else lhdiv[tid - 256] = lut->hdiv[tid - 256];
-            if (tid < 8) lsel[tid] = vkd::kHsvSelectors[tid];
+            lsdiv[tid] = lutv;                       // sdiv[256] and hdiv[256] are adjacent
+            if (tid < 8) lsel[tid] = selv;
         }
         if (tid == 0) *lflag = 0;
         for (int base = 0; base < max(nc, 1); base += NLDSCELL) {
             const int cn_ = min(NLDSCELL, nc - base);
-            if (base > 0) __syncthreads();            // the previous chunk is still being read
-            load_chunk(base, cn_);
+            if (base > 0) {
+                __syncthreads();            // the previous chunk is still being read
+                load_chunk(base, cn_);
+            } else {
+                chunk_store(cn_, first);
+            }
             __syncthreads();
+            if (phase_limit == 11) return;
             // Work list of the chunk: for every candidate the window rows its scanlines can touch (compacted with a
             // prefix sum so that no lane idles on rows outside the cell), then one item per (candidate, edge).
             int *lpref = (int *)hbB;                 // [NLDSCELL + 1] exclusive prefix of row counts (hbB is free in A)
@@ -430,6 +499,7 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
                 if (__builtin_amdgcn_ballot_w64(flagged) != 0 && lane == 0) *lflag = 1;
             }
             __syncthreads();
+            if (phase_limit == 12) return;
             const int nrows = lpref[NLDSCELL];
             // A.1 interior: spans [ceil(xa), floor(xb)] of the x-sorted edge crossings (16.16 fixed point) of one
             //     (candidate, scanline) item, clipped to the window
@@ -476,6 +546,7 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
                     }
                 }
             }
+            if (phase_limit == 13) return;
             // A.2 outline: one (candidate, edge) pair per step; 8-connected Bresenham from the edge's left end,
             //     advanced incrementally (cv::LineIterator) over the part of the edge inside the window
             // (handed out from the LAST lane downwards: the span items above keep the first wavefronts busy, the outline
@@ -602,31 +673,31 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
                             float v;
                             if (inner) {
                                 typedef float f32x2_u4 __attribute__((ext_vector_type(2), aligned(4)));
-                                const float *q0 = (const float *)el.src + (ptrdiff_t)sy * el.sstride + sx;
-                                const f32x2_u4 a = *(const f32x2_u4 *)q0, b = *(const f32x2_u4 *)(q0 + el.sstride);
+                                const float VKX_GLOBAL *q0 = (const float VKX_GLOBAL *)el.src + (ptrdiff_t)sy * el.sstride + sx;
+                                const f32x2_u4 a = *(const f32x2_u4 VKX_GLOBAL *)q0, b = *(const f32x2_u4 VKX_GLOBAL *)(q0 + el.sstride);
                                 const float ax = fx * (1.f / 32), ay = fy * (1.f / 32), bx = 1.f - ax, by = 1.f - ay;
                                 const float p0 = a.x * (by * bx), p1 = a.y * (by * ax), p2 = b.x * (ay * bx), p3 = b.y * (ay * ax);
                                 v = ((p0 + p1) + p2) + p3;
                             } else {
-                                v = vkd::sample_f32((const float *)el.src, sh, sw, el.sstride, X[u], Y[u]);
+                                v = vkd::sample_f32((const float VKX_GLOBAL *)el.src, sh, sw, el.sstride, X[u], Y[u]);
                             }
-                            ((float *)el.dst)[(ptrdiff_t)gy * el.dstride + gx] = v;
+                            ((float VKX_GLOBAL *)el.dst)[(ptrdiff_t)gy * el.dstride + gx] = v;
                         } else {
-                            uint8_t *d = (uint8_t *)el.dst + (ptrdiff_t)gy * el.dstride + (ptrdiff_t)gx * el.cn;
-                            const uint8_t *sp = (const uint8_t *)el.src;
+                            gdst_t d = (gdst_t)el.dst + (ptrdiff_t)gy * el.dstride + (ptrdiff_t)gx * el.cn;
+                            const gsrc_t sp = (gsrc_t)el.src;
                             if (el.cn == 1) {
                                 if (inner) {
-                                    const uint8_t *q0 = sp + (ptrdiff_t)sy * el.sstride + sx;
-                                    const uint32_t a = *(const u16_u1 *)q0, b = *(const u16_u1 *)(q0 + el.sstride);
+                                    const gsrc_t q0 = sp + (ptrdiff_t)sy * el.sstride + sx;
+                                    const uint32_t a = *(const u16_u1 VKX_GLOBAL *)q0, b = *(const u16_u1 VKX_GLOBAL *)(q0 + el.sstride);
                                     d[0] = (uint8_t)(((a & 0xff) * w00 + (a >> 8) * w01 + (b & 0xff) * w10 + (b >> 8) * w11 + 512) >> 10);
                                 } else {
-                                    vkd::sample_u8<1>(sp, sh, sw, el.sstride, X[u], Y[u], d);
+                                    { uint8_t p1[1]; vkd::sample_u8<1>(sp, sh, sw, el.sstride, X[u], Y[u], p1); d[0] = p1[0]; }
                                 }
                             } else if (el.cn == 3) {
                                 uint8_t p3[3];
                                 if (inner) {
-                                    const uint8_t *q0 = sp + (ptrdiff_t)sy * el.sstride + (ptrdiff_t)sx * 3;
-                                    const unsigned long long a = *(const u64_u1 *)q0, b = *(const u64_u1 *)(q0 + el.sstride);
+                                    const gsrc_t q0 = sp + (ptrdiff_t)sy * el.sstride + (ptrdiff_t)sx * 3;
+                                    const unsigned long long a = *(const u64_u1 VKX_GLOBAL *)q0, b = *(const u64_u1 VKX_GLOBAL *)(q0 + el.sstride);
 #pragma unroll
                                     for (int k = 0; k < 3; k++) {
                                         const int v0 = (int)((a >> (8 * k)) & 0xff), v1 = (int)((a >> (8 * (k + 3))) & 0xff);
@@ -640,8 +711,8 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
                             } else {
                                 uint8_t p4[4];
                                 if (inner) {
-                                    const uint8_t *q0 = sp + (ptrdiff_t)sy * el.sstride + (ptrdiff_t)sx * 4;
-                                    const unsigned long long a = *(const u64_u1 *)q0, b = *(const u64_u1 *)(q0 + el.sstride);
+                                    const gsrc_t q0 = sp + (ptrdiff_t)sy * el.sstride + (ptrdiff_t)sx * 4;
+                                    const unsigned long long a = *(const u64_u1 VKX_GLOBAL *)q0, b = *(const u64_u1 VKX_GLOBAL *)(q0 + el.sstride);
 #pragma unroll
                                     for (int k = 0; k < 4; k++) {
                                         const int v0 = (int)((a >> (8 * k)) & 0xff), v1 = (int)((a >> (8 * (k + 4))) & 0xff);
@@ -651,7 +722,7 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
                                 } else {
                                     vkd::sample_u8<4>(sp, sh, sw, el.sstride, X[u], Y[u], p4);
                                 }
-                                *(uint32_t *)d = (uint32_t)p4[0] | ((uint32_t)p4[1] << 8) | ((uint32_t)p4[2] << 16) |
+                                *(uint32_t VKX_GLOBAL *)d = (uint32_t)p4[0] | ((uint32_t)p4[1] << 8) | ((uint32_t)p4[2] << 16) |
                                                  ((uint32_t)p4[3] << 24);
                             }
                         }
@@ -677,11 +748,11 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
                     tb[u] = *(const u64_u1 VKX_GLOBAL *)(src + (size_t)(o0 + (uint32_t)sstride));
                 }
             }
+            uint32_t prb[CGROUP], pg[CGROUP];                // r | b << 16, g of the row's remapped pixel
 #pragma unroll
             for (int u = 0; u < CGROUP; u++) {
-                const int ly = wave * ROWS_PER_WAVE + g0 + u;
+                prb[u] = 0; pg[u] = 0;
                 if (!rowok[u]) continue;                     // uniform over the wavefront
-                uint32_t prb = 0, pg = 0;                    // r | b << 16, g
                 if (colok) {
                     const int fx = X[u] & 31, fy = Y[u] & 31;
                     if (fast[u]) {
@@ -700,38 +771,47 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
                         const uint32_t r = mad_u24(br, wy1, mad_u24_cs(ar, wy0, 512u)) >> 10;
                         const uint32_t g = mad_u24(bg, wy1, mad_u24_cs(ag, wy0, 512u)) >> 10;
                         const uint32_t b = mad_u24(bb, wy1, mad_u24_cs(ab, wy0, 512u)) >> 10;
-                        prb = r | (b << 16);
-                        pg = g;
+                        prb[u] = r | (b << 16);
+                        pg[u] = g;
                     } else {
-                        uint8_t p3[3];
-                        vkd::sample_u8<3>(it.src, sh, sw, sstride, X[u], Y[u], p3);
-                        prb = (uint32_t)p3[0] | ((uint32_t)p3[2] << 16);
-                        pg = p3[1];
+                        rim_sample_rgb(src, sh, sw, sstride, X[u], Y[u], prb[u], pg[u]);
                     }
                 }
-                if (R > 0) {
-                    // D: horizontal u8 x 8.8 pass; tap i of lane l lives in lane srcl[i].  r and b travel as the two
-                    // 16-bit halves of one dword (255 * 256 < 2^16: the halves never carry into each other)
-                    uint32_t arb = 0, ag = 0;
+            }
+            static_assert(CGROUP == 2, "phase D works on the window-row pair of one iteration");
+            const int ly0 = wave * ROWS_PER_WAVE + g0;       // even: the pair (ly0, ly0 + 1)
+            if (!(rowok[0] || rowok[1])) continue;           // uniform over the wavefront
+            if (R > 0) {
+                // D: horizontal u8 x 8.8 pass of both rows; tap i of lane l lives in lane srcl[i].  r and b travel as the two
+                // 16-bit halves of one dword (255 * 256 < 2^16: the halves never carry into each other), the g of the two
+                // rows share a dword the same way: three shuffles and three multiply-adds per tap and row pair
+                const uint32_t gg = pg[0] | (pg[1] << 16);
+                uint32_t a0 = 0, a1 = 0, ag = 0;
 #pragma unroll
-                    for (int i = 0; i < 2 * RMAX + 1; i++) {
-                        if (i < K) {
-                            uint32_t vrb = prb, vg = pg;
-                            if (!(INTERIOR && RC >= 0 && i == RC)) {      // the centre tap of an interior window is the lane's own pixel
-                                vrb = (uint32_t)__builtin_amdgcn_ds_bpermute(srcl[i], (int)prb);
-                                vg = (uint32_t)__builtin_amdgcn_ds_bpermute(srcl[i], (int)pg);
-                            }
-                            // spelled out: given the symmetric taps the compiler factors k (a + b) for the shuffled
-                            // values, whose sum it cannot bound
-                            arb = mad_u24_ks(kq[i], vrb, arb);
-                            ag = mad_u24_ks(kq[i], vg, ag);
+                for (int i = 0; i < 2 * RMAX + 1; i++) {
+                    if (i < K) {
+                        uint32_t v0 = prb[0], v1 = prb[1], vg = gg;
+                        if (!(INTERIOR && RC >= 0 && i == RC)) {      // the centre tap of an interior window is the lane's own pixel
+                            v0 = (uint32_t)__builtin_amdgcn_ds_bpermute(srcl[i], (int)prb[0]);
+                            v1 = (uint32_t)__builtin_amdgcn_ds_bpermute(srcl[i], (int)prb[1]);
+                            vg = (uint32_t)__builtin_amdgcn_ds_bpermute(srcl[i], (int)gg);
                         }
+                        // spelled out: given the symmetric taps the compiler factors k (a + b) for the shuffled
+                        // values, whose sum it cannot bound
+                        a0 = mad_u24_ks(kq[i], v0, a0);
+                        a1 = mad_u24_ks(kq[i], v1, a1);
+                        ag = mad_u24_ks(kq[i], vg, ag);
                     }
-                    own[ly * P_ + lane] = arb;
-                    hbB[ly * W + lane] = (uint16_t)ag;
-                } else {
-                    own[ly * P_ + lane] = (prb & 0xffu) | (pg << 8) | (prb & 0xff0000u);
                 }
+                // (row | next row << 16) per channel, over the consumed owner tags of the pair
+                uint32_t *pl = own + ly0 * P_ + lane;
+                pl[0] = __builtin_amdgcn_perm(a1, a0, 0x05040100u);      // R: low halves
+                pl[64] = ag;                                             // G
+                pl[128] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);    // B: high halves
+            } else {
+#pragma unroll
+                for (int u = 0; u < CGROUP; u++)
+                    if (rowok[u]) own[(ly0 + u) * P_ + lane] = (prb[u] & 0xffu) | (pg[u] << 8) | (prb[u] & 0xff0000u);
             }
         }
         if constexpr (KIND == 3) return;   // element mode ends with the gathers
@@ -746,9 +826,11 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
     // phase A) would pin 16 VGPRs through the register-heavy phases and spill.
     // The descriptor fields only this phase needs are read here, through a pointer the optimiser cannot trace back:
     // hoisted to the top of the kernel they would sit in SGPRs through phases A - D and spill.
-    const ItemDev *ite_ = &it;
+    // (a global-address-space pointer: no FLAT instruction anywhere in this kernel -- flat loads tick both memory counters
+    //  and return out of order with respect to LDS operations)
+    const ItemDev VKX_GLOBAL *ite_ = (const ItemDev VKX_GLOBAL *)&it;
     asm volatile("" : "+s"(ite_));
-    const ItemDev &ite = *ite_;
+    const ItemDev VKX_GLOBAL &ite = *ite_;
     // (such loads come back in VGPRs; the row address arithmetic wants them scalar)
     const gdst_t dst = (gdst_t)uniform64((uint64_t)ite.dst);
     const int16_t VKX_GLOBAL *noise = (const int16_t VKX_GLOBAL *)uniform64((uint64_t)ite.noise);
@@ -764,6 +846,15 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
             nzA[i] = *(const u32_u1 VKX_GLOBAL *)np_;
             nzB[i] = *(const u16_u1 VKX_GLOBAL *)(np_ + 2);
         }
+    }
+    // vertical taps two at a time: the tile row cy = wave + 8 i has the parity of the wavefront, so the pairing of the taps
+    // kq[0 .. K) with the (even row | odd row << 16) dwords is fixed per wavefront
+    uint32_t wpair[RMAX + 1];
+#pragma unroll
+    for (int q = 0; q <= RMAX; q++) {
+        const uint32_t e0 = 2 * q < K ? kq[2 * q < 2 * RMAX + 1 ? 2 * q : 0] : 0u, e1 = 2 * q + 1 < K ? kq[2 * q + 1 < 2 * RMAX + 1 ? 2 * q + 1 : 0] : 0u;
+        const uint32_t o0 = (q > 0 && 2 * q - 1 < K) ? kq[q > 0 ? 2 * q - 1 : 0] : 0u, o1 = 2 * q < K ? kq[2 * q < 2 * RMAX + 1 ? 2 * q : 0] : 0u;
+        wpair[q] = (wave & 1) ? (o0 | (o1 << 16)) : (e0 | (e1 << 16));
     }
     const bool hue_on = __builtin_amdgcn_readfirstlane(ite.hue_on) != 0;
     const int hue_delta = __builtin_amdgcn_readfirstlane(ite.hue_delta);
@@ -790,18 +881,37 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
         uint32_t P = epx;                       // the pixel as r | g << 8 | b << 16
         if constexpr (!EMPTY) {
             if (R > 0) {
-                uint32_t a0 = 0, a1 = 0, a2 = 0;
+                int r, g, b;
+                if constexpr (INTERIOR && RC > 0) {
+                    // taps cy .. cy + 2 RC of the window = RC + 1 row pairs, two taps per v_dot2_u32_u16
+                    const uint32_t *pl = own + (cy & ~1) * P_ + lane;
+                    uint32_t ar = 32768u, ag = 32768u, ab = 32768u;
 #pragma unroll
-                for (int j = 0; j < 2 * RMAX + 1; j++) {
-                    if (j < K) {
-                        const int yy = INTERIOR ? cy + j : reflect101(gy + j - R, dh) - wy0;
-                        const uint16_t *hRB = (const uint16_t *)(own + yy * P_ + lane);
-                        a0 += __umul24(kq[j], (uint32_t)hRB[0]);
-                        a2 += __umul24(kq[j], (uint32_t)hRB[1]);
-                        a1 += __umul24(kq[j], (uint32_t)hbB[yy * W + lane]);
+                    for (int q = 0; q <= RC; q++) {
+                        ar = dot2_u16_ks(wpair[q], pl[q * kPairPitch], ar);
+                        ag = dot2_u16_ks(wpair[q], pl[q * kPairPitch + 64], ag);
+                        ab = dot2_u16_ks(wpair[q], pl[q * kPairPitch + 128], ab);
                     }
+                    r = (int)(ar >> 16); g = (int)(ag >> 16); b = (int)(ab >> 16);
+                } else {
+                    uint32_t a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+                    for (int j = 0; j < 2 * RMAX + 1; j++) {
+                        if (j < K) {
+                            const int yy = INTERIOR ? cy + j : reflect101(gy + j - R, dh) - wy0;
+                            const uint16_t *h16 = (const uint16_t *)(own + (yy & ~1) * P_ + lane) + (yy & 1);
+                            a0 += __umul24(kq[j], (uint32_t)h16[0]);
+                            a1 += __umul24(kq[j], (uint32_t)h16[128]);
+                            a2 += __umul24(kq[j], (uint32_t)h16[256]);
+                        }
+                    }
+                    r = (int)((a0 + 32768u) >> 16); g = (int)((a1 + 32768u) >> 16); b = (int)((a2 + 32768u) >> 16);
                 }
-                const int r = (int)((a0 + 32768u) >> 16), g = (int)((a1 + 32768u) >> 16), b = (int)((a2 + 32768u) >> 16);
+                if (phase_limit == 20) {      // debugging aid: the horizontal sums of the centre row, >> 8
+                    const int yy = INTERIOR ? cy + R : reflect101(gy, dh) - wy0;
+                    const uint16_t *h16 = (const uint16_t *)(own + (yy & ~1) * P_ + lane) + (yy & 1);
+                    r = h16[0] >> 8; g = h16[128] >> 8; b = h16[256] >> 8;
+                }
                 if (hue_on) P = vkd::hue_shift_packed(lsdiv, lhdiv, lsel, hue_delta, r, g, b);
                 else P = (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16);
             } else {
@@ -879,6 +989,7 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
     const int run = (int)((blockIdx.x + blockIdx.y) & 7), pos = (int)(blockIdx.x >> 3);
     const int tl = run * per + pos;
     if (pos >= per || tl >= ntiles) return;
+    if (phase_limit == 10) return;
     const int tile_id = (int)blockIdx.y * slots + tl;   // bins are laid out [image][slot]
     const TileBin bin = bins[tile_id];
     const int ty = tl / it.tiles_x, tx = tl - ty * it.tiles_x;
@@ -889,7 +1000,7 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
 #ifdef VKX_FUSED_CENSUS
     // tools/isa_census.py: only the hot variant (interior window, 5-tap blur) so that its ISA can be read in isolation
     (void)interior;
-    chain_tile<1, STREAK, 2>(it, tl, tile_id, cells, bin, lut, phase_limit);
+    chain_tile<1, STREAK, VKX_FUSED_CENSUS>(it, tl, tile_id, cells, bin, lut, phase_limit);
     return;
 #endif
     if (nc == 0) chain_tile<2, STREAK>(it, tl, tile_id, cells, bin, lut, phase_limit);
@@ -968,7 +1079,8 @@ static int launch_tiles(vkx_ctx *ctx, std::vector<ItemDev> &dev, std::vector<int
     VKX_LAUNCH_CHECK();
     { VKX_TIMED(ctx, "k_chain_setup_svd"); k_chain_setup_svd<<<16, 64, 0, ctx->stream>>>(d_items, d_cell_prefix, n_items, cells, deferred); }
     VKX_LAUNCH_CHECK();
-    // profiling aid: VKX_FUSED_PHASES=1|2 stops the kernel after phase A | C+D
+    // profiling aids: VKX_FUSED_PHASES=1|2 stops the kernel after phase A | C+D, 10..13 inside phase A (tools/phases_a.sh),
+    // 20 writes the horizontal sums of the centre row instead of the finished pixel
     static const int phase_limit = [] { const char *e = getenv("VKX_FUSED_PHASES"); return e ? atoi(e) : 0; }();
     if (elements) {
         { VKX_TIMED(ctx, "k_tile_remap"); k_tile_remap<<<dim3(slots, n_items), NTHREADS, kFusedLds, ctx->stream>>>(d_items, cells, bins); }

@@ -21,9 +21,9 @@ __device__ __forceinline__ void rgb2hsv_full(const int *sdiv, const int *hdiv, i
     const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
     S = (__mul24(diff, sdiv[v]) + (1 << 11)) >> 12;
     int hh = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
-    // |hh| < 2^11 and hdiv < 2^24: the signed 24-bit multiply-add is exact (spelled out -- left to the compiler this
-    // product became a quarter-rate 64-bit multiply)
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(hh) : "v"(hh), "v"(hdiv[diff]), "s"(1 << 11));
+    // |hh| < 2^11 and hdiv < 2^24: the signed 24-bit multiply-add is exact (the intrinsic, not an asm statement with a
+    // scalar operand: see mad_u24_ks in fused.hip)
+    hh = __mul24(hh, hdiv[diff]) + (1 << 11);
     hh >>= 12;
     if (!WRAP_H) hh += hh < 0 ? 256 : 0;
     H = hh;

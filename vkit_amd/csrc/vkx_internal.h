@@ -135,9 +135,10 @@ __device__ __forceinline__ int clamp_u8(int v) { return v < 0 ? 0 : (v > 255 ? 2
 // coordinate in 1/32 px.  The int16 weight table of OpenCV is (32-fy)(32-fx)*32 etc. (with the
 // {32767,0,0,1} quirk at fy=fx=0); (sum*32 + 2^14) >> 15 == (sum + 512) >> 10 for every entry,
 // the quirk entry included, so the table never needs to be materialised.
-template <int CN>
-__device__ __forceinline__ void sample_u8(const uint8_t *__restrict__ src, int sh, int sw, ptrdiff_t sstride,
-                                          int X, int Y, uint8_t *out)
+// PTR: `const uint8_t *` or the same in an explicit address space (a kernel that holds its planes as global-address-space
+// pointers keeps FLAT instructions out of its code that way).
+template <int CN, typename PTR = const uint8_t *>
+__device__ __forceinline__ void sample_u8(PTR src, int sh, int sw, ptrdiff_t sstride, int X, int Y, uint8_t *out)
 {
     const int sx = sat_short(X >> 5), sy = sat_short(Y >> 5);
     const int fx = X & 31, fy = Y & 31;
@@ -147,8 +148,8 @@ __device__ __forceinline__ void sample_u8(const uint8_t *__restrict__ src, int s
         return;
     }
     const bool x0 = sx >= 0, x1 = sx + 1 < sw, y0 = sy >= 0, y1 = sy + 1 < sh;
-    const uint8_t *r0 = src + (ptrdiff_t)sy * sstride + (ptrdiff_t)sx * CN;
-    const uint8_t *r1 = r0 + sstride;
+    const PTR r0 = src + (ptrdiff_t)sy * sstride + (ptrdiff_t)sx * CN;
+    const PTR r1 = r0 + sstride;
     const int w00 = (32 - fy) * (32 - fx), w01 = (32 - fy) * fx, w10 = fy * (32 - fx), w11 = fy * fx;
 #pragma unroll
     for (int k = 0; k < CN; k++) {
@@ -160,15 +161,15 @@ __device__ __forceinline__ void sample_u8(const uint8_t *__restrict__ src, int s
     }
 }
 
-__device__ __forceinline__ float sample_f32(const float *__restrict__ src, int sh, int sw, ptrdiff_t sstride_el,
-                                            int X, int Y)
+template <typename PTR = const float *>
+__device__ __forceinline__ float sample_f32(PTR src, int sh, int sw, ptrdiff_t sstride_el, int X, int Y)
 {
     const int sx = sat_short(X >> 5), sy = sat_short(Y >> 5);
     const int fx = X & 31, fy = Y & 31;
     if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) return 0.f;
     const bool x0 = sx >= 0, x1 = sx + 1 < sw, y0 = sy >= 0, y1 = sy + 1 < sh;
-    const float *r0 = src + (ptrdiff_t)sy * sstride_el + sx;
-    const float *r1 = r0 + sstride_el;
+    const PTR r0 = src + (ptrdiff_t)sy * sstride_el + sx;
+    const PTR r1 = r0 + sstride_el;
     const float ax = fx * (1.f / 32), ay = fy * (1.f / 32);
     const float bx = 1.f - ax, by = 1.f - ay;
     const float w0 = by * bx, w1 = by * ax, w2 = ay * bx, w3 = ay * ax; // exact products (5 bit x 5 bit)
