@@ -22,9 +22,11 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=o
 
 def phase_table():
     """(first line, name) from the phase markers in the source."""
-    marks = [('// ---- A:', 'A raster'), ('// ---- C + D:', 'C map'), ('unsigned long long ta[CGROUP]', 'C gather'),
-             ('// D: horizontal', 'D h-blur'), ('// ---- E:', 'E setup + noise load'), ('a0 += __umul24(kq[j]', 'E v-blur'),
-             ('if (hue_on) hue_shift_px(lsdiv', 'E hue'), ('if (noise) {', 'E noise add'), ('if (STREAK && streak_on)', 'E streak'),
+    marks = [('// ---- A: clear the ownership plane', 'A prologue + raster'), ('// ---- C + D:', 'C map'),
+             ('unsigned long long ta[CGROUP]', 'C gather'), ('static_assert(CGROUP == 2, "phase D', 'D h-blur'),
+             ('// ---- E:', 'E setup + noise load'), ('uint32_t P = epx;', 'E v-blur'),
+             ('if (hue_on) P = vkd::hue_shift_packed(lsdiv, lhdiv, lsel, hue_delta, r, g, b);', 'E hue'),
+             ('if (noise || (STREAK && streak_on))', 'E noise add'),
              ('// 4 adjacent pixels = 12 bytes', 'E pack + store')]
     table = []
     with open(SRC) as f:
@@ -34,7 +36,7 @@ def phase_table():
     for needle, name in marks:
         idx = next((i for i in range(start, len(lines)) if needle in lines[i]), None)
         if idx is not None:
-            table.append((idx + 1 - (3 if name == 'E v-blur' else 0), name))
+            table.append((idx + 1, name))
     end = next(i for i in range(start, len(lines)) if lines[i].startswith('template <bool STREAK>'))
     table.append((end + 1, 'kernel wrapper'))
     table.sort()

@@ -200,6 +200,19 @@ __global__ void __launch_bounds__(64) k_chain_setup_svd(const ItemDev *__restric
     }
 }
 
+// floor(n / d) for 0 <= n < 2^21, d >= 1 through the float32 reciprocal `rcp_d` = 1 / d (any 1-ulp reciprocal will do): the
+// product (n + 0.5) * rcp_d is off by less than 0.5 / d, the distance of (n + 0.5) / d from the nearest integer, and one
+// correction step makes the result independent of that bound.  Replaces the ~25-instruction integer division sequence at
+// the head of every tile (tile row / column, candidate row / column).
+__device__ __forceinline__ int div_small(int n, int d, float rcp_d)
+{
+    int q = (int)(((float)n + 0.5f) * rcp_d);
+    const int r = n - q * d;
+    q += r >= d ? 1 : 0;
+    q -= r < 0 ? 1 : 0;
+    return q;
+}
+
 // a * b + c on the low 24 bits of a and b (full rate)
 __device__ __forceinline__ uint32_t mad_u24(uint32_t a, uint32_t b, uint32_t c)
 {
@@ -366,7 +379,7 @@ __device__ __forceinline__ int cvt_i32_sat(float v)
 // RC: the blur radius as a compile-time constant (0..RMAX), or -1 = read it from the item.  With RC fixed the tap
 // loops of phases D / E unroll to exactly K taps and the tile geometry folds into immediates.
 template <int KIND, bool STREAK = false, int RC = -1>   // 0 generic, 1 interior, 2 empty, 3 element remap (any element types)
-__device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, const int tile_id,
+__device__ __forceinline__ void chain_tile(const ItemDev &it, const int tx, const int ty,
                                            const vkc::CellC *__restrict__ cells, const TileBin &bin,
                                            const HsvLut *__restrict__ lut, int phase_limit)
 {
@@ -385,7 +398,6 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
     // the wavefront index is uniform: read it into an SGPR so that every row index, row address and row predicate
     // derived from it is scalar arithmetic instead of per-lane (64-bit, quarter-rate) multiplies
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ty = tl / it.tiles_x, tx = tl - ty * it.tiles_x;
     const int R = RC >= 0 ? RC : it.R, K = 2 * R + 1, Tw = tile_side(R);
     const int dw = it.dw, dh = it.dh;
     const int x0 = tx * Tw, y0 = ty * Tw;                         // the tile proper
@@ -410,6 +422,7 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
     // lane (NLDSCELL = 2 x 32).  Fetch and store are split so that the first chunk's loads are in flight, together with the
     // hue tables, while the ownership plane is being cleared: one memory round trip at the head of the tile instead of three.
     static_assert(NLDSCELL == 2 * (NTHREADS / 16), "two records per lane and chunk");
+    const float rcp_ncol = __builtin_amdgcn_rcpf((float)max(ncol, 1));
     auto chunk_fetch = [&](int base, int cn_, unsigned long long (&v)[2]) {
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -417,7 +430,7 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
             v[h] = 0;
             if (rec < cn_) {
                 const int k = base + rec;
-                const int rr = k / ncol, cc = k - rr * ncol;
+                const int rr = div_small(k, ncol, rcp_ncol), cc = k - rr * ncol;
                 const unsigned long long VKX_GLOBAL *s8 =
                     (const unsigned long long VKX_GLOBAL *)(gcell + (r0 + rr) * cw + (c0 + cc));
                 v[h] = s8[tid & 15];
@@ -461,8 +474,9 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
             if (tid < 8) lsel[tid] = selv;
         }
         if (tid == 0) *lflag = 0;
-        for (int base = 0; base < max(nc, 1); base += NLDSCELL) {
-            const int cn_ = min(NLDSCELL, nc - base);
+        // (an interior tile has at most NLDSCELL candidates: one pass, no loop)
+        for (int base = 0; base < (INTERIOR ? 1 : max(nc, 1)); base += NLDSCELL) {
+            const int cn_ = INTERIOR ? nc : min(NLDSCELL, nc - base);
             if (base > 0) {
                 __syncthreads();            // the previous chunk is still being read
                 load_chunk(base, cn_);
@@ -569,20 +583,42 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
                     k0 = max(0, cx0 - lx); k1 = min(dx, cx1 - 1 - lx);
                 }
                 if (k0 > k1) continue;
-                int m = vkc::bres_minor(k0, dmaj, dmin);
+                // 32-bit arithmetic throughout: coordinates are below 2^15, so 2 k dmin - dmaj fits an int32 and the error term
+                // (bounded by 2 dmaj along the line) survives the wrap-around of its three large summands
+                int m = 0;
+                {
+                    const int num = 2 * k0 * dmin - dmaj;
+                    if (dmaj != 0 && num > 0) m = (int)(((uint32_t)num + 2u * (uint32_t)dmaj - 1u) / (2u * (uint32_t)dmaj));
+                }
                 // LineIterator's error term after k0 steps: err = dmaj - 2 dmin (k0 + 1) + 2 dmaj m
-                long long err = (long long)dmaj - 2LL * dmin * (k0 + 1) + 2LL * dmaj * m;
+                int err = (int)((uint32_t)dmaj - 2u * (uint32_t)dmin * (uint32_t)(k0 + 1) + 2u * (uint32_t)dmaj * (uint32_t)m);
+                const int up = 2 * dmaj - 2 * dmin, down = -2 * dmin;
+                // the pixel of step k0 in window coordinates, and what a major / minor step adds to it
+                int px = (ymajor ? lx + m : lx + k0) - wx0, py = (ymajor ? ly + sy * k0 : ly + sy * m) - wy0;
+                const int ax = ymajor ? 0 : 1, ay = ymajor ? sy : 0, bx = ymajor ? 1 : 0, by = ymajor ? 0 : sy;
+                const int lox = cx0 - wx0, nx_ = cx1 - cx0, loy = cy0 - wy0, ny_ = cy1 - cy0;
                 const bool check = c.flags & 1;
-                const double h6 = check ? lch[kk * 9 + 6] : 0.0, h7 = check ? lch[kk * 9 + 7] : 0.0;
-                for (int s = k0; s <= k1; s++) {
-                    const int x = ymajor ? lx + m : lx + s;
-                    const int y = ymajor ? ly + sy * s : ly + sy * m;
-                    if (x >= cx0 && x < cx1 && y >= cy0 && y < cy1 &&
-                        !(check && fma(1.0, 1.0, fma(h7, (double)y, h6 * (double)x)) == 0))
-                        atomicMax(own + (y - wy0) * P_ + (x - wx0), tag);
-                    const bool step = err < 0;
-                    err += -2LL * dmin + (step ? 2LL * dmaj : 0LL);
-                    m += step ? 1 : 0;
+                if (!check) {
+                    for (int s = k0; s <= k1; s++) {
+                        const bool inside = INTERIOR ? (unsigned)(px | py) < (unsigned)W
+                                                     : ((unsigned)(px - lox) < (unsigned)nx_ && (unsigned)(py - loy) < (unsigned)ny_);
+                        if (inside) atomicMax(own + py * P_ + px, tag);
+                        const bool step = err < 0;
+                        err += step ? up : down;
+                        px += ax + (step ? bx : 0);
+                        py += ay + (step ? by : 0);
+                    }
+                } else {
+                    const double h6 = lch[kk * 9 + 6], h7 = lch[kk * 9 + 7];
+                    for (int s = k0; s <= k1; s++) {
+                        const bool inside = (unsigned)(px - lox) < (unsigned)nx_ && (unsigned)(py - loy) < (unsigned)ny_;
+                        if (inside && !(fma(1.0, 1.0, fma(h7, (double)(py + wy0), h6 * (double)(px + wx0))) == 0))
+                            atomicMax(own + py * P_ + px, tag);
+                        const bool step = err < 0;
+                        err += step ? up : down;
+                        px += ax + (step ? bx : 0);
+                        py += ay + (step ? by : 0);
+                    }
                 }
             }
         }
@@ -632,7 +668,7 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tl, cons
                             for (int j = 0; j < 8; j++) h[j] = hp[j];
                         } else {
                             const vkc::CellC VKX_GLOBAL *gc =
-                                (const vkc::CellC VKX_GLOBAL *)(gcell + (r0 + k / ncol) * cw + (c0 + k % ncol));
+                                (const vkc::CellC VKX_GLOBAL *)(gcell + (r0 + div_small(k, ncol, rcp_ncol)) * cw + (c0 + k - div_small(k, ncol, rcp_ncol) * ncol));
 #pragma unroll
                             for (int j = 0; j < 8; j++) h[j] = gc->H[j];
                         }
@@ -992,7 +1028,8 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
     if (phase_limit == 10) return;
     const int tile_id = (int)blockIdx.y * slots + tl;   // bins are laid out [image][slot]
     const TileBin bin = bins[tile_id];
-    const int ty = tl / it.tiles_x, tx = tl - ty * it.tiles_x;
+    const int ty = __builtin_amdgcn_readfirstlane(div_small(tl, it.tiles_x, __builtin_amdgcn_rcpf((float)it.tiles_x)));
+    const int tx = tl - ty * it.tiles_x;
     const int Tw = tile_side(it.R);
     const int wx0 = tx * Tw - it.R, wy0 = ty * Tw - it.R;
     const int nc = bin.rmax1 > 0 ? max(0, bin.rmax1 - bin.rmin) * max(0, bin.cmax1 - bin.cmin) : 0;
@@ -1000,24 +1037,24 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
 #ifdef VKX_FUSED_CENSUS
     // tools/isa_census.py: only the hot variant (interior window, 5-tap blur) so that its ISA can be read in isolation
     (void)interior;
-    chain_tile<1, STREAK, VKX_FUSED_CENSUS>(it, tl, tile_id, cells, bin, lut, phase_limit);
+    chain_tile<1, STREAK, VKX_FUSED_CENSUS>(it, tx, ty, cells, bin, lut, phase_limit);
     return;
 #endif
-    if (nc == 0) chain_tile<2, STREAK>(it, tl, tile_id, cells, bin, lut, phase_limit);
+    if (nc == 0) chain_tile<2, STREAK>(it, tx, ty, cells, bin, lut, phase_limit);
     else if (interior) {
         // the common case gets the blur radius as a compile-time constant
         switch (it.R) {
-        case 0: chain_tile<1, STREAK, 0>(it, tl, tile_id, cells, bin, lut, phase_limit); break;
-        case 1: chain_tile<1, STREAK, 1>(it, tl, tile_id, cells, bin, lut, phase_limit); break;
-        case 2: chain_tile<1, STREAK, 2>(it, tl, tile_id, cells, bin, lut, phase_limit); break;
-        default: chain_tile<1, STREAK, 3>(it, tl, tile_id, cells, bin, lut, phase_limit); break;
+        case 0: chain_tile<1, STREAK, 0>(it, tx, ty, cells, bin, lut, phase_limit); break;
+        case 1: chain_tile<1, STREAK, 1>(it, tx, ty, cells, bin, lut, phase_limit); break;
+        case 2: chain_tile<1, STREAK, 2>(it, tx, ty, cells, bin, lut, phase_limit); break;
+        default: chain_tile<1, STREAK, 3>(it, tx, ty, cells, bin, lut, phase_limit); break;
         }
     } else {
         switch (it.R) {
-        case 0: chain_tile<0, STREAK, 0>(it, tl, tile_id, cells, bin, lut, phase_limit); break;
-        case 1: chain_tile<0, STREAK, 1>(it, tl, tile_id, cells, bin, lut, phase_limit); break;
-        case 2: chain_tile<0, STREAK, 2>(it, tl, tile_id, cells, bin, lut, phase_limit); break;
-        default: chain_tile<0, STREAK, 3>(it, tl, tile_id, cells, bin, lut, phase_limit); break;
+        case 0: chain_tile<0, STREAK, 0>(it, tx, ty, cells, bin, lut, phase_limit); break;
+        case 1: chain_tile<0, STREAK, 1>(it, tx, ty, cells, bin, lut, phase_limit); break;
+        case 2: chain_tile<0, STREAK, 2>(it, tx, ty, cells, bin, lut, phase_limit); break;
+        default: chain_tile<0, STREAK, 3>(it, tx, ty, cells, bin, lut, phase_limit); break;
         }
     }
 }
@@ -1037,7 +1074,9 @@ __global__ void __launch_bounds__(NTHREADS, 4) k_tile_remap(const ItemDev *__res
     if (pos >= per || tl >= ntiles) return;
     const int tile_id = (int)blockIdx.y * slots + tl;
     const TileBin bin = bins[tile_id];
-    chain_tile<3>(it, tl, tile_id, cells, bin, nullptr, 0);
+    const int ty = __builtin_amdgcn_readfirstlane(div_small(tl, it.tiles_x, __builtin_amdgcn_rcpf((float)it.tiles_x)));
+    const int tx = tl - ty * it.tiles_x;
+    chain_tile<3>(it, tx, ty, cells, bin, nullptr, 0);
 }
 
 } // namespace
