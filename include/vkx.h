@@ -56,6 +56,27 @@ int vkx_upload(vkx_ctx *ctx, void *dptr, const void *hptr, size_t bytes);   /* s
 int vkx_download(vkx_ctx *ctx, void *hptr, const void *dptr, size_t bytes); /* synchronous */
 int vkx_memset(vkx_ctx *ctx, void *dptr, int value, size_t bytes);          /* async */
 
+/* ---- page-locked host memory, copy streams, ordering ----------------------------------------
+ * For callers that keep host arrays flowing (the reference hands numpy arrays in and out of every operator,
+ * mechanism/distortion/interface.py:824-912; its process pool, utility/pool.py:65-96, is the only overlap it has):
+ * a ctx owns a host->device and a device->host copy stream next to its compute stream.  vkx_upload_async /
+ * vkx_download_async enqueue on those; vkx_ctx_order(later, earlier) makes `later` wait for everything queued on
+ * `earlier` at the time of the call; vkx_event_record / vkx_event_wait let the host wait for one point of one stream.
+ * Copies overlap compute only from / to page-locked memory (vkx_host_alloc). */
+#define VKX_STREAM_COMPUTE 0
+#define VKX_STREAM_COPY_IN 1
+#define VKX_STREAM_COPY_OUT 2
+int vkx_host_alloc(vkx_ctx *ctx, size_t bytes, void **hptr);
+int vkx_host_free(vkx_ctx *ctx, void *hptr);
+int vkx_upload_async(vkx_ctx *ctx, void *dptr, const void *hptr, size_t bytes);
+int vkx_download_async(vkx_ctx *ctx, void *hptr, const void *dptr, size_t bytes);
+/* one host <-> device copy on the named stream of the ctx (to_device != 0: dst is a device pointer) */
+int vkx_memcpy_async(vkx_ctx *ctx, int stream, void *dst, const void *src, size_t bytes, int to_device);
+int vkx_ctx_order(vkx_ctx *ctx, int later_stream, int earlier_stream);
+int vkx_ctx_sync_stream(vkx_ctx *ctx, int stream);
+int vkx_event_record(vkx_ctx *ctx, int stream, void **event);
+int vkx_event_wait(vkx_ctx *ctx, void *event);   /* waits on the host and releases the event */
+
 /* ---- backward-map bilinear remap ----------------------------------------------------
  * cv.remap(src, map_x, map_y, cv.INTER_LINEAR), BORDER_CONSTANT 0
  *   mechanism/distortion/geometric/grid_rendering/grid_blender.py:60 (Image), :80 (Mask,

@@ -1,0 +1,99 @@
+"""The overlapped host-array pipeline (vkit_amd/hostpipe.py: copy streams, events, page-locked buffers) returns the pixels
+of the synchronous operator calls, job after job, whatever the depth and however ragged the jobs."""
+import numpy as np
+import pytest
+from numpy.random import default_rng
+
+import oracle as O
+from test_gpu_parity import synthetic_grid
+
+pytestmark = pytest.mark.gpu
+
+
+def _state(sv, dv, dshape):
+    from types import SimpleNamespace
+    return SimpleNamespace(result_shape=dshape, src_image_grid=SimpleNamespace(vertices=sv),
+                           dst_image_grid=SimpleNamespace(vertices=dv))
+
+
+@pytest.mark.parametrize('depth', [1, 2, 4])
+def test_pipeline_matches_oracle_ragged_jobs(depth):
+    from vkit_amd import _native as N
+    from vkit_amd.hostpipe import HostPipeline
+    ctx = N.default_ctx()
+    rng = default_rng(5 + depth)
+    jobs = []
+    for i in range(9):
+        h, w = int(rng.integers(40, 500)), int(rng.integers(40, 500))
+        sv, dv, dshape = synthetic_grid(h, w, int(rng.integers(12, 30)), float(rng.uniform(2, 12)), seed=i)
+        image = ctx.pinned_empty((h, w, 3), np.uint8)
+        image[...] = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        mask = (rng.random((h, w)) < 0.5).astype(np.uint8)
+        score = rng.random((h, w), dtype=np.float32)
+        noise = rng.integers(-50, 50, tuple(dshape) + (3,)).astype(np.int16) if i % 2 else None
+        jobs.append((image, mask, score, _state(sv, dv, dshape), [None, 0.7, 1.0, 2.0][i % 4], [None, 37, -90][i % 3], noise))
+    with HostPipeline(ctx, depth=depth) as pipe:
+        # (a) every job read right after it was queued: its remap ticket is one job behind its chain ticket
+        for job in jobs:
+            image, mask, score, st, sigma, delta, noise = job
+            t1 = pipe.submit_remap([image, mask, score], st)
+            t2 = pipe.submit_chain(image, st, blur_sigma=sigma, hue_delta=delta, noise=noise)
+            _check(pipe, (t1, t2), job, depth)
+        # (b) as many jobs in flight as there are slots, read back in submission order
+        for start in range(0, len(jobs), depth):
+            group = jobs[start:start + depth]
+            tickets = [pipe.submit_chain(j[0], j[3], blur_sigma=j[4], hue_delta=j[5], noise=j[6]) for j in group]
+            for t, job in zip(tickets, group):
+                _check(pipe, (None, t), job, depth)
+        with pytest.raises(KeyError):
+            pipe.result(0)
+
+
+def _check(pipe, tickets, job, depth):
+    image, mask, score, st, sigma, delta, noise = job
+    t1, t2 = tickets
+    mx, my = O.grid_to_map(st.src_image_grid.vertices, st.dst_image_grid.vertices, st.result_shape)
+    want = O.remap(np.asarray(image), mx, my)
+    if t1 is not None and depth >= 2:      # with a single slot the chain job has already taken the remap job's place
+        outs = pipe.result(t1)
+        assert (outs[0] == want).all() and (outs[1] == O.remap(mask, mx, my)).all()
+        assert (outs[2].view(np.uint32) == O.remap(score, mx, my).view(np.uint32)).all()
+    chain = want
+    if sigma is not None:
+        from oracle_replay import gaussian_ksize
+        chain = O.gaussian_blur(chain, gaussian_ksize(sigma), sigma)
+    if delta is not None:
+        chain = O.color_shift_rgb(chain, delta)
+    if noise is not None:
+        chain = O.add_noise_i16(chain, noise)
+    got = pipe.result(t2)[0]
+    assert got.shape == chain.shape and (got == chain).all()
+
+
+def test_pipeline_full_size_and_pinned_results():
+    """2048^2 jobs back to back; results of the synchronous API come out of the page-locked pool and are recycled."""
+    from vkit_amd import _native as N
+    from vkit_amd.hostpipe import HostPipeline
+    ctx = N.default_ctx()
+    sv, dv, dshape = synthetic_grid(2048, 2048, 20, 18.0, seed=3)
+    st = _state(sv, dv, dshape)
+    rng = default_rng(1)
+    images = []
+    for i in range(3):
+        im = ctx.pinned_empty((2048, 2048, 3), np.uint8)
+        im[...] = rng.integers(0, 256, im.shape, dtype=np.uint8)
+        images.append(im)
+    mx, my = O.grid_to_map(sv, dv, dshape)
+    with HostPipeline(ctx, depth=3) as pipe:
+        tickets = [pipe.submit_chain(im, st, blur_sigma=1.0, hue_delta=37) for im in images for _ in range(2)]
+        for k, t in enumerate(tickets):
+            if k >= len(tickets) - 3:          # the last `depth` jobs are still readable
+                want = O.color_shift_rgb(O.gaussian_blur(O.remap(np.asarray(images[k // 2]), mx, my), 5, 1.0), 37)
+                assert (pipe.result(t)[0] == want).all()
+    # pooled results: same bytes, recycled addresses
+    a = N.grid_remap([images[0]], sv, dv, dshape)[0]
+    addr = a.ctypes.data
+    assert (a == O.remap(np.asarray(images[0]), mx, my)).all()
+    del a
+    b = N.grid_remap([images[1]], sv, dv, dshape)[0]
+    assert b.ctypes.data == addr

@@ -69,6 +69,10 @@ VKX_EXPORT int vkx_ctx_destroy(vkx_ctx *ctx)
     for (auto &t : ctx->resize_tabs) scratch_release(&t.buf);
     for (auto &l : ctx->launches) { (void)hipEventDestroy(l.start); (void)hipEventDestroy(l.stop); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (auto e : ctx->order_events) (void)hipEventDestroy(e);
+    for (auto &st : ctx->copy_stream)
+        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    if (ctx->desc_ring) (void)hipHostFree(ctx->desc_ring);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return VKX_OK;
@@ -181,6 +185,180 @@ VKX_EXPORT int vkx_memset(vkx_ctx *ctx, void *dptr, int value, size_t bytes)
     if (!bytes) return VKX_OK;
     vkx_device_guard guard(ctx);
     VKX_HIP(hipMemsetAsync(dptr, value, bytes, ctx->stream));
+    return VKX_OK;
+}
+
+// ---- pinned host memory, copy streams, ordering --------------------------------------------------------------------
+int vkx_desc_ring_take(vkx_ctx *ctx, size_t bytes, void **hptr)
+{
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes > ctx->desc_cap) {
+        // (re)allocate: nothing queued may still read the old ring
+        vkx_device_guard guard(ctx);
+        VKX_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->desc_ring) VKX_HIP(hipHostFree(ctx->desc_ring));
+        ctx->desc_ring = nullptr;
+        const size_t cap = bytes * 4 > ((size_t)4 << 20) ? bytes * 4 : ((size_t)4 << 20);
+        VKX_HIP(hipHostMalloc((void **)&ctx->desc_ring, cap, hipHostMallocDefault));
+        ctx->desc_cap = cap;
+        ctx->desc_off = 0;
+    }
+    if (ctx->desc_off + bytes > ctx->desc_cap) {
+        // wrap around: the copies queued from the ring so far must have been issued to the device
+        vkx_device_guard guard(ctx);
+        VKX_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->desc_off = 0;
+    }
+    *hptr = ctx->desc_ring + ctx->desc_off;
+    ctx->desc_off += bytes;
+    return VKX_OK;
+}
+
+hipStream_t vkx_stream_by_id(vkx_ctx *ctx, int id, int *rc)
+{
+    *rc = VKX_OK;
+    if (id == VKX_STREAM_COMPUTE) return ctx->stream;
+    if (id != VKX_STREAM_COPY_IN && id != VKX_STREAM_COPY_OUT) {
+        vkx_set_error("stream id %d is not one of VKX_STREAM_*", id);
+        *rc = VKX_ERR_INVALID;
+        return nullptr;
+    }
+    hipStream_t &st = ctx->copy_stream[id - VKX_STREAM_COPY_IN];
+    if (!st) {
+        vkx_device_guard guard(ctx);
+        hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            vkx_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            *rc = VKX_ERR_HIP;
+            st = nullptr;
+        }
+    }
+    return st;
+}
+
+VKX_EXPORT int vkx_host_alloc(vkx_ctx *ctx, size_t bytes, void **hptr)
+{
+    VKX_REQUIRE(ctx && hptr, "NULL argument");
+    vkx_device_guard guard(ctx);
+    hipError_t e = hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        vkx_set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? VKX_ERR_NOMEM : VKX_ERR_HIP;
+    }
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_host_free(vkx_ctx *ctx, void *hptr)
+{
+    VKX_REQUIRE(ctx != nullptr, "ctx is NULL");
+    if (!hptr) return VKX_OK;
+    vkx_device_guard guard(ctx);
+    VKX_HIP(hipHostFree(hptr));
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_upload_async(vkx_ctx *ctx, void *dptr, const void *hptr, size_t bytes)
+{
+    VKX_REQUIRE(ctx && (bytes == 0 || (dptr && hptr)), "NULL argument");
+    if (!bytes) return VKX_OK;
+    int rc;
+    hipStream_t st = vkx_stream_by_id(ctx, VKX_STREAM_COPY_IN, &rc);
+    if (rc) return rc;
+    vkx_device_guard guard(ctx);
+    VKX_HIP(hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, st));
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_download_async(vkx_ctx *ctx, void *hptr, const void *dptr, size_t bytes)
+{
+    VKX_REQUIRE(ctx && (bytes == 0 || (dptr && hptr)), "NULL argument");
+    if (!bytes) return VKX_OK;
+    int rc;
+    hipStream_t st = vkx_stream_by_id(ctx, VKX_STREAM_COPY_OUT, &rc);
+    if (rc) return rc;
+    vkx_device_guard guard(ctx);
+    VKX_HIP(hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, st));
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_memcpy_async(vkx_ctx *ctx, int stream, void *dst, const void *src, size_t bytes, int to_device)
+{
+    VKX_REQUIRE(ctx && (bytes == 0 || (dst && src)), "NULL argument");
+    if (!bytes) return VKX_OK;
+    int rc;
+    hipStream_t st = vkx_stream_by_id(ctx, stream, &rc);
+    if (rc) return rc;
+    vkx_device_guard guard(ctx);
+    VKX_HIP(hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, st));
+    return VKX_OK;
+}
+
+static hipEvent_t take_order_event(vkx_ctx *ctx)
+{
+    if (!ctx->order_events.empty()) {
+        hipEvent_t e = ctx->order_events.back();
+        ctx->order_events.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    return e;
+}
+
+VKX_EXPORT int vkx_ctx_order(vkx_ctx *ctx, int later_stream, int earlier_stream)
+{
+    VKX_REQUIRE(ctx != nullptr, "ctx is NULL");
+    int rc;
+    hipStream_t later = vkx_stream_by_id(ctx, later_stream, &rc);
+    if (rc) return rc;
+    hipStream_t earlier = vkx_stream_by_id(ctx, earlier_stream, &rc);
+    if (rc) return rc;
+    if (later == earlier) return VKX_OK;
+    vkx_device_guard guard(ctx);
+    hipEvent_t e = take_order_event(ctx);
+    VKX_REQUIRE(e != nullptr, "hipEventCreate failed");
+    VKX_HIP(hipEventRecord(e, earlier));
+    VKX_HIP(hipStreamWaitEvent(later, e, 0));
+    ctx->order_events.push_back(e);      // a recorded event may be re-recorded once the wait has been queued
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_ctx_sync_stream(vkx_ctx *ctx, int stream)
+{
+    VKX_REQUIRE(ctx != nullptr, "ctx is NULL");
+    int rc;
+    hipStream_t st = vkx_stream_by_id(ctx, stream, &rc);
+    if (rc) return rc;
+    vkx_device_guard guard(ctx);
+    VKX_HIP(hipStreamSynchronize(st));
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_event_record(vkx_ctx *ctx, int stream, void **event)
+{
+    VKX_REQUIRE(ctx && event, "NULL argument");
+    int rc;
+    hipStream_t st = vkx_stream_by_id(ctx, stream, &rc);
+    if (rc) return rc;
+    vkx_device_guard guard(ctx);
+    hipEvent_t e = nullptr;
+    VKX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipError_t err = hipEventRecord(e, st);
+    if (err != hipSuccess) {
+        (void)hipEventDestroy(e);
+        vkx_set_error("hipEventRecord failed: %s", hipGetErrorString(err));
+        return VKX_ERR_HIP;
+    }
+    *event = (void *)e;
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_event_wait(vkx_ctx *ctx, void *event)
+{
+    VKX_REQUIRE(ctx && event, "NULL argument");
+    vkx_device_guard guard(ctx);
+    VKX_HIP(hipEventSynchronize((hipEvent_t)event));
+    VKX_HIP(hipEventDestroy((hipEvent_t)event));
     return VKX_OK;
 }
 

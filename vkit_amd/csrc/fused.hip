@@ -1100,10 +1100,13 @@ static int launch_tiles(vkx_ctx *ctx, std::vector<ItemDev> &dev, std::vector<int
     const HsvLut *lut = nullptr;
     if (!elements && (rc = vkx_hsv_tables(ctx, (const void **)&lut))) return rc;
     unsigned char *misc = (unsigned char *)ctx->misc.ptr;
-    // the host vectors die with this frame, so the upload is completed before returning from this block
-    VKX_HIP(hipMemcpyAsync(misc + items_off, dev.data(), items_bytes, hipMemcpyHostToDevice, ctx->stream));
-    VKX_HIP(hipMemcpyAsync(misc + prefix_off, prefix.data(), prefix_bytes, hipMemcpyHostToDevice, ctx->stream));
-    VKX_HIP(hipStreamSynchronize(ctx->stream));
+    // the descriptors travel through the ctx's page-locked ring: the copy is queued and the launch returns without a
+    // stream synchronisation (host-array pipelines keep several launches in flight)
+    void *ring = nullptr;
+    if ((rc = vkx_desc_ring_take(ctx, prefix_off + prefix_bytes, &ring))) return rc;
+    memcpy((unsigned char *)ring + items_off, dev.data(), items_bytes);
+    memcpy((unsigned char *)ring + prefix_off, prefix.data(), prefix_bytes);
+    VKX_HIP(hipMemcpyAsync(misc, ring, prefix_off + prefix_bytes, hipMemcpyHostToDevice, ctx->stream));
     const ItemDev *d_items = (const ItemDev *)(misc + items_off);
     const int *d_cell_prefix = (const int *)(misc + prefix_off);
     TileBin *bins = (TileBin *)ctx->owner.ptr;

@@ -58,6 +58,14 @@ struct vkx_ctx {
     vkx_scratch stage[6]; // staging planes of the host-pointer entry points
     vkx_scratch chain[2]; // ping-pong planes of the batched chain entry point
 
+    // Host-array pipelines: two copy streams next to the compute stream (created on first use), a pool of events that
+    // order them, and a page-locked ring through which the launch descriptors of the tile kernels reach the device
+    // without a stream synchronisation (a launch returns while its descriptors are still in flight).
+    hipStream_t copy_stream[2] = {nullptr, nullptr};   // [0] host -> device, [1] device -> host
+    std::vector<hipEvent_t> order_events;              // reusable events of vkx_ctx_order / vkx_event_record
+    unsigned char *desc_ring = nullptr;
+    size_t desc_cap = 0, desc_off = 0;
+
     // The tap tables of the last few CUBIC / LANCZOS4 resize geometries (PageResizingStep resizes seven elements with one
     // geometry: the tables are built and uploaded for the first one only).
     struct ResizeTabs {
@@ -104,6 +112,10 @@ struct vkx_timed {
 #define VKX_TIMED(ctx, name) vkx_timed timed_scope__(ctx, name)
 
 int vkx_scratch_reserve(vkx_ctx *ctx, vkx_scratch *s, size_t bytes);
+// `bytes` of page-locked host memory that stays untouched until everything queued on ctx->stream so far has run
+// (ring allocation; wraps around with one stream synchronisation)
+int vkx_desc_ring_take(vkx_ctx *ctx, size_t bytes, void **hptr);
+hipStream_t vkx_stream_by_id(vkx_ctx *ctx, int id, int *rc);
 
 static inline unsigned vkx_blocks(size_t n, unsigned per_block)
 {

@@ -1,0 +1,225 @@
+"""Host arrays in, host arrays out, with the transfers hidden: an overlapped pipeline over one device context.
+
+The operators of the reference take and return numpy arrays (``Distortion.distort``, vkit/mechanism/distortion/
+interface.py:824-912), one call at a time; its only concurrency is a pool of worker processes
+(vkit/utility/pool.py:65-96).  A synchronous call on the GPU costs upload + kernel + download in sequence -- the link,
+not the kernel, sets its rate.  ``HostPipeline`` runs ``lanes`` independent in-order queues instead (one context -- HIP
+stream, scratch -- per lane) and deals the jobs out round robin: every lane does upload -> kernels -> download on its
+own stream, so while one lane downloads the other uploads and the full-duplex link carries both directions (measured:
+48 GB/s each way at once, 56 GB/s alone).  No cross-stream events are needed -- a job is ordered by its lane -- which
+matters: an event recorded on an idle compute stream to hold back a copy stream serialised the two copy directions on
+this stack (tools/pipe_probe2.py).  Inputs should live in page-locked memory (``ctx.pinned_empty``) for the uploads to
+be asynchronous; results always do -- they are views of the slot's page-locked buffer, valid until ``depth`` further
+jobs have been submitted.
+
+    pipe = HostPipeline()
+    tickets = [pipe.submit_chain(image, state, blur_sigma=1.0, hue_delta=37, noise=noise) for image, state, noise in jobs]
+    for t in tickets:
+        out = pipe.result(t)          # numpy view; copy it to keep it
+"""
+import ctypes
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from vkit_amd import _native
+from vkit_amd.mechanism.distortion.photometric.blur import _estimate_gaussian_kernel_size
+
+
+class _Slot:
+    """Device and page-locked host buffers of one in-flight job (grown on demand, never shrunk)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.dev = {}          # name -> (pointer, capacity)
+        self.host = None       # flat uint8 page-locked result buffer
+        self.event = None      # recorded after the job's last download
+        self.views = None
+        self.ticket = -1
+
+    def device(self, name, nbytes):
+        ptr, cap = self.dev.get(name, (0, 0))
+        if cap < nbytes:
+            if ptr:
+                self.ctx.free(ptr)
+            cap = int(nbytes * 1.25) + 4096
+            ptr = self.ctx.malloc(cap)
+            self.dev[name] = (ptr, cap)
+        return ptr
+
+    def result_buffer(self, nbytes):
+        if self.host is None or self.host.nbytes < nbytes:
+            self.host = self.ctx.pinned_empty((int(nbytes * 1.25) + 4096,), np.uint8)
+        return self.host
+
+    def wait(self):
+        if self.event is not None:
+            self.ctx.event_wait(self.event)
+            self.event = None
+
+    def close(self):
+        self.wait()
+        for ptr, _ in self.dev.values():
+            self.ctx.free(ptr)
+        self.dev.clear()
+        self.host = None
+
+
+class HostPipeline:
+
+    def __init__(self, ctx: Optional[_native.Context] = None, depth: int = 8, lanes: int = 8):
+        # Defaults from tools/pipe_rate.py on MI355X (2048^2 RGB remaps, page-locked inputs): 8 lanes x 1 slot 11.9 Gpx/s,
+        # 4 x 2 8.8, 2 x 2 8.5, 1 x 2 6.6.  The HIP runtime spreads streams over 4 hardware queues; the two copy directions
+        # of different lanes overlap reliably only once lanes share hardware queues (GPU_MAX_HW_QUEUES=2 gives the same
+        # 12 Gpx/s with 4 lanes).  The link carries 2 x 48 GB/s then: about 14 Gpx/s would saturate it.
+        assert depth >= 1 and lanes >= 1
+        self.ctx = ctx or _native.default_ctx()
+        lanes = min(lanes, depth)
+        # lane 0 is the caller's context; the others are private contexts on the same device
+        self.lanes = [self.ctx] + [_native.Context(self.ctx.device) for _ in range(lanes - 1)]
+        self.slots = [_Slot(self.lanes[k % lanes]) for k in range(depth)]
+        self._next = 0
+
+    # ------------------------------------------------------------------------------------------------ helpers
+    def _take_slot(self) -> _Slot:
+        slot = self.slots[self._next % len(self.slots)]
+        slot.wait()                      # its previous job has left the device: buffers are free again
+        slot.ticket = self._next
+        self._next += 1
+        return slot
+
+    @staticmethod
+    def _aligned(offset):
+        return (offset + 255) & ~255
+
+    def _upload_lattices(self, slot, state):
+        sv = _native._vertices(state.src_image_grid.vertices)
+        dv = _native._vertices(state.dst_image_grid.vertices)
+        if sv.shape != dv.shape:
+            raise ValueError('source / destination grids differ in shape')
+        half = self._aligned(sv.nbytes)
+        base = slot.device('lattice', 2 * half)
+        slot.ctx.copy_in(base, sv)
+        slot.ctx.copy_in(base + half, dv)
+        return base, base + half, sv.shape[0], sv.shape[1]
+
+    def _finish(self, slot, pieces):
+        """pieces: [(device pointer, shape, dtype)] -> queue the downloads, return the host views."""
+        total = 0
+        layout = []
+        for _, shape, dtype in pieces:
+            nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+            layout.append((total, nbytes))
+            total = self._aligned(total + nbytes)
+        host = slot.result_buffer(total)
+        views = []
+        for (dptr, shape, dtype), (off, nbytes) in zip(pieces, layout):
+            view = host[off:off + nbytes].view(dtype).reshape(shape)
+            slot.ctx.copy_out(dptr, view)
+            views.append(view)
+        slot.event = slot.ctx.event_record(_native.STREAM_COMPUTE)
+        slot.views = views
+        return slot.ticket
+
+    # ------------------------------------------------------------------------------------------------ jobs
+    def submit_remap(self, mats: Sequence[np.ndarray], state) -> int:
+        """Image / Mask / ScoreMap arrays of one source shape through the state's lattice pair
+        (``DistortionImageGridBased.distort``): up to four elements per job."""
+        mats = [np.ascontiguousarray(m) for m in mats]
+        if not 1 <= len(mats) <= 4:
+            raise ValueError('1..4 elements per job')
+        sh, sw = mats[0].shape[:2]
+        dh, dw = (int(v) for v in state.result_shape)
+        slot = self._take_slot()
+        sv_d, dv_d, rows, cols = self._upload_lattices(slot, state)
+        elems = (_native.VkxElem * len(mats))()
+        pieces = []
+        for j, m in enumerate(mats):
+            if m.shape[:2] != (sh, sw):
+                raise ValueError('all elements of one job must share the source shape')
+            if m.dtype == np.float32 and m.ndim == 2:
+                cn, is_f32, out_shape, sstride, dstride = 1, 1, (dh, dw), sw, dw
+            elif m.dtype == np.uint8 and (m.ndim == 2 or m.shape[2] in (1, 3, 4)):
+                cn = 1 if m.ndim == 2 else m.shape[2]
+                is_f32, out_shape = 0, ((dh, dw) if m.ndim == 2 else (dh, dw, cn))
+                sstride, dstride = sw * cn, dw * cn
+            else:
+                raise TypeError(f'unsupported element {m.dtype} {m.shape}')
+            src_d = slot.device(f'src{j}', m.nbytes)
+            dst_d = slot.device(f'dst{j}', int(np.prod(out_shape)) * m.dtype.itemsize)
+            slot.ctx.copy_in(src_d, m)
+            elems[j] = _native.VkxElem(src_d, dst_d, sstride, dstride, cn, is_f32)
+            pieces.append((dst_d, out_shape, m.dtype))
+        _native.check(_native.lib().vkx_grid_remap_dev(slot.ctx.handle, elems, len(mats), sh, sw, ctypes.c_void_p(sv_d),
+                                                      ctypes.c_void_p(dv_d), rows, cols, dh, dw))
+        return self._finish(slot, pieces)
+
+    def submit_chain(self, image: np.ndarray, state, blur_sigma: Optional[float] = None,
+                     hue_delta: Optional[int] = None, noise: Optional[np.ndarray] = None, streak=None) -> int:
+        """One RGB page through remap -> gaussian_blur -> color_shift -> gaussion_noise -> line_streak (``None`` skips a
+        stage), the fused kernel of ``vkx_chain_rgb_batch_dev``."""
+        image = np.ascontiguousarray(image)
+        if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
+            raise ValueError('submit_chain takes HxWx3 uint8 images')
+        sh, sw = image.shape[:2]
+        dh, dw = (int(v) for v in state.result_shape)
+        slot = self._take_slot()
+        sv_d, dv_d, rows, cols = self._upload_lattices(slot, state)
+        item = _native.VkxChainItem()
+        item.src = slot.device('src0', image.nbytes)
+        item.dst = slot.device('dst0', dh * dw * 3)
+        slot.ctx.copy_in(item.src, image)
+        item.src_stride, item.dst_stride = sw * 3, dw * 3
+        item.sh, item.sw, item.dh, item.dw = sh, sw, dh, dw
+        item.src_vertices, item.dst_vertices, item.rows, item.cols = sv_d, dv_d, rows, cols
+        if noise is not None:
+            noise = np.ascontiguousarray(noise, dtype=np.int16)
+            if noise.shape != (dh, dw, 3):
+                raise ValueError(f'noise plane must be {(dh, dw, 3)}, got {noise.shape}')
+            item.noise = slot.device('noise', noise.nbytes)
+            item.noise_stride_el = dw * 3
+            slot.ctx.copy_in(item.noise, noise)
+        if blur_sigma is not None:
+            item.blur_sigma = float(blur_sigma)
+            item.blur_ksize = _estimate_gaussian_kernel_size(blur_sigma)
+        if hue_delta is not None:
+            item.hue_delta, item.hue_enabled = int(hue_delta), 1
+        if streak is not None:
+            item.streak_enabled = 1
+            item.streak_thickness, item.streak_gap = int(streak.thickness), int(streak.gap)
+            item.streak_dash_thickness, item.streak_dash_gap = int(streak.dash_thickness), int(streak.dash_gap)
+            item.streak_enable_vert, item.streak_enable_hori = int(streak.enable_vert), int(streak.enable_hori)
+            for c in range(3):
+                item.streak_color[c] = int(streak.color[c])
+            item.streak_alpha = float(streak.alpha)
+        items = (_native.VkxChainItem * 1)(item)
+        _native.check(_native.lib().vkx_chain_rgb_batch_dev(slot.ctx.handle, items, 1))
+        return self._finish(slot, [(item.dst, (dh, dw, 3), np.uint8)])
+
+    # ------------------------------------------------------------------------------------------------ results
+    def result(self, ticket: int) -> List[np.ndarray]:
+        """The host views of job ``ticket`` (blocks until its downloads have landed).  They stay valid until ``depth``
+        more jobs have been submitted."""
+        slot = self.slots[ticket % len(self.slots)]
+        if slot.ticket != ticket:
+            raise KeyError(f'job {ticket} has been overwritten: at most {len(self.slots)} jobs stay readable')
+        slot.wait()
+        return slot.views
+
+    def drain(self):
+        for slot in self.slots:
+            slot.wait()
+
+    def close(self):
+        for slot in self.slots:
+            slot.close()
+        for lane in self.lanes[1:]:
+            lane.close()
+        self.lanes = self.lanes[:1]
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
