@@ -145,6 +145,8 @@ def main():
                     help='processes of the all-cores CPU leg (-1 = min(64, cores), 0 = skip)')
     ap.add_argument('--verify', type=int, default=4,
                     help='images of the batch checked against the oracle (spread over the batch, the last one included)')
+    ap.add_argument('--extra-legs', type=int, default=1,
+                    help='at N=1 also measure the throughput noise mode and the drop-in paths (reported beside, never as value)')
     ap.add_argument('--noise-workers', type=int, default=-1,
                     help='processes generating the numpy noise planes (0 = in this process, e.g. under rocprofv3)')
     args = ap.parse_args()
@@ -179,13 +181,21 @@ def main():
     noise_jobs = [(5000 + first + j, tuple(states[j].result_shape) + (3,)) for j in range(B)]
 
     import torch
-    torch.cuda.set_device(local_rank)
-    group = shard.Group(backend='nccl' if (world > 1 or 'MASTER_ADDR' in os.environ) else None,
-                        device=torch.device('cuda', local_rank))
+    # process -> GPU by the pool's rule (local_rank % visible GPUs): one rank per GPU on the driver's N-GPU node; on a
+    # box with fewer GPUs than ranks (the 2-ranks-on-1-GPU rendezvous check, profiles/r2_torchrun_2ranks_1gpu.log) the
+    # ranks share devices and the collectives go through gloo, because RCCL refuses two ranks on one device
+    n_dev = torch.cuda.device_count()
+    device_index = shard.device_for(local_rank, n_dev)
+    shared_devices = world > n_dev
+    torch.cuda.set_device(device_index)
+    backend = None
+    if world > 1 or 'MASTER_ADDR' in os.environ:
+        backend = os.environ.get('VKX_DIST_BACKEND') or ('gloo' if shared_devices else 'nccl')
+    group = shard.Group(backend=backend, device=torch.device('cuda', device_index))
 
     from vkit_amd import _native
     from vkit_amd.batch import ChainBatch
-    ctx = _native.Context(local_rank)
+    ctx = _native.Context(device_index)
     batch = ChainBatch(ctx)
     pool = mp.get_context('spawn').Pool(workers) if workers > 0 else None
     planes = pool.imap(_noise_plane, noise_jobs, chunksize=1) if pool else map(_noise_plane, noise_jobs)
@@ -230,6 +240,53 @@ def main():
 
     if rank != 0:
         return
+
+    # ---- reported beside the headline, N=1 only: the throughput noise mode and the drop-in paths -----------------------
+    throughput_mode, dropin = None, None
+    if world == 1 and args.extra_legs:
+        # (a) the same chain with the noise plane drawn on the device every step (vkx_noise_normal_i16_dev: the reference's
+        #     distribution, not numpy's values) instead of a resident numpy plane: no host generation, no 6 D upload
+        tb = ChainBatch(ctx)
+        for j in range(B):
+            image = np.random.default_rng(1000 + first + j).integers(0, 256, (size, size, 3), dtype=np.uint8)
+            tb.add(image, states[j], blur_sigma=BLUR_SIGMA, hue_delta=HUE_DELTA, noise_std=NOISE_STD, noise_seed=5000 + first + j)
+        tb.run()
+        ctx.sync()
+        ctx.set_timing(True)
+        ctx.reset_timings()
+        tsteps = max(1, min(args.steps, 50))
+        t0 = time.perf_counter()
+        for _ in range(tsteps):
+            tb.run()
+        ctx.sync()
+        tdt = time.perf_counter() - t0
+        tk = ctx.timings()
+        ctx.set_timing(False)
+        throughput_mode = {
+            'value': tb.source_pixels * tsteps / tdt / 1e6, 'unit': 'Mpixels/s', 'steps': tsteps,
+            'ms_per_step': tdt / tsteps * 1e3,
+            'kernels_ms_per_step': {k: round(v[0] / tsteps, 3) for k, v in sorted(tk.items())},
+            'note': 'noise planes drawn on the device every step (Philox2x32-10 + inverse-CDF table of round(N(0, std))): '
+                    'the distribution of the reference, not the values of its numpy stream -- a separately labelled mode',
+        }
+        tb.close()
+        # (b) host arrays in, host arrays out: tools/dropin.py in a process of its own (a clean HIP runtime: the stream ->
+        #     hardware-queue mapping the overlapped pipeline leans on is a property of the process)
+        import subprocess
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmp:
+            out_path = os.path.join(tmp, 'dropin.json')
+            try:
+                proc = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'dropin.py'), out_path, '--quick'],
+                                      capture_output=True, text=True, timeout=240,
+                                      env=dict(os.environ, VKX_DEVICE=str(device_index)))
+                if proc.returncode == 0 and os.path.exists(out_path):
+                    with open(out_path) as fin:
+                        dropin = json.load(fin)
+                else:
+                    dropin = {'error': (proc.stderr or proc.stdout)[-400:]}
+            except Exception as exc:          # the headline must not depend on this leg
+                dropin = {'error': repr(exc)}
 
     src_px = batch.source_pixels            # per rank, per step
     dst_px = batch.result_pixels
@@ -302,7 +359,8 @@ def main():
             'batch_per_gpu': B,
             'image': f'{size}x{size}x3',
             'mean_result_pixels': D,
-            'sharding': f'{world} process(es), one per GPU, independent images, no collective',
+            'sharding': f'{world} process(es), one per GPU, independent images, no collective' +
+                        (f' (ranks share {n_dev} GPU(s): rendezvous over {backend})' if shared_devices else ''),
             'verified_against_oracle': verified,
             'kernel_source_digest': kernel_source_digest(),
             'setup_s': round(t_setup, 1),
@@ -332,6 +390,10 @@ def main():
             'kernels_ms_per_step': {k: round(v[0] / args.steps, 3) for k, v in sorted(kernel_times.items())},
         },
     }
+    if throughput_mode is not None:
+        result['throughput_mode'] = throughput_mode
+    if dropin is not None:
+        result['dropin'] = dropin
     if world == 1:
         result['cpu_baseline'] = cpu_baseline(size, args.cpu_sample)
         n_procs = min(64, os.cpu_count() or 1) if args.cpu_procs < 0 else args.cpu_procs

@@ -430,6 +430,19 @@ int vkx_paint_polys(vkx_ctx *ctx, const int32_t *pts_host, const int32_t *poly_o
                     const float *values_host, uint8_t *mask, ptrdiff_t mask_stride, float *score,
                     ptrdiff_t score_stride_el, int h, int w);
 
+/* ---- throughput-mode noise plane ---------------------------------------------------------------
+ * gaussion_noise (photometric/noise.py:44-54) adds np.round(rng.normal(0, std, shape)) drawn from the caller's numpy
+ * Generator; the parity path takes that int16 plane from the caller (vkx_add_noise_i16, vkx_chain_item.noise).
+ * vkx_noise_normal_i16 draws a plane with the same DISTRIBUTION on the device -- not the same values, which are a
+ * function of numpy's bit stream: sample s of the flat C-order plane takes the (s & 3)-th 16-bit uniform of the
+ * Philox2x32-10 block with counter (s >> 2, seed >> 32) and key = seed low word, and maps it through a 65536-entry
+ * inverse-CDF table of round(N(0, std)) (vkx_noise_normal_table builds that table on the host, for checks).
+ * Separately labelled: a caller opts in.
+ * dst: int16 [h, w, cn], cn in 1..4; _dev: device plane, asynchronous; host variant: host plane, synchronous. */
+int vkx_noise_normal_table(double std, int16_t *table_host /* [65536] */);
+int vkx_noise_normal_i16_dev(vkx_ctx *ctx, int16_t *dst, ptrdiff_t stride_el, int h, int w, int cn, double std, uint64_t seed);
+int vkx_noise_normal_i16(vkx_ctx *ctx, int16_t *dst, ptrdiff_t stride_el, int h, int w, int cn, double std, uint64_t seed);
+
 /* ---- batched geometric + photometric chain (device resident) ---------------------------
  * RandomDistortion's geometric stage followed by photometric members on one page image
  * (mechanism/distortion_policy/random_distortion.py:190-203 applied through

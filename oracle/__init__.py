@@ -730,3 +730,25 @@ def mls_project(src_handles_xy, dst_handles_xy, src_handles_smooth_xy, dst_handl
         raise FloatingPointError(f'vertex {rc - 1}: divide by zero')
     assert rc == 0
     return out
+
+
+def philox2x32_10(c0, c1, key):
+    out = (ctypes.c_uint32 * 2)()
+    lib().vko_philox2x32_10(ctypes.c_uint32(c0), ctypes.c_uint32(c1), ctypes.c_uint32(key), out)
+    return int(out[0]), int(out[1])
+
+
+def noise_normal_table(std):
+    table = np.zeros(65536, np.int16)
+    lib().vko_noise_normal_table(ctypes.c_double(std), _p(table))
+    return table
+
+
+def noise_normal_i16(shape, std, seed):
+    """The library's throughput-mode noise plane (its own definition, not the reference's values)."""
+    h, w = int(shape[0]), int(shape[1])
+    cn = int(shape[2]) if len(shape) > 2 else 1
+    out = np.zeros(tuple(shape), np.int16)
+    rc = lib().vko_noise_normal_i16(_p(out), h, w, cn, ctypes.c_double(std), ctypes.c_uint64(int(seed) & 0xffffffffffffffff))
+    assert rc == 0
+    return out

@@ -2055,3 +2055,58 @@ VKO_API int vko_mls_project(const float *p, const float *q, const double *ps, co
     }
     return 0;
 }
+
+/* -----------------------------------------------------------------------------------------------------------------
+ * Throughput-mode noise plane (include/vkx.h: vkx_noise_normal_i16) -- NOT a restatement of the reference: the reference
+ * draws np.round(rng.normal(0, std, shape)) from numpy's stream (photometric/noise.py:44-54); this mode only shares the
+ * distribution.  What is pinned here is the library's own definition: Philox2x32-10 (Salmon, Moraes, Dror, Shaw,
+ * "Parallel random numbers: as easy as 1, 2, 3", SC'11; Random123 known answers in tests/test_oracle_golden.py) per
+ * pixel, four 16-bit uniforms, inverse-CDF table of round(N(0, std)) at the slice midpoints.
+ * ----------------------------------------------------------------------------------------------------------------- */
+VKO_API void vko_philox2x32_10(uint32_t c0, uint32_t c1, uint32_t key, uint32_t out[2])
+{
+    for (int r = 0; r < 10; r++) {
+        const uint64_t prod = (uint64_t)0xD256D193u * (uint64_t)c0;
+        const uint32_t hi = (uint32_t)(prod >> 32), lo = (uint32_t)prod;
+        c0 = hi ^ key ^ c1;
+        c1 = lo;
+        key += 0x9E3779B9u;
+    }
+    out[0] = c0; out[1] = c1;
+}
+
+VKO_API void vko_noise_normal_table(double std, int16_t *table)
+{
+    const double inv = 1.0 / (std * 1.4142135623730951);
+    int k = -32767;
+    const double z = -4.6 * std;
+    if (z > -32766.0) k = (int)floor(z) - 1;
+    if (k < -32767) k = -32767;
+    double cdf = 0.5 * erfc(-((double)k + 0.5) * inv);
+    for (int u = 0; u < 65536; u++) {
+        const double p = ((double)u + 0.5) / 65536.0;
+        while (cdf <= p && k < 32767) {
+            k++;
+            cdf = 0.5 * erfc(-((double)k + 0.5) * inv);
+        }
+        table[u] = (int16_t)k;
+    }
+}
+
+VKO_API int vko_noise_normal_i16(int16_t *dst, int h, int w, int cn, double std, uint64_t seed)
+{
+    if (cn < 1 || cn > 4 || !(std > 0)) return -1;
+    int16_t *table = (int16_t *)malloc(65536 * sizeof(int16_t));
+    if (!table) return -1;
+    vko_noise_normal_table(std, table);
+    /* sample s of the flat plane: the (s & 3)-th 16-bit uniform of Philox block s >> 2 */
+    const long long n = (long long)h * w * cn;
+    for (long long q = 0; q * 4 < n; q++) {
+        uint32_t r[2];
+        vko_philox2x32_10((uint32_t)q, (uint32_t)(seed >> 32), (uint32_t)seed, r);
+        const uint32_t u[4] = {r[0] & 0xffffu, r[0] >> 16, r[1] & 0xffffu, r[1] >> 16};
+        for (int j = 0; j < 4 && q * 4 + j < n; j++) dst[q * 4 + j] = table[u[j]];
+    }
+    free(table);
+    return 0;
+}

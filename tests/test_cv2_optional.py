@@ -58,3 +58,59 @@ def test_blur_colour_resize():
                          (O.resize_cubic(src, (140, 77)), cv.resize(src, (77, 140), interpolation=cv.INTER_CUBIC))):
         assert np.abs(ours.astype(int) - theirs.astype(int)).max() <= 1
         assert _frac_diff(ours, theirs) < 0.02
+
+
+def test_cell_homography_definition_vs_cv2_on_reference_lattices(golden_dir, capsys):
+    """The one place where the oracle knowingly DEFINES instead of restating: cell homographies in closed form where cv2
+    solves the 8x8 system by SVD.  Over the reference-generated lattices: how many 1/32-px map
+    entries differ between the two solvers, and by how much.  The result is printed (run with -s) so that anyone with
+    a cv2 can pin the number for their build; the assertion is the bound DESIGN quotes."""
+    import json
+    import os
+    flips = total = 0
+    worst = 0.0
+    for fname in ('mls_states.npz',):
+        M = np.load(os.path.join(golden_dir, fname))
+        for m in json.loads(bytes(M['meta_json'])):
+            k = m['key']
+            if k + '_src_grid' not in M.files:
+                continue
+            sv, dv = M[k + '_src_grid'], M[k + '_dst_grid']
+            shape = (int(dv[..., 1].max()) + 1, int(dv[..., 0].max()) + 1)
+            mx, my, owner = O.grid_to_map(sv, dv, shape, want_owner=True)
+            rows, cols = sv.shape[:2]
+            ys, xs = np.nonzero(owner > 0)
+            cell = owner[ys, xs] - 1
+            # cv2's homography per cell, applied the way the reference does (float64 matmul, float32 store)
+            Hs = np.empty(((rows - 1) * (cols - 1), 3, 3))
+            for r in range(rows - 1):
+                for c in range(cols - 1):
+                    q_dst = np.asarray([dv[r, c], dv[r, c + 1], dv[r + 1, c + 1], dv[r + 1, c]], np.float32)
+                    q_src = np.asarray([sv[r, c], sv[r, c + 1], sv[r + 1, c + 1], sv[r + 1, c]], np.float32)
+                    Hs[r * (cols - 1) + c] = cv.getPerspectiveTransform(q_dst, q_src, cv.DECOMP_SVD)
+            H = Hs[cell]
+            den = H[:, 2, 0] * xs + H[:, 2, 1] * ys + H[:, 2, 2]
+            cx = ((H[:, 0, 0] * xs + H[:, 0, 1] * ys + H[:, 0, 2]) / den).astype(np.float32)
+            cy = ((H[:, 1, 0] * xs + H[:, 1, 1] * ys + H[:, 1, 2]) / den).astype(np.float32)
+            fx = np.rint(cx * np.float32(32)) != np.rint(mx[ys, xs] * np.float32(32))
+            fy = np.rint(cy * np.float32(32)) != np.rint(my[ys, xs] * np.float32(32))
+            flips += int(fx.sum() + fy.sum())
+            total += 2 * len(xs)
+            worst = max(worst, float(np.abs(cx - mx[ys, xs]).max()), float(np.abs(cy - my[ys, xs]).max()))
+    with capsys.disabled():
+        print(f'\\ncell homography, closed form vs cv2 {cv.__version__} DECOMP_SVD: {flips} of {total} 1/32-px map entries differ '
+              f'({flips / max(total, 1):.2e}); largest coordinate difference {worst:.3e} px')
+    assert worst < 1e-3 and flips / max(total, 1) < 1e-3
+
+
+def test_hsv2rgb_lsb_rate_vs_cv2(capsys):
+    """HSV -> RGB: the oracle follows the scalar float formula; a cv2 build's SIMD lanes may associate differently.
+    The whole 2^24 cube: how many bytes differ and by how much (printed; bound: 1 LSB, < 0.5 % of the bytes)."""
+    cube = np.stack(np.meshgrid(np.arange(256), np.arange(256), np.arange(256), indexing='ij'), -1).astype(np.uint8).reshape(4096, 4096, 3)
+    ours, theirs = O.hsv2rgb_full(cube), cv.cvtColor(cube, cv.COLOR_HSV2RGB_FULL)
+    diff = np.abs(ours.astype(np.int16) - theirs.astype(np.int16))
+    with capsys.disabled():
+        print(f'\\nHSV2RGB_FULL over the 2^24 cube vs cv2 {cv.__version__}: {int((diff > 0).sum())} of {diff.size} bytes differ, max {int(diff.max())}')
+    assert diff.max() <= 1 and (diff > 0).mean() < 5e-3
+    rt = cv.cvtColor(cube, cv.COLOR_RGB2HSV_FULL)
+    assert (O.rgb2hsv_full(cube) == rt).all()

@@ -97,3 +97,31 @@ def test_pipeline_full_size_and_pinned_results():
     del a
     b = N.grid_remap([images[1]], sv, dv, dshape)[0]
     assert b.ctypes.data == addr
+
+
+def test_device_noise_in_batch_and_pipeline():
+    """Throughput-mode noise: a chain whose plane is drawn on the device equals the chain fed the very same plane (the
+    oracle's statement of the generator) from the host; every run of a batch draws a fresh plane."""
+    from vkit_amd import _native as N
+    from vkit_amd.batch import ChainBatch
+    from vkit_amd.hostpipe import HostPipeline
+    sv, dv, dshape = synthetic_grid(300, 420, 15, 7.0, seed=5)
+    st = _state(sv, dv, dshape)
+    image = default_rng(3).integers(0, 256, (300, 420, 3), dtype=np.uint8)
+    mx, my = O.grid_to_map(sv, dv, dshape)
+    base = O.color_shift_rgb(O.gaussian_blur(O.remap(image, mx, my), 5, 1.0), 37)
+    seed = 0x0123456789abcdef
+    with HostPipeline(N.default_ctx(), depth=2) as pipe:
+        got = pipe.result(pipe.submit_chain(image, st, blur_sigma=1.0, hue_delta=37, noise_std=10.0, noise_seed=seed))[0]
+        assert (got == O.add_noise_i16(base, O.noise_normal_i16(tuple(dshape) + (3,), 10.0, seed))).all()
+    batch = ChainBatch()
+    batch.add(image, st, blur_sigma=1.0, hue_delta=37, noise_std=10.0, noise_seed=seed)
+    batch.run()
+    first = batch.result(0)
+    assert (first == O.add_noise_i16(base, O.noise_normal_i16(tuple(dshape) + (3,), 10.0, seed))).all()
+    batch.run()
+    second = batch.result(0)
+    nxt = (seed + 0x9E3779B97F4A7C15) & 0xffffffffffffffff
+    assert (second == O.add_noise_i16(base, O.noise_normal_i16(tuple(dshape) + (3,), 10.0, nxt))).all()
+    assert (first != second).mean() > 0.5
+    batch.close()

@@ -440,3 +440,17 @@ def test_resize_lanczos4_nan_coefficient_column():
         got, want = N.resize(plane, (dh, dw), 4), O.resize(plane, (dh, dw), 4)
         assert np.isnan(want).any()
         assert ((got == want) | (np.isnan(got) & np.isnan(want))).all()
+
+
+def test_throughput_noise_plane_matches_its_definition():
+    """vkx_noise_normal_i16 (device Philox2x32-10 + inverse-CDF table) against the oracle's statement of the same
+    definition, bit for bit; the chain with a device-drawn plane equals the chain fed the same plane from the host."""
+    from vkit_amd import _native as N
+    for shape, std, seed in (((123, 77, 3), 10.0, 1), ((64, 64, 1), 3.0, 2 ** 63 + 5), ((31, 500, 4), 25.0, 0xdeadbeefcafe),
+                             ((2147, 2115, 3), 10.0, 42), ((50, 70, 3), 100.0, 9), ((3, 5, 1), 0.3, 4)):
+        got = N.noise_normal_i16(shape, std, seed)
+        want = O.noise_normal_i16(shape, std, seed)
+        assert got.dtype == np.int16 and got.shape == want.shape and (got == want).all(), shape
+    assert (N.noise_normal_table(7.5) == O.noise_normal_table(7.5)).all()
+    with pytest.raises(N.VkxError):
+        N.noise_normal_i16((4, 4, 3), 0.0, 1)

@@ -490,3 +490,24 @@ def test_mls_project_small_handle_counts_and_pins():
             PointProjector.project_array(proj, on_integer)
     finally:
         _os.environ.pop('VKX_MLS_HOST_PROJECTION', None)
+
+
+def test_throughput_noise_definition():
+    """The library's device-noise mode (not the reference's values, SURVEY 8b `philox_seed`): Philox2x32-10 against the
+    Random123 known answers, the inverse-CDF table against the exact law of round(N(0, std)), plane moments."""
+    assert O.philox2x32_10(0, 0, 0) == (0xff1dae59, 0x6cd10df2)
+    assert O.philox2x32_10(0xffffffff, 0xffffffff, 0xffffffff) == (0x2c3f628b, 0xab4fd7ad)
+    assert O.philox2x32_10(0x243f6a88, 0x85a308d3, 0x13198a2e) == (0xdd7ce038, 0xf62a4c12)
+    from scipy.stats import norm
+    for std in (0.5, 3.0, 10.0, 25.0, 100.0):
+        t = O.noise_normal_table(std)
+        assert (np.diff(t.astype(np.int32)) >= 0).all() and t[0] == -t[-1]
+        ks = np.arange(int(t.min()), int(t.max()) + 1)
+        freq = np.array([(t == k).sum() for k in ks]) / 65536.0
+        exact = norm.cdf((ks + 0.5) / std) - norm.cdf((ks - 0.5) / std)
+        assert np.abs(freq - exact).max() < 2.0 ** -16 + 1e-9
+    plane = O.noise_normal_i16((257, 301, 3), 10.0, 0x1234567890abcdef)
+    assert abs(plane.mean()) < 0.1 and abs(plane.std() - 10.004) < 0.1
+    assert (plane != O.noise_normal_i16((257, 301, 3), 10.0, 0x1234567890abcdee)).mean() > 0.9
+    # the plane is a flat sample sequence: its shape only folds it
+    assert (O.noise_normal_i16((257, 301, 3), 10.0, 7).ravel() == O.noise_normal_i16((257 * 301 * 3, 1, 1), 10.0, 7).ravel()).all()

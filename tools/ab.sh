@@ -2,7 +2,7 @@
 # A/B of one PMC group between two env settings.  Usage: tools/ab.sh "<counters>" "<envA>" "<envB>"
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --batch 16 --steps 2 --warmup 1 --cpu-sample 0 --verify 0 --noise-workers 0"
+BENCH="python $ROOT/bench.py --batch 16 --steps 2 --warmup 1 --cpu-sample 0 --verify 0 --noise-workers 0 --extra-legs 0"
 for v in A B; do
   if [ $v = A ]; then E="$2"; else E="$3"; fi
   rm -rf /tmp/ab_$v

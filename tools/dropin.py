@@ -6,8 +6,10 @@ bench.py.  Never the bench `value`; bench.py embeds this as `dropin`.
                        kernel), upload, tile kernel, download into a recycled page-locked result
   pipeline_remap_2048  the same remaps through HostPipeline (8 lanes): uploads / kernels / downloads of different jobs
                        overlap on the copy streams; inputs in page-locked memory, states built beforehand
-  pipeline_chain_2048  C3's chain per image through HostPipeline, with its int16 noise plane uploaded (6 B / result px)
-  random_distortion_1024  RandomDistortion.distort on 1024^2 pages (C4's distortion step), default policy table
+  pipeline_chain_2048  C3's chain per image through HostPipeline, with its int16 noise plane uploaded (6 B / result px),
+                       and with the plane drawn on the device instead (throughput mode)
+  random_distortion_1024  RandomDistortion.distort on 1024^2 pages (C4's distortion step), default policy table; its time
+                       is the host arithmetic of the rng-stream members (tools/rd_profile.py)
 Usage: tools/dropin.py [out.json] [--quick]"""
 import json
 import os
@@ -103,6 +105,24 @@ def measure(quick=False):
     out['pipeline_chain_2048_depth8'] = {'images_per_s': jobs / dt, 'mpx_per_s': jobs * S * S / dt / 1e6,
                                         'ms_per_image': dt / jobs * 1e3,
                                         'note': 'C3 chain per image incl. upload of its int16 noise plane (6 B per result pixel)'}
+
+    # the same chain with the noise plane drawn on the device (throughput mode): only the page crosses the link
+    with HostPipeline(ctx) as pipe:
+        pipe.submit_chain(pinned[0], cstates[0], blur_sigma=1.0, hue_delta=37, noise_std=10.0, noise_seed=1)
+        pipe.drain()
+        t0 = time.perf_counter()
+        tickets = []
+        for k in range(jobs):
+            i = k % n_img
+            tickets.append(pipe.submit_chain(pinned[i], cstates[i], blur_sigma=1.0, hue_delta=37, noise_std=10.0, noise_seed=k))
+            if k >= 7:
+                pipe.result(tickets[k - 7])
+        pipe.drain()
+        dt = time.perf_counter() - t0
+    out['pipeline_chain_2048_device_noise'] = {'images_per_s': jobs / dt, 'mpx_per_s': jobs * S * S / dt / 1e6,
+                                               'ms_per_image': dt / jobs * 1e3,
+                                               'note': 'C3 chain per image, noise drawn on the device (vkx_noise_normal_i16_dev): '
+                                                       'the distribution of the reference, not its numpy values'}
 
     # ---- RandomDistortion on 1024^2 pages
     P = 1024

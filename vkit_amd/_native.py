@@ -129,6 +129,9 @@ _SIGNATURES = {
     'vkx_download': [c_void_p, c_void_p, c_void_p, c_size],
     'vkx_memset': [c_void_p, c_void_p, c_int, c_size],
     'vkx_chain_rgb_batch_dev': [c_void_p, ctypes.POINTER(VkxChainItem), c_int],
+    'vkx_noise_normal_table': [c_double, c_void_p],
+    'vkx_noise_normal_i16_dev': [c_void_p, c_void_p, c_ssize, c_int, c_int, c_int, c_double, ctypes.c_uint64],
+    'vkx_noise_normal_i16': [c_void_p, c_void_p, c_ssize, c_int, c_int, c_int, c_double, ctypes.c_uint64],
     'vkx_host_alloc': [c_void_p, c_size, ctypes.POINTER(c_void_p)],
     'vkx_host_free': [c_void_p, c_void_p],
     'vkx_upload_async': [c_void_p, c_void_p, c_void_p, c_size],
@@ -683,6 +686,24 @@ def mls_project(src_handles_xy, dst_handles_xy, src_handles_smooth_xy, dst_handl
         raise FloatingPointError(last_error())
     check(rc)
     return out
+
+
+def noise_normal_i16(shape, std, seed, ctx=None):
+    """Throughput-mode noise plane: int16 ``shape`` = (h, w[, cn]) with the distribution of ``np.round(rng.normal(0, std))``,
+    drawn on the device from Philox2x32-10 keyed by ``seed`` (include/vkx.h: vkx_noise_normal_i16).  NOT the reference's
+    values -- those come from the caller's numpy stream (``gaussion_noise_plane``)."""
+    ctx = ctx or default_ctx()
+    h, w = int(shape[0]), int(shape[1])
+    cn = int(shape[2]) if len(shape) > 2 else 1
+    out = ctx.pinned_empty(tuple(shape), np.int16)
+    check(lib().vkx_noise_normal_i16(ctx.handle, _ptr(out), w * cn, h, w, cn, float(std), int(seed) & 0xffffffffffffffff))
+    return out
+
+
+def noise_normal_table(std):
+    table = np.empty(65536, np.int16)
+    check(lib().vkx_noise_normal_table(float(std), _ptr(table)))
+    return table
 
 
 def gaussian_blur(img, ksize, sigma, ctx=None):

@@ -22,6 +22,8 @@ class ChainBatch:
         self._owned: List[int] = []
         self._dst_shapes: List[Tuple[int, int]] = []
         self._array = None
+        self._device_noise = []      # (item index, std, seed, dh, dw) of the throughput-mode items
+        self._runs = 0
 
     def _put(self, array: np.ndarray) -> int:
         array = np.ascontiguousarray(array)
@@ -31,9 +33,14 @@ class ChainBatch:
         return ptr
 
     def add(self, image: np.ndarray, state: DistortionStateImageGridBased, blur_sigma: Optional[float] = None,
-            hue_delta: Optional[int] = None, noise: Optional[np.ndarray] = None, streak=None):
+            hue_delta: Optional[int] = None, noise: Optional[np.ndarray] = None, streak=None,
+            noise_std: Optional[float] = None, noise_seed: Optional[int] = None):
         """Registers one HxWx3 uint8 image with its image-grid state and per-image photometric parameters (stage order:
-        remap, gaussian_blur, color_shift, gaussion_noise, line_streak; ``None`` skips a stage)."""
+        remap, gaussian_blur, color_shift, gaussion_noise, line_streak; ``None`` skips a stage).
+
+        ``noise``: the caller's int16 plane (parity mode: the reference's values, from the caller's numpy stream).
+        ``noise_std`` + ``noise_seed``: throughput mode -- every ``run`` draws a fresh plane of the same distribution on
+        the device (``vkx_noise_normal_i16_dev``, seed advanced per run), nothing crosses the link."""
         if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
             raise ValueError('ChainBatch takes HxWx3 uint8 images')
         sh, sw = image.shape[:2]
@@ -50,6 +57,13 @@ class ChainBatch:
         item.sh, item.sw, item.dh, item.dw = sh, sw, dh, dw
         item.src_vertices, item.dst_vertices = self._put(sv), self._put(dv)
         item.rows, item.cols = sv.shape[0], sv.shape[1]
+        if noise_std is not None:
+            if noise is not None:
+                raise ValueError('pass either a noise plane or noise_std / noise_seed')
+            item.noise = self.ctx.malloc(dh * dw * 3 * 2)
+            self._owned.append(item.noise)
+            item.noise_stride_el = dw * 3
+            self._device_noise.append((len(self._items), float(noise_std), int(noise_seed or 0), dh, dw))
         if noise is not None:
             if noise.shape != (dh, dw, 3):
                 raise ValueError(f'noise plane must be {(dh, dw, 3)}, got {noise.shape}')
@@ -88,7 +102,12 @@ class ChainBatch:
         """Enqueues the chain for every image on the ctx stream (asynchronous)."""
         if self._array is None:
             self._array = (_native.VkxChainItem * max(len(self._items), 1))(*self._items)
-        _native.check(_native.lib().vkx_chain_rgb_batch_dev(self.ctx.handle, self._array, len(self._items)))
+        lib = _native.lib()
+        for index, std, seed, dh, dw in self._device_noise:
+            _native.check(lib.vkx_noise_normal_i16_dev(self.ctx.handle, self._items[index].noise, dw * 3, dh, dw, 3, std,
+                                                       (seed + self._runs * 0x9E3779B97F4A7C15) & 0xffffffffffffffff))
+        self._runs += 1
+        _native.check(lib.vkx_chain_rgb_batch_dev(self.ctx.handle, self._array, len(self._items)))
 
     def result(self, index: int) -> np.ndarray:
         self.ctx.sync()
@@ -101,6 +120,7 @@ class ChainBatch:
             self.ctx.free(ptr)
         self._owned.clear()
         self._items.clear()
+        self._device_noise.clear()
         self._array = None
 
     def __del__(self):

@@ -66,6 +66,7 @@ VKX_EXPORT int vkx_ctx_destroy(vkx_ctx *ctx)
     scratch_release(&ctx->tables);
     for (auto &s : ctx->stage) scratch_release(&s);
     for (auto &s : ctx->chain) scratch_release(&s);
+    scratch_release(&ctx->noise_table);
     for (auto &t : ctx->resize_tabs) scratch_release(&t.buf);
     for (auto &l : ctx->launches) { (void)hipEventDestroy(l.start); (void)hipEventDestroy(l.stop); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);

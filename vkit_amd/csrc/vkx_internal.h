@@ -57,6 +57,9 @@ struct vkx_ctx {
     bool tables_ready = false;
     vkx_scratch stage[6]; // staging planes of the host-pointer entry points
     vkx_scratch chain[2]; // ping-pong planes of the batched chain entry point
+    vkx_scratch noise_table;          // int16 [65536] inverse-CDF table of vkx_noise_normal_i16 for noise_table_std
+    double noise_table_std = 0.0;
+    bool noise_table_fits8 = false;
 
     // Host-array pipelines: two copy streams next to the compute stream (created on first use), a pool of events that
     // order them, and a page-locked ring through which the launch descriptors of the tile kernels reach the device

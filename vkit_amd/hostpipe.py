@@ -155,9 +155,11 @@ class HostPipeline:
         return self._finish(slot, pieces)
 
     def submit_chain(self, image: np.ndarray, state, blur_sigma: Optional[float] = None,
-                     hue_delta: Optional[int] = None, noise: Optional[np.ndarray] = None, streak=None) -> int:
+                     hue_delta: Optional[int] = None, noise: Optional[np.ndarray] = None, streak=None,
+                     noise_std: Optional[float] = None, noise_seed: Optional[int] = None) -> int:
         """One RGB page through remap -> gaussian_blur -> color_shift -> gaussion_noise -> line_streak (``None`` skips a
-        stage), the fused kernel of ``vkx_chain_rgb_batch_dev``."""
+        stage), the fused kernel of ``vkx_chain_rgb_batch_dev``.  ``noise``: the caller's int16 plane, uploaded (6 bytes
+        per result pixel); ``noise_std`` / ``noise_seed``: throughput mode, the plane is drawn on the device."""
         image = np.ascontiguousarray(image)
         if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
             raise ValueError('submit_chain takes HxWx3 uint8 images')
@@ -172,6 +174,13 @@ class HostPipeline:
         item.src_stride, item.dst_stride = sw * 3, dw * 3
         item.sh, item.sw, item.dh, item.dw = sh, sw, dh, dw
         item.src_vertices, item.dst_vertices, item.rows, item.cols = sv_d, dv_d, rows, cols
+        if noise_std is not None:
+            if noise is not None:
+                raise ValueError('pass either a noise plane or noise_std / noise_seed')
+            item.noise = slot.device('noise', dh * dw * 3 * 2)
+            item.noise_stride_el = dw * 3
+            _native.check(_native.lib().vkx_noise_normal_i16_dev(slot.ctx.handle, item.noise, dw * 3, dh, dw, 3,
+                                                                float(noise_std), int(noise_seed or 0) & 0xffffffffffffffff))
         if noise is not None:
             noise = np.ascontiguousarray(noise, dtype=np.int16)
             if noise.shape != (dh, dw, 3):
