@@ -190,6 +190,22 @@ int vkx_line_streak_u8(vkx_ctx *ctx, uint8_t *img, int h, int w, int cn, ptrdiff
                        int gap, int dash_thickness, int dash_gap, const uint8_t color[4], double alpha,
                        int enable_vert, int enable_hori);
 
+/* ellipse_streak  photometric/streak.py:283-337.  vkx_ellipse_mask_u8: the loop of
+ * cv.ellipse(mask, (cx, cy), axes[i], angle 0, arc 0..360, color 1, thickness) calls (:312-324; LINE_8, shift 0) drawn
+ * onto `mask` (uint8 [h, w]; touched pixels become 1, the others keep their value).  axes_host: HOST int32
+ * [n_ellipses, 2] as (box.width // 2, box.height // 2).  thickness in 1 .. 32767 (filled ellipses are not on the path).
+ * vkx_ellipse_streak_u8: that mask on a cleared plane, then Mask.fill_image(image, color, alpha) in place. */
+int vkx_ellipse_mask_u8_dev(vkx_ctx *ctx, uint8_t *mask, ptrdiff_t mask_stride, int h, int w, int cx, int cy,
+                            const int32_t *axes_host, int n_ellipses, int thickness);
+int vkx_ellipse_mask_u8(vkx_ctx *ctx, uint8_t *mask, ptrdiff_t mask_stride, int h, int w, int cx, int cy,
+                        const int32_t *axes_host, int n_ellipses, int thickness);
+int vkx_ellipse_streak_u8_dev(vkx_ctx *ctx, uint8_t *img, int h, int w, int cn, ptrdiff_t stride, int cx, int cy,
+                              const int32_t *axes_host, int n_ellipses, int thickness, const uint8_t color[4],
+                              double alpha);
+int vkx_ellipse_streak_u8(vkx_ctx *ctx, uint8_t *img, int h, int w, int cn, ptrdiff_t stride, int cx, int cy,
+                          const int32_t *axes_host, int n_ellipses, int thickness, const uint8_t color[4],
+                          double alpha);
+
 /* cv.cvtColor on uint8 images, the codes Image.to_target_mode_image uses (element/image.py:188-202,771-814).
  * HSL images of the reference are HLS with the last two channels swapped on the host. */
 #define VKX_CVT_RGB2HSV_FULL 0

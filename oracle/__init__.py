@@ -752,3 +752,33 @@ def noise_normal_i16(shape, std, seed):
     rc = lib().vko_noise_normal_i16(_p(out), h, w, cn, ctypes.c_double(std), ctypes.c_uint64(int(seed) & 0xffffffffffffffff))
     assert rc == 0
     return out
+
+
+def ellipse_streak(img, thickness=1, aspect_ratio=None, short_side_min=10, short_side_step=10, color=(0, 0, 0), alpha=1.0):
+    """ellipse_streak_image -- photometric/streak.py:296-330: [cv2] cv.ellipse per concentric box, then Mask.fill_image."""
+    out = np.array(img, dtype=np.uint8, order='C')
+    H, W = out.shape[:2]
+    if aspect_ratio is None:
+        aspect_ratio = W / H
+    mask = np.zeros((H, W), np.uint8)
+    for (up, down, left, right) in _centered_boxes(H, W, aspect_ratio, short_side_min, short_side_step):
+        ellipse_outline(mask, (W // 2, H // 2), ((right + 1 - left) // 2, (down + 1 - up) // 2), thickness)
+    fill(out, (0, 0, H, W), tuple(color), mask=mask, alpha=float(alpha))
+    return out
+
+
+def ellipse_outline(mask, center, axes, thickness):
+    """[cv2] cv.ellipse(mask, center=(x, y), axes=(a, b), angle=0, startAngle=0, endAngle=360, color=1, thickness) in place
+    (photometric/streak.py:312-324)."""
+    assert mask.dtype == np.uint8 and mask.ndim == 2 and mask.flags.c_contiguous and mask.flags.writeable
+    rc = lib().vko_ellipse_outline(_p(mask), mask.shape[0], mask.shape[1], int(center[0]), int(center[1]), int(axes[0]),
+                                   int(axes[1]), int(thickness))
+    assert rc == 0
+    return mask
+
+
+def ellipse_vertices(center, axes):
+    """The rounded 16.16 outline vertices cv.ellipse hands to PolyLine for one axis-aligned full ellipse."""
+    xy = np.zeros((74, 2), np.int64)
+    n = lib().vko_ellipse_vertices(int(center[0]), int(center[1]), int(axes[0]), int(axes[1]), _p(xy))
+    return xy[:n]

@@ -25,6 +25,7 @@
 #include <math.h>
 #include <limits.h>
 #include <float.h>
+#include <stdio.h>
 
 #define VKO_API __attribute__((visibility("default")))
 
@@ -2108,5 +2109,317 @@ VKO_API int vko_noise_normal_i16(int16_t *dst, int h, int w, int cn, double std,
         for (int j = 0; j < 4 && q * 4 + j < n; j++) dst[q * 4 + j] = table[u[j]];
     }
     free(table);
+    return 0;
+}
+
+/* -----------------------------------------------------------------------------------------------------------------
+ * [cv2] cv.ellipse(mask, center, axes, angle=0, startAngle=0, endAngle=360, color=1, thickness >= 1) as
+ * ellipse_streak_image calls it (photometric/streak.py:306-326): LINE_8, shift 0, one call per concentric box.
+ * Restated from OpenCV 4.5.x modules/imgproc/src/drawing.cpp (parity unpinned like every [cv2] member: no cv2 in this
+ * image):  ellipse -> EllipseEx (arc step from the larger axis) -> ellipse2Poly (float SinTable of 7-decimal literals,
+ * double vertices in 16.16) -> rounded, consecutive duplicates dropped -> PolyLine(open) -> ThickLine per segment:
+ * thickness <= 1: Line2 (16.16 DDA after clipLine); otherwise FillConvexPoly of the offset quad (its edges through
+ * Line2, then the two-edge scan conversion) and a filled Circle at the segment ends.
+ * ----------------------------------------------------------------------------------------------------------------- */
+#define VKO_XY_SHIFT 16
+#define VKO_XY_ONE (1 << VKO_XY_SHIFT)
+
+static float vko_sin_tab[451];
+static int vko_sin_tab_ready = 0;
+
+static void vko_init_sin_tab(void)
+{
+    /* SinTable[]: sin of whole degrees 0..450 written as 7-decimal float literals */
+    if (vko_sin_tab_ready) return;
+    for (int d = 0; d <= 450; d++) {
+        char buf[32];
+        snprintf(buf, sizeof buf, "%.7f", sin((double)d * 3.14159265358979323846 / 180.0));
+        vko_sin_tab[d] = strtof(buf, 0);
+    }
+    vko_sin_tab_ready = 1;
+}
+
+typedef struct { int64_t x, y; } vko_pt2l;
+
+static inline void vko_put(uint8_t *img, int h, int w, int64_t x, int64_t y)
+{
+    if (0 <= x && x < w && 0 <= y && y < h) img[(ptrdiff_t)y * w + x] = 1;
+}
+
+static inline void vko_hline(uint8_t *img, int w, int y, int x1, int x2)
+{
+    for (int x = x1; x <= x2; x++) img[(ptrdiff_t)y * w + x] = 1;
+}
+
+/* clipLine(Size2l, Point2l&, Point2l&) */
+static int vko_clip_line(int64_t width, int64_t height, vko_pt2l *p1, vko_pt2l *p2)
+{
+    const int64_t right = width - 1, bottom = height - 1;
+    if (width <= 0 || height <= 0) return 0;
+    int64_t x1 = p1->x, y1 = p1->y, x2 = p2->x, y2 = p2->y;
+    int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+    int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+        int64_t a;
+        if (c1 & 12) {
+            a = c1 < 8 ? 0 : bottom;
+            x1 += (int64_t)((double)(a - y1) * (double)(x2 - x1) / (double)(y2 - y1));
+            y1 = a;
+            c1 = (x1 < 0) + (x1 > right) * 2;
+        }
+        if (c2 & 12) {
+            a = c2 < 8 ? 0 : bottom;
+            x2 += (int64_t)((double)(a - y2) * (double)(x2 - x1) / (double)(y2 - y1));
+            y2 = a;
+            c2 = (x2 < 0) + (x2 > right) * 2;
+        }
+        if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+            if (c1) {
+                a = c1 == 1 ? 0 : right;
+                y1 += (int64_t)((double)(a - x1) * (double)(y2 - y1) / (double)(x2 - x1));
+                x1 = a;
+                c1 = 0;
+            }
+            if (c2) {
+                a = c2 == 1 ? 0 : right;
+                y2 += (int64_t)((double)(a - x2) * (double)(y2 - y1) / (double)(x2 - x1));
+                x2 = a;
+                c2 = 0;
+            }
+        }
+    }
+    p1->x = x1; p1->y = y1; p2->x = x2; p2->y = y2;
+    return (c1 | c2) == 0;
+}
+
+/* Line2: end points in 16.16 */
+static void vko_line2(uint8_t *img, int h, int w, vko_pt2l pt1, vko_pt2l pt2)
+{
+    if (!vko_clip_line((int64_t)w << VKO_XY_SHIFT, (int64_t)h << VKO_XY_SHIFT, &pt1, &pt2)) return;
+    int64_t dx = pt2.x - pt1.x, dy = pt2.y - pt1.y;
+    const int64_t j = dx < 0 ? -1 : 0, i = dy < 0 ? -1 : 0;
+    const int64_t ax = (dx ^ j) - j, ay = (dy ^ i) - i;
+    int64_t x_step, y_step;
+    int ecount;
+    if (ax > ay) {
+        dy = (dy ^ j) - j;
+        if (j) { vko_pt2l t = pt1; pt1 = pt2; pt2 = t; }
+        x_step = VKO_XY_ONE;
+        y_step = (dy * VKO_XY_ONE) / (ax | 1);        /* (dy << XY_SHIFT) / (ax | 1), C division */
+        ecount = (int)((pt2.x - pt1.x) >> VKO_XY_SHIFT);
+    } else {
+        dx = (dx ^ i) - i;
+        if (i) { vko_pt2l t = pt1; pt1 = pt2; pt2 = t; }
+        x_step = (dx * VKO_XY_ONE) / (ay | 1);
+        y_step = VKO_XY_ONE;
+        ecount = (int)((pt2.y - pt1.y) >> VKO_XY_SHIFT);
+    }
+    pt1.x += VKO_XY_ONE >> 1;
+    pt1.y += VKO_XY_ONE >> 1;
+    vko_put(img, h, w, (pt2.x + (VKO_XY_ONE >> 1)) >> VKO_XY_SHIFT, (pt2.y + (VKO_XY_ONE >> 1)) >> VKO_XY_SHIFT);
+    if (ax > ay) {
+        pt1.x >>= VKO_XY_SHIFT;
+        while (ecount >= 0) {
+            vko_put(img, h, w, pt1.x, pt1.y >> VKO_XY_SHIFT);
+            pt1.x++;
+            pt1.y += y_step;
+            ecount--;
+        }
+    } else {
+        pt1.y >>= VKO_XY_SHIFT;
+        while (ecount >= 0) {
+            vko_put(img, h, w, pt1.x >> VKO_XY_SHIFT, pt1.y);
+            pt1.x += x_step;
+            pt1.y++;
+            ecount--;
+        }
+    }
+    (void)x_step;
+}
+
+/* FillConvexPoly(img, v, npts, color, LINE_8, shift = XY_SHIFT) */
+static void vko_fill_convex_poly16(uint8_t *img, int h, int w, const vko_pt2l *v, int npts)
+{
+    struct { int idx, di; int64_t x, dx; int ye; } edge[2];
+    const int shift = VKO_XY_SHIFT, delta = 1 << shift >> 1;
+    const int delta1 = VKO_XY_ONE >> 1, delta2 = VKO_XY_ONE >> 1;
+    int imin = 0, edges = npts;
+    int64_t xmin = v[0].x, xmax = v[0].x, ymin = v[0].y, ymax = v[0].y;
+    vko_pt2l p0 = v[npts - 1];
+    for (int i = 0; i < npts; i++) {
+        const vko_pt2l p = v[i];
+        if (p.y < ymin) { ymin = p.y; imin = i; }
+        if (p.y > ymax) ymax = p.y;
+        if (p.x > xmax) xmax = p.x;
+        if (p.x < xmin) xmin = p.x;
+        vko_line2(img, h, w, p0, p);
+        p0 = p;
+    }
+    xmin = (xmin + delta) >> shift;
+    xmax = (xmax + delta) >> shift;
+    ymin = (ymin + delta) >> shift;
+    ymax = (ymax + delta) >> shift;
+    if (npts < 3 || (int)xmax < 0 || (int)ymax < 0 || (int)xmin >= w || (int)ymin >= h) return;
+    if (ymax > h - 1) ymax = h - 1;
+    int y = (int)ymin;
+    edge[0].idx = edge[1].idx = imin;
+    edge[0].ye = edge[1].ye = y;
+    edge[0].di = 1;
+    edge[1].di = npts - 1;
+    edge[0].x = edge[1].x = -VKO_XY_ONE;
+    edge[0].dx = edge[1].dx = 0;
+    do {
+        for (int i = 0; i < 2; i++) {
+            if (y >= edge[i].ye) {
+                int idx0 = edge[i].idx;
+                const int di = edge[i].di;
+                int idx = idx0 + di;
+                if (idx >= npts) idx -= npts;
+                for (; edges-- > 0;) {
+                    const int ty = (int)((v[idx].y + delta) >> shift);
+                    if (ty > y) {
+                        const int64_t xs = v[idx0].x, xe = v[idx].x;
+                        edge[i].ye = ty;
+                        edge[i].dx = ((xe - xs) * 2 + (ty - y)) / (2 * (ty - y));
+                        edge[i].x = xs;
+                        edge[i].idx = idx;
+                        break;
+                    }
+                    idx0 = idx;
+                    idx += di;
+                    if (idx >= npts) idx -= npts;
+                }
+            }
+        }
+        if (edges < 0) break;
+        if (y >= 0) {
+            int left = 0, right = 1;
+            if (edge[0].x > edge[1].x) { left = 1; right = 0; }
+            int xx1 = (int)((edge[left].x + delta1) >> VKO_XY_SHIFT);
+            int xx2 = (int)((edge[right].x + delta2) >> VKO_XY_SHIFT);
+            if (xx2 >= 0 && xx1 < w) {
+                if (xx1 < 0) xx1 = 0;
+                if (xx2 >= w) xx2 = w - 1;
+                vko_hline(img, w, y, xx1, xx2);
+            }
+        }
+        edge[0].x += edge[0].dx;
+        edge[1].x += edge[1].dx;
+    } while (++y <= (int)ymax);
+}
+
+/* Circle(img, center, radius, color, fill = 1) */
+static void vko_circle_fill(uint8_t *img, int h, int w, int cx, int cy, int radius)
+{
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    while (dx >= dy) {
+        const int y11 = cy - dy, y12 = cy + dy, y21 = cy - dx, y22 = cy + dx;
+        int x11 = cx - dx, x12 = cx + dx, x21 = cx - dy, x22 = cx + dy;
+        /* the "inside" fast path writes the same pixels as the clipped one */
+        if (x11 < w && x12 >= 0 && y21 < h && y22 >= 0) {
+            if (x11 < 0) x11 = 0;
+            if (x12 > w - 1) x12 = w - 1;
+            if ((unsigned)y11 < (unsigned)h) vko_hline(img, w, y11, x11, x12);
+            if ((unsigned)y12 < (unsigned)h) vko_hline(img, w, y12, x11, x12);
+            if (x21 < w && x22 >= 0) {
+                if (x21 < 0) x21 = 0;
+                if (x22 > w - 1) x22 = w - 1;
+                if ((unsigned)y21 < (unsigned)h) vko_hline(img, w, y21, x21, x22);
+                if ((unsigned)y22 < (unsigned)h) vko_hline(img, w, y22, x21, x22);
+            }
+        }
+        dy++;
+        err += plus;
+        plus += 2;
+        const int mask = (err <= 0) - 1;
+        err -= minus & mask;
+        dx += mask;
+        minus -= mask & 2;
+    }
+}
+
+/* ThickLine(img, p0, p1, color, thickness, LINE_8, flags, shift = XY_SHIFT) */
+static void vko_thick_line(uint8_t *img, int h, int w, vko_pt2l p0, vko_pt2l p1, int thickness, int flags)
+{
+    if (thickness <= 1) {
+        vko_line2(img, h, w, p0, p1);
+        return;
+    }
+    const double inv_xy_one = 1.0 / VKO_XY_ONE;
+    vko_pt2l pt[4], dp = {0, 0};
+    const double dx = (double)(p0.x - p1.x) * inv_xy_one, dy = (double)(p1.y - p0.y) * inv_xy_one;
+    double r = dx * dx + dy * dy;
+    const int odd = thickness & 1;
+    thickness <<= VKO_XY_SHIFT - 1;
+    if (fabs(r) > DBL_EPSILON) {
+        r = ((double)thickness + (double)(odd * VKO_XY_ONE) * 0.5) / sqrt(r);
+        dp.x = cv_round_d(dy * r);
+        dp.y = cv_round_d(dx * r);
+        pt[0].x = p0.x + dp.x; pt[0].y = p0.y + dp.y;
+        pt[1].x = p0.x - dp.x; pt[1].y = p0.y - dp.y;
+        pt[2].x = p1.x - dp.x; pt[2].y = p1.y - dp.y;
+        pt[3].x = p1.x + dp.x; pt[3].y = p1.y + dp.y;
+        vko_fill_convex_poly16(img, h, w, pt, 4);
+    }
+    for (int i = 0; i < 2; i++) {
+        if (flags & (i + 1)) {
+            const int cx = (int)((p0.x + (VKO_XY_ONE >> 1)) >> VKO_XY_SHIFT);
+            const int cy = (int)((p0.y + (VKO_XY_ONE >> 1)) >> VKO_XY_SHIFT);
+            vko_circle_fill(img, h, w, cx, cy, (thickness + (VKO_XY_ONE >> 1)) >> VKO_XY_SHIFT);
+        }
+        p0 = p1;
+    }
+}
+
+/* The 16.16 outline vertices of one ellipse (EllipseEx's `v`): returns their number (<= 74) */
+VKO_API int vko_ellipse_vertices(int cx, int cy, int ax, int ay, int64_t *xy /* [74][2] */)
+{
+    vko_init_sin_tab();
+    const int64_t cxs = (int64_t)cx * VKO_XY_ONE, cys = (int64_t)cy * VKO_XY_ONE;
+    int64_t aw = (int64_t)ax * VKO_XY_ONE, ah = (int64_t)ay * VKO_XY_ONE;
+    if (aw < 0) aw = -aw;
+    if (ah < 0) ah = -ah;
+    int delta = (int)(((aw > ah ? aw : ah) + (VKO_XY_ONE >> 1)) >> VKO_XY_SHIFT);
+    delta = delta < 3 ? 90 : delta < 10 ? 30 : delta < 15 ? 18 : 5;
+    const float alpha = vko_sin_tab[450], beta = vko_sin_tab[0];     /* sincos(angle = 0) */
+    int n = 0;
+    int64_t prev_x = -1, prev_y = -1;      /* Point2l(0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF) */
+    int npoly = 0;
+    double first_x = 0, first_y = 0;
+    for (int i = 0; i < 360 + delta; i += delta) {
+        int angle = i > 360 ? 360 : i;
+        const double x = (double)aw * vko_sin_tab[450 - angle], y = (double)ah * vko_sin_tab[angle];
+        const double px = (double)cxs + x * alpha - y * beta, py = (double)cys + x * beta + y * alpha;
+        if (npoly == 0) { first_x = px; first_y = py; }
+        npoly++;
+        int64_t qx = (int64_t)cv_round_d(px / VKO_XY_ONE) * VKO_XY_ONE;
+        int64_t qy = (int64_t)cv_round_d(py / VKO_XY_ONE) * VKO_XY_ONE;
+        qx += cv_round_d(px - (double)qx);
+        qy += cv_round_d(py - (double)qy);
+        if (qx != prev_x || qy != prev_y) {
+            xy[2 * n] = qx; xy[2 * n + 1] = qy;
+            n++;
+            prev_x = qx; prev_y = qy;
+        }
+    }
+    (void)first_x; (void)first_y;
+    if (n == 1) {          /* a zero-size polygon: two copies of the centre */
+        xy[0] = xy[2] = cxs; xy[1] = xy[3] = cys;
+        n = 2;
+    }
+    return n;
+}
+
+VKO_API int vko_ellipse_outline(uint8_t *mask, int h, int w, int cx, int cy, int ax, int ay, int thickness)
+{
+    if (thickness < 1 || thickness > 32767) return -1;       /* cv.ellipse: 0 < thickness <= MAX_THICKNESS here */
+    int64_t xy[74 * 2];
+    const int n = vko_ellipse_vertices(cx, cy, ax, ay, xy);
+    int flags = 3;                                           /* PolyLine(is_closed = false): 2 + !is_closed */
+    for (int i = 1; i < n; i++) {
+        const vko_pt2l p0 = {xy[2 * i - 2], xy[2 * i - 1]}, p1 = {xy[2 * i], xy[2 * i + 1]};
+        vko_thick_line(mask, h, w, p0, p1, thickness, flags);
+        flags = 2;
+    }
     return 0;
 }

@@ -11,7 +11,7 @@ from vkit_amd.mechanism.distortion.photometric.opt import OutOfBoundBehavior
 GRID_BASED = ('similarity_mls', 'camera_plane_only', 'camera_cubic_curve', 'camera_plane_line_fold',
               'camera_plane_line_curve')
 AFFINE = ('shear_hori', 'shear_vert', 'rotate', 'skew_hori', 'skew_vert')
-IDENTITY = ('jpeg_quality', 'ellipse_streak')     # out of the accelerated path: the image passes through
+IDENTITY = ('jpeg_quality',)     # out of the accelerated path: the image passes through
 
 
 def gaussian_ksize(sigma):
@@ -64,6 +64,8 @@ PHOTOMETRIC = {
                                               c.enable_vert, c.enable_hori),
     'rectangle_streak': lambda m, c: O.rectangle_streak(m, c.thickness, c.aspect_ratio, c.dash_thickness, c.dash_gap,
                                                         c.short_side_min, c.short_side_step, c.color, c.alpha),
+    'ellipse_streak': lambda m, c: O.ellipse_streak(m, c.thickness, c.aspect_ratio, c.short_side_min, c.short_side_step,
+                                                    c.color, c.alpha),
 }
 REPLAYABLE = tuple(PHOTOMETRIC) + GRID_BASED + AFFINE + IDENTITY
 

@@ -224,16 +224,18 @@ def test_glass_shuffle_planes_match_reference(golden_dir):
 
 
 def test_out_of_path_policies_sample_like_the_reference_and_pass_through(golden_dir, monkeypatch, caplog):
-    """jpeg_quality / ellipse_streak: the config is drawn like the reference's (the rng stream stays aligned), the image
-    passes through unchanged with one logged warning; VKX_STRICT_UNSUPPORTED=1 raises instead."""
+    """jpeg_quality: the config is drawn like the reference's (the rng stream stays aligned), the image passes through
+    unchanged with one logged warning; VKX_STRICT_UNSUPPORTED=1 raises instead."""
     import logging
     from vkit_amd.mechanism.distortion.photometric import opt as photo_opt
+    from vkit_amd.mechanism.distortion.photometric.opt import OUT_OF_PATH_OPERATORS
+    assert OUT_OF_PATH_OPERATORS == ('jpeg_quality',)
     with open(os.path.join(golden_dir, 'policy_configs.json')) as f:
-        records = [r for r in json.load(f) if r['name'] in ('jpeg_quality', 'ellipse_streak')]
-    assert {r['name'] for r in records} == {'jpeg_quality', 'ellipse_streak'}
+        records = [r for r in json.load(f) if r['name'] in OUT_OF_PATH_OPERATORS]
+    assert {r['name'] for r in records} == set(OUT_OF_PATH_OPERATORS)
     rd = random_distortion_factory.create(None)
     image = Image(mat=default_rng(0).integers(0, 256, (96, 80, 3), dtype=np.uint8))
-    for name in ('jpeg_quality', 'ellipse_streak'):
+    for name in OUT_OF_PATH_OPERATORS:
         policy = [p for p in rd.stages[0].config.distortion_policies if p.name == name][0]
         rec = [r for r in records if r['name'] == name and r['level'] == 5 and r['seed'] == 1 and r['shape'] == [96, 80]][0]
         rng = default_rng(1)

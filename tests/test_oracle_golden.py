@@ -511,3 +511,55 @@ def test_throughput_noise_definition():
     assert (plane != O.noise_normal_i16((257, 301, 3), 10.0, 0x1234567890abcdee)).mean() > 0.9
     # the plane is a flat sample sequence: its shape only folds it
     assert (O.noise_normal_i16((257, 301, 3), 10.0, 7).ravel() == O.noise_normal_i16((257 * 301 * 3, 1, 1), 10.0, 7).ravel()).all()
+
+
+def test_ellipse_outline_restatement():
+    """[cv2] cv.ellipse restatement (parity unpinned: no cv2 here).  What can be pinned without cv2: a known answer derived
+    by hand from Line2's 16.16 DDA for the four-segment polygon of axes (2, 1), and the properties any outline has -- the
+    pixels hug the ellipse, the curve is closed (a flood from outside never reaches the centre), thickness only adds
+    pixels, clipping equals drawing on a larger plane and cropping but for a few pixels at the cut."""
+    m = np.zeros((9, 11), np.uint8)
+    O.ellipse_outline(m, (5, 4), (2, 1), 1)
+    want = {(0, 1), (1, 1), (2, 0), (-2, 0), (-1, 0), (0, -1), (1, -1)}      # (dx, dy) around the centre
+    assert {(int(x) - 5, int(y) - 4) for y, x in zip(*np.nonzero(m))} == want
+    verts = O.ellipse_vertices((100, 80), (60, 30))
+    assert len(verts) == 73 and (verts[0] == verts[-1]).all()                # 5-degree steps, closed at 360
+    assert (verts[0] == [(100 + 60) << 16, 80 << 16]).all() and (verts[18] == [100 << 16, (80 + 30) << 16]).all()
+    assert len(O.ellipse_vertices((10, 10), (2, 2))) == 5 and len(O.ellipse_vertices((10, 10), (12, 3))) == 21
+    assert (O.ellipse_vertices((7, 9), (0, 0)) == [[7 << 16, 9 << 16]] * 2).all()
+
+    yy, xx = np.mgrid[0:160, 0:200]
+    for a, b in ((60, 30), (25, 70), (90, 75)):
+        prev = None
+        for t in (1, 2, 3, 5):
+            m = np.zeros((160, 200), np.uint8)
+            O.ellipse_outline(m, (100, 80), (a, b), t)
+            assert set(np.unique(m)) == {0, 1}
+            # distance from the ellipse, first order: |f - 1| / |grad f| with f = (x/a)^2 + (y/b)^2
+            fx, fy = (xx - 100) / a, (yy - 80) / b
+            f = fx * fx + fy * fy
+            grad = 2 * np.sqrt((fx / a) ** 2 + (fy / b) ** 2) + 1e-12
+            dist = np.abs(f - 1) / grad
+            assert dist[m > 0].max() <= t / 2 + 1.6, (a, b, t, dist[m > 0].max())
+            # closed: flood the background from the corner; the centre stays dry
+            reach = np.zeros_like(m, bool)
+            stack = [(0, 0)]
+            while stack:
+                y, x = stack.pop()
+                if 0 <= y < 160 and 0 <= x < 200 and not reach[y, x] and not m[y, x]:
+                    reach[y, x] = True
+                    stack += [(y + 1, x), (y - 1, x), (y, x + 1), (y, x - 1)]
+            assert not reach[80, 100]
+            if prev is not None and t != 2:
+                assert (m >= prev).all()
+            prev = m if t != 1 else None
+            # clipping: the same ellipse on a plane shifted by (37, 41) and cut
+            big = np.zeros((160, 200), np.uint8)
+            O.ellipse_outline(big, (100 - 41, 80 - 37), (a, b), t)
+            diff = big[:160 - 37, :200 - 41] != m[37:, 41:]
+            # (clipLine moves the end points of cut segments: a few pixels next to the cut may differ, nothing else)
+            assert not diff[4:, 4:].any() and diff.sum() <= 4, (a, b, t)
+    img = default_rng(0).integers(0, 256, (120, 90, 3), dtype=np.uint8)
+    out = O.ellipse_streak(img, thickness=2, alpha=1.0, color=(1, 2, 3))
+    changed = (out != img).any(axis=2)
+    assert changed.any() and (out[changed] == (1, 2, 3)).all()

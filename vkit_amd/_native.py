@@ -194,6 +194,8 @@ for _sfx in ('', '_dev'):
     _SIGNATURES['vkx_paint_polys' + _sfx] = [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_ssize, c_void_p,
                                              c_ssize, c_int, c_int]
     _SIGNATURES['vkx_fill_poly_mask_u8' + _sfx] = [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_ssize]
+    _SIGNATURES['vkx_ellipse_mask_u8' + _sfx] = [c_void_p, c_void_p, c_ssize, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int]
+    _SIGNATURES['vkx_ellipse_streak_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_double]
 
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['vkx_version', 'vkx_last_error', 'vkx_ctx_stream'])
 
@@ -911,6 +913,33 @@ def line_streak(img, thickness, gap, dash_thickness, dash_gap, color, alpha, ena
     col[:cn] = np.asarray(color, dtype=np.uint8).reshape(-1)[:cn]
     check(lib().vkx_line_streak_u8(ctx.handle, _ptr(out), h, w, cn, stride, int(thickness), int(gap), int(dash_thickness),
                                    int(dash_gap), _ptr(col), float(alpha), int(bool(enable_vert)), int(bool(enable_hori))))
+    return out
+
+
+def ellipse_mask(mask, center, axes, thickness, ctx=None):
+    """Draws cv.ellipse(mask, center=(x, y), axes=(a, b), 0, 0, 360, 1, thickness) for every row of ``axes`` onto the
+    writable uint8 plane ``mask`` (in place)."""
+    ctx = ctx or default_ctx()
+    if mask.dtype != np.uint8 or mask.ndim != 2 or not mask.flags.c_contiguous or not mask.flags.writeable:
+        raise ValueError('mask must be a writable C-contiguous uint8 plane')
+    axes = np.ascontiguousarray(np.asarray(axes, dtype=np.int32).reshape(-1, 2))
+    h, w = mask.shape
+    check(lib().vkx_ellipse_mask_u8(ctx.handle, _ptr(mask), w, h, w, int(center[0]), int(center[1]), _ptr(axes),
+                                    int(axes.shape[0]), int(thickness)))
+    return mask
+
+
+def ellipse_streak(img, center, axes, thickness, color, alpha, ctx=None):
+    """ellipse_streak_image's raster and blend; returns a new array."""
+    ctx = ctx or default_ctx()
+    out = ctx.pinned_empty(np.shape(img), np.uint8)
+    np.copyto(out, img)
+    _, h, w, cn, stride = _u8_plane(out)
+    axes = np.ascontiguousarray(np.asarray(axes, dtype=np.int32).reshape(-1, 2))
+    col = np.zeros(4, np.uint8)
+    col[:cn] = np.asarray(color, dtype=np.uint8).reshape(-1)[:cn]
+    check(lib().vkx_ellipse_streak_u8(ctx.handle, _ptr(out), h, w, cn, stride, int(center[0]), int(center[1]), _ptr(axes),
+                                      int(axes.shape[0]), int(thickness), _ptr(col), float(alpha)))
     return out
 
 

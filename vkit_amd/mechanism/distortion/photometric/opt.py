@@ -26,12 +26,12 @@ def to_original_image(image: Image, mode: ImageMode):
     return image
 
 
-# Operators the reference has but whose pixel work lies outside this path (a JPEG codec round trip,
-# the cv.ellipse rasteriser).  They keep their name, config class and config generator, so that RandomDistortion's
+# Operators the reference has but whose pixel work lies outside this path (a JPEG codec round trip).
+# They keep their name, config class and config generator, so that RandomDistortion's
 # policy table, its sampling and the caller's rng stream stay the reference's draw for draw; the image passes through
 # unchanged and a warning is logged once per operator.  VKX_STRICT_UNSUPPORTED=1 turns the pass-through into a
 # NotImplementedError for callers that must not miss a stage silently.
-OUT_OF_PATH_OPERATORS = ('jpeg_quality', 'ellipse_streak')
+OUT_OF_PATH_OPERATORS = ('jpeg_quality',)
 _warned = set()
 
 

@@ -1,7 +1,8 @@
-"""Streak distortions (reference: photometric/streak.py): periodic line stripes and concentric rectangles
-alpha-blended onto the image -- vertical structures first, then horizontal ones, so crossings are blended
+"""Streak distortions (reference: photometric/streak.py): periodic line stripes, concentric rectangles and concentric
+ellipses alpha-blended onto the image -- vertical structures first, then horizontal ones, so crossings are blended
 twice.  ``line_streak`` evaluates its stripe masks analytically inside one HIP kernel; ``rectangle_streak``
-builds its two bar masks with index arithmetic on the host and blends them as two composite layers."""
+builds its two bar masks with index arithmetic on the host and blends them as two composite layers;
+``ellipse_streak`` rasterises the ``cv.ellipse`` outlines on the device and blends them as one layer."""
 from typing import List, Optional, Tuple
 
 import attrs
@@ -11,7 +12,6 @@ from numpy.random import Generator as RandomGenerator
 from vkit_amd import _native
 from vkit_amd.element import Box, Image
 from ..interface import Distortion, DistortionConfig, DistortionNopState
-from .opt import pass_through_out_of_path
 
 
 @attrs.define
@@ -146,10 +146,23 @@ class EllipseStreakConfig(DistortionConfig):
 
 
 def ellipse_streak_image(config: EllipseStreakConfig, state, image: Image, rng: Optional[RandomGenerator]):
-    """reference photometric/streak.py:283-337: concentric ``cv.ellipse`` outlines blended like the other streaks.  The
-    polygonal-arc + thick-polyline rasteriser of cv.ellipse is outside the path; see ``pass_through_out_of_path``."""
+    """reference photometric/streak.py:296-330: one ``cv.ellipse`` outline per concentric box (axes = half the box sides,
+    centre = the image centre), blended like the other streaks.  Raster and blend run on the device in one call
+    (csrc/ellipse.hip)."""
     _check_color(image, config.color)
-    return pass_through_out_of_path('ellipse_streak', image)
+    if not isinstance(config.alpha, float):
+        raise AttributeError('alpha must be a float')
+    if config.alpha < 0.0 or config.alpha > 1.0:
+        raise RuntimeError(f'alpha={config.alpha} is invalid.')
+    aspect_ratio = config.aspect_ratio
+    if aspect_ratio is None:
+        aspect_ratio = image.width / image.height
+    boxes = generate_centered_boxes(image.height, image.width, aspect_ratio, config.short_side_min,
+                                    config.short_side_step)
+    axes = [(box.width // 2, box.height // 2) for box in boxes]
+    mat = _native.ellipse_streak(image.mat, (image.width // 2, image.height // 2), axes, config.thickness,
+                                 config.color, config.alpha)
+    return attrs.evolve(image, mat=mat)
 
 
 ellipse_streak = Distortion(

@@ -3,8 +3,8 @@ distortion_policy/random_distortion.py).
 
 Stage 0 draws 0..2 photometric policies, stage 1 (prob 0.75) exactly one geometric policy, optionally followed
 by a forced rotate stage.  The policy TABLE (names, order, weights) is the reference's, so that a given rng
-state selects the same policies.  Two members (``UNSUPPORTED_POLICY_NAMES``) sample their configs like the
-reference but leave the image unchanged: their pixel work is outside the accelerated path.
+state selects the same policies.  One member (``UNSUPPORTED_POLICY_NAMES``: ``jpeg_quality``) samples its config like the
+reference but leaves the image unchanged: its pixel work is outside the accelerated path.
 """
 import logging
 from collections import defaultdict
@@ -29,7 +29,6 @@ logger = logging.getLogger(__name__)
 # table, the sampling and the rng stream are the reference's whether or not they are listed in disabled_policy_names.
 UNSUPPORTED_POLICY_NAMES = (
     'jpeg_quality',
-    'ellipse_streak',
 )
 
 
