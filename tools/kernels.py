@@ -14,7 +14,7 @@ from vkit_amd import _native as N
 ctx = N.Context(0)
 lib = N.lib()
 rng = np.random.default_rng(0)
-H = W = 2048
+H = W = int(sys.argv[1]) if len(sys.argv) > 1 else 2048     # 8192: 201 MB per plane, past the 256 MiB Infinity Cache
 S = H * W
 img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
 
@@ -54,8 +54,8 @@ cases = [
     ('k_histogram', lambda: lib.vkx_histogram_u8_dev(ctx.handle, d_img, H, W, 3, W * 3, d_hist), 3 * S),
     ('k_apply_lut', lambda: lib.vkx_apply_lut_u8_dev(ctx.handle, d_img, H, W, 3, W * 3, lut.ctypes.data, 0, d_out, W * 3), 6 * S),
     ('k_gather', lambda: lib.vkx_gather_u8_dev(ctx.handle, d_img, H, W, 3, W * 3, d_py, d_px, W, d_out, H, W, W * 3), 6 * S + 8 * S),
-    ('k_resize_cubic (x1.05)', lambda: lib.vkx_resize_cubic_u8_dev(ctx.handle, d_img, H, W, 3, W * 3, d_out, 2150, 2150, 2150 * 3), 3 * S + 3 * 2150 * 2150),
-    ('k_resize_linear (x0.37)', lambda: lib.vkx_resize_u8_dev(ctx.handle, d_img, H, W, 3, W * 3, d_out, 758, 758, 758 * 3, 1), 3 * S + 3 * 758 * 758),
+    ('k_resize_cubic (x1.05)', lambda: lib.vkx_resize_cubic_u8_dev(ctx.handle, d_img, H, W, 3, W * 3, d_out, H * 21 // 20, W * 21 // 20, W * 21 // 20 * 3), 3 * S + 3 * (H * 21 // 20) * (W * 21 // 20)),
+    ('k_resize_linear (x0.37)', lambda: lib.vkx_resize_u8_dev(ctx.handle, d_img, H, W, 3, W * 3, d_out, H * 37 // 100, W * 37 // 100, W * 37 // 100 * 3, 1), 3 * S + 3 * (H * 37 // 100) * (W * 37 // 100)),
 ]
 rows = []
 for name, fn, nbytes in cases:
