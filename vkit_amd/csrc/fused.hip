@@ -8,13 +8,15 @@
 //                      (((64 - 2R) & ~3)^2 pixels, R = blur radius) plus its halo:
 //      A  the tile's candidate cells are pulled into LDS and rasterised into an LDS ownership plane with
 //         ds_max ("the later cell in row-major order wins", grid_rendering/type.py:222-256);
-//      C  per window row: inv_H * (x, y, 1) in double (the FMA chain of the reference's dgemm), 1/32-px
-//         quantisation, bilinear gather straight from HBM/L2 with two unaligned 8-byte loads per pixel;
+//      C  per window-row pair: inv_H * (x, y, 1) in double (the FMA chain of the reference's dgemm), both quotients
+//         through one refined reciprocal whose float32 rounding is proven per wavefront (exact IEEE division
+//         otherwise), 1/32-px quantisation, bilinear gather straight from HBM/L2 with two unaligned 8-byte loads per
+//         pixel, v_dot4_u32_u8 horizontal pairs;
 //      D  horizontal 8.8 fixed-point Gaussian pass with wavefront shuffles (the remapped pixel never leaves
-//         its register), result to LDS in place of the ownership tags;
-//      E  vertical pass out of LDS (lane stride 1, conflict free), RGB -> HSV_FULL -> hue shift -> RGB,
-//         + int16 noise, clip, optional line_streak blends; neighbouring lanes pack 4 pixels into 3 dwords with one
-//         shuffle and store.
+//         its register), results to LDS in place of the ownership tags as (row | next row << 16) planes per channel;
+//      E  vertical pass out of LDS as v_dot2_u32_u16 (two taps per instruction), RGB -> HSV_FULL -> hue shift -> RGB
+//         (one byte permute per pixel selects the sector's channels), + int16 noise, clip, optional line_streak
+//         blends; neighbouring lanes pack 4 pixels into 3 dwords with one shuffle and store.
 //      Variants of the tile body (template KIND): interior windows (border logic compiled out), empty tiles (no cell
 //      reaches the window: constant colour), and the element mode of k_tile_remap.
 //   k_tile_remap       the same tile machinery for vkx_grid_remap: 1-4 elements of any supported type (uint8 x 1 / 3 / 4
