@@ -410,7 +410,9 @@ int vkx_grid_project_points(vkx_ctx *ctx, const int32_t *src_vertices, const int
  *   src_handles_smooth / dst_handles_smooth  float64 [n_handles, 2]: a vertex exactly on a source handle maps to that
  *                                            handle's target (mls.py:57-61; the last duplicate wins like the dict)
  *   vertices_xy, out_xy                      float64 [n_vertices, 2]
- * n_handles <= 128.  VKX_ERR_DIVIDE where the reference's np.errstate(divide='raise') fires (a vertex on an integer
+ * Any number of handles (tables beyond 2048 handles are read through the caches instead of LDS).  Note that the reference's
+ * own result depends on the BLAS kernels of its host for the weighted centroids (sgemv): this entry point follows numpy 2.2 +
+ * OpenBLAS 0.3.29 on an AVX-512 host, the machine tests/golden was generated on.  VKX_ERR_DIVIDE where the reference's np.errstate(divide='raise') fires (a vertex on an integer
  * handle position that is not an exact handle hit).  _dev: device pointers, `status` int32 (zeroed by the caller)
  * receives 1 + the index of such a vertex. */
 int vkx_mls_project_dev(vkx_ctx *ctx, const float *src_handles, const float *dst_handles,

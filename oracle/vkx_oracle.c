@@ -1990,10 +1990,17 @@ static float vko_mls_weight(const float *p, int i, float vx, float vy)
 
 static float vko_pairwise_sum_f32(const float *a, int n)
 {
+    /* numpy's pairwise_sum (loops_utils.h.src): < 8 sequential, up to the 128-element block eight running sums, beyond it
+     * the halves (the first a multiple of 8) summed recursively */
     if (n < 8) {
         float res = a[0];
         for (int i = 1; i < n; i++) res = res + a[i];
         return res;
+    }
+    if (n > 128) {
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        return vko_pairwise_sum_f32(a, n2) + vko_pairwise_sum_f32(a + n2, n - n2);
     }
     float r[8];
     for (int j = 0; j < 8; j++) r[j] = a[j];
@@ -2008,8 +2015,9 @@ static float vko_pairwise_sum_f32(const float *a, int n)
 VKO_API int vko_mls_project(const float *p, const float *q, const double *ps, const double *qs, int n,
                             const double *vertices, int n_vertices, double *out)
 {
-    if (n < 1 || n > 128) return -1;
-    float w[128], t[128];
+    if (n < 1) return -1;
+    float *w = (float *)malloc(sizeof(float) * 2 * (size_t)n), *t = w + n;
+    if (!w) return -1;
     for (int v = 0; v < n_vertices; v++) {
         const double vxd = vertices[2 * v], vyd = vertices[2 * v + 1];
         int hit = -1;
@@ -2019,20 +2027,32 @@ VKO_API int vko_mls_project(const float *p, const float *q, const double *ps, co
         const float vx = (float)vxd, vy = (float)vyd;
         for (int i = 0; i < n; i++) {
             const float dx = p[2 * i] - vx, dy = p[2 * i + 1] - vy;
-            if (dx * dx + dy * dy == 0.f) return v + 1;
+            if (dx * dx + dy * dy == 0.f) { free(w); return v + 1; }
             w[i] = vko_mls_weight(p, i, vx, vy);                        /* mls.py:64-74 */
         }
         const float sw = vko_pairwise_sum_f32(w, n);
         float psx, psy, qsx, qsy;
-        if (n == 4) {
-            const float w0 = w[0] / sw, w1 = w[1] / sw, w2 = w[2] / sw, w3 = w[3] / sw;
-            psx = fmaf(w0, p[0], w1 * p[2]) + fmaf(w2, p[4], w3 * p[6]);
-            psy = fmaf(w0, p[1], w1 * p[3]) + fmaf(w2, p[5], w3 * p[7]);
-            qsx = fmaf(w0, q[0], w1 * q[2]) + fmaf(w2, q[4], w3 * q[6]);
-            qsy = fmaf(w0, q[1], w1 * q[3]) + fmaf(w2, q[5], w3 * q[7]);
-        } else {
-            psx = psy = qsx = qsy = 0.f;
-            for (int i = 0; i < n; i++) {                               /* mls.py:77-78 */
+        /* mls.py:77-78  w_norm (N,) @ p (N, 2): cblas_sgemv on a 2 x N column-major matrix.  OpenBLAS 0.3.29 as numpy 2.2.6
+         * ships it, on an AVX-512 host (the machine the goldens were generated on): 5 <= N <= 48 goes to the SkylakeX
+         * small-matrix kernel, one fused multiply-add per handle in order; every other N to the generic two-row tail of
+         * sgemv_n_4.c, which takes the handles four at a time as
+         *   temp += fma(w0, p0, w1 p1);  temp += fma(w2, p2, w3 p3);
+         * and the rest one fused multiply-add each.  (A host whose OpenBLAS picks other kernels -- no AVX-512 -- rounds the
+         * reference's own lattice differently for 5 <= N <= 48: the reference is machine dependent here.) */
+        psx = psy = qsx = qsy = 0.f;
+        {
+            int i = 0;
+            if (n < 5 || n > 48) {
+                for (; i + 4 <= n; i += 4) {
+                    for (int h = 0; h < 4; h += 2) {
+                        const float wa = w[i + h] / sw, wb = w[i + h + 1] / sw;
+                        const float *pa = p + 2 * (i + h), *pb = pa + 2, *qa = q + 2 * (i + h), *qb = qa + 2;
+                        psx = psx + fmaf(wa, pa[0], wb * pb[0]); psy = psy + fmaf(wa, pa[1], wb * pb[1]);
+                        qsx = qsx + fmaf(wa, qa[0], wb * qb[0]); qsy = qsy + fmaf(wa, qa[1], wb * qb[1]);
+                    }
+                }
+            }
+            for (; i < n; i++) {
                 const float wn = w[i] / sw;
                 psx = fmaf(wn, p[2 * i], psx); psy = fmaf(wn, p[2 * i + 1], psy);
                 qsx = fmaf(wn, q[2 * i], qsx); qsy = fmaf(wn, q[2 * i + 1], qsy);
@@ -2054,6 +2074,7 @@ VKO_API int vko_mls_project(const float *p, const float *q, const double *ps, co
         out[2 * v] = (double)(sx / mu + qsx);                           /* mls.py:131 */
         out[2 * v + 1] = (double)(sy / mu + qsy);
     }
+    free(w);
     return 0;
 }
 

@@ -94,14 +94,37 @@ def test_mls_lattices_on_device_match_reference(N, golden_dir):
     assert checked == 12
 
 
+def test_mls_states_of_elongated_pages(N, monkeypatch):
+    """Elongated pages give the policy's handle lattice far more than 128 handles (a randomised soak found this shape
+    class): the state built with the device projection equals the one built vertex by vertex with the numpy statement."""
+    from vkit_amd.mechanism import distortion as D
+    from vkit_amd.mechanism.distortion_policy.geometric import mls as P_mls
+    seen = []
+    for shape, seed in (((64, 900), 0), ((900, 64), 1), ((47, 1500), 2), ((300, 310), 3)):
+        gen = P_mls.SimilarityMlsConfigGenerator(P_mls.SimilarityMlsConfigGeneratorConfig(), 5)
+        cfg = gen(shape, default_rng(seed))
+        seen.append(len(cfg.src_handle_points))
+        monkeypatch.delenv('VKX_MLS_HOST_PROJECTION', raising=False)
+        dev = D.similarity_mls.generate_state(cfg, shape)
+        monkeypatch.setenv('VKX_MLS_HOST_PROJECTION', '1')
+        host = D.similarity_mls.generate_state(cfg, shape)
+        monkeypatch.delenv('VKX_MLS_HOST_PROJECTION', raising=False)
+        assert dev.result_shape == host.result_shape, shape
+        assert (dev.dst_image_grid.vertices == host.dst_image_grid.vertices).all(), shape
+        assert (dev.dst_image_grid.smooth == host.dst_image_grid.smooth).all(), shape
+    assert max(seen) > 128 and min(seen) <= 48, seen
+
+
 def test_mls_project_kernel_matches_oracle(N):
-    """Handle counts around numpy's reduction special cases, exact handle hits, the divide-by-zero error."""
+    """Handle counts around numpy's reduction special cases (pairwise blocks of 8 and 128) and OpenBLAS's sgemv kernel switch
+    (5..48 handles), tables in LDS and beyond it, exact handle hits, the divide-by-zero error."""
     rng = default_rng(21)
-    for n in (2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 24, 25, 31, 40, 128):
+    for n in (2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 24, 25, 31, 40, 48, 49, 50, 52, 127, 128, 129, 136, 150, 255, 256, 257, 300, 517, 1030, 2048,
+              2049, 2500):
         ps = rng.integers(0, 3000, (n, 2)).astype(np.float64) + 0.25 * (np.arange(n) % 3)[:, None]
         qs = ps + rng.normal(0, 25, (n, 2))
         p, q = np.rint(ps).astype(np.float32), np.rint(qs).astype(np.float32)
-        V = rng.integers(0, 3000, (5000, 2)).astype(np.float64) + 0.5
+        V = rng.integers(0, 3000, (5000 if n <= 300 else 300, 2)).astype(np.float64) + 0.5
         V[7] = ps[n - 1]
         got = N.mls_project(p, q, ps, qs, V)
         want = O.mls_project(p, q, ps, qs, V)
@@ -110,8 +133,6 @@ def test_mls_project_kernel_matches_oracle(N):
     on_integer = np.array([[float(p[1, 0]), float(p[1, 1])]])       # handle 1 sits at x + 0.25: no exact hit
     with pytest.raises(FloatingPointError):
         N.mls_project(p, q, ps, qs, on_integer)
-    with pytest.raises(N.VkxError):
-        N.mls_project(np.zeros((129, 2), np.float32), np.zeros((129, 2), np.float32), np.zeros((129, 2)), np.zeros((129, 2)), V)
 
 
 # ---------------------------------------------------------------------------------------------- C2 / C5

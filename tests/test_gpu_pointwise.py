@@ -454,3 +454,108 @@ def test_throughput_noise_plane_matches_its_definition():
     assert (N.noise_normal_table(7.5) == O.noise_normal_table(7.5)).all()
     with pytest.raises(N.VkxError):
         N.noise_normal_i16((4, 4, 3), 0.0, 1)
+
+
+def test_dense_and_pitched_planes_agree():
+    """The element-wise and RGB pixel kernels have two bodies: 16 bytes (4 pixels) per lane on dense, aligned planes, one
+    byte (pixel) per lane on any pitch.  Both must produce the oracle's bytes: every entry point is run on a dense plane, on
+    a padded one (odd pitch: unaligned rows) and, where the operator allows it, in place."""
+    import ctypes
+    from vkit_amd import _native as N
+    ctx, lib = N.default_ctx(), N.lib()
+    rng = default_rng(77)
+
+    def run(call, src, cn, pitch_pad, extra=None, inplace=False):
+        """call(src_ptr, src_pitch, dst_ptr, dst_pitch, extra_ptr, extra_pitch_el) on device copies; returns the result"""
+        h, w = src.shape[:2]
+        row = w * cn
+        pitch = row + pitch_pad
+        host = np.zeros((h, pitch), np.uint8)
+        host[:, :row] = src.reshape(h, row)
+        d_src, d_dst = ctx.malloc(host.nbytes + 64), ctx.malloc(host.nbytes + 64)
+        ctx.upload(d_src, host)
+        ctx.upload(d_dst, np.full((h, pitch), 0xA5, np.uint8))
+        d_extra, extra_pitch = 0, 0
+        if extra is not None:
+            per = extra.size // h
+            extra_pitch = per + (pitch_pad if pitch_pad else 0)
+            e = np.zeros((h, extra_pitch), extra.dtype)
+            e[:, :per] = extra.reshape(h, per)
+            d_extra = ctx.malloc(e.nbytes + 64)
+            ctx.upload(d_extra, e)
+        N.check(call(d_src, pitch, d_src if inplace else d_dst, pitch, d_extra, extra_pitch))
+        out = np.zeros((h, pitch), np.uint8)
+        ctx.download(d_src if inplace else d_dst, out)
+        ctx.sync()
+        for p in (d_src, d_dst, d_extra):
+            if p:
+                ctx.free(p)
+        if not inplace:
+            assert (out[:, row:] == 0xA5).all()          # nothing written into the padding
+        return out[:, :row].reshape(src.shape)
+
+    for (h, w) in ((37, 53), (64, 64), (1, 7), (5, 1), (130, 257)):
+        rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        gray = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        rgba = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        noise = rng.integers(-300, 300, (h, w, 3)).astype(np.int16)
+        noise[0, 0] = (32767, -32768, 255)
+        sel = rng.integers(0, 3, (h, w)).astype(np.uint8)
+        cases = []
+        for delta in (37, -200, 0):
+            cases.append((f'color_shift {delta}', rgb, 3, None, O.color_shift_rgb(rgb, delta), True,
+                          lambda s, sp, d, dp, e, ep, delta=delta: lib.vkx_color_shift_rgb_dev(ctx.handle, s, h, w, sp, delta, d, dp)))
+        cases.append(('rgb2hsv', rgb, 3, None, None, True,
+                      lambda s, sp, d, dp, e, ep: lib.vkx_cvt_rgb_hsv_u8_dev(ctx.handle, s, h, w, sp, 1, d, dp)))
+        cases.append(('hsv2rgb', rgb, 3, None, None, True,
+                      lambda s, sp, d, dp, e, ep: lib.vkx_cvt_rgb_hsv_u8_dev(ctx.handle, s, h, w, sp, 0, d, dp)))
+        cases.append(('brightness', rgb, 3, None, O.brightness_shift_rgb(rgb, 20), True,
+                      lambda s, sp, d, dp, e, ep: lib.vkx_brightness_shift_rgb_dev(ctx.handle, s, h, w, sp, 20, d, dp)))
+        cases.append(('color_balance', rgb, 3, None, O.color_balance_rgb(rgb, 0.4), True,
+                      lambda s, sp, d, dp, e, ep: lib.vkx_color_balance_rgb_dev(ctx.handle, s, h, w, sp, ctypes.c_double(0.4), d, dp)))
+        for mat, cn in ((rgb, 3), (gray, 1), (rgba, 4)):
+            cases.append((f'mean_shift cn{cn}', mat, cn, None, None, True,
+                          lambda s, sp, d, dp, e, ep, cn=cn: lib.vkx_mean_shift_u8_dev(ctx.handle, s, h, w, cn, sp, 40, 1, 128, 0, 0b101, d, dp)))
+            cases.append((f'mean_shift cycle cn{cn}', mat, cn, None, None, True,
+                          lambda s, sp, d, dp, e, ep, cn=cn: lib.vkx_mean_shift_u8_dev(ctx.handle, s, h, w, cn, sp, -77, 0, 0, 1, 0, d, dp)))
+            cases.append((f'complement cn{cn}', mat, cn, None, None, True,
+                          lambda s, sp, d, dp, e, ep, cn=cn: lib.vkx_pointwise_u8_dev(ctx.handle, s, h, w, cn, sp, 0, 100, 1, 0b011, d, dp)))
+            cases.append((f'posterize cn{cn}', mat, cn, None, None, True,
+                          lambda s, sp, d, dp, e, ep, cn=cn: lib.vkx_pointwise_u8_dev(ctx.handle, s, h, w, cn, sp, 1, 5, 0, 0, d, dp)))
+            cases.append((f'impulse cn{cn}', mat, cn, sel, None, True,
+                          lambda s, sp, d, dp, e, ep, cn=cn: lib.vkx_impulse_noise_u8_dev(ctx.handle, s, h, w, cn, sp, e, ep, d, dp)))
+            lut = rng.integers(0, 256, (cn, 256), dtype=np.uint8)
+            cases.append((f'lut cn{cn}', mat, cn, None, None, True,
+                          lambda s, sp, d, dp, e, ep, cn=cn, lut=lut: lib.vkx_apply_lut_u8_dev(ctx.handle, s, h, w, cn, sp, lut.ctypes.data, 0b110, d, dp)))
+        cases.append(('add_noise', rgb, 3, noise, O.add_noise_i16(rgb, noise), True,
+                      lambda s, sp, d, dp, e, ep: lib.vkx_add_noise_i16_dev(ctx.handle, s, h, w, 3, sp, e, ep, d, dp)))
+        for name, mat, cn, extra, want, can_inplace, call in cases:
+            dense = run(call, mat, cn, 0, extra)
+            pitched = run(call, mat, cn, 5, extra)
+            np.testing.assert_array_equal(dense, pitched, err_msg=f'{name} {(h, w)}')
+            if want is not None:
+                np.testing.assert_array_equal(dense, want, err_msg=f'{name} {(h, w)} vs oracle')
+            if can_inplace:
+                np.testing.assert_array_equal(run(call, mat, cn, 0, extra, inplace=True), dense, err_msg=f'{name} in place')
+
+
+def test_histogram_dense_and_pitched():
+    from vkit_amd import _native as N
+    ctx, lib = N.default_ctx(), N.lib()
+    rng = default_rng(78)
+    for (h, w, cn) in ((37, 53, 3), (64, 64, 1), (1, 7, 4), (300, 517, 3), (2048, 2048, 3)):
+        mat = rng.integers(0, 256, (h, w, cn), dtype=np.uint8)
+        mat[: h // 2] //= 3                                           # crowded bins
+        want = np.stack([np.bincount(mat[:, :, c].ravel(), minlength=256) for c in range(cn)]).astype(np.int32)
+        for pad in (0, 3):
+            pitch = w * cn + pad
+            host = np.zeros((h, pitch), np.uint8)
+            host[:, :w * cn] = mat.reshape(h, -1)
+            d_src, d_hist = ctx.malloc(host.nbytes + 64), ctx.malloc(4 * 256 * 4)
+            ctx.upload(d_src, host)
+            N.check(lib.vkx_histogram_u8_dev(ctx.handle, d_src, h, w, cn, pitch, d_hist))
+            got = np.zeros((cn, 256), np.int32)
+            ctx.download(d_hist, got)
+            ctx.sync()
+            ctx.free(d_src); ctx.free(d_hist)
+            np.testing.assert_array_equal(got, want, err_msg=str((h, w, cn, pad)))

@@ -469,7 +469,7 @@ def test_mls_project_small_handle_counts_and_pins():
         from vkit_amd.mechanism.distortion.geometric.mls import SimilarityMlsPointProjector
         from vkit_amd.mechanism.distortion.geometric.grid_rendering.point_projector import PointProjector
         rng = default_rng(11)
-        for n in (2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 24, 25, 31, 40):
+        for n in (2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 24, 25, 31, 40, 127, 128, 129, 136, 150, 255, 256, 257, 300, 517, 1030):
             src = [(float(x) + 0.25 * (i % 3), float(y)) for i, (x, y) in enumerate(rng.integers(0, 300, (n, 2)))]
             dst = [(x + float(rng.normal(0, 9)), y + float(rng.normal(0, 9))) for x, y in src]
             sp = PointTuple(Point.create(y=y, x=x) for x, y in src)

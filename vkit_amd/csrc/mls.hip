@@ -6,8 +6,10 @@
 //   np.sum over a contiguous axis       numpy's pairwise sum: n < 8 sequential; otherwise 8 running sums over whole
 //                                       blocks of 8, ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the tail sequentially
 //   np.sum(.., axis=0) of an (N, 2)     row after row, sequential
-//   (N,) @ (N, 2)                       sgemv: acc = fma(w_i, p_i, acc) in handle order; exactly four handles:
-//                                       fma(w0, p0, w1 p1) + fma(w2, p2, w3 p3)
+//   (N,) @ (N, 2)                       sgemv on a 2 x N matrix.  5 <= N <= 48 (OpenBLAS's SkylakeX small-matrix kernel on the
+//                                       AVX-512 host the goldens come from): acc = fma(w_i, p_i, acc) in handle order;
+//                                       other N (the generic two-row tail of sgemv_n_4.c): handles four at a time as
+//                                       acc += fma(w0, p0, w1 p1); acc += fma(w2, p2, w3 p3), the rest one fma each
 //   (N, 2) @ (2, 2), (N,1,2) @ (N,2,2)  fma(a1, b1, a0 b0)
 // (established against numpy 2.2.6 + OpenBLAS 0.3.29 with the generator of tests/golden/make_golden.py; the lattices of
 // tests/golden/mls_states.npz pin it).  Compiled with -ffp-contract=off: fused operations appear only as fmaf().
@@ -15,7 +17,8 @@
 
 namespace {
 
-constexpr int kMaxHandles = 128;   // numpy's pairwise sum recurses beyond its 128-element block
+constexpr int kPairwiseBlock = 128;  // numpy's pairwise sum halves its range recursively beyond this many elements
+constexpr int kLdsHandles = 2048;    // handle tables up to this size are staged in LDS (16 bytes per handle)
 
 struct Handles {
     const float *p, *q;        // [n, 2] (x, y): integer handle positions as float32 (PointTuple.to_smooth_np_array)
@@ -33,33 +36,74 @@ __device__ __forceinline__ float weight(const float *p, int i, float vx, float v
 }
 
 template <typename F>
-__device__ __forceinline__ float pairwise_sum(int n, F term)
+__device__ __forceinline__ float pairwise_block(int lo, int n, F term)     // n <= kPairwiseBlock
 {
     if (n < 8) {
-        float res = term(0);
-        for (int i = 1; i < n; i++) res = res + term(i);
+        float res = term(lo);
+        for (int i = 1; i < n; i++) res = res + term(lo + i);
         return res;
     }
     float r[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) r[j] = term(j);
+    for (int j = 0; j < 8; j++) r[j] = term(lo + j);
     int i = 8;
     for (; i < n - (n % 8); i += 8) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) r[j] = r[j] + term(i + j);
+        for (int j = 0; j < 8; j++) r[j] = r[j] + term(lo + i + j);
     }
     float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    for (; i < n; i++) res = res + term(i);
+    for (; i < n; i++) res = res + term(lo + i);
+    return res;
+}
+
+template <typename F>
+__device__ __forceinline__ float pairwise_sum(int n, F term)
+{
+    if (n <= kPairwiseBlock) return pairwise_block(0, n, term);
+    // sum(a, n) = sum(a, n2) + sum(a + n2, n - n2) with n2 = n / 2 rounded down to a multiple of 8, as an explicit stack
+    // (depth 12 reaches 128 * 2^11 handles)
+    int lo_s[12], n_s[12], stage[12];
+    float left[12], res = 0.f;
+    int sp = 1;
+    lo_s[0] = 0; n_s[0] = n; stage[0] = 0;
+    while (sp > 0) {
+        const int k = sp - 1;
+        int n2 = n_s[k] / 2;
+        n2 -= n2 % 8;
+        if (stage[k] == 0) {
+            if (n_s[k] <= kPairwiseBlock || sp == 12) {
+                res = pairwise_block(lo_s[k], n_s[k], term);
+                sp--;
+            } else {
+                stage[k] = 1;
+                lo_s[sp] = lo_s[k]; n_s[sp] = n2; stage[sp] = 0;
+                sp++;
+            }
+        } else if (stage[k] == 1) {
+            left[k] = res;
+            stage[k] = 2;
+            lo_s[sp] = lo_s[k] + n2; n_s[sp] = n_s[k] - n2; stage[sp] = 0;
+            sp++;
+        } else {
+            res = left[k] + res;
+            sp--;
+        }
+    }
     return res;
 }
 
 __global__ void __launch_bounds__(64) k_mls_project(Handles hd, const double *__restrict__ vertices, int n_vertices,
                                                     double *__restrict__ out, int *__restrict__ bad)
 {
-    __shared__ float sp[2 * kMaxHandles], sq[2 * kMaxHandles];
+    extern __shared__ float staged[];              // [2 n] source handles, [2 n] targets when n <= kLdsHandles
     const int n = hd.n;
-    for (int i = threadIdx.x; i < 2 * n; i += 64) { sp[i] = hd.p[i]; sq[i] = hd.q[i]; }
-    __syncthreads();
+    const float *sp = hd.p, *sq = hd.q;
+    if (n <= kLdsHandles) {
+        for (int i = threadIdx.x; i < 2 * n; i += 64) { staged[i] = hd.p[i]; staged[2 * n + i] = hd.q[i]; }
+        __syncthreads();
+        sp = staged;
+        sq = staged + 2 * n;
+    }
     const int v = blockIdx.x * 64 + threadIdx.x;
     if (v >= n_vertices) return;
     const double vxd = vertices[2 * v], vyd = vertices[2 * v + 1];
@@ -83,15 +127,21 @@ __global__ void __launch_bounds__(64) k_mls_project(Handles hd, const double *__
     // weighted centroids p*, q*
     float psx, psy, qsx, qsy;
     auto wn = [&](int i) { return weight(sp, i, vx, vy, zero) / sw; };
-    if (n == 4) {
-        const float w0 = wn(0), w1 = wn(1), w2 = wn(2), w3 = wn(3);
-        psx = fmaf(w0, sp[0], w1 * sp[2]) + fmaf(w2, sp[4], w3 * sp[6]);
-        psy = fmaf(w0, sp[1], w1 * sp[3]) + fmaf(w2, sp[5], w3 * sp[7]);
-        qsx = fmaf(w0, sq[0], w1 * sq[2]) + fmaf(w2, sq[4], w3 * sq[6]);
-        qsy = fmaf(w0, sq[1], w1 * sq[3]) + fmaf(w2, sq[5], w3 * sq[7]);
-    } else {
-        psx = psy = qsx = qsy = 0.f;
-        for (int i = 0; i < n; i++) {
+    psx = psy = qsx = qsy = 0.f;
+    {
+        int i = 0;
+        if (n < 5 || n > 48) {
+            for (; i + 4 <= n; i += 4) {
+#pragma unroll
+                for (int h = 0; h < 4; h += 2) {
+                    const float wa = wn(i + h), wb = wn(i + h + 1);
+                    const float *pa = sp + 2 * (i + h), *qa = sq + 2 * (i + h);
+                    psx = psx + fmaf(wa, pa[0], wb * pa[2]); psy = psy + fmaf(wa, pa[1], wb * pa[3]);
+                    qsx = qsx + fmaf(wa, qa[0], wb * qa[2]); qsy = qsy + fmaf(wa, qa[1], wb * qa[3]);
+                }
+            }
+        }
+        for (; i < n; i++) {
             const float w = wn(i);
             psx = fmaf(w, sp[2 * i], psx); psy = fmaf(w, sp[2 * i + 1], psy);
             qsx = fmaf(w, sq[2 * i], qsx); qsy = fmaf(w, sq[2 * i + 1], qsy);
@@ -129,12 +179,11 @@ VKX_EXPORT int vkx_mls_project_dev(vkx_ctx *ctx, const float *src_handles, const
 {
     VKX_REQUIRE(ctx && src_handles && dst_handles && src_handles_smooth && dst_handles_smooth, "NULL argument");
     VKX_REQUIRE(n_handles >= 1 && n_vertices >= 0, "bad sizes");
-    if (n_handles > kMaxHandles) return VKX_ERR_UNSUPPORTED;
     if (n_vertices == 0) return VKX_OK;
     VKX_REQUIRE(vertices_xy && out_xy && status, "NULL argument");
     vkx_device_guard guard(ctx);
     Handles hd{src_handles, dst_handles, src_handles_smooth, dst_handles_smooth, n_handles};
-    { VKX_TIMED(ctx, "k_mls_project"); k_mls_project<<<vkx_blocks((size_t)n_vertices, 64), 64, 0, ctx->stream>>>(hd, vertices_xy, n_vertices, out_xy, status); }
+    { VKX_TIMED(ctx, "k_mls_project"); k_mls_project<<<vkx_blocks((size_t)n_vertices, 64), 64, n_handles <= kLdsHandles ? sizeof(float) * 4 * (size_t)n_handles : 0, ctx->stream>>>(hd, vertices_xy, n_vertices, out_xy, status); }
     VKX_LAUNCH_CHECK();
     return VKX_OK;
 }
@@ -145,10 +194,6 @@ VKX_EXPORT int vkx_mls_project(vkx_ctx *ctx, const float *src_handles, const flo
 {
     VKX_REQUIRE(ctx && src_handles && dst_handles && src_handles_smooth && dst_handles_smooth, "NULL argument");
     VKX_REQUIRE(n_handles >= 1 && n_vertices >= 0, "bad sizes");
-    if (n_handles > kMaxHandles) {
-        vkx_set_error("vkx_mls_project: more than %d handles", kMaxHandles);
-        return VKX_ERR_UNSUPPORTED;
-    }
     if (n_vertices == 0) return VKX_OK;
     VKX_REQUIRE(vertices_xy && out_xy, "NULL argument");
     vkx_device_guard guard(ctx);

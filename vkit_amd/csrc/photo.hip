@@ -8,6 +8,7 @@
 #include <float.h>
 
 #include <math.h>
+#include <string.h>
 
 namespace {
 
@@ -534,6 +535,272 @@ __global__ void __launch_bounds__(256) k_line_streak(uint8_t *img, int h, int w,
     }
 }
 
+// ---- dense planes: 16 bytes per lane ---------------------------------------------------------------------------------
+// The kernels above take any row pitch and move one byte (or one pixel) per lane: at 8192^2 they reach 1.0 - 1.6 TB/s,
+// bound by the number of memory instructions.  A dense plane (row pitch == row bytes, 16-byte aligned base pointers) is one
+// flat byte string: a lane takes one aligned 16-byte group of it, so a wavefront moves 1 KiB per load.  Same arithmetic
+// per byte.  The channel of byte j of group t is (16 t + j) mod cn.
+__device__ __forceinline__ int first_channel16(size_t t, int cn) { return cn == 3 ? (int)(t % 3) : 0; }   // 16 = 1 mod 3; 1, 2, 4 divide 16
+
+template <class F>
+__device__ __forceinline__ void map_bytes16(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, size_t n, int cn, F f)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, i0 = t * 16;
+    if (i0 >= n) return;
+    int c = first_channel16(t, cn);
+    if (i0 + 16 <= n) {
+        const uint4 in = *(const uint4 *)(src + i0);
+        uint32_t w[4] = {in.x, in.y, in.z, in.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t o = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                o |= (uint32_t)(f((int)((w[k] >> (8 * b)) & 0xffu), c, 4 * k + b) & 0xff) << (8 * b);
+                c = c + 1 == cn ? 0 : c + 1;
+            }
+            w[k] = o;
+        }
+        *(uint4 *)(dst + i0) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+        for (int j = 0; i0 + j < n; j++) {
+            dst[i0 + j] = (uint8_t)f((int)src[i0 + j], c, j);
+            c = c + 1 == cn ? 0 : c + 1;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_mean_shift16(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, size_t n, int cn,
+                                                      int delta, int has_thr, int thr, int cycle, unsigned chmask)
+{
+    map_bytes16(src, dst, n, cn, [=](int v, int c, int) {
+        if ((chmask == 0 || ((chmask >> c) & 1u)) && delta != 0) {
+            bool apply = true;
+            if (has_thr) apply = delta > 0 ? (v <= thr) : (thr <= v);
+            if (apply) v += delta;
+            v = cycle ? (v & 255) : vkd::clamp_u8(v);      // python's % 256 of a two's complement int is & 255
+        }
+        return v;
+    });
+}
+
+__global__ void __launch_bounds__(256) k_pointwise16(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, size_t n, int cn,
+                                                     int op, int p0, int p1, unsigned chmask)
+{
+    // complement / posterization (the permutation needs whole pixels: k_pointwise)
+    map_bytes16(src, dst, n, cn, [=](int v, int c, int) {
+        const bool on = chmask == 0 || ((chmask >> c) & 1u);
+        if (op == VKX_POINT_COMPLEMENT) {
+            if (on && (p0 < 0 || (p1 ? v <= p0 : p0 <= v))) v = 255 - v;
+        } else if (on) {
+            v &= (0xFF >> p0) << p0;
+        }
+        return v;
+    });
+}
+
+__global__ void __launch_bounds__(256) k_apply_lut16(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, size_t n, int cn,
+                                                     const uint8_t *__restrict__ lut /* [cn][256] */, unsigned chmask)
+{
+    __shared__ uint8_t table[4 * 256];
+    for (int i = threadIdx.x; i < cn * 256; i += 256) table[i] = lut[i];
+    __syncthreads();
+    map_bytes16(src, dst, n, cn, [&](int v, int c, int) {
+        return (chmask == 0 || ((chmask >> c) & 1u)) ? (int)table[c * 256 + v] : v;
+    });
+}
+
+__global__ void __launch_bounds__(256) k_add_noise16(const uint8_t *__restrict__ src, const int16_t *__restrict__ noise,
+                                                     uint8_t *__restrict__ dst, size_t n)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, i0 = t * 16;
+    if (i0 >= n) return;
+    if (i0 + 16 <= n) {
+        const uint4 in = *(const uint4 *)(src + i0);
+        const uint4 na = *(const uint4 *)(noise + i0), nb = *(const uint4 *)(noise + i0 + 8);
+        const uint32_t w[4] = {in.x, in.y, in.z, in.w};
+        const uint32_t z[8] = {na.x, na.y, na.z, na.w, nb.x, nb.y, nb.z, nb.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            o[k] = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int j = 4 * k + b;
+                const int16_t nz = (int16_t)(z[j >> 1] >> (16 * (j & 1)));
+                // int16 arithmetic like the reference's (uint8 -> int16) + int16 sum: wraps at 16 bits
+                const int v = (int16_t)((int16_t)((w[k] >> (8 * b)) & 0xffu) + nz);
+                o[k] |= (uint32_t)vkd::clamp_u8(v) << (8 * b);
+            }
+        }
+        *(uint4 *)(dst + i0) = make_uint4(o[0], o[1], o[2], o[3]);
+    } else {
+        for (size_t i = i0; i < n; i++) dst[i] = (uint8_t)vkd::clamp_u8((int16_t)((int16_t)src[i] + noise[i]));
+    }
+}
+
+// impulse_noise on a dense plane: a lane takes 16 PIXELS (16 selector bytes, 16 CN pixel bytes)
+template <int CN>
+__global__ void __launch_bounds__(256) k_impulse_noise16(const uint8_t *__restrict__ src, const uint8_t *__restrict__ sel,
+                                                         uint8_t *__restrict__ dst, size_t npix)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, p0 = t * 16;
+    if (p0 >= npix) return;
+    if (p0 + 16 <= npix) {
+        const uint4 sv = *(const uint4 *)(sel + p0);
+        const uint32_t m[4] = {sv.x, sv.y, sv.z, sv.w};
+        uint32_t w[4 * CN];
+#pragma unroll
+        for (int q = 0; q < CN; q++) {
+            const uint4 in = *(const uint4 *)(src + p0 * CN + 16 * q);
+            w[4 * q] = in.x; w[4 * q + 1] = in.y; w[4 * q + 2] = in.z; w[4 * q + 3] = in.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 16 * CN; j++) {
+            const int px = j / CN;
+            const uint32_t s = (m[px >> 2] >> (8 * (px & 3))) & 0xffu;
+            const uint32_t keep = (w[j >> 2] >> (8 * (j & 3))) & 0xffu;
+            const uint32_t v = s == 1 ? 255u : (s == 2 ? 0u : keep);
+            w[j >> 2] = (w[j >> 2] & ~(0xffu << (8 * (j & 3)))) | (v << (8 * (j & 3)));
+        }
+#pragma unroll
+        for (int q = 0; q < CN; q++) *(uint4 *)(dst + p0 * CN + 16 * q) = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    } else {
+        for (size_t p = p0; p < npix; p++) {
+            const int s = sel[p];
+            for (int c = 0; c < CN; c++) dst[p * CN + c] = s == 1 ? (uint8_t)255 : (s == 2 ? (uint8_t)0 : src[p * CN + c]);
+        }
+    }
+}
+
+// RGB pixel operators on a dense plane: a lane takes 4 pixels = 12 bytes = 3 dwords; the HSV division tables and the hue
+// sector selectors sit in LDS (colour shift: the arithmetic of the fused chain kernel, vkd::hue_shift_packed).
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+
+template <class F>
+__device__ __forceinline__ void map_rgb4(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, size_t npix, F f)
+{
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, p0 = t * 4;
+    if (p0 >= npix) return;
+    if (p0 + 4 <= npix) {
+        const u32x3 in = *(const u32x3 *)(src + p0 * 3);
+        const uint32_t w0 = in.x, w1 = in.y, w2 = in.z;
+        // bytes: r0 g0 b0 r1 | g1 b1 r2 g2 | b2 r3 g3 b3;  f returns r | g << 8 | b << 16
+        const uint32_t q0 = f(w0 & 0xffu, (w0 >> 8) & 0xffu, (w0 >> 16) & 0xffu);
+        const uint32_t q1 = f(w0 >> 24, w1 & 0xffu, (w1 >> 8) & 0xffu);
+        const uint32_t q2 = f((w1 >> 16) & 0xffu, w1 >> 24, w2 & 0xffu);
+        const uint32_t q3 = f((w2 >> 8) & 0xffu, (w2 >> 16) & 0xffu, w2 >> 24);
+        u32x3 out;
+        out.x = q0 | (q1 << 24);
+        out.y = (q1 >> 8) | (q2 << 16);
+        out.z = (q2 >> 16) | (q3 << 8);
+        *(u32x3 *)(dst + p0 * 3) = out;
+    } else {
+        for (size_t p = p0; p < npix; p++) {
+            const uint32_t q = f(src[p * 3], src[p * 3 + 1], src[p * 3 + 2]);
+            dst[p * 3] = (uint8_t)q; dst[p * 3 + 1] = (uint8_t)(q >> 8); dst[p * 3 + 2] = (uint8_t)(q >> 16);
+        }
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_hsv4(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, size_t npix, int delta,
+                                              const HsvTables *__restrict__ T)
+{
+    __shared__ int lsdiv[256], lhdiv[256];
+    __shared__ uint32_t lsel[8];
+    if (MODE != 2) {
+        lsdiv[threadIdx.x] = T->sdiv[threadIdx.x];
+        lhdiv[threadIdx.x] = T->hdiv[threadIdx.x];
+        if (threadIdx.x < 8) lsel[threadIdx.x] = vkd::kHsvSelectors[threadIdx.x];
+        __syncthreads();
+    }
+    map_rgb4(src, dst, npix, [&](uint32_t a, uint32_t b, uint32_t c) -> uint32_t {
+        if (MODE == 0) return vkd::hue_shift_packed(lsdiv, lhdiv, lsel, delta, (int)a, (int)b, (int)c);
+        int x, y, z;
+        if (MODE == 1) vkd::rgb2hsv_full(lsdiv, lhdiv, (int)a, (int)b, (int)c, x, y, z);
+        else vkd::hsv2rgb_full((int)a, (int)b, (int)c, x, y, z);
+        return (uint32_t)x | ((uint32_t)y << 8) | ((uint32_t)z << 16);
+    });
+}
+
+// brightness_shift / RGB <-> HLS / color_balance (k_cvt modes 0, 1, 2, 5)
+template <int MODE>
+__global__ void __launch_bounds__(256) k_cvt4(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, size_t npix, int delta,
+                                              float w0, float w1)
+{
+    map_rgb4(src, dst, npix, [=](uint32_t ua, uint32_t ub, uint32_t uc) -> uint32_t {
+        int a = (int)ua, b = (int)ub, c = (int)uc;
+        if (MODE == 5) {
+            const float gray = (float)rgb2gray_px(a, b, c);
+            const int in[3] = {a, b, c};
+            uint32_t q = 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float t0 = w0 * gray, t1 = w1 * (float)in[k];
+                float v = t0 + t1;
+                v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
+                q |= (uint32_t)(uint8_t)v << (8 * k);
+            }
+            return q;
+        }
+        if (MODE == 0 || MODE == 1) {
+            int H, L, S;
+            rgb2hls_px(a, b, c, H, L, S);
+            a = H; b = L; c = S;
+        }
+        if (MODE == 0 && delta != 0) b = vkd::clamp_u8(b + delta);
+        if (MODE == 0 || MODE == 2) {
+            int R, G, B;
+            hls2rgb_px(a, b, c, R, G, B);
+            a = R; b = G; c = B;
+        }
+        return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16);
+    });
+}
+
+// Histogram of a dense plane: a few hundred workgroups stride over the 16-byte groups, every wavefront counts into its
+// own LDS copy (fewer same-address collisions), one flush per workgroup (the per-row version above flushes 768 counters from
+// thousands of workgroups: device-scope atomics on 768 addresses were its whole run time).
+__global__ void __launch_bounds__(256) k_histogram16(const uint8_t *__restrict__ src, size_t n, int cn, int *__restrict__ hist)
+{
+    __shared__ int lh[4][4 * 256];
+    for (int i = threadIdx.x; i < 4 * 4 * 256; i += 256) (&lh[0][0])[i] = 0;
+    __syncthreads();
+    int *mine = lh[threadIdx.x >> 6];
+    const size_t groups = (n + 15) / 16, stride = (size_t)gridDim.x * 256;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < groups; t += stride) {
+        const size_t i0 = t * 16;
+        int c = first_channel16(t, cn);
+        if (i0 + 16 <= n) {
+            const uint4 in = *(const uint4 *)(src + i0);
+            const uint32_t w[4] = {in.x, in.y, in.z, in.w};
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                atomicAdd(&mine[c * 256 + (int)((w[j >> 2] >> (8 * (j & 3))) & 0xffu)], 1);
+                c = c + 1 == cn ? 0 : c + 1;
+            }
+        } else {
+            for (size_t i = i0; i < n; i++) {
+                atomicAdd(&mine[c * 256 + src[i]], 1);
+                c = c + 1 == cn ? 0 : c + 1;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cn * 256; i += 256) {
+        const int v = lh[0][i] + lh[1][i] + lh[2][i] + lh[3][i];
+        if (v) atomicAdd(&hist[i], v);
+    }
+}
+
+// a plane qualifies when its rows follow each other without gaps and every pointer is aligned for the widest access
+inline bool dense16(const void *a, ptrdiff_t a_pitch, const void *b, ptrdiff_t b_pitch, size_t row_bytes, int h, unsigned align = 16)
+{
+    return (h == 1 || ((size_t)a_pitch == row_bytes && (size_t)b_pitch == row_bytes)) &&
+           (((uintptr_t)a | (uintptr_t)b) & (align - 1)) == 0;
+}
+
 int check_plane(vkx_ctx *ctx, const void *src, const void *dst, int h, int w)
 {
     VKX_REQUIRE(ctx && src && dst, "NULL argument");
@@ -637,6 +904,12 @@ static int launch_hsv(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t 
     const HsvTables *T = nullptr;
     rc = hsv_tables(ctx, &T);
     if (rc) return rc;
+    if (dense16(src, src_stride, dst, dst_stride, (size_t)w * 3, h, 4)) {
+        const size_t npix = (size_t)h * w;
+        { VKX_TIMED(ctx, "k_hsv"); k_hsv4<MODE><<<vkx_blocks((npix + 3) / 4, 256), 256, 0, ctx->stream>>>(src, dst, npix, delta, T); }
+        VKX_LAUNCH_CHECK();
+        return VKX_OK;
+    }
     dim3 block(64, 4), grid(vkx_blocks(w, 64), vkx_blocks(h, 4));
     { VKX_TIMED(ctx, "k_hsv"); k_hsv<MODE><<<grid, block, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, delta, T); }
     VKX_LAUNCH_CHECK();
@@ -663,6 +936,14 @@ static int launch_cvt(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t 
     int rc = check_plane(ctx, src, dst, h, w);
     if (rc) return rc;
     if (h == 0 || w == 0) return VKX_OK;
+    if constexpr (MODE == 0 || MODE == 1 || MODE == 2 || MODE == 5) {
+        if (dense16(src, src_stride, dst, dst_stride, (size_t)w * 3, h, 4)) {
+            const size_t npix = (size_t)h * w;
+            { VKX_TIMED(ctx, "k_cvt"); k_cvt4<MODE><<<vkx_blocks((npix + 3) / 4, 256), 256, 0, ctx->stream>>>(src, dst, npix, delta, w0, w1); }
+            VKX_LAUNCH_CHECK();
+            return VKX_OK;
+        }
+    }
     dim3 block(64, 4), grid(vkx_blocks(w, 64), vkx_blocks(h, 4));
     { VKX_TIMED(ctx, "k_cvt"); k_cvt<MODE><<<grid, block, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, delta, w0, w1); }
     VKX_LAUNCH_CHECK();
@@ -713,6 +994,13 @@ VKX_EXPORT int vkx_mean_shift_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, in
     if (rc) return rc;
     VKX_REQUIRE(cn >= 1 && cn <= 4, "1..4 channels");
     if (h == 0 || w == 0) return VKX_OK;
+    if (dense16(src, src_stride, dst, dst_stride, (size_t)w * cn, h)) {
+        const size_t n = (size_t)h * w * cn;
+        { VKX_TIMED(ctx, "k_mean_shift"); k_mean_shift16<<<vkx_blocks((n + 15) / 16, 256), 256, 0, ctx->stream>>>(src, dst, n, cn, delta, has_threshold,
+                                                                                                           threshold, cycle, channel_mask); }
+        VKX_LAUNCH_CHECK();
+        return VKX_OK;
+    }
     dim3 block(64, 4), grid(vkx_blocks((size_t)w * cn, 64), vkx_blocks(h, 4));
     { VKX_TIMED(ctx, "k_mean_shift"); k_mean_shift<<<grid, block, 0, ctx->stream>>>(src, h, w, cn, src_stride, dst, dst_stride, delta, has_threshold,
                                                   threshold, cycle, channel_mask); }
@@ -734,6 +1022,12 @@ VKX_EXPORT int vkx_pointwise_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int
         for (int c = 0; c < cn; c++) VKX_REQUIRE(((p0 >> (2 * c)) & 3) < cn, "permutation index out of range");
     }
     if (h == 0 || w == 0) return VKX_OK;
+    if (op != VKX_POINT_PERMUTE && dense16(src, src_stride, dst, dst_stride, (size_t)w * cn, h)) {
+        const size_t n = (size_t)h * w * cn;
+        { VKX_TIMED(ctx, "k_pointwise"); k_pointwise16<<<vkx_blocks((n + 15) / 16, 256), 256, 0, ctx->stream>>>(src, dst, n, cn, op, p0, p1, channel_mask); }
+        VKX_LAUNCH_CHECK();
+        return VKX_OK;
+    }
     dim3 block(64, 4), grid(vkx_blocks((size_t)w * cn, 64), vkx_blocks(h, 4));
     { VKX_TIMED(ctx, "k_pointwise"); k_pointwise<<<grid, block, 0, ctx->stream>>>(src, h, w, cn, src_stride, dst, dst_stride, op, p0, p1, channel_mask); }
     VKX_LAUNCH_CHECK();
@@ -749,6 +1043,17 @@ VKX_EXPORT int vkx_impulse_noise_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h,
     VKX_REQUIRE(selector != nullptr, "NULL selector plane");
     VKX_REQUIRE(cn >= 1 && cn <= 4, "1..4 channels");
     if (h == 0 || w == 0) return VKX_OK;
+    if (cn != 2 && dense16(src, src_stride, dst, dst_stride, (size_t)w * cn, h) && (h == 1 || selector_stride == w) &&
+        ((uintptr_t)selector & 15) == 0) {
+        const size_t npix = (size_t)h * w;
+        const unsigned blocks = vkx_blocks((npix + 15) / 16, 256);
+        VKX_TIMED(ctx, "k_impulse_noise");
+        if (cn == 1) k_impulse_noise16<1><<<blocks, 256, 0, ctx->stream>>>(src, selector, dst, npix);
+        else if (cn == 3) k_impulse_noise16<3><<<blocks, 256, 0, ctx->stream>>>(src, selector, dst, npix);
+        else k_impulse_noise16<4><<<blocks, 256, 0, ctx->stream>>>(src, selector, dst, npix);
+        VKX_LAUNCH_CHECK();
+        return VKX_OK;
+    }
     dim3 block(64, 4), grid(vkx_blocks((size_t)w * cn, 64), vkx_blocks(h, 4));
     { VKX_TIMED(ctx, "k_impulse_noise"); k_impulse_noise<<<grid, block, 0, ctx->stream>>>(src, h, w, cn, src_stride, selector, selector_stride, dst, dst_stride); }
     VKX_LAUNCH_CHECK();
@@ -777,6 +1082,13 @@ VKX_EXPORT int vkx_histogram_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int
     VKX_REQUIRE(cn >= 1 && cn <= 4, "1..4 channels");
     VKX_HIP(hipMemsetAsync(hist, 0, sizeof(int32_t) * 256 * cn, ctx->stream));
     if (h == 0 || w == 0) return VKX_OK;
+    if ((h == 1 || (size_t)src_stride == (size_t)w * cn) && ((uintptr_t)src & 15) == 0) {
+        const size_t n = (size_t)h * w * cn;
+        const unsigned blocks = std::min(vkx_blocks((n + 15) / 16, 256), 1024u);      // 4 per CU
+        { VKX_TIMED(ctx, "k_histogram"); k_histogram16<<<blocks, 256, 0, ctx->stream>>>(src, n, cn, hist); }
+        VKX_LAUNCH_CHECK();
+        return VKX_OK;
+    }
     dim3 grid(std::min(vkx_blocks((size_t)w * cn, 256), 16u), std::min((unsigned)h, 256u));
     { VKX_TIMED(ctx, "k_histogram"); k_histogram<<<grid, 256, 0, ctx->stream>>>(src, h, w, cn, src_stride, hist); }
     VKX_LAUNCH_CHECK();
@@ -793,8 +1105,18 @@ VKX_EXPORT int vkx_apply_lut_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int
     if (h == 0 || w == 0) return VKX_OK;
     rc = vkx_scratch_reserve(ctx, &ctx->misc, 1024);
     if (rc) return rc;
-    VKX_HIP(hipMemcpyAsync(ctx->misc.ptr, lut_host, (size_t)256 * cn, hipMemcpyHostToDevice, ctx->stream));
-    VKX_HIP(hipStreamSynchronize(ctx->stream));   // the table is the caller's memory
+    // the table is the caller's memory: it travels through the page-locked descriptor ring, no stream synchronisation
+    void *staged = nullptr;
+    rc = vkx_desc_ring_take(ctx, (size_t)256 * cn, &staged);
+    if (rc) return rc;
+    memcpy(staged, lut_host, (size_t)256 * cn);
+    VKX_HIP(hipMemcpyAsync(ctx->misc.ptr, staged, (size_t)256 * cn, hipMemcpyHostToDevice, ctx->stream));
+    if (dense16(src, src_stride, dst, dst_stride, (size_t)w * cn, h)) {
+        const size_t n = (size_t)h * w * cn;
+        { VKX_TIMED(ctx, "k_apply_lut"); k_apply_lut16<<<vkx_blocks((n + 15) / 16, 256), 256, 0, ctx->stream>>>(src, dst, n, cn, (const uint8_t *)ctx->misc.ptr, channel_mask); }
+        VKX_LAUNCH_CHECK();
+        return VKX_OK;
+    }
     dim3 block(64, 4), grid(vkx_blocks((size_t)w * cn, 64), vkx_blocks(h, 4));
     { VKX_TIMED(ctx, "k_apply_lut"); k_apply_lut<<<grid, block, 0, ctx->stream>>>(src, h, w, cn, src_stride, dst, dst_stride, (const uint8_t *)ctx->misc.ptr, channel_mask); }
     VKX_LAUNCH_CHECK();
@@ -851,6 +1173,13 @@ VKX_EXPORT int vkx_add_noise_i16_dev(vkx_ctx *ctx, const uint8_t *src, int h, in
     VKX_REQUIRE(noise != nullptr, "NULL noise plane");
     VKX_REQUIRE(cn >= 1 && cn <= 4, "1..4 channels");
     if (h == 0 || w == 0) return VKX_OK;
+    if (dense16(src, src_stride, dst, dst_stride, (size_t)w * cn, h) && (h == 1 || noise_stride_el == (ptrdiff_t)w * cn) &&
+        ((uintptr_t)noise & 15) == 0) {
+        const size_t n = (size_t)h * w * cn;
+        { VKX_TIMED(ctx, "k_add_noise"); k_add_noise16<<<vkx_blocks((n + 15) / 16, 256), 256, 0, ctx->stream>>>(src, noise, dst, n); }
+        VKX_LAUNCH_CHECK();
+        return VKX_OK;
+    }
     dim3 block(64, 4), grid(vkx_blocks((size_t)w * cn, 64), vkx_blocks(h, 4));
     { VKX_TIMED(ctx, "k_add_noise"); k_add_noise<<<grid, block, 0, ctx->stream>>>(src, h, w * cn, src_stride, noise, noise_stride_el, dst, dst_stride); }
     VKX_LAUNCH_CHECK();

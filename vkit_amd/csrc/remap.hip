@@ -46,6 +46,9 @@ struct CoordPerspective { // warpPerspective: inverse matrix, per pixel in doubl
     }
 };
 
+typedef unsigned long long u64_u1 __attribute__((aligned(1)));
+typedef uint32_t u32_u1 __attribute__((aligned(1)));
+
 template <int CN, class Coord>
 __global__ void __launch_bounds__(256) k_sample_u8(const uint8_t *__restrict__ src, int sh, int sw, ptrdiff_t sstride,
                                                    uint8_t *__restrict__ dst, int dh, int dw, ptrdiff_t dstride,
@@ -53,14 +56,62 @@ __global__ void __launch_bounds__(256) k_sample_u8(const uint8_t *__restrict__ s
 {
     const int x = blockIdx.x * 64 + threadIdx.x;
     const int y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= dw || y >= dh) return;
-    int X, Y;
-    coord(x, y, X, Y);
-    uint8_t px[CN];
-    vkd::sample_u8<CN>(src, sh, sw, sstride, X, Y, px);
-    uint8_t *d = dst + (ptrdiff_t)y * dstride + (ptrdiff_t)x * CN;
+    if constexpr (CN == 3) {
+        // RGB: the gather and the store of the fused chain kernel (fused.hip, phases C and E).  A pixel whose 2 x 2 taps lie
+        // inside the source takes two unaligned 8-byte loads (6 bytes each are the tap pair of a row), horizontal pairs as
+        // v_dot4_u32_u8, the vertical pair as 24-bit multiply-adds: the same integer as the four weighted taps.  Four
+        // neighbouring lanes write their 12 bytes as three dwords.
+        if (y >= dh) return;                    // uniform over the wavefront (a wavefront is one row of the block)
+        const int lane = threadIdx.x;
+        const bool active = x < dw;
+        uint32_t P = 0;                         // r | g << 8 | b << 16
+        if (active) {
+            int X, Y;
+            coord(x, y, X, Y);
+            const int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
+            if ((unsigned)sx < (unsigned)max(sw - 2, 0) && (unsigned)sy < (unsigned)(sh - 1)) {
+                const uint8_t *q = src + (ptrdiff_t)sy * sstride + (ptrdiff_t)sx * 3;   // 3 sx + 8 <= 3 sw
+                const unsigned long long ta = *(const u64_u1 *)q, tb = *(const u64_u1 *)(q + sstride);
+                const uint32_t wx = (uint32_t)(32 - fx) | ((uint32_t)fx << 24);
+                const uint32_t t0 = (uint32_t)ta, t1 = (uint32_t)(ta >> 32), b0 = (uint32_t)tb, b1 = (uint32_t)(tb >> 32);
+                const uint32_t ar = __builtin_amdgcn_udot4(t0, wx, 0u, false);
+                const uint32_t ag = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t1, t0, 1), wx, 0u, false);
+                const uint32_t ab = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t1, t0, 2), wx, 0u, false);
+                const uint32_t br = __builtin_amdgcn_udot4(b0, wx, 0u, false);
+                const uint32_t bg = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b1, b0, 1), wx, 0u, false);
+                const uint32_t bb = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b1, b0, 2), wx, 0u, false);
+                const uint32_t wy0 = (uint32_t)(32 - fy), wy1 = (uint32_t)fy;
+                const uint32_t r = (__umul24(br, wy1) + __umul24(ar, wy0) + 512u) >> 10;
+                const uint32_t g = (__umul24(bg, wy1) + __umul24(ag, wy0) + 512u) >> 10;
+                const uint32_t b = (__umul24(bb, wy1) + __umul24(ab, wy0) + 512u) >> 10;
+                P = r | (g << 8) | (b << 16);
+            } else {
+                uint8_t px[3];
+                vkd::sample_u8<3>(src, sh, sw, sstride, X, Y, px);
+                P = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);
+            }
+        }
+        const uint32_t Pn = (uint32_t)__builtin_amdgcn_ds_bpermute(min(lane + 1, 63) << 2, (int)P);
+        if (!active) return;
+        uint8_t *drow = dst + (ptrdiff_t)y * dstride;
+        const int m = x & 3;
+        if (x < (dw & ~3)) {
+            if (m < 3) *(u32_u1 *)(drow + (ptrdiff_t)(x >> 2) * 12 + m * 4) = (P >> (8 * m)) | (Pn << (24 - 8 * m));
+        } else {
+            uint8_t *d = drow + (ptrdiff_t)x * 3;
+            d[0] = (uint8_t)P; d[1] = (uint8_t)(P >> 8); d[2] = (uint8_t)(P >> 16);
+        }
+        return;
+    } else {
+        if (x >= dw || y >= dh) return;
+        int X, Y;
+        coord(x, y, X, Y);
+        uint8_t px[CN];
+        vkd::sample_u8<CN>(src, sh, sw, sstride, X, Y, px);
+        uint8_t *d = dst + (ptrdiff_t)y * dstride + (ptrdiff_t)x * CN;
 #pragma unroll
-    for (int k = 0; k < CN; k++) d[k] = px[k];
+        for (int k = 0; k < CN; k++) d[k] = px[k];
+    }
 }
 
 template <class Coord>
