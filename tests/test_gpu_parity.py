@@ -202,8 +202,11 @@ def test_grid_4096_shared_state_three_outputs(N):
 # ------------------------------------------------------------------------------------------ photometric
 def test_gaussian_blur(N):
     rng = default_rng(6)
-    for shape in [(40, 50, 3), (33, 65), (1, 17, 3), (19, 1), (2, 2, 3), (3, 200, 4), (5, 5)]:
+    # (RGB planes take the packed tile kernel: widths around its 62 / 60 / 58-column tiles and 4-pixel store groups)
+    for shape in [(40, 50, 3), (33, 65), (1, 17, 3), (19, 1), (2, 2, 3), (3, 200, 4), (5, 5), (70, 61, 3), (35, 62, 3), (64, 123, 3),
+                  (97, 258, 3), (31, 3, 3)]:
         img = rng.integers(0, 256, shape, dtype=np.uint8)
+        img[-1, -1] = 255
         for ksize, sigma in [(3, 0.5), (3, 0.7), (5, 0.9), (5, 1.0), (7, 2.0)]:
             assert (N.gaussian_blur(img, ksize, sigma) == O.gaussian_blur(img, ksize, sigma)).all(), (shape, ksize)
 

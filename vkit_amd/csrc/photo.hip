@@ -149,6 +149,72 @@ __global__ void __launch_bounds__(256) k_gaussian_blur_tiled(const uint8_t *__re
     }
 }
 
+// RGB form of the tiled blur with the packing of the fused chain kernel (fused.hip, phases D / E): r and b ride in the two
+// 16-bit halves of one dword through the horizontal pass (255 * 256 < 2^16: the halves never carry), so a tap is two
+// ds_bpermute on byte addresses computed once + two 24-bit multiply-adds instead of three __shfl (which rebuild their index
+// math on every call) + three multiplies; four neighbouring lanes store their 12 bytes as three dwords.
+typedef uint32_t blur_u32_u1 __attribute__((aligned(1)));
+
+template <int R>
+__global__ void __launch_bounds__(256) k_gaussian_blur_rgb(const uint8_t *__restrict__ src, int h, int w, ptrdiff_t sstride,
+                                                           uint8_t *__restrict__ dst, ptrdiff_t dstride, BlurKernel K)
+{
+    constexpr int KS = 2 * R + 1, TW = 64 - 2 * R;
+    __shared__ uint32_t hrb[(kBlurTileH + 2 * R) * 64];      // r sum | b sum << 16 (8.8 each)
+    __shared__ uint16_t hg[(kBlurTileH + 2 * R) * 64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * kBlurTileH;
+    const int gx = reflect101(x0 - R + lane, w);
+    const int rows = min(kBlurTileH, h - y0) + 2 * R;
+    uint32_t kq[KS];
+    int from[KS];
+#pragma unroll
+    for (int i = 0; i < KS; i++) {
+        kq[i] = K.k[i];
+        from[i] = min(max(lane + i - R, 0), 63) << 2;
+    }
+    for (int row = wave; row < rows; row += 4) {
+        const uint8_t *p = src + (ptrdiff_t)reflect101(y0 - R + row, h) * sstride + (ptrdiff_t)gx * 3;
+        const uint32_t rb = (uint32_t)p[0] | ((uint32_t)p[2] << 16), g = p[1];
+        uint32_t arb = 0, ag = 0;
+#pragma unroll
+        for (int i = 0; i < KS; i++) {
+            const uint32_t vrb = i == R ? rb : (uint32_t)__builtin_amdgcn_ds_bpermute(from[i], (int)rb);
+            const uint32_t vg = i == R ? g : (uint32_t)__builtin_amdgcn_ds_bpermute(from[i], (int)g);
+            arb += __umul24(kq[i], vrb);  // both halves at once: k <= 256, each half <= 255, the operand fits 24 bits
+            ag += __umul24(kq[i], vg);
+        }
+        hrb[row * 64 + lane] = arb;
+        hg[row * 64 + lane] = (uint16_t)ag;
+    }
+    __syncthreads();
+    const int ox = lane - R, x = x0 + ox;
+    const bool ocol = ox >= 0 && ox < TW && x < w;
+    const int full4 = x0 + ((min(TW, w - x0) >> 2) << 2);    // columns of this tile covered by whole 4-pixel groups (TW % 4 == 2 for R = 1, 3)
+    for (int orow = wave; orow < rows - 2 * R; orow += 4) {
+        uint32_t ar = 32768u, ag = 32768u, ab = 32768u;
+#pragma unroll
+        for (int j = 0; j < KS; j++) {
+            const uint32_t vrb = hrb[(orow + j) * 64 + lane], vg = hg[(orow + j) * 64 + lane];
+            ar += __umul24(kq[j], vrb & 0xffffu);
+            ab += __umul24(kq[j], vrb >> 16);
+            ag += __umul24(kq[j], vg);
+        }
+        const uint32_t P = (ar >> 16) | ((ag >> 16) << 8) | (ab & 0xff0000u);     // sums stay below 2^24: no clamp needed
+        // 12-byte groups start at the tile's first output column (lane R): group phase of this lane
+        const int m = ox & 3;
+        const uint32_t Pn = (uint32_t)__builtin_amdgcn_ds_bpermute(min(lane + 1, 63) << 2, (int)P);
+        if (!ocol) continue;
+        uint8_t *drow = dst + (ptrdiff_t)(y0 + orow) * dstride;
+        if (x < full4) {
+            if (m < 3) *(blur_u32_u1 *)(drow + (ptrdiff_t)x0 * 3 + (ox >> 2) * 12 + m * 4) = (P >> (8 * m)) | (Pn << (24 - 8 * m));
+        } else {
+            uint8_t *d = drow + (ptrdiff_t)x * 3;
+            d[0] = (uint8_t)P; d[1] = (uint8_t)(P >> 8); d[2] = (uint8_t)(P >> 16);
+        }
+    }
+}
+
 // ---- cv.filter2D(uint8 image, -1, float32 kernel) (defocus_blur / motion_blur, photometric/blur.py:85-192) -------
 // Correlation anchored at the kernel centre, BORDER_REFLECT_101; per pixel the non-zero taps in row-major order,
 // s += k * float(px) with separate roundings, then cvRound + saturate.  One workgroup = a 64 x 16 output tile: the
@@ -834,7 +900,11 @@ VKX_EXPORT int vkx_gaussian_blur_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h,
         VKX_TIMED(ctx, "k_gaussian_blur");
         switch (cn) {
         case 1: k_gaussian_blur_tiled<1><<<tgrid, 256, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K); break;
-        case 3: k_gaussian_blur_tiled<3><<<tgrid, 256, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K); break;
+        case 3:
+            if (K.kw == 3) k_gaussian_blur_rgb<1><<<tgrid, 256, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K);
+            else if (K.kw == 5) k_gaussian_blur_rgb<2><<<tgrid, 256, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K);
+            else k_gaussian_blur_rgb<3><<<tgrid, 256, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K);
+            break;
         default: k_gaussian_blur_tiled<4><<<tgrid, 256, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K); break;
         }
         VKX_LAUNCH_CHECK();
