@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Wall time of the three pipeline callers of the path on a C4-shaped synthetic page (1024^2, 64 text lines, 384 char
+polygons): PageAssemblerStep.run, PageDistortionStep.run, PageResizingStep.run -- host arrays in, host arrays out -- and
+where the host time goes (cProfile, top cumulative entries).  Usage: tools/page_steps.py [size] [n_lines] > out.json"""
+import cProfile
+import io
+import json
+import os
+import pstats
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+from numpy.random import default_rng
+
+from test_gpu_composite import _synthetic_page_input
+from vkit_amd import _native as N
+from vkit_amd.pipeline import text_detection as T
+
+size = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+n_lines = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+ctx = N.default_ctx()
+step_input = _synthetic_page_input(seed=3, size=size, n_lines=n_lines)
+assembler = T.page_assembler_step_factory.create()
+distortion = T.page_distortion_step_factory.create()
+resizing = T.page_resizing_step_factory.create()
+
+
+def timed(fn, reps):
+    fn(0)
+    ctx.set_timing(True); ctx.reset_timings()
+    t0 = time.perf_counter()
+    for k in range(reps):
+        fn(k + 1)
+    dt = (time.perf_counter() - t0) / reps
+    kernels = {n: round(v[0] / reps, 4) for n, v in ctx.timings().items()}
+    ctx.set_timing(False)
+    return dt, kernels
+
+
+def top(fn, reps, n=14):
+    pr = cProfile.Profile()
+    pr.enable()
+    for k in range(reps):
+        fn(100 + k)
+    pr.disable()
+    res = {}
+    for key in ('cumulative', 'tottime'):
+        buf = io.StringIO()
+        pstats.Stats(pr, stream=buf).sort_stats(key).print_stats(n)
+        res[key] = [l.strip().replace(ROOT + '/', '') for l in buf.getvalue().splitlines() if l.strip() and l.strip()[0].isdigit()][:n + 1]
+    return res
+
+
+out = {'page': f'{size}x{size}', 'text_lines': n_lines}
+page_out = assembler.run(step_input, default_rng(0))
+dt, k = timed(lambda s: assembler.run(step_input, default_rng(s)), 10)
+out['page_assembler'] = {'ms': round(dt * 1e3, 3), 'kernel_ms_per_run': k, 'gpu_ms': round(sum(k.values()), 3),
+                         'profile_top': top(lambda s: assembler.run(step_input, default_rng(s)), 6)}
+dist_in = T.PageDistortionStepInput(page_out)
+dist_out = distortion.run(dist_in, default_rng(0))
+dt, k = timed(lambda s: distortion.run(dist_in, default_rng(s)), 12)
+out['page_distortion'] = {'ms': round(dt * 1e3, 3), 'kernel_ms_per_run': k, 'gpu_ms': round(sum(k.values()), 3),
+                          'profile_top': top(lambda s: distortion.run(dist_in, default_rng(s)), 6)}
+res_in = T.PageResizingStepInput(page_distortion_step_output=dist_out)
+try:
+    dt, k = timed(lambda s: resizing.run(res_in, default_rng(s)), 10)
+    out['page_resizing'] = {'ms': round(dt * 1e3, 3), 'kernel_ms_per_run': k, 'gpu_ms': round(sum(k.values()), 3)}
+except Exception as exc:      # the step refuses pages without text lines of a minimum height
+    out['page_resizing'] = {'error': repr(exc)}
+print(json.dumps(out, indent=1))

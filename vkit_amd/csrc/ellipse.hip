@@ -289,10 +289,10 @@ VKX_EXPORT int vkx_ellipse_mask_u8(vkx_ctx *ctx, uint8_t *mask, ptrdiff_t stride
     if (rc) return rc;
     uint8_t *d = (uint8_t *)ctx->stage[1].ptr;
     // the caller's mask is drawn onto, as cv.ellipse does
-    VKX_HIP(hipMemcpy2DAsync(d, (size_t)w, mask, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, ctx->stream));
+    VKX_HIP(vkx_copy_plane(d, (size_t)w, mask, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, ctx->stream));
     rc = vkx_ellipse_mask_u8_dev(ctx, d, w, h, w, cx, cy, axes_host, n_ellipses, thickness);
     if (rc) return rc;
-    VKX_HIP(hipMemcpy2DAsync(mask, (size_t)stride, d, (size_t)w, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, ctx->stream));
+    VKX_HIP(vkx_copy_plane(mask, (size_t)stride, d, (size_t)w, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, ctx->stream));
     VKX_HIP(hipStreamSynchronize(ctx->stream));
     return VKX_OK;
 }
@@ -335,11 +335,11 @@ VKX_EXPORT int vkx_ellipse_streak_u8(vkx_ctx *ctx, uint8_t *img, int h, int w, i
     if (rc) return rc;
     uint8_t *d = (uint8_t *)ctx->stage[0].ptr;
     if ((size_t)stride == row) VKX_HIP(hipMemcpyAsync(d, img, bytes, hipMemcpyHostToDevice, ctx->stream));
-    else VKX_HIP(hipMemcpy2DAsync(d, row, img, (size_t)stride, row, (size_t)h, hipMemcpyHostToDevice, ctx->stream));
+    else VKX_HIP(vkx_copy_plane(d, row, img, (size_t)stride, row, (size_t)h, hipMemcpyHostToDevice, ctx->stream));
     rc = vkx_ellipse_streak_u8_dev(ctx, d, h, w, cn, (ptrdiff_t)row, cx, cy, axes_host, n_ellipses, thickness, color, alpha);
     if (rc) return rc;
     if ((size_t)stride == row) VKX_HIP(hipMemcpyAsync(img, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    else VKX_HIP(hipMemcpy2DAsync(img, (size_t)stride, d, row, row, (size_t)h, hipMemcpyDeviceToHost, ctx->stream));
+    else VKX_HIP(vkx_copy_plane(img, (size_t)stride, d, row, row, (size_t)h, hipMemcpyDeviceToHost, ctx->stream));
     VKX_HIP(hipStreamSynchronize(ctx->stream));
     return VKX_OK;
 }

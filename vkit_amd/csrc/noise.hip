@@ -164,7 +164,7 @@ VKX_EXPORT int vkx_noise_normal_i16(vkx_ctx *ctx, int16_t *dst, ptrdiff_t stride
     if (stride_el == (ptrdiff_t)w * cn)
         VKX_HIP(hipMemcpyAsync(dst, ctx->stage[1].ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
     else
-        VKX_HIP(hipMemcpy2DAsync(dst, (size_t)stride_el * 2, ctx->stage[1].ptr, (size_t)w * cn * 2, (size_t)w * cn * 2, (size_t)h,
+        VKX_HIP(vkx_copy_plane(dst, (size_t)stride_el * 2, ctx->stage[1].ptr, (size_t)w * cn * 2, (size_t)w * cn * 2, (size_t)h,
                                  hipMemcpyDeviceToHost, ctx->stream));
     VKX_HIP(hipStreamSynchronize(ctx->stream));
     return VKX_OK;

@@ -290,15 +290,15 @@ VKX_EXPORT int vkx_paint_polys(vkx_ctx *ctx, const int32_t *pts_host, const int3
     uint8_t *d_mask = mask ? (uint8_t *)ctx->stage[1].ptr : nullptr;
     float *d_score = score ? (float *)((unsigned char *)ctx->stage[1].ptr + mbytes) : nullptr;
     if (mask)
-        VKX_HIP(hipMemcpy2DAsync(d_mask, (size_t)w, mask, (size_t)mask_stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, ctx->stream));
+        VKX_HIP(vkx_copy_plane(d_mask, (size_t)w, mask, (size_t)mask_stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice, ctx->stream));
     if (score)
-        VKX_HIP(hipMemcpy2DAsync(d_score, (size_t)w * 4, score, (size_t)score_stride_el * 4, (size_t)w * 4, (size_t)h, hipMemcpyHostToDevice, ctx->stream));
+        VKX_HIP(vkx_copy_plane(d_score, (size_t)w * 4, score, (size_t)score_stride_el * 4, (size_t)w * 4, (size_t)h, hipMemcpyHostToDevice, ctx->stream));
     rc = vkx_paint_polys_dev(ctx, pts_host, poly_offsets_host, n_polys, values_host, d_mask, w, d_score, w, h, w);
     if (rc) return rc;
     if (mask)
-        VKX_HIP(hipMemcpy2DAsync(mask, (size_t)mask_stride, d_mask, (size_t)w, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, ctx->stream));
+        VKX_HIP(vkx_copy_plane(mask, (size_t)mask_stride, d_mask, (size_t)w, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, ctx->stream));
     if (score)
-        VKX_HIP(hipMemcpy2DAsync(score, (size_t)score_stride_el * 4, d_score, (size_t)w * 4, (size_t)w * 4, (size_t)h, hipMemcpyDeviceToHost, ctx->stream));
+        VKX_HIP(vkx_copy_plane(score, (size_t)score_stride_el * 4, d_score, (size_t)w * 4, (size_t)w * 4, (size_t)h, hipMemcpyDeviceToHost, ctx->stream));
     VKX_HIP(hipStreamSynchronize(ctx->stream));
     return VKX_OK;
 }
@@ -355,7 +355,7 @@ VKX_EXPORT int vkx_fill_poly_mask_u8(vkx_ctx *ctx, const int32_t *pts_host, int 
     VKX_HIP(hipMemsetAsync(d, 0, bytes, ctx->stream));
     rc = vkx_fill_poly_mask_u8_dev(ctx, pts_host, npts, d, h, w, w);
     if (rc) return rc;
-    VKX_HIP(hipMemcpy2DAsync(mask, (size_t)stride, d, (size_t)w, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, ctx->stream));
+    VKX_HIP(vkx_copy_plane(mask, (size_t)stride, d, (size_t)w, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, ctx->stream));
     VKX_HIP(hipStreamSynchronize(ctx->stream));
     return VKX_OK;
 }

@@ -225,6 +225,9 @@ class Distortion(Generic[_T_CONFIG, _T_STATE]):
                                           points: Union[PointList, PointTuple, Iterable[Point]]):
         internals.restore_rng_if_supported()
         points = PointList(points)
+        if not self.is_geometric:
+            # photometric distortions move nothing: the reference walks the points one by one to return each unchanged
+            return points.to_point_tuple()
         if self.func_points:
             return self.func_points(internals.config, internals.state, internals.shape, points, internals.rng)
         return PointList(self.distort_point_based_on_internals(internals, point) for point in points).to_point_tuple()
@@ -239,6 +242,8 @@ class Distortion(Generic[_T_CONFIG, _T_STATE]):
 
     def distort_polygons_based_on_internals(self, internals: DistortionInternals, polygons: Iterable[Polygon]):
         internals.restore_rng_if_supported()
+        if not self.is_geometric:
+            return list(polygons)          # unchanged (the reference rebuilds equal polygons point by point)
         if self.func_polygons:
             return self.func_polygons(internals.config, internals.state, internals.shape, polygons, internals.rng)
         return [self.distort_polygon_based_on_internals(internals, polygon) for polygon in polygons]

@@ -105,14 +105,10 @@ def paint_polygons(shape: Tuple[int, int], polygons: Sequence[Polygon], values: 
     np_mask = np.zeros((height, width), np.uint8) if want_mask else None
     np_score = np.zeros((height, width), np.float32) if values is not None else None
     if polygons:
-        # a polygon's raster is defined on its bounding box with the vertices made box-relative
-        # (reference element/polygon.py:105-138,70-77); translating the integer vertices back commutes with it
-        pts = []
-        for polygon in polygons:
-            box = polygon.bounding_box
-            rel = polygon.self_relative_polygon.to_np_array()
-            pts.append(rel + np.asarray([box.left, box.up], np.int32))
-        _native.paint_polys(pts, values=values, mask=np_mask, score=np_score)
+        # a polygon's raster is defined on its bounding box with the integer vertices made box-relative (reference
+        # element/polygon.py:105-138,70-77): shifting them back by the integer box origin gives the integer vertices
+        # themselves, so the polygons go to the device as they are (no per-polygon box / relative-polygon objects)
+        _native.paint_polys([polygon.to_np_array() for polygon in polygons], values=values, mask=np_mask, score=np_score)
     mask = Mask(mat=np_mask) if want_mask else None
     score_map = ScoreMap(mat=np_score, is_prob=False) if values is not None else None
     return mask, score_map
