@@ -51,6 +51,8 @@ while time.time() - t0 < budget:
         want = [warp(image.mat, M, dsize), warp(mask.mat, M, dsize), warp(score.mat, M, dsize)]
     for got, exp, what in zip((res.image.mat, res.mask.mat, res.score_map.mat), want, ('image', 'mask', 'score_map')):
         assert got.shape == exp.shape and (got == exp).all(), (policy.name, level, (h, w), seed, what)
-    assert len(res.points) == 6
+    # (PointTuple.from_np_array drops a closing duplicate -- first == last -- like the reference, element/point.py:156-166:
+    #  the affine family returns 5 points when the first and the last random point coincide after the transform)
+    assert len(res.points) in (5, 6), (policy.name, level, (h, w), seed, len(res.points), [p.to_xy_pair() for p in pts])
     counts[policy.name] = counts.get(policy.name, 0) + 1
 print('soak4 ok', counts, round(time.time() - t0), 's')

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fifth soak: the deterministic photometric operators end to end -- policy-sampled configs at random levels on random RGB
+"""Fifth soak: the deterministic photometric operators (ellipse_streak included) end to end -- policy-sampled configs at random levels on random RGB
 pages through ``DistortionPolicy.distort``, against the oracle called with the sampled config.
 Usage: tools/soak5.py <seconds> <seed>"""
 import os
@@ -56,6 +56,8 @@ ORACLES = {
                                               c.enable_vert, c.enable_hori),
     'rectangle_streak': lambda m, c: O.rectangle_streak(m, c.thickness, c.aspect_ratio, c.dash_thickness, c.dash_gap,
                                                         c.short_side_min, c.short_side_step, c.color, c.alpha),
+    'ellipse_streak': lambda m, c: O.ellipse_streak(m, c.thickness, c.aspect_ratio, c.short_side_min, c.short_side_step, c.color,
+                                                    c.alpha),
 }
 factories = [P_blur.gaussian_blur_policy_factory, P_blur.defocus_blur_policy_factory, P_blur.motion_blur_policy_factory,
              P_blur.zoom_in_blur_policy_factory, P_color.mean_shift_policy_factory, P_color.color_shift_policy_factory,
@@ -63,7 +65,7 @@ factories = [P_blur.gaussian_blur_policy_factory, P_blur.defocus_blur_policy_fac
              P_color.boundary_equalization_policy_factory, P_color.histogram_equalization_policy_factory,
              P_color.complement_policy_factory, P_color.posterization_policy_factory, P_color.color_balance_policy_factory,
              P_effect.pixelation_policy_factory, P_streak.line_streak_policy_factory,
-             P_streak.rectangle_streak_policy_factory]
+             P_streak.rectangle_streak_policy_factory, P_streak.ellipse_streak_policy_factory]
 policies = [f.create(None) for f in factories]
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
