@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""C2 timing: similarity_mls (level 5) grid remap only, 2048^2 RGB, one ragged batch through the fused tile kernel
-(device resident).  MLS states are built on the host (pure Python per vertex), so the batch is 16 images."""
+"""C2 timing (BASELINE config 1): similarity_mls (level 5) grid remap only, 2048^2 RGB, batch 64, one ragged batch through
+the fused tile kernel (device resident).  The states are built per image with the device lattice projection."""
 import json
 import os
 import sys
@@ -15,7 +15,7 @@ from vkit_amd.batch import ChainBatch
 from vkit_amd.mechanism import distortion as D
 from vkit_amd.mechanism.distortion_policy.geometric import mls as P_mls
 
-B, SIZE = 16, 2048
+B, SIZE = 64, 2048
 ctx = N.Context(0)
 gen = P_mls.SimilarityMlsConfigGenerator(P_mls.SimilarityMlsConfigGeneratorConfig(), 5)
 t0 = time.perf_counter()
