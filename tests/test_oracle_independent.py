@@ -1,0 +1,244 @@
+"""Second opinions for the oracle's [cv2] restatements from libraries that ARE installed here (scipy, matplotlib, numpy).
+
+cv2 is absent, so none of the [cv2] members can be pinned bit for bit.  What can be checked is that
+each restatement computes the OPERATION OpenCV documents -- bilinear resampling at the given coordinates, a Gaussian of the
+given sigma with reflect-101 borders, the HSV / HLS / grey colour models, polygon coverage, pinhole projection ... -- by
+comparing it with an independent implementation of that operation within the tolerance the fixed-point arithmetic of the
+restatement explains (stated per test).  A wrong tap order, border mode, coordinate convention, channel order or scale
+factor fails these tests; a wrong rounding of the last bit does not -- that is what `parity unpinned` means.
+"""
+import colorsys
+
+import numpy as np
+import pytest
+from numpy.random import default_rng
+from scipy import ndimage
+from scipy.spatial.transform import Rotation
+
+import oracle as O
+
+
+def _smooth_image(rng, h, w, cn=3):
+    """Band-limited random image: neighbouring pixels differ by a few grey levels, so a 1/32-px coordinate quantisation
+    moves a bilinear sample by well under one level."""
+    base = rng.random((h // 8 + 3, w // 8 + 3, cn))
+    img = ndimage.zoom(base, (8, 8, 1), order=3)[:h, :w]
+    img = (img - img.min()) / (img.max() - img.min())
+    return np.ascontiguousarray((img * 255).round().astype(np.uint8))
+
+
+def test_remap_is_bilinear_resampling_with_zero_border():
+    rng = default_rng(1)
+    img = _smooth_image(rng, 96, 128)
+    yy, xx = np.mgrid[0:80, 0:100].astype(np.float32)
+    mx = (xx * 1.17 + 6 * np.sin(yy / 9) - 4).astype(np.float32)        # leaves the source on the left / right
+    my = (yy * 1.11 + 5 * np.cos(xx / 11) - 3).astype(np.float32)
+    got = O.remap(img, mx, my).astype(np.int32)
+    ref = np.stack([ndimage.map_coordinates(img[:, :, c].astype(np.float64), [my, mx], order=1, mode='grid-constant', cval=0.0)
+                    for c in range(3)], -1)
+    # cv.remap quantises the coordinates to 1/32 px: 1/64 px of error per axis times the local gradient (<= 33 levels per
+    # pixel inside this image, the full pixel value across the zero border) plus the rounding
+    inside = (mx >= 0) & (mx <= 127) & (my >= 0) & (my <= 95)
+    err = np.abs(got - ref).max(axis=2)
+    assert err[inside].max() <= 2.0 and err.max() <= 255 / 64 * 2 + 1
+    score = rng.random((96, 128), dtype=np.float32)
+    got_f = O.remap(score, mx, my)
+    ref_f = ndimage.map_coordinates(score.astype(np.float64), [my, mx], order=1, mode='grid-constant', cval=0.0)
+    assert np.abs(got_f - ref_f).max() <= 0.04                             # 1/32-px quantisation on white noise
+    mask = (rng.random((96, 128)) < 0.5).astype(np.uint8)
+    got_m = O.remap(mask, mx, my)
+    assert set(np.unique(got_m)) <= {0, 1}
+    ref_m = ndimage.map_coordinates(mask.astype(np.float64), [my, mx], order=1, mode='grid-constant', cval=0.0)
+    clear = np.abs(ref_m - 0.5) > 0.05                                     # away from the rounding threshold
+    assert (got_m[clear] == (ref_m[clear] > 0.5)).all()
+
+
+def test_warp_affine_and_perspective_resample_through_the_inverse_matrix():
+    rng = default_rng(2)
+    img = _smooth_image(rng, 90, 110)
+    M = np.array([[0.9, -0.25, 14.0], [0.2, 0.95, -6.0]])
+    dsize = (120, 100)                                                      # (width, height)
+    got = O.warp_affine(img, M, dsize).astype(np.int32)
+    A = np.vstack([M, [0, 0, 1]])
+    Ai = np.linalg.inv(A)
+    yy, xx = np.mgrid[0:dsize[1], 0:dsize[0]].astype(np.float64)
+    sx = Ai[0, 0] * xx + Ai[0, 1] * yy + Ai[0, 2]
+    sy = Ai[1, 0] * xx + Ai[1, 1] * yy + Ai[1, 2]
+    ref = np.stack([ndimage.map_coordinates(img[:, :, c].astype(np.float64), [sy, sx], order=1, mode='grid-constant', cval=0.0)
+                    for c in range(3)], -1)
+    inside = (sx >= 0) & (sx <= 109) & (sy >= 0) & (sy <= 89)
+    err = np.abs(got - ref).max(axis=2)
+    assert err[inside].max() <= 2.0 and err.max() <= 255 / 64 * 2 + 1
+    P = np.array([[1.05, 0.08, -3.0], [-0.04, 0.97, 5.0], [1.2e-4, -0.8e-4, 1.0]])
+    got = O.warp_perspective(img, P, dsize).astype(np.int32)
+    Pi = np.linalg.inv(P)
+    den = Pi[2, 0] * xx + Pi[2, 1] * yy + Pi[2, 2]
+    sx = (Pi[0, 0] * xx + Pi[0, 1] * yy + Pi[0, 2]) / den
+    sy = (Pi[1, 0] * xx + Pi[1, 1] * yy + Pi[1, 2]) / den
+    ref = np.stack([ndimage.map_coordinates(img[:, :, c].astype(np.float64), [sy, sx], order=1, mode='grid-constant', cval=0.0)
+                    for c in range(3)], -1)
+    inside = (sx >= 0) & (sx <= 109) & (sy >= 0) & (sy <= 89)
+    err = np.abs(got - ref).max(axis=2)
+    assert err[inside].max() <= 2.0 and err.max() <= 255 / 64 * 2 + 1
+
+
+def test_perspective_transform_solves_the_four_point_system():
+    rng = default_rng(3)
+    for _ in range(50):
+        src = np.array([[0, 0], [40, 0], [40, 30], [0, 30]], np.float32) + rng.normal(0, 3, (4, 2)).astype(np.float32)
+        dst = src + rng.normal(0, 4, (4, 2)).astype(np.float32)
+        H = O.get_perspective_transform(src, dst)
+        # the DLT system of cv.getPerspectiveTransform, solved independently
+        A, b = [], []
+        for (x, y), (u, v) in zip(src.astype(np.float64), dst.astype(np.float64)):
+            A.append([x, y, 1, 0, 0, 0, -x * u, -y * u]); b.append(u)
+            A.append([0, 0, 0, x, y, 1, -x * v, -y * v]); b.append(v)
+        ref = np.append(np.linalg.solve(np.array(A), np.array(b)), 1.0).reshape(3, 3)
+        assert np.abs(H - ref).max() <= 1e-7 * max(1.0, np.abs(ref).max())
+        p = np.c_[src.astype(np.float64), np.ones(4)] @ H.T
+        assert np.abs(p[:, :2] / p[:, 2:] - dst).max() <= 1e-6
+
+
+def test_gaussian_blur_is_a_gaussian_with_reflect_101_borders():
+    rng = default_rng(4)
+    img = rng.integers(0, 256, (70, 90, 3), dtype=np.uint8)
+    for ksize, sigma in ((3, 0.7), (5, 1.0), (7, 2.0)):
+        got = O.gaussian_blur(img, ksize, sigma).astype(np.float64)
+        r = ksize // 2
+        k = np.exp(-np.arange(-r, r + 1) ** 2 / (2.0 * sigma * sigma))
+        k /= k.sum()
+        ref = ndimage.correlate1d(ndimage.correlate1d(img.astype(np.float64), k, axis=0, mode='mirror'), k, axis=1, mode='mirror')
+        # 8-bit kernel coefficients (each off by up to 1/512 of 255 levels, twice) and 8.8 intermediate sums
+        assert np.abs(got - ref).max() <= 1.5, (ksize, sigma)
+        assert sum(O.gaussian_kernel_q8(ksize, sigma)) == 256
+
+
+def test_filter2d_is_a_correlation_with_reflect_101_borders():
+    rng = default_rng(5)
+    img = rng.integers(0, 256, (40, 50, 3), dtype=np.uint8)
+    kernel = rng.random((5, 7)).astype(np.float32)
+    kernel /= kernel.sum()
+    got = O.filter2d(img, kernel).astype(np.float64)
+    ref = np.stack([ndimage.correlate(img[:, :, c].astype(np.float64), kernel.astype(np.float64), mode='mirror')
+                    for c in range(3)], -1)
+    assert np.abs(got - ref).max() <= 0.51                                  # float32 accumulation + rounding to uint8
+
+
+def test_colour_models():
+    rng = default_rng(6)
+    px = rng.integers(0, 256, (4000, 3), dtype=np.uint8)
+    px[:8] = [[0, 0, 0], [255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [128, 128, 128], [255, 255, 0], [0, 255, 255]]
+    img = px.reshape(50, 80, 3)
+    hsv = O.rgb2hsv_full(img).reshape(-1, 3).astype(np.float64)
+    hls = O.rgb2hls_full(img).reshape(-1, 3).astype(np.float64)
+    gray = O.rgb2gray(img).reshape(-1).astype(np.float64)
+    for i, (r, g, b) in enumerate(px / 255.0):
+        h, s, v = colorsys.rgb_to_hsv(r, g, b)
+        assert abs(hsv[i, 2] - v * 255) <= 0.5 and abs(hsv[i, 1] - s * 255) <= 1.0, px[i]
+        if s * v > 0.08:                                                     # the hue is ill-conditioned near grey
+            dh = abs(hsv[i, 0] - h * 256)
+            assert min(dh, 256 - dh) <= 1.5 + 0.35 / (s * v), (px[i], hsv[i], h * 256)
+        hh, l, ss = colorsys.rgb_to_hls(r, g, b)
+        assert abs(hls[i, 1] - l * 255) <= 0.51 and abs(hls[i, 2] - ss * 255) <= 1.0 + (2.0 if min(l, 1 - l) < 0.02 else 0.0), px[i]
+    # ITU-R BT.601 luma, OpenCV's coefficients
+    assert np.abs(gray - (px @ np.array([0.299, 0.587, 0.114]))).max() <= 0.51
+    # the round trips return the pixel within the quantisation of the 8-bit intermediate (greys exactly: s == 0)
+    back = O.hsv2rgb_full(O.rgb2hsv_full(img)).astype(np.int32)
+    assert np.abs(back - img).max() <= 4 and (back[0, [0, 1, 5]] == img[0, [0, 1, 5]]).all()
+    back = O.hls2rgb_full(O.rgb2hls_full(img)).astype(np.int32)
+    assert np.abs(back - img).max() <= 4
+    # a hue shift by a full turn is the identity of the round trip; by a third of a turn it rotates the primaries
+    assert (O.color_shift_rgb(img, 256) == O.color_shift_rgb(img, 0)).all()
+    prim = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255]]], np.uint8)
+    rot = O.color_shift_rgb(prim, 85).astype(np.int32)                      # 85 / 256 of a turn: red -> green -> blue -> red
+    assert np.abs(rot - prim[:, [1, 2, 0]].astype(np.int32)).max() <= 4
+
+
+def test_fill_poly_covers_the_polygon():
+    from matplotlib.path import Path
+    rng = default_rng(7)
+    for _ in range(30):
+        n = int(rng.integers(3, 9))
+        ang = np.sort(rng.uniform(0, 2 * np.pi, n))
+        rad = rng.uniform(8, 28, n)
+        pts = np.stack([32 + rad * np.cos(ang), 32 + rad * np.sin(ang)], 1).round().astype(np.int32)   # star-shaped, simple
+        mask = O.fill_poly((64, 64), pts)
+        yy, xx = np.mgrid[0:64, 0:64]
+        centres = np.c_[xx.ravel(), yy.ravel()].astype(np.float64)
+        inside = Path(pts.astype(np.float64)).contains_points(centres).reshape(64, 64)
+        # distance of every pixel centre from the polygon's boundary
+        a, b = pts.astype(np.float64), np.roll(pts, -1, axis=0).astype(np.float64)
+        ab = b - a
+        t = np.clip(((centres[:, None, :] - a) * ab).sum(-1) / np.maximum((ab * ab).sum(-1), 1e-12), 0, 1)
+        dist = np.sqrt((((a + t[..., None] * ab) - centres[:, None, :]) ** 2).sum(-1)).min(axis=1).reshape(64, 64)
+        assert mask[inside & (dist > 1.0)].all()                            # the interior is filled
+        assert not mask[~inside & (dist > 1.0)].any()                       # nothing further than a pixel outside
+        for x, y in pts:
+            assert mask[y, x] == 1                                          # vertices belong to the raster (the outline is drawn)
+
+
+def test_resize_linear_and_area_follow_the_half_pixel_convention():
+    rng = default_rng(8)
+    img = _smooth_image(rng, 64, 96)
+    for dh, dw in ((40, 50), (100, 130)):
+        got = O.resize_linear(img, (dh, dw)).astype(np.float64)
+        yy, xx = np.mgrid[0:dh, 0:dw].astype(np.float64)
+        sy = np.clip((yy + 0.5) * 64 / dh - 0.5, 0, 63)
+        sx = np.clip((xx + 0.5) * 96 / dw - 0.5, 0, 95)
+        ref = np.stack([ndimage.map_coordinates(img[:, :, c].astype(np.float64), [sy, sx], order=1, mode='nearest')
+                        for c in range(3)], -1)
+        assert np.abs(got - ref).max() <= 1.5, (dh, dw)
+    big = rng.integers(0, 256, (60, 90, 3), dtype=np.uint8)
+    got = O.resize(big, (20, 30), 3).astype(np.float64)                    # INTER_AREA, integer factor 3: box means
+    ref = big.reshape(20, 3, 30, 3, 3).astype(np.float64).mean(axis=(1, 3))
+    assert np.abs(got - ref).max() <= 0.51
+
+
+def test_rodrigues_and_pinhole_projection():
+    rng = default_rng(9)
+    for _ in range(40):
+        rvec = rng.normal(0, 0.8, 3)
+        R = O.rodrigues(rvec)
+        assert np.abs(R - Rotation.from_rotvec(rvec).as_matrix()).max() <= 1e-12
+        pts = rng.uniform(-50, 50, (20, 3)) + [0, 0, 400]
+        tvec = rng.normal(0, 5, 3)
+        fx, fy, cx, cy = 900.0, 870.0, 320.0, 240.0
+        got = O.project_points(pts, rvec, tvec, fx, fy, cx, cy)
+        cam = pts @ R.T + tvec
+        ref = np.stack([fx * cam[:, 0] / cam[:, 2] + cx, fy * cam[:, 1] / cam[:, 2] + cy], 1)
+        assert np.abs(got - ref).max() <= 1e-9
+    assert np.abs(O.rodrigues(np.zeros(3)) - np.eye(3)).max() == 0
+
+
+def test_ellipse_outline_follows_the_parametric_ellipse():
+    # the vertices handed to the polyline are points of the ellipse (7-decimal sine table: 1e-5 of the axis)
+    for axes in ((60, 30), (25, 70), (200, 200)):
+        v = O.ellipse_vertices((300, 250), axes).astype(np.float64) / 65536.0
+        f = ((v[:, 0] - 300) / axes[0]) ** 2 + ((v[:, 1] - 250) / axes[1]) ** 2
+        assert np.abs(f - 1).max() <= 2e-4 + 2.0 / 65536, axes
+
+
+@pytest.mark.parametrize('angle', [0, 30, 90, 137])
+def test_motion_kernel_is_a_normalised_line(angle):
+    k = O.motion_kernel(7, angle)
+    n = k.shape[0]
+    # (the reference normalises the line BEFORE it rotates and smooths it: the sum drifts from 1 by a per cent or so)
+    assert k.shape == (n, n) and n % 2 == 1 and n >= 15 and abs(float(k.sum()) - 1.0) <= 0.03 and (k >= 0).all()
+    yy, xx = np.mgrid[-(n // 2):n // 2 + 1, -(n // 2):n // 2 + 1]
+    t = np.deg2rad(angle)
+    # the mass sits on a line through the centre at `angle` (either handedness: the test pins the shape, not the sign)
+    spread = min(float((k * np.abs(xx * np.sin(t) + yy * np.cos(t))).sum()), float((k * np.abs(xx * np.sin(t) - yy * np.cos(t))).sum()))
+    assert spread / float(k.sum()) <= 1.0
+    assert float((k * np.hypot(xx, yy)).sum()) / float(k.sum()) >= 2.5    # ... and it is a line of length ~2 r, not a blob
+
+
+def test_histogram_equalisation_is_the_cumulative_map():
+    rng = default_rng(10)
+    plane = np.clip(rng.normal(110, 30, (80, 100)), 0, 255).astype(np.uint8)
+    got = O.equalize_hist_plane(plane).astype(np.int64)
+    hist = np.bincount(plane.ravel(), minlength=256)
+    cdf = np.cumsum(hist)
+    first = int(hist[np.nonzero(hist)[0][0]])
+    lut = np.clip(np.round((cdf - first) * 255.0 / (plane.size - first)), 0, 255).astype(np.int64)
+    assert np.abs(got - lut[plane]).max() <= 1                              # float32 scale in cv.equalizeHist: ties may differ
+    assert got.min() == 0 and got.max() == 255
