@@ -242,3 +242,43 @@ def test_histogram_equalisation_is_the_cumulative_map():
     lut = np.clip(np.round((cdf - first) * 255.0 / (plane.size - first)), 0, 255).astype(np.int64)
     assert np.abs(got - lut[plane]).max() <= 1                              # float32 scale in cv.equalizeHist: ties may differ
     assert got.min() == 0 and got.max() == 255
+
+
+def _resample_separable(img, dsize, weights_fn, taps):
+    """Float64 separable resampling at OpenCV's half-pixel coordinates with replicated borders; weights_fn(t) -> `taps`
+    weights for the taps floor(s) - taps/2 + 1 ... at fractional offset t."""
+    def axis(mat, n_out, ax):
+        n_in = mat.shape[ax]
+        s = (np.arange(n_out) + 0.5) * n_in / n_out - 0.5
+        base = np.floor(s).astype(int)
+        t = s - base
+        w = np.stack([weights_fn(tt) for tt in t])                           # [n_out, taps]
+        idx = np.clip(base[:, None] + np.arange(-(taps // 2) + 1, taps // 2 + 1)[None, :], 0, n_in - 1)
+        taken = np.take(mat, idx, axis=ax)                                   # axis ax replaced by (n_out, taps)
+        shape = [1] * taken.ndim
+        shape[ax], shape[ax + 1] = n_out, taps
+        return (taken * w.reshape(shape)).sum(axis=ax + 1)
+    out = axis(img.astype(np.float64), dsize[0], 0)
+    return axis(out, dsize[1], 1)
+
+
+def test_resize_cubic_and_lanczos4_weights():
+    rng = default_rng(11)
+    img = _smooth_image(rng, 48, 64)
+
+    def keys(t, a=-0.75):                                                   # the bicubic kernel OpenCV documents (A = -0.75)
+        x = np.array([t + 1, t, 1 - t, 2 - t])
+        return np.where(x <= 1, ((a + 2) * x - (a + 3)) * x * x + 1, ((a * x - 5 * a) * x + 8 * a) * x - 4 * a)
+
+    def lanczos4(t):
+        x = np.arange(-3, 5) - t
+        w = np.where(np.abs(x) < 1e-12, 1.0, np.sinc(x) * np.sinc(x / 4.0))
+        return w / w.sum()
+
+    for dsize in ((70, 90), (30, 45)):
+        got = O.resize_cubic(img, dsize).astype(np.float64)
+        ref = np.clip(_resample_separable(img, dsize, keys, 4), 0, 255)
+        assert np.abs(got - ref).max() <= 1.5, ('cubic', dsize)
+        got = O.resize(img, dsize, 4).astype(np.float64)                    # cv.INTER_LANCZOS4
+        ref = np.clip(_resample_separable(img, dsize, lanczos4, 8), 0, 255)
+        assert np.abs(got - ref).max() <= 1.5, ('lanczos4', dsize)
