@@ -282,3 +282,23 @@ def test_resize_cubic_and_lanczos4_weights():
         got = O.resize(img, dsize, 4).astype(np.float64)                    # cv.INTER_LANCZOS4
         ref = np.clip(_resample_separable(img, dsize, lanczos4, 8), 0, 255)
         assert np.abs(got - ref).max() <= 1.5, ('lanczos4', dsize)
+
+
+def test_product_camera_math_against_scipy():
+    """The host-side camera model of the product (geometric/camera.py: its own float64 Rodrigues / projectPoints, the cv2
+    calls of the reference's camera.py:96-118) against scipy's rotation and the pinhole formula."""
+    from vkit_amd.mechanism.distortion.geometric import camera as C
+    rng = default_rng(12)
+    for _ in range(40):
+        rvec = rng.normal(0, 0.9, 3)
+        R = C.rodrigues(rvec)
+        assert np.abs(R - Rotation.from_rotvec(rvec).as_matrix()).max() <= 1e-12
+        assert np.abs(R - O.rodrigues(rvec)).max() <= 1e-15                  # product and oracle: the same numbers
+        pts = rng.uniform(-80, 80, (30, 3)) + [0, 0, 600]
+        tvec = rng.normal(0, 8, 3)
+        K = np.array([[910.0, 0, 400.0], [0, 905.0, 300.0], [0, 0, 1]])
+        got = C.project_points(pts, rvec, tvec, K)
+        cam = pts @ R.T + tvec
+        ref = np.stack([K[0, 0] * cam[:, 0] / cam[:, 2] + K[0, 2], K[1, 1] * cam[:, 1] / cam[:, 2] + K[1, 2]], 1)
+        assert (np.abs(got - ref) <= 1e-12 * np.maximum(1.0, np.abs(ref))).all()
+    assert (C.rodrigues(np.zeros(3)) == np.eye(3)).all()
