@@ -125,3 +125,52 @@ def test_device_noise_in_batch_and_pipeline():
     assert (second == O.add_noise_i16(base, O.noise_normal_i16(tuple(dshape) + (3,), 10.0, nxt))).all()
     assert (first != second).mean() > 0.5
     batch.close()
+
+
+def test_operator_api_on_the_overlapped_path():
+    """``HostPipeline.submit_distortion`` returns what ``distortion.distort`` returns: pixel elements, points, polygons,
+    result shape, config / state on request -- for similarity_mls and a camera model, several jobs in flight."""
+    from vkit_amd.element import Image, Mask, Point, PointList, Polygon, ScoreMap
+    from vkit_amd.hostpipe import HostPipeline
+    from vkit_amd.mechanism import distortion as D
+    from vkit_amd.mechanism.distortion_policy.geometric import camera as P_cam, mls as P_mls
+    rng = default_rng(41)
+    jobs = []
+    for k, (op, gen) in enumerate([(D.similarity_mls, P_mls.SimilarityMlsConfigGenerator(P_mls.SimilarityMlsConfigGeneratorConfig(), 5)),
+                                   (D.camera_cubic_curve, P_cam.CameraCubicCurveConfigGenerator(P_cam.CameraCubicCurveConfigGeneratorConfig(), 6)),
+                                   (D.similarity_mls, P_mls.SimilarityMlsConfigGenerator(P_mls.SimilarityMlsConfigGeneratorConfig(), 9))] * 2):
+        h, w = int(rng.integers(100, 400)), int(rng.integers(100, 400))
+        image = Image(mat=rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
+        mask = Mask(mat=(rng.random((h, w)) < 0.5).astype(np.uint8))
+        score = ScoreMap(mat=rng.random((h, w), dtype=np.float32))
+        points = PointList(Point.create(y=int(y), x=int(x)) for y, x in zip(rng.integers(0, h - 1, 5), rng.integers(0, w - 1, 5)))
+        polygons = [Polygon.from_xy_pairs([(10, 10), (w - 12, 14), (w - 20, h - 15), (8, h - 11)])]
+        config = gen((h, w), default_rng(k))
+        jobs.append((op, config, image, mask, score, points, polygons))
+    with HostPipeline(depth=4, lanes=4) as pipe:
+        tickets = [pipe.submit_distortion(op, config, image=image, mask=mask if k % 2 == 0 else None, score_map=score,
+                                          points=points, polygons=polygons, get_config=True, get_state=(k == 1))
+                   for k, (op, config, image, mask, score, points, polygons) in enumerate(jobs[:4])]
+        results = [pipe.result_distortion(t, copy=True) for t in tickets]
+        # more jobs than slots: results are read as they are recycled
+        for k, job in enumerate(jobs[4:], start=4):
+            op, config, image, mask, score, points, polygons = job
+            t = pipe.submit_distortion(op, config, image=image, mask=mask, score_map=score, points=points, polygons=polygons)
+            results.append(pipe.result_distortion(t, copy=True))
+    for k, (res, (op, config, image, mask, score, points, polygons)) in enumerate(zip(results, jobs)):
+        with_mask = mask if (k >= 4 or k % 2 == 0) else None
+        want = op.distort(config, image=image, mask=with_mask, score_map=score, points=points, polygons=polygons,
+                          get_config=k < 4, get_state=(k == 1))
+        assert res.shape == want.shape
+        np.testing.assert_array_equal(res.image.mat, want.image.mat)
+        if with_mask is not None:
+            np.testing.assert_array_equal(res.mask.mat, want.mask.mat)
+        else:
+            assert res.mask is None
+        np.testing.assert_array_equal(res.score_map.mat.view(np.uint32), want.score_map.mat.view(np.uint32))
+        assert [p.to_xy_pair() for p in res.points] == [p.to_xy_pair() for p in want.points]
+        assert [poly.to_xy_pairs() for poly in res.polygons] == [poly.to_xy_pairs() for poly in want.polygons]
+        assert (res.config is not None) == (k < 4) and (res.state is not None) == (k == 1)
+    with HostPipeline() as pipe:
+        with pytest.raises(TypeError):
+            pipe.submit_distortion(D.rotate, {'angle': 3}, image=jobs[0][2])
