@@ -672,6 +672,48 @@ __global__ void __launch_bounds__(256) k_resize_sep(const T *__restrict__ src, i
     const int ylast = min(y0 + kSepTileH, dh) - 1;
     const int rmin = clip_index(yofs[y0] - LEFT, sh), rmax = clip_index(yofs[ylast] + KS / 2, sh);
     const int nrows = rmax - rmin + 1;
+    if constexpr (sizeof(T) == 1) {
+        // uint8: a thread keeps its column -- tap offset and the KS coefficients are loaded once, not once per source row --
+        // and, when no tap is clipped, fetches the KS x CN consecutive source bytes of a row as whole dwords
+        const int hx = threadIdx.x & 63, hdx = x0 + hx;
+        if (hdx < dw) {
+            const int s0 = xofs[hdx] - LEFT;
+            int a[KS];
+#pragma unroll
+            for (int j = 0; j < KS; j++) a[j] = (int)xa[hdx * KS + j];
+            const bool whole = s0 >= 0 && s0 + KS <= sw;
+            constexpr int NB = KS * CN, ND = (NB + 3) / 4;
+            typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+            for (int r = threadIdx.x >> 6; r < nrows; r += 4) {
+                const uint8_t *row = (const uint8_t *)src + (ptrdiff_t)(rmin + r) * sstride;
+                int hsum[CN];
+#pragma unroll
+                for (int c = 0; c < CN; c++) hsum[c] = 0;
+                // (the last dword may reach up to 3 bytes past the taps: only inside the row, never past the plane)
+                if (whole && (ptrdiff_t)(s0 * CN + ND * 4) <= (ptrdiff_t)sw * CN) {
+                    uint32_t w[ND];
+#pragma unroll
+                    for (int q = 0; q < ND; q++) w[q] = *(const u32_unaligned *)(row + (ptrdiff_t)s0 * CN + 4 * q);
+#pragma unroll
+                    for (int j = 0; j < KS; j++)
+#pragma unroll
+                        for (int c = 0; c < CN; c++) {
+                            const int b = j * CN + c;
+                            hsum[c] += (int)((w[b >> 2] >> (8 * (b & 3))) & 0xffu) * a[j];
+                        }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < KS; j++) {
+                        const int sx = clip_index(s0 + j, sw) * CN;
+#pragma unroll
+                        for (int c = 0; c < CN; c++) hsum[c] += (int)row[sx + c] * a[j];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < CN; c++) hbuf[(r * kSepTileW + hx) * CN + c] = (AT)hsum[c];
+            }
+        }
+    } else {
     for (int idx = threadIdx.x; idx < nrows * kSepTileW; idx += 256) {
         const int r = idx / kSepTileW, lx = idx - r * kSepTileW, dx = x0 + lx;
         if (dx >= dw) continue;
@@ -684,22 +726,54 @@ __global__ void __launch_bounds__(256) k_resize_sep(const T *__restrict__ src, i
             const CT a = xa[dx * KS + j];
 #pragma unroll
             for (int c = 0; c < CN; c++) {
-                if constexpr (sizeof(T) == 1) {
-                    const AT term = (AT)((int)row[sx + c] * (int)a);
-                    hsum[c] = j == 0 ? term : hsum[c] + term;
-                } else {
-                    const AT term = row[sx + c] * a;
-                    hsum[c] = j == 0 ? term : hsum[c] + term;
-                }
+                const AT term = row[sx + c] * a;
+                hsum[c] = j == 0 ? term : hsum[c] + term;
             }
         }
 #pragma unroll
         for (int c = 0; c < CN; c++) hbuf[(r * kSepTileW + lx) * CN + c] = hsum[c];
     }
+    }
     __syncthreads();
     const int lx = threadIdx.x & 63, dx = x0 + lx;
+    // the destination row is the same for the 64 lanes of a wavefront: row offsets and vertical coefficients are scalar
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if constexpr (sizeof(T) == 1 && CN == 3) {
+        // RGB: four neighbouring lanes store their 12 bytes as three dwords (the group store of the fused chain kernel)
+        typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+        const int tw = min(kSepTileW, dw - x0), full4 = (tw >> 2) << 2;
+        const int right4 = min(lx + 1, 63) << 2;
+        for (int y = y0 + wave; y <= ylast; y += 4) {
+            const int t0 = yofs[y] - LEFT;
+            int acc[3] = {0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < KS; k++) {
+                const AT *h = hbuf + ((clip_index(t0 + k, sh) - rmin) * kSepTileW + lx) * 3;
+                const int b = (int)yb[y * KS + k];
+#pragma unroll
+                for (int c = 0; c < 3; c++) acc[c] += (int)h[c] * b;
+            }
+            uint32_t P = 0;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int r = (acc[c] + (1 << 21)) >> 22;
+                P |= (uint32_t)(r < 0 ? 0 : (r > 255 ? 255 : r)) << (8 * c);
+            }
+            const uint32_t Pn = (uint32_t)__builtin_amdgcn_ds_bpermute(right4, (int)P);
+            if (dx >= dw) continue;
+            uint8_t *orow = (uint8_t *)dst + (ptrdiff_t)y * dstride;
+            const int m = lx & 3;
+            if (lx < full4) {
+                if (m < 3) *(u32_unaligned *)(orow + (ptrdiff_t)x0 * 3 + (lx >> 2) * 12 + m * 4) = (P >> (8 * m)) | (Pn << (24 - 8 * m));
+            } else {
+                uint8_t *o = orow + (ptrdiff_t)dx * 3;
+                o[0] = (uint8_t)P; o[1] = (uint8_t)(P >> 8); o[2] = (uint8_t)(P >> 16);
+            }
+        }
+        return;
+    }
     if (dx >= dw) return;
-    for (int y = y0 + (threadIdx.x >> 6); y <= ylast; y += 4) {
+    for (int y = y0 + wave; y <= ylast; y += 4) {
         const int t0 = yofs[y] - LEFT;
         AT acc[CN];
 #pragma unroll
