@@ -314,10 +314,11 @@ def _synthetic_page_input(seed, size=256, n_lines=24):
     )
 
 
-def test_page_assembler_layer_order(N):
+@pytest.mark.parametrize('size,n_lines', [(256, 24), (1024, 64)])      # (1024, 64): BASELINE config 3's page, 64 text layers
+def test_page_assembler_layer_order(N, size, n_lines):
     from vkit_amd.mechanism.distortion import rotate
     from vkit_amd.pipeline import text_detection as T
-    step_input = _synthetic_page_input(seed=7)
+    step_input = _synthetic_page_input(seed=7, size=size, n_lines=n_lines)
     page = T.page_assembler_step_factory.create().run(step_input, default_rng(0)).page
 
     # the same layer list applied one by one with the oracle, in the reference's order
@@ -357,13 +358,14 @@ def test_page_assembler_layer_order(N):
     assert (page.image.mat != step_input.page_background_step_output.background_image.mat).any()
 
 
-def test_page_distortion_step(N):
+@pytest.mark.parametrize('size,n_lines,seeds', [(256, 24, 6), (1024, 64, 2)])   # (1024, 64): BASELINE config 3's page
+def test_page_distortion_step(N, size, n_lines, seeds):
     from oracle_replay import REPLAYABLE, replay
     from vkit_amd.mechanism.distortion_policy import random_distortion_factory
     from vkit_amd.mechanism.distortion_policy.random_distortion import RandomDistortionDebug
     from vkit_amd.element import Mask, PointList
     from vkit_amd.pipeline import text_detection as T
-    step_input = _synthetic_page_input(seed=9)
+    step_input = _synthetic_page_input(seed=9, size=size, n_lines=n_lines)
     page_output = T.page_assembler_step_factory.create().run(step_input, default_rng(0))
     # every policy the oracle can replay from (config, state) stays enabled -- the two pass-through members included;
     # the members whose random planes are rebuilt elsewhere (test_gpu_pointwise.py) are switched off here
@@ -373,7 +375,7 @@ def test_page_distortion_step(N):
     step = T.page_distortion_step_factory.create({'random_distortion_factory_config': factory_config})
     shapes = set()
     replayed = set()
-    for seed in range(6):
+    for seed in range(seeds):
         out = step.run(T.PageDistortionStepInput(page_output), default_rng(seed))
         shapes.add(out.page_image.shape)
 
@@ -451,7 +453,7 @@ def test_page_distortion_step(N):
         assert out.page_char_heights == [float(v) for v in char_h]
         assert out.page_seal_impression_char_mask.mat.sum() > 0
     assert len(shapes) > 1  # geometric distortions did change the page shape, so the resize branch ran
-    assert len(replayed) >= 6, replayed
+    assert len(replayed) >= (6 if seeds >= 6 else 2), replayed
 
 
 @pytest.mark.parametrize('src_shape,dst_shape', [((20, 30), (33, 47)), ((64, 64), (32, 32)), ((97, 131), (40, 55)),
