@@ -310,6 +310,12 @@ int vkx_fill_u8_dev(vkx_ctx *ctx, uint8_t *dst, int h, int w, int cn, ptrdiff_t 
                     const vkx_layer *layers, int n_layers);
 int vkx_fill_u8(vkx_ctx *ctx, uint8_t *dst, int h, int w, int cn, ptrdiff_t dst_stride,
                 const vkx_layer *layers, int n_layers);
+/* The layer lists of n_pages equally shaped device destinations in ONE launch (a batch of pages assembled together,
+ * PageAssemblerStep.run per page of the batch): page p takes layers[layer_begin[p] .. layer_begin[p + 1]) in order, with the
+ * pixels vkx_fill_u8_dev(dsts[p], ...) would produce.  dsts_host: HOST array of n_pages device pointers; layer_begin_host:
+ * HOST int32 [n_pages + 1], layer_begin[0] == 0. */
+int vkx_fill_u8_batch_dev(vkx_ctx *ctx, uint8_t *const *dsts_host, int n_pages, int h, int w, int cn, ptrdiff_t dst_stride,
+                          const vkx_layer *layers, const int32_t *layer_begin_host);
 
 /* float32 destinations: ScoreMap fills (Box.fill_score_map element/box.py:368-392, Mask.fill_score_map
  * element/mask.py:575-599, Polygon.fill_score_map element/polygon.py:475-487), the label height maps of

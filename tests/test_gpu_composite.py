@@ -481,3 +481,66 @@ def test_pixelation_operator(N):
     np.testing.assert_array_equal(D.pixelation.distort({'ratio': 0.5}, image=big).image.mat, O.pixelation(big.mat, 0.5))
     np.testing.assert_array_equal(image.to_resized_image(resized_height=100, cv_resize_interpolation=1).mat,
                                   O.resize_linear(image.mat, (100, round(100 * 311 / 257))))
+
+
+def test_fill_batch_matches_per_page_calls(N):
+    """vkx_fill_u8_batch_dev: the layer lists of several equally shaped device pages in one launch equal the per-page calls
+    (and the oracle's sequential fills) -- pages with many layers, one layer, no layer; shared alpha planes."""
+    import ctypes
+    ctx, lib = N.default_ctx(), N.lib()
+    rng = default_rng(55)
+    h, w, cn = 150, 210, 3
+    n_pages = 6
+    pages = [rng.integers(0, 256, (h, w, cn), dtype=np.uint8) for _ in range(n_pages)]
+    counts = [9, 1, 0, 17, 2, 30]
+    keep, specs, layer_begin = [], [], [0]
+    total = sum(counts)
+    layers = (N.VkxLayer * max(total, 1))()
+    k = 0
+    for p, cnt in enumerate(counts):
+        for _ in range(cnt):
+            bh, bw = int(rng.integers(1, h)), int(rng.integers(1, w))
+            up, left = int(rng.integers(0, h - bh + 1)), int(rng.integers(0, w - bw + 1))
+            kind = int(rng.integers(3))
+            L = layers[k]
+            L.up, L.left, L.height, L.width = up, left, bh, bw
+            color = tuple(int(v) for v in rng.integers(0, 256, 3))
+            for c in range(3):
+                L.value_const[c] = color[c]
+            alpha = mask = None
+            if kind == 0:
+                alpha = (rng.random((bh, bw), dtype=np.float32) * (rng.random((bh, bw)) < 0.5)).astype(np.float32)
+                d = ctx.malloc(alpha.nbytes); ctx.upload(d, alpha); keep.append(d)
+                L.alpha, L.alpha_stride_el, L.alpha_scalar = d, bw, 1.0
+            elif kind == 1:
+                mask = (rng.random((bh, bw)) < 0.4).astype(np.uint8)
+                d = ctx.malloc(mask.nbytes); ctx.upload(d, mask); keep.append(d)
+                L.mask, L.mask_stride, L.alpha_scalar = d, bw, float(rng.choice([1.0, 0.35]))
+            else:
+                L.alpha_scalar = float(rng.choice([1.0, 0.6, 0.0]))
+            specs.append((p, (up, left, bh, bw), color, alpha, mask, float(L.alpha_scalar)))
+            k += 1
+        layer_begin.append(k)
+    d_batch = [ctx.malloc(pg.nbytes) for pg in pages]
+    d_single = [ctx.malloc(pg.nbytes) for pg in pages]
+    for dp, ds, pg in zip(d_batch, d_single, pages):
+        ctx.upload(dp, pg); ctx.upload(ds, pg)
+    ptrs = (ctypes.c_void_p * n_pages)(*d_batch)
+    begin = np.asarray(layer_begin, np.int32)
+    N.check(lib.vkx_fill_u8_batch_dev(ctx.handle, ptrs, n_pages, h, w, cn, w * cn, layers, begin.ctypes.data))
+    for p in range(n_pages):
+        if counts[p]:
+            sub = ctypes.cast(ctypes.byref(layers[layer_begin[p]]), ctypes.POINTER(N.VkxLayer))
+            N.check(lib.vkx_fill_u8_dev(ctx.handle, d_single[p], h, w, cn, w * cn, sub, counts[p]))
+    for p in range(n_pages):
+        got_b, got_s = np.empty_like(pages[p]), np.empty_like(pages[p])
+        ctx.download(d_batch[p], got_b); ctx.download(d_single[p], got_s)
+        ctx.sync()
+        np.testing.assert_array_equal(got_b, got_s, err_msg=f'page {p}')
+        want = pages[p].copy()
+        for (pp, box, color, alpha, mask, a) in specs:
+            if pp == p:
+                O.fill(want, box, color, mask=mask, alpha=alpha if alpha is not None else a)
+        np.testing.assert_array_equal(got_b, want, err_msg=f'page {p} vs oracle')
+    for d in keep + d_batch + d_single:
+        ctx.free(d)

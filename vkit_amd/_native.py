@@ -197,6 +197,7 @@ for _sfx in ('', '_dev'):
     _SIGNATURES['vkx_ellipse_mask_u8' + _sfx] = [c_void_p, c_void_p, c_ssize, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int]
     _SIGNATURES['vkx_ellipse_streak_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_double]
 
+_SIGNATURES['vkx_fill_u8_batch_dev'] = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_ssize, ctypes.POINTER(VkxLayer), c_void_p]
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['vkx_version', 'vkx_last_error', 'vkx_ctx_stream'])
 
 _lib = None

@@ -8,6 +8,8 @@
 // untouched pixels are neither read nor written.
 #include "vkx_internal.h"
 
+#include <string.h>
+
 #include <vector>
 
 namespace {
@@ -70,9 +72,15 @@ template <typename T, int CN>
 __global__ void __launch_bounds__(256) k_composite(T *dst, ptrdiff_t dstride, int h, int w,
                                                    const LayerDev<T> *__restrict__ layers,
                                                    const int *__restrict__ tile_ids, const int *__restrict__ tile_begin,
-                                                   const int *__restrict__ tile_layers, int tiles_x)
+                                                   const int *__restrict__ tile_layers, int tiles_x,
+                                                   T *const *__restrict__ pages = nullptr, int tiles_per_page = 0)
 {
-    const int tile = tile_ids[blockIdx.x];
+    int tile = tile_ids[blockIdx.x];
+    if (pages) {                       // a batch of equally shaped destinations: the tile id carries the page
+        const int page = tile / tiles_per_page;
+        tile -= page * tiles_per_page;
+        dst = pages[page];
+    }
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int x = tx * kTileW + (threadIdx.x & 63);
     const int ybase = ty * kTileH + (threadIdx.x >> 6);
@@ -131,15 +139,33 @@ __global__ void __launch_bounds__(256) k_composite(T *dst, ptrdiff_t dstride, in
 
 // Host side of k_composite: bins `devl` (already validated, skippable layers removed) into tiles, stages the CSR and
 // the layer records in ctx->misc, launches.
+// `page_begin` (size n_pages + 1, or empty for a single destination): layers [page_begin[p], page_begin[p + 1]) belong to
+// destination pages[p]; all destinations share h, w and the row pitch.
 template <typename T, int CN>
-int composite_launch(vkx_ctx *ctx, T *dst, int h, int w, ptrdiff_t dstride, const std::vector<LayerDev<T>> &devl)
+int composite_launch(vkx_ctx *ctx, T *dst, int h, int w, ptrdiff_t dstride, const std::vector<LayerDev<T>> &devl,
+                     T *const *pages = nullptr, const std::vector<int> &page_begin = std::vector<int>())
 {
     const int tiles_x = (w + kTileW - 1) / kTileW, tiles_y = (h + kTileH - 1) / kTileH;
-    std::vector<int> count((size_t)tiles_x * tiles_y, 0);
-    for (const LayerDev<T> &L : devl)
+    const int tiles_pp = tiles_x * tiles_y, n_pages = pages ? (int)page_begin.size() - 1 : 1;
+    if ((long long)tiles_pp * n_pages > 0x7fffffffLL) return VKX_ERR_UNSUPPORTED;
+    auto page_of = [&](size_t i) {     // layers are grouped by page in ascending order
+        int p = 0;
+        while (pages && (int)i >= page_begin[(size_t)p + 1]) p++;
+        return p;
+    };
+    std::vector<int> count((size_t)tiles_pp * n_pages, 0), layer_page(devl.size(), 0);
+    for (size_t i = 0, p = 0; i < devl.size(); i++) {
+        while (pages && (int)i >= page_begin[p + 1]) p++;
+        layer_page[i] = (int)p;
+    }
+    (void)page_of;
+    for (size_t i = 0; i < devl.size(); i++) {
+        const LayerDev<T> &L = devl[i];
+        const size_t base_t = (size_t)layer_page[i] * tiles_pp;
         for (int ty = L.up / kTileH; ty <= (L.up + L.height - 1) / kTileH; ty++)
-            for (int tx = L.left / kTileW; tx <= (L.left + L.width - 1) / kTileW; tx++) count[(size_t)ty * tiles_x + tx]++;
-    std::vector<int> tile_ids, tile_begin, slot((size_t)tiles_x * tiles_y, -1);
+            for (int tx = L.left / kTileW; tx <= (L.left + L.width - 1) / kTileW; tx++) count[base_t + (size_t)ty * tiles_x + tx]++;
+    }
+    std::vector<int> tile_ids, tile_begin, slot(count.size(), -1);
     int total = 0;
     for (size_t t = 0; t < count.size(); t++)
         if (count[t]) {
@@ -152,25 +178,33 @@ int composite_launch(vkx_ctx *ctx, T *dst, int h, int w, ptrdiff_t dstride, cons
     std::vector<int> cursor(tile_begin.begin(), tile_begin.end() - 1), tile_layers((size_t)total);
     for (size_t i = 0; i < devl.size(); i++) {
         const LayerDev<T> &L = devl[i];
+        const size_t base_t = (size_t)layer_page[i] * tiles_pp;
         for (int ty = L.up / kTileH; ty <= (L.up + L.height - 1) / kTileH; ty++)
             for (int tx = L.left / kTileW; tx <= (L.left + L.width - 1) / kTileW; tx++)
-                tile_layers[(size_t)cursor[slot[(size_t)ty * tiles_x + tx]]++] = (int)i;   // ascending i per tile
+                tile_layers[(size_t)cursor[slot[base_t + (size_t)ty * tiles_x + tx]]++] = (int)i;   // ascending i per tile
     }
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o0 = 0, o1 = o0 + up(sizeof(LayerDev<T>) * devl.size()), o2 = o1 + up(sizeof(int) * tile_ids.size());
-    const size_t o3 = o2 + up(sizeof(int) * tile_begin.size()), bytes = o3 + up(sizeof(int) * tile_layers.size());
+    const size_t o3 = o2 + up(sizeof(int) * tile_begin.size()), o4 = o3 + up(sizeof(int) * tile_layers.size());
+    const size_t bytes = o4 + up(sizeof(T *) * (pages ? (size_t)n_pages : 0));
     int rc = vkx_scratch_reserve(ctx, &ctx->misc, bytes);
     if (rc) return rc;
     unsigned char *base = (unsigned char *)ctx->misc.ptr;
-    VKX_HIP(hipMemcpyAsync(base + o0, devl.data(), sizeof(LayerDev<T>) * devl.size(), hipMemcpyHostToDevice, ctx->stream));
-    VKX_HIP(hipMemcpyAsync(base + o1, tile_ids.data(), sizeof(int) * tile_ids.size(), hipMemcpyHostToDevice, ctx->stream));
-    VKX_HIP(hipMemcpyAsync(base + o2, tile_begin.data(), sizeof(int) * tile_begin.size(), hipMemcpyHostToDevice, ctx->stream));
-    VKX_HIP(hipMemcpyAsync(base + o3, tile_layers.data(), sizeof(int) * tile_layers.size(), hipMemcpyHostToDevice, ctx->stream));
-    VKX_HIP(hipStreamSynchronize(ctx->stream)); // the vectors live on this frame
+    // the tables travel as ONE copy out of the ctx's page-locked descriptor ring: the launch returns without a stream
+    // synchronisation (a page assembler issues one such call per page)
+    void *ring = nullptr;
+    if ((rc = vkx_desc_ring_take(ctx, bytes, &ring))) return rc;
+    unsigned char *stage = (unsigned char *)ring;
+    memcpy(stage + o0, devl.data(), sizeof(LayerDev<T>) * devl.size());
+    memcpy(stage + o1, tile_ids.data(), sizeof(int) * tile_ids.size());
+    memcpy(stage + o2, tile_begin.data(), sizeof(int) * tile_begin.size());
+    memcpy(stage + o3, tile_layers.data(), sizeof(int) * tile_layers.size());
+    if (pages) memcpy(stage + o4, pages, sizeof(T *) * (size_t)n_pages);
+    VKX_HIP(hipMemcpyAsync(base, stage, bytes, hipMemcpyHostToDevice, ctx->stream));
     { VKX_TIMED(ctx, "k_composite");
       k_composite<T, CN><<<(unsigned)tile_ids.size(), 256, 0, ctx->stream>>>(
           dst, dstride, h, w, (const LayerDev<T> *)(base + o0), (const int *)(base + o1), (const int *)(base + o2),
-          (const int *)(base + o3), tiles_x); }
+          (const int *)(base + o3), tiles_x, pages ? (T *const *)(base + o4) : nullptr, tiles_pp); }
     VKX_LAUNCH_CHECK();
     return VKX_OK;
 }
@@ -246,6 +280,45 @@ VKX_EXPORT int vkx_fill_u8_dev(vkx_ctx *ctx, uint8_t *dst, int h, int w, int cn,
     case 1: return composite_launch<uint8_t, 1>(ctx, dst, h, w, dst_stride, devl);
     case 3: return composite_launch<uint8_t, 3>(ctx, dst, h, w, dst_stride, devl);
     default: return composite_launch<uint8_t, 4>(ctx, dst, h, w, dst_stride, devl);
+    }
+}
+
+// The layer lists of n_pages equally shaped uint8 destinations in ONE launch (a batch of pages assembled together: the
+// per-page launch is latency bound -- 1024 workgroups for a 1024^2 page).  Page p takes layers[layer_begin[p] ..
+// layer_begin[p + 1]) in order, exactly as vkx_fill_u8_dev(dsts[p], ...) would.
+VKX_EXPORT int vkx_fill_u8_batch_dev(vkx_ctx *ctx, uint8_t *const *dsts_host, int n_pages, int h, int w, int cn,
+                                     ptrdiff_t dst_stride, const vkx_layer *layers, const int32_t *layer_begin_host)
+{
+    VKX_REQUIRE(ctx && dsts_host && layer_begin_host, "NULL argument");
+    VKX_REQUIRE(n_pages >= 1 && cn >= 1, "bad batch");
+    VKX_REQUIRE(cn == 1 || cn == 3 || cn == 4, "1, 3 or 4 channels");
+    VKX_REQUIRE(layer_begin_host[0] == 0, "layer_begin[0] must be 0");
+    for (int p = 0; p < n_pages; p++) {
+        VKX_REQUIRE(dsts_host[p] != nullptr, "NULL destination");
+        VKX_REQUIRE(layer_begin_host[p + 1] >= layer_begin_host[p], "layer_begin must not decrease");
+    }
+    const int n_layers = layer_begin_host[n_pages];
+    VKX_REQUIRE(n_layers == 0 || layers, "bad layer list");
+    int rc = check_layers(layers, n_layers, h, w);
+    if (rc) return rc;
+    std::vector<LayerDev<uint8_t>> devl;
+    std::vector<int> page_begin((size_t)n_pages + 1, 0);
+    devl.reserve((size_t)n_layers);
+    for (int p = 0; p < n_pages; p++) {
+        for (int i = layer_begin_host[p]; i < layer_begin_host[p + 1]; i++) {
+            LayerDev<uint8_t> L;
+            if (!to_layer_dev(layers[i], &L)) continue;
+            L.value = layers[i].value; L.value_stride = layers[i].value_stride;
+            for (int c = 0; c < 4; c++) L.value_const[c] = layers[i].value_const[c];
+            devl.push_back(L);
+        }
+        page_begin[(size_t)p + 1] = (int)devl.size();
+    }
+    if (devl.empty()) return VKX_OK;
+    switch (cn) {
+    case 1: return composite_launch<uint8_t, 1>(ctx, nullptr, h, w, dst_stride, devl, dsts_host, page_begin);
+    case 3: return composite_launch<uint8_t, 3>(ctx, nullptr, h, w, dst_stride, devl, dsts_host, page_begin);
+    default: return composite_launch<uint8_t, 4>(ctx, nullptr, h, w, dst_stride, devl, dsts_host, page_begin);
     }
 }
 
