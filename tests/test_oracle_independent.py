@@ -302,3 +302,41 @@ def test_product_camera_math_against_scipy():
         ref = np.stack([K[0, 0] * cam[:, 0] / cam[:, 2] + K[0, 2], K[1, 1] * cam[:, 1] / cam[:, 2] + K[1, 2]], 1)
         assert (np.abs(got - ref) <= 1e-12 * np.maximum(1.0, np.abs(ref))).all()
     assert (C.rodrigues(np.zeros(3)) == np.eye(3)).all()
+
+
+def test_grid_to_map_is_the_per_cell_inverse_homography():
+    """ImageGrid.generate_remap_params (grid_rendering/type.py:209-261) restated by the oracle: every destination pixel well
+    inside a destination cell maps through that cell's quad -> quad homography, solved here independently (numpy DLT)."""
+    from matplotlib.path import Path
+    rng = default_rng(13)
+    ys, xs = np.arange(0, 121, 24), np.arange(0, 145, 24)
+    sv = np.array([[(x, y) for x in xs] for y in ys], np.int32)                      # [rows, cols, (x, y)]
+    dv = sv + rng.integers(-6, 7, sv.shape)
+    dv[..., 0] -= dv[..., 0].min()
+    dv[..., 1] -= dv[..., 1].min()
+    shape = (int(dv[..., 1].max()) + 1, int(dv[..., 0].max()) + 1)
+    mx, my = O.grid_to_map(sv, dv, shape)
+    yy, xx = np.mgrid[0:shape[0], 0:shape[1]]
+    centres = np.c_[xx.ravel(), yy.ravel()].astype(np.float64)
+    checked = 0
+    for r in range(len(ys) - 1):
+        for c in range(len(xs) - 1):
+            dq = np.array([dv[r, c], dv[r, c + 1], dv[r + 1, c + 1], dv[r + 1, c]], np.float64)
+            sq = np.array([sv[r, c], sv[r, c + 1], sv[r + 1, c + 1], sv[r + 1, c]], np.float64)
+            A, b = [], []
+            for (x, y), (u, v) in zip(dq, sq):                                        # destination -> source
+                A.append([x, y, 1, 0, 0, 0, -x * u, -y * u]); b.append(u)
+                A.append([0, 0, 0, x, y, 1, -x * v, -y * v]); b.append(v)
+            H = np.append(np.linalg.solve(np.array(A), np.array(b)), 1.0).reshape(3, 3)
+            # pixels at least 2 px inside this cell: no neighbour's outline can own them
+            a, bb = dq, np.roll(dq, -1, axis=0)
+            ab = bb - a
+            t = np.clip(((centres[:, None, :] - a) * ab).sum(-1) / (ab * ab).sum(-1), 0, 1)
+            dist = np.sqrt((((a + t[..., None] * ab) - centres[:, None, :]) ** 2).sum(-1)).min(axis=1)
+            inside = Path(dq).contains_points(centres) & (dist > 2.0)
+            p = np.c_[centres[inside], np.ones(int(inside.sum()))] @ H.T
+            want = p[:, :2] / p[:, 2:]
+            got = np.c_[mx.ravel()[inside], my.ravel()[inside]]
+            assert np.abs(got - want).max() <= 1e-3                                   # float32 storage of the map
+            checked += int(inside.sum())
+    assert checked > 0.5 * shape[0] * shape[1]
