@@ -8,6 +8,9 @@ namespace {
 struct CoordMap {      // cv.remap: coordinates come from two float planes
     const float *mx, *my;
     ptrdiff_t stride;
+    struct Column {};
+    __device__ __forceinline__ Column column(int) const { return Column(); }
+    __device__ __forceinline__ void at(const Column &, int x, int y, int &X, int &Y) const { (*this)(x, y, X, Y); }
     __device__ __forceinline__ void operator()(int x, int y, int &X, int &Y) const
     {
         X = vkd::cv_round(mx[(ptrdiff_t)y * stride + x] * 32.f);
@@ -17,6 +20,20 @@ struct CoordMap {      // cv.remap: coordinates come from two float planes
 
 struct CoordAffine {   // warpAffine: inverse matrix, AB_BITS = 10 fixed point
     double m[6];
+    // adelta[x] / bdelta[x] of cv::warpAffine depend on the column only: a lane that walks several rows of its column
+    // computes them once
+    struct Column { int adelta, bdelta; };
+    __device__ __forceinline__ Column column(int x) const
+    {
+        return Column{vkd::cv_round(m[0] * x * 1024), vkd::cv_round(m[3] * x * 1024)};
+    }
+    __device__ __forceinline__ void at(const Column &c, int, int y, int &X, int &Y) const
+    {
+        const int X0 = vkd::cv_round((m[1] * y + m[2]) * 1024) + 16;
+        const int Y0 = vkd::cv_round((m[4] * y + m[5]) * 1024) + 16;
+        X = (X0 + c.adelta) >> 5;
+        Y = (Y0 + c.bdelta) >> 5;
+    }
     __device__ __forceinline__ void operator()(int x, int y, int &X, int &Y) const
     {
         const int adelta = vkd::cv_round(m[0] * x * 1024);
@@ -31,6 +48,9 @@ struct CoordAffine {   // warpAffine: inverse matrix, AB_BITS = 10 fixed point
 struct CoordPerspective { // warpPerspective: inverse matrix, per pixel in double, 32x32 blocks
     double m[9];
     int bw0;
+    struct Column {};
+    __device__ __forceinline__ Column column(int) const { return Column(); }
+    __device__ __forceinline__ void at(const Column &, int x, int y, int &X, int &Y) const { (*this)(x, y, X, Y); }
     __device__ __forceinline__ void operator()(int x, int y, int &X, int &Y) const
     {
         const int xb = (x / bw0) * bw0, x1 = x - xb;
@@ -49,6 +69,8 @@ struct CoordPerspective { // warpPerspective: inverse matrix, per pixel in doubl
 typedef unsigned long long u64_u1 __attribute__((aligned(1)));
 typedef uint32_t u32_u1 __attribute__((aligned(1)));
 
+constexpr int kRgbRows = 4;      // rows a wavefront of the RGB path walks
+
 template <int CN, class Coord>
 __global__ void __launch_bounds__(256) k_sample_u8(const uint8_t *__restrict__ src, int sh, int sw, ptrdiff_t sstride,
                                                    uint8_t *__restrict__ dst, int dh, int dw, ptrdiff_t dstride,
@@ -61,45 +83,50 @@ __global__ void __launch_bounds__(256) k_sample_u8(const uint8_t *__restrict__ s
         // inside the source takes two unaligned 8-byte loads (6 bytes each are the tap pair of a row), horizontal pairs as
         // v_dot4_u32_u8, the vertical pair as 24-bit multiply-adds: the same integer as the four weighted taps.  Four
         // neighbouring lanes write their 12 bytes as three dwords.
-        if (y >= dh) return;                    // uniform over the wavefront (a wavefront is one row of the block)
+        // a wavefront walks kRgbRows consecutive rows of its 64 columns: per-column coordinate terms are computed once
         const int lane = threadIdx.x;
         const bool active = x < dw;
-        uint32_t P = 0;                         // r | g << 8 | b << 16
-        if (active) {
-            int X, Y;
-            coord(x, y, X, Y);
-            const int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
-            if ((unsigned)sx < (unsigned)max(sw - 2, 0) && (unsigned)sy < (unsigned)(sh - 1)) {
-                const uint8_t *q = src + (ptrdiff_t)sy * sstride + (ptrdiff_t)sx * 3;   // 3 sx + 8 <= 3 sw
-                const unsigned long long ta = *(const u64_u1 *)q, tb = *(const u64_u1 *)(q + sstride);
-                const uint32_t wx = (uint32_t)(32 - fx) | ((uint32_t)fx << 24);
-                const uint32_t t0 = (uint32_t)ta, t1 = (uint32_t)(ta >> 32), b0 = (uint32_t)tb, b1 = (uint32_t)(tb >> 32);
-                const uint32_t ar = __builtin_amdgcn_udot4(t0, wx, 0u, false);
-                const uint32_t ag = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t1, t0, 1), wx, 0u, false);
-                const uint32_t ab = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t1, t0, 2), wx, 0u, false);
-                const uint32_t br = __builtin_amdgcn_udot4(b0, wx, 0u, false);
-                const uint32_t bg = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b1, b0, 1), wx, 0u, false);
-                const uint32_t bb = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b1, b0, 2), wx, 0u, false);
-                const uint32_t wy0 = (uint32_t)(32 - fy), wy1 = (uint32_t)fy;
-                const uint32_t r = (__umul24(br, wy1) + __umul24(ar, wy0) + 512u) >> 10;
-                const uint32_t g = (__umul24(bg, wy1) + __umul24(ag, wy0) + 512u) >> 10;
-                const uint32_t b = (__umul24(bb, wy1) + __umul24(ab, wy0) + 512u) >> 10;
-                P = r | (g << 8) | (b << 16);
-            } else {
-                uint8_t px[3];
-                vkd::sample_u8<3>(src, sh, sw, sstride, X, Y, px);
-                P = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);
+        const typename Coord::Column col = coord.column(x);
+        for (int rr = 0; rr < kRgbRows; rr++) {
+            const int yy = (blockIdx.y * 4 + threadIdx.y) * kRgbRows + rr;
+            if (yy >= dh) break;                // uniform over the wavefront
+            uint32_t P = 0;                     // r | g << 8 | b << 16
+            if (active) {
+                int X, Y;
+                coord.at(col, x, yy, X, Y);
+                const int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
+                if ((unsigned)sx < (unsigned)max(sw - 2, 0) && (unsigned)sy < (unsigned)(sh - 1)) {
+                    const uint8_t *q = src + (ptrdiff_t)sy * sstride + (ptrdiff_t)sx * 3;   // 3 sx + 8 <= 3 sw
+                    const unsigned long long ta = *(const u64_u1 *)q, tb = *(const u64_u1 *)(q + sstride);
+                    const uint32_t wx = (uint32_t)(32 - fx) | ((uint32_t)fx << 24);
+                    const uint32_t t0 = (uint32_t)ta, t1 = (uint32_t)(ta >> 32), b0 = (uint32_t)tb, b1 = (uint32_t)(tb >> 32);
+                    const uint32_t ar = __builtin_amdgcn_udot4(t0, wx, 0u, false);
+                    const uint32_t ag = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t1, t0, 1), wx, 0u, false);
+                    const uint32_t ab = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t1, t0, 2), wx, 0u, false);
+                    const uint32_t br = __builtin_amdgcn_udot4(b0, wx, 0u, false);
+                    const uint32_t bg = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b1, b0, 1), wx, 0u, false);
+                    const uint32_t bb = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b1, b0, 2), wx, 0u, false);
+                    const uint32_t wy0 = (uint32_t)(32 - fy), wy1 = (uint32_t)fy;
+                    const uint32_t r = (__umul24(br, wy1) + __umul24(ar, wy0) + 512u) >> 10;
+                    const uint32_t g = (__umul24(bg, wy1) + __umul24(ag, wy0) + 512u) >> 10;
+                    const uint32_t b = (__umul24(bb, wy1) + __umul24(ab, wy0) + 512u) >> 10;
+                    P = r | (g << 8) | (b << 16);
+                } else {
+                    uint8_t px[3];
+                    vkd::sample_u8<3>(src, sh, sw, sstride, X, Y, px);
+                    P = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);
+                }
             }
-        }
-        const uint32_t Pn = (uint32_t)__builtin_amdgcn_ds_bpermute(min(lane + 1, 63) << 2, (int)P);
-        if (!active) return;
-        uint8_t *drow = dst + (ptrdiff_t)y * dstride;
-        const int m = x & 3;
-        if (x < (dw & ~3)) {
-            if (m < 3) *(u32_u1 *)(drow + (ptrdiff_t)(x >> 2) * 12 + m * 4) = (P >> (8 * m)) | (Pn << (24 - 8 * m));
-        } else {
-            uint8_t *d = drow + (ptrdiff_t)x * 3;
-            d[0] = (uint8_t)P; d[1] = (uint8_t)(P >> 8); d[2] = (uint8_t)(P >> 16);
+            const uint32_t Pn = (uint32_t)__builtin_amdgcn_ds_bpermute(min(lane + 1, 63) << 2, (int)P);
+            if (!active) continue;
+            uint8_t *drow = dst + (ptrdiff_t)yy * dstride;
+            const int m = x & 3;
+            if (x < (dw & ~3)) {
+                if (m < 3) *(u32_u1 *)(drow + (ptrdiff_t)(x >> 2) * 12 + m * 4) = (P >> (8 * m)) | (Pn << (24 - 8 * m));
+            } else {
+                uint8_t *d = drow + (ptrdiff_t)x * 3;
+                d[0] = (uint8_t)P; d[1] = (uint8_t)(P >> 8); d[2] = (uint8_t)(P >> 16);
+            }
         }
         return;
     } else {
@@ -138,7 +165,7 @@ int launch_u8(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_
     dim3 block(64, 4), grid(vkx_blocks(dw, 64), vkx_blocks(dh, 4));
     switch (cn) {
     case 1: { VKX_TIMED(ctx, "k_sample_u8"); k_sample_u8<1, Coord><<<grid, block, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, coord); } break;
-    case 3: { VKX_TIMED(ctx, "k_sample_u8"); k_sample_u8<3, Coord><<<grid, block, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, coord); } break;
+    case 3: { VKX_TIMED(ctx, "k_sample_u8"); k_sample_u8<3, Coord><<<dim3(grid.x, vkx_blocks(dh, 4 * kRgbRows)), block, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, coord); } break;
     case 4: { VKX_TIMED(ctx, "k_sample_u8"); k_sample_u8<4, Coord><<<grid, block, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, coord); } break;
     default: vkx_set_error("unsupported channel count %d", cn); return VKX_ERR_UNSUPPORTED;
     }
