@@ -577,27 +577,37 @@ struct StreakParams {
     uint8_t color[4];
 };
 
+constexpr int kStreakRows = 16;     // rows a wavefront walks: the column's stripe phases are computed once
+
 template <int CN>
 __global__ void __launch_bounds__(256) k_line_streak(uint8_t *img, int h, int w, ptrdiff_t stride, StreakParams P)
 {
+    // The stripes cover a fraction thickness / (thickness + gap) of the columns and of the rows: a wavefront walks
+    // kStreakRows rows of its 64 columns, the column's phase in the stripe / dash periods is a per-lane constant, the row's
+    // is uniform over the wavefront, and rows / lanes outside every stripe cost a compare each.
     const int x = blockIdx.x * 64 + threadIdx.x;
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= w || y >= h) return;
-    bool mv = P.enable_vert && (x % P.step) < P.thickness;
-    bool mh = P.enable_hori && (y % P.step) < P.thickness;
-    if (P.dash) {
-        if ((y % P.dash_step) < P.dash_gap) mv = false;
-        if ((x % P.dash_step) < P.dash_gap) mh = false;
-    }
-    if (!mv && !mh) return;
-    uint8_t *d = img + (ptrdiff_t)y * stride + (ptrdiff_t)x * CN;
+    if (x >= w) return;
+    const bool col_v = P.enable_vert && (x % P.step) < P.thickness;          // the column lies in a vertical stripe
+    const bool col_gap = P.dash && (x % P.dash_step) < P.dash_gap;           // ... in a dash gap of the horizontal ones
+    const int y0 = (blockIdx.y * 4 + threadIdx.y) * kStreakRows;
+    uint8_t *d = img + (ptrdiff_t)y0 * stride + (ptrdiff_t)x * CN;
+    for (int r = 0; r < kStreakRows; r++, d += stride) {
+        const int y = y0 + r;
+        if (y >= h) break;
+        bool mv = col_v, mh = P.enable_hori && (y % P.step) < P.thickness;
+        if (P.dash) {
+            if ((y % P.dash_step) < P.dash_gap) mv = false;
+            if (col_gap) mh = false;
+        }
+        if (!mv && !mh) continue;
 #pragma unroll
-    for (int c = 0; c < CN; c++) {
-        uint8_t v = d[c];
-        // vertical stripes first, then horizontal ones: crossings are blended twice (streak.py:96-99)
-        if (mv) v = P.copy ? P.color[c] : blend_u8(v, P.color[c], P.alpha);
-        if (mh) v = P.copy ? P.color[c] : blend_u8(v, P.color[c], P.alpha);
-        d[c] = v;
+        for (int c = 0; c < CN; c++) {
+            uint8_t v = d[c];
+            // vertical stripes first, then horizontal ones: crossings are blended twice (streak.py:96-99)
+            if (mv) v = P.copy ? P.color[c] : blend_u8(v, P.color[c], P.alpha);
+            if (mh) v = P.copy ? P.color[c] : blend_u8(v, P.color[c], P.alpha);
+            d[c] = v;
+        }
     }
 }
 
@@ -1280,7 +1290,7 @@ VKX_EXPORT int vkx_line_streak_u8_dev(vkx_ctx *ctx, uint8_t *img, int h, int w, 
     P.copy = alpha == 1.0;
     P.alpha = (float)alpha;
     for (int c = 0; c < 4; c++) P.color[c] = c < cn ? color[c] : 0;
-    dim3 block(64, 4), grid(vkx_blocks(w, 64), vkx_blocks(h, 4));
+    dim3 block(64, 4), grid(vkx_blocks(w, 64), vkx_blocks(h, 4 * kStreakRows));
     switch (cn) {
     case 1: { VKX_TIMED(ctx, "k_line_streak"); k_line_streak<1><<<grid, block, 0, ctx->stream>>>(img, h, w, stride, P); } break;
     case 3: { VKX_TIMED(ctx, "k_line_streak"); k_line_streak<3><<<grid, block, 0, ctx->stream>>>(img, h, w, stride, P); } break;
