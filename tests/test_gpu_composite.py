@@ -544,3 +544,54 @@ def test_fill_batch_matches_per_page_calls(N):
         np.testing.assert_array_equal(got_b, want, err_msg=f'page {p} vs oracle')
     for d in keep + d_batch + d_single:
         ctx.free(d)
+
+
+def test_chain_batch_assembles_pages_on_the_device(N):
+    """ChainBatch.set_layers: the layer lists of all pages are composited onto the device-resident sources by one batched
+    launch at every run, then the chain runs -- sources and results equal the oracle's sequential fills + chain."""
+    from vkit_amd.batch import ChainBatch
+    from vkit_amd.mechanism import distortion as D
+    from vkit_amd.mechanism.distortion_policy.geometric import camera as P_cam
+    rng = default_rng(77)
+    h, w = 200, 260
+    gen = P_cam.CameraCubicCurveConfigGenerator(P_cam.CameraCubicCurveConfigGeneratorConfig(), 5)
+    batch = ChainBatch()
+    specs = []
+    for p in range(5):
+        state = D.camera_cubic_curve.generate_state(gen((h, w), default_rng(p)), (h, w))
+        noise = rng.integers(-30, 30, tuple(state.result_shape) + (3,)).astype(np.int16)
+        batch.add(rng.integers(0, 256, (h, w, 3), dtype=np.uint8), state, blur_sigma=1.0, hue_delta=20 * p - 37, noise=noise)
+        layers, plan = [N.make_layer((0, 0, h, w), 3, (200 - p, 190, 180))], [((0, 0, h, w), (200 - p, 190, 180), None, 1.0)]
+        for _ in range(int(rng.integers(0, 12))):
+            bh, bw = int(rng.integers(1, h)), int(rng.integers(1, w))
+            box = (int(rng.integers(0, h - bh + 1)), int(rng.integers(0, w - bw + 1)), bh, bw)
+            kind = int(rng.integers(3))
+            if kind == 0:
+                alpha = (rng.random((bh, bw), dtype=np.float32) * (rng.random((bh, bw)) < 0.5)).astype(np.float32)
+                color = tuple(int(v) for v in rng.integers(0, 256, 3))
+                layers.append(N.make_layer(box, 3, color, alpha=alpha)); plan.append((box, color, None, alpha))
+            elif kind == 1:
+                mask = (rng.random((bh, bw)) < 0.4).astype(np.uint8)
+                value = rng.integers(0, 256, (bh, bw, 3), dtype=np.uint8)
+                layers.append(N.make_layer(box, 3, value, mask=mask, alpha=0.7)); plan.append((box, value, mask, 0.7))
+            else:
+                color = tuple(int(v) for v in rng.integers(0, 256, 3))
+                layers.append(N.make_layer(box, 3, color, alpha=0.45)); plan.append((box, color, None, 0.45))
+        if p != 3:                      # page 3 keeps its uploaded source: no layers
+            batch.set_layers(p, layers)
+        specs.append((state, noise, plan if p != 3 else None))
+    uploaded3 = batch.source(3).copy()
+    for rep in range(2):                # the second run starts from the composited pages: the background layer re-initialises
+        batch.run()
+        for p, (state, noise, plan) in enumerate(specs):
+            if plan is None:
+                want_src = uploaded3
+            else:
+                want_src = np.zeros((h, w, 3), np.uint8)
+                for box, value, mask, alpha in plan:
+                    O.fill(want_src, box, value, mask=mask, alpha=alpha)
+            np.testing.assert_array_equal(batch.source(p), want_src, err_msg=f'source {p} run {rep}')
+            mx, my = O.grid_to_map(state.src_image_grid.vertices, state.dst_image_grid.vertices, state.result_shape)
+            want = O.add_noise_i16(O.color_shift_rgb(O.gaussian_blur(O.remap(want_src, mx, my), 5, 1.0), 20 * p - 37), noise)
+            np.testing.assert_array_equal(batch.result(p), want, err_msg=f'result {p} run {rep}')
+    batch.close()

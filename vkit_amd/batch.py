@@ -5,6 +5,7 @@ HBM between the geometric and the photometric members (BASELINE config 3).
 planes) and issues the whole batch with ONE ``vkx_chain_rgb_batch_dev`` call.  Images shard across GPUs by
 giving every process (one per GPU) its own ``ChainBatch``; there is no exchange step.
 """
+import ctypes
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -24,6 +25,8 @@ class ChainBatch:
         self._array = None
         self._device_noise = []      # (item index, std, seed, dh, dw) of the throughput-mode items
         self._runs = 0
+        self._page_layers = {}       # item index -> [VkxLayer with device planes]: assembled into the source before the chain
+        self._layer_tables = None
 
     def _put(self, array: np.ndarray) -> int:
         array = np.ascontiguousarray(array)
@@ -87,6 +90,57 @@ class ChainBatch:
         self._array = None
         return len(self._items) - 1
 
+    def set_layers(self, index: int, layers):
+        """The text / image layers of page ``index`` (``_native.make_layer`` records for its source shape, in paint order:
+        ``PageAssemblerStep.run``, pipeline/text_detection/page_assembler.py:155-236).  Their planes are uploaded once; every
+        ``run`` composites the layers of ALL pages onto the sources with one ``vkx_fill_u8_batch_dev`` launch -- a first layer
+        covering the page re-initialises it -- and then sends the pages through the chain: assembling and distorting a batch
+        of pages never leaves HBM (BASELINE config 3).  All pages of a batch that carry layers must share one source shape."""
+        item = self._items[index]
+        dev_layers = []
+        for layer, _keep in layers:
+            if not isinstance(layer, _native.VkxLayer):
+                raise TypeError('layers for uint8 pages: make_layer(..., dtype=np.uint8)')
+            rec = _native.VkxLayer()
+            ctypes.pointer(rec)[0] = layer
+            for field, nbytes in (('mask', layer.height * layer.width), ('alpha', layer.height * layer.width * 4),
+                                  ('value', layer.height * layer.width * 3)):
+                host = getattr(layer, field)
+                if host:
+                    plane = np.ctypeslib.as_array(ctypes.cast(host, ctypes.POINTER(ctypes.c_uint8)), shape=(nbytes,))
+                    setattr(rec, field, self._put(plane))
+            dev_layers.append(rec)
+        for other in self._page_layers:
+            if (self._items[other].sh, self._items[other].sw) != (item.sh, item.sw):
+                raise ValueError('pages with layers must share one source shape')
+        self._page_layers[index] = dev_layers
+        self._layer_tables = None
+
+    def _composite(self):
+        if self._layer_tables is None:
+            order = sorted(self._page_layers)
+            total = sum(len(self._page_layers[i]) for i in order)
+            table = (_native.VkxLayer * max(total, 1))()
+            begin = np.zeros(len(order) + 1, np.int32)
+            k = 0
+            for n, i in enumerate(order):
+                for rec in self._page_layers[i]:
+                    table[k] = rec
+                    k += 1
+                begin[n + 1] = k
+            ptrs = (ctypes.c_void_p * len(order))(*[self._items[i].src for i in order])
+            first = self._items[order[0]]
+            self._layer_tables = (ptrs, len(order), int(first.sh), int(first.sw), table, begin)
+        ptrs, n, sh, sw, table, begin = self._layer_tables
+        _native.check(_native.lib().vkx_fill_u8_batch_dev(self.ctx.handle, ptrs, n, sh, sw, 3, sw * 3, table, begin.ctypes.data))
+
+    def source(self, index: int) -> np.ndarray:
+        """The (assembled) source page ``index`` as it sits on the device."""
+        self.ctx.sync()
+        item = self._items[index]
+        out = np.empty((int(item.sh), int(item.sw), 3), np.uint8)
+        return self.ctx.download(item.src, out)
+
     def __len__(self):
         return len(self._items)
 
@@ -107,6 +161,8 @@ class ChainBatch:
             _native.check(lib.vkx_noise_normal_i16_dev(self.ctx.handle, self._items[index].noise, dw * 3, dh, dw, 3, std,
                                                        (seed + self._runs * 0x9E3779B97F4A7C15) & 0xffffffffffffffff))
         self._runs += 1
+        if self._page_layers:
+            self._composite()
         _native.check(lib.vkx_chain_rgb_batch_dev(self.ctx.handle, self._array, len(self._items)))
 
     def result(self, index: int) -> np.ndarray:
@@ -121,6 +177,8 @@ class ChainBatch:
         self._owned.clear()
         self._items.clear()
         self._device_noise.clear()
+        self._page_layers.clear()
+        self._layer_tables = None
         self._array = None
 
     def __del__(self):
