@@ -148,17 +148,11 @@ int composite_launch(vkx_ctx *ctx, T *dst, int h, int w, ptrdiff_t dstride, cons
     const int tiles_x = (w + kTileW - 1) / kTileW, tiles_y = (h + kTileH - 1) / kTileH;
     const int tiles_pp = tiles_x * tiles_y, n_pages = pages ? (int)page_begin.size() - 1 : 1;
     if ((long long)tiles_pp * n_pages > 0x7fffffffLL) return VKX_ERR_UNSUPPORTED;
-    auto page_of = [&](size_t i) {     // layers are grouped by page in ascending order
-        int p = 0;
-        while (pages && (int)i >= page_begin[(size_t)p + 1]) p++;
-        return p;
-    };
     std::vector<int> count((size_t)tiles_pp * n_pages, 0), layer_page(devl.size(), 0);
-    for (size_t i = 0, p = 0; i < devl.size(); i++) {
+    for (size_t i = 0, p = 0; i < devl.size(); i++) {      // layers are grouped by page in ascending order
         while (pages && (int)i >= page_begin[p + 1]) p++;
         layer_page[i] = (int)p;
     }
-    (void)page_of;
     for (size_t i = 0; i < devl.size(); i++) {
         const LayerDev<T> &L = devl[i];
         const size_t base_t = (size_t)layer_page[i] * tiles_pp;
