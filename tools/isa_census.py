@@ -105,7 +105,8 @@ def main():
         counts[cur][cls] += 1
         ops[cur][op] += 1
     classes = ['VALU', 'VALU fp64', 'SALU', 'SALU ctl', 'LDS', 'VMEM']
-    meta = re.search(r'\.vgpr_count:\s+(\d+)', text[m.start():])
+    # the kernel's own entry of the amdhsa metadata (entries list .name before .vgpr_count)
+    meta = re.search(r'\.name:\s+' + re.escape(m.group(1)) + r'\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)', text)
     print('# ISA census: k_chain_fused, interior window, 5-tap blur, no streak (static instruction counts)\n')
     print('Generated by `tools/isa_census.py` from the compiler\'s gfx950 assembly of `vkit_amd/csrc/fused.hip` '
           '(`-DVKX_FUSED_CENSUS -g1`); phases from the `.loc` line of every instruction.\n')
@@ -129,7 +130,8 @@ def main():
         top = ', '.join(f'{op} x{c}' for op, c in ops[n].most_common(14))
         print(f'* **{n}**: {top}')
     if meta:
-        print(f'\nVGPRs: {meta.group(1)}')
+        print(f'\nVGPRs of this single-variant build: {meta.group(1)} (the production kernel holds every variant and is compiled to 64 VGPRs, '
+              '8 wavefronts per SIMD)')
 
 
 if __name__ == '__main__':
