@@ -23,8 +23,8 @@ SOLVER_JACOBI = 1  # restatement of OpenCV's built-in DECOMP_SVD path for every 
 
 
 def build(force=False):
-    src = os.path.join(_HERE, 'vkx_oracle.c')
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, 'vkx_oracle.c'), os.path.join(_HERE, 'np_random.c')]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.run(['make', '-C', _HERE], check=True, capture_output=True)
     return _LIB_PATH
 
@@ -782,3 +782,55 @@ def ellipse_vertices(center, axes):
     xy = np.zeros((74, 2), np.int64)
     n = lib().vko_ellipse_vertices(int(center[0]), int(center[1]), int(axes[0]), int(axes[1]), _p(xy))
     return xy[:n]
+
+
+# ---------------------------------------------------------------------------------------------
+# numpy Generator streams (oracle/np_random.c): PCG64 + ziggurat normal + uniform doubles + choice
+# ---------------------------------------------------------------------------------------------
+def np_state_words(rng):
+    """{state lo, state hi, inc lo, inc hi} of a numpy Generator over PCG64."""
+    st = rng.bit_generator.state
+    assert st['bit_generator'] == 'PCG64'
+    s, inc = st['state']['state'], st['state']['inc']
+    m = (1 << 64) - 1
+    return np.array([s & m, s >> 64, inc & m, inc >> 64], np.uint64)
+
+
+def np_normal(words, n, loc, scale):
+    """rng.normal(loc, scale, n) from the state words; returns (samples, words after, raw draws used)."""
+    words = words.copy()
+    out = np.empty(n, np.float64)
+    lib().vko_np_normal.restype = ctypes.c_uint64
+    used = lib().vko_np_normal(_p(words), ctypes.c_int64(n), ctypes.c_double(loc), ctypes.c_double(scale), _p(out))
+    return out, words, used
+
+
+def np_normal_i16(words, n, std):
+    words = words.copy()
+    out = np.empty(n, np.int16)
+    lib().vko_np_normal_i16.restype = ctypes.c_uint64
+    used = lib().vko_np_normal_i16(_p(words), ctypes.c_int64(n), ctypes.c_double(std), _p(out))
+    return out, words, used
+
+
+def np_random(words, n):
+    words = words.copy()
+    out = np.empty(n, np.float64)
+    lib().vko_np_random.restype = ctypes.c_uint64
+    used = lib().vko_np_random(_p(words), ctypes.c_int64(n), _p(out))
+    return out, words, used
+
+
+def np_choice_cdf(words, n, cdf):
+    words = words.copy()
+    cdf = np.ascontiguousarray(cdf, np.float64)
+    out = np.empty(n, np.uint8)
+    lib().vko_np_choice_cdf.restype = ctypes.c_uint64
+    used = lib().vko_np_choice_cdf(_p(words), ctypes.c_int64(n), _p(cdf), len(cdf), _p(out))
+    return out, words, used
+
+
+def np_advance(words, delta):
+    words = words.copy()
+    lib().vko_np_advance(_p(words), ctypes.c_uint64(delta & ((1 << 64) - 1)), ctypes.c_uint64(delta >> 64))
+    return words
