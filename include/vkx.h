@@ -454,6 +454,49 @@ int vkx_paint_polys(vkx_ctx *ctx, const int32_t *pts_host, const int32_t *poly_o
                     const float *values_host, uint8_t *mask, ptrdiff_t mask_stride, float *score,
                     ptrdiff_t score_stride_el, int h, int w);
 
+/* ---- the numpy Generator streams of the noise operators, drawn on the device -------------------------------------
+ * photometric/noise.py:44-54 (gaussion_noise), :160-190 (speckle_noise), :100-157 (impulse_noise) draw from the
+ * caller's numpy Generator (PCG64).  A job = one stream: the generator's 128-bit state and increment
+ * (rng.bit_generator.state['state']) and the number of samples.  The device produces the SAME values numpy would
+ * (PCG64 jump-ahead + the 256-layer ziggurat with its variable number of raw draws per sample resolved by a two-pass
+ * scan), and reports how many raw 64-bit draws the call consumed, so that the caller can advance its generator
+ * (state' = pcg64 jump by `draws`).  Kinds:
+ *   VKX_NP_NORMAL_I16     dst int16 [n]  = np.round(rng.normal(0, scale, n)).astype(int16)
+ *   VKX_NP_NORMAL_ADD_U8  dst uint8 [n]  = clip(int16(src) + the plane above, 0, 255)          (gaussion_noise, fused)
+ *   VKX_NP_SPECKLE_U8     dst uint8 [n]  = uint8(clip(src + src * rng.normal(0, scale, n), 0, 255)) in float64
+ *   VKX_NP_CHOICE3_U8     dst uint8 [n]  = rng.choice((0, 1, 2), n, p) as #{k : cdf[k] <= rng.random()}, cdf = cumsum(p) / sum
+ *   VKX_NP_IMPULSE_U8     dst uint8 [n, cn] = src with salt (255) where the selector is 1, pepper (0) where it is 2
+ * src / dst are dense device arrays (vkx_np_draw_batch_dev: asynchronous on the ctx stream, results_host is valid after a
+ * synchronisation).  exp() / log1p() of the device differ from glibc's in the last bits: a decision or an
+ * emitted integer that could depend on them sets VKX_NP_AMBIGUOUS in the job's result (the caller then redraws that plane
+ * with numpy itself; expected < 1e-6 per 2048^2 plane); VKX_NP_SHORT = the provisioned raw draws did not yield n samples
+ * (same remedy; never observed). */
+#define VKX_NP_NORMAL_I16 0
+#define VKX_NP_NORMAL_ADD_U8 1
+#define VKX_NP_SPECKLE_U8 2
+#define VKX_NP_CHOICE3_U8 3
+#define VKX_NP_IMPULSE_U8 4
+#define VKX_NP_AMBIGUOUS 1u
+#define VKX_NP_SHORT 2u
+typedef struct vkx_np_job {
+    uint64_t state[2];   /* PCG64 state, low / high word */
+    uint64_t inc[2];     /* PCG64 increment, low / high word */
+    int64_t n;           /* samples (normal kinds) or elements (uniform kinds) */
+    int32_t kind, cn;
+    double scale;        /* std of the normal kinds */
+    double cdf[3];       /* uniform kinds */
+    const void *src;     /* device */
+    void *dst;           /* device */
+} vkx_np_job;
+typedef struct vkx_np_result {
+    unsigned long long draws;    /* raw 64-bit draws consumed */
+    unsigned long long samples;  /* samples the provisioned draws yielded (>= n unless VKX_NP_SHORT) */
+    uint32_t flags, reserved;
+} vkx_np_result;
+int vkx_np_draw_batch_dev(vkx_ctx *ctx, const vkx_np_job *jobs_host, int n_jobs, vkx_np_result *results_host);
+/* one job whose src / dst are HOST arrays; synchronous */
+int vkx_np_draw(vkx_ctx *ctx, const vkx_np_job *job, vkx_np_result *result_host);
+
 /* ---- throughput-mode noise plane ---------------------------------------------------------------
  * gaussion_noise (photometric/noise.py:44-54) adds np.round(rng.normal(0, std, shape)) drawn from the caller's numpy
  * Generator; the parity path takes that int16 plane from the caller (vkx_add_noise_i16, vkx_chain_item.noise).

@@ -111,6 +111,32 @@ class VkxLayerF32(ctypes.Structure):
     ]
 
 
+class VkxNpJob(ctypes.Structure):
+    _fields_ = [
+        ('state', ctypes.c_uint64 * 2),
+        ('inc', ctypes.c_uint64 * 2),
+        ('n', ctypes.c_int64),
+        ('kind', ctypes.c_int32),
+        ('cn', ctypes.c_int32),
+        ('scale', c_double),
+        ('cdf', c_double * 3),
+        ('src', c_void_p),
+        ('dst', c_void_p),
+    ]
+
+
+class VkxNpResult(ctypes.Structure):
+    _fields_ = [
+        ('draws', ctypes.c_uint64),
+        ('samples', ctypes.c_uint64),
+        ('flags', ctypes.c_uint32),
+        ('reserved', ctypes.c_uint32),
+    ]
+
+
+NP_NORMAL_I16, NP_NORMAL_ADD_U8, NP_SPECKLE_U8, NP_CHOICE3_U8, NP_IMPULSE_U8 = 0, 1, 2, 3, 4
+NP_AMBIGUOUS, NP_SHORT = 1, 2
+
 FILL_PLAIN, FILL_KEEP_MAX, FILL_KEEP_MIN = 0, 1, 2
 STREAM_COMPUTE, STREAM_COPY_IN, STREAM_COPY_OUT = 0, 1, 2
 
@@ -132,6 +158,8 @@ _SIGNATURES = {
     'vkx_noise_normal_table': [c_double, c_void_p],
     'vkx_noise_normal_i16_dev': [c_void_p, c_void_p, c_ssize, c_int, c_int, c_int, c_double, ctypes.c_uint64],
     'vkx_noise_normal_i16': [c_void_p, c_void_p, c_ssize, c_int, c_int, c_int, c_double, ctypes.c_uint64],
+    'vkx_np_draw_batch_dev': [c_void_p, ctypes.POINTER(VkxNpJob), c_int, ctypes.POINTER(VkxNpResult)],
+    'vkx_np_draw': [c_void_p, ctypes.POINTER(VkxNpJob), ctypes.POINTER(VkxNpResult)],
     'vkx_host_alloc': [c_void_p, c_size, ctypes.POINTER(c_void_p)],
     'vkx_host_free': [c_void_p, c_void_p],
     'vkx_upload_async': [c_void_p, c_void_p, c_void_p, c_size],
@@ -903,6 +931,121 @@ def add_noise_i16(img, noise, ctx=None):
     dst = ctx.pinned_empty(img.shape, img.dtype)
     check(lib().vkx_add_noise_i16(ctx.handle, _ptr(img), h, w, cn, stride, _ptr(noise), w * cn, _ptr(dst), stride))
     return dst
+
+
+# ---- the caller's numpy Generator stream drawn on the device (include/vkx.h: vkx_np_*) -------------------------------
+_PCG_MULT = 0x2360ED051FC65DA44385DF649FCCF645
+_M128 = (1 << 128) - 1
+_M64 = (1 << 64) - 1
+
+
+def np_stream(rng):
+    """(state, inc) of a numpy Generator over PCG64, or None for any other bit generator (the caller then draws on the
+    host).  ``VKX_HOST_RNG=1`` forces the host path."""
+    if os.environ.get('VKX_HOST_RNG', '') == '1':
+        return None
+    bit_generator = getattr(rng, 'bit_generator', None)
+    if type(bit_generator).__name__ != 'PCG64':
+        return None
+    st = bit_generator.state['state']
+    return int(st['state']), int(st['inc'])
+
+
+def pcg64_jump(state, inc, delta):
+    """PCG64 state after ``delta`` raw draws (pcg_advance_lcg_128)."""
+    acc_mult, acc_plus, cur_mult, cur_plus = 1, 0, _PCG_MULT, inc
+    while delta > 0:
+        if delta & 1:
+            acc_mult = (acc_mult * cur_mult) & _M128
+            acc_plus = (acc_plus * cur_mult + cur_plus) & _M128
+        cur_plus = ((cur_mult + 1) * cur_plus) & _M128
+        cur_mult = (cur_mult * cur_mult) & _M128
+        delta >>= 1
+    return (acc_mult * state + acc_plus) & _M128
+
+
+def np_consume(rng, draws):
+    """Moves the caller's generator past ``draws`` raw 64-bit draws, as if numpy had made them: the LCG state jumps, a
+    buffered 32-bit half (``has_uint32``) stays where it is (``bit_generator.advance`` would drop it)."""
+    st = rng.bit_generator.state
+    st['state']['state'] = pcg64_jump(int(st['state']['state']), int(st['state']['inc']), int(draws))
+    rng.bit_generator.state = st
+
+
+def np_job(kind, stream, n, scale=0.0, cdf=(2.0, 2.0, 2.0), cn=1, src=None, dst=None):
+    job = VkxNpJob()
+    state, inc = stream
+    job.state[0], job.state[1] = state & _M64, state >> 64
+    job.inc[0], job.inc[1] = inc & _M64, inc >> 64
+    job.n, job.kind, job.cn, job.scale = int(n), kind, cn, float(scale)
+    for k in range(3):
+        job.cdf[k] = float(cdf[k])
+    job.src, job.dst = src, dst
+    return job
+
+
+def np_draw(kind, rng, dst, src=None, scale=0.0, cdf=(2.0, 2.0, 2.0), cn=1, ctx=None):
+    """One stream job on host arrays (``vkx_np_draw``).  Returns True and advances ``rng`` when the device result is
+    known to be numpy's; False (``rng`` untouched, ``dst`` undefined) when the generator is not PCG64 or a decision fell
+    inside the libm ambiguity margin -- the caller then draws on the host."""
+    stream = np_stream(rng)
+    if stream is None or dst.size == 0:
+        return False
+    ctx = ctx or default_ctx()
+    n = dst.size // cn if kind == NP_IMPULSE_U8 else dst.size
+    job = np_job(kind, stream, n, scale, cdf, cn, _ptr(src) if src is not None else None, _ptr(dst))
+    res = VkxNpResult()
+    rc = lib().vkx_np_draw(ctx.handle, ctypes.byref(job), ctypes.byref(res))
+    if rc == ERR_INVALID:   # a stream the device path does not take (scale / length limits): host
+        return False
+    check(rc)
+    if res.flags:
+        return False
+    np_consume(rng, res.draws)
+    return True
+
+
+def np_gaussion_noise(img, std, rng, ctx=None):
+    """``clip(int16(img) + np.round(rng.normal(0, std, img.shape)).astype(int16), 0, 255)`` with the samples drawn on the
+    device from ``rng``'s stream (photometric/noise.py:44-54); None when the host has to draw."""
+    ctx = ctx or default_ctx()
+    img = np.ascontiguousarray(img)
+    dst = ctx.pinned_empty(img.shape, np.uint8)
+    return dst if np_draw(NP_NORMAL_ADD_U8, rng, dst, img, scale=std, ctx=ctx) else None
+
+
+def np_normal_i16(shape, std, rng, ctx=None):
+    """``np.round(rng.normal(0, std, shape)).astype(np.int16)`` drawn on the device; None when the host has to draw."""
+    ctx = ctx or default_ctx()
+    dst = ctx.pinned_empty(shape, np.int16)
+    return dst if np_draw(NP_NORMAL_I16, rng, dst, scale=std, ctx=ctx) else None
+
+
+def np_speckle_noise(img, std, rng, ctx=None):
+    """``uint8(clip(img + img * rng.normal(0, std, img.shape), 0, 255))`` (photometric/noise.py:172-183)."""
+    ctx = ctx or default_ctx()
+    img = np.ascontiguousarray(img)
+    dst = ctx.pinned_empty(img.shape, np.uint8)
+    return dst if np_draw(NP_SPECKLE_U8, rng, dst, img, scale=std, ctx=ctx) else None
+
+
+def _choice_cdf(p):
+    # Generator.choice: cdf = p.cumsum(); cdf /= cdf[-1]
+    cdf = np.cumsum(np.asarray(p, dtype=np.float64))
+    cdf /= cdf[-1]
+    return cdf
+
+
+def np_impulse_noise(img, prob_salt, prob_pepper, rng, ctx=None):
+    """``rng.choice((0, 1, 2), size=(H, W), p=[keep, salt, pepper])`` drawn on the device and applied
+    (photometric/noise.py:125-150)."""
+    ctx = ctx or default_ctx()
+    img, h, w, cn, _stride = _u8_plane(img)
+    p = np.array([1 - prob_salt - prob_pepper, prob_salt, prob_pepper], dtype=np.float64)
+    if not (p >= 0).all() or not np.isfinite(p).all():
+        return None      # let numpy raise its own error on the host path
+    dst = ctx.pinned_empty(img.shape, np.uint8)
+    return dst if np_draw(NP_IMPULSE_U8, rng, dst, img, cdf=_choice_cdf(p), cn=cn, ctx=ctx) else None
 
 
 def line_streak(img, thickness, gap, dash_thickness, dash_gap, color, alpha, enable_vert, enable_hori, ctx=None):

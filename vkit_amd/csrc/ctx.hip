@@ -67,6 +67,8 @@ VKX_EXPORT int vkx_ctx_destroy(vkx_ctx *ctx)
     for (auto &s : ctx->stage) scratch_release(&s);
     for (auto &s : ctx->chain) scratch_release(&s);
     scratch_release(&ctx->noise_table);
+    scratch_release(&ctx->np_tabs);
+    scratch_release(&ctx->np_work);
     for (auto &t : ctx->resize_tabs) scratch_release(&t.buf);
     for (auto &l : ctx->launches) { (void)hipEventDestroy(l.start); (void)hipEventDestroy(l.stop); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);

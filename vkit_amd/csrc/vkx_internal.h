@@ -60,6 +60,8 @@ struct vkx_ctx {
     vkx_scratch noise_table;          // int16 [65536] inverse-CDF table of vkx_noise_normal_i16 for noise_table_std
     double noise_table_std = 0.0;
     bool noise_table_fits8 = false;
+    vkx_scratch np_tabs;              // jump constants + ziggurat tables of the numpy streams (nprand.hip), uploaded once
+    vkx_scratch np_work;              // per-call tile arrays of the numpy streams
 
     // Host-array pipelines: two copy streams next to the compute stream (created on first use), a pool of events that
     // order them, and a page-locked ring through which the launch descriptors of the tile kernels reach the device
