@@ -476,6 +476,7 @@ int vkx_paint_polys(vkx_ctx *ctx, const int32_t *pts_host, const int32_t *poly_o
 #define VKX_NP_SPECKLE_U8 2
 #define VKX_NP_CHOICE3_U8 3
 #define VKX_NP_IMPULSE_U8 4
+#define VKX_NP_DEBUG_WIDE_MARGIN 0x100 /* or-ed into kind: every wedge test counts as ambiguous (exercises the fallback in tests) */
 #define VKX_NP_AMBIGUOUS 1u
 #define VKX_NP_SHORT 2u
 typedef struct vkx_np_job {

@@ -1,0 +1,175 @@
+"""The numpy Generator streams drawn on the device (include/vkx.h: vkx_np_*) against numpy ITSELF: every value and the
+generator state after the call.  Reference call sites: photometric/noise.py:44-54, 100-157, 160-190."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from vkit_amd import _native as N
+from vkit_amd.mechanism.distortion import gaussion_noise, impulse_noise, speckle_noise
+from vkit_amd.mechanism.distortion.photometric.noise import GaussionNoiseConfig, ImpulseNoiseConfig, SpeckleNoiseConfig
+from vkit_amd.element import Image
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_state(a, b):
+    return a.bit_generator.state == b.bit_generator.state
+
+
+@pytest.mark.parametrize('seed,n,std', [(0, 1, 1.0), (1, 63, 10.0), (2, 64, 10.0), (3, 1023, 2.5), (4, 1024, 2.5), (5, 1025, 40.0),
+                                        (6, 70_001, 10.0), (7, 3 * 1024 * 1024, 0.0), (8, 2047 * 2049 * 3, 10.0),
+                                        (9, 12_582_912, 255.0)])
+def test_rounded_normal_plane_matches_numpy(seed, n, std):
+    rng, ref = np.random.default_rng(seed), np.random.default_rng(seed)
+    want = np.round(ref.normal(0, std, n)).astype(np.int16)
+    got = N.np_normal_i16((n,), std, rng)
+    assert got is not None
+    assert (got == want).all()
+    assert _same_state(rng, ref)
+
+
+def test_stream_continues_across_calls_and_other_draws():
+    rng, ref = np.random.default_rng(77), np.random.default_rng(77)
+    for r in (rng, ref):
+        r.integers(0, 10, 3, dtype=np.int32)       # leaves a buffered 32-bit half behind
+        r.random(5)
+    for n, std in ((1000, 3.0), (70_000, 10.0), (5, 1.0), (300_000, 25.0)):
+        want = np.round(ref.normal(0, std, n)).astype(np.int16)
+        got = N.np_normal_i16((n,), std, rng)
+        assert (got == want).all() and _same_state(rng, ref)
+    # the buffered half is still there: the next 32-bit draw agrees
+    assert (rng.integers(0, 1 << 30, 4, dtype=np.int32) == ref.integers(0, 1 << 30, 4, dtype=np.int32)).all()
+
+
+def test_operators_draw_on_the_device_and_match_the_host_formulas():
+    img = np.random.default_rng(5).integers(0, 256, (301, 211, 3), dtype=np.uint8)
+    rng, ref = np.random.default_rng(11), np.random.default_rng(11)
+
+    got = N.np_gaussion_noise(img, 12.5, rng)
+    want = np.clip(img.astype(np.int16) + np.round(ref.normal(0, 12.5, img.shape)).astype(np.int16), 0, 255).astype(np.uint8)
+    assert (got == want).all() and _same_state(rng, ref)
+
+    got = N.np_speckle_noise(img, 0.3, rng)
+    m = img.astype(np.float32)
+    want = np.clip(m + m * ref.normal(0, 0.3, m.shape), 0, 255).astype(np.uint8)
+    assert (got == want).all() and _same_state(rng, ref)
+
+    for sel_img in (img, img[:, :, 0].copy()):
+        got = N.np_impulse_noise(sel_img, 0.05, 0.03, rng)
+        mask = ref.choice((0, 1, 2), size=sel_img.shape[:2], p=[1 - 0.05 - 0.03, 0.05, 0.03])
+        want = sel_img.copy()
+        want[mask == 1] = 255
+        want[mask == 2] = 0
+        assert (got == want).all() and _same_state(rng, ref)
+
+
+def test_distortion_operators_take_the_device_path(monkeypatch):
+    """gaussion / speckle / impulse through Distortion.distort: same pixels and same generator state as the host formulas,
+    and the device path is the one that ran."""
+    img = Image(mat=np.random.default_rng(1).integers(0, 256, (257, 199, 3), dtype=np.uint8))
+    taken = []
+    inner = N.np_draw
+
+    def counted(*args, **kwargs):
+        ok = inner(*args, **kwargs)
+        taken.append(ok)
+        return ok
+
+    monkeypatch.setattr(N, 'np_draw', counted)
+    for op, config, formula in (
+        (gaussion_noise, GaussionNoiseConfig(std=9.0),
+         lambda r, m: np.clip(m.astype(np.int16) + np.round(r.normal(0, 9.0, m.shape)).astype(np.int16), 0, 255).astype(np.uint8)),
+        (speckle_noise, SpeckleNoiseConfig(std=0.2),
+         lambda r, m: np.clip(m.astype(np.float32) + m.astype(np.float32) * r.normal(0, 0.2, m.shape), 0, 255).astype(np.uint8)),
+    ):
+        rng, ref = np.random.default_rng(3), np.random.default_rng(3)
+        out = op.distort(config, img, rng=rng)
+        want = formula(ref, img.mat)
+        assert (out.mat == want).all()
+        assert _same_state(rng, ref)
+        # replay from the recorded state gives the same pixels
+        again = op.distort(config, img)
+        assert (again.mat == want).all()
+
+    rng, ref = np.random.default_rng(4), np.random.default_rng(4)
+    config = ImpulseNoiseConfig(prob_salt=0.04, prob_pepper=0.06)
+    out = impulse_noise.distort(config, img, rng=rng)
+    mask = ref.choice((0, 1, 2), size=img.shape, p=[1 - 0.04 - 0.06, 0.04, 0.06])
+    want = img.mat.copy()
+    want[mask == 1] = 255
+    want[mask == 2] = 0
+    assert (out.mat == want).all() and _same_state(rng, ref)
+    assert taken == [True] * 5
+
+
+def test_other_bit_generators_and_forced_host_mode_fall_back(monkeypatch):
+    img = np.random.default_rng(5).integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    rng = np.random.Generator(np.random.Philox(1))
+    assert N.np_gaussion_noise(img, 5.0, rng) is None
+    monkeypatch.setenv('VKX_HOST_RNG', '1')
+    assert N.np_gaussion_noise(img, 5.0, np.random.default_rng(0)) is None
+    # the operator still works through the host draw
+    rng, ref = np.random.Generator(np.random.Philox(1)), np.random.Generator(np.random.Philox(1))
+    out = gaussion_noise.distort(GaussionNoiseConfig(std=5.0), Image(mat=img), rng=rng)
+    want = np.clip(img.astype(np.int16) + np.round(ref.normal(0, 5.0, img.shape)).astype(np.int16), 0, 255).astype(np.uint8)
+    assert (out.mat == want).all()
+
+
+def test_ambiguity_flag_is_raised_and_leaves_the_generator_alone():
+    """VKX_NP_DEBUG_WIDE_MARGIN declares every wedge test ambiguous: the job reports it, np_draw then refuses the result."""
+    ctx = N.default_ctx()
+    rng = np.random.default_rng(9)
+    before = rng.bit_generator.state
+    n = 100_000
+    dst = ctx.pinned_empty((n,), np.int16)
+    job = N.np_job(N.NP_NORMAL_I16 | 0x100, N.np_stream(rng), n, 10.0, dst=N._ptr(dst))
+    res = N.VkxNpResult()
+    N.check(N.lib().vkx_np_draw(ctx.handle, ctypes.byref(job), ctypes.byref(res)))
+    assert res.flags & N.NP_AMBIGUOUS
+    assert rng.bit_generator.state == before
+    # the values themselves are still numpy's (the flag is conservative)
+    assert (dst == np.round(np.random.default_rng(9).normal(0, 10.0, n)).astype(np.int16)).all()
+
+
+def test_batch_of_streams_device_resident():
+    ctx = N.default_ctx()
+    B, n = 7, 1_000_003
+    jobs = (N.VkxNpJob * B)()
+    res = (N.VkxNpResult * B)()
+    bufs = []
+    for i in range(B):
+        p = ctx.malloc(n * 2)
+        bufs.append(p)
+        jobs[i] = N.np_job(N.NP_NORMAL_I16, N.np_stream(np.random.default_rng(100 + i)), n - i, 4.0 + i, dst=p)
+    N.check(N.lib().vkx_np_draw_batch_dev(ctx.handle, jobs, B, res))
+    ctx.sync()
+    for i in range(B):
+        ref = np.random.default_rng(100 + i)
+        want = np.round(ref.normal(0, 4.0 + i, n - i)).astype(np.int16)
+        got = np.empty(n - i, np.int16)
+        ctx.download(bufs[i], got)
+        assert res[i].flags == 0
+        assert (got == want).all()
+        st = ref.bit_generator.state['state']
+        assert N.pcg64_jump(*N.np_stream(np.random.default_rng(100 + i)), res[i].draws) == st['state']
+        ctx.free(bufs[i])
+
+
+def test_a_billion_samples():
+    """>= 1e9 samples over seeds / lengths / deviations, every one compared with numpy (about a minute of host draws)."""
+    ctx = N.default_ctx()
+    total = 0
+    chunk = 0
+    while total < 1_000_000_000:
+        n = 83_886_080 + 1021 * chunk        # ~84 M samples per stream, varying length
+        std = (0.7, 3.0, 10.0, 25.0, 60.0, 254.0)[chunk % 6]
+        rng, ref = np.random.default_rng(9000 + chunk), np.random.default_rng(9000 + chunk)
+        got = N.np_normal_i16((n,), std, rng, ctx)
+        want = np.round(ref.normal(0, std, n)).astype(np.int16)
+        assert got is not None, chunk
+        assert (got == want).all(), chunk
+        assert _same_state(rng, ref), chunk
+        total += n
+        chunk += 1
+        del got, want

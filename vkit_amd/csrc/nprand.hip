@@ -38,6 +38,7 @@
 namespace {
 
 typedef unsigned __int128 u128;
+#define VKX_GLOBAL __attribute__((address_space(1)))
 
 constexpr int kRounds = 16;               // rounds of 64 draws per tile
 constexpr int kTile = 64 * kRounds;       // raw draws per tile
@@ -100,15 +101,17 @@ struct NpJob {
     int n_tiles;
     int kind, cn;
     double loc, scale;
+    double margin;           // relative width of the exp() ambiguity window (2^-42; VKX_NP_DEBUG_WIDE_MARGIN: 1)
     double cdf[3];
     const uint8_t *src;
     void *dst;
 };
 
 struct TileInfo {            // pass 1, assuming carry-in 0
-    uint32_t count0, out0;
+    uint32_t count0, out0;   // out0: bit 31 = the tile holds a tail sample
     uint64_t start0, emit0;  // round 0: positions that start an attempt / that emit a sample
 };
+constexpr uint32_t kIrregular = 0x80000000u;   // TilePlan::c_in: the carry-in is not a start of the recorded chain
 struct TilePlan {
     unsigned long long prefix;   // index of the tile's first sample
     uint32_t c_in, count;
@@ -125,167 +128,325 @@ __device__ __forceinline__ uint64_t pcg_out(u128 s)
 }
 __device__ __forceinline__ double u2dbl(uint64_t u) { return (double)(long long)(u >> 11) * (1.0 / 9007199254740992.0); }
 
-// lane i <- lane i + 1 (lane 63 keeps `own`): DPP wave_shl:1
-__device__ __forceinline__ uint32_t from_next_lane(uint32_t v, uint32_t own)
+// What the samples become.  A draw is reduced to the emitter's `Val` as soon as it exists (an int16 step for the rounded
+// kinds: 16 of them fit 8 registers while the tile waits for its true starts); pos = index of the sample in C order.
+__device__ __forceinline__ int rounded_step(const NpJob &job, double z, bool inexact, uint32_t &flags)
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)own, (int)v, 0x130, 0xf, 0xf, false);
+    const double v = job.scale * z;            // 0 + std * z; np.round = rint, C cast to int16
+    if (inexact) {
+        const double f = v - floor(v);
+        if (fabs(f - 0.5) < 1e-9) flags |= VKX_NP_AMBIGUOUS;
+    }
+    return (int16_t)__double2int_rn(v);
 }
-
-struct Attempt {
-    double x;        // standard normal value when `emits`
-    int len;         // raw draws the attempt consumes
-    bool emits;
-    bool inexact;    // x went through log1p: its last bits are not glibc's
-};
-
-// What the samples become.  pos = index of the sample in C order.
 struct EmitNone {
-    static constexpr bool kEnabled = false;
-    __device__ void operator()(const NpJob &, long long, double, bool, uint32_t &) const {}
+    typedef int Val;
+    typedef int16_t Store;
+    __device__ static Val make(const NpJob &, double, bool, uint32_t &) { return 0; }
+    __device__ static void store(const NpJob &, long long, Val, bool, uint32_t &) {}
 };
 struct EmitI16 {   // np.round(0 + std * z).astype(int16)
-    static constexpr bool kEnabled = true;
-    __device__ void operator()(const NpJob &job, long long pos, double z, bool inexact, uint32_t &flags) const
-    {
-        const double v = job.scale * z;
-        if (inexact) {
-            const double f = v - floor(v);
-            if (fabs(f - 0.5) < 1e-9) flags |= VKX_NP_AMBIGUOUS;
-        }
-        ((int16_t *)job.dst)[pos] = (int16_t)__double2int_rn(v);
-    }
+    static constexpr bool kCheckAtStore = false;
+    typedef int Val;
+    typedef int16_t Store;
+    __device__ static Val make(const NpJob &job, double z, bool inexact, uint32_t &flags) { return rounded_step(job, z, inexact, flags); }
+    __device__ static void store(const NpJob &job, long long pos, Val k, bool, uint32_t &) { ((int16_t VKX_GLOBAL *)job.dst)[pos] = (int16_t)k; }
 };
 struct EmitAddU8 {   // clip(int16(px) + noise, 0, 255): the whole gaussion_noise operator
-    static constexpr bool kEnabled = true;
-    __device__ void operator()(const NpJob &job, long long pos, double z, bool inexact, uint32_t &flags) const
+    static constexpr bool kCheckAtStore = false;
+    typedef int Val;
+    typedef int16_t Store;
+    __device__ static Val make(const NpJob &job, double z, bool inexact, uint32_t &flags) { return rounded_step(job, z, inexact, flags); }
+    __device__ static void store(const NpJob &job, long long pos, Val k, bool, uint32_t &)
     {
-        const double v = job.scale * z;
-        if (inexact) {
-            const double f = v - floor(v);
-            if (fabs(f - 0.5) < 1e-9) flags |= VKX_NP_AMBIGUOUS;
-        }
-        const int k = (int16_t)__double2int_rn(v);
-        const int s = (int16_t)((int)job.src[pos] + k);
-        ((uint8_t *)job.dst)[pos] = (uint8_t)vkd::clamp_u8(s);
+        const int s = (int16_t)((int)((const uint8_t VKX_GLOBAL *)job.src)[pos] + k);
+        ((uint8_t VKX_GLOBAL *)job.dst)[pos] = (uint8_t)vkd::clamp_u8(s);
     }
 };
 struct EmitSpeckle {   // uint8(clip(px + px * (0 + std * z), 0, 255)) in float64
-    static constexpr bool kEnabled = true;
-    __device__ void operator()(const NpJob &job, long long pos, double z, bool inexact, uint32_t &flags) const
+    static constexpr bool kCheckAtStore = true;
+    typedef double Val;
+    typedef double Store;
+    __device__ static Val make(const NpJob &, double z, bool, uint32_t &) { return z; }
+    __device__ static void store(const NpJob &job, long long pos, Val z, bool inexact, uint32_t &flags)
     {
         const double noise = 0.0 + job.scale * z;
-        const double m = (double)job.src[pos];
+        const double m = (double)((const uint8_t VKX_GLOBAL *)job.src)[pos];
         const double t = m * noise;
         double r = m + t;
         if (inexact && fabs(r - rint(r)) < 1e-9) flags |= VKX_NP_AMBIGUOUS;
         r = r < 0.0 ? 0.0 : (r > 255.0 ? 255.0 : r);
-        ((uint8_t *)job.dst)[pos] = (uint8_t)(int)r;
+        ((uint8_t VKX_GLOBAL *)job.dst)[pos] = (uint8_t)(int)r;
     }
 };
 
+// Per-wavefront LDS workspace of a tile walk.
+constexpr int kEvCap = 128;      // attempts per tile that are not a fast accept: mean 15.4, sigma 3.9
+template <typename Val>
+struct WaveWork {
+    uint64_t ev_s[kEvCap][2];    // LCG state of the event's draw; after evaluation [0] holds the bits of a tail sample
+    uint16_t ev_pos[kEvCap];     // 64 * round + lane
+    uint16_t ev_info[kEvCap];    // draws consumed | emits << 8 | tail << 9
+    uint64_t slow[kRounds];      // per round: the lanes whose attempt is not a fast accept
+    uint64_t semit[kRounds];     // per round: the events that emit a sample, as a lane mask
+    uint64_t cov[kRounds];       // per round: the draws consumed by an attempt that started earlier
+    Val val[kRounds + 1][64];    // what every draw would emit as a fast accept (int16 steps, or the float64 draw); pass 2
+                                 // stages a tile's compacted samples here (one spare row: the alignment shift)
+};
+
+__device__ __forceinline__ uint64_t rfl64(uint64_t v)
+{
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ int mbcnt64(uint64_t m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 // The walk of one wavefront over one tile.  `base` = LCG state before the tile's first draw, `c_in` = leading draws
 // already consumed by the previous tile's last attempt.  Lane l owns draws 64 r + l of the tile.
-template <class Emit>
+//   phase 1  all rounds, branch-free but for the event push: draw, ziggurat layer lookup, value of a fast accept; the
+//            few draws whose attempt needs more (wedge test, tail) are queued with their LCG state
+//   phase 2  the queue is evaluated densely, one event per lane: exp() / log1p() run once per tile instead of once per
+//            round with one active lane
+//   phase 3  per round: the scalar walk over the multi-draw attempts that gives the true starts, then the emission
+//   MODE kCount   the walk only: samples the tile yields and its carry-out for the given carry-in
+//   MODE kRecord  carry-in 0: besides the count, what every draw would emit (`rec_val`, 1024 per tile, in draw order) and
+//                 the 16 emit masks (`rec_mask`) go to global memory for k_np_place
+//   MODE kEmit    the samples are stored at their final index
+enum { kCount = 0, kRecord = 1, kEmit = 2 };
+template <class Emit, int MODE>
 __device__ void walk_tile(const NpJob &job, const JumpTabs &g_jump, const uint4 *__restrict__ zig /* LDS: ki | wi */, const double *__restrict__ fi /* LDS */,
-                          u128 base, uint32_t c_in, long long prefix, long long draw_base, const Emit &emit, uint32_t &count_out,
-                          uint32_t &carry_out, uint64_t &start0, uint64_t &emit0, uint32_t &flags, unsigned long long *draws_used)
+                          WaveWork<typename Emit::Store> &ws, u128 base, uint32_t c_in, long long prefix, long long draw_base,
+                          typename Emit::Store VKX_GLOBAL *rec_val, uint64_t VKX_GLOBAL *rec_mask,
+                          uint32_t &count_out, uint32_t &carry_out, uint64_t &start0, uint64_t &emit0, bool &has_tail, uint32_t &flags,
+                          unsigned long long *draws_used)
 {
     const int lane = __lane_id();
     const u128 inc = mk128(job.inc);
     const u128 a64 = mk128(g_jump.a64), c64 = mk128(job.c64);
+    // wave-uniform by construction; said explicitly so that the start walk below stays on the scalar unit
+    c_in = (uint32_t)__builtin_amdgcn_readfirstlane((int)c_in);
+    prefix = (long long)rfl64((uint64_t)prefix);
+    draw_base = (long long)rfl64((uint64_t)draw_base);
     // state after draw `lane` of the tile has been stepped
     u128 s = mk128(&g_jump.lane[lane][0]) * base + mk128(&g_jump.lane[lane][2]) * inc;
-    uint32_t carry = c_in, count = 0;
-    start0 = 0;
-    emit0 = 0;
+    uint32_t nev = 0;
+    if (lane < kRounds) ws.semit[lane] = 0;
 #pragma unroll 1
     for (int r = 0; r < kRounds; r++) {
-        if (Emit::kEnabled && prefix + count >= job.n) break;   // everything wanted has been written
         const uint64_t u = pcg_out(s);
         const int idx = (int)(u & 0xff);
         const uint64_t rabs = (u >> 9) & 0x000fffffffffffffull;
         const uint4 e = zig[idx];
         const uint64_t ki = ((uint64_t)e.y << 32) | e.x;
-        const double wi = __longlong_as_double(((long long)e.w << 32) | e.z);
-        // rabs < 2^52: exact conversion through the exponent trick
-        double x = (__longlong_as_double((long long)(0x4330000000000000ull | rabs)) - 4503599627370496.0) * wi;
-        if (u & 0x100) x = -x;
-        Attempt at;
-        at.x = x; at.len = 1; at.emits = true; at.inexact = false;
-        const bool fast = rabs < ki;
-        const uint64_t slow = __ballot(!fast);
+        if (MODE != kCount) {
+            const double wi = __longlong_as_double(((long long)e.w << 32) | e.z);
+            // rabs < 2^52: exact conversion through the exponent trick
+            double x = (__longlong_as_double((long long)(0x4330000000000000ull | rabs)) - 4503599627370496.0) * wi;
+            const typename Emit::Store v = (typename Emit::Store)Emit::make(job, (u & 0x100) ? -x : x, false, flags);
+#ifndef NPX_NO_REC_STORE
+            if (MODE == kRecord) rec_val[64 * r + lane] = v;
+#else
+            if (MODE == kRecord && v == 12345) rec_val[64 * r + lane] = v;
+#endif
+            else ws.val[r][lane] = v;
+        }
+        const uint64_t slow = __ballot(rabs >= ki);
+        if (lane == 0) ws.slow[r] = slow;
         if (slow) {
-            // the draw after this one: the next lane's, or (lane 63) one own step
-            uint64_t un;
-            {
-                const uint32_t lo = from_next_lane((uint32_t)u, 0u), hi = from_next_lane((uint32_t)(u >> 32), 0u);
-                un = ((uint64_t)hi << 32) | lo;
+            if (rabs >= ki) {
+                const uint32_t slot = nev + (uint32_t)mbcnt64(slow);
+                if (slot < (uint32_t)kEvCap) {
+                    ws.ev_s[slot][0] = (uint64_t)s;
+                    ws.ev_s[slot][1] = (uint64_t)(s >> 64);
+                    ws.ev_pos[slot] = (uint16_t)(64 * r + lane);
+                }
             }
-            if ((slow >> 63) && lane == 63) un = pcg_out(PCG_MULT * s + inc);
-            if (!fast) {
-                if (idx != 0) {
-                    const double f1 = fi[idx], f0 = fi[idx - 1];
-                    const double lhs = (f0 - f1) * u2dbl(un) + f1;
-                    const double t = -0.5 * x;
-                    const double rhs = exp(t * x);
-                    at.len = 2;
-                    at.emits = lhs < rhs;
-                    if (fabs(rhs - lhs) <= lhs * 0x1p-42) flags |= VKX_NP_AMBIGUOUS;
-                } else {
-                    u128 t = s;
-                    int len = 1;
-                    double xx;
-                    for (;;) {
-                        t = PCG_MULT * t + inc;
-                        const double u1 = u2dbl(pcg_out(t));
-                        t = PCG_MULT * t + inc;
-                        const double u2 = u2dbl(pcg_out(t));
-                        len += 2;
-                        xx = -kNorInvR * log1p(-u1);
-                        const double yy = -log1p(-u2);
-                        const double l2 = yy + yy, r2 = xx * xx;
-                        if (fabs(l2 - r2) <= r2 * 0x1p-40) flags |= VKX_NP_AMBIGUOUS;
-                        if (l2 > r2) break;
-                    }
-                    at.len = len;
-                    at.x = ((rabs >> 8) & 1) ? -(kNorR + xx) : kNorR + xx;
-                    at.inexact = true;
+            nev += (uint32_t)__builtin_popcountll(slow);
+        }
+        s = a64 * s + c64;
+    }
+#ifdef NPX_NO_PHASE2
+    nev = 0;
+#endif
+    if (nev > (uint32_t)kEvCap) {   // never observed; the job is redrawn on the host
+        flags |= VKX_NP_SHORT;
+        nev = kEvCap;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (MODE == kRecord) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail samples below overwrite phase 1's stores
+    has_tail = false;
+    // phase 2
+#pragma unroll
+    for (int q = 0; q < kEvCap / 64; q++) {
+        if ((uint32_t)(64 * q) >= nev) break;
+        const uint32_t ev = 64 * q + lane;
+        if (ev < nev) {
+            const u128 se = ((u128)ws.ev_s[ev][1] << 64) | ws.ev_s[ev][0];
+            const int pos = ws.ev_pos[ev];
+            const uint64_t u = pcg_out(se);
+            const int idx = (int)(u & 0xff);
+            const uint64_t rabs = (u >> 9) & 0x000fffffffffffffull;
+            uint32_t info;
+            if (idx != 0) {
+                double x = (__longlong_as_double((long long)(0x4330000000000000ull | rabs)) - 4503599627370496.0) *
+                           __longlong_as_double(((long long)zig[idx].w << 32) | zig[idx].z);
+                if (u & 0x100) x = -x;
+                const double un = u2dbl(pcg_out(PCG_MULT * se + inc));
+                const double f1 = fi[idx], f0 = fi[idx - 1];
+                const double lhs = (f0 - f1) * un + f1;
+                const double t = -0.5 * x;
+                const double rhs = exp(t * x);
+                if (fabs(rhs - lhs) <= lhs * job.margin) flags |= VKX_NP_AMBIGUOUS;
+                info = 2u | (lhs < rhs ? 0x100u : 0u);
+            } else {
+                u128 t = se;
+                uint32_t len = 1;
+                double xx;
+                for (;;) {
+                    t = PCG_MULT * t + inc;
+                    const double u1 = u2dbl(pcg_out(t));
+                    t = PCG_MULT * t + inc;
+                    const double u2 = u2dbl(pcg_out(t));
+                    len += 2;
+                    xx = -kNorInvR * log1p(-u1);
+                    const double yy = -log1p(-u2);
+                    const double l2 = yy + yy, r2 = xx * xx;
+                    if (fabs(l2 - r2) <= r2 * 0x1p-40) flags |= VKX_NP_AMBIGUOUS;
+                    if (l2 > r2 || len > 200) break;
+                }
+                if (len > 200) flags |= VKX_NP_SHORT;
+                const double z = ((rabs >> 8) & 1) ? -(kNorR + xx) : kNorR + xx;
+                if (MODE == kRecord) {
+                    rec_val[pos] = (typename Emit::Store)Emit::make(job, z, true, flags);
+                } else if (MODE == kEmit) {
+                    const typename Emit::Val v = Emit::make(job, z, true, flags);
+                    uint64_t bits = 0;
+                    memcpy(&bits, &v, sizeof v);
+                    ws.ev_s[ev][0] = bits;
+                }
+                has_tail = true;
+                info = len | 0x300u;
+            }
+            ws.ev_info[ev] = (uint16_t)info;
+            if (info & 0x100u) atomicOr((unsigned long long *)&ws.semit[pos >> 6], 1ull << (pos & 63));
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    has_tail = __ballot(has_tail) != 0;
+    // phase 3: which attempts really start.  Every event (an attempt that is not a fast accept) consumes at least one
+    // draw after its own; an event is void when an earlier valid one has consumed its draw.  The events are sorted by
+    // position, so a void event always follows the valid event that covers it directly or through other void events:
+    // when no event starts inside its predecessor's span (4 tiles out of 5) all are valid and nothing is serial.
+    uint32_t P = 0xffffu, end = 0, info = 0;
+    if ((uint32_t)lane < nev) {
+        P = ws.ev_pos[lane];
+        info = ws.ev_info[lane];
+        end = P + (info & 0xffu);
+    }
+    uint64_t valid;
+    uint32_t carry = c_in > (uint32_t)kTile ? c_in - kTile : 0u;
+    if (nev <= 64) {
+        const uint32_t prev_end = (uint32_t)__builtin_amdgcn_update_dpp((int)c_in, (int)end, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        const uint64_t live = nev == 64 ? ~0ull : ((1ull << nev) - 1);
+        const uint64_t touch = __ballot((uint32_t)lane < nev && P < prev_end);
+        valid = live;
+        if (touch) {
+            uint32_t cover_end = c_in;
+            valid = 0;
+            for (uint32_t e = 0; e < nev; e++) {
+                const uint32_t pe = (uint32_t)__builtin_amdgcn_readlane((int)P, (int)e);
+                if (pe >= cover_end) {
+                    valid |= 1ull << e;
+                    cover_end = (uint32_t)__builtin_amdgcn_readlane((int)end, (int)e);
                 }
             }
         }
-        // true starts of this round: positions not consumed by an earlier attempt
-        uint64_t covered = carry >= 64 ? ~0ull : ((1ull << carry) - 1);
-        carry = carry >= 64 ? carry - 64 : 0;
-        uint64_t todo = slow & ~covered;
-        while (todo) {
-            const int j = __builtin_ctzll(todo);
-            const int len = __builtin_amdgcn_readlane(at.len, j);
-            const int end = j + len;                       // first position after the attempt
-            uint64_t span;
-            if (end >= 64) {
-                span = j == 63 ? 0ull : (~0ull << (j + 1));
-                if ((uint32_t)(end - 64) > carry) carry = (uint32_t)(end - 64);
-            } else {
-                span = ((1ull << end) - 1) & ~((2ull << j) - 1);
-            }
-            covered |= span;
-            todo &= ~covered & ~(1ull << j);
+        if (valid) {
+            const uint32_t last_end = (uint32_t)__builtin_amdgcn_readlane((int)end, 63 - __builtin_clzll(valid));
+            if (last_end > (uint32_t)kTile && last_end - kTile > carry) carry = last_end - kTile;
         }
-        const uint64_t starts = ~covered;
-        const uint64_t emits = starts & __ballot(at.emits);
-        if (r == 0) { start0 = starts; emit0 = emits; }
-        if (Emit::kEnabled) {
-            const bool mine = (emits >> lane) & 1;
-            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(emits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)emits, 0u));
-            const long long pos = prefix + count + rank;
-            if (mine && pos < job.n) {
-                emit(job, pos, at.x, at.inexact, flags);
-                if (pos == job.n - 1) *draws_used = (unsigned long long)(draw_base + 64 * r + lane + at.len);
+        // the draws each valid event consumes after its own: positions P + 1 .. end - 1
+        if (lane < kRounds) ws.cov[lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if ((valid >> lane) & 1) {
+            uint32_t p0 = P + 1, p1 = end < (uint32_t)kTile ? end : (uint32_t)kTile;     // [p0, p1)
+            while (p0 < p1) {
+                const uint32_t r = p0 >> 6, stop = (r + 1) << 6 < p1 ? (r + 1) << 6 : p1;
+                const uint32_t lo = p0 & 63, n = stop - p0;
+                const uint64_t bits = (n == 64 ? ~0ull : ((1ull << n) - 1)) << lo;
+                atomicOr((unsigned long long *)&ws.cov[r], bits);
+                p0 = stop;
             }
         }
-        count += (uint32_t)__builtin_popcountll(emits);
-        s = a64 * s + c64;
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        // more than 64 events in one tile (12 sigma): the plain serial walk
+        valid = 0;
+        if (lane < kRounds) ws.cov[lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        uint32_t cover_end = c_in;
+        for (uint32_t e = 0; e < nev; e++) {
+            const uint32_t pe = ws.ev_pos[e], ee = pe + (ws.ev_info[e] & 0xffu);
+            if (pe < cover_end) continue;
+            cover_end = ee;
+            if (lane == 0)
+                for (uint32_t q = pe + 1; q < ee && q < (uint32_t)kTile; q++) ws.cov[q >> 6] |= 1ull << (q & 63);
+        }
+        if (cover_end > (uint32_t)kTile && cover_end - kTile > carry) carry = cover_end - kTile;
+        __builtin_amdgcn_wave_barrier();
     }
+    // lane r: the masks of round r
+    uint64_t my_mask = 0, my_starts = 0;
+    if (lane < kRounds) {
+        uint64_t cov = ws.cov[lane];
+        const uint32_t lo = 64u * lane;
+        if (c_in > lo) cov |= c_in - lo >= 64 ? ~0ull : ((1ull << (c_in - lo)) - 1);
+        const uint64_t slow = ws.slow[lane];
+        my_starts = ~cov;
+        my_mask = my_starts & (~slow | ws.semit[lane]);
+    }
+    start0 = rfl64(my_starts);
+    emit0 = rfl64(my_mask);
+    uint32_t count = (uint32_t)__builtin_popcountll(my_mask);
+    count += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)count, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
+    count += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)count, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
+    count += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)count, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
+    count += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)count, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+    count = (uint32_t)__builtin_amdgcn_readlane((int)count, 15);
+    if (MODE == kEmit) {
+        uint32_t done = 0, ebase = 0;
+#pragma unroll 1
+        for (int r = 0; r < kRounds; r++) {
+            if (prefix + done >= job.n) break;   // everything wanted has been written
+            const uint64_t emits = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(my_mask >> 32), r) << 32) |
+                                   (uint32_t)__builtin_amdgcn_readlane((int)my_mask, r);
+            const uint64_t slow = rfl64(ws.slow[r]);
+            const bool mine = (emits >> lane) & 1;
+            const long long pos = prefix + done + mbcnt64(emits);
+            if (mine && pos < job.n) {
+                typename Emit::Val z = (typename Emit::Val)ws.val[r][lane];
+                bool inexact = false;
+                int len = 1;
+                if ((slow >> lane) & 1) {
+                    const uint32_t ev = ebase + (uint32_t)mbcnt64(slow);
+                    const uint32_t einfo = ws.ev_info[ev];
+                    len = (int)(einfo & 0xff);
+                    if (einfo & 0x200u) {
+                        const uint64_t bits = ws.ev_s[ev][0];
+                        memcpy(&z, &bits, sizeof z);
+                        inexact = true;
+                    }
+                }
+                Emit::store(job, pos, z, inexact, flags);
+                if (pos == job.n - 1) *draws_used = (unsigned long long)(draw_base + 64 * r + lane + len);
+            }
+            done += (uint32_t)__builtin_popcountll(emits);
+            ebase += (uint32_t)__builtin_popcountll(slow);
+        }
+    }
+    if (MODE == kRecord && lane < kRounds) rec_mask[lane] = my_mask;
     count_out = count;
     carry_out = carry;
 }
@@ -326,12 +487,15 @@ __global__ void __launch_bounds__(256) k_np_tile_states(const NpJob *__restrict_
     states[2 * tile + 1] = (uint64_t)(s >> 64);
 }
 
-__global__ void __launch_bounds__(256) k_np_scan(const NpJob *__restrict__ jobs, int n_jobs, long long total_tiles,
+template <class Emit>
+__global__ void __launch_bounds__(256) k_np_draw(const NpJob *__restrict__ jobs, int n_jobs, long long total_tiles,
                                                  const uint64_t *__restrict__ states, TileInfo *__restrict__ info,
+                                                 typename Emit::Store *__restrict__ rec_val, uint64_t *__restrict__ rec_mask,
                                                  vkx_np_result *__restrict__ results, const NpTabs *__restrict__ tabs)
 {
     __shared__ uint4 zig[256];
     __shared__ double fi[256];
+    __shared__ WaveWork<typename Emit::Store> work[4];
     load_tables(zig, fi, tabs);
     const JumpTabs &g_jump = tabs->jump;
     const long long n_waves = (long long)gridDim.x * 4;
@@ -340,10 +504,13 @@ __global__ void __launch_bounds__(256) k_np_scan(const NpJob *__restrict__ jobs,
         const NpJob &job = jobs[j];
         uint32_t count, carry, flags = 0;
         uint64_t start0, emit0;
-        walk_tile(job, g_jump, zig, fi, mk128(&states[2 * tile]), 0u, 0, 0, EmitNone(), count, carry, start0, emit0, flags, nullptr);
+        bool has_tail;
+        walk_tile<Emit, kRecord>(job, g_jump, zig, fi, work[threadIdx.x >> 6], mk128(&states[2 * tile]), 0u, 0, 0,
+                                 (typename Emit::Store VKX_GLOBAL *)(rec_val + tile * kTile), (uint64_t VKX_GLOBAL *)(rec_mask + tile * kRounds),
+                                 count, carry, start0, emit0, has_tail, flags, nullptr);
         if (__lane_id() == 0) {
             TileInfo t;
-            t.count0 = count; t.out0 = carry; t.start0 = start0; t.emit0 = emit0;
+            t.count0 = count; t.out0 = carry | (has_tail ? 0x80000000u : 0u); t.start0 = start0; t.emit0 = emit0;
             info[tile] = t;
         }
         if (flags) atomicOr(&results[j].flags, flags);
@@ -357,6 +524,7 @@ __global__ void __launch_bounds__(1024) k_np_resolve(const NpJob *__restrict__ j
 {
     __shared__ uint4 zig[256];
     __shared__ double fi[256];
+    __shared__ WaveWork<int16_t> work[1];
     __shared__ unsigned long long part[1024];
     __shared__ uint32_t n_irregular;
     extern __shared__ uint64_t irregular[];     // one bit per tile
@@ -374,7 +542,7 @@ __global__ void __launch_bounds__(1024) k_np_resolve(const NpJob *__restrict__ j
         const int j = w * 64 + (threadIdx.x & 63);
         bool bad = false;
         if (j < T) {
-            const uint32_t c = j ? info[j - 1].out0 : 0u;
+            const uint32_t c = j ? (info[j - 1].out0 & 0x7fffffffu) : 0u;
             const TileInfo t = info[j];
             const bool ok = c < 64 && ((t.start0 >> c) & 1);
             TilePlan p;
@@ -402,19 +570,25 @@ __global__ void __launch_bounds__(1024) k_np_resolve(const NpJob *__restrict__ j
                 const int b = __builtin_ctzll(m);
                 const int j = w * 64 + b;
                 const TileInfo t = info[j];
-                const uint32_t c = ((volatile TilePlan *)plan)[j].c_in;
+                const uint32_t c = ((volatile TilePlan *)plan)[j].c_in & ~kIrregular;
+                const uint32_t out0 = t.out0 & 0x7fffffffu;
                 uint32_t count, out;
+                bool simulated = false;
                 if (c < 64 && ((t.start0 >> c) & 1)) {
                     count = t.count0 - (uint32_t)__builtin_popcountll(t.emit0 & ((1ull << c) - 1));
-                    out = t.out0;
+                    out = out0;
                 } else {
                     uint64_t s0, e0;
-                    walk_tile(job, g_jump, zig, fi, mk128(&st[2 * j]), c, 0, 0, EmitNone(), count, out, s0, e0, flags, nullptr);
+                    bool ht;
+                    walk_tile<EmitNone, kCount>(job, g_jump, zig, fi, work[0], mk128(&st[2 * j]), c, 0, 0, nullptr, nullptr, count, out, s0, e0,
+                                                ht, flags, nullptr);
+                    simulated = true;
                 }
                 if (threadIdx.x == 0) {
                     plan[j].count = count;
+                    plan[j].c_in = c | (simulated ? kIrregular : 0u);
                     irregular[w] = m & ~(1ull << b);
-                    if (j + 1 < T && out != t.out0) {
+                    if (j + 1 < T && out != out0) {
                         const TileInfo tn = info[j + 1];
                         const bool ok = out < 64 && ((tn.start0 >> out) & 1);
                         plan[j + 1].c_in = out;
@@ -454,25 +628,165 @@ __global__ void __launch_bounds__(1024) k_np_resolve(const NpJob *__restrict__ j
     }
 }
 
+// The fast path of pass 2 for one tile: m = (lane r < 16) the emit mask of round r.
+// Element-granular version (speckle: float64 records, byte traffic; a rare single-image operator).
 template <class Emit>
-__global__ void __launch_bounds__(256) k_np_emit(const NpJob *__restrict__ jobs, int n_jobs, long long total_tiles,
-                                                 const uint64_t *__restrict__ states, const TilePlan *__restrict__ plan,
-                                                 vkx_np_result *__restrict__ results, const NpTabs *__restrict__ tabs)
+struct Placer {
+    struct Draws {};
+    __device__ static Draws load(const typename Emit::Store *) { return Draws(); }
+    __device__ static void place(const NpJob &job, const Draws &, const typename Emit::Store *__restrict__ rec, uint64_t m, long long prefix,
+                                 typename Emit::Store *, uint32_t &flags)
+{
+    const typename Emit::Store VKX_GLOBAL *vals = (const typename Emit::Store VKX_GLOBAL *)rec;
+    const int lane = __lane_id();
+    uint32_t count = 0;
+#pragma unroll 4
+    for (int r = 0; r < kRounds; r++) {
+        const uint64_t emits = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(m >> 32), r) << 32) |
+                               (uint32_t)__builtin_amdgcn_readlane((int)m, r);
+        const long long pos = prefix + count + mbcnt64(emits);
+        if (((emits >> lane) & 1) && pos < job.n) Emit::store(job, pos, (typename Emit::Val)vals[64 * r + lane], false, flags);
+        count += (uint32_t)__builtin_popcountll(emits);
+    }
+}
+};
+
+// int16 records: sub-dword global accesses cost the texture path one lane per cycle, so the records are read as dwords
+// (two consecutive draws per lane), compacted into LDS at their rank, and leave as whole dwords.
+// `shift` = (index of the tile's first sample) mod (elements per dword): LDS slot i holds element (prefix - shift) + i.
+struct TileDraws { uint32_t v[kRounds / 2]; };     // lane l: draws 128 q + 2 l, + 1 of the tile as int16 pairs
+__device__ __forceinline__ TileDraws load_tile_i16(const int16_t *__restrict__ rec)
+{
+    const uint32_t VKX_GLOBAL *vals = (const uint32_t VKX_GLOBAL *)rec;
+    const int lane = __lane_id();
+    TileDraws d;
+#pragma unroll
+    for (int q = 0; q < kRounds / 2; q++) d.v[q] = vals[64 * q + lane];
+    return d;
+}
+__device__ __forceinline__ uint32_t stage_tile_i16(const TileDraws &d, uint64_t m, uint32_t shift, int16_t *st)
+{
+    const int lane = __lane_id();
+    const int b = (2 * lane) & 63;
+    uint32_t count = 0;
+#pragma unroll
+    for (int q = 0; q < kRounds / 2; q++) {
+        const uint32_t v = d.v[q];
+        const uint64_t ma = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(m >> 32), 2 * q) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)m, 2 * q);
+        const uint64_t mb = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(m >> 32), 2 * q + 1) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)m, 2 * q + 1);
+        const uint32_t ca = (uint32_t)__builtin_popcountll(ma);
+        const uint64_t mine = lane < 32 ? ma : mb;
+        const uint32_t rank = shift + count + (lane < 32 ? 0u : ca) + (uint32_t)__builtin_popcountll(mine & ((1ull << b) - 1));
+        const uint32_t e0 = (uint32_t)(mine >> b) & 1u, e1 = (uint32_t)(mine >> (b + 1)) & 1u;
+        if (e0) st[rank] = (int16_t)v;
+        if (e1) st[rank + e0] = (int16_t)(v >> 16);
+        count += ca + (uint32_t)__builtin_popcountll(mb);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return count;
+}
+
+template <>
+struct Placer<EmitI16> {
+    typedef TileDraws Draws;
+    __device__ static Draws load(const int16_t *rec) { return load_tile_i16(rec); }
+    __device__ static void place(const NpJob &job, const Draws &d, const int16_t *, uint64_t m, long long prefix, int16_t *st, uint32_t &)
+{
+    const int lane = __lane_id();
+    const uint32_t shift = (uint32_t)prefix & 1u;
+    uint32_t total = stage_tile_i16(d, m, shift, st);
+    if (prefix + total > job.n) total = (uint32_t)(job.n - prefix);
+    int16_t VKX_GLOBAL *dst = (int16_t VKX_GLOBAL *)job.dst + (prefix - shift);
+    const uint32_t end = shift + total;                // slots [shift, end) are valid
+    for (uint32_t k = lane; 2 * k < end; k += 64) {
+        const uint32_t v = ((const uint32_t *)st)[k];
+        if (2 * k >= shift && 2 * k + 1 < end) ((uint32_t VKX_GLOBAL *)dst)[k] = v;
+        else if (2 * k >= shift) dst[2 * k] = (int16_t)v;
+        else if (2 * k + 1 < end) dst[2 * k + 1] = (int16_t)(v >> 16);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+};
+
+template <>
+struct Placer<EmitAddU8> {
+    typedef TileDraws Draws;
+    __device__ static Draws load(const int16_t *rec) { return load_tile_i16(rec); }
+    __device__ static void place(const NpJob &job, const Draws &d, const int16_t *, uint64_t m, long long prefix, int16_t *st, uint32_t &)
+{
+    const int lane = __lane_id();
+    const uint32_t shift = (uint32_t)prefix & 3u;
+    uint32_t total = stage_tile_i16(d, m, shift, st);
+    if (prefix + total > job.n) total = (uint32_t)(job.n - prefix);
+    const uint8_t VKX_GLOBAL *src = (const uint8_t VKX_GLOBAL *)job.src + (prefix - shift);
+    uint8_t VKX_GLOBAL *dst = (uint8_t VKX_GLOBAL *)job.dst + (prefix - shift);
+    const uint32_t end = shift + total;
+    for (uint32_t k = lane; 4 * k < end; k += 64) {
+        const uint2 nz = ((const uint2 *)st)[k];
+        const bool whole = 4 * k >= shift && 4 * k + 3 < end;
+        uint32_t px = 0;
+        if (whole) px = ((const uint32_t VKX_GLOBAL *)src)[k];
+        else
+            for (int t = 0; t < 4; t++)
+                if (4 * k + t >= shift && 4 * k + t < end) px |= (uint32_t)src[4 * k + t] << (8 * t);
+        const int n0 = (int16_t)nz.x, n1 = (int16_t)(nz.x >> 16), n2 = (int16_t)nz.y, n3 = (int16_t)(nz.y >> 16);
+        const uint32_t o0 = (uint32_t)vkd::clamp_u8((int16_t)((int)(px & 0xff) + n0));
+        const uint32_t o1 = (uint32_t)vkd::clamp_u8((int16_t)((int)((px >> 8) & 0xff) + n1));
+        const uint32_t o2 = (uint32_t)vkd::clamp_u8((int16_t)((int)((px >> 16) & 0xff) + n2));
+        const uint32_t o3 = (uint32_t)vkd::clamp_u8((int16_t)((int)(px >> 24) + n3));
+        const uint32_t out = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
+        if (whole) ((uint32_t VKX_GLOBAL *)dst)[k] = out;
+        else
+            for (int t = 0; t < 4; t++)
+                if (4 * k + t >= shift && 4 * k + t < end) dst[4 * k + t] = (uint8_t)(out >> (8 * t));
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+};
+
+// Pass 2: the recorded draws of a tile go to their final index.  Tiles whose carry-in does not merge into the recorded
+// chain (~2e-4 of them), the tile holding a job's last sample (its draw count is reported) and, for emitters that check
+// a tail sample against its pixel, tiles with a tail sample are walked again from the generator state.
+template <class Emit>
+__global__ void __launch_bounds__(256) k_np_place(const NpJob *__restrict__ jobs, int n_jobs, long long total_tiles,
+                                                  const uint64_t *__restrict__ states, const TileInfo *__restrict__ info,
+                                                  const TilePlan *__restrict__ plan, const typename Emit::Store *__restrict__ rec_val,
+                                                  const uint64_t *__restrict__ rec_mask, vkx_np_result *__restrict__ results,
+                                                  const NpTabs *__restrict__ tabs)
 {
     __shared__ uint4 zig[256];
     __shared__ double fi[256];
+    __shared__ __attribute__((aligned(16))) WaveWork<typename Emit::Store> work[4];
     load_tables(zig, fi, tabs);
     const JumpTabs &g_jump = tabs->jump;
+    const int lane = __lane_id();
     const long long n_waves = (long long)gridDim.x * 4;
     for (long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); tile < total_tiles; tile += n_waves) {
         const int j = job_of_tile(jobs, n_jobs, tile);
         const NpJob &job = jobs[j];
+        // everything the fast path reads is requested before the plan decides (one memory round trip per tile)
         const TilePlan p = plan[tile];
-        if ((long long)p.prefix >= job.n) continue;
-        uint32_t count, carry, flags = 0;
-        uint64_t start0, emit0;
-        walk_tile(job, g_jump, zig, fi, mk128(&states[2 * tile]), p.c_in, (long long)p.prefix, (tile - job.tile_base) * kTile, Emit(), count,
-                  carry, start0, emit0, flags, &results[j].draws);
+        uint64_t m = lane < kRounds ? ((const uint64_t VKX_GLOBAL *)rec_mask)[tile * kRounds + lane] : 0ull;
+        const typename Placer<Emit>::Draws draws = Placer<Emit>::load(rec_val + tile * kTile);
+        const long long prefix = (long long)rfl64(p.prefix);
+        if (prefix >= job.n) continue;
+        const uint32_t c_in = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.c_in);
+        const uint32_t tcount = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.count);
+        const bool last = prefix + tcount >= job.n;
+        const bool tail = Emit::kCheckAtStore && (info[tile].out0 >> 31);
+        uint32_t flags = 0;
+        if ((c_in & kIrregular) || last || tail) {
+            uint32_t count, carry;
+            uint64_t start0, emit0;
+            bool ht;
+            walk_tile<Emit, kEmit>(job, g_jump, zig, fi, work[threadIdx.x >> 6], mk128(&states[2 * tile]), c_in & ~kIrregular, prefix,
+                                   (tile - job.tile_base) * kTile, nullptr, nullptr, count, carry, start0, emit0, ht, flags, &results[j].draws);
+        } else {
+            if (lane == 0) m &= ~((1ull << c_in) - 1);     // c_in < 64 is a start of the recorded chain: the draws before it belong to the previous tile
+            Placer<Emit>::place(job, draws, rec_val + tile * kTile, m, prefix, &work[threadIdx.x >> 6].val[0][0], flags);
+        }
         if (flags) atomicOr(&results[j].flags, flags);
     }
 }
@@ -553,7 +867,7 @@ VKX_EXPORT int vkx_np_draw_batch_dev(vkx_ctx *ctx, const vkx_np_job *jobs, int n
 {
     VKX_REQUIRE(ctx && jobs && results_host, "NULL argument");
     VKX_REQUIRE(n_jobs >= 1 && n_jobs <= 65535, "1 .. 65535 jobs per call");
-    const int kind = jobs[0].kind;
+    const int kind = jobs[0].kind & 0xff;
     const bool uniform = kind == VKX_NP_CHOICE3_U8 || kind == VKX_NP_IMPULSE_U8;
     long long total_tiles = 0;
     int max_tiles = 0;
@@ -561,13 +875,14 @@ VKX_EXPORT int vkx_np_draw_batch_dev(vkx_ctx *ctx, const vkx_np_job *jobs, int n
         const vkx_np_job &j = jobs[i];
         VKX_REQUIRE(j.n >= 1 && j.n <= 0x7fffffffLL, "1 .. 2^31 - 1 samples per job");
         VKX_REQUIRE(j.dst != nullptr, "NULL destination");
-        switch (j.kind) {
+        const int jkind = j.kind & 0xff;
+        switch (jkind) {
         case VKX_NP_NORMAL_I16:
-            VKX_REQUIRE(!uniform && j.kind == kind, "the jobs of one call share a kind");
+            VKX_REQUIRE(!uniform && jkind == kind, "the jobs of one call share a kind");
             break;
         case VKX_NP_NORMAL_ADD_U8:
         case VKX_NP_SPECKLE_U8:
-            VKX_REQUIRE(!uniform && j.kind == kind, "the jobs of one call share a kind");
+            VKX_REQUIRE(!uniform && jkind == kind, "the jobs of one call share a kind");
             VKX_REQUIRE(j.src != nullptr, "NULL source");
             break;
         case VKX_NP_CHOICE3_U8:
@@ -582,7 +897,7 @@ VKX_EXPORT int vkx_np_draw_batch_dev(vkx_ctx *ctx, const vkx_np_job *jobs, int n
         }
         if (!uniform) VKX_REQUIRE(j.scale >= 0.0 && j.scale < 400.0, "scale outside [0, 400)");   // |z| < 40: int16 holds it
         const long long tiles = np_tiles_for(j, uniform);
-        VKX_REQUIRE(tiles <= 400000, "stream too long for one job");
+        VKX_REQUIRE(tiles <= 262144, "stream too long for one job (2.6e8 samples)");
         max_tiles = std::max<int>(max_tiles, (int)tiles);
         total_tiles += tiles;
     }
@@ -595,6 +910,9 @@ VKX_EXPORT int vkx_np_draw_batch_dev(vkx_ctx *ctx, const vkx_np_job *jobs, int n
     const size_t o_states = take((size_t)total_tiles * 16);
     const size_t o_info = take(uniform ? 0 : (size_t)total_tiles * sizeof(TileInfo));
     const size_t o_plan = take(uniform ? 0 : (size_t)total_tiles * sizeof(TilePlan));
+    const size_t val_bytes = kind == VKX_NP_SPECKLE_U8 ? 8 : 2;
+    const size_t o_rmask = take(uniform ? 0 : (size_t)total_tiles * kRounds * 8);
+    const size_t o_rval = take(uniform ? 0 : (size_t)total_tiles * kTile * val_bytes);
     const size_t o_jobs = take((size_t)n_jobs * sizeof(NpJob));
     const size_t o_results = take((size_t)n_jobs * sizeof(vkx_np_result));
     rc = vkx_scratch_reserve(ctx, &ctx->np_work, off);
@@ -617,7 +935,8 @@ VKX_EXPORT int vkx_np_draw_batch_dev(vkx_ctx *ctx, const vkx_np_job *jobs, int n
         d.tile_base = tile_base;
         d.n_tiles = (int)np_tiles_for(j, uniform);
         tile_base += d.n_tiles;
-        d.kind = j.kind; d.cn = j.cn;
+        d.kind = j.kind & 0xff; d.cn = j.cn;
+        d.margin = (j.kind & VKX_NP_DEBUG_WIDE_MARGIN) ? 1.0 : 0x1p-42;
         d.loc = 0.0; d.scale = j.scale;
         d.cdf[0] = j.cdf[0]; d.cdf[1] = j.cdf[1]; d.cdf[2] = j.cdf[2];
         d.src = (const uint8_t *)j.src;
@@ -642,9 +961,16 @@ VKX_EXPORT int vkx_np_draw_batch_dev(vkx_ctx *ctx, const vkx_np_job *jobs, int n
         k_np_choice_impulse<<<wg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, res, tabs);
         VKX_LAUNCH_CHECK();
     } else {
+        uint64_t *rmask = (uint64_t *)(base + o_rmask);
+        void *rval = base + o_rval;
         {
-            VKX_TIMED(ctx, "k_np_scan");
-            k_np_scan<<<wg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, res, tabs);
+            VKX_TIMED(ctx, "k_np_draw");
+            if (kind == VKX_NP_SPECKLE_U8)
+                k_np_draw<EmitSpeckle><<<wg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, (double *)rval, rmask, res, tabs);
+            else if (kind == VKX_NP_NORMAL_ADD_U8)
+                k_np_draw<EmitAddU8><<<wg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, (int16_t *)rval, rmask, res, tabs);
+            else
+                k_np_draw<EmitI16><<<wg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, (int16_t *)rval, rmask, res, tabs);
             VKX_LAUNCH_CHECK();
         }
         {
@@ -654,13 +980,13 @@ VKX_EXPORT int vkx_np_draw_batch_dev(vkx_ctx *ctx, const vkx_np_job *jobs, int n
             VKX_LAUNCH_CHECK();
         }
         {
-            VKX_TIMED(ctx, "k_np_emit");
-            if (kind == VKX_NP_NORMAL_I16)
-                k_np_emit<EmitI16><<<wg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, plan, res, tabs);
+            VKX_TIMED(ctx, "k_np_place");
+            if (kind == VKX_NP_SPECKLE_U8)
+                k_np_place<EmitSpeckle><<<wg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, (const double *)rval, rmask, res, tabs);
             else if (kind == VKX_NP_NORMAL_ADD_U8)
-                k_np_emit<EmitAddU8><<<wg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, plan, res, tabs);
+                k_np_place<EmitAddU8><<<wg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, (const int16_t *)rval, rmask, res, tabs);
             else
-                k_np_emit<EmitSpeckle><<<wg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, plan, res, tabs);
+                k_np_place<EmitI16><<<wg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, (const int16_t *)rval, rmask, res, tabs);
             VKX_LAUNCH_CHECK();
         }
     }
@@ -675,7 +1001,7 @@ VKX_EXPORT int vkx_np_draw(vkx_ctx *ctx, const vkx_np_job *job, vkx_np_result *r
     VKX_REQUIRE(job->n >= 1 && job->n <= 0x7fffffffLL, "1 .. 2^31 - 1 samples per job");
     VKX_REQUIRE(job->dst != nullptr, "NULL destination");
     size_t src_bytes = 0, dst_bytes = 0;
-    switch (job->kind) {
+    switch (job->kind & 0xff) {
     case VKX_NP_NORMAL_I16: dst_bytes = (size_t)job->n * 2; break;
     case VKX_NP_NORMAL_ADD_U8: case VKX_NP_SPECKLE_U8: src_bytes = dst_bytes = (size_t)job->n; break;
     case VKX_NP_CHOICE3_U8: dst_bytes = (size_t)job->n; break;

@@ -2,9 +2,12 @@
 ``speckle_noise`` (:160-190) and ``poisson_noise`` (:64-98), which is one ``rng.poisson`` call on the caller's stream
 plus a saturating narrow on the GPU.
 
-The samples come from the caller-visible numpy Generator stream -- ``np.round(rng.normal(0, std, shape))`` in C
-order, one draw per channel value -- so that a stored ``config.rng_state`` reproduces the same pixels; the add
-and clip run on the GPU (``vkx_add_noise_i16``)."""
+The samples are the caller-visible numpy Generator stream -- ``np.round(rng.normal(0, std, shape))`` in C order, one
+draw per channel value -- so that a stored ``config.rng_state`` reproduces the same pixels.  For the default bit
+generator (PCG64) the stream itself is drawn on the device (``vkx_np_draw``: jump-ahead + ziggurat, value for value
+numpy's) and the caller's generator is moved past the draws it would have made; any other bit generator, or a draw the
+device declares ambiguous in the last bits of ``exp`` / ``log1p``, takes the host draw below and only the pixel
+arithmetic runs on the GPU."""
 from typing import Any, Mapping, Optional
 
 import attrs
@@ -42,9 +45,12 @@ def gaussion_noise_plane(std: float, shape, rng: RandomGenerator) -> np.ndarray:
 
 def gaussion_noise_image(config: GaussionNoiseConfig, state, image: Image, rng: Optional[RandomGenerator]):
     assert rng
-    noise = gaussion_noise_plane(config.std, image.mat.shape, rng)
+    mat = _native.np_gaussion_noise(image.mat, config.std, rng)
+    if mat is None:
+        noise = gaussion_noise_plane(config.std, image.mat.shape, rng)
+        mat = _native.add_noise_i16(image.mat, noise)
     # the mode is re-inferred from the array, like the reference
-    return Image(mat=_native.add_noise_i16(image.mat, noise))
+    return Image(mat=mat)
 
 
 gaussion_noise = Distortion(
@@ -80,8 +86,11 @@ def impulse_noise_image(config: ImpulseNoiseConfig, state, image: Image, rng: Op
     assert rng
     prob_presv = 1 - config.prob_salt - config.prob_pepper
     assert prob_presv >= 0.0
-    selector = rng.choice((0, 1, 2), size=image.shape, p=[prob_presv, config.prob_salt, config.prob_pepper])
-    return Image(mat=_native.impulse_noise(image.mat, selector.astype(np.uint8)))
+    mat = _native.np_impulse_noise(image.mat, config.prob_salt, config.prob_pepper, rng)
+    if mat is None:
+        selector = rng.choice((0, 1, 2), size=image.shape, p=[prob_presv, config.prob_salt, config.prob_pepper])
+        mat = _native.impulse_noise(image.mat, selector.astype(np.uint8))
+    return Image(mat=mat)
 
 
 impulse_noise = Distortion(
@@ -113,8 +122,11 @@ class SpeckleNoiseConfig(DistortionConfig):
 def speckle_noise_image(config: SpeckleNoiseConfig, state, image: Image, rng: Optional[RandomGenerator]):
     """``clip(px + px * N(0, std))`` with float64 samples, one per channel value in C order."""
     assert rng
-    noise = rng.normal(0, config.std, image.mat.shape)
-    return Image(mat=_native.speckle_noise(image.mat, noise))
+    mat = _native.np_speckle_noise(image.mat, config.std, rng)
+    if mat is None:
+        noise = rng.normal(0, config.std, image.mat.shape)
+        mat = _native.speckle_noise(image.mat, noise)
+    return Image(mat=mat)
 
 
 speckle_noise = Distortion(
