@@ -746,15 +746,50 @@ struct Placer<EmitAddU8> {
 }
 };
 
-// Pass 2: the recorded draws of a tile go to their final index.  Tiles whose carry-in does not merge into the recorded
-// chain (~2e-4 of them), the tile holding a job's last sample (its draw count is reported) and, for emitters that check
-// a tail sample against its pixel, tiles with a tail sample are walked again from the generator state.
+// Pass 2: the recorded draws of a tile go to their final index (k_np_place, one wavefront per tile, nothing but the
+// tile's records, masks and plan to read).  Tiles whose carry-in does not merge into the recorded chain (~2e-4 of them),
+// the tile holding a job's last sample (its draw count is reported) and, for emitters that check a tail sample against
+// its pixel, tiles with a tail sample are left to k_np_place_walk, which walks them again from the generator state.
+__device__ __forceinline__ bool tile_needs_walk(const NpJob &job, const TilePlan &p, uint32_t out0, bool check_at_store)
+{
+    return (p.c_in & kIrregular) || (long long)p.prefix + p.count >= job.n || (check_at_store && (out0 >> 31));
+}
+
 template <class Emit>
 __global__ void __launch_bounds__(256) k_np_place(const NpJob *__restrict__ jobs, int n_jobs, long long total_tiles,
-                                                  const uint64_t *__restrict__ states, const TileInfo *__restrict__ info,
-                                                  const TilePlan *__restrict__ plan, const typename Emit::Store *__restrict__ rec_val,
-                                                  const uint64_t *__restrict__ rec_mask, vkx_np_result *__restrict__ results,
-                                                  const NpTabs *__restrict__ tabs)
+                                                  const TileInfo *__restrict__ info, const TilePlan *__restrict__ plan,
+                                                  const typename Emit::Store *__restrict__ rec_val, const uint64_t *__restrict__ rec_mask,
+                                                  vkx_np_result *__restrict__ results)
+{
+    __shared__ __attribute__((aligned(16))) typename Emit::Store stage[4][kTile + 64];
+    const int lane = __lane_id();
+    const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= total_tiles) return;
+    // everything the tile reads is requested before the plan decides (one memory round trip per tile)
+    const TilePlan p = plan[tile];
+    uint64_t m = lane < kRounds ? ((const uint64_t VKX_GLOBAL *)rec_mask)[tile * kRounds + lane] : 0ull;
+    const typename Placer<Emit>::Draws draws = Placer<Emit>::load(rec_val + tile * kTile);
+    const uint32_t out0 = Emit::kCheckAtStore ? info[tile].out0 : 0u;
+    const int j = job_of_tile(jobs, n_jobs, tile);
+    const NpJob &job = jobs[j];
+    const long long prefix = (long long)rfl64(p.prefix);
+    if (prefix >= job.n) return;
+    TilePlan pu;
+    pu.prefix = (unsigned long long)prefix;
+    pu.c_in = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.c_in);
+    pu.count = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.count);
+    if (tile_needs_walk(job, pu, (uint32_t)__builtin_amdgcn_readfirstlane((int)out0), Emit::kCheckAtStore)) return;
+    uint32_t flags = 0;
+    if (lane == 0) m &= ~((1ull << pu.c_in) - 1);     // c_in < 64 is a start of the recorded chain: the draws before it belong to the previous tile
+    Placer<Emit>::place(job, draws, rec_val + tile * kTile, m, prefix, stage[threadIdx.x >> 6], flags);
+    if (flags) atomicOr(&results[j].flags, flags);
+}
+
+template <class Emit>
+__global__ void __launch_bounds__(256) k_np_place_walk(const NpJob *__restrict__ jobs, int n_jobs, long long total_tiles,
+                                                       const uint64_t *__restrict__ states, const TileInfo *__restrict__ info,
+                                                       const TilePlan *__restrict__ plan, vkx_np_result *__restrict__ results,
+                                                       const NpTabs *__restrict__ tabs)
 {
     __shared__ uint4 zig[256];
     __shared__ double fi[256];
@@ -763,31 +798,31 @@ __global__ void __launch_bounds__(256) k_np_place(const NpJob *__restrict__ jobs
     const JumpTabs &g_jump = tabs->jump;
     const int lane = __lane_id();
     const long long n_waves = (long long)gridDim.x * 4;
-    for (long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); tile < total_tiles; tile += n_waves) {
-        const int j = job_of_tile(jobs, n_jobs, tile);
-        const NpJob &job = jobs[j];
-        // everything the fast path reads is requested before the plan decides (one memory round trip per tile)
-        const TilePlan p = plan[tile];
-        uint64_t m = lane < kRounds ? ((const uint64_t VKX_GLOBAL *)rec_mask)[tile * kRounds + lane] : 0ull;
-        const typename Placer<Emit>::Draws draws = Placer<Emit>::load(rec_val + tile * kTile);
-        const long long prefix = (long long)rfl64(p.prefix);
-        if (prefix >= job.n) continue;
-        const uint32_t c_in = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.c_in);
-        const uint32_t tcount = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.count);
-        const bool last = prefix + tcount >= job.n;
-        const bool tail = Emit::kCheckAtStore && (info[tile].out0 >> 31);
-        uint32_t flags = 0;
-        if ((c_in & kIrregular) || last || tail) {
-            uint32_t count, carry;
+    // 64 tiles per step: a lane looks at one plan, the wavefront then walks the few tiles that asked for it
+    for (long long t0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; t0 < total_tiles; t0 += n_waves * 64) {
+        const long long mine = t0 + lane;
+        bool want = false;
+        if (mine < total_tiles) {
+            const NpJob &jb = jobs[job_of_tile(jobs, n_jobs, mine)];
+            const TilePlan p = plan[mine];
+            want = (long long)p.prefix < jb.n && tile_needs_walk(jb, p, info[mine].out0, Emit::kCheckAtStore);
+        }
+        uint64_t todo = __ballot(want);
+        while (todo) {
+            const int b = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const long long tile = t0 + b;
+            const int j = job_of_tile(jobs, n_jobs, tile);
+            const NpJob &job = jobs[j];
+            const TilePlan p = plan[tile];
+            uint32_t count, carry, flags = 0;
             uint64_t start0, emit0;
             bool ht;
-            walk_tile<Emit, kEmit>(job, g_jump, zig, fi, work[threadIdx.x >> 6], mk128(&states[2 * tile]), c_in & ~kIrregular, prefix,
-                                   (tile - job.tile_base) * kTile, nullptr, nullptr, count, carry, start0, emit0, ht, flags, &results[j].draws);
-        } else {
-            if (lane == 0) m &= ~((1ull << c_in) - 1);     // c_in < 64 is a start of the recorded chain: the draws before it belong to the previous tile
-            Placer<Emit>::place(job, draws, rec_val + tile * kTile, m, prefix, &work[threadIdx.x >> 6].val[0][0], flags);
+            walk_tile<Emit, kEmit>(job, g_jump, zig, fi, work[threadIdx.x >> 6], mk128(&states[2 * tile]), p.c_in & ~kIrregular,
+                                   (long long)p.prefix, (tile - job.tile_base) * kTile, nullptr, nullptr, count, carry, start0, emit0, ht,
+                                   flags, &results[j].draws);
+            if (flags) atomicOr(&results[j].flags, flags);
         }
-        if (flags) atomicOr(&results[j].flags, flags);
     }
 }
 
@@ -981,12 +1016,24 @@ VKX_EXPORT int vkx_np_draw_batch_dev(vkx_ctx *ctx, const vkx_np_job *jobs, int n
         }
         {
             VKX_TIMED(ctx, "k_np_place");
+            const unsigned pg = vkx_blocks((size_t)total_tiles, 4);
             if (kind == VKX_NP_SPECKLE_U8)
-                k_np_place<EmitSpeckle><<<wg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, (const double *)rval, rmask, res, tabs);
+                k_np_place<EmitSpeckle><<<pg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, info, plan, (const double *)rval, rmask, res);
             else if (kind == VKX_NP_NORMAL_ADD_U8)
-                k_np_place<EmitAddU8><<<wg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, (const int16_t *)rval, rmask, res, tabs);
+                k_np_place<EmitAddU8><<<pg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, info, plan, (const int16_t *)rval, rmask, res);
             else
-                k_np_place<EmitI16><<<wg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, (const int16_t *)rval, rmask, res, tabs);
+                k_np_place<EmitI16><<<pg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, info, plan, (const int16_t *)rval, rmask, res);
+            VKX_LAUNCH_CHECK();
+        }
+        {
+            VKX_TIMED(ctx, "k_np_place_walk");
+            const unsigned wg2 = (unsigned)std::min<long long>((total_tiles + 255) / 256, 256 * 4);
+            if (kind == VKX_NP_SPECKLE_U8)
+                k_np_place_walk<EmitSpeckle><<<wg2, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, tabs);
+            else if (kind == VKX_NP_NORMAL_ADD_U8)
+                k_np_place_walk<EmitAddU8><<<wg2, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, tabs);
+            else
+                k_np_place_walk<EmitI16><<<wg2, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, tabs);
             VKX_LAUNCH_CHECK();
         }
     }
