@@ -245,11 +245,7 @@ __device__ void walk_tile(const NpJob &job, const JumpTabs &g_jump, const uint4 
             // rabs < 2^52: exact conversion through the exponent trick
             double x = (__longlong_as_double((long long)(0x4330000000000000ull | rabs)) - 4503599627370496.0) * wi;
             const typename Emit::Store v = (typename Emit::Store)Emit::make(job, (u & 0x100) ? -x : x, false, flags);
-#ifndef NPX_NO_REC_STORE
             if (MODE == kRecord) rec_val[64 * r + lane] = v;
-#else
-            if (MODE == kRecord && v == 12345) rec_val[64 * r + lane] = v;
-#endif
             else ws.val[r][lane] = v;
         }
         const uint64_t slow = __ballot(rabs >= ki);
@@ -267,9 +263,6 @@ __device__ void walk_tile(const NpJob &job, const JumpTabs &g_jump, const uint4 
         }
         s = a64 * s + c64;
     }
-#ifdef NPX_NO_PHASE2
-    nev = 0;
-#endif
     if (nev > (uint32_t)kEvCap) {   // never observed; the job is redrawn on the host
         flags |= VKX_NP_SHORT;
         nev = kEvCap;
@@ -297,9 +290,18 @@ __device__ void walk_tile(const NpJob &job, const JumpTabs &g_jump, const uint4 
                 const double f1 = fi[idx], f0 = fi[idx - 1];
                 const double lhs = (f0 - f1) * un + f1;
                 const double t = -0.5 * x;
-                const double rhs = exp(t * x);
-                if (fabs(rhs - lhs) <= lhs * job.margin) flags |= VKX_NP_AMBIGUOUS;
-                info = 2u | (lhs < rhs ? 0x100u : 0u);
+                const double y = t * x;                       // in [-6.7, 0]
+                // most tests are decided by a float32 estimate of exp(y) (hardware exp2: relative error < 2^-20 with the
+                // argument reduction lost in y * log2(e)); only those within 2^-14 of the threshold pay for the float64 exp
+                const float r32 = __builtin_amdgcn_exp2f((float)y * 1.44269504f);
+                const float l32 = (float)lhs;
+                bool accept = l32 < r32;
+                if (fabsf(l32 - r32) <= r32 * 0x1p-14f || job.margin >= 1.0) {
+                    const double rhs = exp(y);
+                    if (fabs(rhs - lhs) <= lhs * job.margin) flags |= VKX_NP_AMBIGUOUS;
+                    accept = lhs < rhs;
+                }
+                info = 2u | (accept ? 0x100u : 0u);
             } else {
                 u128 t = se;
                 uint32_t len = 1;
