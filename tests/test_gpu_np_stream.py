@@ -86,18 +86,18 @@ def test_distortion_operators_take_the_device_path(monkeypatch):
         # the operator contract (distortion/interface.py:261-347): the pixels come from a private generator holding the
         # caller's state, the caller's own stream moves on by one rng.random()
         rng, ref = np.random.default_rng(3), np.random.default_rng(3)
-        out = op.distort(config, img, rng=rng)
+        out = op.distort(config, image=img, rng=rng)
         want = formula(np.random.default_rng(3), img.mat)
         assert (out.image.mat == want).all()
         ref.random()
         assert _same_state(rng, ref)
         # replay from the recorded state gives the same pixels
-        again = op.distort(config, img)
+        again = op.distort(config, image=img)
         assert (again.image.mat == want).all()
 
     rng = np.random.default_rng(4)
     config = ImpulseNoiseConfig(prob_salt=0.04, prob_pepper=0.06)
-    out = impulse_noise.distort(config, img, rng=rng)
+    out = impulse_noise.distort(config, image=img, rng=rng)
     mask = np.random.default_rng(4).choice((0, 1, 2), size=img.shape, p=[1 - 0.04 - 0.06, 0.04, 0.06])
     want = img.mat.copy()
     want[mask == 1] = 255
@@ -113,7 +113,7 @@ def test_other_bit_generators_and_forced_host_mode_fall_back(monkeypatch):
     monkeypatch.setenv('VKX_HOST_RNG', '1')
     assert N.np_gaussion_noise(img, 5.0, np.random.default_rng(0)) is None
     # the operator still works through the host draw
-    out = gaussion_noise.distort(GaussionNoiseConfig(std=5.0), Image(mat=img), rng=np.random.default_rng(8))
+    out = gaussion_noise.distort(GaussionNoiseConfig(std=5.0), image=Image(mat=img), rng=np.random.default_rng(8))
     want = np.clip(img.astype(np.int16) + np.round(np.random.default_rng(8).normal(0, 5.0, img.shape)).astype(np.int16), 0, 255)
     assert (out.image.mat == want.astype(np.uint8)).all()
 

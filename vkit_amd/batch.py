@@ -24,6 +24,10 @@ class ChainBatch:
         self._dst_shapes: List[Tuple[int, int]] = []
         self._array = None
         self._device_noise = []      # (item index, std, seed, dh, dw) of the throughput-mode items
+        self._stream_noise = []      # (item index, std, (state, inc), samples): the caller's numpy stream drawn on the device
+        self._stream_jobs = None     # [(VkxNpJob array, VkxNpResult array, [item index])] in chunks, built on the first run
+        self.stream_chunk = 64       # planes per vkx_np_draw_batch_dev call (bounds the scratch of the two-pass draw)
+        self.stream_fallbacks = 0    # planes the device declared ambiguous and the host drew instead
         self._runs = 0
         self._page_layers = {}       # item index -> [VkxLayer with device planes]: assembled into the source before the chain
         self._layer_tables = None
@@ -37,11 +41,14 @@ class ChainBatch:
 
     def add(self, image: np.ndarray, state: DistortionStateImageGridBased, blur_sigma: Optional[float] = None,
             hue_delta: Optional[int] = None, noise: Optional[np.ndarray] = None, streak=None,
-            noise_std: Optional[float] = None, noise_seed: Optional[int] = None):
+            noise_std: Optional[float] = None, noise_seed: Optional[int] = None, noise_rng=None):
         """Registers one HxWx3 uint8 image with its image-grid state and per-image photometric parameters (stage order:
         remap, gaussian_blur, color_shift, gaussion_noise, line_streak; ``None`` skips a stage).
 
         ``noise``: the caller's int16 plane (parity mode: the reference's values, from the caller's numpy stream).
+        ``noise_std`` + ``noise_rng`` (a numpy Generator over PCG64, left untouched): parity mode without a host plane --
+        every ``run`` draws ``np.round(rng.normal(0, std, (dh, dw, 3)))`` from that generator's stream ON THE DEVICE, value for
+        value what numpy would have drawn (``vkx_np_draw_batch_dev``); the same plane every run, like a resident one.
         ``noise_std`` + ``noise_seed``: throughput mode -- every ``run`` draws a fresh plane of the same distribution on
         the device (``vkx_noise_normal_i16_dev``, seed advanced per run), nothing crosses the link."""
         if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
@@ -62,11 +69,18 @@ class ChainBatch:
         item.rows, item.cols = sv.shape[0], sv.shape[1]
         if noise_std is not None:
             if noise is not None:
-                raise ValueError('pass either a noise plane or noise_std / noise_seed')
+                raise ValueError('pass either a noise plane or noise_std with noise_seed / noise_rng')
             item.noise = self.ctx.malloc(dh * dw * 3 * 2)
             self._owned.append(item.noise)
             item.noise_stride_el = dw * 3
-            self._device_noise.append((len(self._items), float(noise_std), int(noise_seed or 0), dh, dw))
+            if noise_rng is not None:
+                stream = _native.np_stream(noise_rng)
+                if stream is None:
+                    raise ValueError('noise_rng must be a numpy Generator over PCG64 (numpy.random.default_rng)')
+                self._stream_noise.append((len(self._items), float(noise_std), stream, dh * dw * 3))
+                self._stream_jobs = None
+            else:
+                self._device_noise.append((len(self._items), float(noise_std), int(noise_seed or 0), dh, dw))
         if noise is not None:
             if noise.shape != (dh, dw, 3):
                 raise ValueError(f'noise plane must be {(dh, dw, 3)}, got {noise.shape}')
@@ -152,11 +166,55 @@ class ChainBatch:
     def result_pixels(self) -> int:
         return sum(h * w for h, w in self._dst_shapes)
 
-    def run(self):
-        """Enqueues the chain for every image on the ctx stream (asynchronous)."""
+    def _draw_streams(self):
+        """The int16 planes of the ``noise_rng`` items, drawn from their numpy streams on the device."""
+        lib = _native.lib()
+        first = self._stream_jobs is None
+        if first:
+            self._stream_jobs = []
+            for k in range(0, len(self._stream_noise), max(1, self.stream_chunk)):
+                part = self._stream_noise[k:k + max(1, self.stream_chunk)]
+                jobs = (_native.VkxNpJob * len(part))()
+                for t, (index, std, stream, n) in enumerate(part):
+                    jobs[t] = _native.np_job(_native.NP_NORMAL_I16, stream, n, std, dst=self._items[index].noise)
+                self._stream_jobs.append((jobs, (_native.VkxNpResult * len(part))(), part))
+        for jobs, results, _part in self._stream_jobs:
+            _native.check(lib.vkx_np_draw_batch_dev(self.ctx.handle, jobs, len(jobs), results))
+        if first:
+            # the streams are fixed, so is the device's verdict on them: a plane it declared ambiguous in the last bits of
+            # exp / log1p (expected < 1e-6 per plane) is drawn by numpy once and stays resident like a caller's plane
+            self.ctx.sync()
+            kept = []
+            for jobs, results, part in self._stream_jobs:
+                good = []
+                for t, (index, std, (state, inc), n) in enumerate(part):
+                    if results[t].flags:
+                        rng = np.random.default_rng()
+                        st = rng.bit_generator.state
+                        st['state'] = {'state': state, 'inc': inc}
+                        rng.bit_generator.state = st
+                        plane = np.round(rng.normal(0, std, n)).astype(np.int16)
+                        self.ctx.upload(self._items[index].noise, plane)
+                        self.stream_fallbacks += 1
+                    else:
+                        good.append(part[t])
+                if len(good) == len(part):
+                    kept.append((jobs, results, part))
+                elif good:
+                    njobs = (_native.VkxNpJob * len(good))()
+                    for t, (index, std, stream, n) in enumerate(good):
+                        njobs[t] = _native.np_job(_native.NP_NORMAL_I16, stream, n, std, dst=self._items[index].noise)
+                    kept.append((njobs, (_native.VkxNpResult * len(good))(), good))
+            self._stream_jobs = kept
+
+    def run(self, draw_streams: bool = True):
+        """Enqueues the chain for every image on the ctx stream (asynchronous).  ``draw_streams=False`` leaves the planes of
+        the ``noise_rng`` items as the previous run drew them (they are the same every run)."""
         if self._array is None:
             self._array = (_native.VkxChainItem * max(len(self._items), 1))(*self._items)
         lib = _native.lib()
+        if self._stream_noise and (draw_streams or self._stream_jobs is None):
+            self._draw_streams()
         for index, std, seed, dh, dw in self._device_noise:
             _native.check(lib.vkx_noise_normal_i16_dev(self.ctx.handle, self._items[index].noise, dw * 3, dh, dw, 3, std,
                                                        (seed + self._runs * 0x9E3779B97F4A7C15) & 0xffffffffffffffff))
@@ -177,6 +235,8 @@ class ChainBatch:
         self._owned.clear()
         self._items.clear()
         self._device_noise.clear()
+        self._stream_noise.clear()
+        self._stream_jobs = None
         self._page_layers.clear()
         self._layer_tables = None
         self._array = None
