@@ -64,6 +64,20 @@ def test_operators_draw_on_the_device_and_match_the_host_formulas():
         assert (got == want).all() and _same_state(rng, ref)
 
 
+def test_speckle_with_black_pixels_stays_on_the_device():
+    """A zero pixel is zero whatever the noise: a tail draw landing on one is not an ambiguity (several seeds, 3 M samples each:
+    ~800 tail draws per plane, a third of them on black pixels here)."""
+    img = np.random.default_rng(2).integers(0, 256, (1024, 1024, 3), dtype=np.uint8)
+    img[::3] = 0
+    for seed in range(4):
+        rng, ref = np.random.default_rng(seed), np.random.default_rng(seed)
+        got = N.np_speckle_noise(img, 0.25, rng)
+        assert got is not None, seed
+        m = img.astype(np.float32)
+        want = np.clip(m + m * ref.normal(0, 0.25, m.shape), 0, 255).astype(np.uint8)
+        assert (got == want).all() and _same_state(rng, ref)
+
+
 def test_distortion_operators_take_the_device_path(monkeypatch):
     """gaussion / speckle / impulse through Distortion.distort: same pixels and same generator state as the host formulas,
     and the device path is the one that ran."""

@@ -52,6 +52,7 @@ struct JumpTabs {
     uint64_t pow2[64][4];    // j = 2^i: A^j lo, hi, G_j lo, hi
     uint64_t lane[64][4];    // j = l + 1
     uint64_t a64[2], g64[2];
+    uint64_t a128[2], g128[2];
 };
 static JumpTabs g_jump_host;
 static bool g_jump_host_ready = false;
@@ -84,6 +85,9 @@ static void build_jump_tabs()
     jump_consts(64, &a, &g);
     g_jump_host.a64[0] = (uint64_t)a; g_jump_host.a64[1] = (uint64_t)(a >> 64);
     g_jump_host.g64[0] = (uint64_t)g; g_jump_host.g64[1] = (uint64_t)(g >> 64);
+    jump_consts(128, &a, &g);
+    g_jump_host.a128[0] = (uint64_t)a; g_jump_host.a128[1] = (uint64_t)(a >> 64);
+    g_jump_host.g128[0] = (uint64_t)g; g_jump_host.g128[1] = (uint64_t)(g >> 64);
     g_jump_host_ready = true;
 }
 
@@ -96,6 +100,7 @@ struct NpTabs {              // uploaded once per context
 struct NpJob {
     uint64_t state[2], inc[2];
     uint64_t c64[2];         // inc * G_64: the addend of a 64-draw stride
+    uint64_t c128[2];        // inc * G_128
     long long n;             // samples wanted
     long long tile_base;     // index of the job's first tile in the batch-wide tile arrays
     int n_tiles;
@@ -137,7 +142,8 @@ __device__ __forceinline__ int rounded_step(const NpJob &job, double z, bool ine
         const double f = v - floor(v);
         if (fabs(f - 0.5) < 1e-9) flags |= VKX_NP_AMBIGUOUS;
     }
-    return (int16_t)__double2int_rn(v);
+    // |v| < 2^31: adding 1.5 * 2^52 leaves rint(v) (round half to even) in the low dword
+    return (int16_t)(int)__double_as_longlong(v + 6755399441055744.0);
 }
 struct EmitNone {
     typedef int Val;
@@ -174,7 +180,9 @@ struct EmitSpeckle {   // uint8(clip(px + px * (0 + std * z), 0, 255)) in float6
         const double m = (double)((const uint8_t VKX_GLOBAL *)job.src)[pos];
         const double t = m * noise;
         double r = m + t;
-        if (inexact && fabs(r - rint(r)) < 1e-9) flags |= VKX_NP_AMBIGUOUS;
+        // a tail draw carries log1p's last bits: the pixel is in doubt only when px + px * noise sits on an integer boundary
+        // (a zero pixel stays zero whatever the noise)
+        if (inexact && m != 0.0 && fabs(r - rint(r)) < 1e-9) flags |= VKX_NP_AMBIGUOUS;
         r = r < 0.0 ? 0.0 : (r > 255.0 ? 255.0 : r);
         ((uint8_t VKX_GLOBAL *)job.dst)[pos] = (uint8_t)(int)r;
     }
@@ -233,9 +241,10 @@ __device__ void walk_tile(const NpJob &job, const JumpTabs &g_jump, const uint4 
     u128 s = mk128(&g_jump.lane[lane][0]) * base + mk128(&g_jump.lane[lane][2]) * inc;
     uint32_t nev = 0;
     if (lane < kRounds) ws.semit[lane] = 0;
-#pragma unroll 1
-    for (int r = 0; r < kRounds; r++) {
-        const uint64_t u = pcg_out(s);
+    // two rounds per iteration from two independent generator states (draws 64 r + l and 64 (r + 1) + l, both striding
+    // 128): twice the instruction-level parallelism for the long dependent chain state -> draw -> table -> compare
+    auto round = [&](int r, const u128 &st) {
+        const uint64_t u = pcg_out(st);
         const int idx = (int)(u & 0xff);
         const uint64_t rabs = (u >> 9) & 0x000fffffffffffffull;
         const uint4 e = zig[idx];
@@ -244,7 +253,9 @@ __device__ void walk_tile(const NpJob &job, const JumpTabs &g_jump, const uint4 
             const double wi = __longlong_as_double(((long long)e.w << 32) | e.z);
             // rabs < 2^52: exact conversion through the exponent trick
             double x = (__longlong_as_double((long long)(0x4330000000000000ull | rabs)) - 4503599627370496.0) * wi;
-            const typename Emit::Store v = (typename Emit::Store)Emit::make(job, (u & 0x100) ? -x : x, false, flags);
+            // x >= 0: the sign (bit 8 of the draw) is or-ed into the float64 sign bit
+            x = __longlong_as_double(__double_as_longlong(x) | ((long long)((uint32_t)u << 23 & 0x80000000u) << 32));
+            const typename Emit::Store v = (typename Emit::Store)Emit::make(job, x, false, flags);
             if (MODE == kRecord) rec_val[64 * r + lane] = v;
             else ws.val[r][lane] = v;
         }
@@ -254,14 +265,22 @@ __device__ void walk_tile(const NpJob &job, const JumpTabs &g_jump, const uint4 
             if (rabs >= ki) {
                 const uint32_t slot = nev + (uint32_t)mbcnt64(slow);
                 if (slot < (uint32_t)kEvCap) {
-                    ws.ev_s[slot][0] = (uint64_t)s;
-                    ws.ev_s[slot][1] = (uint64_t)(s >> 64);
+                    ws.ev_s[slot][0] = (uint64_t)st;
+                    ws.ev_s[slot][1] = (uint64_t)(st >> 64);
                     ws.ev_pos[slot] = (uint16_t)(64 * r + lane);
                 }
             }
             nev += (uint32_t)__builtin_popcountll(slow);
         }
-        s = a64 * s + c64;
+    };
+    const u128 a128 = mk128(g_jump.a128), c128 = mk128(job.c128);
+    u128 s2 = a64 * s + c64;
+#pragma unroll 1
+    for (int r = 0; r < kRounds; r += 2) {
+        round(r, s);
+        round(r + 1, s2);
+        s = a128 * s + c128;
+        s2 = a128 * s2 + c128;
     }
     if (nev > (uint32_t)kEvCap) {   // never observed; the job is redrawn on the host
         flags |= VKX_NP_SHORT;
@@ -960,6 +979,7 @@ VKX_EXPORT int vkx_np_draw_batch_dev(vkx_ctx *ctx, const vkx_np_job *jobs, int n
     if ((rc = vkx_desc_ring_take(ctx, (size_t)n_jobs * sizeof(NpJob), &ring))) return rc;
     NpJob *hj = (NpJob *)ring;
     const u128 g64 = ((u128)g_jump_host.g64[1] << 64) | g_jump_host.g64[0];
+    const u128 g128 = ((u128)g_jump_host.g128[1] << 64) | g_jump_host.g128[0];
     long long tile_base = 0;
     for (int i = 0; i < n_jobs; i++) {
         const vkx_np_job &j = jobs[i];
@@ -968,6 +988,8 @@ VKX_EXPORT int vkx_np_draw_batch_dev(vkx_ctx *ctx, const vkx_np_job *jobs, int n
         d.inc[0] = j.inc[0]; d.inc[1] = j.inc[1];
         const u128 c64 = (((u128)j.inc[1] << 64) | j.inc[0]) * g64;
         d.c64[0] = (uint64_t)c64; d.c64[1] = (uint64_t)(c64 >> 64);
+        const u128 c128 = (((u128)j.inc[1] << 64) | j.inc[0]) * g128;
+        d.c128[0] = (uint64_t)c128; d.c128[1] = (uint64_t)(c128 >> 64);
         d.n = j.n;
         d.tile_base = tile_base;
         d.n_tiles = (int)np_tiles_for(j, uniform);
