@@ -429,7 +429,7 @@ class PinnedPool:
 
     GRANULE = 1 << 16
 
-    def __init__(self, ctx, cap_bytes=2 << 30, max_bytes=16 << 30):
+    def __init__(self, ctx, cap_bytes=2 << 30, max_bytes=6 << 30):
         import weakref
         self._weakref = weakref
         self._ctx = weakref.ref(ctx)
@@ -444,17 +444,26 @@ class PinnedPool:
         dtype = np.dtype(dtype)
         nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
         ctx = self._ctx()
-        if not self.enabled or nbytes < self.GRANULE or ctx is None or self._out + nbytes > self.max_bytes:
+        if not self.enabled or nbytes < self.GRANULE or ctx is None or not ctx._h:
             return np.empty(shape, dtype)
         size = (nbytes + self.GRANULE - 1) // self.GRANULE * self.GRANULE
         with self._lock:
+            if self._out + size > self.max_bytes:
+                return np.empty(shape, dtype)
             blocks = self._free.get(size)
             ptr = blocks.pop() if blocks else None
             if ptr is not None:
                 self._idle -= size
+            self._out += size
         if ptr is None:
-            ptr = ctx.host_alloc(size)
-        self._out += size
+            try:
+                ptr = ctx.host_alloc(size)
+            except VkxError:
+                # page-locked memory is a limited resource (memlock ulimit, many worker processes): a pageable array is
+                # slower to fill, never wrong
+                with self._lock:
+                    self._out -= size
+                return np.empty(shape, dtype)
         buf = (ctypes.c_char * size).from_address(ptr)
         self._weakref.finalize(buf, self._release, ptr, size)
         return np.frombuffer(buf, dtype=dtype, count=nbytes // dtype.itemsize).reshape(shape)
@@ -467,11 +476,7 @@ class PinnedPool:
                 self._free.setdefault(size, []).append(ptr)
                 self._idle += size
                 return
-        if ctx is not None and ctx._h:
-            try:
-                ctx.host_free(ptr)
-            except Exception:
-                pass
+        _free_pinned(ctx, ptr)
 
     def close(self):
         ctx = self._ctx()
@@ -484,6 +489,30 @@ class PinnedPool:
                         ctx.host_free(ptr)
                     except Exception:
                         pass
+
+
+_orphan_blocks = []
+_orphan_lock = threading.Lock()
+
+
+def _free_pinned(ctx, ptr):
+    """hipHostFree through ``ctx``; a block whose context is gone waits for the next live one (vkx_host_free needs a
+    context for the device guard), so nothing stays page-locked for the life of the process."""
+    with _orphan_lock:
+        todo = _orphan_blocks + [ptr]
+        del _orphan_blocks[:]
+    if ctx is None or not ctx._h:
+        live = [c for c in _default_ctx.values() if c._h]
+        ctx = live[0] if live else None
+    if ctx is None:
+        with _orphan_lock:
+            _orphan_blocks.extend(todo)
+        return
+    for p in todo:
+        try:
+            ctx.host_free(p)
+        except Exception:
+            pass
 
 
 _default_ctx = {}

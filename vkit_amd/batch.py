@@ -127,6 +127,13 @@ class ChainBatch:
         for other in self._page_layers:
             if (self._items[other].sh, self._items[other].sw) != (item.sh, item.sw):
                 raise ValueError('pages with layers must share one source shape')
+        for old in self._page_layers.get(index, ()):      # the planes of the list this call replaces
+            for field in ('mask', 'alpha', 'value'):
+                ptr = getattr(old, field)
+                if ptr and ptr in self._owned:
+                    self.ctx.sync()
+                    self._owned.remove(ptr)
+                    self.ctx.free(ptr)
         self._page_layers[index] = dev_layers
         self._layer_tables = None
 

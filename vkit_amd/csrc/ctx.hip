@@ -112,7 +112,14 @@ VKX_EXPORT int vkx_ctx_set_stream(vkx_ctx *ctx, void *hip_stream)
             return VKX_ERR_INVALID;
         }
     }
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    hipStream_t next = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    if (next != ctx->stream && ctx->desc_off != 0) {
+        // slices of the descriptor ring may still be read by work queued on the stream being left; the ring's reuse
+        // rules (wrap, reallocation) only ever wait for the CURRENT stream
+        vkx_device_guard guard(ctx);
+        VKX_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    ctx->stream = next;
     return VKX_OK;
 }
 

@@ -39,6 +39,7 @@ class _Slot:
         self.host = None       # flat uint8 page-locked result buffer
         self.event = None      # recorded after the job's last download
         self.views = None
+        self.inputs = []       # the caller's arrays the queued uploads still read (released when the event has completed)
         self.ticket = -1
 
     def device(self, name, nbytes):
@@ -60,6 +61,14 @@ class _Slot:
         if self.event is not None:
             self.ctx.event_wait(self.event)
             self.event = None
+        self.inputs = []       # every copy of the job has run: the input arrays may go back to their pool
+
+    def copy_in(self, dptr, array):
+        """Queues an asynchronous upload and keeps ``array`` alive until the job's event has completed: a page-locked
+        result of another call handed straight in (``submit_remap([op(x).mat], state)``) would otherwise return to the
+        pinned pool -- and to another lane's download -- while the DMA is still reading it."""
+        self.inputs.append(array)
+        self.ctx.copy_in(dptr, array)
 
     def close(self):
         self.wait()
@@ -104,8 +113,8 @@ class HostPipeline:
             raise ValueError('source / destination grids differ in shape')
         half = self._aligned(sv.nbytes)
         base = slot.device('lattice', 2 * half)
-        slot.ctx.copy_in(base, sv)
-        slot.ctx.copy_in(base + half, dv)
+        slot.copy_in(base, sv)
+        slot.copy_in(base + half, dv)
         return base, base + half, sv.shape[0], sv.shape[1]
 
     def _finish(self, slot, pieces):
@@ -129,7 +138,9 @@ class HostPipeline:
     # ------------------------------------------------------------------------------------------------ jobs
     def submit_remap(self, mats: Sequence[np.ndarray], state) -> int:
         """Image / Mask / ScoreMap arrays of one source shape through the state's lattice pair
-        (``DistortionImageGridBased.distort``): up to four elements per job."""
+        (``DistortionImageGridBased.distort``): up to four elements per job.  The uploads are asynchronous: the pipeline
+        holds a reference to every input array until the job has completed, and the caller must not MODIFY them before
+        ``result(ticket)`` has returned."""
         mats = [np.ascontiguousarray(m) for m in mats]
         if not 1 <= len(mats) <= 4:
             raise ValueError('1..4 elements per job')
@@ -152,7 +163,7 @@ class HostPipeline:
                 raise TypeError(f'unsupported element {m.dtype} {m.shape}')
             src_d = slot.device(f'src{j}', m.nbytes)
             dst_d = slot.device(f'dst{j}', int(np.prod(out_shape)) * m.dtype.itemsize)
-            slot.ctx.copy_in(src_d, m)
+            slot.copy_in(src_d, m)
             elems[j] = _native.VkxElem(src_d, dst_d, sstride, dstride, cn, is_f32)
             pieces.append((dst_d, out_shape, m.dtype))
         _native.check(_native.lib().vkx_grid_remap_dev(slot.ctx.handle, elems, len(mats), sh, sw, ctypes.c_void_p(sv_d),
@@ -164,7 +175,8 @@ class HostPipeline:
                      noise_std: Optional[float] = None, noise_seed: Optional[int] = None) -> int:
         """One RGB page through remap -> gaussian_blur -> color_shift -> gaussion_noise -> line_streak (``None`` skips a
         stage), the fused kernel of ``vkx_chain_rgb_batch_dev``.  ``noise``: the caller's int16 plane, uploaded (6 bytes
-        per result pixel); ``noise_std`` / ``noise_seed``: throughput mode, the plane is drawn on the device."""
+        per result pixel); ``noise_std`` / ``noise_seed``: throughput mode, the plane is drawn on the device.  ``image`` and
+        ``noise`` are referenced until the job has completed and must not be modified before ``result(ticket)``."""
         image = np.ascontiguousarray(image)
         if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
             raise ValueError('submit_chain takes HxWx3 uint8 images')
@@ -175,7 +187,7 @@ class HostPipeline:
         item = _native.VkxChainItem()
         item.src = slot.device('src0', image.nbytes)
         item.dst = slot.device('dst0', dh * dw * 3)
-        slot.ctx.copy_in(item.src, image)
+        slot.copy_in(item.src, image)
         item.src_stride, item.dst_stride = sw * 3, dw * 3
         item.sh, item.sw, item.dh, item.dw = sh, sw, dh, dw
         item.src_vertices, item.dst_vertices, item.rows, item.cols = sv_d, dv_d, rows, cols
@@ -192,7 +204,7 @@ class HostPipeline:
                 raise ValueError(f'noise plane must be {(dh, dw, 3)}, got {noise.shape}')
             item.noise = slot.device('noise', noise.nbytes)
             item.noise_stride_el = dw * 3
-            slot.ctx.copy_in(item.noise, noise)
+            slot.copy_in(item.noise, noise)
         if blur_sigma is not None:
             item.blur_sigma = float(blur_sigma)
             item.blur_ksize = _estimate_gaussian_kernel_size(blur_sigma)
