@@ -126,6 +126,31 @@ def measure(quick=False):
                                                'note': 'C3 chain per image, noise drawn on the device (vkx_noise_normal_i16_dev): '
                                                        'the distribution of the reference, not its numpy values'}
 
+    # the same chain, value-exact: the plane np.round(default_rng(5000 + i).normal(0, 10, shape)) is drawn on the device from
+    # the numpy stream (vkx_np_draw_batch_dev), nothing but the page crosses the link; checked against the uploaded-plane job
+    with HostPipeline(ctx) as pipe:
+        want = pipe.result(pipe.submit_chain(pinned[0], cstates[0], blur_sigma=1.0, hue_delta=37, noise=noises[0]))[0].copy()
+        got = pipe.result(pipe.submit_chain(pinned[0], cstates[0], blur_sigma=1.0, hue_delta=37, noise_std=10.0,
+                                            noise_rng=default_rng(5000)))[0]
+        exact = bool((got == want).all())
+        for _ in pipe.slots:
+            pipe.submit_chain(pinned[0], cstates[0], blur_sigma=1.0, hue_delta=37, noise_std=10.0, noise_rng=default_rng(5000))
+        pipe.drain()
+        t0 = time.perf_counter()
+        tickets = []
+        for k in range(jobs):
+            i = k % n_img
+            tickets.append(pipe.submit_chain(pinned[i], cstates[i], blur_sigma=1.0, hue_delta=37, noise_std=10.0,
+                                             noise_rng=default_rng(5000 + i)))
+            if k >= 7:
+                pipe.result(tickets[k - 7])
+        pipe.drain()
+        dt = time.perf_counter() - t0
+    out['pipeline_chain_2048_numpy_stream'] = {'images_per_s': jobs / dt, 'mpx_per_s': jobs * S * S / dt / 1e6,
+                                               'ms_per_image': dt / jobs * 1e3, 'equals_uploaded_plane_job': exact,
+                                               'note': 'C3 chain per image, the numpy noise stream of the image drawn on the device '
+                                                       '(value for value the reference\'s plane): only the page crosses the link'}
+
     # ---- RandomDistortion on 1024^2 pages
     P = 1024
     pages = [Image(mat=default_rng(100 + i).integers(0, 256, (P, P, 3), dtype=np.uint8)) for i in range(8)]

@@ -1001,6 +1001,30 @@ def np_consume(rng, draws):
     rng.bit_generator.state = st
 
 
+class NpResults:
+    """``VkxNpResult[n]`` in page-locked memory: the device -> host copy of vkx_np_draw_batch_dev stays asynchronous (into a
+    pageable array the runtime stages it and blocks the calling thread until the stream has drained)."""
+
+    def __init__(self, ctx, n):
+        self._ctx, self.n = ctx, int(n)
+        self._ptr = ctx.host_alloc(max(1, self.n) * ctypes.sizeof(VkxNpResult))
+        self.array = (VkxNpResult * max(1, self.n)).from_address(self._ptr)
+
+    def __getitem__(self, i):
+        return self.array[i]
+
+    def close(self):
+        if self._ptr:
+            _free_pinned(self._ctx, self._ptr)
+            self._ptr = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def np_job(kind, stream, n, scale=0.0, cdf=(2.0, 2.0, 2.0), cn=1, src=None, dst=None):
     job = VkxNpJob()
     state, inc = stream

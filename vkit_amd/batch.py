@@ -184,9 +184,9 @@ class ChainBatch:
                 jobs = (_native.VkxNpJob * len(part))()
                 for t, (index, std, stream, n) in enumerate(part):
                     jobs[t] = _native.np_job(_native.NP_NORMAL_I16, stream, n, std, dst=self._items[index].noise)
-                self._stream_jobs.append((jobs, (_native.VkxNpResult * len(part))(), part))
+                self._stream_jobs.append((jobs, _native.NpResults(self.ctx, len(part)), part))
         for jobs, results, _part in self._stream_jobs:
-            _native.check(lib.vkx_np_draw_batch_dev(self.ctx.handle, jobs, len(jobs), results))
+            _native.check(lib.vkx_np_draw_batch_dev(self.ctx.handle, jobs, len(jobs), results.array))
         if first:
             # the streams are fixed, so is the device's verdict on them: a plane it declared ambiguous in the last bits of
             # exp / log1p (expected < 1e-6 per plane) is drawn by numpy once and stays resident like a caller's plane
@@ -211,7 +211,7 @@ class ChainBatch:
                     njobs = (_native.VkxNpJob * len(good))()
                     for t, (index, std, stream, n) in enumerate(good):
                         njobs[t] = _native.np_job(_native.NP_NORMAL_I16, stream, n, std, dst=self._items[index].noise)
-                    kept.append((njobs, (_native.VkxNpResult * len(good))(), good))
+                    kept.append((njobs, _native.NpResults(self.ctx, len(good)), good))
             self._stream_jobs = kept
 
     def run(self, draw_streams: bool = True):

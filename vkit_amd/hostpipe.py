@@ -30,6 +30,13 @@ from vkit_amd import _native
 from vkit_amd.mechanism.distortion.photometric.blur import _estimate_gaussian_kernel_size
 
 
+def _clone_rng(rng):
+    """A generator with ``rng``'s bit generator state (``rng`` itself stays where it is)."""
+    clone = np.random.Generator(type(rng.bit_generator)())
+    clone.bit_generator.state = rng.bit_generator.state
+    return clone
+
+
 class _Slot:
     """Device and page-locked host buffers of one in-flight job (grown on demand, never shrunk)."""
 
@@ -40,6 +47,8 @@ class _Slot:
         self.event = None      # recorded after the job's last download
         self.views = None
         self.inputs = []       # the caller's arrays the queued uploads still read (released when the event has completed)
+        self.np_check = None   # (VkxNpJob array, NpResults, redo closure) of a device-drawn numpy noise stream
+        self.np_results = None
         self.ticket = -1
 
     def device(self, name, nbytes):
@@ -76,6 +85,9 @@ class _Slot:
             self.ctx.free(ptr)
         self.dev.clear()
         self.host = None
+        if self.np_results is not None:
+            self.np_results.close()
+            self.np_results = None
 
 
 class HostPipeline:
@@ -98,6 +110,7 @@ class HostPipeline:
     def _take_slot(self) -> _Slot:
         slot = self.slots[self._next % len(self.slots)]
         slot.wait()                      # its previous job has left the device: buffers are free again
+        slot.np_check = None
         slot.ticket = self._next
         self._next += 1
         return slot
@@ -172,10 +185,13 @@ class HostPipeline:
 
     def submit_chain(self, image: np.ndarray, state, blur_sigma: Optional[float] = None,
                      hue_delta: Optional[int] = None, noise: Optional[np.ndarray] = None, streak=None,
-                     noise_std: Optional[float] = None, noise_seed: Optional[int] = None) -> int:
+                     noise_std: Optional[float] = None, noise_seed: Optional[int] = None, noise_rng=None) -> int:
         """One RGB page through remap -> gaussian_blur -> color_shift -> gaussion_noise -> line_streak (``None`` skips a
         stage), the fused kernel of ``vkx_chain_rgb_batch_dev``.  ``noise``: the caller's int16 plane, uploaded (6 bytes
-        per result pixel); ``noise_std`` / ``noise_seed``: throughput mode, the plane is drawn on the device.  ``image`` and
+        per result pixel); ``noise_std`` / ``noise_rng`` (a numpy Generator over PCG64, left untouched): the plane
+        ``np.round(noise_rng.normal(0, noise_std, shape))`` is drawn on the device from that generator's stream, value for value
+        -- the reference's pixels with nothing but the image over the link; ``noise_std`` / ``noise_seed``: throughput mode,
+        a plane of the same distribution.  ``image`` and
         ``noise`` are referenced until the job has completed and must not be modified before ``result(ticket)``."""
         image = np.ascontiguousarray(image)
         if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
@@ -196,8 +212,30 @@ class HostPipeline:
                 raise ValueError('pass either a noise plane or noise_std / noise_seed')
             item.noise = slot.device('noise', dh * dw * 3 * 2)
             item.noise_stride_el = dw * 3
-            _native.check(_native.lib().vkx_noise_normal_i16_dev(slot.ctx.handle, item.noise, dw * 3, dh, dw, 3,
-                                                                float(noise_std), int(noise_seed or 0) & 0xffffffffffffffff))
+            stream = _native.np_stream(noise_rng) if noise_rng is not None else None
+            if noise_rng is not None and stream is None:
+                # not a PCG64 generator (or VKX_HOST_RNG=1): the host draws, the plane travels
+                return self.submit_chain(image, state, blur_sigma, hue_delta,
+                                         np.round(_clone_rng(noise_rng).normal(0, noise_std, (dh, dw, 3))).astype(np.int16), streak)
+            if stream is not None:
+                jobs = (_native.VkxNpJob * 1)(_native.np_job(_native.NP_NORMAL_I16, stream, dh * dw * 3, noise_std, dst=item.noise))
+                if slot.np_results is None:
+                    slot.np_results = _native.NpResults(slot.ctx, 1)
+                results = slot.np_results
+                _native.check(_native.lib().vkx_np_draw_batch_dev(slot.ctx.handle, jobs, 1, results.array))
+
+                def redo(image=image, state=state, stream=stream):
+                    # the device declared a decision of this stream ambiguous in the last bits of exp / log1p: numpy draws
+                    rng = np.random.default_rng()
+                    st = rng.bit_generator.state
+                    st['state'] = {'state': stream[0], 'inc': stream[1]}
+                    rng.bit_generator.state = st
+                    plane = np.round(rng.normal(0, noise_std, (dh, dw, 3))).astype(np.int16)
+                    return self.submit_chain(image, state, blur_sigma, hue_delta, plane, streak)
+                slot.np_check = (jobs, results, redo)
+            else:
+                _native.check(_native.lib().vkx_noise_normal_i16_dev(slot.ctx.handle, item.noise, dw * 3, dh, dw, 3,
+                                                                    float(noise_std), int(noise_seed or 0) & 0xffffffffffffffff))
         if noise is not None:
             noise = np.ascontiguousarray(noise, dtype=np.int16)
             if noise.shape != (dh, dw, 3):
@@ -272,6 +310,12 @@ class HostPipeline:
         if slot.ticket != ticket:
             raise KeyError(f'job {ticket} has been overwritten: at most {len(self.slots)} jobs stay readable')
         slot.wait()
+        if slot.np_check is not None:
+            _jobs, results, redo = slot.np_check
+            slot.np_check = None
+            if results[0].flags:
+                views = [np.array(v) for v in self.result(redo())]     # synchronous, with the host-drawn plane
+                slot.views = views
         return slot.views
 
     def drain(self):
