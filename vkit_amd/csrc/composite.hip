@@ -137,6 +137,174 @@ __global__ void __launch_bounds__(256) k_composite(T *dst, ptrdiff_t dstride, in
     }
 }
 
+// uint8 RGB destinations whose rows are whole 4-pixel groups (row pitch and width multiples of 4: every page the pipeline
+// composes): a lane owns FOUR consecutive pixels of one row = 12 bytes = three dwords, so the destination moves as
+// dwordx3 accesses, float alpha planes as dwordx4, byte masks as one dword and image layers as three.  The records of
+// the tile's layers are copied to LDS by the whole workgroup in one round trip (instead of one dependent scalar load
+// chain per layer), the planes of layer n + 1 are requested before layer n is blended, a wavefront whose 256 pixels a
+// layer does not select skips its arithmetic, and the destination is not read where the tile's first layer is an opaque
+// plain copy (the page background).  Arithmetic per pixel: exactly blend_px / the copy rules of k_composite.
+constexpr int kRgbRecs = 32;     // layer records staged in LDS per pass
+typedef uint32_t u32_a1 __attribute__((aligned(1)));
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+struct RgbFetch {
+    float a[4];          // alpha of the four pixels (scalar alpha replicated)
+    uint32_t sel;        // bit i: pixel i is selected by the layer
+    uint32_t v[3];       // the twelve value bytes (image layers) or the constant colour replicated
+};
+
+__device__ __forceinline__ RgbFetch rgb_fetch(const LayerDev<uint8_t> &L, int x0, int y)
+{
+    RgbFetch f;
+    f.sel = 0;
+    f.a[0] = f.a[1] = f.a[2] = f.a[3] = L.alpha_scalar;
+    const uint32_t c0 = L.value_const[0], c1 = L.value_const[1], c2 = L.value_const[2];
+    f.v[0] = c0 | (c1 << 8) | (c2 << 16) | (c0 << 24);
+    f.v[1] = c1 | (c2 << 8) | (c0 << 16) | (c1 << 24);
+    f.v[2] = c2 | (c0 << 8) | (c1 << 16) | (c2 << 24);
+    const int by = y - L.up, bx = x0 - L.left;
+    if (by < 0 || by >= L.height || bx + 3 < 0 || bx >= L.width) return f;
+    if (bx >= 0 && bx + 3 < L.width) {
+        uint32_t inside = 0xf;
+        if (L.alpha) {
+            const f32x4_a4 a = *(const f32x4_a4 *)(L.alpha + (ptrdiff_t)by * L.alpha_stride + bx);
+            f.a[0] = a.x; f.a[1] = a.y; f.a[2] = a.z; f.a[3] = a.w;
+        }
+        if (L.mask) {
+            const uint32_t m = *(const u32_a1 *)(L.mask + (ptrdiff_t)by * L.mask_stride + bx);
+            inside = ((m & 0xffu) ? 1u : 0u) | ((m & 0xff00u) ? 2u : 0u) | ((m & 0xff0000u) ? 4u : 0u) | ((m >> 24) ? 8u : 0u);
+        } else if (L.alpha) {
+            inside = (f.a[0] > 0.0f ? 1u : 0u) | (f.a[1] > 0.0f ? 2u : 0u) | (f.a[2] > 0.0f ? 4u : 0u) | (f.a[3] > 0.0f ? 8u : 0u);
+        }
+        f.sel = inside;
+        if (L.value) {
+            const u32_a1 *v = (const u32_a1 *)(L.value + (ptrdiff_t)by * L.value_stride + (ptrdiff_t)bx * 3);
+            f.v[0] = v[0]; f.v[1] = v[1]; f.v[2] = v[2];
+        }
+    } else {
+        // the layer's box edge cuts the group: pixel by pixel
+        uint8_t vb[12];
+        for (int i = 0; i < 12; i++) vb[i] = (uint8_t)(f.v[i >> 2] >> (8 * (i & 3)));
+        for (int i = 0; i < 4; i++) {
+            const int b = bx + i;
+            if (b < 0 || b >= L.width) continue;
+            const float a = L.alpha ? L.alpha[(ptrdiff_t)by * L.alpha_stride + b] : L.alpha_scalar;
+            f.a[i] = a;
+            const bool sel = L.mask ? L.mask[(ptrdiff_t)by * L.mask_stride + b] > 0 : (L.alpha ? a > 0.0f : true);
+            if (sel) f.sel |= 1u << i;
+            if (L.value)
+                for (int c = 0; c < 3; c++) vb[3 * i + c] = L.value[(ptrdiff_t)by * L.value_stride + (ptrdiff_t)b * 3 + c];
+        }
+        for (int k = 0; k < 3; k++) f.v[k] = vb[4 * k] | (vb[4 * k + 1] << 8) | (vb[4 * k + 2] << 16) | ((uint32_t)vb[4 * k + 3] << 24);
+    }
+    return f;
+}
+
+__global__ void __launch_bounds__(256) k_composite_rgb(uint8_t *dst, ptrdiff_t dstride, int h, int w,
+                                                       const LayerDev<uint8_t> *__restrict__ layers,
+                                                       const int *__restrict__ tile_ids, const int *__restrict__ tile_begin,
+                                                       const int *__restrict__ tile_layers, int tiles_x,
+                                                       uint8_t *const *__restrict__ pages, int tiles_per_page)
+{
+    __shared__ LayerDev<uint8_t> recs[kRgbRecs];
+    int tile = tile_ids[blockIdx.x];
+    if (pages) {
+        const int page = tile / tiles_per_page;
+        tile -= page * tiles_per_page;
+        dst = pages[page];
+    }
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int x0 = tx * kTileW + 4 * (threadIdx.x & 15);
+    const int y = ty * kTileH + (threadIdx.x >> 4);
+    const bool in_page = x0 < w && y < h;       // w % 4 == 0: a group is inside or outside as a whole
+    const int lb = tile_begin[blockIdx.x], le = tile_begin[blockIdx.x + 1];
+    uint32_t *drow = (uint32_t *)(dst + (ptrdiff_t)y * dstride + (ptrdiff_t)x0 * 3);
+    uint32_t px[3] = {0, 0, 0};
+    bool have = false, dirty = false;
+    for (int base = lb; base < le; base += kRgbRecs) {
+        const int n = min(kRgbRecs, le - base);
+        __syncthreads();
+        // the records of this pass: n * 24 dwords, one per thread and step
+        constexpr int kDw = (int)(sizeof(LayerDev<uint8_t>) / 4);
+        for (int i = threadIdx.x; i < n * kDw; i += 256) {
+            const int r = i / kDw, d = i - r * kDw;
+            ((uint32_t *)&recs[r])[d] = ((const uint32_t *)&layers[tile_layers[base + r]])[d];
+        }
+        __syncthreads();
+        if (!in_page) continue;
+        if (base == lb) {
+            // the destination is needed unless the first layer writes all four pixels unconditionally
+            const LayerDev<uint8_t> &F = recs[0];
+            const bool covers = F.copy && F.mode == VKX_FILL_PLAIN && !F.mask && y >= F.up && y < F.up + F.height &&
+                                x0 >= F.left && x0 + 3 < F.left + F.width;
+            if (!covers) {
+                px[0] = drow[0]; px[1] = drow[1]; px[2] = drow[2];
+                have = true;
+            }
+        }
+        RgbFetch cur = rgb_fetch(recs[0], x0, y);
+        for (int li = 0; li < n; li++) {
+            const LayerDev<uint8_t> &L = recs[li];
+            RgbFetch nxt;
+            nxt.sel = 0;
+            if (li + 1 < n) nxt = rgb_fetch(recs[li + 1], x0, y);
+            if (__ballot(cur.sel != 0)) {
+                if (cur.sel) {
+                    uint8_t pb[12], vb[12];
+                    for (int i = 0; i < 12; i++) {
+                        pb[i] = (uint8_t)(px[i >> 2] >> (8 * (i & 3)));
+                        vb[i] = (uint8_t)(cur.v[i >> 2] >> (8 * (i & 3)));
+                    }
+                    for (int i = 0; i < 4; i++) {
+                        if (!((cur.sel >> i) & 1)) continue;
+                        if (L.copy) {
+                            for (int c = 0; c < 3; c++) {
+                                const uint8_t val = vb[3 * i + c], d = pb[3 * i + c];
+                                if (L.mode == VKX_FILL_PLAIN || (L.mode == VKX_FILL_KEEP_MAX ? d < val : d > val)) pb[3 * i + c] = val;
+                            }
+                        } else {
+                            const float w1 = cur.a[i], w0 = 1.0f - w1;
+                            for (int c = 0; c < 3; c++) pb[3 * i + c] = blend_px(w0, w1, pb[3 * i + c], vb[3 * i + c]);
+                        }
+                    }
+                    for (int k = 0; k < 3; k++) px[k] = pb[4 * k] | (pb[4 * k + 1] << 8) | (pb[4 * k + 2] << 16) | ((uint32_t)pb[4 * k + 3] << 24);
+                    dirty = true;
+                }
+            }
+            cur = nxt;
+        }
+    }
+    (void)have;
+    if (in_page && dirty) { drow[0] = px[0]; drow[1] = px[1]; drow[2] = px[2]; }
+}
+
+// The 4-pixel-group kernel for uint8 RGB when every destination is dword aligned with whole groups per row.
+template <typename T, int CN>
+bool composite_rgb_groups(vkx_ctx *, T *, ptrdiff_t, int, int, unsigned char *, size_t, size_t, size_t, size_t, size_t, size_t, int,
+                          T *const *, int, int)
+{
+    return false;
+}
+template <>
+bool composite_rgb_groups<uint8_t, 3>(vkx_ctx *ctx, uint8_t *dst, ptrdiff_t dstride, int h, int w, unsigned char *base, size_t o0,
+                                      size_t o1, size_t o2, size_t o3, size_t o4, size_t n_tiles, int tiles_x,
+                                      uint8_t *const *pages, int n_pages, int tiles_pp)
+{
+    if ((w & 3) || (dstride & 3)) return false;
+    if (pages) {
+        for (int p = 0; p < n_pages; p++)
+            if ((uintptr_t)pages[p] & 3) return false;
+    } else if ((uintptr_t)dst & 3) {
+        return false;
+    }
+    VKX_TIMED(ctx, "k_composite_rgb");
+    k_composite_rgb<<<(unsigned)n_tiles, 256, 0, ctx->stream>>>(
+        dst, dstride, h, w, (const LayerDev<uint8_t> *)(base + o0), (const int *)(base + o1), (const int *)(base + o2),
+        (const int *)(base + o3), tiles_x, pages ? (uint8_t *const *)(base + o4) : nullptr, tiles_pp);
+    return hipGetLastError() == hipSuccess;
+}
+
 // Host side of k_composite: bins `devl` (already validated, skippable layers removed) into tiles, stages the CSR and
 // the layer records in ctx->misc, launches.
 // `page_begin` (size n_pages + 1, or empty for a single destination): layers [page_begin[p], page_begin[p + 1]) belong to
@@ -195,6 +363,8 @@ int composite_launch(vkx_ctx *ctx, T *dst, int h, int w, ptrdiff_t dstride, cons
     memcpy(stage + o3, tile_layers.data(), sizeof(int) * tile_layers.size());
     if (pages) memcpy(stage + o4, pages, sizeof(T *) * (size_t)n_pages);
     VKX_HIP(hipMemcpyAsync(base, stage, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (composite_rgb_groups<T, CN>(ctx, dst, dstride, h, w, base, o0, o1, o2, o3, o4, tile_ids.size(), tiles_x, pages, n_pages, tiles_pp))
+        return VKX_OK;
     { VKX_TIMED(ctx, "k_composite");
       k_composite<T, CN><<<(unsigned)tile_ids.size(), 256, 0, ctx->stream>>>(
           dst, dstride, h, w, (const LayerDev<T> *)(base + o0), (const int *)(base + o1), (const int *)(base + o2),
