@@ -1230,6 +1230,30 @@ def paint_polys(polygons, values=None, mask=None, score=None, ctx=None):
                                 _ptr(score) if score is not None else None, w, h, w))
 
 
+def paint_polys_flat(points_xy, offsets, values=None, mask=None, score=None, ctx=None):
+    """``paint_polys`` for polygons that already are one int (N, 2) vertex array + (P + 1) offsets (element/soup.py)."""
+    ctx = ctx or default_ctx()
+    plane = mask if mask is not None else score
+    if plane is None:
+        raise ValueError('mask or score is required')
+    h, w = plane.shape
+    for arr, dt in ((mask, np.uint8), (score, np.float32)):
+        if arr is not None and (arr.dtype != dt or arr.shape != (h, w) or not arr.flags.c_contiguous
+                                or not arr.flags.writeable):
+            raise ValueError(f'planes must be writable C-contiguous {(h, w)} arrays (uint8 mask, float32 score)')
+    flat = np.ascontiguousarray(points_xy, dtype=np.int32).reshape(-1, 2)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    n = offsets.shape[0] - 1
+    vals = None
+    if score is not None:
+        vals = np.ascontiguousarray(np.asarray(values, dtype=np.float32))
+        if vals.shape != (n,):
+            raise ValueError('one value per polygon is required with a score plane')
+    check(lib().vkx_paint_polys(ctx.handle, _ptr(flat), _ptr(offsets), n, _ptr(vals) if vals is not None else None,
+                                _ptr(mask) if mask is not None else None, w,
+                                _ptr(score) if score is not None else None, w, h, w))
+
+
 def make_layer(box, cn, value, mask=None, alpha=1.0, mode=FILL_PLAIN, dtype=np.uint8):
     """One composite layer for a uint8 (cn channels) or float32 (cn == 1) destination.
     box = (up, left, height, width).  Returns (VkxLayer | VkxLayerF32, keepalive list)."""

@@ -14,22 +14,52 @@ from .type import Shapable
 
 @attrs.define(frozen=True, eq=False)
 class Polygon:
-    points: 'PointTuple'
+    # ``Polygon(points=...)`` as in the reference; a polygon that came out of an array operator (``from_smooth_xy``)
+    # holds its vertices as one float64 array and builds the ``PointTuple`` on first access of ``.points``
+    _points: Optional['PointTuple'] = attrs.field(default=None, alias='points')
 
     _bounding_box: Optional['Box'] = attrs.field(default=None, init=False, repr=False)
     _np_mask: Optional[np.ndarray] = attrs.field(default=None, init=False, repr=False)
     _mask: Optional['Mask'] = attrs.field(default=None, init=False, repr=False)
+    _smooth_xy: Optional[np.ndarray] = attrs.field(default=None, init=False, repr=False)
 
     def __attrs_post_init__(self):
-        assert self.points
+        assert self._points is None or self._points
 
     @classmethod
     def create(cls, points: Union['PointList', 'PointTuple', Iterable['Point']]):
         return cls(points=PointTuple(points))
 
+    @classmethod
+    def from_smooth_xy(cls, smooth_xy: np.ndarray):
+        """A polygon over the float64 (n, 2) array of smooth (x, y) vertices (``Point.create(y=y, x=x)`` per row, lazily)."""
+        smooth_xy = np.asarray(smooth_xy, dtype=np.float64).reshape(-1, 2)
+        assert smooth_xy.shape[0] > 0
+        polygon = cls(points=None)
+        object.__setattr__(polygon, '_smooth_xy', smooth_xy)
+        return polygon
+
+    @property
+    def points(self) -> 'PointTuple':
+        if self._points is None:
+            assert self._smooth_xy is not None
+            object.__setattr__(self, '_points', PointTuple(Point.create(y=float(y), x=float(x)) for x, y in self._smooth_xy))
+        return self._points
+
+    @property
+    def smooth_xy(self) -> np.ndarray:
+        """float64 (n, 2) smooth (x, y) of the vertices (cached)."""
+        if self._smooth_xy is None:
+            arr = np.empty((len(self._points), 2), np.float64)
+            for k, p in enumerate(self._points):
+                arr[k, 0] = p.smooth_x
+                arr[k, 1] = p.smooth_y
+            object.__setattr__(self, '_smooth_xy', arr)
+        return self._smooth_xy
+
     @property
     def num_points(self):
-        return len(self.points)
+        return self._smooth_xy.shape[0] if self._points is None else len(self._points)
 
     @property
     def bounding_box(self):
@@ -116,9 +146,13 @@ class Polygon:
         return cls(points=PointTuple.from_np_array(np_points))
 
     def to_np_array(self):
+        if self._points is None:
+            return np.rint(self._smooth_xy).astype(np.int32)
         return self.points.to_np_array()
 
     def to_smooth_np_array(self):
+        if self._points is None:     # PointTuple quirk: the integer positions as float32
+            return np.rint(self._smooth_xy).astype(np.float32)
         return self.points.to_smooth_np_array()
 
     # ---- operators

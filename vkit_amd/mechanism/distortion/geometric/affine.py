@@ -14,7 +14,7 @@ import numpy as np
 from numpy.random import Generator as RandomGenerator
 
 from vkit_amd import _native
-from vkit_amd.element import Image, Mask, Point, PointList, PointTuple, Polygon, ScoreMap
+from vkit_amd.element import Image, Mask, Point, PointArray, PointList, PointTuple, Polygon, PolygonSoup, ScoreMap
 from ..interface import Distortion, DistortionConfig, DistortionState
 
 
@@ -33,19 +33,22 @@ def affine_np_points(trans_mat: np.ndarray, np_points: np.ndarray) -> np.ndarray
     return moved.transpose()
 
 
-def affine_points(trans_mat: np.ndarray, points: PointTuple):
-    return PointTuple.from_np_array(affine_np_points(trans_mat, points.to_smooth_np_array()))
+def affine_points(trans_mat: np.ndarray, points):
+    """``PointTuple.from_np_array(affine_np_points(trans_mat, points.to_smooth_np_array()))`` (reference affine.py:65-67) on
+    arrays: the INTEGER positions go in (PointTuple quirk), the moved values become the smooth positions, and -- like
+    ``from_np_array`` -- a closing duplicate (first == last by integer position, more than two points) is dropped."""
+    points = PointArray.from_points(points, tuple_like=True)
+    moved = PolygonSoup.from_np_arrays_dropping_closing_duplicates(
+        affine_np_points(trans_mat, points.to_smooth_np_array()), np.array([0, len(points)]))
+    return PointArray(moved.smooth_xy, tuple_like=True)
 
 
 def affine_polygons(trans_mat: np.ndarray, polygons: Sequence[Polygon]) -> Sequence[Polygon]:
-    # one matrix product for the vertices of all polygons
-    flat = PointList()
-    spans = []
-    for polygon in polygons:
-        spans.append((len(flat), len(flat) + polygon.num_points))
-        flat.extend(polygon.points)
-    moved = affine_np_points(trans_mat, flat.to_smooth_np_array())
-    return [Polygon.from_np_array(moved[begin:end]) for begin, end in spans]
+    """One matrix product for the vertices of all polygons; the SMOOTH positions as float32 go in (they are collected in a
+    ``PointList`` by the reference, affine.py:70-82), each polygon is rebuilt through ``Polygon.from_np_array``."""
+    soup = PolygonSoup.from_polygons(polygons)
+    moved = affine_np_points(trans_mat, soup.smooth_xy.astype(np.float32))
+    return PolygonSoup.from_np_arrays_dropping_closing_duplicates(moved, soup.offsets)
 
 
 def convert_dsize_to_result_shape(dsize: Optional[Tuple[int, int]]):
@@ -243,9 +246,8 @@ def affine_trait_func_mask(config, state, mask: Mask, rng: Optional[RandomGenera
 def affine_trait_func_points(config, state, shape: Tuple[int, int],
                              points: Union[PointList, PointTuple, Iterable[Point]], rng: Optional[RandomGenerator]):
     assert state
-    points = PointTuple(points)
     if config.is_nop:
-        return points
+        return PointArray.from_points(points, tuple_like=True)
     assert state.trans_mat is not None
     return affine_points(state.trans_mat, points)
 
@@ -253,9 +255,8 @@ def affine_trait_func_points(config, state, shape: Tuple[int, int],
 def affine_trait_func_polygons(config, state, shape: Tuple[int, int], polygons: Iterable[Polygon],
                                rng: Optional[RandomGenerator]):
     assert state
-    polygons = tuple(polygons)
     if config.is_nop:
-        return polygons
+        return PolygonSoup.from_polygons(polygons)
     assert state.trans_mat is not None
     return affine_polygons(state.trans_mat, polygons)
 

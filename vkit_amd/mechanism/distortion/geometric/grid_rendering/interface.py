@@ -10,7 +10,7 @@ import numpy as np
 from numpy.random import Generator as RandomGenerator
 
 from vkit_amd import _native
-from vkit_amd.element import Image, Mask, Point, PointTuple, Polygon, ScoreMap
+from vkit_amd.element import Image, Mask, Point, PointArray, PointTuple, Polygon, PolygonSoup, ScoreMap
 from ...interface import Distortion, DistortionConfig, DistortionState
 from .grid_creator import create_dst_image_grid_and_shift_amounts_and_resize_ratios
 from .image_grid import ImageGrid
@@ -96,34 +96,29 @@ class FuncImageGridBased(Generic[_T_CONFIG, _T_STATE]):
 
 
     @classmethod
-    def _project(cls, state, points):
+    def _project_arrays(cls, state, int_xy: np.ndarray, smooth_xy: np.ndarray) -> np.ndarray:
         """All points of one call through the lattice in ONE device launch (the reference loops point by point,
-        distortion/interface.py:638-661)."""
+        distortion/interface.py:638-661): int (n, 2) rounded positions pick the cell, float64 (n, 2) smooth positions
+        are mapped; returns float64 (n, 2)."""
         src_grid, dst_grid = state.src_image_grid, state.dst_image_grid
         assert src_grid.grid_size
-        points = list(points)
-        if not points:
-            return []
-        out = _native.project_points(src_grid.vertices, dst_grid.vertices, src_grid.grid_size,
-                                     [(p.x, p.y) for p in points], [(p.smooth_x, p.smooth_y) for p in points])
-        return [Point.create(y=float(y), x=float(x)) for x, y in out]
+        if smooth_xy.shape[0] == 0:
+            return smooth_xy
+        return np.array(_native.project_points(src_grid.vertices, dst_grid.vertices, src_grid.grid_size, int_xy, smooth_xy))
 
     @classmethod
     def func_points(cls, config, state, shape: Tuple[int, int], points, rng: Optional[RandomGenerator]):
+        """Returns a ``PointArray`` (a sequence of ``Point`` over one array; ``PointTuple`` semantics)."""
         assert state
-        return PointTuple(cls._project(state, points))
+        points = PointArray.from_points(points, tuple_like=True)
+        return PointArray(cls._project_arrays(state, points.int_xy, points.smooth_xy), tuple_like=True)
 
     @classmethod
     def func_polygons(cls, config, state, shape: Tuple[int, int], polygons, rng: Optional[RandomGenerator]):
+        """Returns a ``PolygonSoup`` (a sequence of ``Polygon`` over one vertex array)."""
         assert state
-        polygons = list(polygons)
-        flat = cls._project(state, [p for polygon in polygons for p in polygon.points])
-        out, k = [], 0
-        for polygon in polygons:
-            n = len(polygon.points)
-            out.append(Polygon.create(points=flat[k:k + n]))
-            k += n
-        return out
+        soup = PolygonSoup.from_polygons(polygons)
+        return soup.with_smooth_xy(cls._project_arrays(state, soup.int_xy, soup.smooth_xy))
 
 
 class DistortionImageGridBased(Distortion[_T_CONFIG, _T_STATE]):

@@ -20,7 +20,7 @@ import attrs
 from numpy.random import Generator as RandomGenerator
 from numpy.random import default_rng
 
-from vkit_amd.element import Image, Mask, Point, PointList, PointTuple, Polygon, ScoreMap, Shapable
+from vkit_amd.element import Image, Mask, Point, PointArray, PointList, PointTuple, Polygon, PolygonSoup, ScoreMap, Shapable
 from vkit_amd.utility import dyn_structure, get_config_class_snake_case_name
 
 
@@ -224,12 +224,22 @@ class Distortion(Generic[_T_CONFIG, _T_STATE]):
     def distort_points_based_on_internals(self, internals: DistortionInternals,
                                           points: Union[PointList, PointTuple, Iterable[Point]]):
         internals.restore_rng_if_supported()
+        if isinstance(points, PointArray):
+            # array-native container (element/soup.py): stays an array through photometric operators and through the
+            # batched geometric ones
+            if not self.is_geometric:
+                return points.to_point_tuple()
+            if self.func_points:
+                return self.func_points(internals.config, internals.state, internals.shape, points, internals.rng)
         points = PointList(points)
         if not self.is_geometric:
             # photometric distortions move nothing: the reference walks the points one by one to return each unchanged
             return points.to_point_tuple()
         if self.func_points:
-            return self.func_points(internals.config, internals.state, internals.shape, points, internals.rng)
+            moved = self.func_points(internals.config, internals.state, internals.shape, points, internals.rng)
+            # the batched operators answer with a PointArray; a caller that handed in point objects gets the
+            # reference's container back
+            return PointTuple(moved) if isinstance(moved, PointArray) else moved
         return PointList(self.distort_point_based_on_internals(internals, point) for point in points).to_point_tuple()
 
     def distort_polygon_based_on_internals(self, internals: DistortionInternals, polygon: Polygon):
@@ -243,9 +253,13 @@ class Distortion(Generic[_T_CONFIG, _T_STATE]):
     def distort_polygons_based_on_internals(self, internals: DistortionInternals, polygons: Iterable[Polygon]):
         internals.restore_rng_if_supported()
         if not self.is_geometric:
-            return list(polygons)          # unchanged (the reference rebuilds equal polygons point by point)
+            # unchanged (the reference rebuilds equal polygons point by point); a PolygonSoup stays one
+            return polygons if isinstance(polygons, PolygonSoup) else list(polygons)
         if self.func_polygons:
-            return self.func_polygons(internals.config, internals.state, internals.shape, polygons, internals.rng)
+            moved = self.func_polygons(internals.config, internals.state, internals.shape, polygons, internals.rng)
+            if isinstance(moved, PolygonSoup) and not isinstance(polygons, PolygonSoup):
+                return list(moved)         # polygon objects in, polygon objects out
+            return moved
         return [self.distort_polygon_based_on_internals(internals, polygon) for polygon in polygons]
 
     # ------------------------------------------------------------------ single-element conveniences
@@ -310,7 +324,10 @@ class Distortion(Generic[_T_CONFIG, _T_STATE]):
         if result.polygon:
             result.polygon = result.polygon.to_clipped_polygon(result.shape)
         if result.polygons:
-            result.polygons = [polygon.to_clipped_polygon(result.shape) for polygon in result.polygons]
+            if isinstance(result.polygons, PolygonSoup):
+                result.polygons = result.polygons.to_clipped_polygons(result.shape)
+            else:
+                result.polygons = [polygon.to_clipped_polygon(result.shape) for polygon in result.polygons]
 
     def distort(
         self,

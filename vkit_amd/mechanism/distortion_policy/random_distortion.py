@@ -13,7 +13,7 @@ from typing import Any, Iterable, List, Mapping, Optional, Sequence, Tuple, Unio
 import attrs
 from numpy.random import Generator as RandomGenerator
 
-from vkit_amd.element import Box, Image, Mask, Point, PointList, PointTuple, Polygon, ScoreMap, Shapable
+from vkit_amd.element import Box, Image, Mask, Point, PointArray, PointList, PointTuple, Polygon, PolygonSoup, ScoreMap, Shapable
 from vkit_amd.utility import PathType, dyn_structure, normalize_to_probs, rng_choice_with_size
 from ..distortion.interface import Distortion, DistortionResult
 from .geometric import affine, camera, mls
@@ -196,7 +196,10 @@ class RandomDistortion:
         if distortion_result.polygon:
             distortion_result.polygon = distortion_result.polygon.to_shifted_polygon(**shift)
         if distortion_result.polygons:
-            distortion_result.polygons = [p.to_shifted_polygon(**shift) for p in distortion_result.polygons]
+            if isinstance(distortion_result.polygons, PolygonSoup):
+                distortion_result.polygons = distortion_result.polygons.to_shifted_polygons(**shift)
+            else:
+                distortion_result.polygons = [p.to_shifted_polygon(**shift) for p in distortion_result.polygons]
         return distortion_result
 
     def distort(
@@ -214,10 +217,14 @@ class RandomDistortion:
     ):
         shape = Distortion.get_shape(shapable_or_shape=shapable_or_shape, image=image, mask=mask,
                                      score_map=score_map)
+        # array-native containers (element/soup.py) pass through as they are
+        if points and not isinstance(points, PointArray):
+            points = PointTuple(points)
         result = DistortionResult(shape=shape, image=image, mask=mask, score_map=score_map, point=point,
-                                  points=PointTuple(points) if points else None, polygon=polygon)
+                                  points=(points.to_point_tuple() if isinstance(points, PointArray) else points) if points else None,
+                                  polygon=polygon)
         if polygons:
-            result.polygons = tuple(polygons)
+            result.polygons = polygons if isinstance(polygons, PolygonSoup) else tuple(polygons)
         for stage in self.stages:
             result = stage.apply_distortions(result, self.level_min, self.level_max, rng, debug=debug)
         return self.trim_distortion_result(result)

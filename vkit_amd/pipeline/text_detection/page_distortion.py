@@ -19,7 +19,7 @@ import numpy as np
 from numpy.random import Generator as RandomGenerator
 
 from vkit_amd import _native
-from vkit_amd.element import Image, Mask, Point, PointList, Polygon, ScoreMap
+from vkit_amd.element import Image, Mask, Point, PointArray, PointList, Polygon, PolygonSoup, ScoreMap
 from vkit_amd.mechanism.distortion_policy import RandomDistortionDebug, random_distortion_factory
 from vkit_amd.utility import PathType
 from ..interface import PipelineStep, PipelineStepFactory
@@ -88,6 +88,15 @@ class ElementFlattener(Generic[_E]):
     def flatten(self):
         return tuple(itertools.chain.from_iterable(self.grouped_elements))
 
+    def flatten_polygons(self) -> PolygonSoup:
+        """The groups as ONE array-backed sequence of polygons (element/soup.py): the chain's geometric operators, its
+        clipping and the label paint then work on the vertex array and build no ``Point`` / ``Polygon`` object."""
+        return PolygonSoup.concatenate([PolygonSoup.from_polygons(group) for group in self.grouped_elements])
+
+    def flatten_points(self) -> PointArray:
+        groups = [PointArray.from_points(group) for group in self.grouped_elements]
+        return PointArray(np.concatenate([g.smooth_xy for g in groups], axis=0) if groups else np.zeros((0, 2)))
+
     def unflatten(self, flattened_elements: Sequence[_E]) -> Sequence[Sequence[_E]]:
         assert len(flattened_elements) == sum(self.group_sizes)
         grouped, begin = [], 0
@@ -104,11 +113,14 @@ def paint_polygons(shape: Tuple[int, int], polygons: Sequence[Polygon], values: 
     height, width = shape
     np_mask = np.zeros((height, width), np.uint8) if want_mask else None
     np_score = np.zeros((height, width), np.float32) if values is not None else None
-    if polygons:
+    if len(polygons):
         # a polygon's raster is defined on its bounding box with the integer vertices made box-relative (reference
         # element/polygon.py:105-138,70-77): shifting them back by the integer box origin gives the integer vertices
         # themselves, so the polygons go to the device as they are (no per-polygon box / relative-polygon objects)
-        _native.paint_polys([polygon.to_np_array() for polygon in polygons], values=values, mask=np_mask, score=np_score)
+        if isinstance(polygons, PolygonSoup):
+            _native.paint_polys_flat(polygons.int_xy, polygons.offsets, values=values, mask=np_mask, score=np_score)
+        else:
+            _native.paint_polys([polygon.to_np_array() for polygon in polygons], values=values, mask=np_mask, score=np_score)
     mask = Mask(mat=np_mask) if want_mask else None
     score_map = ScoreMap(mat=np_score, is_prob=False) if values is not None else None
     return mask, score_map
@@ -179,9 +191,10 @@ class PageDistortionStep(PipelineStep[PageDistortionStepConfig, PageDistortionSt
             char_heights = [0.0] * len(char_polygons)
             for idx in order:
                 char_heights[idx] = float(np_heights[idx])
+            ordered = (char_polygons.reordered(order) if isinstance(char_polygons, PolygonSoup)
+                       else [char_polygons[idx] for idx in order])
             _, char_height_score_map = paint_polygons(
-                distorted_image.shape, [char_polygons[idx] for idx in order],
-                values=[char_heights[idx] for idx in order], want_mask=False)
+                distorted_image.shape, ordered, values=[char_heights[idx] for idx in order], want_mask=False)
         return char_mask, seal_impression_char_mask, char_height_score_map, char_heights, None
 
     def run(self, input: PageDistortionStepInput, rng: RandomGenerator):
@@ -219,8 +232,8 @@ class PageDistortionStep(PipelineStep[PageDistortionStepConfig, PageDistortionSt
         result = self.random_distortion.distort(
             image=page.image,
             mask=page_active_mask,
-            polygons=polygon_flattener.flatten(),
-            points=PointList(point_flattener.flatten()),
+            polygons=polygon_flattener.flatten_polygons(),
+            points=point_flattener.flatten_points(),
             rng=rng,
             debug=page_random_distortion_debug,
         )
@@ -234,7 +247,9 @@ class PageDistortionStep(PipelineStep[PageDistortionStepConfig, PageDistortionSt
         (char_polygons, adjusted_char_polygons, text_line_polygons, disconnected_text_region_polygons,
          non_text_region_polygons, seal_impression_char_polygons) = polygon_flattener.unflatten(polygons)
         (char_height_points_up, char_height_points_down, text_line_height_points_up,
-         text_line_height_points_down) = map(PointList, point_flattener.unflatten(points))
+         text_line_height_points_down) = (
+            group.to_point_list() if isinstance(group, PointArray) else PointList(group)
+            for group in point_flattener.unflatten(points))
 
         text_line_height_points_group_sizes = page_text_line_polygon_collection.height_points_group_sizes
         assert len(text_line_polygons) == len(text_line_height_points_group_sizes)
