@@ -214,10 +214,27 @@ int vkx_ellipse_streak_u8(vkx_ctx *ctx, uint8_t *img, int h, int w, int cn, ptrd
 #define VKX_CVT_HLS2RGB_FULL 3
 #define VKX_CVT_RGB2GRAY 4   /* [h, w, 3] -> [h, w]; not in place */
 #define VKX_CVT_GRAY2RGB 5   /* [h, w] -> [h, w, 3]; not in place */
+#define VKX_CVT_RGBA2RGB 6   /* [h, w, 4] -> [h, w, 3]: alpha dropped; not in place */
+#define VKX_CVT_RGB2RGBA 7   /* [h, w, 3] -> [h, w, 4]: alpha 255 */
+#define VKX_CVT_GRAY2RGBA 8  /* [h, w] -> [h, w, 4] */
+#define VKX_CVT_RGBA2GRAY 9  /* [h, w, 4] -> [h, w] */
 int vkx_cvt_color_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t src_stride, int code,
                          uint8_t *dst, ptrdiff_t dst_stride);
 int vkx_cvt_color_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t src_stride, int code,
                      uint8_t *dst, ptrdiff_t dst_stride);
+/* color_balance on any image mode  photometric/color.py:371-396: dst = uint8(clip(w0 * a + w1 * b, 0, 255)) on the channels of
+ * channel_mask (0 = all), b elsewhere; a = the grey version of the image in the image's own mode, b = the image, w0 = 1 - ratio,
+ * w1 = ratio (float32 products rounded separately, truncation). */
+int vkx_blend_u8_dev(vkx_ctx *ctx, const uint8_t *a, ptrdiff_t a_stride, const uint8_t *b, ptrdiff_t b_stride, int h, int w,
+                     int cn, double w0, double w1, unsigned channel_mask, uint8_t *dst, ptrdiff_t dst_stride);
+int vkx_blend_u8(vkx_ctx *ctx, const uint8_t *a, ptrdiff_t a_stride, const uint8_t *b, ptrdiff_t b_stride, int h, int w, int cn,
+                 double w0, double w1, unsigned channel_mask, uint8_t *dst, ptrdiff_t dst_stride);
+/* fog with fractional fog values (GRAYSCALE images)  photometric/effect.py:192-205: dst = uint8(clip((1 - m) * px + m * fog[c]))
+ * with the float32 weight plane m [h, w]; `fog`: cn float32 values on the host. */
+int vkx_fog_f32_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride, const float *weight,
+                       ptrdiff_t weight_stride_el, const float *fog, uint8_t *dst, ptrdiff_t dst_stride);
+int vkx_fog_f32_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride, const float *weight,
+                   ptrdiff_t weight_stride_el, const float *fog, uint8_t *dst, ptrdiff_t dst_stride);
 /* brightness_shift on RGB with the default HSL intermediate  photometric/color.py:125-160: RGB2HLS_FULL,
  * L = clip(L + delta), HLS2RGB_FULL, one pass.  In place allowed. */
 int vkx_brightness_shift_rgb_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, ptrdiff_t src_stride, int delta,

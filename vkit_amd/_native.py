@@ -201,6 +201,9 @@ for _sfx in ('', '_dev'):
                                                                         c_ssize]
     _SIGNATURES['vkx_add_noise_i16' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_ssize, c_void_p, c_ssize]
     _SIGNATURES['vkx_cvt_color_u8' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_int, c_void_p, c_ssize]
+    _SIGNATURES['vkx_blend_u8' + _sfx] = [c_void_p, c_void_p, c_ssize, c_void_p, c_ssize, c_int, c_int, c_int, c_double, c_double, c_uint,
+                                         c_void_p, c_ssize]
+    _SIGNATURES['vkx_fog_f32_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_ssize, c_void_p, c_void_p, c_ssize]
     _SIGNATURES['vkx_brightness_shift_rgb' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_int, c_void_p, c_ssize]
     _SIGNATURES['vkx_color_balance_rgb' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_double, c_void_p, c_ssize]
     _SIGNATURES['vkx_histogram_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p]
@@ -807,19 +810,49 @@ def mean_shift(img, delta, threshold=None, channels=None, cycle=False, ctx=None)
 
 
 POINT_COMPLEMENT, POINT_POSTERIZE, POINT_PERMUTE = 0, 1, 2
-CVT_RGB2HSV_FULL, CVT_HSV2RGB_FULL, CVT_RGB2HLS_FULL, CVT_HLS2RGB_FULL, CVT_RGB2GRAY, CVT_GRAY2RGB = range(6)
+(CVT_RGB2HSV_FULL, CVT_HSV2RGB_FULL, CVT_RGB2HLS_FULL, CVT_HLS2RGB_FULL, CVT_RGB2GRAY, CVT_GRAY2RGB, CVT_RGBA2RGB, CVT_RGB2RGBA,
+ CVT_GRAY2RGBA, CVT_RGBA2GRAY) = range(10)
+_CVT_CHANNELS = {CVT_RGB2GRAY: (3, 1), CVT_GRAY2RGB: (1, 3), CVT_RGBA2RGB: (4, 3), CVT_RGB2RGBA: (3, 4), CVT_GRAY2RGBA: (1, 4),
+                 CVT_RGBA2GRAY: (4, 1)}
 
 
 def cvt_color(img, code, ctx=None):
     """cv.cvtColor for the codes of include/vkx.h (VKX_CVT_*)."""
     ctx = ctx or default_ctx()
     img, h, w, cn, stride = _u8_plane(img)
-    want_cn = 1 if code == CVT_GRAY2RGB else 3
+    want_cn, out_cn = _CVT_CHANNELS.get(code, (3, 3))
     if cn != want_cn:
         raise ValueError(f'conversion code {code} takes {want_cn}-channel input')
-    dst = ctx.pinned_empty((h, w) if code == CVT_RGB2GRAY else (h, w, 3), np.uint8)
-    check(lib().vkx_cvt_color_u8(ctx.handle, _ptr(img), h, w, stride, int(code), _ptr(dst),
-                                 w if code == CVT_RGB2GRAY else w * 3))
+    dst = ctx.pinned_empty((h, w) if out_cn == 1 else (h, w, out_cn), np.uint8)
+    check(lib().vkx_cvt_color_u8(ctx.handle, _ptr(img), h, w, stride, int(code), _ptr(dst), w * out_cn))
+    return dst
+
+
+def blend_u8(a, b, w0, w1, channels=None, ctx=None):
+    """uint8(clip(w0 * a + w1 * b, 0, 255)) on ``channels`` (None = all), ``b`` elsewhere (include/vkx.h vkx_blend_u8)."""
+    ctx = ctx or default_ctx()
+    a, h, w, cn, stride = _u8_plane(a)
+    b = np.ascontiguousarray(b)
+    if b.shape != a.shape or b.dtype != np.uint8:
+        raise ValueError('the two planes must agree in shape and dtype')
+    dst = ctx.pinned_empty(a.shape, np.uint8)
+    check(lib().vkx_blend_u8(ctx.handle, _ptr(a), stride, _ptr(b), stride, h, w, cn, float(w0), float(w1), _channel_mask(channels),
+                             _ptr(dst), stride))
+    return dst
+
+
+def fog_f32(img, weight, fog_values, ctx=None):
+    """uint8(clip((1 - weight) * img + weight * fog_values[c], 0, 255)): float32 weight plane (H, W), float32 fog per channel."""
+    ctx = ctx or default_ctx()
+    img, h, w, cn, stride = _u8_plane(img)
+    weight = np.ascontiguousarray(weight, dtype=np.float32)
+    if weight.shape != (h, w):
+        raise ValueError('weight plane must be (H, W)')
+    fog = np.ascontiguousarray(np.asarray(fog_values, dtype=np.float32).reshape(-1))
+    if fog.shape[0] != cn:
+        raise ValueError('one fog value per channel')
+    dst = ctx.pinned_empty(img.shape, np.uint8)
+    check(lib().vkx_fog_f32_u8(ctx.handle, _ptr(img), h, w, cn, stride, _ptr(weight), w, _ptr(fog), _ptr(dst), stride))
     return dst
 
 

@@ -508,13 +508,44 @@ VKX_EXPORT int vkx_cvt_color_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, 
 {
     VKX_REQUIRE(ctx && src && dst, "NULL argument");
     VKX_REQUIRE(h >= 0 && w >= 0, "bad shape");
-    const int scn = code == VKX_CVT_GRAY2RGB ? 1 : 3, dcn = code == VKX_CVT_RGB2GRAY ? 1 : 3;
+    const int scn = code == VKX_CVT_GRAY2RGB || code == VKX_CVT_GRAY2RGBA ? 1 : (code == VKX_CVT_RGBA2RGB || code == VKX_CVT_RGBA2GRAY ? 4 : 3);
+    const int dcn = code == VKX_CVT_RGB2GRAY || code == VKX_CVT_RGBA2GRAY ? 1 : (code == VKX_CVT_RGB2RGBA || code == VKX_CVT_GRAY2RGBA ? 4 : 3);
     HostStage st(ctx);
     const int s = st.add(src, nullptr, (size_t)w * scn, h, src_stride);
     const int d = st.add(nullptr, dst, (size_t)w * dcn, h, dst_stride);
     VKX_TRY(st.commit());
     VKX_TRY(vkx_cvt_color_u8_dev(ctx, st.dev<uint8_t>(s), h, w, (ptrdiff_t)w * scn, code, st.dev<uint8_t>(d),
                                  (ptrdiff_t)w * dcn));
+    return st.finish();
+}
+
+VKX_EXPORT int vkx_blend_u8(vkx_ctx *ctx, const uint8_t *a, ptrdiff_t a_stride, const uint8_t *b, ptrdiff_t b_stride, int h, int w,
+                            int cn, double w0, double w1, unsigned channel_mask, uint8_t *dst, ptrdiff_t dst_stride)
+{
+    VKX_REQUIRE(ctx && a && b && dst, "NULL argument");
+    VKX_REQUIRE(h >= 0 && w >= 0 && cn >= 1 && cn <= 4, "bad shape");
+    HostStage st(ctx);
+    const int ia = st.add(a, nullptr, (size_t)w * cn, h, a_stride);
+    const int ib = st.add(b, nullptr, (size_t)w * cn, h, b_stride);
+    const int d = st.add(nullptr, dst, (size_t)w * cn, h, dst_stride);
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_blend_u8_dev(ctx, st.dev<uint8_t>(ia), (ptrdiff_t)w * cn, st.dev<uint8_t>(ib), (ptrdiff_t)w * cn, h, w, cn, w0, w1,
+                             channel_mask, st.dev<uint8_t>(d), (ptrdiff_t)w * cn));
+    return st.finish();
+}
+
+VKX_EXPORT int vkx_fog_f32_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride, const float *weight,
+                              ptrdiff_t weight_stride_el, const float *fog, uint8_t *dst, ptrdiff_t dst_stride)
+{
+    VKX_REQUIRE(ctx && src && weight && fog && dst, "NULL argument");
+    VKX_REQUIRE(h >= 0 && w >= 0 && cn >= 1 && cn <= 4, "bad shape");
+    HostStage st(ctx);
+    const int s = st.add(src, nullptr, (size_t)w * cn, h, src_stride);
+    const int m = st.add(weight, nullptr, (size_t)w * 4, h, weight_stride_el * 4);
+    const int d = st.add(nullptr, dst, (size_t)w * cn, h, dst_stride);
+    VKX_TRY(st.commit());
+    VKX_TRY(vkx_fog_f32_u8_dev(ctx, st.dev<uint8_t>(s), h, w, cn, (ptrdiff_t)w * cn, st.dev<float>(m), w, fog, st.dev<uint8_t>(d),
+                               (ptrdiff_t)w * cn));
     return st.finish();
 }
 

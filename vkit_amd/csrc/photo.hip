@@ -412,6 +412,64 @@ __global__ void __launch_bounds__(256) k_cvt(const uint8_t *__restrict__ src, in
     d[0] = (uint8_t)a; d[1] = (uint8_t)b; d[2] = (uint8_t)c;
 }
 
+// RGBA conversions of Image.to_target_mode_image (element/image.py:188-216): 6 RGBA -> RGB (alpha dropped), 7 RGB -> RGBA
+// (alpha 255), 8 GRAY -> RGBA, 9 RGBA -> GRAY (the RGB2Gray weights on the first three channels)
+template <int MODE>
+__global__ void __launch_bounds__(256) k_cvt_alpha(const uint8_t *__restrict__ src, int h, int w, ptrdiff_t sstride,
+                                                   uint8_t *__restrict__ dst, ptrdiff_t dstride)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    constexpr int SCN = MODE == 6 || MODE == 9 ? 4 : (MODE == 7 ? 3 : 1), DCN = MODE == 6 ? 3 : (MODE == 9 ? 1 : 4);
+    const uint8_t *s = src + (ptrdiff_t)y * sstride + (ptrdiff_t)x * SCN;
+    uint8_t *d = dst + (ptrdiff_t)y * dstride + (ptrdiff_t)x * DCN;
+    if (MODE == 6) { d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; }
+    else if (MODE == 7) { d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = 255; }
+    else if (MODE == 8) { const uint8_t v = s[0]; d[0] = v; d[1] = v; d[2] = v; d[3] = 255; }
+    else d[0] = (uint8_t)rgb2gray_px(s[0], s[1], s[2]);
+}
+
+// uint8(clip(w0 * a + w1 * b, 0, 255)) on the channels of `chmask` (0 = all), b copied elsewhere: color_balance on any
+// image mode (photometric/color.py:371-396: float32 products rounded separately, clip, truncation)
+__global__ void __launch_bounds__(256) k_blend_u8(const uint8_t *__restrict__ a, ptrdiff_t astride, const uint8_t *__restrict__ b,
+                                                  ptrdiff_t bstride, int h, int wc, int cn, float w0, float w1, unsigned chmask,
+                                                  uint8_t *__restrict__ dst, ptrdiff_t dstride)
+{
+    const int xe = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (xe >= wc || y >= h) return;
+    const int c = xe % cn;
+    const uint8_t vb = b[(ptrdiff_t)y * bstride + xe];
+    uint8_t out = vb;
+    if (chmask == 0 || ((chmask >> c) & 1u)) {
+        const float t0 = w0 * (float)a[(ptrdiff_t)y * astride + xe], t1 = w1 * (float)vb;
+        float v = t0 + t1;
+        v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
+        out = (uint8_t)v;
+    }
+    dst[(ptrdiff_t)y * dstride + xe] = out;
+}
+
+// uint8(clip((1 - m) * px + m * fog, 0, 255)) with a float32 weight plane m [h, w] shared by the cn channels and one
+// float32 fog value per channel: fog on GRAYSCALE images, whose fog value is fractional (photometric/effect.py:194-197)
+__global__ void __launch_bounds__(256) k_fog_f32(const uint8_t *__restrict__ src, ptrdiff_t sstride, const float *__restrict__ m,
+                                                 ptrdiff_t mstride, int h, int w, int cn, float f0, float f1, float f2, float f3,
+                                                 uint8_t *__restrict__ dst, ptrdiff_t dstride)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= w || y >= h) return;
+    const float mk = m[(ptrdiff_t)y * mstride + x], inv = 1.0f - mk;
+    const float fog[4] = {f0, f1, f2, f3};
+    for (int c = 0; c < cn; c++) {
+        const float t0 = inv * (float)src[(ptrdiff_t)y * sstride + (ptrdiff_t)x * cn + c], t1 = mk * fog[c];
+        float v = t0 + t1;
+        v = v < 0.f ? 0.f : (v > 255.f ? 255.f : v);
+        dst[(ptrdiff_t)y * dstride + (ptrdiff_t)x * cn + c] = (uint8_t)v;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_mean_shift(const uint8_t *__restrict__ src, int h, int w, int cn, ptrdiff_t sstride,
                                                     uint8_t *__restrict__ dst, ptrdiff_t dstride, int delta, int has_thr,
                                                     int thr, int cycle, unsigned chmask)
@@ -1042,6 +1100,20 @@ VKX_EXPORT int vkx_cvt_color_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int
     case VKX_CVT_GRAY2RGB:
         VKX_REQUIRE(src != dst, "GRAY2RGB cannot run in place");
         return launch_cvt<4>(ctx, src, h, w, src_stride, 0, 0.f, 0.f, dst, dst_stride);
+    case VKX_CVT_RGBA2RGB: case VKX_CVT_RGB2RGBA: case VKX_CVT_GRAY2RGBA: case VKX_CVT_RGBA2GRAY: {
+        int rc = check_plane(ctx, src, dst, h, w);
+        if (rc) return rc;
+        VKX_REQUIRE(src != dst, "the alpha conversions cannot run in place");
+        if (h == 0 || w == 0) return VKX_OK;
+        dim3 block(64, 4), grid(vkx_blocks(w, 64), vkx_blocks(h, 4));
+        VKX_TIMED(ctx, "k_cvt_alpha");
+        if (code == VKX_CVT_RGBA2RGB) k_cvt_alpha<6><<<grid, block, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride);
+        else if (code == VKX_CVT_RGB2RGBA) k_cvt_alpha<7><<<grid, block, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride);
+        else if (code == VKX_CVT_GRAY2RGBA) k_cvt_alpha<8><<<grid, block, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride);
+        else k_cvt_alpha<9><<<grid, block, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride);
+        VKX_LAUNCH_CHECK();
+        return VKX_OK;
+    }
     case VKX_CVT_RGB2HSV_FULL: return vkx_cvt_rgb_hsv_u8_dev(ctx, src, h, w, src_stride, 1, dst, dst_stride);
     case VKX_CVT_HSV2RGB_FULL: return vkx_cvt_rgb_hsv_u8_dev(ctx, src, h, w, src_stride, 0, dst, dst_stride);
     default:
@@ -1064,6 +1136,36 @@ VKX_EXPORT int vkx_color_balance_rgb_dev(vkx_ctx *ctx, const uint8_t *src, int h
         return VKX_ERR_INVALID;
     }
     return launch_cvt<5>(ctx, src, h, w, src_stride, 0, (float)(1 - ratio), (float)ratio, dst, dst_stride);
+}
+
+VKX_EXPORT int vkx_blend_u8_dev(vkx_ctx *ctx, const uint8_t *a, ptrdiff_t a_stride, const uint8_t *b, ptrdiff_t b_stride, int h,
+                                int w, int cn, double w0, double w1, unsigned channel_mask, uint8_t *dst, ptrdiff_t dst_stride)
+{
+    int rc = check_plane(ctx, a, dst, h, w);
+    if (rc) return rc;
+    VKX_REQUIRE(b != nullptr && cn >= 1 && cn <= 4, "bad argument");
+    if (h == 0 || w == 0) return VKX_OK;
+    dim3 block(64, 4), grid(vkx_blocks((size_t)w * cn, 64), vkx_blocks(h, 4));
+    VKX_TIMED(ctx, "k_blend_u8");
+    k_blend_u8<<<grid, block, 0, ctx->stream>>>(a, a_stride, b, b_stride, h, w * cn, cn, (float)w0, (float)w1, channel_mask, dst, dst_stride);
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_fog_f32_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride, const float *weight,
+                                  ptrdiff_t weight_stride_el, const float *fog /* host, cn values */, uint8_t *dst, ptrdiff_t dst_stride)
+{
+    int rc = check_plane(ctx, src, dst, h, w);
+    if (rc) return rc;
+    VKX_REQUIRE(weight && fog && cn >= 1 && cn <= 4, "bad argument");
+    if (h == 0 || w == 0) return VKX_OK;
+    float f[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < cn; c++) f[c] = fog[c];
+    dim3 block(64, 4), grid(vkx_blocks(w, 64), vkx_blocks(h, 4));
+    VKX_TIMED(ctx, "k_fog_f32");
+    k_fog_f32<<<grid, block, 0, ctx->stream>>>(src, src_stride, weight, weight_stride_el, h, w, cn, f[0], f[1], f[2], f[3], dst, dst_stride);
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
 }
 
 VKX_EXPORT int vkx_mean_shift_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,

@@ -214,27 +214,31 @@ class Image(Shapable):
         return attrs.evolve(self, mat=self.mat[up:down + 1, left:right + 1])
 
     def to_target_mode_image(self, target_mode: ImageMode):
-        """cv.cvtColor chain of the reference (image.py:771-814) among GRAYSCALE / RGB / HSV / HSL: source -> RGB ->
-        target, HSL stored as HLS with the last two channels swapped.  The conversions run on the GPU; RGBA and the
-        float32 ``*_GCN`` modes are outside the accelerated path."""
+        """cv.cvtColor chain of the reference (image.py:771-814) among GRAYSCALE / RGB / RGBA / HSV / HSL: the two shortcuts
+        GRAYSCALE <-> RGBA, otherwise source -> RGB -> target, HSL stored as HLS with the last two channels swapped.  The
+        conversions run on the GPU; the float32 ``*_GCN`` modes are outside the accelerated path."""
         if target_mode == self.mode:
             return self
         from vkit_amd import _native
-        supported = (ImageMode.GRAYSCALE, ImageMode.RGB, ImageMode.HSV, ImageMode.HSL)
+        supported = (ImageMode.GRAYSCALE, ImageMode.RGB, ImageMode.RGBA, ImageMode.HSV, ImageMode.HSL)
         if self.mode not in supported or target_mode not in supported:
             raise NotImplementedError(
                 f'image mode conversion {self.mode} -> {target_mode} is outside the accelerated path')
         mat = self.mat
         if self.mode == ImageMode.HSL:
             mat = mat[:, :, [0, 2, 1]]           # HSL -> HLS
+        shortcut = {(ImageMode.GRAYSCALE, ImageMode.RGBA): _native.CVT_GRAY2RGBA,
+                    (ImageMode.RGBA, ImageMode.GRAYSCALE): _native.CVT_RGBA2GRAY}.get((self.mode, target_mode))
+        if shortcut is not None:
+            return Image(mat=_native.cvt_color(mat, shortcut), mode=target_mode)
         if self.mode != ImageMode.RGB:
-            code = {ImageMode.GRAYSCALE: _native.CVT_GRAY2RGB, ImageMode.HSV: _native.CVT_HSV2RGB_FULL,
-                    ImageMode.HSL: _native.CVT_HLS2RGB_FULL}[self.mode]
+            code = {ImageMode.GRAYSCALE: _native.CVT_GRAY2RGB, ImageMode.RGBA: _native.CVT_RGBA2RGB,
+                    ImageMode.HSV: _native.CVT_HSV2RGB_FULL, ImageMode.HSL: _native.CVT_HLS2RGB_FULL}[self.mode]
             mat = _native.cvt_color(mat, code)
         if target_mode == ImageMode.RGB:
             return Image(mat=mat, mode=ImageMode.RGB)
-        code = {ImageMode.GRAYSCALE: _native.CVT_RGB2GRAY, ImageMode.HSV: _native.CVT_RGB2HSV_FULL,
-                ImageMode.HSL: _native.CVT_RGB2HLS_FULL}[target_mode]
+        code = {ImageMode.GRAYSCALE: _native.CVT_RGB2GRAY, ImageMode.RGBA: _native.CVT_RGB2RGBA,
+                ImageMode.HSV: _native.CVT_RGB2HSV_FULL, ImageMode.HSL: _native.CVT_RGB2HLS_FULL}[target_mode]
         mat = _native.cvt_color(mat, code)
         if target_mode == ImageMode.HSL:
             mat = mat[:, :, [0, 2, 1]]           # HLS -> HSL

@@ -62,7 +62,9 @@ def color_shift_image(config: ColorShiftConfig, state, image: Image, rng: Option
     if mode in (ImageMode.HSV, ImageMode.HSL):
         return _mean_shift(image, [0], config.delta, None, OutOfBoundBehavior.CYCLE)
     if mode != ImageMode.RGB:
-        raise NotImplementedError(f'color_shift on image mode {mode} is outside the accelerated path')
+        # GRAYSCALE / RGBA: the reference's own route (color.py:93-116): to HSV, hue add, back to the mode
+        shifted = _mean_shift(image.to_hsv_image(), [0], config.delta, None, OutOfBoundBehavior.CYCLE)
+        return shifted.to_target_mode_image(mode)
     if config.delta == 0:
         # the reference still round-trips through HSV (the hue add is skipped, the conversions are not)
         return image.to_hsv_image().to_target_mode_image(mode)
@@ -192,9 +194,14 @@ def color_balance_image(config: ColorBalanceConfig, state, image: Image, rng: Op
     if image.mode == ImageMode.GRAYSCALE:
         return image
     assert 0.0 <= config.ratio <= 1.0
-    if image.mode != ImageMode.RGB:
-        raise NotImplementedError(f'color_balance on image mode {image.mode} is outside the accelerated path')
-    return attrs.evolve(image, mat=_native.color_balance_rgb(image.mat, config.ratio))
+    if image.mode == ImageMode.RGB:
+        return attrs.evolve(image, mat=_native.color_balance_rgb(image.mat, config.ratio))
+    # any other mode (reference color.py:380-396): the grey version of the image brought back to the image's mode, blended
+    # with the image -- on saturation and value / lightness only for HSV / HSL, on every channel (alpha included) for RGBA
+    grayscale_like = image.to_grayscale_image().to_target_mode_image(image.mode)
+    channels = [1, 2] if image.mode in (ImageMode.HSV, ImageMode.HSL) else None
+    mat = _native.blend_u8(grayscale_like.mat, image.mat, 1 - config.ratio, config.ratio, channels=channels)
+    return attrs.evolve(image, mat=mat)
 
 
 color_balance = Distortion(

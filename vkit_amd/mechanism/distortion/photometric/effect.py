@@ -124,9 +124,7 @@ class FogConfig(DistortionConfig):
 
 def fog_image(config: FogConfig, state, image: Image, rng: Optional[RandomGenerator]):
     mode = image.mode
-    if mode == ImageMode.GRAYSCALE:
-        raise NotImplementedError('fog on GRAYSCALE images (a fractional grey fog value) is outside the accelerated path')
-    if mode != ImageMode.RGB:
+    if mode not in (ImageMode.GRAYSCALE, ImageMode.RGB):
         image = image.to_rgb_image()
     assert rng is not None
     mask = generate_diamond_square_mask(image.shape, config.roughness, rng)
@@ -138,6 +136,10 @@ def fog_image(config: FogConfig, state, image: Image, rng: Optional[RandomGenera
     mask *= (config.ratio_max - config.ratio_min)
     mask += config.ratio_min
 
+    if image.mode == ImageMode.GRAYSCALE:
+        # the grey fog value is fractional (reference effect.py:194-197): float32(0.2126 R + 0.7152 G + 0.0722 B)
+        val = 0.2126 * config.fog_rgb[0] + 0.7152 * config.fog_rgb[1] + 0.0722 * config.fog_rgb[2]
+        return attrs.evolve(image, mat=_native.fog_f32(image.mat, mask, [np.float32(val)]))
     mat = np.array(image.mat)
     layer = _native.make_layer((0, 0, image.height, image.width), 3, tuple(int(v) for v in config.fog_rgb), alpha=mask)
     _native.fill(mat, [layer])
