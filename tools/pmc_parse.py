@@ -10,6 +10,7 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 from collections import defaultdict
@@ -32,10 +33,13 @@ def main():
         with open(path) as fin:
             for row in csv.DictReader(fin):
                 name = row['Kernel_Name']
-                if 'k_chain' not in name:
+                if 'k_chain' not in name and 'k_np_' not in name:
                     continue
-                short = 'k_chain_fused' if 'k_chain_fused' in name else (
-                    'k_chain_setup_svd' if 'setup_svd' in name else 'k_chain_setup')
+                if 'k_np_' in name:
+                    short = re.search(r'k_np_[a-z_]+', name).group(0)
+                else:
+                    short = 'k_chain_fused' if 'k_chain_fused' in name else (
+                        'k_chain_setup_svd' if 'setup_svd' in name else 'k_chain_setup')
                 sums[short][row['Counter_Name']] += float(row['Counter_Value'])
                 counts[short][row['Counter_Name']] += 1
     lines = [f'# rocprofv3 PMC counters, {tag}, bench.py --batch {images} --steps 2 --warmup 1 (per launch, mean over '
