@@ -70,7 +70,7 @@ int vkx_host_alloc(vkx_ctx *ctx, size_t bytes, void **hptr);
 int vkx_host_free(vkx_ctx *ctx, void *hptr);
 int vkx_upload_async(vkx_ctx *ctx, void *dptr, const void *hptr, size_t bytes);
 int vkx_download_async(vkx_ctx *ctx, void *hptr, const void *dptr, size_t bytes);
-/* one host <-> device copy on the named stream of the ctx (to_device != 0: dst is a device pointer) */
+/* one copy on the named stream of the ctx: to_device 0 = device -> host, 1 = host -> device, 2 = device -> device */
 int vkx_memcpy_async(vkx_ctx *ctx, int stream, void *dst, const void *src, size_t bytes, int to_device);
 int vkx_ctx_order(vkx_ctx *ctx, int later_stream, int earlier_stream);
 int vkx_ctx_sync_stream(vkx_ctx *ctx, int stream);

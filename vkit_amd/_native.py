@@ -406,11 +406,36 @@ class Context:
     def event_wait(self, event):
         check(lib().vkx_event_wait(self.handle, c_void_p(event)))
 
+    # ---- device-resident arrays (DevArray): pooled device memory behind the elements' lazy ``.mat`` ------------------
+    @property
+    def device_pool(self):
+        pool = getattr(self, '_device_pool', None)
+        if pool is None:
+            pool = self._device_pool = DevicePool(self)
+        return pool
+
+    def dev_empty(self, shape, dtype=np.uint8):
+        """An uninitialised C-contiguous array in device memory."""
+        return self.device_pool.empty(shape, dtype)
+
+    def to_device(self, array):
+        """``array`` (numpy or DevArray) as a DevArray of this context; a host array is uploaded (synchronous copy)."""
+        if isinstance(array, DevArray):
+            return array
+        array = np.ascontiguousarray(array)
+        out = self.device_pool.empty(array.shape, array.dtype)
+        if array.nbytes:
+            self.upload(out.ptr, array)
+        return out
+
     def close(self):
         if self._h:
             pool = getattr(self, '_pinned_pool', None)
             if pool is not None:
                 pool.close()
+            dpool = getattr(self, '_device_pool', None)
+            if dpool is not None:
+                dpool.close()
             lib().vkx_ctx_destroy(self._h)
             self._h = c_void_p()
 
@@ -419,6 +444,132 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+class DevArray:
+    """A C-contiguous array in device memory: ``shape`` / ``dtype`` / ``ndim`` / ``nbytes`` like numpy, ``ptr`` the device
+    address, ``host()`` the (cached, page-locked) numpy copy.  Every kernel of a context runs on its one stream, so arrays
+    chain from call to call without synchronisation; the block returns to the context's pool when the object dies --
+    whatever is still queued on the stream has been queued before any later user of the block."""
+
+    __slots__ = ('ctx', 'ptr', 'shape', 'dtype', '_host', '_size', '__weakref__')
+
+    def __init__(self, ctx, ptr, shape, dtype, size):
+        self.ctx, self.ptr, self.shape, self.dtype, self._size = ctx, ptr, tuple(int(v) for v in shape), np.dtype(dtype), size
+        self._host = None
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    @property
+    def nbytes(self):
+        return self.size * self.dtype.itemsize
+
+    def host(self):
+        """The numpy copy (downloaded once; read-only views of it are what the elements' ``.mat`` hand out)."""
+        if self._host is None:
+            out = self.ctx.pinned_empty(self.shape, self.dtype)
+            if self.nbytes:
+                self.ctx.download(self.ptr, out)
+            self._host = out
+        return self._host
+
+    def invalidate_host(self):
+        """Call after a kernel has written the array in place."""
+        self._host = None
+
+    def __repr__(self):
+        return f'DevArray(shape={self.shape}, dtype={self.dtype}, device={self.ctx.device})'
+
+
+class DevicePool:
+    """Size-classed free lists of device blocks (hipMalloc / hipFree cost ~100 us and hipFree synchronises the device)."""
+
+    GRANULE = 1 << 16
+
+    def __init__(self, ctx, cap_bytes=4 << 30):
+        import weakref
+        self._weakref = weakref
+        self._ctx = weakref.ref(ctx)
+        self._free = {}
+        self._idle = 0
+        self.cap_bytes = cap_bytes
+        self._lock = threading.Lock()
+
+    def empty(self, shape, dtype=np.uint8):
+        ctx = self._ctx()
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        size = max(self.GRANULE, (nbytes + self.GRANULE - 1) // self.GRANULE * self.GRANULE)
+        with self._lock:
+            blocks = self._free.get(size)
+            ptr = blocks.pop() if blocks else None
+            if ptr is not None:
+                self._idle -= size
+        if ptr is None:
+            ptr = ctx.malloc(size)
+        arr = DevArray(ctx, ptr, shape, dtype, size)
+        self._weakref.finalize(arr, self._release, ptr, size)
+        return arr
+
+    def _release(self, ptr, size):
+        ctx = self._ctx()
+        if ctx is None or not ctx._h:
+            return                      # the context is gone and took its allocations with the process
+        with self._lock:
+            if self._idle + size <= self.cap_bytes:
+                self._free.setdefault(size, []).append(ptr)
+                self._idle += size
+                return
+        try:
+            ctx.free(ptr)
+        except Exception:
+            pass
+
+    def close(self):
+        ctx = self._ctx()
+        with self._lock:
+            blocks, self._free, self._idle = self._free, {}, 0
+        if ctx is not None and ctx._h:
+            for ptrs in blocks.values():
+                for ptr in ptrs:
+                    try:
+                        ctx.free(ptr)
+                    except Exception:
+                        pass
+
+
+# Resident mode: inside ``with resident():`` the wrappers below leave their results on the device (DevArray) even for
+# host inputs; outside, a result is resident exactly when an input was.
+_RESIDENT = threading.local()
+
+
+class resident:
+    def __init__(self, enabled=True):
+        self.enabled = enabled
+
+    def __enter__(self):
+        self.prev = getattr(_RESIDENT, 'on', False)
+        _RESIDENT.on = self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        _RESIDENT.on = self.prev
+        return False
+
+
+def resident_mode():
+    return getattr(_RESIDENT, 'on', False)
+
+
+def host_array(a):
+    """numpy view of ``a`` (DevArray -> its host copy)."""
+    return a.host() if isinstance(a, DevArray) else a
 
 
 class PinnedPool:
@@ -570,6 +721,47 @@ def _out_like(img, dh, dw, ctx=None):
     return (ctx or default_ctx()).pinned_empty(shape, img.dtype)
 
 
+class _Call:
+    """One wrapper call: decides host or device path from its inputs, hands out pointers, allocates outputs of the same
+    kind.  ``fn(name)`` is the C entry point of that path (``name`` or ``name + '_dev'``: the two share a signature)."""
+
+    def __init__(self, ctx, *arrays):
+        self.ctx = ctx or default_ctx()
+        self.dev = resident_mode() or any(isinstance(a, DevArray) for a in arrays)
+        self.keep = []
+
+    def fn(self, name):
+        return getattr(lib(), name + '_dev' if self.dev else name)
+
+    def src(self, a, dtype=None):
+        """Pointer of an input array on this call's side (uploads / downloads as needed)."""
+        if self.dev:
+            if not isinstance(a, DevArray):
+                a = np.ascontiguousarray(a, dtype=dtype) if dtype is not None else np.ascontiguousarray(a)
+                a = self.ctx.to_device(a)
+            self.keep.append(a)
+            return c_void_p(a.ptr)
+        a = host_array(a)
+        a = np.ascontiguousarray(a, dtype=dtype) if dtype is not None else np.ascontiguousarray(a)
+        self.keep.append(a)
+        return _ptr(a)
+
+    def out(self, shape, dtype=np.uint8):
+        arr = self.ctx.dev_empty(shape, dtype) if self.dev else self.ctx.pinned_empty(shape, dtype)
+        return arr, (c_void_p(arr.ptr) if self.dev else _ptr(arr))
+
+
+def _shape_u8(img):
+    """(h, w, cn, row stride in bytes) of a uint8 HxW[xC] numpy array or DevArray."""
+    if np.dtype(img.dtype) != np.uint8:
+        raise TypeError(f'expected uint8, got {img.dtype}')
+    if img.ndim == 2:
+        return img.shape[0], img.shape[1], 1, img.shape[1]
+    if img.ndim == 3:
+        return img.shape[0], img.shape[1], img.shape[2], img.shape[1] * img.shape[2]
+    raise ValueError(f'expected HxW or HxWxC, got shape {img.shape}')
+
+
 def remap(src, map_x, map_y, ctx=None):
     ctx = ctx or default_ctx()
     map_x = np.ascontiguousarray(map_x, dtype=np.float32)
@@ -593,9 +785,23 @@ def remap(src, map_x, map_y, ctx=None):
 
 
 def _warp(kind, src, mat, dsize, ctx):
-    ctx = ctx or default_ctx()
     dw, dh = int(dsize[0]), int(dsize[1])
     n = 6 if kind == 'affine' else 9
+    M = np.ascontiguousarray(np.asarray(mat, dtype=np.float64).reshape(n))
+    call = _Call(ctx, src)
+    if np.dtype(src.dtype) == np.float32:
+        if src.ndim != 2:
+            raise ValueError('float32 sources are single channel')
+        sh, sw = src.shape
+        dst, dptr = call.out((dh, dw), np.float32)
+        check(call.fn(f'vkx_warp_{kind}_f32')(call.ctx.handle, call.src(src), sh, sw, sw, _ptr(M), dptr, dh, dw, dw))
+        return dst
+    sh, sw, cn, sstride = _shape_u8(src)
+    dst, dptr = call.out((dh, dw) if src.ndim == 2 else (dh, dw, cn), np.uint8)
+    check(call.fn(f'vkx_warp_{kind}_u8')(call.ctx.handle, call.src(src), sh, sw, cn, sstride, _ptr(M), dptr, dh, dw, dw * cn))
+    return dst
+
+
     M = np.ascontiguousarray(np.asarray(mat, dtype=np.float64).reshape(n))
     if src.dtype == np.float32:
         src = np.ascontiguousarray(src)
@@ -644,36 +850,36 @@ def grid_to_map(src_vertices, dst_vertices, dst_shape, want_owner=False, ctx=Non
 
 
 def grid_remap(mats, src_vertices, dst_vertices, dst_shape, ctx=None):
-    """Gathers every array of ``mats`` (uint8 HxW[xC] / float32 HxW, all of one source shape) through one grid."""
-    ctx = ctx or default_ctx()
+    """Gathers every array of ``mats`` (uint8 HxW[xC] / float32 HxW, all of one source shape; numpy or DevArray) through one
+    grid.  Results are of the inputs' kind (DevArray when any input is one, or in resident mode)."""
     sv, dv = _vertices(src_vertices), _vertices(dst_vertices)
     if sv.shape != dv.shape:
         raise ValueError('source / destination grids differ in shape')
     rows, cols = sv.shape[:2]
     dh, dw = int(dst_shape[0]), int(dst_shape[1])
+    call = _Call(ctx, *mats)
+    sv_p, dv_p = call.src(sv), call.src(dv)         # the device entry point reads the lattices on the device
     outs = []
     for i in range(0, len(mats), 4):
-        chunk = [np.ascontiguousarray(m) for m in mats[i:i + 4]]
+        chunk = list(mats[i:i + 4])
         sh, sw = chunk[0].shape[:2]
         arr = (VkxElem * len(chunk))()
-        chunk_out = []
         for j, m in enumerate(chunk):
-            if m.shape[:2] != (sh, sw):
+            if tuple(m.shape[:2]) != (sh, sw):
                 raise ValueError('all elements of one call must share the source shape')
-            if m.dtype == np.float32:
+            if np.dtype(m.dtype) == np.float32:
                 if m.ndim != 2:
                     raise ValueError('float32 elements are single channel')
-                out = ctx.pinned_empty((dh, dw), np.float32)
-                arr[j] = VkxElem(m.ctypes.data, out.ctypes.data, sw, dw, 1, 1)
-            elif m.dtype == np.uint8:
+                out, optr = call.out((dh, dw), np.float32)
+                arr[j] = VkxElem(call.src(m).value, optr.value, sw, dw, 1, 1)
+            elif np.dtype(m.dtype) == np.uint8:
                 cn = 1 if m.ndim == 2 else m.shape[2]
-                out = _out_like(m, dh, dw, ctx)
-                arr[j] = VkxElem(m.ctypes.data, out.ctypes.data, sw * cn, dw * cn, cn, 0)
+                out, optr = call.out((dh, dw) if m.ndim == 2 else (dh, dw, cn), np.uint8)
+                arr[j] = VkxElem(call.src(m).value, optr.value, sw * cn, dw * cn, cn, 0)
             else:
                 raise TypeError(f'unsupported dtype {m.dtype}')
-            chunk_out.append(out)
-        check(lib().vkx_grid_remap(ctx.handle, arr, len(chunk), sh, sw, _ptr(sv), _ptr(dv), rows, cols, dh, dw))
-        outs.extend(chunk_out)
+            outs.append(out)
+        check(call.fn('vkx_grid_remap')(call.ctx.handle, arr, len(chunk), sh, sw, sv_p, dv_p, rows, cols, dh, dw))
     return outs
 
 
@@ -770,42 +976,39 @@ def noise_normal_table(std):
 
 
 def gaussian_blur(img, ksize, sigma, ctx=None):
-    ctx = ctx or default_ctx()
-    img, h, w, cn, stride = _u8_plane(img)
-    dst = ctx.pinned_empty(img.shape, img.dtype)
-    check(lib().vkx_gaussian_blur_u8(ctx.handle, _ptr(img), h, w, cn, stride, int(ksize), float(sigma), _ptr(dst), stride))
+    call = _Call(ctx, img)
+    h, w, cn, stride = _shape_u8(img)
+    dst, dptr = call.out(img.shape, np.uint8)
+    check(call.fn('vkx_gaussian_blur_u8')(call.ctx.handle, call.src(img), h, w, cn, stride, int(ksize), float(sigma), dptr, stride))
     return dst
 
 
 def color_shift_rgb(img, delta, ctx=None):
-    ctx = ctx or default_ctx()
-    img, h, w, cn, stride = _u8_plane(img)
+    call = _Call(ctx, img)
+    h, w, cn, stride = _shape_u8(img)
     if cn != 3:
         raise ValueError('color_shift_rgb needs an HxWx3 image')
-    dst = ctx.pinned_empty(img.shape, img.dtype)
-    check(lib().vkx_color_shift_rgb(ctx.handle, _ptr(img), h, w, stride, int(delta), _ptr(dst), stride))
+    dst, dptr = call.out(img.shape, np.uint8)
+    check(call.fn('vkx_color_shift_rgb')(call.ctx.handle, call.src(img), h, w, stride, int(delta), dptr, stride))
     return dst
 
 
 def cvt_rgb_hsv(img, to_hsv, ctx=None):
-    ctx = ctx or default_ctx()
-    img, h, w, cn, stride = _u8_plane(img)
+    call = _Call(ctx, img)
+    h, w, cn, stride = _shape_u8(img)
     if cn != 3:
         raise ValueError('RGB <-> HSV needs an HxWx3 image')
-    dst = ctx.pinned_empty(img.shape, img.dtype)
-    check(lib().vkx_cvt_rgb_hsv_u8(ctx.handle, _ptr(img), h, w, stride, int(bool(to_hsv)), _ptr(dst), stride))
+    dst, dptr = call.out(img.shape, np.uint8)
+    check(call.fn('vkx_cvt_rgb_hsv_u8')(call.ctx.handle, call.src(img), h, w, stride, int(bool(to_hsv)), dptr, stride))
     return dst
 
 
 def mean_shift(img, delta, threshold=None, channels=None, cycle=False, ctx=None):
-    ctx = ctx or default_ctx()
-    img, h, w, cn, stride = _u8_plane(img)
-    chmask = 0
-    for c in channels or ():
-        chmask |= 1 << int(c)
-    dst = ctx.pinned_empty(img.shape, img.dtype)
-    check(lib().vkx_mean_shift_u8(ctx.handle, _ptr(img), h, w, cn, stride, int(delta), int(threshold is not None),
-                                  int(threshold or 0), int(bool(cycle)), chmask, _ptr(dst), stride))
+    call = _Call(ctx, img)
+    h, w, cn, stride = _shape_u8(img)
+    dst, dptr = call.out(img.shape, np.uint8)
+    check(call.fn('vkx_mean_shift_u8')(call.ctx.handle, call.src(img), h, w, cn, stride, int(delta), int(threshold is not None),
+                                       int(threshold or 0), int(bool(cycle)), _channel_mask(channels), dptr, stride))
     return dst
 
 
@@ -818,61 +1021,60 @@ _CVT_CHANNELS = {CVT_RGB2GRAY: (3, 1), CVT_GRAY2RGB: (1, 3), CVT_RGBA2RGB: (4, 3
 
 def cvt_color(img, code, ctx=None):
     """cv.cvtColor for the codes of include/vkx.h (VKX_CVT_*)."""
-    ctx = ctx or default_ctx()
-    img, h, w, cn, stride = _u8_plane(img)
+    call = _Call(ctx, img)
+    h, w, cn, stride = _shape_u8(img)
     want_cn, out_cn = _CVT_CHANNELS.get(code, (3, 3))
     if cn != want_cn:
         raise ValueError(f'conversion code {code} takes {want_cn}-channel input')
-    dst = ctx.pinned_empty((h, w) if out_cn == 1 else (h, w, out_cn), np.uint8)
-    check(lib().vkx_cvt_color_u8(ctx.handle, _ptr(img), h, w, stride, int(code), _ptr(dst), w * out_cn))
+    dst, dptr = call.out((h, w) if out_cn == 1 else (h, w, out_cn), np.uint8)
+    check(call.fn('vkx_cvt_color_u8')(call.ctx.handle, call.src(img), h, w, stride, int(code), dptr, w * out_cn))
     return dst
 
 
 def blend_u8(a, b, w0, w1, channels=None, ctx=None):
     """uint8(clip(w0 * a + w1 * b, 0, 255)) on ``channels`` (None = all), ``b`` elsewhere (include/vkx.h vkx_blend_u8)."""
-    ctx = ctx or default_ctx()
-    a, h, w, cn, stride = _u8_plane(a)
-    b = np.ascontiguousarray(b)
-    if b.shape != a.shape or b.dtype != np.uint8:
+    call = _Call(ctx, a, b)
+    h, w, cn, stride = _shape_u8(a)
+    if tuple(b.shape) != tuple(a.shape) or np.dtype(b.dtype) != np.uint8:
         raise ValueError('the two planes must agree in shape and dtype')
-    dst = ctx.pinned_empty(a.shape, np.uint8)
-    check(lib().vkx_blend_u8(ctx.handle, _ptr(a), stride, _ptr(b), stride, h, w, cn, float(w0), float(w1), _channel_mask(channels),
-                             _ptr(dst), stride))
+    dst, dptr = call.out(a.shape, np.uint8)
+    check(call.fn('vkx_blend_u8')(call.ctx.handle, call.src(a), stride, call.src(b), stride, h, w, cn, float(w0), float(w1),
+                                  _channel_mask(channels), dptr, stride))
     return dst
 
 
 def fog_f32(img, weight, fog_values, ctx=None):
     """uint8(clip((1 - weight) * img + weight * fog_values[c], 0, 255)): float32 weight plane (H, W), float32 fog per channel."""
-    ctx = ctx or default_ctx()
-    img, h, w, cn, stride = _u8_plane(img)
-    weight = np.ascontiguousarray(weight, dtype=np.float32)
-    if weight.shape != (h, w):
+    call = _Call(ctx, img, weight)
+    h, w, cn, stride = _shape_u8(img)
+    if tuple(weight.shape) != (h, w):
         raise ValueError('weight plane must be (H, W)')
     fog = np.ascontiguousarray(np.asarray(fog_values, dtype=np.float32).reshape(-1))
     if fog.shape[0] != cn:
         raise ValueError('one fog value per channel')
-    dst = ctx.pinned_empty(img.shape, np.uint8)
-    check(lib().vkx_fog_f32_u8(ctx.handle, _ptr(img), h, w, cn, stride, _ptr(weight), w, _ptr(fog), _ptr(dst), stride))
+    dst, dptr = call.out(img.shape, np.uint8)
+    check(call.fn('vkx_fog_f32_u8')(call.ctx.handle, call.src(img), h, w, cn, stride, call.src(weight, np.float32), w, _ptr(fog), dptr,
+                                    stride))
     return dst
 
 
 def brightness_shift_rgb(img, delta, ctx=None):
-    ctx = ctx or default_ctx()
-    img, h, w, cn, stride = _u8_plane(img)
+    call = _Call(ctx, img)
+    h, w, cn, stride = _shape_u8(img)
     if cn != 3:
         raise ValueError('expected an RGB image')
-    dst = ctx.pinned_empty(img.shape, img.dtype)
-    check(lib().vkx_brightness_shift_rgb(ctx.handle, _ptr(img), h, w, stride, int(delta), _ptr(dst), stride))
+    dst, dptr = call.out(img.shape, np.uint8)
+    check(call.fn('vkx_brightness_shift_rgb')(call.ctx.handle, call.src(img), h, w, stride, int(delta), dptr, stride))
     return dst
 
 
 def color_balance_rgb(img, ratio, ctx=None):
-    ctx = ctx or default_ctx()
-    img, h, w, cn, stride = _u8_plane(img)
+    call = _Call(ctx, img)
+    h, w, cn, stride = _shape_u8(img)
     if cn != 3:
         raise ValueError('expected an RGB image')
-    dst = ctx.pinned_empty(img.shape, img.dtype)
-    check(lib().vkx_color_balance_rgb(ctx.handle, _ptr(img), h, w, stride, float(ratio), _ptr(dst), stride))
+    dst, dptr = call.out(img.shape, np.uint8)
+    check(call.fn('vkx_color_balance_rgb')(call.ctx.handle, call.src(img), h, w, stride, float(ratio), dptr, stride))
     return dst
 
 
@@ -885,11 +1087,11 @@ def _channel_mask(channels):
 
 def pointwise(img, op, p0=0, p1=0, channels=None, ctx=None):
     """complement / posterization / channel permutation (include/vkx.h VKX_POINT_*)."""
-    ctx = ctx or default_ctx()
-    img, h, w, cn, stride = _u8_plane(img)
-    dst = ctx.pinned_empty(img.shape, img.dtype)
-    check(lib().vkx_pointwise_u8(ctx.handle, _ptr(img), h, w, cn, stride, int(op), int(p0), int(p1),
-                                 _channel_mask(channels), _ptr(dst), stride))
+    call = _Call(ctx, img)
+    h, w, cn, stride = _shape_u8(img)
+    dst, dptr = call.out(img.shape, np.uint8)
+    check(call.fn('vkx_pointwise_u8')(call.ctx.handle, call.src(img), h, w, cn, stride, int(op), int(p0), int(p1),
+                                      _channel_mask(channels), dptr, stride))
     return dst
 
 
@@ -904,94 +1106,92 @@ def permute_channels(img, indices, ctx=None):
 
 
 def histogram(img, ctx=None):
-    """Per-channel histogram, int32 [cn, 256]."""
-    ctx = ctx or default_ctx()
-    img, h, w, cn, stride = _u8_plane(img)
-    hist = np.zeros((cn, 256), np.int32)
-    check(lib().vkx_histogram_u8(ctx.handle, _ptr(img), h, w, cn, stride, _ptr(hist)))
-    return hist
+    """Per-channel histogram, int32 [cn, 256] (a host array: the tables built from it are host arithmetic)."""
+    call = _Call(ctx, img)
+    h, w, cn, stride = _shape_u8(img)
+    hist, hptr = call.out((cn, 256), np.int32)
+    if not call.dev:
+        hist[...] = 0
+    check(call.fn('vkx_histogram_u8')(call.ctx.handle, call.src(img), h, w, cn, stride, hptr))
+    return np.array(host_array(hist))
 
 
 def filter2d(img, kernel, ctx=None):
     """cv.filter2D(img, -1, kernel) for uint8 images and float32 kernels of up to 15 x 15 taps."""
-    ctx = ctx or default_ctx()
-    img, h, w, cn, stride = _u8_plane(img)
+    call = _Call(ctx, img)
+    h, w, cn, stride = _shape_u8(img)
     kernel = np.ascontiguousarray(kernel, dtype=np.float32)
     if kernel.ndim != 2:
         raise ValueError('kernel must be 2-D')
-    dst = ctx.pinned_empty(img.shape, img.dtype)
-    check(lib().vkx_filter2d_u8(ctx.handle, _ptr(img), h, w, cn, stride, _ptr(kernel), kernel.shape[0], kernel.shape[1],
-                                _ptr(dst), stride))
+    dst, dptr = call.out(img.shape, np.uint8)
+    check(call.fn('vkx_filter2d_u8')(call.ctx.handle, call.src(img), h, w, cn, stride, _ptr(kernel), kernel.shape[0], kernel.shape[1],
+                                     dptr, stride))
     return dst
 
 
 def apply_lut(img, lut, channels=None, ctx=None):
     """dst[..., c] = lut[c][img[..., c]] on the selected channels; lut uint8 [cn, 256]."""
-    ctx = ctx or default_ctx()
-    img, h, w, cn, stride = _u8_plane(img)
+    call = _Call(ctx, img)
+    h, w, cn, stride = _shape_u8(img)
     lut = np.ascontiguousarray(lut, dtype=np.uint8)
     if lut.shape != (cn, 256):
         raise ValueError(f'table must be uint8 [{cn}, 256]')
-    dst = ctx.pinned_empty(img.shape, img.dtype)
-    check(lib().vkx_apply_lut_u8(ctx.handle, _ptr(img), h, w, cn, stride, _ptr(lut), _channel_mask(channels),
-                                 _ptr(dst), stride))
+    dst, dptr = call.out(img.shape, np.uint8)
+    check(call.fn('vkx_apply_lut_u8')(call.ctx.handle, call.src(img), h, w, cn, stride, _ptr(lut), _channel_mask(channels), dptr, stride))
     return dst
 
 
 def gather(img, pos_y, pos_x, ctx=None):
     """img[pos_y, pos_x] for two integer index planes of one shape."""
-    ctx = ctx or default_ctx()
-    img, h, w, cn, stride = _u8_plane(img)
+    call = _Call(ctx, img)
+    h, w, cn, stride = _shape_u8(img)
     pos_y = np.ascontiguousarray(pos_y, dtype=np.int32)
     pos_x = np.ascontiguousarray(pos_x, dtype=np.int32)
     if pos_y.ndim != 2 or pos_y.shape != pos_x.shape:
         raise ValueError('index planes must be 2-D and of one shape')
     dh, dw = pos_y.shape
-    dst = ctx.pinned_empty((dh, dw) + img.shape[2:], np.uint8)
-    check(lib().vkx_gather_u8(ctx.handle, _ptr(img), h, w, cn, stride, _ptr(pos_y), _ptr(pos_x), dw, _ptr(dst), dh, dw,
-                              dw * cn))
+    dst, dptr = call.out((dh, dw) + tuple(img.shape[2:]), np.uint8)
+    check(call.fn('vkx_gather_u8')(call.ctx.handle, call.src(img), h, w, cn, stride, call.src(pos_y), call.src(pos_x), dw, dptr, dh, dw,
+                                   dw * cn))
     return dst
 
 
 def saturate_i64(samples, ctx=None):
     """np.clip(samples, 0, 255).astype(np.uint8) for an int64 array."""
-    ctx = ctx or default_ctx()
-    samples = np.ascontiguousarray(samples, dtype=np.int64)
-    dst = ctx.pinned_empty(samples.shape, np.uint8)
-    check(lib().vkx_saturate_i64_u8(ctx.handle, _ptr(samples), samples.size, _ptr(dst)))
+    call = _Call(ctx, samples)
+    dst, dptr = call.out(np.shape(samples), np.uint8)
+    check(call.fn('vkx_saturate_i64_u8')(call.ctx.handle, call.src(samples, np.int64), int(np.prod(np.shape(samples))), dptr))
     return dst
 
 
 def impulse_noise(img, selector, ctx=None):
-    ctx = ctx or default_ctx()
-    img, h, w, cn, stride = _u8_plane(img)
-    selector = np.ascontiguousarray(selector, dtype=np.uint8)
-    if selector.shape != (h, w):
+    call = _Call(ctx, img)
+    h, w, cn, stride = _shape_u8(img)
+    if tuple(np.shape(selector)) != (h, w):
         raise ValueError('selector plane must be (H, W)')
-    dst = ctx.pinned_empty(img.shape, img.dtype)
-    check(lib().vkx_impulse_noise_u8(ctx.handle, _ptr(img), h, w, cn, stride, _ptr(selector), w, _ptr(dst), stride))
+    dst, dptr = call.out(img.shape, np.uint8)
+    check(call.fn('vkx_impulse_noise_u8')(call.ctx.handle, call.src(img), h, w, cn, stride, call.src(selector, np.uint8), w, dptr, stride))
     return dst
 
 
 def speckle_noise(img, noise, ctx=None):
-    ctx = ctx or default_ctx()
-    img, h, w, cn, stride = _u8_plane(img)
-    noise = np.ascontiguousarray(noise, dtype=np.float64)
-    if noise.shape != img.shape:
+    call = _Call(ctx, img)
+    h, w, cn, stride = _shape_u8(img)
+    if tuple(np.shape(noise)) != tuple(img.shape):
         raise ValueError('noise plane must have the image shape')
-    dst = ctx.pinned_empty(img.shape, img.dtype)
-    check(lib().vkx_speckle_noise_u8(ctx.handle, _ptr(img), h, w, cn, stride, _ptr(noise), w * cn, _ptr(dst), stride))
+    dst, dptr = call.out(img.shape, np.uint8)
+    check(call.fn('vkx_speckle_noise_u8')(call.ctx.handle, call.src(img), h, w, cn, stride, call.src(noise, np.float64), w * cn, dptr,
+                                          stride))
     return dst
 
 
 def add_noise_i16(img, noise, ctx=None):
-    ctx = ctx or default_ctx()
-    img, h, w, cn, stride = _u8_plane(img)
-    noise = np.ascontiguousarray(noise, dtype=np.int16)
-    if noise.shape != img.shape:
+    call = _Call(ctx, img)
+    h, w, cn, stride = _shape_u8(img)
+    if tuple(np.shape(noise)) != tuple(img.shape):
         raise ValueError('noise plane must have the image shape')
-    dst = ctx.pinned_empty(img.shape, img.dtype)
-    check(lib().vkx_add_noise_i16(ctx.handle, _ptr(img), h, w, cn, stride, _ptr(noise), w * cn, _ptr(dst), stride))
+    dst, dptr = call.out(img.shape, np.uint8)
+    check(call.fn('vkx_add_noise_i16')(call.ctx.handle, call.src(img), h, w, cn, stride, call.src(noise, np.int16), w * cn, dptr, stride))
     return dst
 
 
@@ -1070,49 +1270,49 @@ def np_job(kind, stream, n, scale=0.0, cdf=(2.0, 2.0, 2.0), cn=1, src=None, dst=
     return job
 
 
-def np_draw(kind, rng, dst, src=None, scale=0.0, cdf=(2.0, 2.0, 2.0), cn=1, ctx=None):
-    """One stream job on host arrays (``vkx_np_draw``).  Returns True and advances ``rng`` when the device result is
-    known to be numpy's; False (``rng`` untouched, ``dst`` undefined) when the generator is not PCG64 or a decision fell
+def np_draw(kind, rng, out_shape, out_dtype, src=None, scale=0.0, cdf=(2.0, 2.0, 2.0), cn=1, ctx=None):
+    """One stream job (``vkx_np_draw`` on host arrays, ``vkx_np_draw_batch_dev`` when ``src`` is a DevArray or in resident mode).
+    Returns the result (numpy array or DevArray) and advances ``rng`` when the device result is known to be numpy's; None
+    (``rng`` untouched) when the generator is not PCG64, the stream is outside the device path's limits, or a decision fell
     inside the libm ambiguity margin -- the caller then draws on the host."""
     stream = np_stream(rng)
-    if stream is None or dst.size == 0:
-        return False
-    ctx = ctx or default_ctx()
-    n = dst.size // cn if kind == NP_IMPULSE_U8 else dst.size
-    job = np_job(kind, stream, n, scale, cdf, cn, _ptr(src) if src is not None else None, _ptr(dst))
+    size = int(np.prod(out_shape, dtype=np.int64))
+    if stream is None or size == 0:
+        return None
+    call = _Call(ctx, *([src] if src is not None else []))
+    n = size // cn if kind == NP_IMPULSE_U8 else size
+    dst, dptr = call.out(out_shape, out_dtype)
+    job = np_job(kind, stream, n, scale, cdf, cn, call.src(src) if src is not None else None, dptr)
     res = VkxNpResult()
-    rc = lib().vkx_np_draw(ctx.handle, ctypes.byref(job), ctypes.byref(res))
+    if call.dev:
+        rc = lib().vkx_np_draw_batch_dev(call.ctx.handle, ctypes.byref(job), 1, ctypes.byref(res))
+        if rc == 0:
+            call.ctx.sync()             # the verdict on the stream (flags) decides whether the result stands
+    else:
+        rc = lib().vkx_np_draw(call.ctx.handle, ctypes.byref(job), ctypes.byref(res))
     if rc == ERR_INVALID:   # a stream the device path does not take (scale / length limits): host
-        return False
+        return None
     check(rc)
     if res.flags:
-        return False
+        return None
     np_consume(rng, res.draws)
-    return True
+    return dst
 
 
 def np_gaussion_noise(img, std, rng, ctx=None):
     """``clip(int16(img) + np.round(rng.normal(0, std, img.shape)).astype(int16), 0, 255)`` with the samples drawn on the
     device from ``rng``'s stream (photometric/noise.py:44-54); None when the host has to draw."""
-    ctx = ctx or default_ctx()
-    img = np.ascontiguousarray(img)
-    dst = ctx.pinned_empty(img.shape, np.uint8)
-    return dst if np_draw(NP_NORMAL_ADD_U8, rng, dst, img, scale=std, ctx=ctx) else None
+    return np_draw(NP_NORMAL_ADD_U8, rng, img.shape, np.uint8, img, scale=std, ctx=ctx)
 
 
 def np_normal_i16(shape, std, rng, ctx=None):
     """``np.round(rng.normal(0, std, shape)).astype(np.int16)`` drawn on the device; None when the host has to draw."""
-    ctx = ctx or default_ctx()
-    dst = ctx.pinned_empty(shape, np.int16)
-    return dst if np_draw(NP_NORMAL_I16, rng, dst, scale=std, ctx=ctx) else None
+    return np_draw(NP_NORMAL_I16, rng, shape, np.int16, scale=std, ctx=ctx)
 
 
 def np_speckle_noise(img, std, rng, ctx=None):
     """``uint8(clip(img + img * rng.normal(0, std, img.shape), 0, 255))`` (photometric/noise.py:172-183)."""
-    ctx = ctx or default_ctx()
-    img = np.ascontiguousarray(img)
-    dst = ctx.pinned_empty(img.shape, np.uint8)
-    return dst if np_draw(NP_SPECKLE_U8, rng, dst, img, scale=std, ctx=ctx) else None
+    return np_draw(NP_SPECKLE_U8, rng, img.shape, np.uint8, img, scale=std, ctx=ctx)
 
 
 def _choice_cdf(p):
@@ -1125,24 +1325,28 @@ def _choice_cdf(p):
 def np_impulse_noise(img, prob_salt, prob_pepper, rng, ctx=None):
     """``rng.choice((0, 1, 2), size=(H, W), p=[keep, salt, pepper])`` drawn on the device and applied
     (photometric/noise.py:125-150)."""
-    ctx = ctx or default_ctx()
-    img, h, w, cn, _stride = _u8_plane(img)
+    h, w, cn, _stride = _shape_u8(img)
     p = np.array([1 - prob_salt - prob_pepper, prob_salt, prob_pepper], dtype=np.float64)
     if not (p >= 0).all() or not np.isfinite(p).all():
         return None      # let numpy raise its own error on the host path
-    dst = ctx.pinned_empty(img.shape, np.uint8)
-    return dst if np_draw(NP_IMPULSE_U8, rng, dst, img, cdf=_choice_cdf(p), cn=cn, ctx=ctx) else None
+    return np_draw(NP_IMPULSE_U8, rng, img.shape, np.uint8, img, cdf=_choice_cdf(p), cn=cn, ctx=ctx)
 
 
 def line_streak(img, thickness, gap, dash_thickness, dash_gap, color, alpha, enable_vert, enable_hori, ctx=None):
     """Returns a new array (the kernel works in place on a copy)."""
-    ctx = ctx or default_ctx()
-    out = np.array(img, dtype=np.uint8, order='C')
-    _, h, w, cn, stride = _u8_plane(out)
+    call = _Call(ctx, img)
+    h, w, cn, stride = _shape_u8(img)
     col = np.zeros(4, np.uint8)
     col[:cn] = np.asarray(color, dtype=np.uint8).reshape(-1)[:cn]
-    check(lib().vkx_line_streak_u8(ctx.handle, _ptr(out), h, w, cn, stride, int(thickness), int(gap), int(dash_thickness),
-                                   int(dash_gap), _ptr(col), float(alpha), int(bool(enable_vert)), int(bool(enable_hori))))
+    if call.dev:
+        out = call.ctx.dev_empty(img.shape, np.uint8)
+        check(lib().vkx_memcpy_async(call.ctx.handle, STREAM_COMPUTE, c_void_p(out.ptr), call.src(img), out.nbytes, 2))
+        optr = c_void_p(out.ptr)
+    else:
+        out = np.array(host_array(img), dtype=np.uint8, order='C')
+        optr = _ptr(out)
+    check(call.fn('vkx_line_streak_u8')(call.ctx.handle, optr, h, w, cn, stride, int(thickness), int(gap), int(dash_thickness),
+                                        int(dash_gap), _ptr(col), float(alpha), int(bool(enable_vert)), int(bool(enable_hori))))
     return out
 
 
@@ -1161,25 +1365,31 @@ def ellipse_mask(mask, center, axes, thickness, ctx=None):
 
 def ellipse_streak(img, center, axes, thickness, color, alpha, ctx=None):
     """ellipse_streak_image's raster and blend; returns a new array."""
-    ctx = ctx or default_ctx()
-    out = ctx.pinned_empty(np.shape(img), np.uint8)
-    np.copyto(out, img)
-    _, h, w, cn, stride = _u8_plane(out)
+    call = _Call(ctx, img)
+    h, w, cn, stride = _shape_u8(img)
     axes = np.ascontiguousarray(np.asarray(axes, dtype=np.int32).reshape(-1, 2))
     col = np.zeros(4, np.uint8)
     col[:cn] = np.asarray(color, dtype=np.uint8).reshape(-1)[:cn]
-    check(lib().vkx_ellipse_streak_u8(ctx.handle, _ptr(out), h, w, cn, stride, int(center[0]), int(center[1]), _ptr(axes),
-                                      int(axes.shape[0]), int(thickness), _ptr(col), float(alpha)))
+    if call.dev:
+        out = call.ctx.dev_empty(img.shape, np.uint8)
+        check(lib().vkx_memcpy_async(call.ctx.handle, STREAM_COMPUTE, c_void_p(out.ptr), call.src(img), out.nbytes, 2))
+        optr = c_void_p(out.ptr)
+    else:
+        out = call.ctx.pinned_empty(img.shape, np.uint8)
+        np.copyto(out, host_array(img))
+        optr = _ptr(out)
+    check(call.fn('vkx_ellipse_streak_u8')(call.ctx.handle, optr, h, w, cn, stride, int(center[0]), int(center[1]), _ptr(axes),
+                                           int(axes.shape[0]), int(thickness), _ptr(col), float(alpha)))
     return out
 
 
 def fill_poly_mask(shape, pts, ctx=None):
     """cv.fillPoly(zeros(shape, uint8), [pts], 1); pts int (N, 2) as (x, y), all inside the array."""
-    ctx = ctx or default_ctx()
+    call = _Call(ctx)
     h, w = int(shape[0]), int(shape[1])
     pts = np.ascontiguousarray(np.asarray(pts, dtype=np.int32).reshape(-1, 2))
-    mask = ctx.pinned_empty((h, w), np.uint8)
-    check(lib().vkx_fill_poly_mask_u8(ctx.handle, _ptr(pts), int(pts.shape[0]), _ptr(mask), h, w, w))
+    mask, mptr = call.out((h, w), np.uint8)
+    check(call.fn('vkx_fill_poly_mask_u8')(call.ctx.handle, _ptr(pts), int(pts.shape[0]), mptr, h, w, w))
     return mask
 
 
@@ -1191,100 +1401,102 @@ INTER_NEAREST, INTER_LINEAR, INTER_CUBIC, INTER_AREA, INTER_LANCZOS4, INTER_LINE
 
 def resize(src, dsize_hw, interpolation, ctx=None):
     """cv.resize(src, (dw, dh), interpolation=<cv2 code 0..6>) for uint8 HxW[xC] or float32 HxW arrays."""
-    ctx = ctx or default_ctx()
+    call = _Call(ctx, src)
     dh, dw = int(dsize_hw[0]), int(dsize_hw[1])
-    if src.dtype == np.float32:
-        src = np.ascontiguousarray(src)
+    if np.dtype(src.dtype) == np.float32:
         if src.ndim != 2:
             raise ValueError('float32 planes are HxW')
         sh, sw = src.shape
-        dst = ctx.pinned_empty((dh, dw), np.float32)
-        check(lib().vkx_resize_f32(ctx.handle, _ptr(src), sh, sw, sw, _ptr(dst), dh, dw, dw, int(interpolation)))
+        dst, dptr = call.out((dh, dw), np.float32)
+        check(call.fn('vkx_resize_f32')(call.ctx.handle, call.src(src), sh, sw, sw, dptr, dh, dw, dw, int(interpolation)))
         return dst
-    src, sh, sw, cn, stride = _u8_plane(src)
-    dst = ctx.pinned_empty((dh, dw) + src.shape[2:], np.uint8)
-    check(lib().vkx_resize_u8(ctx.handle, _ptr(src), sh, sw, cn, stride, _ptr(dst), dh, dw, dw * cn, int(interpolation)))
+    sh, sw, cn, stride = _shape_u8(src)
+    dst, dptr = call.out((dh, dw) + tuple(src.shape[2:]), np.uint8)
+    check(call.fn('vkx_resize_u8')(call.ctx.handle, call.src(src), sh, sw, cn, stride, dptr, dh, dw, dw * cn, int(interpolation)))
     return dst
 
 
 def zoom_in_blur(img, sizes_hw, alpha, ctx=None):
     """include/vkx.h vkx_zoom_in_blur_u8: sizes_hw = [(height, width), ...] of the enlarged copies."""
-    ctx = ctx or default_ctx()
-    img, h, w, cn, stride = _u8_plane(img)
+    call = _Call(ctx, img)
+    h, w, cn, stride = _shape_u8(img)
     sizes = np.ascontiguousarray(np.asarray(sizes_hw, dtype=np.int32).reshape(-1, 2))
-    dst = ctx.pinned_empty(img.shape, img.dtype)
-    check(lib().vkx_zoom_in_blur_u8(ctx.handle, _ptr(img), h, w, cn, stride, _ptr(sizes), int(sizes.shape[0]), float(alpha),
-                                    _ptr(dst), stride))
+    dst, dptr = call.out(img.shape, np.uint8)
+    check(call.fn('vkx_zoom_in_blur_u8')(call.ctx.handle, call.src(img), h, w, cn, stride, _ptr(sizes), int(sizes.shape[0]), float(alpha),
+                                         dptr, stride))
     return dst
 
 
 def resize_cubic(src, dsize_hw, ctx=None):
     """cv.resize(src, (dw, dh), interpolation=cv.INTER_CUBIC) for uint8 HxW[xC] or float32 HxW arrays."""
-    ctx = ctx or default_ctx()
+    call = _Call(ctx, src)
     dh, dw = int(dsize_hw[0]), int(dsize_hw[1])
-    if src.dtype == np.float32:
+    if np.dtype(src.dtype) == np.float32:
         if src.ndim != 2:
             raise ValueError('float32 resize takes a 2-D array')
-        src = np.ascontiguousarray(src)
         sh, sw = src.shape
-        dst = ctx.pinned_empty((dh, dw), np.float32)
-        check(lib().vkx_resize_cubic_f32(ctx.handle, _ptr(src), sh, sw, sw, _ptr(dst), dh, dw, dw))
+        dst, dptr = call.out((dh, dw), np.float32)
+        check(call.fn('vkx_resize_cubic_f32')(call.ctx.handle, call.src(src), sh, sw, sw, dptr, dh, dw, dw))
         return dst
-    src, sh, sw, cn, stride = _u8_plane(src)
-    dst = ctx.pinned_empty((dh, dw) + src.shape[2:], np.uint8)
-    check(lib().vkx_resize_cubic_u8(ctx.handle, _ptr(src), sh, sw, cn, stride, _ptr(dst), dh, dw, dw * cn))
+    sh, sw, cn, stride = _shape_u8(src)
+    dst, dptr = call.out((dh, dw) + tuple(src.shape[2:]), np.uint8)
+    check(call.fn('vkx_resize_cubic_u8')(call.ctx.handle, call.src(src), sh, sw, cn, stride, dptr, dh, dw, dw * cn))
     return dst
 
 
-def paint_polys(polygons, values=None, mask=None, score=None, ctx=None):
-    """Ordered paint of ``polygons`` (sequence of int (N_i, 2) arrays of (x, y) in plane coordinates) into the
-    writable uint8 ``mask`` and / or float32 ``score`` planes, in place: later polygons win on overlaps."""
-    ctx = ctx or default_ctx()
+def _paint(flat, offsets, n, values, mask, score, ctx):
     plane = mask if mask is not None else score
     if plane is None:
         raise ValueError('mask or score is required')
     h, w = plane.shape
+    dev = isinstance(plane, DevArray)
     for arr, dt in ((mask, np.uint8), (score, np.float32)):
-        if arr is not None and (arr.dtype != dt or arr.shape != (h, w) or not arr.flags.c_contiguous
-                                or not arr.flags.writeable):
+        if arr is None:
+            continue
+        if isinstance(arr, DevArray) != dev:
+            raise ValueError('mask and score planes must both be numpy arrays or both DevArrays')
+        if np.dtype(arr.dtype) != dt or tuple(arr.shape) != (h, w) or (not dev and (not arr.flags.c_contiguous or not arr.flags.writeable)):
             raise ValueError(f'planes must be writable C-contiguous {(h, w)} arrays (uint8 mask, float32 score)')
-    pts = [np.asarray(p, dtype=np.int32).reshape(-1, 2) for p in polygons]
-    offsets = np.zeros(len(pts) + 1, np.int32)
-    if pts:
-        offsets[1:] = np.cumsum([len(p) for p in pts])
-    flat = np.ascontiguousarray(np.concatenate(pts, axis=0)) if pts else np.zeros((0, 2), np.int32)
-    vals = None
-    if score is not None:
-        vals = np.ascontiguousarray(np.asarray(values, dtype=np.float32))
-        if vals.shape != (len(pts),):
-            raise ValueError('one value per polygon is required with a score plane')
-    check(lib().vkx_paint_polys(ctx.handle, _ptr(flat), _ptr(offsets), len(pts), _ptr(vals) if vals is not None else None,
-                                _ptr(mask) if mask is not None else None, w,
-                                _ptr(score) if score is not None else None, w, h, w))
-
-
-def paint_polys_flat(points_xy, offsets, values=None, mask=None, score=None, ctx=None):
-    """``paint_polys`` for polygons that already are one int (N, 2) vertex array + (P + 1) offsets (element/soup.py)."""
-    ctx = ctx or default_ctx()
-    plane = mask if mask is not None else score
-    if plane is None:
-        raise ValueError('mask or score is required')
-    h, w = plane.shape
-    for arr, dt in ((mask, np.uint8), (score, np.float32)):
-        if arr is not None and (arr.dtype != dt or arr.shape != (h, w) or not arr.flags.c_contiguous
-                                or not arr.flags.writeable):
-            raise ValueError(f'planes must be writable C-contiguous {(h, w)} arrays (uint8 mask, float32 score)')
-    flat = np.ascontiguousarray(points_xy, dtype=np.int32).reshape(-1, 2)
-    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
-    n = offsets.shape[0] - 1
     vals = None
     if score is not None:
         vals = np.ascontiguousarray(np.asarray(values, dtype=np.float32))
         if vals.shape != (n,):
             raise ValueError('one value per polygon is required with a score plane')
-    check(lib().vkx_paint_polys(ctx.handle, _ptr(flat), _ptr(offsets), n, _ptr(vals) if vals is not None else None,
-                                _ptr(mask) if mask is not None else None, w,
-                                _ptr(score) if score is not None else None, w, h, w))
+    pm = (c_void_p(mask.ptr) if dev else _ptr(mask)) if mask is not None else None
+    ps = (c_void_p(score.ptr) if dev else _ptr(score)) if score is not None else None
+    fn = lib().vkx_paint_polys_dev if dev else lib().vkx_paint_polys
+    check(fn(ctx.handle, _ptr(flat), _ptr(offsets), n, _ptr(vals) if vals is not None else None, pm, w, ps, w, h, w))
+    for arr in (mask, score):
+        if dev and arr is not None:
+            arr.invalidate_host()
+
+
+def paint_polys(polygons, values=None, mask=None, score=None, ctx=None):
+    """Ordered paint of ``polygons`` (sequence of int (N_i, 2) arrays of (x, y) in plane coordinates) into the
+    writable uint8 ``mask`` and / or float32 ``score`` planes (numpy arrays or DevArrays), in place: later polygons win on
+    overlaps."""
+    pts = [np.asarray(p, dtype=np.int32).reshape(-1, 2) for p in polygons]
+    offsets = np.zeros(len(pts) + 1, np.int32)
+    if pts:
+        offsets[1:] = np.cumsum([len(p) for p in pts])
+    flat = np.ascontiguousarray(np.concatenate(pts, axis=0)) if pts else np.zeros((0, 2), np.int32)
+    _paint(flat, offsets, len(pts), values, mask, score, ctx or default_ctx())
+
+
+def paint_polys_flat(points_xy, offsets, values=None, mask=None, score=None, ctx=None):
+    """``paint_polys`` for polygons that already are one int (N, 2) vertex array + (P + 1) offsets (element/soup.py)."""
+    flat = np.ascontiguousarray(points_xy, dtype=np.int32).reshape(-1, 2)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    _paint(flat, offsets, offsets.shape[0] - 1, values, mask, score, ctx or default_ctx())
+
+
+def dev_zeros(shape, dtype=np.uint8, ctx=None):
+    """A zeroed DevArray."""
+    ctx = ctx or default_ctx()
+    arr = ctx.dev_empty(shape, dtype)
+    if arr.nbytes:
+        check(lib().vkx_memset(ctx.handle, c_void_p(arr.ptr), 0, arr.nbytes))
+    return arr
 
 
 def make_layer(box, cn, value, mask=None, alpha=1.0, mode=FILL_PLAIN, dtype=np.uint8):
@@ -1298,31 +1510,37 @@ def make_layer(box, cn, value, mask=None, alpha=1.0, mode=FILL_PLAIN, dtype=np.u
     layer = VkxLayerF32() if is_f32 else VkxLayer()
     layer.up, layer.left, layer.height, layer.width = up, left, bh, bw
     layer.mode = int(mode)
+    def _address(plane):
+        return plane.ptr if isinstance(plane, DevArray) else plane.ctypes.data
+
     if mask is not None:
-        mask = np.ascontiguousarray(mask, dtype=np.uint8)
-        if mask.shape != (bh, bw):
+        if not isinstance(mask, DevArray):
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        if tuple(mask.shape) != (bh, bw) or np.dtype(mask.dtype) != np.uint8:
             raise ValueError(f'mask shape {mask.shape} != box shape {(bh, bw)}')
         keep.append(mask)
-        layer.mask, layer.mask_stride = mask.ctypes.data, bw
-    if isinstance(alpha, np.ndarray):
-        alpha = np.ascontiguousarray(alpha, dtype=np.float32)
-        if alpha.shape != (bh, bw):
+        layer.mask, layer.mask_stride = _address(mask), bw
+    if isinstance(alpha, (np.ndarray, DevArray)):
+        if not isinstance(alpha, DevArray):
+            alpha = np.ascontiguousarray(alpha, dtype=np.float32)
+        if tuple(alpha.shape) != (bh, bw) or np.dtype(alpha.dtype) != np.float32:
             raise ValueError(f'alpha shape {alpha.shape} != box shape {(bh, bw)}')
         keep.append(alpha)
-        layer.alpha, layer.alpha_stride_el = alpha.ctypes.data, bw
+        layer.alpha, layer.alpha_stride_el = _address(alpha), bw
         layer.alpha_scalar = 1.0
     else:
         layer.alpha_scalar = float(alpha)
-    if isinstance(value, np.ndarray):
-        value = np.ascontiguousarray(value.astype(dtype, copy=False))
+    if isinstance(value, (np.ndarray, DevArray)):
+        if not isinstance(value, DevArray):
+            value = np.ascontiguousarray(value.astype(dtype, copy=False))
         want = (bh, bw) if cn == 1 and value.ndim == 2 else (bh, bw, cn)
-        if value.shape != want:
+        if tuple(value.shape) != want or np.dtype(value.dtype) != np.dtype(dtype):
             raise RuntimeError('value is np.ndarray but shape is not matched.')
         keep.append(value)
         if is_f32:
-            layer.value, layer.value_stride_el = value.ctypes.data, bw
+            layer.value, layer.value_stride_el = _address(value), bw
         else:
-            layer.value, layer.value_stride = value.ctypes.data, bw * cn
+            layer.value, layer.value_stride = _address(value), bw * cn
     elif is_f32:
         layer.value_const = float(np.float32(value))
     else:
@@ -1338,23 +1556,50 @@ def make_layer(box, cn, value, mask=None, alpha=1.0, mode=FILL_PLAIN, dtype=np.u
 
 
 def fill(dst, layers, ctx=None):
-    """Applies ``layers`` (list of (layer, keepalive) from make_layer with dst's dtype) to the writable uint8 or
-    float32 array ``dst`` in place."""
+    """Applies ``layers`` (list of (layer, keepalive) from make_layer with dst's dtype) to ``dst`` in place: a writable uint8
+    or float32 numpy array, or a DevArray (host planes of the layers are then uploaded for the call, DevArray planes are used
+    where they are; a host destination takes host planes only)."""
     ctx = ctx or default_ctx()
-    if dst.dtype not in (np.uint8, np.float32) or not dst.flags.c_contiguous or not dst.flags.writeable:
+    dev = isinstance(dst, DevArray)
+    if np.dtype(dst.dtype) not in (np.uint8, np.float32) or (not dev and (not dst.flags.c_contiguous or not dst.flags.writeable)):
         raise ValueError('dst must be a writable C-contiguous uint8 or float32 array')
     h, w = dst.shape[:2]
     cn = 1 if dst.ndim == 2 else dst.shape[2]
-    cls = VkxLayerF32 if dst.dtype == np.float32 else VkxLayer
+    is_f32 = np.dtype(dst.dtype) == np.float32
+    cls = VkxLayerF32 if is_f32 else VkxLayer
     arr = (cls * max(len(layers), 1))()
-    for i, (layer, _keep) in enumerate(layers):
+    keep = []
+    for i, (layer, planes) in enumerate(layers):
         if not isinstance(layer, cls):
             raise TypeError('layer built for another destination dtype')
         arr[i] = layer
-    if dst.dtype == np.float32:
-        if cn != 1:
-            raise ValueError('float32 destinations are single channel')
-        check(lib().vkx_fill_f32(ctx.handle, _ptr(dst), h, w, w, arr, len(layers)))
+        if not dev and any(isinstance(plane, DevArray) for plane in planes):
+            raise ValueError('a host destination cannot take device planes')
+        if dev:
+            # the record holds host addresses of the arrays in `planes` (or DevArrays' own addresses): device copies
+            for field in ('mask', 'alpha', 'value'):
+                addr = getattr(layer, field)
+                if not addr:
+                    continue
+                for plane in planes:
+                    if isinstance(plane, DevArray):
+                        if plane.ptr == addr:
+                            keep.append(plane)
+                            break
+                    elif plane.ctypes.data == addr:
+                        d = ctx.to_device(plane)
+                        keep.append(d)
+                        setattr(arr[i], field, d.ptr)
+                        break
+                else:
+                    raise ValueError('layer plane without its keepalive array: pass the pair make_layer returned')
+    if is_f32 and cn != 1:
+        raise ValueError('float32 destinations are single channel')
+    dptr = c_void_p(dst.ptr) if dev else _ptr(dst)
+    if is_f32:
+        check((lib().vkx_fill_f32_dev if dev else lib().vkx_fill_f32)(ctx.handle, dptr, h, w, w, arr, len(layers)))
     else:
-        check(lib().vkx_fill_u8(ctx.handle, _ptr(dst), h, w, cn, w * cn, arr, len(layers)))
+        check((lib().vkx_fill_u8_dev if dev else lib().vkx_fill_u8)(ctx.handle, dptr, h, w, cn, w * cn, arr, len(layers)))
+    if dev:
+        dst.invalidate_host()
     return dst

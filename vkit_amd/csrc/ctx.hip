@@ -299,7 +299,8 @@ VKX_EXPORT int vkx_memcpy_async(vkx_ctx *ctx, int stream, void *dst, const void 
     hipStream_t st = vkx_stream_by_id(ctx, stream, &rc);
     if (rc) return rc;
     vkx_device_guard guard(ctx);
-    VKX_HIP(hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, st));
+    VKX_HIP(hipMemcpyAsync(dst, src, bytes,
+                           to_device == 2 ? hipMemcpyDeviceToDevice : (to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost), st));
     return VKX_OK;
 }
 

@@ -10,7 +10,7 @@ from typing import Optional, Tuple, Union
 import attrs
 import numpy as np
 
-from ._writable import WritableContext
+from ._writable import LazyMat, WritableContext
 from .opt import generate_shape_and_resized_shape
 from .type import Shapable
 
@@ -82,33 +82,34 @@ class ImageSetItemConfig:
 
 
 @attrs.define(frozen=True, eq=False)
-class Image(Shapable):
-    mat: np.ndarray
+class Image(LazyMat, Shapable):
+    _mat: np.ndarray = attrs.field(alias='mat')
     mode: ImageMode = ImageMode.NONE
     box: Optional['Box'] = None
 
     def __attrs_post_init__(self):
         if self.mode != ImageMode.NONE:
-            assert self.mode.to_dtype() == self.mat.dtype
-            assert self.mode.to_ndim() == self.mat.ndim
+            assert self.mode.to_dtype() == self._mat.dtype
+            assert self.mode.to_ndim() == self._mat.ndim
         else:
             # infer the mode from the array (uint8 only)
-            if self.mat.dtype == np.float32:
+            if self._mat.dtype == np.float32:
                 raise NotImplementedError('mode is None and mat.dtype == np.float32.')
-            if self.mat.dtype != np.uint8:
-                raise NotImplementedError(f'Invalid mat.dtype={self.mat.dtype}.')
-            if self.mat.ndim == 2:
+            if self._mat.dtype != np.uint8:
+                raise NotImplementedError(f'Invalid mat.dtype={self._mat.dtype}.')
+            if self._mat.ndim == 2:
                 mode = ImageMode.GRAYSCALE
-            elif self.mat.ndim == 3 and self.mat.shape[2] == 4:
+            elif self._mat.ndim == 3 and self._mat.shape[2] == 4:
                 mode = ImageMode.RGBA
-            elif self.mat.ndim == 3 and self.mat.shape[2] == 3:
+            elif self._mat.ndim == 3 and self._mat.shape[2] == 3:
                 mode = ImageMode.RGB
-            elif self.mat.ndim == 3:
-                raise NotImplementedError(f'Invalid num_channels={self.mat.shape[2]}.')
+            elif self._mat.ndim == 3:
+                raise NotImplementedError(f'Invalid num_channels={self._mat.shape[2]}.')
             else:
-                raise NotImplementedError(f'mat.ndim={self.mat.ndim} not supported.')
+                raise NotImplementedError(f'mat.ndim={self._mat.ndim} not supported.')
             object.__setattr__(self, 'mode', mode)
-        self.mat.flags.writeable = False
+        if isinstance(self._mat, np.ndarray):
+            self._mat.flags.writeable = False
         if self.box and self.shape != self.box.shape:
             raise RuntimeError('self.shape != box.shape.')
 
@@ -132,15 +133,15 @@ class Image(Shapable):
     # ---- properties
     @property
     def height(self):
-        return self.mat.shape[0]
+        return self._mat.shape[0]
 
     @property
     def width(self):
-        return self.mat.shape[1]
+        return self._mat.shape[1]
 
     @property
     def num_channels(self):
-        return 0 if self.mat.ndim == 2 else self.mat.shape[2]
+        return 0 if self._mat.ndim == 2 else self._mat.shape[2]
 
     @property
     def writable_context(self):
@@ -152,7 +153,7 @@ class Image(Shapable):
 
     def assign_mat(self, mat: np.ndarray):
         with self.writable_context:
-            object.__setattr__(self, 'mat', mat)
+            object.__setattr__(self, '_mat', mat)
 
     def __setitem__(self, element, config):
         """image[box | polygon | mask | score_map] = value | ImageSetItemConfig (reference image.py:667-712)."""
@@ -185,11 +186,11 @@ class Image(Shapable):
         from vkit_amd import _native
         if cv_resize_interpolation not in range(7):
             raise ValueError(f'unknown cv2 interpolation code {cv_resize_interpolation}')
-        if self.mat.dtype != np.uint8:
+        if self._mat.dtype != np.uint8:
             raise NotImplementedError('float32 image modes are outside the accelerated path')
         _, _, resized_height, resized_width = generate_shape_and_resized_shape(
             shapable_or_shape=self, resized_height=resized_height, resized_width=resized_width)
-        return attrs.evolve(self, mat=_native.resize(self.mat, (resized_height, resized_width), cv_resize_interpolation))
+        return attrs.evolve(self, mat=_native.resize(self.arr, (resized_height, resized_width), cv_resize_interpolation))
 
     def to_conducted_resized_image(self, shapable_or_shape, resized_height: Optional[int] = None,
                                    resized_width: Optional[int] = None, cv_resize_interpolation: int = 2):
@@ -224,9 +225,9 @@ class Image(Shapable):
         if self.mode not in supported or target_mode not in supported:
             raise NotImplementedError(
                 f'image mode conversion {self.mode} -> {target_mode} is outside the accelerated path')
-        mat = self.mat
+        mat = self.arr
         if self.mode == ImageMode.HSL:
-            mat = mat[:, :, [0, 2, 1]]           # HSL -> HLS
+            mat = self.mat[:, :, [0, 2, 1]]      # HSL -> HLS
         shortcut = {(ImageMode.GRAYSCALE, ImageMode.RGBA): _native.CVT_GRAY2RGBA,
                     (ImageMode.RGBA, ImageMode.GRAYSCALE): _native.CVT_RGBA2GRAY}.get((self.mode, target_mode))
         if shortcut is not None:
@@ -241,7 +242,7 @@ class Image(Shapable):
                 ImageMode.HSV: _native.CVT_RGB2HSV_FULL, ImageMode.HSL: _native.CVT_RGB2HLS_FULL}[target_mode]
         mat = _native.cvt_color(mat, code)
         if target_mode == ImageMode.HSL:
-            mat = mat[:, :, [0, 2, 1]]           # HLS -> HSL
+            mat = _native.host_array(mat)[:, :, [0, 2, 1]]           # HLS -> HSL
         return Image(mat=mat, mode=target_mode)
 
     def to_rgb_image(self):

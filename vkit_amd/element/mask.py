@@ -4,24 +4,29 @@ from typing import Iterable, Optional, Tuple, Union
 import attrs
 import numpy as np
 
-from ._writable import WritableContext
+from ._writable import LazyMat, WritableContext
 from .opt import generate_resized_shape
 from .type import ElementSetOperationMode, Shapable
 
 
+_LUT_INVERT = (np.arange(256) == 0).astype(np.uint8).reshape(1, 256)           # (~(mat > 0)).astype(uint8)
+_LUT_X255 = ((np.arange(256) > 0).astype(np.uint8) * 255).reshape(1, 256)      # (mat > 0).astype(uint8) * 255
+
+
 @attrs.define(frozen=True, eq=False)
-class Mask(Shapable):
-    mat: np.ndarray
+class Mask(LazyMat, Shapable):
+    _mat: np.ndarray = attrs.field(alias='mat')
     box: Optional['Box'] = None
 
     _np_mask: Optional[np.ndarray] = attrs.field(default=None, init=False, repr=False)
 
     def __attrs_post_init__(self):
-        if self.mat.dtype != np.uint8:
+        if self._mat.dtype != np.uint8:
             raise RuntimeError('mat.dtype != np.uint8')
-        if self.mat.ndim != 2:
+        if self._mat.ndim != 2:
             raise RuntimeError('ndim should == 2.')
-        self.mat.flags.writeable = False
+        if isinstance(self._mat, np.ndarray):
+            self._mat.flags.writeable = False
         if self.box and self.shape != self.box.shape:
             raise RuntimeError('self.shape != box.shape.')
 
@@ -65,11 +70,11 @@ class Mask(Shapable):
     # ---- properties
     @property
     def height(self):
-        return self.mat.shape[0]
+        return self._mat.shape[0]
 
     @property
     def width(self):
-        return self.mat.shape[1]
+        return self._mat.shape[1]
 
     @property
     def equivalent_box(self):
@@ -94,9 +99,12 @@ class Mask(Shapable):
 
     def assign_mat(self, mat: np.ndarray):
         with self.writable_context:
-            object.__setattr__(self, 'mat', mat)
+            object.__setattr__(self, '_mat', mat)
 
     def to_inverted_mask(self):
+        if self.on_device:
+            from vkit_amd import _native
+            return attrs.evolve(self, mat=_native.apply_lut(self.arr, _LUT_INVERT))
         return attrs.evolve(self, mat=(~self.np_mask).astype(np.uint8))
 
     def to_shifted_mask(self, offset_y: int = 0, offset_x: int = 0):
@@ -112,6 +120,12 @@ class Mask(Shapable):
             raise ValueError(f'unknown cv2 interpolation code {cv_resize_interpolation}')
         resized_height, resized_width = generate_resized_shape(
             height=self.height, width=self.width, resized_height=resized_height, resized_width=resized_width)
+        if self.on_device or _native.resident_mode():
+            # the same three steps as table look-ups around the device resize: (> 0) * 255, resize, > threshold
+            plane = _native.apply_lut(self.arr, _LUT_X255)
+            plane = _native.resize(plane, (resized_height, resized_width), cv_resize_interpolation)
+            above = (np.arange(256) > binarization_threshold).astype(np.uint8).reshape(1, 256)
+            return Mask(mat=_native.apply_lut(plane, above))
         mat = _native.resize(self.np_mask.astype(np.uint8) * 255, (resized_height, resized_width), cv_resize_interpolation)
         return Mask(mat=(mat > binarization_threshold).astype(np.uint8))
 

@@ -8,26 +8,27 @@ from typing import Optional, Tuple
 import attrs
 import numpy as np
 
-from ._writable import WritableContext
+from ._writable import LazyMat, WritableContext
 from .opt import generate_shape_and_resized_shape
 from .type import ElementSetOperationMode, Shapable
 
 
 @attrs.define(frozen=True, eq=False)
-class ScoreMap(Shapable):
-    mat: np.ndarray
+class ScoreMap(LazyMat, Shapable):
+    _mat: np.ndarray = attrs.field(alias='mat')
     box: Optional['Box'] = None
     is_prob: bool = True
 
     def __attrs_post_init__(self):
-        if self.mat.ndim != 2:
+        if self._mat.ndim != 2:
             raise RuntimeError('ndim should == 2.')
         if self.box and self.shape != self.box.shape:
             raise RuntimeError('self.shape != box.shape.')
-        if self.mat.dtype != np.float32:
+        if self._mat.dtype != np.float32:
             raise RuntimeError('mat.dtype != np.float32')
-        self.mat.flags.writeable = False
-        if self.is_prob and self.mat.size:
+        if isinstance(self._mat, np.ndarray):
+            self._mat.flags.writeable = False
+        if self.is_prob and self._mat.size:
             if self.mat.min() < 0.0 or self.mat.max() > 1.0:
                 raise RuntimeError('score not in range [0.0, 1.0]')
 
@@ -44,11 +45,11 @@ class ScoreMap(Shapable):
 
     @property
     def height(self):
-        return self.mat.shape[0]
+        return self._mat.shape[0]
 
     @property
     def width(self):
-        return self.mat.shape[1]
+        return self._mat.shape[1]
 
     @property
     def equivalent_box(self):
@@ -63,7 +64,7 @@ class ScoreMap(Shapable):
 
     def assign_mat(self, mat: np.ndarray):
         with self.writable_context:
-            object.__setattr__(self, 'mat', mat)
+            object.__setattr__(self, '_mat', mat)
 
     def to_shifted_score_map(self, offset_y: int = 0, offset_x: int = 0):
         assert self.box
@@ -78,9 +79,9 @@ class ScoreMap(Shapable):
             raise ValueError(f'unknown cv2 interpolation code {cv_resize_interpolation}')
         _, _, resized_height, resized_width = generate_shape_and_resized_shape(
             shapable_or_shape=self.shape, resized_height=resized_height, resized_width=resized_width)
-        mat = _native.resize(self.mat, (resized_height, resized_width), cv_resize_interpolation)
+        mat = _native.resize(self.arr, (resized_height, resized_width), cv_resize_interpolation)
         if self.is_prob:
-            mat = np.clip(mat, 0.0, 1.0)
+            mat = np.clip(_native.host_array(mat), 0.0, 1.0)
         return attrs.evolve(self, mat=mat)
 
     def to_cropped_score_map(self, up=None, down=None, left=None, right=None):

@@ -230,17 +230,17 @@ def affine_trait_func_mat(config, state, mat: np.ndarray):
 
 def affine_trait_func_image(config, state, image: Image, rng: Optional[RandomGenerator]):
     # the mode is re-inferred from the array, like the reference (affine.py:436)
-    return Image(mat=affine_trait_func_mat(config, state, image.mat))
+    return Image(mat=affine_trait_func_mat(config, state, image.arr))
 
 
 def affine_trait_func_score_map(config, state, score_map: ScoreMap, rng: Optional[RandomGenerator]):
     assert state
-    return ScoreMap(mat=affine_trait_func_mat(config, state, score_map.mat))
+    return ScoreMap(mat=affine_trait_func_mat(config, state, score_map.arr))
 
 
 def affine_trait_func_mask(config, state, mask: Mask, rng: Optional[RandomGenerator]):
     assert state
-    return Mask(mat=affine_trait_func_mat(config, state, mask.mat))
+    return Mask(mat=affine_trait_func_mat(config, state, mask.arr))
 
 
 def affine_trait_func_points(config, state, shape: Tuple[int, int],

@@ -61,18 +61,18 @@ class FuncImageGridBased(Generic[_T_CONFIG, _T_STATE]):
     @classmethod
     def func_image(cls, config, state, image: Image, rng: Optional[RandomGenerator]):
         assert state
-        return Image(mat=blend_src_to_dst(image.mat, state.src_image_grid, state.dst_image_grid), mode=image.mode)
+        return Image(mat=blend_src_to_dst(image.arr, state.src_image_grid, state.dst_image_grid), mode=image.mode)
 
     @classmethod
     def func_score_map(cls, config, state, score_map: ScoreMap, rng: Optional[RandomGenerator]):
         assert state
-        return ScoreMap(mat=blend_src_to_dst(score_map.mat, state.src_image_grid, state.dst_image_grid))
+        return ScoreMap(mat=blend_src_to_dst(score_map.arr, state.src_image_grid, state.dst_image_grid))
 
     @classmethod
     def func_mask(cls, config, state, mask: Mask, rng: Optional[RandomGenerator]):
         # bilinear on the 0/1 bytes, exactly like the reference (grid_blender.py:74-81): no nearest neighbour
         assert state
-        return Mask(mat=blend_src_to_dst(mask.mat, state.src_image_grid, state.dst_image_grid))
+        return Mask(mat=blend_src_to_dst(mask.arr, state.src_image_grid, state.dst_image_grid))
 
     @classmethod
     def func_active_mask(cls, config, state, shape: Tuple[int, int], rng: Optional[RandomGenerator]):
@@ -155,7 +155,7 @@ class DistortionImageGridBased(Distortion[_T_CONFIG, _T_STATE]):
                                  corner_points, polygon, polygons, get_active_mask, get_config, True,
                                  disable_clip_result_elements, rng)
         state = result.state
-        outs = _native.grid_remap([e.mat for e in shared], state.src_image_grid.vertices,
+        outs = _native.grid_remap([e.arr for e in shared], state.src_image_grid.vertices,
                                   state.dst_image_grid.vertices, state.dst_image_grid.image_shape)
         it = iter(outs)
         if image is not None:

@@ -32,7 +32,7 @@ class GaussianBlurConfig(DistortionConfig):
 def gaussian_blur_image(config: GaussianBlurConfig, state, image: Image, rng: Optional[RandomGenerator]):
     mode = image.mode
     image = to_rgb_image(image, mode)
-    mat = _native.gaussian_blur(image.mat, _estimate_gaussian_kernel_size(config.sigma), config.sigma)
+    mat = _native.gaussian_blur(image.arr, _estimate_gaussian_kernel_size(config.sigma), config.sigma)
     return to_original_image(attrs.evolve(image, mat=mat), mode)
 
 
@@ -97,7 +97,7 @@ def _anti_aliasing_ksize_and_padding(anti_aliasing_sigma: float):
 def _filter2d_image(image: Image, kernel: np.ndarray):
     mode = image.mode
     image = to_rgb_image(image, mode)
-    return to_original_image(attrs.evolve(image, mat=_native.filter2d(image.mat, kernel)), mode)
+    return to_original_image(attrs.evolve(image, mat=_native.filter2d(image.arr, kernel)), mode)
 
 
 @attrs.define
@@ -218,7 +218,7 @@ def glass_blur_image(config: GlassBlurConfig, state, image: Image, rng: Optional
     mode = image.mode
     image = to_rgb_image(image, mode)
     assert rng is not None
-    mat = _native.gaussian_blur(image.mat, _estimate_gaussian_kernel_size(config.sigma), config.sigma)
+    mat = _native.gaussian_blur(image.arr, _estimate_gaussian_kernel_size(config.sigma), config.sigma)
     pos_y, pos_x = glass_shuffle_planes(image.shape, config.delta, config.loop, rng)
     mat = _native.gather(mat, pos_y, pos_x)
     return to_original_image(attrs.evolve(image, mat=mat), mode)
@@ -244,7 +244,7 @@ def zoom_in_blur_image(config: ZoomInBlurConfig, state, image: Image, rng: Optio
     # the enlargement factors 1 + step, 1 + 2 step, ... up to 1 + ratio (numpy's float arange, like the reference)
     sizes = [(round(image.height * factor), round(image.width * factor))
              for factor in np.arange(1 + config.step, 1 + config.ratio + config.step, config.step)]
-    mat = _native.zoom_in_blur(image.mat, sizes, config.alpha)
+    mat = _native.zoom_in_blur(image.arr, sizes, config.alpha)
     return to_original_image(attrs.evolve(image, mat=mat), mode)
 
 

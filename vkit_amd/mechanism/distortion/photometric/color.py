@@ -26,7 +26,7 @@ def _mean_shift(image: Image, channels: Optional[Sequence[int]], delta: int, thr
         raise NotImplementedError()
     if threshold is not None:
         assert delta != 0
-    mat = _native.mean_shift(image.mat, delta, threshold=threshold, channels=channels,
+    mat = _native.mean_shift(image.arr, delta, threshold=threshold, channels=channels,
                              cycle=(oob_behavior == OutOfBoundBehavior.CYCLE))
     return attrs.evolve(image, mat=mat)
 
@@ -68,7 +68,7 @@ def color_shift_image(config: ColorShiftConfig, state, image: Image, rng: Option
     if config.delta == 0:
         # the reference still round-trips through HSV (the hue add is skipped, the conversions are not)
         return image.to_hsv_image().to_target_mode_image(mode)
-    return Image(mat=_native.color_shift_rgb(image.mat, config.delta), mode=ImageMode.RGB)
+    return Image(mat=_native.color_shift_rgb(image.arr, config.delta), mode=ImageMode.RGB)
 
 
 color_shift = Distortion(
@@ -89,7 +89,7 @@ def complement_image(config: ComplementConfig, state, image: Image, rng: Optiona
     """255 - v on the selected channels, optionally only where ``threshold <= v`` (or ``v <= threshold``)."""
     if config.threshold is not None:
         assert 0 <= config.threshold <= 255
-    mat = _native.pointwise(image.mat, _native.POINT_COMPLEMENT,
+    mat = _native.pointwise(image.arr, _native.POINT_COMPLEMENT,
                             -1 if config.threshold is None else int(config.threshold),
                             int(config.enable_threshold_lte), channels=config.channels)
     return attrs.evolve(image, mat=mat)
@@ -113,7 +113,7 @@ def posterization_image(config: PosterizationConfig, state, image: Image, rng: O
     assert 0 <= config.num_bits < 8
     if config.num_bits == 0:
         return image
-    mat = _native.pointwise(image.mat, _native.POINT_POSTERIZE, int(config.num_bits), channels=config.channels)
+    mat = _native.pointwise(image.arr, _native.POINT_POSTERIZE, int(config.num_bits), channels=config.channels)
     return attrs.evolve(image, mat=mat)
 
 
@@ -146,7 +146,7 @@ def channel_permutation_image(config: ChannelPermutationConfig, state, image: Im
     """``mat[:, :, rng.permutation(num_channels)]``: the permutation is drawn on the host, the gather runs on the GPU."""
     assert rng
     indices = rng.permutation(image.num_channels)
-    return attrs.evolve(image, mat=_native.permute_channels(image.mat, indices))
+    return attrs.evolve(image, mat=_native.permute_channels(image.arr, indices))
 
 
 channel_permutation = Distortion(
@@ -167,7 +167,7 @@ def brightness_shift_image(config: BrightnessShiftConfig, state, image: Image, r
     intermediate takes one fused kernel (RGB -> HLS_FULL, L += delta, HLS_FULL -> RGB)."""
     mode = image.mode
     if mode == ImageMode.RGB and config.intermediate_image_mode == ImageMode.HSL:
-        return Image(mat=_native.brightness_shift_rgb(image.mat, config.delta), mode=ImageMode.RGB)
+        return Image(mat=_native.brightness_shift_rgb(image.arr, config.delta), mode=ImageMode.RGB)
     if mode not in (ImageMode.HSV, ImageMode.HSL):
         assert config.intermediate_image_mode in (ImageMode.HSV, ImageMode.HSL)
         image = image.to_target_mode_image(config.intermediate_image_mode)
@@ -195,12 +195,12 @@ def color_balance_image(config: ColorBalanceConfig, state, image: Image, rng: Op
         return image
     assert 0.0 <= config.ratio <= 1.0
     if image.mode == ImageMode.RGB:
-        return attrs.evolve(image, mat=_native.color_balance_rgb(image.mat, config.ratio))
+        return attrs.evolve(image, mat=_native.color_balance_rgb(image.arr, config.ratio))
     # any other mode (reference color.py:380-396): the grey version of the image brought back to the image's mode, blended
     # with the image -- on saturation and value / lightness only for HSV / HSL, on every channel (alpha included) for RGBA
     grayscale_like = image.to_grayscale_image().to_target_mode_image(image.mode)
     channels = [1, 2] if image.mode in (ImageMode.HSV, ImageMode.HSL) else None
-    mat = _native.blend_u8(grayscale_like.mat, image.mat, 1 - config.ratio, config.ratio, channels=channels)
+    mat = _native.blend_u8(grayscale_like.arr, image.arr, 1 - config.ratio, config.ratio, channels=channels)
     return attrs.evolve(image, mat=mat)
 
 
@@ -243,7 +243,7 @@ def std_shift_image(config: StdShiftConfig, state, image: Image, rng: Optional[R
     lut = np.tile(np.arange(256, dtype=np.uint8), (max(image.num_channels, 1), 1))
     for k, c in enumerate(selected):
         lut[c] = table[:, k]
-    return attrs.evolve(image, mat=_native.apply_lut(image.mat, lut, channels=selected))
+    return attrs.evolve(image, mat=_native.apply_lut(image.arr, lut, channels=selected))
 
 
 std_shift = Distortion(
@@ -266,7 +266,7 @@ def boundary_equalization_image(config: BoundaryEqualizationConfig, state, image
                                 rng: Optional[RandomGenerator]):
     """Stretch every selected channel to [0, 255]: ``round((v - min) * (255 / (max - min)))`` in float32.  The minimum /
     maximum come from the GPU histogram; the per-value expression is evaluated once per grey level into a table."""
-    hist = _native.histogram(image.mat)
+    hist = _native.histogram(image.arr)
     selected = _selected_channels(image, config.channels)
     lut = np.tile(np.arange(256, dtype=np.uint8), (hist.shape[0], 1))
     levels = np.arange(256, dtype=np.float32)
@@ -285,7 +285,7 @@ def boundary_equalization_image(config: BoundaryEqualizationConfig, state, image
         lut[c] = np.clip(np.round(values), 0, 255).astype(np.uint8)
     if not any_delta:
         return image
-    return attrs.evolve(image, mat=_native.apply_lut(image.mat, lut, channels=selected))
+    return attrs.evolve(image, mat=_native.apply_lut(image.arr, lut, channels=selected))
 
 
 boundary_equalization = Distortion(
@@ -319,12 +319,12 @@ def _equalize_hist_table(hist_c: np.ndarray) -> np.ndarray:
 
 def histogram_equalization_image(config: HistogramEqualizationConfig, state, image: Image,
                                  rng: Optional[RandomGenerator]):
-    hist = _native.histogram(image.mat)
+    hist = _native.histogram(image.arr)
     selected = _selected_channels(image, config.channels)
     lut = np.tile(np.arange(256, dtype=np.uint8), (hist.shape[0], 1))
     for c in selected:
         lut[c] = _equalize_hist_table(hist[c])
-    return attrs.evolve(image, mat=_native.apply_lut(image.mat, lut, channels=selected))
+    return attrs.evolve(image, mat=_native.apply_lut(image.arr, lut, channels=selected))
 
 
 histogram_equalization = Distortion(

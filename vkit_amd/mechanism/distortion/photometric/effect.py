@@ -42,7 +42,7 @@ class PixelationConfig(DistortionConfig):
 def pixelation_image(config: PixelationConfig, state, image: Image, rng: Optional[RandomGenerator]):
     assert 0 < config.ratio < 1
     small_shape = (round(image.height * config.ratio), round(image.width * config.ratio))
-    small = _native.resize(image.mat, small_shape, _native.INTER_LINEAR)
+    small = _native.resize(image.arr, small_shape, _native.INTER_LINEAR)
     return attrs.evolve(image, mat=_native.resize(small, image.shape, _native.INTER_NEAREST))
 
 
@@ -139,7 +139,7 @@ def fog_image(config: FogConfig, state, image: Image, rng: Optional[RandomGenera
     if image.mode == ImageMode.GRAYSCALE:
         # the grey fog value is fractional (reference effect.py:194-197): float32(0.2126 R + 0.7152 G + 0.0722 B)
         val = 0.2126 * config.fog_rgb[0] + 0.7152 * config.fog_rgb[1] + 0.0722 * config.fog_rgb[2]
-        return attrs.evolve(image, mat=_native.fog_f32(image.mat, mask, [np.float32(val)]))
+        return attrs.evolve(image, mat=_native.fog_f32(image.arr, mask, [np.float32(val)]))
     mat = np.array(image.mat)
     layer = _native.make_layer((0, 0, image.height, image.width), 3, tuple(int(v) for v in config.fog_rgb), alpha=mask)
     _native.fill(mat, [layer])

@@ -45,10 +45,10 @@ def gaussion_noise_plane(std: float, shape, rng: RandomGenerator) -> np.ndarray:
 
 def gaussion_noise_image(config: GaussionNoiseConfig, state, image: Image, rng: Optional[RandomGenerator]):
     assert rng
-    mat = _native.np_gaussion_noise(image.mat, config.std, rng)
+    mat = _native.np_gaussion_noise(image.arr, config.std, rng)
     if mat is None:
-        noise = gaussion_noise_plane(config.std, image.mat.shape, rng)
-        mat = _native.add_noise_i16(image.mat, noise)
+        noise = gaussion_noise_plane(config.std, image.arr.shape, rng)
+        mat = _native.add_noise_i16(image.arr, noise)
     # the mode is re-inferred from the array, like the reference
     return Image(mat=mat)
 
@@ -86,10 +86,10 @@ def impulse_noise_image(config: ImpulseNoiseConfig, state, image: Image, rng: Op
     assert rng
     prob_presv = 1 - config.prob_salt - config.prob_pepper
     assert prob_presv >= 0.0
-    mat = _native.np_impulse_noise(image.mat, config.prob_salt, config.prob_pepper, rng)
+    mat = _native.np_impulse_noise(image.arr, config.prob_salt, config.prob_pepper, rng)
     if mat is None:
         selector = rng.choice((0, 1, 2), size=image.shape, p=[prob_presv, config.prob_salt, config.prob_pepper])
-        mat = _native.impulse_noise(image.mat, selector.astype(np.uint8))
+        mat = _native.impulse_noise(image.arr, selector.astype(np.uint8))
     return Image(mat=mat)
 
 
@@ -122,10 +122,10 @@ class SpeckleNoiseConfig(DistortionConfig):
 def speckle_noise_image(config: SpeckleNoiseConfig, state, image: Image, rng: Optional[RandomGenerator]):
     """``clip(px + px * N(0, std))`` with float64 samples, one per channel value in C order."""
     assert rng
-    mat = _native.np_speckle_noise(image.mat, config.std, rng)
+    mat = _native.np_speckle_noise(image.arr, config.std, rng)
     if mat is None:
-        noise = rng.normal(0, config.std, image.mat.shape)
-        mat = _native.speckle_noise(image.mat, noise)
+        noise = rng.normal(0, config.std, image.arr.shape)
+        mat = _native.speckle_noise(image.arr, noise)
     return Image(mat=mat)
 
 

@@ -27,7 +27,7 @@ class LineStreakConfig(DistortionConfig):
 
 
 def _check_color(image: Image, color):
-    if image.mat.ndim != 3 or len(color) != image.mat.shape[2]:
+    if image.arr.ndim != 3 or len(color) != image.arr.shape[2]:
         raise RuntimeError('value is tuple but len(value) != num_channels.')
 
 
@@ -37,7 +37,7 @@ def line_streak_image(config: LineStreakConfig, state, image: Image, rng: Option
         raise AttributeError('alpha must be a float')
     if config.alpha < 0.0 or config.alpha > 1.0:
         raise RuntimeError(f'alpha={config.alpha} is invalid.')
-    mat = _native.line_streak(image.mat, config.thickness, config.gap, config.dash_thickness, config.dash_gap,
+    mat = _native.line_streak(image.arr, config.thickness, config.gap, config.dash_thickness, config.dash_gap,
                               config.color, config.alpha, config.enable_vert, config.enable_hori)
     return attrs.evolve(image, mat=mat)
 
@@ -160,7 +160,7 @@ def ellipse_streak_image(config: EllipseStreakConfig, state, image: Image, rng: 
     boxes = generate_centered_boxes(image.height, image.width, aspect_ratio, config.short_side_min,
                                     config.short_side_step)
     axes = [(box.width // 2, box.height // 2) for box in boxes]
-    mat = _native.ellipse_streak(image.mat, (image.width // 2, image.height // 2), axes, config.thickness,
+    mat = _native.ellipse_streak(image.arr, (image.width // 2, image.height // 2), axes, config.thickness,
                                  config.color, config.alpha)
     return attrs.evolve(image, mat=mat)
 

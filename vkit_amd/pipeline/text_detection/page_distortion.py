@@ -111,8 +111,13 @@ def paint_polygons(shape: Tuple[int, int], polygons: Sequence[Polygon], values: 
     """Sequential ``polygon.fill_mask(mask)`` / ``polygon.fill_score_map(score_map, value)`` over ``polygons`` on
     fresh planes, as one ordered device paint.  Returns (Mask | None, ScoreMap | None)."""
     height, width = shape
-    np_mask = np.zeros((height, width), np.uint8) if want_mask else None
-    np_score = np.zeros((height, width), np.float32) if values is not None else None
+    if _native.resident_mode():
+        # the planes are painted where the page lives and stay there until somebody reads ``.mat``
+        np_mask = _native.dev_zeros((height, width), np.uint8) if want_mask else None
+        np_score = _native.dev_zeros((height, width), np.float32) if values is not None else None
+    else:
+        np_mask = np.zeros((height, width), np.uint8) if want_mask else None
+        np_score = np.zeros((height, width), np.float32) if values is not None else None
     if len(polygons):
         # a polygon's raster is defined on its bounding box with the integer vertices made box-relative (reference
         # element/polygon.py:105-138,70-77): shifting them back by the integer box origin gives the integer vertices
@@ -150,6 +155,14 @@ class PageDistortionStep(PipelineStep[PageDistortionStepConfig, PageDistortionSt
         if page_bottom_layer_image.shape != page_image.shape:
             page_bottom_layer_image = page_bottom_layer_image.to_resized_image(
                 resized_height=page_image.height, resized_width=page_image.width)
+        if page_image.on_device and page_image.arr.ndim == 3:
+            # the same fill where the page lives: inverted mask (a table look-up) selects, the bottom layer is the value
+            ctx = page_image.arr.ctx
+            inverted = ctx.to_device(page_active_mask.to_inverted_mask().arr)
+            layer = _native.make_layer((0, 0, page_image.height, page_image.width), page_image.arr.shape[2],
+                                       ctx.to_device(page_bottom_layer_image.arr), mask=inverted)
+            _native.fill(page_image.arr, [layer])
+            return
         page_active_mask.to_inverted_mask().fill_image(page_image, page_bottom_layer_image)
 
     def generate_text_line_labelings(self, distorted_image: Image, text_line_polygons: Sequence[Polygon],
@@ -229,6 +242,16 @@ class PageDistortionStep(PipelineStep[PageDistortionStepConfig, PageDistortionSt
             page_active_mask.mat[:, 0] = 0
             page_active_mask.mat[:, -1] = 0
 
+        # everything from here to the end of the step stays on the device (element ``.mat`` downloads on first touch):
+        # the operators of the chain hand DevArrays to each other, the inactive-region fill and the label paint run where
+        # the page is, and a PageResizingStep behind this one reads the planes from HBM
+        with _native.resident():
+            return self._run_resident(page, rng, page_active_mask, polygon_flattener, point_flattener,
+                                      page_random_distortion_debug, page_char_polygon_collection,
+                                      page_text_line_polygon_collection)
+
+    def _run_resident(self, page, rng, page_active_mask, polygon_flattener, point_flattener, page_random_distortion_debug,
+                      page_char_polygon_collection, page_text_line_polygon_collection):
         result = self.random_distortion.distort(
             image=page.image,
             mask=page_active_mask,
