@@ -13,6 +13,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import attrs
 import numpy as np
 from numpy.random import default_rng
 
@@ -75,10 +76,29 @@ dist_out = distortion.run(dist_in, default_rng(0))
 dt, k = timed(lambda s: distortion.run(dist_in, default_rng(s)), 48, 'page_distortion')
 out['page_distortion'] = {'ms': round(dt * 1e3, 3), 'kernel_ms_per_run': k, 'gpu_ms': round(sum(k.values()), 3),
                           'profile_top': top(lambda s: distortion.run(dist_in, default_rng(s)), 6)}
+
+
+def touch(step_output):
+    """Reads every pixel element of a step output on the host (``.mat`` downloads a device-resident element)."""
+    for field in attrs.fields(type(step_output)):
+        value = getattr(step_output, field.name)
+        if hasattr(value, 'mat'):
+            value.mat
+    return step_output
+
+
+dt, k = timed(lambda s: touch(distortion.run(dist_in, default_rng(s))), 48, 'page_distortion_outputs_on_host')
+out['page_distortion_outputs_on_host'] = {'ms': round(dt * 1e3, 3), 'note': 'the same runs with every output element read on the host afterwards'}
 res_in = T.PageResizingStepInput(page_distortion_step_output=dist_out)
 try:
     dt, k = timed(lambda s: resizing.run(res_in, default_rng(s)), 10, 'page_resizing')
     out['page_resizing'] = {'ms': round(dt * 1e3, 3), 'kernel_ms_per_run': k, 'gpu_ms': round(sum(k.values()), 3)}
+    dt, k = timed(lambda s: touch(resizing.run(res_in, default_rng(s))), 10, 'page_resizing_outputs_on_host')
+    out['page_resizing_outputs_on_host'] = {'ms': round(dt * 1e3, 3)}
+    chain_in = lambda s: T.PageResizingStepInput(page_distortion_step_output=distortion.run(dist_in, default_rng(s)))
+    dt, k = timed(lambda s: touch(resizing.run(chain_in(s), default_rng(s))), 48, 'distortion_then_resizing_outputs_on_host')
+    out['distortion_then_resizing_outputs_on_host'] = {'ms': round(dt * 1e3, 3), 'gpu_ms': round(sum(k.values()), 3),
+                                                       'note': 'PageDistortionStep.run -> PageResizingStep.run, resized outputs read on the host: the full-size label planes never cross the link'}
 except Exception as exc:      # the step refuses pages without text lines of a minimum height
     out['page_resizing'] = {'error': repr(exc)}
 for name, stats in PER_RUN.items():
