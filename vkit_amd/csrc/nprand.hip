@@ -715,17 +715,27 @@ struct Placer<EmitI16> {
     __device__ static Draws load(const int16_t *rec) { return load_tile_i16(rec); }
     __device__ static void place(const NpJob &job, const Draws &d, const int16_t *, uint64_t m, long long prefix, int16_t *st, uint32_t &)
 {
-    const int lane = __lane_id();
     const uint32_t shift = (uint32_t)prefix & 1u;
     uint32_t total = stage_tile_i16(d, m, shift, st);
     if (prefix + total > job.n) total = (uint32_t)(job.n - prefix);
+    finish(job, total, shift, prefix, st);
+}
+    // slots [shift, shift + total) of `st` hold the tile's samples: whole dwords to dst[prefix ...]
+    __device__ static void finish(const NpJob &job, uint32_t total, uint32_t shift, long long prefix, int16_t *st)
+{
+    const uint32_t lane = (uint32_t)__lane_id();
     int16_t VKX_GLOBAL *dst = (int16_t VKX_GLOBAL *)job.dst + (prefix - shift);
     const uint32_t end = shift + total;                // slots [shift, end) are valid
-    for (uint32_t k = lane; 2 * k < end; k += 64) {
-        const uint32_t v = ((const uint32_t *)st)[k];
-        if (2 * k >= shift && 2 * k + 1 < end) ((uint32_t VKX_GLOBAL *)dst)[k] = v;
-        else if (2 * k >= shift) dst[2 * k] = (int16_t)v;
-        else if (2 * k + 1 < end) dst[2 * k + 1] = (int16_t)(v >> 16);
+    const uint32_t full_hi = end >> 1;                 // dwords [shift, full_hi) are whole
+    uint32_t VKX_GLOBAL *dst32 = (uint32_t VKX_GLOBAL *)dst + lane;
+    const uint32_t *st32 = (const uint32_t *)st + lane;
+    if (lane >= shift && lane < full_hi) dst32[0] = st32[0];
+#pragma unroll
+    for (uint32_t i = 1; i < kTile / 128; i++)
+        if (lane + 64 * i < full_hi) dst32[64 * i] = st32[64 * i];
+    if (lane == 0) {
+        if (shift && end > 1) dst[1] = st[1];
+        if ((end & 1) && end - 1 >= shift) dst[end - 1] = st[end - 1];
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -737,31 +747,44 @@ struct Placer<EmitAddU8> {
     __device__ static Draws load(const int16_t *rec) { return load_tile_i16(rec); }
     __device__ static void place(const NpJob &job, const Draws &d, const int16_t *, uint64_t m, long long prefix, int16_t *st, uint32_t &)
 {
-    const int lane = __lane_id();
     const uint32_t shift = (uint32_t)prefix & 3u;
     uint32_t total = stage_tile_i16(d, m, shift, st);
     if (prefix + total > job.n) total = (uint32_t)(job.n - prefix);
+    finish(job, total, shift, prefix, st);
+}
+    __device__ static void finish(const NpJob &job, uint32_t total, uint32_t shift, long long prefix, int16_t *st)
+{
+    typedef short pk16 __attribute__((ext_vector_type(2)));
+    const uint32_t lane = (uint32_t)__lane_id();
     const uint8_t VKX_GLOBAL *src = (const uint8_t VKX_GLOBAL *)job.src + (prefix - shift);
     uint8_t VKX_GLOBAL *dst = (uint8_t VKX_GLOBAL *)job.dst + (prefix - shift);
     const uint32_t end = shift + total;
-    for (uint32_t k = lane; 4 * k < end; k += 64) {
-        const uint2 nz = ((const uint2 *)st)[k];
-        const bool whole = 4 * k >= shift && 4 * k + 3 < end;
-        uint32_t px = 0;
-        if (whole) px = ((const uint32_t VKX_GLOBAL *)src)[k];
-        else
-            for (int t = 0; t < 4; t++)
-                if (4 * k + t >= shift && 4 * k + t < end) px |= (uint32_t)src[4 * k + t] << (8 * t);
-        const int n0 = (int16_t)nz.x, n1 = (int16_t)(nz.x >> 16), n2 = (int16_t)nz.y, n3 = (int16_t)(nz.y >> 16);
-        const uint32_t o0 = (uint32_t)vkd::clamp_u8((int16_t)((int)(px & 0xff) + n0));
-        const uint32_t o1 = (uint32_t)vkd::clamp_u8((int16_t)((int)((px >> 8) & 0xff) + n1));
-        const uint32_t o2 = (uint32_t)vkd::clamp_u8((int16_t)((int)((px >> 16) & 0xff) + n2));
-        const uint32_t o3 = (uint32_t)vkd::clamp_u8((int16_t)((int)(px >> 24) + n3));
-        const uint32_t out = o0 | (o1 << 8) | (o2 << 16) | (o3 << 24);
-        if (whole) ((uint32_t VKX_GLOBAL *)dst)[k] = out;
-        else
-            for (int t = 0; t < 4; t++)
-                if (4 * k + t >= shift && 4 * k + t < end) dst[4 * k + t] = (uint8_t)(out >> (8 * t));
+    const uint32_t full_lo = (shift + 3) >> 2, full_hi = end >> 2;      // dwords [full_lo, full_hi) are whole
+    const uint32_t VKX_GLOBAL *src32 = (const uint32_t VKX_GLOBAL *)src + lane;
+    uint32_t VKX_GLOBAL *dst32 = (uint32_t VKX_GLOBAL *)dst + lane;
+    const uint2 *st64 = (const uint2 *)st + lane;
+    auto whole = [&](uint32_t i) {
+        const uint32_t px = src32[64 * i];
+        const uint2 nz = st64[64 * i];
+        // bytes 0 1 | 2 3 of the pixel dword as int16 pairs, + noise, clamp, repack
+        pk16 lo = __builtin_bit_cast(pk16, __builtin_amdgcn_perm(0u, px, 0x0c010c00u));
+        pk16 hi = __builtin_bit_cast(pk16, __builtin_amdgcn_perm(0u, px, 0x0c030c02u));
+        lo += __builtin_bit_cast(pk16, nz.x);
+        hi += __builtin_bit_cast(pk16, nz.y);
+        const pk16 zero = {0, 0}, top = {255, 255};
+        lo = __builtin_elementwise_min(__builtin_elementwise_max(lo, zero), top);
+        hi = __builtin_elementwise_min(__builtin_elementwise_max(hi, zero), top);
+        dst32[64 * i] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x06040200u);
+    };
+    if (lane >= full_lo && lane < full_hi) whole(0);
+#pragma unroll
+    for (uint32_t i = 1; i < kTile / 256; i++)
+        if (lane + 64 * i < full_hi) whole(i);
+    // the bytes of the partial dwords at both ends
+    if (lane < 8) {
+        const uint32_t e = lane < 4 ? lane : 4 * full_hi + (lane - 4);
+        const bool mine = lane < 4 ? (shift > 0 && e >= shift && e < end) : (e < end && !(full_hi == 0 && shift > 0));
+        if (mine) dst[e] = (uint8_t)vkd::clamp_u8((int16_t)((int)src[e] + (int)st[e]));
     }
     __builtin_amdgcn_wave_barrier();
 }
