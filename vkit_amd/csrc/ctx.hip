@@ -224,6 +224,39 @@ int vkx_desc_ring_take(vkx_ctx *ctx, size_t bytes, void **hptr)
     return VKX_OK;
 }
 
+namespace {
+__global__ void k_small_copy(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, unsigned n_words)
+{
+    for (unsigned i = threadIdx.x; i < n_words; i += blockDim.x) dst[i] = src[i];
+}
+}  // namespace
+
+int vkx_small_to_device(vkx_ctx *ctx, void *dev, const void *ring_host, size_t bytes)
+{
+    void *mapped = nullptr;
+    if (bytes % 4 != 0 || bytes > ((size_t)1 << 20) || hipHostGetDevicePointer(&mapped, const_cast<void *>(ring_host), 0) != hipSuccess) {
+        (void)hipGetLastError();
+        VKX_HIP(hipMemcpyAsync(dev, ring_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return VKX_OK;
+    }
+    k_small_copy<<<1, 256, 0, ctx->stream>>>((uint32_t *)dev, (const uint32_t *)mapped, (unsigned)(bytes / 4));
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
+int vkx_small_to_host(vkx_ctx *ctx, void *host, const void *dev, size_t bytes)
+{
+    void *mapped = nullptr;
+    if (bytes % 4 != 0 || bytes > ((size_t)1 << 20) || hipHostGetDevicePointer(&mapped, host, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        VKX_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        return VKX_OK;
+    }
+    k_small_copy<<<1, 256, 0, ctx->stream>>>((uint32_t *)mapped, (const uint32_t *)dev, (unsigned)(bytes / 4));
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
 hipStream_t vkx_stream_by_id(vkx_ctx *ctx, int id, int *rc)
 {
     *rc = VKX_OK;

@@ -1081,6 +1081,20 @@ __global__ void __launch_bounds__(NTHREADS, 4) k_tile_remap(const ItemDev *__res
     chain_tile<3>(it, tx, ty, cells, bin, nullptr, 0);
 }
 
+// One dispatch instead of a descriptor copy and three memsets (every dispatch on a pipeline lane's stream costs the
+// pipeline tens of microseconds while other lanes' plane transfers are in flight): the descriptors are read from the
+// page-locked ring through its device mapping, the tile bins start at (min 0x7f7f7f7f, max + 1 = 0), the deferred list
+// is empty.
+__global__ void __launch_bounds__(256) k_chain_prologue(uint32_t *__restrict__ desc_dst, const uint32_t *__restrict__ desc_src,
+                                                        unsigned n_words, TileBin *__restrict__ bins, unsigned nbins,
+                                                        int *__restrict__ deferred)
+{
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_words) desc_dst[i] = desc_src[i];
+    if (i < nbins) bins[i] = TileBin{0x7f7f7f7f, 0x7f7f7f7f, 0, 0};
+    if (i == 0) *deferred = 0;
+}
+
 } // namespace
 
 // Shared host tail of the two tile kernels: scratch, descriptor upload, cell setup, launch.
@@ -1108,17 +1122,19 @@ static int launch_tiles(vkx_ctx *ctx, std::vector<ItemDev> &dev, std::vector<int
     if ((rc = vkx_desc_ring_take(ctx, prefix_off + prefix_bytes, &ring))) return rc;
     memcpy((unsigned char *)ring + items_off, dev.data(), items_bytes);
     memcpy((unsigned char *)ring + prefix_off, prefix.data(), prefix_bytes);
-    VKX_HIP(hipMemcpyAsync(misc, ring, prefix_off + prefix_bytes, hipMemcpyHostToDevice, ctx->stream));
     const ItemDev *d_items = (const ItemDev *)(misc + items_off);
     const int *d_cell_prefix = (const int *)(misc + prefix_off);
     TileBin *bins = (TileBin *)ctx->owner.ptr;
     vkc::CellC *cells = (vkc::CellC *)ctx->cells.ptr;
-
-    // bins: mins start at 0x7f7f7f7f, maxs at 0 -> one strided 2D memset per half
-    VKX_HIP(hipMemset2DAsync(bins, sizeof(TileBin), 0x7f, 8, nbins, ctx->stream));
-    VKX_HIP(hipMemset2DAsync((unsigned char *)bins + 8, sizeof(TileBin), 0x00, 8, nbins, ctx->stream));
     int *deferred = (int *)((unsigned char *)ctx->cells.ptr + cells_bytes);
-    VKX_HIP(hipMemsetAsync(deferred, 0, sizeof(int), ctx->stream));
+    {
+        void *ring_dev = nullptr;
+        VKX_HIP(hipHostGetDevicePointer(&ring_dev, ring, 0));
+        const size_t n_words = (prefix_off + prefix_bytes + 3) / 4;
+        k_chain_prologue<<<vkx_blocks(std::max(n_words, nbins), 256), 256, 0, ctx->stream>>>((uint32_t *)misc, (const uint32_t *)ring_dev,
+                                                                                            (unsigned)n_words, bins, (unsigned)nbins, deferred);
+        VKX_LAUNCH_CHECK();
+    }
     { VKX_TIMED(ctx, "k_chain_setup"); k_chain_setup<<<vkx_blocks((size_t)ncells, 256), 256, 0, ctx->stream>>>(d_items, d_cell_prefix, n_items, (int)ncells, slots, cells, bins, deferred); }
     VKX_LAUNCH_CHECK();
     { VKX_TIMED(ctx, "k_chain_setup_svd"); k_chain_setup_svd<<<16, 64, 0, ctx->stream>>>(d_items, d_cell_prefix, n_items, cells, deferred); }

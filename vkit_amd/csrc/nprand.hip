@@ -492,9 +492,30 @@ __device__ __forceinline__ int job_of_tile(const NpJob *jobs, int n_jobs, long l
     return lo;
 }
 
-__global__ void __launch_bounds__(256) k_np_tile_states(const NpJob *__restrict__ jobs, int n_jobs, long long total_tiles,
-                                                        uint64_t *__restrict__ states /* [total_tiles][2] */, const NpTabs *__restrict__ tabs)
+// Small calls (one page of a host pipeline) carry their jobs in the kernel arguments: on a stream that shares the device
+// with the multi-megabyte transfers of other pipeline lanes every extra dispatch (a descriptor copy, a memset) costs the
+// pipeline tens of microseconds (tools/probes/pipe_np_trace.py).  The first workgroup leaves them in device memory for
+// the kernels that follow, zeroes the results and the completion counter.
+constexpr int kInlineJobs = 8;
+struct NpJobPack { NpJob jobs[kInlineJobs]; };
+
+template <bool INLINE>
+__global__ void __launch_bounds__(256) k_np_tile_states(const NpJob *__restrict__ jobs_dev, NpJobPack pack, int n_jobs, long long total_tiles,
+                                                        uint64_t *__restrict__ states /* [total_tiles][2] */, NpJob *__restrict__ jobs_out,
+                                                        vkx_np_result *__restrict__ results, unsigned *__restrict__ done,
+                                                        const NpTabs *__restrict__ tabs)
 {
+    const NpJob *jobs = INLINE ? pack.jobs : jobs_dev;
+    if (blockIdx.x == 0) {
+        if (INLINE) {
+            const uint32_t *src = (const uint32_t *)pack.jobs;
+            uint32_t *dst = (uint32_t *)jobs_out;
+            for (unsigned i = threadIdx.x; i < (unsigned)n_jobs * (sizeof(NpJob) / 4); i += 256) dst[i] = src[i];
+        }
+        uint32_t *r = (uint32_t *)results;
+        for (unsigned i = threadIdx.x; i < (unsigned)n_jobs * (sizeof(vkx_np_result) / 4); i += 256) r[i] = 0;
+        if (threadIdx.x == 0) *done = 0;
+    }
     const JumpTabs &g_jump = tabs->jump;
     const long long tile = (long long)blockIdx.x * 256 + threadIdx.x;
     if (tile >= total_tiles) return;
@@ -506,6 +527,24 @@ __global__ void __launch_bounds__(256) k_np_tile_states(const NpJob *__restrict_
         if (d & 1) s = mk128(&g_jump.pow2[i][0]) * s + mk128(&g_jump.pow2[i][2]) * inc;
     states[2 * tile] = (uint64_t)s;
     states[2 * tile + 1] = (uint64_t)(s >> 64);
+}
+
+// The last workgroup of a call's final kernel hands the results to the host through the mapping of its page-locked
+// buffer (results_host == nullptr: the caller's buffer is pageable, the host queues a copy instead).
+__device__ __forceinline__ void np_results_out(unsigned *done, const vkx_np_result *results, vkx_np_result *results_host, int n_jobs)
+{
+    if (!results_host) return;
+    __shared__ bool s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(done, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const uint32_t *src = (const uint32_t *)results;
+    uint32_t *dst = (uint32_t *)results_host;
+    for (unsigned i = threadIdx.x; i < (unsigned)n_jobs * (sizeof(vkx_np_result) / 4); i += blockDim.x)
+        dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <class Emit>
@@ -833,6 +872,7 @@ template <class Emit>
 __global__ void __launch_bounds__(256) k_np_place_walk(const NpJob *__restrict__ jobs, int n_jobs, long long total_tiles,
                                                        const uint64_t *__restrict__ states, const TileInfo *__restrict__ info,
                                                        const TilePlan *__restrict__ plan, vkx_np_result *__restrict__ results,
+                                                       unsigned *__restrict__ done, vkx_np_result *__restrict__ results_host,
                                                        const NpTabs *__restrict__ tabs)
 {
     __shared__ uint4 zig[256];
@@ -868,12 +908,14 @@ __global__ void __launch_bounds__(256) k_np_place_walk(const NpJob *__restrict__
             if (flags) atomicOr(&results[j].flags, flags);
         }
     }
+    np_results_out(done, results, results_host, n_jobs);
 }
 
 // ---- uniform doubles: one draw per element (Generator.random / Generator.choice with p) -----------------------------
 // impulse_noise: selector = #{k : cdf[k] <= u} per PIXEL (0 keep, 1 salt, 2 pepper), applied to all cn channels.
 __global__ void __launch_bounds__(256) k_np_choice_impulse(const NpJob *__restrict__ jobs, int n_jobs, long long total_tiles,
                                                            const uint64_t *__restrict__ states, vkx_np_result *__restrict__ results,
+                                                           unsigned *__restrict__ done, vkx_np_result *__restrict__ results_host,
                                                            const NpTabs *__restrict__ tabs)
 {
     const JumpTabs &g_jump = tabs->jump;
@@ -908,6 +950,7 @@ __global__ void __launch_bounds__(256) k_np_choice_impulse(const NpJob *__restri
             s = a64 * s + c64;
         }
     }
+    np_results_out(done, results, results_host, n_jobs);
 }
 
 } // namespace
@@ -993,14 +1036,20 @@ VKX_EXPORT int vkx_np_draw_batch_dev(vkx_ctx *ctx, const vkx_np_job *jobs, int n
     const size_t o_rmask = take(uniform ? 0 : (size_t)total_tiles * kRounds * 8);
     const size_t o_rval = take(uniform ? 0 : (size_t)total_tiles * kTile * val_bytes);
     const size_t o_jobs = take((size_t)n_jobs * sizeof(NpJob));
-    const size_t o_results = take((size_t)n_jobs * sizeof(vkx_np_result));
+    const size_t o_results = take((size_t)n_jobs * sizeof(vkx_np_result) + sizeof(unsigned));    // + the completion counter
     rc = vkx_scratch_reserve(ctx, &ctx->np_work, off);
     if (rc) return rc;
     unsigned char *base = (unsigned char *)ctx->np_work.ptr;
 
-    void *ring = nullptr;
-    if ((rc = vkx_desc_ring_take(ctx, (size_t)n_jobs * sizeof(NpJob), &ring))) return rc;
-    NpJob *hj = (NpJob *)ring;
+    // the device forms of the jobs: in the kernel arguments of the first kernel (small calls) or through the ctx ring
+    NpJobPack pack;
+    const bool inline_jobs = n_jobs <= kInlineJobs;
+    NpJob *hj = pack.jobs;
+    if (!inline_jobs) {
+        void *ring = nullptr;
+        if ((rc = vkx_desc_ring_take(ctx, (size_t)n_jobs * sizeof(NpJob), &ring))) return rc;
+        hj = (NpJob *)ring;
+    }
     const u128 g64 = ((u128)g_jump_host.g64[1] << 64) | g_jump_host.g64[0];
     const u128 g128 = ((u128)g_jump_host.g128[1] << 64) | g_jump_host.g128[0];
     long long tile_base = 0;
@@ -1025,22 +1074,31 @@ VKX_EXPORT int vkx_np_draw_batch_dev(vkx_ctx *ctx, const vkx_np_job *jobs, int n
         d.dst = j.dst;
     }
     vkx_device_guard guard(ctx);
-    VKX_HIP(hipMemcpyAsync(base + o_jobs, hj, (size_t)n_jobs * sizeof(NpJob), hipMemcpyHostToDevice, ctx->stream));
-    VKX_HIP(hipMemsetAsync(base + o_results, 0, (size_t)n_jobs * sizeof(vkx_np_result), ctx->stream));
+    if (!inline_jobs && (rc = vkx_small_to_device(ctx, base + o_jobs, hj, (size_t)n_jobs * sizeof(NpJob)))) return rc;
     const NpJob *dj = (const NpJob *)(base + o_jobs);
     uint64_t *states = (uint64_t *)(base + o_states);
     TileInfo *info = (TileInfo *)(base + o_info);
     TilePlan *plan = (TilePlan *)(base + o_plan);
     vkx_np_result *res = (vkx_np_result *)(base + o_results);
+    unsigned *done = (unsigned *)(res + n_jobs);
+    // page-locked results: the call's last kernel writes them through the mapping
+    vkx_np_result *res_mapped = nullptr;
+    if (hipHostGetDevicePointer((void **)&res_mapped, results_host, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        res_mapped = nullptr;
+    }
     const unsigned wg = (unsigned)std::min<long long>((total_tiles + 3) / 4, 256 * 8);
     {
         VKX_TIMED(ctx, "k_np_tile_states");
-        k_np_tile_states<<<vkx_blocks((size_t)total_tiles, 256), 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, tabs);
+        if (inline_jobs)
+            k_np_tile_states<true><<<vkx_blocks((size_t)total_tiles, 256), 256, 0, ctx->stream>>>(dj, pack, n_jobs, total_tiles, states, (NpJob *)(base + o_jobs), res, done, tabs);
+        else
+            k_np_tile_states<false><<<vkx_blocks((size_t)total_tiles, 256), 256, 0, ctx->stream>>>(dj, pack, n_jobs, total_tiles, states, (NpJob *)(base + o_jobs), res, done, tabs);
         VKX_LAUNCH_CHECK();
     }
     if (uniform) {
         VKX_TIMED(ctx, "k_np_choice_impulse");
-        k_np_choice_impulse<<<wg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, res, tabs);
+        k_np_choice_impulse<<<wg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, res, done, res_mapped, tabs);
         VKX_LAUNCH_CHECK();
     } else {
         uint64_t *rmask = (uint64_t *)(base + o_rmask);
@@ -1076,15 +1134,15 @@ VKX_EXPORT int vkx_np_draw_batch_dev(vkx_ctx *ctx, const vkx_np_job *jobs, int n
             VKX_TIMED(ctx, "k_np_place_walk");
             const unsigned wg2 = (unsigned)std::min<long long>((total_tiles + 255) / 256, 256 * 4);
             if (kind == VKX_NP_SPECKLE_U8)
-                k_np_place_walk<EmitSpeckle><<<wg2, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, tabs);
+                k_np_place_walk<EmitSpeckle><<<wg2, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, done, res_mapped, tabs);
             else if (kind == VKX_NP_NORMAL_ADD_U8)
-                k_np_place_walk<EmitAddU8><<<wg2, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, tabs);
+                k_np_place_walk<EmitAddU8><<<wg2, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, done, res_mapped, tabs);
             else
-                k_np_place_walk<EmitI16><<<wg2, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, tabs);
+                k_np_place_walk<EmitI16><<<wg2, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, done, res_mapped, tabs);
             VKX_LAUNCH_CHECK();
         }
     }
-    VKX_HIP(hipMemcpyAsync(results_host, res, (size_t)n_jobs * sizeof(vkx_np_result), hipMemcpyDeviceToHost, ctx->stream));
+    if (!res_mapped) VKX_HIP(hipMemcpyAsync(results_host, res, (size_t)n_jobs * sizeof(vkx_np_result), hipMemcpyDeviceToHost, ctx->stream));
     return VKX_OK;
 }
 

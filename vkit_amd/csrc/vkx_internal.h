@@ -120,6 +120,13 @@ int vkx_scratch_reserve(vkx_ctx *ctx, vkx_scratch *s, size_t bytes);
 // `bytes` of page-locked host memory that stays untouched until everything queued on ctx->stream so far has run
 // (ring allocation; wraps around with one stream synchronisation)
 int vkx_desc_ring_take(vkx_ctx *ctx, size_t bytes, void **hptr);
+// Small records between page-locked host memory and the device ON the compute stream, by a one-workgroup kernel that
+// reads / writes the host memory through its device mapping: a hipMemcpyAsync of a few hundred bytes queues on the copy
+// engines behind the multi-megabyte plane transfers of the other lanes of a host pipeline and stalls the kernels after
+// it for the length of those transfers.  `bytes` a multiple of 4.  to_host falls back to hipMemcpyAsync when `host` is
+// not mapped page-locked memory.
+int vkx_small_to_device(vkx_ctx *ctx, void *dev, const void *ring_host, size_t bytes);
+int vkx_small_to_host(vkx_ctx *ctx, void *host, const void *dev, size_t bytes);
 hipStream_t vkx_stream_by_id(vkx_ctx *ctx, int id, int *rc);
 
 // Plane copies between host and device staging: hipMemcpy2DAsync is an order of magnitude slower than a linear copy on
