@@ -327,6 +327,10 @@ int vkx_fill_u8_dev(vkx_ctx *ctx, uint8_t *dst, int h, int w, int cn, ptrdiff_t 
                     const vkx_layer *layers, int n_layers);
 int vkx_fill_u8(vkx_ctx *ctx, uint8_t *dst, int h, int w, int cn, ptrdiff_t dst_stride,
                 const vkx_layer *layers, int n_layers);
+/* device page, HOST layer planes (page_assembler.py:155-236 onto a device-resident page): the planes are staged for the
+ * call, the page stays where it is; asynchronous */
+int vkx_fill_u8_dev_host_layers(vkx_ctx *ctx, uint8_t *dst_dev, int h, int w, int cn, ptrdiff_t dst_stride,
+                                const vkx_layer *layers_host_planes, int n_layers);
 /* The layer lists of n_pages equally shaped device destinations in ONE launch (a batch of pages assembled together,
  * PageAssemblerStep.run per page of the batch): page p takes layers[layer_begin[p] .. layer_begin[p + 1]) in order, with the
  * pixels vkx_fill_u8_dev(dsts[p], ...) would produce.  dsts_host: HOST array of n_pages device pointers; layer_begin_host:
@@ -526,6 +530,14 @@ int vkx_np_draw(vkx_ctx *ctx, const vkx_np_job *job, vkx_np_result *result_host)
  * dst: int16 [h, w, cn], cn in 1..4; _dev: device plane, asynchronous; host variant: host plane, synchronous. */
 int vkx_noise_normal_table(double std, int16_t *table_host /* [65536] */);
 int vkx_noise_normal_i16_dev(vkx_ctx *ctx, int16_t *dst, ptrdiff_t stride_el, int h, int w, int cn, double std, uint64_t seed);
+/* the planes of a batch that share `std` in one launch (each with its own seed): the table is staged once per workgroup */
+typedef struct vkx_noise_plane {
+    int16_t *dst;          /* device */
+    ptrdiff_t stride_el;
+    int h, w, cn, reserved;
+    uint64_t seed;
+} vkx_noise_plane;
+int vkx_noise_normal_i16_batch_dev(vkx_ctx *ctx, const vkx_noise_plane *planes_host, int n_planes, double std);
 int vkx_noise_normal_i16(vkx_ctx *ctx, int16_t *dst, ptrdiff_t stride_el, int h, int w, int cn, double std, uint64_t seed);
 
 /* ---- batched geometric + photometric chain (device resident) ---------------------------

@@ -71,6 +71,8 @@ page_out = assembler.run(step_input, default_rng(0))
 dt, k = timed(lambda s: assembler.run(step_input, default_rng(s)), 10, 'page_assembler')
 out['page_assembler'] = {'ms': round(dt * 1e3, 3), 'kernel_ms_per_run': k, 'gpu_ms': round(sum(k.values()), 3),
                          'profile_top': top(lambda s: assembler.run(step_input, default_rng(s)), 6)}
+dt, k = timed(lambda s: assembler.run(step_input, default_rng(s)).page.image.mat, 10, 'page_assembler_outputs_on_host')
+out['page_assembler_outputs_on_host'] = {'ms': round(dt * 1e3, 3), 'note': 'the same runs with the assembled page read on the host afterwards'}
 dist_in = T.PageDistortionStepInput(page_out)
 dist_out = distortion.run(dist_in, default_rng(0))
 dt, k = timed(lambda s: distortion.run(dist_in, default_rng(s)), 48, 'page_distortion')

@@ -125,6 +125,15 @@ class VkxNpJob(ctypes.Structure):
     ]
 
 
+class VkxNoisePlane(ctypes.Structure):
+    _fields_ = [
+        ('dst', ctypes.c_void_p),
+        ('stride_el', ctypes.c_ssize_t),
+        ('h', ctypes.c_int), ('w', ctypes.c_int), ('cn', ctypes.c_int), ('reserved', ctypes.c_int),
+        ('seed', ctypes.c_uint64),
+    ]
+
+
 class VkxNpResult(ctypes.Structure):
     _fields_ = [
         ('draws', ctypes.c_uint64),
@@ -158,6 +167,7 @@ _SIGNATURES = {
     'vkx_noise_normal_table': [c_double, c_void_p],
     'vkx_noise_normal_i16_dev': [c_void_p, c_void_p, c_ssize, c_int, c_int, c_int, c_double, ctypes.c_uint64],
     'vkx_noise_normal_i16': [c_void_p, c_void_p, c_ssize, c_int, c_int, c_int, c_double, ctypes.c_uint64],
+    'vkx_noise_normal_i16_batch_dev': [c_void_p, ctypes.POINTER(VkxNoisePlane), c_int, c_double],
     'vkx_np_draw_batch_dev': [c_void_p, ctypes.POINTER(VkxNpJob), c_int, ctypes.POINTER(VkxNpResult)],
     'vkx_np_draw': [c_void_p, ctypes.POINTER(VkxNpJob), ctypes.POINTER(VkxNpResult)],
     'vkx_host_alloc': [c_void_p, c_size, ctypes.POINTER(c_void_p)],
@@ -228,6 +238,7 @@ for _sfx in ('', '_dev'):
     _SIGNATURES['vkx_ellipse_mask_u8' + _sfx] = [c_void_p, c_void_p, c_ssize, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int]
     _SIGNATURES['vkx_ellipse_streak_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_double]
 
+_SIGNATURES['vkx_fill_u8_dev_host_layers'] = [c_void_p] + _PLANE_U8 + [ctypes.POINTER(VkxLayer), c_int]
 _SIGNATURES['vkx_fill_u8_batch_dev'] = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_ssize, ctypes.POINTER(VkxLayer), c_void_p]
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['vkx_version', 'vkx_last_error', 'vkx_ctx_stream'])
 
@@ -1499,48 +1510,55 @@ def dev_zeros(shape, dtype=np.uint8, ctx=None):
     return arr
 
 
+_F32 = np.dtype(np.float32)
+_U8 = np.dtype(np.uint8)
+
+
+def _plane(plane, dtype):
+    """(array to keep alive, its address): host planes C-contiguous in ``dtype``, DevArrays as they are."""
+    if isinstance(plane, DevArray):
+        return plane, plane.ptr
+    if plane.dtype != dtype or not plane.flags.c_contiguous:
+        plane = np.ascontiguousarray(plane, dtype=dtype)
+    return plane, plane.__array_interface__['data'][0]
+
+
 def make_layer(box, cn, value, mask=None, alpha=1.0, mode=FILL_PLAIN, dtype=np.uint8):
     """One composite layer for a uint8 (cn channels) or float32 (cn == 1) destination.
     box = (up, left, height, width).  Returns (VkxLayer | VkxLayerF32, keepalive list)."""
-    up, left, bh, bw = (int(v) for v in box)
-    is_f32 = np.dtype(dtype) == np.float32
+    up, left, bh, bw = box
+    dtype = np.dtype(dtype)
+    is_f32 = dtype == _F32
     if is_f32 and cn != 1:
         raise ValueError('float32 destinations are single channel')
     keep = []
     layer = VkxLayerF32() if is_f32 else VkxLayer()
-    layer.up, layer.left, layer.height, layer.width = up, left, bh, bw
-    layer.mode = int(mode)
-    def _address(plane):
-        return plane.ptr if isinstance(plane, DevArray) else plane.ctypes.data
-
+    layer.up, layer.left, layer.height, layer.width, layer.mode = int(up), int(left), int(bh), int(bw), int(mode)
     if mask is not None:
-        if not isinstance(mask, DevArray):
-            mask = np.ascontiguousarray(mask, dtype=np.uint8)
-        if tuple(mask.shape) != (bh, bw) or np.dtype(mask.dtype) != np.uint8:
+        mask, address = _plane(mask, _U8)
+        if tuple(mask.shape) != (bh, bw) or mask.dtype != _U8:
             raise ValueError(f'mask shape {mask.shape} != box shape {(bh, bw)}')
         keep.append(mask)
-        layer.mask, layer.mask_stride = _address(mask), bw
+        layer.mask, layer.mask_stride = address, bw
     if isinstance(alpha, (np.ndarray, DevArray)):
-        if not isinstance(alpha, DevArray):
-            alpha = np.ascontiguousarray(alpha, dtype=np.float32)
-        if tuple(alpha.shape) != (bh, bw) or np.dtype(alpha.dtype) != np.float32:
+        alpha, address = _plane(alpha, _F32)
+        if tuple(alpha.shape) != (bh, bw) or alpha.dtype != _F32:
             raise ValueError(f'alpha shape {alpha.shape} != box shape {(bh, bw)}')
         keep.append(alpha)
-        layer.alpha, layer.alpha_stride_el = _address(alpha), bw
+        layer.alpha, layer.alpha_stride_el = address, bw
         layer.alpha_scalar = 1.0
     else:
         layer.alpha_scalar = float(alpha)
     if isinstance(value, (np.ndarray, DevArray)):
-        if not isinstance(value, DevArray):
-            value = np.ascontiguousarray(value.astype(dtype, copy=False))
+        value, address = _plane(value, dtype)
         want = (bh, bw) if cn == 1 and value.ndim == 2 else (bh, bw, cn)
-        if tuple(value.shape) != want or np.dtype(value.dtype) != np.dtype(dtype):
+        if tuple(value.shape) != want or value.dtype != dtype:
             raise RuntimeError('value is np.ndarray but shape is not matched.')
         keep.append(value)
         if is_f32:
-            layer.value, layer.value_stride_el = _address(value), bw
+            layer.value, layer.value_stride_el = address, bw
         else:
-            layer.value, layer.value_stride = _address(value), bw * cn
+            layer.value, layer.value_stride = address, bw * cn
     elif is_f32:
         layer.value_const = float(np.float32(value))
     else:
@@ -1550,8 +1568,10 @@ def make_layer(box, cn, value, mask=None, alpha=1.0, mode=FILL_PLAIN, dtype=np.u
             vals = value
         else:
             vals = (value,) * cn
+        const = layer.value_const
         for c in range(cn):
-            layer.value_const[c] = int(np.uint8(vals[c]))
+            v = vals[c]
+            const[c] = int(v) if 0 <= v <= 255 else int(np.uint8(v))     # out of range: numpy's own complaint
     return layer, keep
 
 
@@ -1569,6 +1589,15 @@ def fill(dst, layers, ctx=None):
     cls = VkxLayerF32 if is_f32 else VkxLayer
     arr = (cls * max(len(layers), 1))()
     keep = []
+    if dev and not is_f32 and not any(isinstance(plane, DevArray) for _, planes in layers for plane in planes):
+        # every plane on the host: staged by the library in one transfer, the page stays on the device
+        for i, (layer, planes) in enumerate(layers):
+            if not isinstance(layer, cls):
+                raise TypeError('layer built for another destination dtype')
+            arr[i] = layer
+        check(lib().vkx_fill_u8_dev_host_layers(ctx.handle, c_void_p(dst.ptr), h, w, cn, w * cn, arr, len(layers)))
+        dst.invalidate_host()
+        return dst
     for i, (layer, planes) in enumerate(layers):
         if not isinstance(layer, cls):
             raise TypeError('layer built for another destination dtype')

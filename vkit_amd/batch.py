@@ -222,9 +222,18 @@ class ChainBatch:
         lib = _native.lib()
         if self._stream_noise and (draw_streams or self._stream_jobs is None):
             self._draw_streams()
-        for index, std, seed, dh, dw in self._device_noise:
-            _native.check(lib.vkx_noise_normal_i16_dev(self.ctx.handle, self._items[index].noise, dw * 3, dh, dw, 3, std,
-                                                       (seed + self._runs * 0x9E3779B97F4A7C15) & 0xffffffffffffffff))
+        if self._device_noise:
+            # the planes that share a deviation in one launch (its inverse-CDF table is staged once per workgroup)
+            by_std = {}
+            for index, std, seed, dh, dw in self._device_noise:
+                by_std.setdefault(std, []).append((index, seed, dh, dw))
+            for std, members in by_std.items():
+                planes = (_native.VkxNoisePlane * len(members))()
+                for t, (index, seed, dh, dw) in enumerate(members):
+                    pl = planes[t]
+                    pl.dst, pl.stride_el, pl.h, pl.w, pl.cn = self._items[index].noise, dw * 3, dh, dw, 3
+                    pl.seed = (seed + self._runs * 0x9E3779B97F4A7C15) & 0xffffffffffffffff
+                _native.check(lib.vkx_noise_normal_i16_batch_dev(self.ctx.handle, planes, len(members), std))
         self._runs += 1
         if self._page_layers:
             self._composite()

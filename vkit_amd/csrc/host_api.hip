@@ -345,6 +345,36 @@ VKX_EXPORT int vkx_line_streak_u8(vkx_ctx *ctx, uint8_t *img, int h, int w, int 
     return st.finish();
 }
 
+// Device page, host layer planes (the text lines of a page assembled onto a device-resident image): the planes are staged
+// like vkx_fill_u8's, the page neither travels nor is waited for.  Asynchronous on the ctx stream.
+VKX_EXPORT int vkx_fill_u8_dev_host_layers(vkx_ctx *ctx, uint8_t *dst_dev, int h, int w, int cn, ptrdiff_t dst_stride,
+                                           const vkx_layer *layers, int n_layers)
+{
+    VKX_REQUIRE(ctx && dst_dev, "NULL argument");
+    VKX_REQUIRE(h >= 0 && w >= 0 && cn > 0, "bad shape");
+    VKX_REQUIRE(n_layers >= 0 && (n_layers == 0 || layers), "bad layer list");
+    HostStage st(ctx);
+    std::vector<int> mid(n_layers, -1), aid(n_layers, -1), vid(n_layers, -1);
+    for (int i = 0; i < n_layers; i++) {
+        const vkx_layer &l = layers[i];
+        VKX_REQUIRE(l.height >= 0 && l.width >= 0, "bad layer box");
+        if (l.mask) mid[i] = st.add(l.mask, nullptr, (size_t)l.width, l.height, l.mask_stride);
+        if (l.alpha) aid[i] = st.add(l.alpha, nullptr, (size_t)l.width * 4, l.height, l.alpha_stride_el * 4);
+        if (l.value) vid[i] = st.add(l.value, nullptr, (size_t)l.width * cn, l.height, l.value_stride);
+    }
+    VKX_TRY(st.commit());
+    std::vector<vkx_layer> dl(layers, layers + n_layers);
+    for (int i = 0; i < n_layers; i++) {
+        dl[i].mask = st.dev<uint8_t>(mid[i]);
+        dl[i].mask_stride = layers[i].width;
+        dl[i].alpha = st.dev<float>(aid[i]);
+        dl[i].alpha_stride_el = layers[i].width;
+        dl[i].value = st.dev<uint8_t>(vid[i]);
+        dl[i].value_stride = (ptrdiff_t)layers[i].width * cn;
+    }
+    return vkx_fill_u8_dev(ctx, dst_dev, h, w, cn, dst_stride, dl.data(), n_layers);
+}
+
 VKX_EXPORT int vkx_fill_u8(vkx_ctx *ctx, uint8_t *dst, int h, int w, int cn, ptrdiff_t dst_stride,
                            const vkx_layer *layers, int n_layers)
 {

@@ -26,9 +26,10 @@ __device__ __forceinline__ void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t
 {
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-        const uint32_t hi = __umulhi(0xD256D193u, c0), lo = 0xD256D193u * c0;
-        c0 = hi ^ key ^ c1;
-        c1 = lo;
+        // both halves of the product from one v_mad_u64_u32 (full rate; v_mul_hi_u32 + v_mul_lo_u32 are quarter rate)
+        const uint64_t prod = (uint64_t)0xD256D193u * c0;
+        c0 = (uint32_t)(prod >> 32) ^ key ^ c1;
+        c1 = (uint32_t)prod;
         key += 0x9E3779B9u;
     }
     o0 = c0; o1 = c1;
@@ -37,10 +38,19 @@ __device__ __forceinline__ void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t
 // One Philox block = four consecutive samples = 8 bytes of the plane per lane and iteration: the stores of a wavefront
 // are one contiguous 512-byte run.  The inverse-CDF table sits in LDS as int8 when every entry fits (std up to ~30, the
 // policy's whole range; 64 KB, two workgroups per CU); larger deviations read the int16 table through L2.
+struct NoisePlane {            // device form of vkx_noise_plane
+    int16_t *dst;
+    long long n;               // samples
+    long long stride_el;
+    int w_el, pad;
+    uint32_t key, stream;
+};
+
+// All planes of a call in one launch: the 64 KB table is staged once per workgroup, not once per plane and workgroup (a
+// 2048^2 x 3 plane is six iterations per thread).  `planes` == nullptr: the single plane `one` of the kernel arguments.
 template <bool LDS_TABLE>
-__global__ void __launch_bounds__(1024) k_noise_normal_i16(int16_t *__restrict__ dst, long long n, int w_el, ptrdiff_t stride_el,
-                                                           const int16_t *__restrict__ table, const int8_t *__restrict__ table8,
-                                                           uint32_t key, uint32_t stream)
+__global__ void __launch_bounds__(1024) k_noise_normal_i16(const NoisePlane *__restrict__ planes, NoisePlane one, int n_planes,
+                                                           const int16_t *__restrict__ table, const int8_t *__restrict__ table8)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int8_t *lt = (int8_t *)smem;
@@ -50,28 +60,36 @@ __global__ void __launch_bounds__(1024) k_noise_normal_i16(int16_t *__restrict__
         for (int i = threadIdx.x; i < 65536 / 16; i += 1024) l[i] = g[i];
         __syncthreads();
     }
-    const long long groups = (n + 3) >> 2;
-    for (long long q = (long long)blockIdx.x * 1024 + threadIdx.x; q < groups; q += (long long)gridDim.x * 1024) {
-        uint32_t r0, r1;
-        philox2x32_10((uint32_t)q, stream, key, r0, r1);
-        const uint32_t u0 = r0 & 0xffffu, u1 = r0 >> 16, u2 = r1 & 0xffffu, u3 = r1 >> 16;
-        int k0, k1, k2, k3;
-        if (LDS_TABLE) { k0 = lt[u0]; k1 = lt[u1]; k2 = lt[u2]; k3 = lt[u3]; }
-        else { k0 = table[u0]; k1 = table[u1]; k2 = table[u2]; k3 = table[u3]; }
-        const long long s = q << 2;
-        if (stride_el == w_el && s + 3 < n) {
-            // contiguous plane: the four samples are 8 adjacent bytes
-            uint2 v;
-            v.x = (uint32_t)(k0 & 0xffff) | ((uint32_t)k1 << 16);
-            v.y = (uint32_t)(k2 & 0xffff) | ((uint32_t)k3 << 16);
-            *(uint2 *)(dst + s) = v;
-        } else {
-            const int ks[4] = {k0, k1, k2, k3};
-            for (int j = 0; j < 4; j++) {
-                const long long t = s + j;
-                if (t >= n) break;
-                const long long row = t / w_el;
-                dst[row * stride_el + (t - row * w_el)] = (int16_t)ks[j];
+    for (int p = 0; p < n_planes; p++) {
+        const NoisePlane pl = planes ? planes[p] : one;
+        int16_t *__restrict__ dst = pl.dst;
+        const long long n = pl.n, stride_el = pl.stride_el;
+        const int w_el = pl.w_el;
+        const long long groups = (n + 3) >> 2;
+        // the workgroups take turns at the short last stride of a plane
+        const unsigned first = (blockIdx.x + (unsigned)p * 37u) % gridDim.x;
+        for (long long q = (long long)first * 1024 + threadIdx.x; q < groups; q += (long long)gridDim.x * 1024) {
+            uint32_t r0, r1;
+            philox2x32_10((uint32_t)q, pl.stream, pl.key, r0, r1);
+            const uint32_t u0 = r0 & 0xffffu, u1 = r0 >> 16, u2 = r1 & 0xffffu, u3 = r1 >> 16;
+            int k0, k1, k2, k3;
+            if (LDS_TABLE) { k0 = lt[u0]; k1 = lt[u1]; k2 = lt[u2]; k3 = lt[u3]; }
+            else { k0 = table[u0]; k1 = table[u1]; k2 = table[u2]; k3 = table[u3]; }
+            const long long s = q << 2;
+            if (stride_el == w_el && s + 3 < n) {
+                // contiguous plane: the four samples are 8 adjacent bytes
+                uint2 v;
+                v.x = (uint32_t)(k0 & 0xffff) | ((uint32_t)k1 << 16);
+                v.y = (uint32_t)(k2 & 0xffff) | ((uint32_t)k3 << 16);
+                *(uint2 *)(dst + s) = v;
+            } else {
+                const int ks[4] = {k0, k1, k2, k3};
+                for (int j = 0; j < 4; j++) {
+                    const long long t = s + j;
+                    if (t >= n) break;
+                    const long long row = t / w_el;
+                    dst[row * stride_el + (t - row * w_el)] = (int16_t)ks[j];
+                }
             }
         }
     }
@@ -110,21 +128,30 @@ VKX_EXPORT int vkx_noise_normal_table(double std, int16_t *table_host)
     return VKX_OK;
 }
 
-VKX_EXPORT int vkx_noise_normal_i16_dev(vkx_ctx *ctx, int16_t *dst, ptrdiff_t stride_el, int h, int w, int cn, double std,
-                                        uint64_t seed)
+VKX_EXPORT int vkx_noise_normal_i16_batch_dev(vkx_ctx *ctx, const vkx_noise_plane *planes, int n_planes, double std)
 {
-    VKX_REQUIRE(ctx && dst, "NULL argument");
-    VKX_REQUIRE(h >= 0 && w >= 0 && cn >= 1 && cn <= 4, "bad shape");
+    VKX_REQUIRE(ctx && planes, "NULL argument");
+    VKX_REQUIRE(n_planes >= 1 && n_planes <= 65536, "1 .. 65536 planes per call");
     VKX_REQUIRE(std > 0.0 && std < 8000.0, "std out of range");
-    VKX_REQUIRE((long long)h * w * cn <= 0x3ffffffffLL, "more than 2^34 samples");
-    if (h == 0 || w == 0) return VKX_OK;
-    VKX_REQUIRE(stride_el >= (ptrdiff_t)w * cn, "row stride shorter than a row");
+    long long most = 0;
+    int live = 0;
+    for (int i = 0; i < n_planes; i++) {
+        const vkx_noise_plane &p = planes[i];
+        VKX_REQUIRE(p.h >= 0 && p.w >= 0 && p.cn >= 1 && p.cn <= 4, "bad shape");
+        VKX_REQUIRE((long long)p.h * p.w * p.cn <= 0x3ffffffffLL, "more than 2^34 samples");
+        if (p.h == 0 || p.w == 0) continue;
+        VKX_REQUIRE(p.dst != nullptr, "NULL plane");
+        VKX_REQUIRE(p.stride_el >= (ptrdiff_t)p.w * p.cn, "row stride shorter than a row");
+        most = std::max(most, (long long)p.h * p.w * p.cn);
+        live++;
+    }
+    if (!live) return VKX_OK;
     // the tables of the last std stay on the device (a chain uses one std for a whole batch): int16 [65536], then the
     // same entries as int8 when they all fit
     constexpr size_t kT16 = 65536 * sizeof(int16_t), kT8 = 65536;
+    int rc;
     if (!ctx->noise_table.ptr || ctx->noise_table_std != std) {
-        int rc = vkx_scratch_reserve(ctx, &ctx->noise_table, kT16 + kT8);
-        if (rc) return rc;
+        if ((rc = vkx_scratch_reserve(ctx, &ctx->noise_table, kT16 + kT8))) return rc;
         void *ring = nullptr;
         if ((rc = vkx_desc_ring_take(ctx, kT16 + kT8, &ring))) return rc;
         int16_t *t16 = (int16_t *)ring;
@@ -136,17 +163,50 @@ VKX_EXPORT int vkx_noise_normal_i16_dev(vkx_ctx *ctx, int16_t *dst, ptrdiff_t st
         VKX_HIP(hipMemcpyAsync(ctx->noise_table.ptr, ring, kT16 + kT8, hipMemcpyHostToDevice, ctx->stream));
         ctx->noise_table_std = std;
     }
-    const long long n = (long long)h * w * cn;
     const int16_t *t16 = (const int16_t *)ctx->noise_table.ptr;
     const int8_t *t8 = (const int8_t *)ctx->noise_table.ptr + kT16;
-    const unsigned blocks = (unsigned)std::min<long long>(((n + 3) / 4 + 1023) / 1024, 512);    // 2 resident workgroups per CU
+    auto device_form = [](const vkx_noise_plane &p) {
+        NoisePlane d;
+        d.dst = p.dst; d.n = (long long)p.h * p.w * p.cn; d.stride_el = (long long)p.stride_el; d.w_el = p.w * p.cn; d.pad = 0;
+        d.key = (uint32_t)p.seed; d.stream = (uint32_t)(p.seed >> 32);
+        return d;
+    };
+    NoisePlane one = {};
+    const NoisePlane *d_planes = nullptr;
+    int n_dev = 0;
+    if (live == 1) {
+        for (int i = 0; i < n_planes; i++)
+            if (planes[i].h && planes[i].w) one = device_form(planes[i]);
+        n_dev = 1;
+    } else {
+        if ((rc = vkx_scratch_reserve(ctx, &ctx->misc, sizeof(NoisePlane) * (size_t)live))) return rc;
+        void *ring = nullptr;
+        if ((rc = vkx_desc_ring_take(ctx, sizeof(NoisePlane) * (size_t)live, &ring))) return rc;
+        NoisePlane *h = (NoisePlane *)ring;
+        for (int i = 0; i < n_planes; i++)
+            if (planes[i].h && planes[i].w) h[n_dev++] = device_form(planes[i]);
+        vkx_device_guard guard(ctx);
+        if ((rc = vkx_small_to_device(ctx, ctx->misc.ptr, ring, sizeof(NoisePlane) * (size_t)live))) return rc;
+        d_planes = (const NoisePlane *)ctx->misc.ptr;
+    }
+    vkx_device_guard guard(ctx);
+    const unsigned blocks = (unsigned)std::min<long long>(((most + 3) / 4 + 1023) / 1024, 512);    // 2 resident workgroups per CU
     VKX_TIMED(ctx, "k_noise_normal_i16");
     if (ctx->noise_table_fits8)
-        k_noise_normal_i16<true><<<blocks, 1024, kT8, ctx->stream>>>(dst, n, w * cn, stride_el, t16, t8, (uint32_t)seed, (uint32_t)(seed >> 32));
+        k_noise_normal_i16<true><<<blocks, 1024, kT8, ctx->stream>>>(d_planes, one, n_dev, t16, t8);
     else
-        k_noise_normal_i16<false><<<blocks, 1024, 0, ctx->stream>>>(dst, n, w * cn, stride_el, t16, t8, (uint32_t)seed, (uint32_t)(seed >> 32));
+        k_noise_normal_i16<false><<<blocks, 1024, 0, ctx->stream>>>(d_planes, one, n_dev, t16, t8);
     VKX_LAUNCH_CHECK();
     return VKX_OK;
+}
+
+VKX_EXPORT int vkx_noise_normal_i16_dev(vkx_ctx *ctx, int16_t *dst, ptrdiff_t stride_el, int h, int w, int cn, double std,
+                                        uint64_t seed)
+{
+    VKX_REQUIRE(ctx && dst, "NULL argument");
+    vkx_noise_plane p = {};
+    p.dst = dst; p.stride_el = stride_el; p.h = h; p.w = w; p.cn = cn; p.seed = seed;
+    return vkx_noise_normal_i16_batch_dev(ctx, &p, 1, std);
 }
 
 VKX_EXPORT int vkx_noise_normal_i16(vkx_ctx *ctx, int16_t *dst, ptrdiff_t stride_el, int h, int w, int cn, double std,

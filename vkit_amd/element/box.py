@@ -11,6 +11,8 @@ import attrs
 import numpy as np
 
 from .opt import (
+    DeviceWindow,
+    _deferred_stack,
     clip_val,
     extract_shape_from_shapable_or_shape,
     fill_np_array,
@@ -168,7 +170,12 @@ class Box(Shapable):
         keep_min_value: bool = False,
     ):
         full_shape = (mat.shape[0], mat.shape[1])
-        window = mat if full_shape == self.shape else self.extract_np_array(mat)
+        if full_shape == self.shape:
+            window = mat
+        elif isinstance(mat, np.ndarray):
+            window = self.extract_np_array(mat)
+        else:       # a device-resident array: the composite takes the box as layer geometry, nothing is sliced
+            window = DeviceWindow(self.shape + tuple(mat.shape[2:]), mat.dtype)
         if isinstance(value, np.ndarray):
             if (value.shape[0], value.shape[1]) != (window.shape[0], window.shape[1]):
                 assert (value.shape[0], value.shape[1]) == full_shape
@@ -178,8 +185,10 @@ class Box(Shapable):
         if isinstance(alpha, ScoreMap):
             assert alpha.is_prob  # ScoreMap.box is ignored
             alpha = alpha.mat
-        if np_mask is None and isinstance(alpha, np.ndarray):
-            np_mask = (alpha > 0.0)  # sparse alpha: untouched where alpha == 0
+        if np_mask is None and isinstance(alpha, np.ndarray) and (keep_max_value or keep_min_value or mat.dtype != np.uint8):
+            # sparse alpha: untouched where alpha == 0.  A plain uint8 blend needs no selection plane for that:
+            # (1 - 0) * d + 0 * v is d exactly in float32, so the composite leaves those pixels as they are by arithmetic
+            np_mask = (alpha > 0.0)
         origin = None if window is mat else (mat, self.up, self.left)
         fill_np_array(window, value, np_mask=np_mask, alpha=alpha, keep_max_value=keep_max_value,
                       keep_min_value=keep_min_value, origin=origin)
@@ -191,6 +200,15 @@ class Box(Shapable):
                 value = self._extract_element(value)
             value = value.mat
         np_mask = self.get_np_mask_from_element_mask(element_mask)
+        stack = _deferred_stack()
+        if not isinstance(element._mat, np.ndarray):
+            # device-resident element: no write flag to manage; recorded by an open deferred composite or applied now
+            relative_box.fill_np_array(element._mat, value, np_mask=np_mask, **kwargs)
+            return
+        if stack and stack[-1].base is element._mat:
+            # an open deferred composite on this element records the layer; it writes (and handles the write flag) on exit
+            relative_box.fill_np_array(element._mat, value, np_mask=np_mask, **kwargs)
+            return
         with element.writable_context:
             relative_box.fill_np_array(element.mat, value, np_mask=np_mask, **kwargs)
 

@@ -8,6 +8,7 @@ from typing import Optional, Tuple, Union
 
 import numpy as np
 
+from vkit_amd import _native
 from .type import Shapable
 
 
@@ -53,8 +54,11 @@ class deferred_fill:
     ``base`` inside the block -- the writes have not happened yet.
     """
 
-    def __init__(self, base: np.ndarray):
-        if base.dtype not in (np.uint8, np.float32) or not base.flags.c_contiguous:
+    def __init__(self, base):
+        """``base``: a numpy array, or the ``DevArray`` of a device-resident element (the layers' host planes are staged
+        for the one call, the page never leaves the device)."""
+        self.on_device = isinstance(base, _native.DevArray)
+        if base.dtype not in (np.uint8, np.float32) or not (self.on_device or base.flags.c_contiguous):
             raise ValueError('deferred_fill needs a C-contiguous uint8 or float32 destination')
         self.base = base
         self.layers = []
@@ -72,8 +76,9 @@ class deferred_fill:
             stack.remove(self)
         # an exception inside the block abandons the recorded layers: the destination is left as it was, the
         # exception propagates
-        if exc_type is None and self.layers:
-            from vkit_amd import _native
+        if exc_type is None and self.layers and self.on_device:
+            _native.fill(self.base, self.layers)
+        elif exc_type is None and self.layers:
             writeable = self.base.flags.writeable
             self.base.flags.writeable = True
             try:
@@ -82,6 +87,14 @@ class deferred_fill:
                 self.base.flags.writeable = writeable
         self.layers = []
         return False
+
+
+class DeviceWindow:
+    """What ``fill_np_array`` needs to know of a box of a device-resident array: shape, dtype, ndim."""
+    __slots__ = ('shape', 'dtype', 'ndim')
+
+    def __init__(self, shape, dtype):
+        self.shape, self.dtype, self.ndim = tuple(shape), np.dtype(dtype), len(shape)
 
 
 # one stack per thread: contexts (streams, scratch) are per thread too (_native.default_ctx), and two threads
@@ -110,8 +123,6 @@ def fill_np_array(
     ``mat`` may be a (non-contiguous) box view of a larger array; pass ``origin=(base, up, left)`` so the
     composite is issued on the contiguous base array with the box as layer geometry.
     """
-    from vkit_amd import _native
-
     if mat.dtype == np.float32:
         if mat.ndim != 2:
             raise NotImplementedError('float32 fills are implemented for 2-D arrays (ScoreMap)')
@@ -149,7 +160,7 @@ def fill_np_array(
     if stack and stack[-1].accepts(base):
         stack[-1].layers.append(layer)
         return
-    if base.flags.c_contiguous:
+    if isinstance(base, _native.DevArray) or base.flags.c_contiguous:
         _native.fill(base, [layer])
     else:
         packed = np.ascontiguousarray(base)

@@ -21,6 +21,7 @@ import attrs
 import numpy as np
 from numpy.random import Generator as RandomGenerator
 
+from vkit_amd import _native
 from vkit_amd.element import Box, Image, Mask, PointList, Polygon, ScoreMap, Shapable
 from vkit_amd.element.opt import deferred_fill
 from vkit_amd.mechanism.distortion import rotate
@@ -263,7 +264,10 @@ class PageAssemblerStep(PipelineStep[PageAssemblerStepConfig, PageAssemblerStepI
         labels = input.page_text_line_label_step_output
 
         assert background_image.mat.shape == (page_layout.height, page_layout.width, 3)
-        assembled_image = background_image.copy()
+        # the page is assembled on the device: the upload of the background is the copy the reference makes, the layers'
+        # planes are staged once, and the steps that follow (page distortion, resizing) take the page where it is --
+        # ``.mat`` downloads it on first touch
+        assembled_image = attrs.evolve(background_image, mat=_native.default_ctx().to_device(background_image.mat))
 
         # Seal impressions are rotated first (device warps, independent of the page); their layers are recorded
         # last, so the composite order is untouched.
@@ -289,7 +293,7 @@ class PageAssemblerStep(PipelineStep[PageAssemblerStepConfig, PageAssemblerStepI
             page_seal_impression_char_polygons.extend(
                 polygon.to_shifted_polygon(offset_y=up, offset_x=left) for polygon in (rotated.polygons or ()))
 
-        with assembled_image.writable_context, deferred_fill(assembled_image.mat):
+        with deferred_fill(assembled_image.arr):
             for page_image in page_image_collection.page_images:
                 page_image.box.fill_image(assembled_image, page_image.image, alpha=page_image.alpha)
             for score_map in barcodes.barcode_qr_score_maps:
