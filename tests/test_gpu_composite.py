@@ -105,6 +105,52 @@ def test_deferred_fill_equals_sequential(N):
     np.testing.assert_array_equal(sequential.mat, want)
 
 
+def test_fills_on_a_device_resident_page(N):
+    """Box / Mask / ScoreMap fills aimed at an Image whose pixels live in device memory (what PageAssemblerStep builds its
+    page on): applied one by one, and recorded by a deferred composite and staged in one transfer
+    (vkx_fill_u8_dev_host_layers) -- both equal the host-array result, and the page is downloaded only when ``.mat`` is read."""
+    from vkit_amd.element import Box, Image, Mask, ScoreMap
+    from vkit_amd.element.opt import deferred_fill
+    rng = default_rng(12)
+    base = rng.integers(0, 256, (150, 200, 3), dtype=np.uint8)
+    layers = []
+    for k in range(30):
+        h, w = int(rng.integers(4, 50)), int(rng.integers(4, 90))
+        up, left = int(rng.integers(0, 150 - h)), int(rng.integers(0, 200 - w))
+        box = Box(up=up, down=up + h - 1, left=left, right=left + w - 1)
+        if k % 3 == 0:
+            alpha = (rng.random((h, w), dtype=np.float32) * (rng.random((h, w)) < 0.5)).astype(np.float32)
+            layers.append(('score', ScoreMap(mat=alpha, box=box), tuple(int(v) for v in rng.integers(0, 256, 3))))
+        elif k % 3 == 1:
+            layers.append(('box', box, Image(mat=rng.integers(0, 256, (h, w, 3), dtype=np.uint8)), float(rng.random())))
+        else:
+            layers.append(('mask', Mask(mat=(rng.random((h, w)) < 0.5).astype(np.uint8), box=box),
+                           Image(mat=rng.integers(0, 256, (h, w, 3), dtype=np.uint8))))
+
+    def apply(image):
+        for layer in layers:
+            if layer[0] == 'score':
+                image[layer[1]] = layer[2]
+            elif layer[0] == 'box':
+                layer[1].fill_image(image, layer[2], alpha=layer[3])
+            else:
+                layer[1].fill_image(image, layer[2])
+
+    on_host = Image(mat=base.copy())
+    apply(on_host)
+    ctx = N.default_ctx()
+    one_by_one = Image(mat=ctx.to_device(base))
+    apply(one_by_one)
+    assert one_by_one.on_device
+    np.testing.assert_array_equal(one_by_one.mat, on_host.mat)
+    deferred = Image(mat=ctx.to_device(base))
+    with deferred_fill(deferred.arr) as session:
+        apply(deferred)
+        assert len(session.layers) == len(layers)
+    assert deferred.on_device
+    np.testing.assert_array_equal(deferred.mat, on_host.mat)
+
+
 def test_deferred_fill_float32_layers(N):
     """A list of float32 layers (height-map style fills with masks, keep-max / keep-min, alpha planes) in one launch."""
     from vkit_amd.element import Box, Mask, ScoreMap

@@ -454,6 +454,19 @@ def test_throughput_noise_plane_matches_its_definition():
     assert (N.noise_normal_table(7.5) == O.noise_normal_table(7.5)).all()
     with pytest.raises(N.VkxError):
         N.noise_normal_i16((4, 4, 3), 0.0, 1)
+    # the planes of a batch in one launch (vkx_noise_normal_i16_batch_dev): ragged shapes, own seeds, an empty plane, and
+    # more planes than the kernel-argument form holds
+    ctx = N.default_ctx()
+    shapes = [(123, 77, 3), (1, 1, 1), (0, 5, 3), (301, 257, 3), (64, 64, 4)] + [(17 + k, 29, 3) for k in range(9)]
+    seeds = [0x1234 + 977 * k for k in range(len(shapes))]
+    outs = [ctx.dev_empty(shape if shape[0] else (1, 1, 1), np.int16) for shape in shapes]
+    planes = (N.VkxNoisePlane * len(shapes))()
+    for pl, out, shape, seed in zip(planes, outs, shapes, seeds):
+        pl.dst, pl.stride_el, pl.h, pl.w, pl.cn, pl.seed = out.ptr, shape[1] * shape[2], shape[0], shape[1], shape[2], seed
+    N.check(N.lib().vkx_noise_normal_i16_batch_dev(ctx.handle, planes, len(shapes), 12.5))
+    for out, shape, seed in zip(outs, shapes, seeds):
+        if shape[0]:
+            assert (out.host() == O.noise_normal_i16(shape, 12.5, seed)).all(), shape
 
 
 def test_dense_and_pitched_planes_agree():
