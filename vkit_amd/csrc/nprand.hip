@@ -461,7 +461,8 @@ __device__ void walk_tile(const NpJob &job, const JumpTabs &g_jump, const uint4 
                     }
                 }
                 Emit::store(job, pos, z, inexact, flags);
-                if (pos == job.n - 1) *draws_used = (unsigned long long)(draw_base + 64 * r + lane + len);
+                if (pos == job.n - 1)      // write-through: read by the last workgroup of the kernel (np_results_out)
+                    __hip_atomic_store(draws_used, (unsigned long long)(draw_base + 64 * r + lane + len), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             done += (uint32_t)__builtin_popcountll(emits);
             ebase += (uint32_t)__builtin_popcountll(slow);
@@ -535,12 +536,13 @@ __device__ __forceinline__ void np_results_out(unsigned *done, const vkx_np_resu
 {
     if (!results_host) return;
     __shared__ bool s_last;
-    __threadfence();
+    // this kernel's writes to `results` are device-scope atomics (flags) and write-through stores (draws): once a wavefront's
+    // own stores are acknowledged they are visible to the sc1 loads below -- no L2 write-back fence (~2 us per workgroup)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) s_last = atomicAdd(done, 1u) == gridDim.x - 1;
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     const uint32_t *src = (const uint32_t *)results;
     uint32_t *dst = (uint32_t *)results_host;
     for (unsigned i = threadIdx.x; i < (unsigned)n_jobs * (sizeof(vkx_np_result) / 4); i += blockDim.x)
@@ -925,8 +927,8 @@ __global__ void __launch_bounds__(256) k_np_choice_impulse(const NpJob *__restri
         const int jb = job_of_tile(jobs, n_jobs, tile);
         const NpJob &job = jobs[jb];
         if (tile == job.tile_base && lane == 0) {
-            results[jb].draws = (unsigned long long)job.n;
-            results[jb].samples = (unsigned long long)job.n;
+            __hip_atomic_store(&results[jb].draws, (unsigned long long)job.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&results[jb].samples, (unsigned long long)job.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const u128 inc = mk128(job.inc), a64 = mk128(g_jump.a64), c64 = mk128(job.c64);
         u128 s = mk128(&g_jump.lane[lane][0]) * mk128(&states[2 * tile]) + mk128(&g_jump.lane[lane][2]) * inc;
