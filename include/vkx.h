@@ -527,7 +527,8 @@ int vkx_np_draw(vkx_ctx *ctx, const vkx_np_job *job, vkx_np_result *result_host)
  * Philox2x32-10 block with counter (s >> 2, seed >> 32) and key = seed low word, and maps it through a 65536-entry
  * inverse-CDF table of round(N(0, std)) (vkx_noise_normal_table builds that table on the host, for checks).
  * Separately labelled: a caller opts in.
- * dst: int16 [h, w, cn], cn in 1..4; _dev: device plane, asynchronous; host variant: host plane, synchronous. */
+ * dst: int16 [h, w, cn], cn in 1..4; _dev: device plane (8-byte aligned when dense: stride_el == w * cn), asynchronous;
+ * host variant: host plane, synchronous. */
 int vkx_noise_normal_table(double std, int16_t *table_host /* [65536] */);
 int vkx_noise_normal_i16_dev(vkx_ctx *ctx, int16_t *dst, ptrdiff_t stride_el, int h, int w, int cn, double std, uint64_t seed);
 /* the planes of a batch that share `std` in one launch (each with its own seed): the table is staged once per workgroup */

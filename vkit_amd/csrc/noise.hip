@@ -142,6 +142,8 @@ VKX_EXPORT int vkx_noise_normal_i16_batch_dev(vkx_ctx *ctx, const vkx_noise_plan
         if (p.h == 0 || p.w == 0) continue;
         VKX_REQUIRE(p.dst != nullptr, "NULL plane");
         VKX_REQUIRE(p.stride_el >= (ptrdiff_t)p.w * p.cn, "row stride shorter than a row");
+        // a dense plane leaves as 8-byte stores (four samples of one Philox block)
+        VKX_REQUIRE(p.stride_el != (ptrdiff_t)p.w * p.cn || ((uintptr_t)p.dst & 7) == 0, "a dense plane must be 8-byte aligned");
         most = std::max(most, (long long)p.h * p.w * p.cn);
         live++;
     }
