@@ -453,3 +453,58 @@ def test_std_shift_tables_match_reference(golden_dir, monkeypatch):
             assert (got.reshape(-1)[:4096] == head).all(), case
         n += 1
     assert n == 9
+
+
+def test_layer_records_of_the_composite(monkeypatch):
+    """What ``Box.fill_*`` hands to the composite (no GPU: the records are collected by an open deferred composite and the
+    block is abandoned): geometry, plane addresses, strides and modes; a plain uint8 alpha blend carries no selection plane
+    ((1 - 0) * d + 0 * v is d exactly), keep_max / float32 destinations keep the reference's ``alpha > 0`` selection."""
+    from vkit_amd import _native as N
+    from vkit_amd.element import Box, Image, Mask, ScoreMap
+    from vkit_amd.element.opt import deferred_fill
+    rng = default_rng(5)
+    page = Image(mat=rng.integers(0, 256, (40, 60, 3), dtype=np.uint8))
+    alpha = (rng.random((8, 10), dtype=np.float32) * (rng.random((8, 10)) < 0.5)).astype(np.float32)
+    box = Box(up=3, down=10, left=7, right=16)
+    value = rng.integers(0, 256, (8, 10, 3), dtype=np.uint8)
+    mask = Mask(mat=(rng.random((8, 10)) < 0.5).astype(np.uint8), box=box)
+
+    class Abandon(Exception):
+        pass
+
+    with pytest.raises(Abandon):
+        with page.writable_context, deferred_fill(page.mat) as session:
+            ScoreMap(mat=alpha, box=box).fill_image(page, (1, 2, 3))
+            box.fill_image(page, Image(mat=value), alpha=0.25)
+            mask.fill_image(page, Image(mat=value))
+            box.fill_np_array(page.mat, 200, alpha=alpha, keep_max_value=True)
+            recorded = list(session.layers)
+            raise Abandon()
+    assert len(recorded) == 4
+    (l0, k0), (l1, k1), (l2, k2), (l3, k3) = recorded
+    for layer in (l0, l1, l2, l3):
+        assert (layer.up, layer.left, layer.height, layer.width) == (3, 7, 8, 10)
+    # score map, constant colour: alpha plane, no mask, the colour in value_const
+    assert l0.alpha == alpha.__array_interface__['data'][0] and l0.alpha_stride_el == 10 and not l0.mask and not l0.value
+    assert list(l0.value_const)[:3] == [1, 2, 3] and l0.mode == N.FILL_PLAIN and any(p is alpha for p in k0)
+    # image value, scalar alpha
+    assert l1.value == value.__array_interface__['data'][0] and l1.value_stride == 30 and l1.alpha_scalar == 0.25 and not l1.alpha
+    # mask selects, value plane
+    assert l2.mask and l2.mask_stride == 10 and l2.value and l2.alpha_scalar == 1.0
+    # keep_max with an alpha plane keeps the reference's alpha > 0 selection
+    assert l3.mode == N.FILL_KEEP_MAX and l3.mask and l3.alpha
+    assert (k3[0] == (alpha > 0)).all()
+    # the page was not written and is read-only again
+    assert not page.mat.flags.writeable
+    # a float32 destination keeps the selection plane too
+    smap = ScoreMap(mat=np.zeros((40, 60), np.float32))
+    with pytest.raises(Abandon):
+        with smap.writable_context, deferred_fill(smap.mat) as session:
+            box.fill_np_array(smap.mat, 0.5, alpha=alpha)
+            assert session.layers[0][0].mask
+            raise Abandon()
+    # constants outside uint8 fail like numpy's own assignment does
+    with pytest.raises(OverflowError):
+        N.make_layer((0, 0, 2, 2), 3, (300, 0, 0))
+    layer, keep = N.make_layer((0, 0, 2, 2), 1, 7.9)
+    assert layer.value_const[0] == 7
