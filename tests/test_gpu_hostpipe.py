@@ -127,6 +127,78 @@ def test_device_noise_in_batch_and_pipeline():
     batch.close()
 
 
+def test_numpy_stream_noise_in_batch_and_pipeline(monkeypatch):
+    """``noise_rng``: the plane np.round(rng.normal(0, std, shape)) of the caller's numpy stream, drawn on the device.  By
+    default the generator adds its samples to the chain's output (no plane); ``stream_noise_planes=True`` and images with a
+    streak stage keep an int16 plane that the chain kernel adds.  All of them equal the oracle fed numpy's own plane, the
+    caller's generator is left alone, and a stream the device declares ambiguous is drawn by numpy instead."""
+    from vkit_amd import _native as N
+    from vkit_amd.batch import ChainBatch
+    from vkit_amd.hostpipe import HostPipeline
+    from vkit_amd.mechanism.distortion.photometric.streak import LineStreakConfig
+    shapes = [(300, 420, 15, 7.0, 5), (257, 333, 11, 5.0, 6), (190, 512, 16, 9.0, 7)]
+    cases = []
+    for k, (h, w, step, amp, seed) in enumerate(shapes):
+        sv, dv, dshape = synthetic_grid(h, w, step, amp, seed=seed)
+        image = default_rng(30 + k).integers(0, 256, (h, w, 3), dtype=np.uint8)
+        mx, my = O.grid_to_map(sv, dv, dshape)
+        base = O.color_shift_rgb(O.gaussian_blur(O.remap(image, mx, my), 5, 1.0), 37)
+        plane = np.round(default_rng(900 + k).normal(0, 12.0, tuple(dshape) + (3,))).astype(np.int16)
+        cases.append((image, _state(sv, dv, dshape), O.add_noise_i16(base, plane)))
+    streak = LineStreakConfig(thickness=2, gap=9, dash_thickness=3, dash_gap=5, alpha=0.6, color=(10, 200, 30), enable_vert=True,
+                              enable_hori=True)
+
+    def run_batch(**kwargs):
+        batch = ChainBatch(**kwargs)
+        rngs = [default_rng(900 + k) for k in range(len(cases))]
+        before = [r.bit_generator.state for r in rngs]
+        for (image, st, _want), r in zip(cases, rngs):
+            batch.add(image, st, blur_sigma=1.0, hue_delta=37, noise_std=12.0, noise_rng=r)
+        batch.run()
+        batch.run()       # the same pixels every run
+        got = [batch.result(k) for k in range(len(cases))]
+        fallbacks = batch.stream_fallbacks
+        planes = [bool(it.noise) for it in batch._items]
+        batch.close()
+        assert [r.bit_generator.state for r in rngs] == before
+        return got, fallbacks, planes
+
+    got, fallbacks, planes = run_batch()
+    assert fallbacks == 0 and not any(planes)
+    for g, (_i, _s, want) in zip(got, cases):
+        assert (g == want).all()
+    got, fallbacks, planes = run_batch(stream_noise_planes=True)
+    assert fallbacks == 0 and all(planes)
+    for g, (_i, _s, want) in zip(got, cases):
+        assert (g == want).all()
+    # a streak is drawn over the noise: that image keeps a plane
+    image, st, want = cases[0]
+    batch = ChainBatch()
+    batch.add(image, st, blur_sigma=1.0, hue_delta=37, noise_std=12.0, noise_rng=default_rng(900), streak=streak)
+    batch.add(image, st, blur_sigma=1.0, hue_delta=37, noise_std=12.0, noise_rng=default_rng(900))
+    batch.run()
+    assert bool(batch._items[0].noise) and not batch._items[1].noise
+    assert (batch.result(0) == O.line_streak(want, 2, 9, 3, 5, (10, 200, 30), 0.6, True, True)).all()
+    assert (batch.result(1) == want).all()
+    batch.close()
+    # the pipeline: the same, one image per job
+    with HostPipeline(N.default_ctx(), depth=4) as pipe:
+        tickets = [pipe.submit_chain(image, st, blur_sigma=1.0, hue_delta=37, noise_std=12.0, noise_rng=default_rng(900 + k))
+                   for k, (image, st, _w) in enumerate(cases)]
+        for t, (_i, _s, want) in zip(tickets, cases):
+            assert (pipe.result(t)[0] == want).all()
+    # every wedge decision declared ambiguous: numpy draws, the pixels stay the same
+    real = N.np_job
+    monkeypatch.setattr(N, 'np_job', lambda kind, *a, **k: real(kind | 0x100, *a, **k))
+    got, fallbacks, planes = run_batch()
+    assert fallbacks == len(cases) and all(planes)
+    for g, (_i, _s, want) in zip(got, cases):
+        assert (g == want).all()
+    with HostPipeline(N.default_ctx(), depth=2) as pipe:
+        image, st, want = cases[1]
+        assert (pipe.result(pipe.submit_chain(image, st, blur_sigma=1.0, hue_delta=37, noise_std=12.0, noise_rng=default_rng(901)))[0] == want).all()
+
+
 def test_operator_api_on_the_overlapped_path():
     """``HostPipeline.submit_distortion`` returns what ``distortion.distort`` returns: pixel elements, points, polygons,
     result shape, config / state on request -- for similarity_mls and a camera model, several jobs in flight."""

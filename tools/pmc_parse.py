@@ -5,7 +5,7 @@ profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.md, profiles/<tag>_traffic.j
 HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are collected in
 separate --pmc passes; both are reported in KiB; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 B, so it is
 doubled.  WRITE_SIZE is taken as reported (uncalibrated, stated as such).
-Usage: tools/pmc_parse.py <tag> <images-per-launch>"""
+Usage: tools/pmc_parse.py <tag> <images-per-launch> [noise-planes: 1 when the record was taken with bench.py --noise-planes 1]"""
 import csv
 import glob
 import json
@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     tag, images = sys.argv[1], int(sys.argv[2])
+    noise_planes = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     out_dir = os.path.join(ROOT, 'profiles')
     stats = os.path.join(ROOT, 'gpurun_out', f'stats_{tag}', 'stats_kernel_stats.csv')
     if os.path.exists(stats):
@@ -80,7 +81,7 @@ def main():
             t.update(valu_insts_per_image=d['SQ_INSTS_VALU'] / images, valu_insts_per_wavefront=d['SQ_INSTS_VALU'] / d['SQ_WAVES'])
         t.update(source=f'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, batch {images} '
                         f'(profiles/{tag}_pmc_batch{images}.md); FETCH_SIZE doubled (gfx950), WRITE_SIZE as reported',
-                 images=images)
+                 images=images, noise_planes=noise_planes)
         # the digest of the kernel sources the GPU box profiled (tools/record.sh writes it next to the counters)
         dpath = os.path.join(ROOT, 'gpurun_out', f'digest_{tag}.txt')
         if os.path.exists(dpath):

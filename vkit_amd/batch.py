@@ -17,15 +17,22 @@ from vkit_amd.mechanism.distortion.photometric.blur import _estimate_gaussian_ke
 
 class ChainBatch:
 
-    def __init__(self, ctx: Optional[_native.Context] = None):
+    def __init__(self, ctx: Optional[_native.Context] = None, stream_noise_planes: bool = False):
+        """``stream_noise_planes``: keep an int16 plane in HBM for every ``noise_rng`` image and let the chain kernel add it
+        (the form of rounds 1 - 2, and what ``run(draw_streams=False)`` re-reads).  By default the noise of such an image is
+        added by the generator itself, after the chain: the pass that puts the samples at their final index adds them to
+        the chain's output in place (``VKX_NP_NORMAL_ADD_U8``) -- same pixels, no 6-byte-per-pixel plane to write and read.
+        Images with a ``streak`` stage keep a plane either way (the streak is drawn over the noise)."""
         self.ctx = ctx or _native.default_ctx()
+        self.stream_noise_planes = bool(stream_noise_planes)
         self._items: List[_native.VkxChainItem] = []
         self._owned: List[int] = []
         self._dst_shapes: List[Tuple[int, int]] = []
         self._array = None
         self._device_noise = []      # (item index, std, seed, dh, dw) of the throughput-mode items
-        self._stream_noise = []      # (item index, std, (state, inc), samples): the caller's numpy stream drawn on the device
+        self._stream_noise = []      # (item index, std, (state, inc), samples, late): the caller's numpy stream drawn on the device
         self._stream_jobs = None     # [(VkxNpJob array, VkxNpResult array, [item index])] in chunks, built on the first run
+        self._late_jobs = None       # the same for the images whose noise the generator adds after the chain
         self.stream_chunk = 64       # planes per vkx_np_draw_batch_dev call (bounds the scratch of the two-pass draw)
         self.stream_fallbacks = 0    # planes the device declared ambiguous and the host drew instead
         self._runs = 0
@@ -70,15 +77,17 @@ class ChainBatch:
         if noise_std is not None:
             if noise is not None:
                 raise ValueError('pass either a noise plane or noise_std with noise_seed / noise_rng')
-            item.noise = self.ctx.malloc(dh * dw * 3 * 2)
-            self._owned.append(item.noise)
-            item.noise_stride_el = dw * 3
+            late = noise_rng is not None and streak is None and not self.stream_noise_planes
+            if not late:
+                item.noise = self.ctx.malloc(dh * dw * 3 * 2)
+                self._owned.append(item.noise)
+                item.noise_stride_el = dw * 3
             if noise_rng is not None:
                 stream = _native.np_stream(noise_rng)
                 if stream is None:
                     raise ValueError('noise_rng must be a numpy Generator over PCG64 (numpy.random.default_rng)')
-                self._stream_noise.append((len(self._items), float(noise_std), stream, dh * dw * 3))
-                self._stream_jobs = None
+                self._stream_noise.append((len(self._items), float(noise_std), stream, dh * dw * 3, late))
+                self._stream_jobs = self._late_jobs = None
             else:
                 self._device_noise.append((len(self._items), float(noise_std), int(noise_seed or 0), dh, dw))
         if noise is not None:
@@ -173,55 +182,79 @@ class ChainBatch:
     def result_pixels(self) -> int:
         return sum(h * w for h, w in self._dst_shapes)
 
-    def _draw_streams(self):
-        """The int16 planes of the ``noise_rng`` items, drawn from their numpy streams on the device."""
+    def _job(self, entry):
+        index, std, stream, n, late = entry
+        item = self._items[index]
+        if late:
+            return _native.np_job(_native.NP_NORMAL_ADD_U8, stream, n, std, src=item.dst, dst=item.dst)
+        return _native.np_job(_native.NP_NORMAL_I16, stream, n, std, dst=item.noise)
+
+    def _build_jobs(self, entries):
+        chunks = []
+        step = max(1, self.stream_chunk)
+        for k in range(0, len(entries), step):
+            part = entries[k:k + step]
+            jobs = (_native.VkxNpJob * len(part))()
+            for t, entry in enumerate(part):
+                jobs[t] = self._job(entry)
+            chunks.append((jobs, _native.NpResults(self.ctx, len(part)), part))
+        return chunks
+
+    def _launch(self, chunks):
         lib = _native.lib()
-        first = self._stream_jobs is None
-        if first:
-            self._stream_jobs = []
-            for k in range(0, len(self._stream_noise), max(1, self.stream_chunk)):
-                part = self._stream_noise[k:k + max(1, self.stream_chunk)]
-                jobs = (_native.VkxNpJob * len(part))()
-                for t, (index, std, stream, n) in enumerate(part):
-                    jobs[t] = _native.np_job(_native.NP_NORMAL_I16, stream, n, std, dst=self._items[index].noise)
-                self._stream_jobs.append((jobs, _native.NpResults(self.ctx, len(part)), part))
-        for jobs, results, _part in self._stream_jobs:
+        for jobs, results, _part in chunks:
             _native.check(lib.vkx_np_draw_batch_dev(self.ctx.handle, jobs, len(jobs), results.array))
-        if first:
-            # the streams are fixed, so is the device's verdict on them: a plane it declared ambiguous in the last bits of
-            # exp / log1p (expected < 1e-6 per plane) is drawn by numpy once and stays resident like a caller's plane
-            self.ctx.sync()
-            kept = []
-            for jobs, results, part in self._stream_jobs:
-                good = []
-                for t, (index, std, (state, inc), n) in enumerate(part):
+
+    def _verify_streams(self):
+        """After the first run: the streams are fixed, so is the device's verdict on them.  A stream it declared ambiguous in
+        the last bits of exp / log1p (expected < 1e-6 per plane) is drawn by numpy once and stays resident as a plane the
+        chain adds, like a caller's.  Returns True when an image changed sides (its output has to be produced again)."""
+        self.ctx.sync()
+        flagged = set()
+        for chunks in (self._stream_jobs, self._late_jobs):
+            for _jobs, results, part in chunks:
+                for t, entry in enumerate(part):
                     if results[t].flags:
-                        rng = np.random.default_rng()
-                        st = rng.bit_generator.state
-                        st['state'] = {'state': state, 'inc': inc}
-                        rng.bit_generator.state = st
-                        plane = np.round(rng.normal(0, std, n)).astype(np.int16)
-                        self.ctx.upload(self._items[index].noise, plane)
-                        self.stream_fallbacks += 1
-                    else:
-                        good.append(part[t])
-                if len(good) == len(part):
-                    kept.append((jobs, results, part))
-                elif good:
-                    njobs = (_native.VkxNpJob * len(good))()
-                    for t, (index, std, stream, n) in enumerate(good):
-                        njobs[t] = _native.np_job(_native.NP_NORMAL_I16, stream, n, std, dst=self._items[index].noise)
-                    kept.append((njobs, _native.NpResults(self.ctx, len(good)), good))
-            self._stream_jobs = kept
+                        flagged.add(entry[0])
+        if not flagged:
+            return False
+        kept = []
+        for entry in self._stream_noise:
+            index, std, (state, inc), n, late = entry
+            if index not in flagged:
+                kept.append(entry)
+                continue
+            rng = np.random.default_rng()
+            st = rng.bit_generator.state
+            st['state'] = {'state': state, 'inc': inc}
+            rng.bit_generator.state = st
+            plane = np.round(rng.normal(0, std, n)).astype(np.int16)
+            item = self._items[index]
+            if late:
+                item.noise = self.ctx.malloc(plane.nbytes)
+                self._owned.append(item.noise)
+                item.noise_stride_el = int(item.dw) * 3
+            self.ctx.upload(item.noise, plane)
+            self.stream_fallbacks += 1
+        self._stream_noise = kept
+        self._array = (_native.VkxChainItem * max(len(self._items), 1))(*self._items)
+        self._stream_jobs = self._build_jobs([e for e in kept if not e[4]])
+        self._late_jobs = self._build_jobs([e for e in kept if e[4]])
+        return True
 
     def run(self, draw_streams: bool = True):
-        """Enqueues the chain for every image on the ctx stream (asynchronous).  ``draw_streams=False`` leaves the planes of
-        the ``noise_rng`` items as the previous run drew them (they are the same every run)."""
+        """Enqueues the chain for every image on the ctx stream (asynchronous).  ``draw_streams=False`` leaves the PLANES of
+        the ``noise_rng`` items as the previous run drew them (they are the same every run); noise that the generator adds
+        after the chain is always drawn."""
         if self._array is None:
             self._array = (_native.VkxChainItem * max(len(self._items), 1))(*self._items)
         lib = _native.lib()
-        if self._stream_noise and (draw_streams or self._stream_jobs is None):
-            self._draw_streams()
+        first = self._stream_noise and self._stream_jobs is None
+        if first:
+            self._stream_jobs = self._build_jobs([e for e in self._stream_noise if not e[4]])
+            self._late_jobs = self._build_jobs([e for e in self._stream_noise if e[4]])
+        if self._stream_noise and (draw_streams or first):
+            self._launch(self._stream_jobs)
         if self._device_noise:
             # the planes that share a deviation in one launch (its inverse-CDF table is staged once per workgroup)
             by_std = {}
@@ -238,6 +271,11 @@ class ChainBatch:
         if self._page_layers:
             self._composite()
         _native.check(lib.vkx_chain_rgb_batch_dev(self.ctx.handle, self._array, len(self._items)))
+        if self._stream_noise and self._late_jobs:
+            self._launch(self._late_jobs)
+        if first and self._verify_streams():
+            self._runs -= 1
+            self.run(draw_streams=True)
 
     def result(self, index: int) -> np.ndarray:
         self.ctx.sync()
@@ -252,7 +290,7 @@ class ChainBatch:
         self._items.clear()
         self._device_noise.clear()
         self._stream_noise.clear()
-        self._stream_jobs = None
+        self._stream_jobs = self._late_jobs = None
         self._page_layers.clear()
         self._layer_tables = None
         self._array = None

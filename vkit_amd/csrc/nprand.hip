@@ -789,11 +789,36 @@ struct Placer<EmitAddU8> {
     __device__ static void place(const NpJob &job, const Draws &d, const int16_t *, uint64_t m, long long prefix, int16_t *st, uint32_t &)
 {
     const uint32_t shift = (uint32_t)prefix & 3u;
+    // the pixels the tile's samples go onto are requested before the samples are compacted: their latency hides behind
+    // the staging (every whole dword of the plane that the tile can reach; what the count leaves unused is dropped)
+    const uint32_t lane = (uint32_t)__lane_id();
+    const long long first = prefix - shift;
+    const uint32_t VKX_GLOBAL *src32 = (const uint32_t VKX_GLOBAL *)((const uint8_t VKX_GLOBAL *)job.src + first) + lane;
+    uint32_t px[kTile / 256];
+#pragma unroll
+    for (uint32_t i = 0; i < kTile / 256; i++) {      // shift + total <= 1027: whole dwords 0 .. 255
+        px[i] = 0;
+        if (first + 4 * (long long)(lane + 64 * i) + 3 < job.n) px[i] = src32[64 * i];
+    }
     uint32_t total = stage_tile_i16(d, m, shift, st);
     if (prefix + total > job.n) total = (uint32_t)(job.n - prefix);
-    finish(job, total, shift, prefix, st);
+    finish_px(job, total, shift, prefix, st, px);
 }
     __device__ static void finish(const NpJob &job, uint32_t total, uint32_t shift, long long prefix, int16_t *st)
+{
+    const uint32_t lane = (uint32_t)__lane_id();
+    const long long first = prefix - shift;
+    const uint32_t VKX_GLOBAL *src32 = (const uint32_t VKX_GLOBAL *)((const uint8_t VKX_GLOBAL *)job.src + first) + lane;
+    uint32_t px[kTile / 256];
+#pragma unroll
+    for (uint32_t i = 0; i < kTile / 256; i++) {      // shift + total <= 1027: whole dwords 0 .. 255
+        px[i] = 0;
+        if (first + 4 * (long long)(lane + 64 * i) + 3 < job.n) px[i] = src32[64 * i];
+    }
+    finish_px(job, total, shift, prefix, st, px);
+}
+    __device__ static void finish_px(const NpJob &job, uint32_t total, uint32_t shift, long long prefix, int16_t *st,
+                                     const uint32_t (&pxs)[kTile / 256])
 {
     typedef short pk16 __attribute__((ext_vector_type(2)));
     const uint32_t lane = (uint32_t)__lane_id();
@@ -801,11 +826,10 @@ struct Placer<EmitAddU8> {
     uint8_t VKX_GLOBAL *dst = (uint8_t VKX_GLOBAL *)job.dst + (prefix - shift);
     const uint32_t end = shift + total;
     const uint32_t full_lo = (shift + 3) >> 2, full_hi = end >> 2;      // dwords [full_lo, full_hi) are whole
-    const uint32_t VKX_GLOBAL *src32 = (const uint32_t VKX_GLOBAL *)src + lane;
     uint32_t VKX_GLOBAL *dst32 = (uint32_t VKX_GLOBAL *)dst + lane;
     const uint2 *st64 = (const uint2 *)st + lane;
     auto whole = [&](uint32_t i) {
-        const uint32_t px = src32[64 * i];
+        const uint32_t px = pxs[i];
         const uint2 nz = st64[64 * i];
         // bytes 0 1 | 2 3 of the pixel dword as int16 pairs, + noise, clamp, repack
         pk16 lo = __builtin_bit_cast(pk16, __builtin_amdgcn_perm(0u, px, 0x0c010c00u));

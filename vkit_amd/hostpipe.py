@@ -24,6 +24,8 @@ jobs have been submitted.
 import ctypes
 from typing import List, Optional, Sequence
 
+import os
+
 import numpy as np
 
 from vkit_amd import _native
@@ -217,22 +219,30 @@ class HostPipeline:
         item.src_stride, item.dst_stride = sw * 3, dw * 3
         item.sh, item.sw, item.dh, item.dw = sh, sw, dh, dw
         item.src_vertices, item.dst_vertices, item.rows, item.cols = sv_d, dv_d, rows, cols
+        late_job = None       # a numpy stream whose samples the generator adds to the chain's output (no plane)
         if noise_std is not None:
             if noise is not None:
                 raise ValueError('pass either a noise plane or noise_std / noise_seed')
-            item.noise = slot.device('noise', dh * dw * 3 * 2)
-            item.noise_stride_el = dw * 3
             stream = _native.np_stream(noise_rng) if noise_rng is not None else None
             if noise_rng is not None and stream is None:
                 # not a PCG64 generator (or VKX_HOST_RNG=1): the host draws, the plane travels
                 return self.submit_chain(image, state, blur_sigma, hue_delta,
                                          np.round(_clone_rng(noise_rng).normal(0, noise_std, (dh, dw, 3))).astype(np.int16), streak)
+            if stream is not None and streak is None:
+                # gaussion_noise is the chain's last member here: the pass that puts the samples at their final index adds
+                # them to the chain's output in place -- same pixels, no int16 plane written and read back
+                late_job = _native.np_job(_native.NP_NORMAL_ADD_U8, stream, dh * dw * 3, noise_std, src=item.dst, dst=item.dst)
+            else:
+                item.noise = slot.device('noise', dh * dw * 3 * 2)
+                item.noise_stride_el = dw * 3
             if stream is not None:
-                jobs = (_native.VkxNpJob * 1)(_native.np_job(_native.NP_NORMAL_I16, stream, dh * dw * 3, noise_std, dst=item.noise))
+                jobs = (_native.VkxNpJob * 1)(late_job if late_job is not None else
+                                              _native.np_job(_native.NP_NORMAL_I16, stream, dh * dw * 3, noise_std, dst=item.noise))
                 if slot.np_results is None:
                     slot.np_results = _native.NpResults(slot.ctx, 1)
                 results = slot.np_results
-                _native.check(_native.lib().vkx_np_draw_batch_dev(slot.ctx.handle, jobs, 1, results.array))
+                if late_job is None:
+                    _native.check(_native.lib().vkx_np_draw_batch_dev(slot.ctx.handle, jobs, 1, results.array))
 
                 def redo(image=image, state=state, stream=stream):
                     # the device declared a decision of this stream ambiguous in the last bits of exp / log1p: numpy draws
@@ -268,6 +278,9 @@ class HostPipeline:
             item.streak_alpha = float(streak.alpha)
         items = (_native.VkxChainItem * 1)(item)
         _native.check(_native.lib().vkx_chain_rgb_batch_dev(slot.ctx.handle, items, 1))
+        if late_job is not None:
+            jobs, results, _redo = slot.np_check
+            _native.check(_native.lib().vkx_np_draw_batch_dev(slot.ctx.handle, jobs, 1, results.array))
         return self._finish(slot, [(item.dst, (dh, dw, 3), np.uint8)])
 
     def submit_distortion(self, distortion, config_or_config_generator, image=None, mask=None, score_map=None, point=None,
