@@ -33,7 +33,7 @@ class ChainBatch:
         self._stream_noise = []      # (item index, std, (state, inc), samples, late): the caller's numpy stream drawn on the device
         self._stream_jobs = None     # [(VkxNpJob array, VkxNpResult array, [item index])] in chunks, built on the first run
         self._late_jobs = None       # the same for the images whose noise the generator adds after the chain
-        self.stream_chunk = 64       # planes per vkx_np_draw_batch_dev call (bounds the scratch of the two-pass draw)
+        self.stream_chunk = 4096     # planes per vkx_np_draw_batch_dev call (the library pipelines a call in chunks of 32 planes)
         self.stream_fallbacks = 0    # planes the device declared ambiguous and the host drew instead
         self._runs = 0
         self._page_layers = {}       # item index -> [VkxLayer with device planes]: assembled into the source before the chain

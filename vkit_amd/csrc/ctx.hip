@@ -68,7 +68,8 @@ VKX_EXPORT int vkx_ctx_destroy(vkx_ctx *ctx)
     for (auto &s : ctx->chain) scratch_release(&s);
     scratch_release(&ctx->noise_table);
     scratch_release(&ctx->np_tabs);
-    scratch_release(&ctx->np_work);
+    scratch_release(&ctx->np_work[0]);
+    scratch_release(&ctx->np_work[1]);
     for (auto &t : ctx->resize_tabs) scratch_release(&t.buf);
     for (auto &l : ctx->launches) { (void)hipEventDestroy(l.start); (void)hipEventDestroy(l.stop); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -364,6 +365,18 @@ VKX_EXPORT int vkx_ctx_order(vkx_ctx *ctx, int later_stream, int earlier_stream)
     VKX_HIP(hipEventRecord(e, earlier));
     VKX_HIP(hipStreamWaitEvent(later, e, 0));
     ctx->order_events.push_back(e);      // a recorded event may be re-recorded once the wait has been queued
+    return VKX_OK;
+}
+
+// `later` continues after everything queued on `earlier` so far (internal form of vkx_ctx_order on raw streams)
+int vkx_stream_order(vkx_ctx *ctx, hipStream_t later, hipStream_t earlier)
+{
+    if (later == earlier) return VKX_OK;
+    hipEvent_t e = take_order_event(ctx);
+    VKX_REQUIRE(e != nullptr, "hipEventCreate failed");
+    VKX_HIP(hipEventRecord(e, earlier));
+    VKX_HIP(hipStreamWaitEvent(later, e, 0));
+    ctx->order_events.push_back(e);
     return VKX_OK;
 }
 

@@ -1008,17 +1008,196 @@ static long long np_tiles_for(const vkx_np_job &j, bool uniform)
     return (draws + kTile - 1) / kTile;
 }
 
+// One chunk of a call: its tile arrays in one of the two scratch slots, its jobs, its slice of the results.
+struct NpChunk {
+    const vkx_np_job *jobs;
+    int n_jobs, kind, max_tiles, slot;
+    bool uniform, inline_jobs;
+    long long total_tiles;
+    vkx_np_result *results_host, *res_mapped;
+    unsigned char *base;
+    size_t o_states, o_info, o_plan, o_rmask, o_rval, o_jobs, o_results;
+    NpJobPack pack;
+    const NpTabs *tabs;
+};
+
+static int np_chunk_prepare(vkx_ctx *ctx, NpChunk &c)
+{
+    const bool uniform = c.uniform;
+    c.total_tiles = 0;
+    c.max_tiles = 0;
+    for (int i = 0; i < c.n_jobs; i++) {
+        const long long tiles = np_tiles_for(c.jobs[i], uniform);
+        c.max_tiles = std::max<int>(c.max_tiles, (int)tiles);
+        c.total_tiles += tiles;
+    }
+    size_t off = 0;
+    auto take = [&off](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    c.o_states = take((size_t)c.total_tiles * 16);
+    c.o_info = take(uniform ? 0 : (size_t)c.total_tiles * sizeof(TileInfo));
+    c.o_plan = take(uniform ? 0 : (size_t)c.total_tiles * sizeof(TilePlan));
+    const size_t val_bytes = c.kind == VKX_NP_SPECKLE_U8 ? 8 : 2;
+    c.o_rmask = take(uniform ? 0 : (size_t)c.total_tiles * kRounds * 8);
+    c.o_rval = take(uniform ? 0 : (size_t)c.total_tiles * kTile * val_bytes);
+    c.o_jobs = take((size_t)c.n_jobs * sizeof(NpJob));
+    c.o_results = take((size_t)c.n_jobs * sizeof(vkx_np_result) + sizeof(unsigned));    // + the completion counter
+    int rc = vkx_scratch_reserve(ctx, &ctx->np_work[c.slot], off);
+    if (rc) return rc;
+    c.base = (unsigned char *)ctx->np_work[c.slot].ptr;
+
+    // the device forms of the jobs: in the kernel arguments of the first kernel (small calls) or through the ctx ring
+    c.inline_jobs = c.n_jobs <= kInlineJobs;
+    NpJob *hj = c.pack.jobs;
+    if (!c.inline_jobs) {
+        void *ring = nullptr;
+        if ((rc = vkx_desc_ring_take(ctx, (size_t)c.n_jobs * sizeof(NpJob), &ring))) return rc;
+        hj = (NpJob *)ring;
+    }
+    const u128 g64 = ((u128)g_jump_host.g64[1] << 64) | g_jump_host.g64[0];
+    const u128 g128 = ((u128)g_jump_host.g128[1] << 64) | g_jump_host.g128[0];
+    long long tile_base = 0;
+    for (int i = 0; i < c.n_jobs; i++) {
+        const vkx_np_job &j = c.jobs[i];
+        NpJob &d = hj[i];
+        d.state[0] = j.state[0]; d.state[1] = j.state[1];
+        d.inc[0] = j.inc[0]; d.inc[1] = j.inc[1];
+        const u128 c64 = (((u128)j.inc[1] << 64) | j.inc[0]) * g64;
+        d.c64[0] = (uint64_t)c64; d.c64[1] = (uint64_t)(c64 >> 64);
+        const u128 c128 = (((u128)j.inc[1] << 64) | j.inc[0]) * g128;
+        d.c128[0] = (uint64_t)c128; d.c128[1] = (uint64_t)(c128 >> 64);
+        d.n = j.n;
+        d.tile_base = tile_base;
+        d.n_tiles = (int)np_tiles_for(j, uniform);
+        tile_base += d.n_tiles;
+        d.kind = j.kind & 0xff; d.cn = j.cn;
+        d.margin = (j.kind & VKX_NP_DEBUG_WIDE_MARGIN) ? 1.0 : 0x1p-42;
+        d.loc = 0.0; d.scale = j.scale;
+        d.cdf[0] = j.cdf[0]; d.cdf[1] = j.cdf[1]; d.cdf[2] = j.cdf[2];
+        d.src = (const uint8_t *)j.src;
+        d.dst = j.dst;
+    }
+    if (!c.inline_jobs && (rc = vkx_small_to_device(ctx, c.base + c.o_jobs, hj, (size_t)c.n_jobs * sizeof(NpJob)))) return rc;
+    // page-locked results: the chunk's last kernel writes them through the mapping
+    c.res_mapped = nullptr;
+    if (hipHostGetDevicePointer((void **)&c.res_mapped, c.results_host, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        c.res_mapped = nullptr;
+    }
+    return VKX_OK;
+}
+
+// tile states + the draw pass (VALU bound); the uniform kinds are complete after it.  On ctx->stream.
+static int np_chunk_front(vkx_ctx *ctx, NpChunk &c)
+{
+    unsigned char *base = c.base;
+    const NpJob *dj = (const NpJob *)(base + c.o_jobs);
+    uint64_t *states = (uint64_t *)(base + c.o_states);
+    TileInfo *info = (TileInfo *)(base + c.o_info);
+    vkx_np_result *res = (vkx_np_result *)(base + c.o_results);
+    unsigned *done = (unsigned *)(res + c.n_jobs);
+    const long long total_tiles = c.total_tiles;
+    const int n_jobs = c.n_jobs, kind = c.kind;
+    const NpTabs *tabs = c.tabs;
+    // workgroups of a few tiles per wavefront: a chunk's draw shares the device with the placement pass of the chunk before it
+    // (2 048 persistent workgroups -- two generations of the 4 096 wavefronts the device holds -- measured 8.3 ms per 256
+    // planes, workgroups of 4 tiles per wavefront 7.5 ms: the dispatcher balances them, and the placement pass gets slots)
+    static const int tiles_per_wave = [] { const char *e = getenv("VKX_NP_TPW"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }();
+    const unsigned wg = (unsigned)((total_tiles + 4 * tiles_per_wave - 1) / (4 * tiles_per_wave));
+    {
+        VKX_TIMED(ctx, "k_np_tile_states");
+        if (c.inline_jobs)
+            k_np_tile_states<true><<<vkx_blocks((size_t)total_tiles, 256), 256, 0, ctx->stream>>>(dj, c.pack, n_jobs, total_tiles, states, (NpJob *)(base + c.o_jobs), res, done, tabs);
+        else
+            k_np_tile_states<false><<<vkx_blocks((size_t)total_tiles, 256), 256, 0, ctx->stream>>>(dj, c.pack, n_jobs, total_tiles, states, (NpJob *)(base + c.o_jobs), res, done, tabs);
+        VKX_LAUNCH_CHECK();
+    }
+    if (c.uniform) {
+        VKX_TIMED(ctx, "k_np_choice_impulse");
+        k_np_choice_impulse<<<wg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, res, done, c.res_mapped, tabs);
+        VKX_LAUNCH_CHECK();
+        return VKX_OK;
+    }
+    uint64_t *rmask = (uint64_t *)(base + c.o_rmask);
+    void *rval = base + c.o_rval;
+    VKX_TIMED(ctx, "k_np_draw");
+    if (kind == VKX_NP_SPECKLE_U8)
+        k_np_draw<EmitSpeckle><<<wg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, (double *)rval, rmask, res, tabs);
+    else if (kind == VKX_NP_NORMAL_ADD_U8)
+        k_np_draw<EmitAddU8><<<wg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, (int16_t *)rval, rmask, res, tabs);
+    else
+        k_np_draw<EmitI16><<<wg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, (int16_t *)rval, rmask, res, tabs);
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
+// resolve + place + walk (memory / latency bound) and the results.  On ctx->stream.
+static int np_chunk_back(vkx_ctx *ctx, NpChunk &c)
+{
+    if (c.uniform) {
+        if (!c.res_mapped)
+            VKX_HIP(hipMemcpyAsync(c.results_host, c.base + c.o_results, (size_t)c.n_jobs * sizeof(vkx_np_result), hipMemcpyDeviceToHost, ctx->stream));
+        return VKX_OK;
+    }
+    unsigned char *base = c.base;
+    const NpJob *dj = (const NpJob *)(base + c.o_jobs);
+    uint64_t *states = (uint64_t *)(base + c.o_states);
+    TileInfo *info = (TileInfo *)(base + c.o_info);
+    TilePlan *plan = (TilePlan *)(base + c.o_plan);
+    vkx_np_result *res = (vkx_np_result *)(base + c.o_results);
+    unsigned *done = (unsigned *)(res + c.n_jobs);
+    uint64_t *rmask = (uint64_t *)(base + c.o_rmask);
+    void *rval = base + c.o_rval;
+    const long long total_tiles = c.total_tiles;
+    const int n_jobs = c.n_jobs, kind = c.kind;
+    const NpTabs *tabs = c.tabs;
+    {
+        VKX_TIMED(ctx, "k_np_resolve");
+        const size_t bits = (((size_t)c.max_tiles + 63) / 64) * 8;
+        k_np_resolve<<<n_jobs, 1024, bits, ctx->stream>>>(dj, states, info, plan, res, tabs);
+        VKX_LAUNCH_CHECK();
+    }
+    {
+        VKX_TIMED(ctx, "k_np_place");
+        const unsigned pg = vkx_blocks((size_t)total_tiles, 4);
+        if (kind == VKX_NP_SPECKLE_U8)
+            k_np_place<EmitSpeckle><<<pg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, info, plan, (const double *)rval, rmask, res);
+        else if (kind == VKX_NP_NORMAL_ADD_U8)
+            k_np_place<EmitAddU8><<<pg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, info, plan, (const int16_t *)rval, rmask, res);
+        else
+            k_np_place<EmitI16><<<pg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, info, plan, (const int16_t *)rval, rmask, res);
+        VKX_LAUNCH_CHECK();
+    }
+    {
+        VKX_TIMED(ctx, "k_np_place_walk");
+        const unsigned wg2 = (unsigned)std::min<long long>((total_tiles + 255) / 256, 256 * 4);
+        if (kind == VKX_NP_SPECKLE_U8)
+            k_np_place_walk<EmitSpeckle><<<wg2, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, done, c.res_mapped, tabs);
+        else if (kind == VKX_NP_NORMAL_ADD_U8)
+            k_np_place_walk<EmitAddU8><<<wg2, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, done, c.res_mapped, tabs);
+        else
+            k_np_place_walk<EmitI16><<<wg2, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, done, c.res_mapped, tabs);
+        VKX_LAUNCH_CHECK();
+    }
+    if (!c.res_mapped)
+        VKX_HIP(hipMemcpyAsync(c.results_host, res, (size_t)n_jobs * sizeof(vkx_np_result), hipMemcpyDeviceToHost, ctx->stream));
+    return VKX_OK;
+}
+
 // Every job is one generator stream.  The jobs of one call are all of the normal family and of ONE kind, or all of the
 // uniform family.  Asynchronous on the ctx stream: `results_host` (page-locked for a truly asynchronous copy) is valid
 // after the stream has been synchronised.
+// A large call runs as chunks of kChunkJobs jobs in software-pipelined form: the draw pass of a chunk (VALU bound) on the
+// ctx stream, its resolve / place / walk passes (HBM and latency bound) on the context's second stream, so that the
+// placement of chunk c shares the device with the draw of chunk c + 1; the tile arrays of consecutive chunks alternate
+// between two scratch slots, and the ctx stream continues after the last chunk has been placed.
+constexpr int kChunkJobs = 32;
+
 VKX_EXPORT int vkx_np_draw_batch_dev(vkx_ctx *ctx, const vkx_np_job *jobs, int n_jobs, vkx_np_result *results_host)
 {
     VKX_REQUIRE(ctx && jobs && results_host, "NULL argument");
     VKX_REQUIRE(n_jobs >= 1 && n_jobs <= 65535, "1 .. 65535 jobs per call");
     const int kind = jobs[0].kind & 0xff;
     const bool uniform = kind == VKX_NP_CHOICE3_U8 || kind == VKX_NP_IMPULSE_U8;
-    long long total_tiles = 0;
-    int max_tiles = 0;
     for (int i = 0; i < n_jobs; i++) {
         const vkx_np_job &j = jobs[i];
         VKX_REQUIRE(j.n >= 1 && j.n <= 0x7fffffffLL, "1 .. 2^31 - 1 samples per job");
@@ -1044,131 +1223,48 @@ VKX_EXPORT int vkx_np_draw_batch_dev(vkx_ctx *ctx, const vkx_np_job *jobs, int n
             VKX_REQUIRE(false, "unknown job kind");
         }
         if (!uniform) VKX_REQUIRE(j.scale >= 0.0 && j.scale < 400.0, "scale outside [0, 400)");   // |z| < 40: int16 holds it
-        const long long tiles = np_tiles_for(j, uniform);
-        VKX_REQUIRE(tiles <= 262144, "stream too long for one job (2.6e8 samples)");
-        max_tiles = std::max<int>(max_tiles, (int)tiles);
-        total_tiles += tiles;
+        VKX_REQUIRE(np_tiles_for(j, uniform) <= 262144, "stream too long for one job (2.6e8 samples)");
     }
     const NpTabs *tabs = nullptr;
     int rc = np_tables(ctx, &tabs);
     if (rc) return rc;
-
-    size_t off = 0;
-    auto take = [&off](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t o_states = take((size_t)total_tiles * 16);
-    const size_t o_info = take(uniform ? 0 : (size_t)total_tiles * sizeof(TileInfo));
-    const size_t o_plan = take(uniform ? 0 : (size_t)total_tiles * sizeof(TilePlan));
-    const size_t val_bytes = kind == VKX_NP_SPECKLE_U8 ? 8 : 2;
-    const size_t o_rmask = take(uniform ? 0 : (size_t)total_tiles * kRounds * 8);
-    const size_t o_rval = take(uniform ? 0 : (size_t)total_tiles * kTile * val_bytes);
-    const size_t o_jobs = take((size_t)n_jobs * sizeof(NpJob));
-    const size_t o_results = take((size_t)n_jobs * sizeof(vkx_np_result) + sizeof(unsigned));    // + the completion counter
-    rc = vkx_scratch_reserve(ctx, &ctx->np_work, off);
-    if (rc) return rc;
-    unsigned char *base = (unsigned char *)ctx->np_work.ptr;
-
-    // the device forms of the jobs: in the kernel arguments of the first kernel (small calls) or through the ctx ring
-    NpJobPack pack;
-    const bool inline_jobs = n_jobs <= kInlineJobs;
-    NpJob *hj = pack.jobs;
-    if (!inline_jobs) {
-        void *ring = nullptr;
-        if ((rc = vkx_desc_ring_take(ctx, (size_t)n_jobs * sizeof(NpJob), &ring))) return rc;
-        hj = (NpJob *)ring;
-    }
-    const u128 g64 = ((u128)g_jump_host.g64[1] << 64) | g_jump_host.g64[0];
-    const u128 g128 = ((u128)g_jump_host.g128[1] << 64) | g_jump_host.g128[0];
-    long long tile_base = 0;
-    for (int i = 0; i < n_jobs; i++) {
-        const vkx_np_job &j = jobs[i];
-        NpJob &d = hj[i];
-        d.state[0] = j.state[0]; d.state[1] = j.state[1];
-        d.inc[0] = j.inc[0]; d.inc[1] = j.inc[1];
-        const u128 c64 = (((u128)j.inc[1] << 64) | j.inc[0]) * g64;
-        d.c64[0] = (uint64_t)c64; d.c64[1] = (uint64_t)(c64 >> 64);
-        const u128 c128 = (((u128)j.inc[1] << 64) | j.inc[0]) * g128;
-        d.c128[0] = (uint64_t)c128; d.c128[1] = (uint64_t)(c128 >> 64);
-        d.n = j.n;
-        d.tile_base = tile_base;
-        d.n_tiles = (int)np_tiles_for(j, uniform);
-        tile_base += d.n_tiles;
-        d.kind = j.kind & 0xff; d.cn = j.cn;
-        d.margin = (j.kind & VKX_NP_DEBUG_WIDE_MARGIN) ? 1.0 : 0x1p-42;
-        d.loc = 0.0; d.scale = j.scale;
-        d.cdf[0] = j.cdf[0]; d.cdf[1] = j.cdf[1]; d.cdf[2] = j.cdf[2];
-        d.src = (const uint8_t *)j.src;
-        d.dst = j.dst;
-    }
     vkx_device_guard guard(ctx);
-    if (!inline_jobs && (rc = vkx_small_to_device(ctx, base + o_jobs, hj, (size_t)n_jobs * sizeof(NpJob)))) return rc;
-    const NpJob *dj = (const NpJob *)(base + o_jobs);
-    uint64_t *states = (uint64_t *)(base + o_states);
-    TileInfo *info = (TileInfo *)(base + o_info);
-    TilePlan *plan = (TilePlan *)(base + o_plan);
-    vkx_np_result *res = (vkx_np_result *)(base + o_results);
-    unsigned *done = (unsigned *)(res + n_jobs);
-    // page-locked results: the call's last kernel writes them through the mapping
-    vkx_np_result *res_mapped = nullptr;
-    if (hipHostGetDevicePointer((void **)&res_mapped, results_host, 0) != hipSuccess) {
-        (void)hipGetLastError();
-        res_mapped = nullptr;
+    static const bool pipelined = [] { const char *e = getenv("VKX_NP_PIPELINE"); return !(e && e[0] == '0'); }();
+    const int n_chunks = (!uniform && pipelined && n_jobs >= 2 * kChunkJobs) ? (n_jobs + kChunkJobs - 1) / kChunkJobs : 1;
+    auto chunk_of = [&](int k, NpChunk &c) {
+        const int per = (n_jobs + n_chunks - 1) / n_chunks, first = k * per;
+        c.jobs = jobs + first;
+        c.n_jobs = std::min(per, n_jobs - first);
+        c.kind = kind; c.uniform = uniform; c.slot = k & 1;
+        c.results_host = results_host + first;
+        c.tabs = tabs;
+    };
+    if (n_chunks == 1) {
+        NpChunk c;
+        chunk_of(0, c);
+        if ((rc = np_chunk_prepare(ctx, c)) || (rc = np_chunk_front(ctx, c))) return rc;
+        return np_chunk_back(ctx, c);
     }
-    const unsigned wg = (unsigned)std::min<long long>((total_tiles + 3) / 4, 256 * 8);
-    {
-        VKX_TIMED(ctx, "k_np_tile_states");
-        if (inline_jobs)
-            k_np_tile_states<true><<<vkx_blocks((size_t)total_tiles, 256), 256, 0, ctx->stream>>>(dj, pack, n_jobs, total_tiles, states, (NpJob *)(base + o_jobs), res, done, tabs);
-        else
-            k_np_tile_states<false><<<vkx_blocks((size_t)total_tiles, 256), 256, 0, ctx->stream>>>(dj, pack, n_jobs, total_tiles, states, (NpJob *)(base + o_jobs), res, done, tabs);
-        VKX_LAUNCH_CHECK();
+    hipStream_t main_stream = ctx->stream;
+    hipStream_t aux = vkx_stream_by_id(ctx, VKX_STREAM_COPY_IN, &rc);
+    if (rc) return rc;
+    std::vector<hipEvent_t> placed(n_chunks, nullptr);
+    for (int k = 0; k < n_chunks; k++) {
+        NpChunk c;
+        chunk_of(k, c);
+        // the slot's previous tenant (chunk k - 2) must have been placed before its arrays are overwritten
+        if (k >= 2) VKX_HIP(hipStreamWaitEvent(main_stream, placed[k - 2], 0));
+        if ((rc = np_chunk_prepare(ctx, c)) || (rc = np_chunk_front(ctx, c))) return rc;
+        if ((rc = vkx_stream_order(ctx, aux, main_stream))) return rc;
+        ctx->stream = aux;
+        rc = np_chunk_back(ctx, c);
+        ctx->stream = main_stream;
+        if (rc) return rc;
+        VKX_HIP(hipEventCreateWithFlags(&placed[k], hipEventDisableTiming));
+        VKX_HIP(hipEventRecord(placed[k], aux));
     }
-    if (uniform) {
-        VKX_TIMED(ctx, "k_np_choice_impulse");
-        k_np_choice_impulse<<<wg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, res, done, res_mapped, tabs);
-        VKX_LAUNCH_CHECK();
-    } else {
-        uint64_t *rmask = (uint64_t *)(base + o_rmask);
-        void *rval = base + o_rval;
-        {
-            VKX_TIMED(ctx, "k_np_draw");
-            if (kind == VKX_NP_SPECKLE_U8)
-                k_np_draw<EmitSpeckle><<<wg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, (double *)rval, rmask, res, tabs);
-            else if (kind == VKX_NP_NORMAL_ADD_U8)
-                k_np_draw<EmitAddU8><<<wg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, (int16_t *)rval, rmask, res, tabs);
-            else
-                k_np_draw<EmitI16><<<wg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, (int16_t *)rval, rmask, res, tabs);
-            VKX_LAUNCH_CHECK();
-        }
-        {
-            VKX_TIMED(ctx, "k_np_resolve");
-            const size_t bits = (((size_t)max_tiles + 63) / 64) * 8;
-            k_np_resolve<<<n_jobs, 1024, bits, ctx->stream>>>(dj, states, info, plan, res, tabs);
-            VKX_LAUNCH_CHECK();
-        }
-        {
-            VKX_TIMED(ctx, "k_np_place");
-            const unsigned pg = vkx_blocks((size_t)total_tiles, 4);
-            if (kind == VKX_NP_SPECKLE_U8)
-                k_np_place<EmitSpeckle><<<pg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, info, plan, (const double *)rval, rmask, res);
-            else if (kind == VKX_NP_NORMAL_ADD_U8)
-                k_np_place<EmitAddU8><<<pg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, info, plan, (const int16_t *)rval, rmask, res);
-            else
-                k_np_place<EmitI16><<<pg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, info, plan, (const int16_t *)rval, rmask, res);
-            VKX_LAUNCH_CHECK();
-        }
-        {
-            VKX_TIMED(ctx, "k_np_place_walk");
-            const unsigned wg2 = (unsigned)std::min<long long>((total_tiles + 255) / 256, 256 * 4);
-            if (kind == VKX_NP_SPECKLE_U8)
-                k_np_place_walk<EmitSpeckle><<<wg2, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, done, res_mapped, tabs);
-            else if (kind == VKX_NP_NORMAL_ADD_U8)
-                k_np_place_walk<EmitAddU8><<<wg2, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, done, res_mapped, tabs);
-            else
-                k_np_place_walk<EmitI16><<<wg2, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, done, res_mapped, tabs);
-            VKX_LAUNCH_CHECK();
-        }
-    }
-    if (!res_mapped) VKX_HIP(hipMemcpyAsync(results_host, res, (size_t)n_jobs * sizeof(vkx_np_result), hipMemcpyDeviceToHost, ctx->stream));
+    for (int k = std::max(0, n_chunks - 2); k < n_chunks; k++) VKX_HIP(hipStreamWaitEvent(main_stream, placed[k], 0));
+    for (hipEvent_t e : placed) (void)hipEventDestroy(e);      // destruction is deferred until the event has completed
     return VKX_OK;
 }
 

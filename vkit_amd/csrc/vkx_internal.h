@@ -61,7 +61,7 @@ struct vkx_ctx {
     double noise_table_std = 0.0;
     bool noise_table_fits8 = false;
     vkx_scratch np_tabs;              // jump constants + ziggurat tables of the numpy streams (nprand.hip), uploaded once
-    vkx_scratch np_work;              // per-call tile arrays of the numpy streams
+    vkx_scratch np_work[2];           // tile arrays of the numpy streams: the chunks of a call alternate (nprand.hip)
 
     // Host-array pipelines: two copy streams next to the compute stream (created on first use), a pool of events that
     // order them, and a page-locked ring through which the launch descriptors of the tile kernels reach the device
@@ -128,6 +128,7 @@ int vkx_desc_ring_take(vkx_ctx *ctx, size_t bytes, void **hptr);
 int vkx_small_to_device(vkx_ctx *ctx, void *dev, const void *ring_host, size_t bytes);
 int vkx_small_to_host(vkx_ctx *ctx, void *host, const void *dev, size_t bytes);
 hipStream_t vkx_stream_by_id(vkx_ctx *ctx, int id, int *rc);
+int vkx_stream_order(vkx_ctx *ctx, hipStream_t later, hipStream_t earlier);
 
 // Plane copies between host and device staging: hipMemcpy2DAsync is an order of magnitude slower than a linear copy on
 // this stack (12 ms instead of 1 ms for a 2048^2 RGB plane), so planes whose rows follow each other without gaps -- every
