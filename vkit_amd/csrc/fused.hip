@@ -189,16 +189,16 @@ __global__ void __launch_bounds__(64) k_chain_setup_svd(const ItemDev *__restric
                                                         int n_items, vkc::CellC *__restrict__ cells,
                                                         const int *__restrict__ deferred)
 {
-    __shared__ double ws[64 * vkc::kJacobiWs];   // 76 KB: the solver's workspace lives in LDS, the launch is scratch free
+    // eight lanes per cell (vkc::homography_jacobi_group8): registers only, no workspace
     const int n = deferred[0];
-    for (int j = blockIdx.x * 64 + threadIdx.x; j < n; j += gridDim.x * 64) {
+    const int sub = threadIdx.x & 7;
+    for (int j = blockIdx.x * 8 + (threadIdx.x >> 3); j < n; j += gridDim.x * 8) {
         const int gid = deferred[1 + j];
         const ItemDev &it = items[find_item(cell_prefix, n_items, gid)];
         vkc::CellC rec;
         int xmin, xmax, ymin, ymax;
-        vkc::build_cell<vkc::kCellJacobiWorkspace>(it.sv, it.dv, it.rows, it.cols, gid - it.cell_base, rec, xmin, xmax, ymin, ymax,
-                              ws + threadIdx.x * vkc::kJacobiWs);
-        cells[gid] = rec;
+        vkc::build_cell<vkc::kCellJacobiGroup8>(it.sv, it.dv, it.rows, it.cols, gid - it.cell_base, rec, xmin, xmax, ymin, ymax);
+        if (sub == 0) cells[gid] = rec;
     }
 }
 
@@ -1137,7 +1137,7 @@ static int launch_tiles(vkx_ctx *ctx, std::vector<ItemDev> &dev, std::vector<int
     }
     { VKX_TIMED(ctx, "k_chain_setup"); k_chain_setup<<<vkx_blocks((size_t)ncells, 256), 256, 0, ctx->stream>>>(d_items, d_cell_prefix, n_items, (int)ncells, slots, cells, bins, deferred); }
     VKX_LAUNCH_CHECK();
-    { VKX_TIMED(ctx, "k_chain_setup_svd"); k_chain_setup_svd<<<16, 64, 0, ctx->stream>>>(d_items, d_cell_prefix, n_items, cells, deferred); }
+    { VKX_TIMED(ctx, "k_chain_setup_svd"); k_chain_setup_svd<<<128, 64, 0, ctx->stream>>>(d_items, d_cell_prefix, n_items, cells, deferred); }
     VKX_LAUNCH_CHECK();
     // profiling aids: VKX_FUSED_PHASES=1|2 stops the kernel after phase A | C+D, 10..13 inside phase A (tools/phases_a.sh),
     // 20 writes the horizontal sums of the centre row instead of the finished pixel

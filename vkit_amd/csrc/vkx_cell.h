@@ -169,6 +169,117 @@ __device__ __forceinline__ void homography_jacobi_ws(const float from[8], const 
     H[8] = 1.;
 }
 
+// The same solver run by EIGHT lanes per system (lane k of the group holds column k of A^T and of V^T in registers; the
+// singular values W are replicated): rotations update their sixteen elements in parallel, and every sum the scalar code
+// accumulates over k is accumulated in the same order from the same 0.0 -- the eight addends are fetched from the group's
+// lanes and added one after the other -- so the result is the scalar solver's bit for bit.  The pair loop is unrolled: no
+// indexed register, no LDS workspace (the one-lane form keeps 152 doubles in LDS and pays its latency on every access).
+// All eight lanes of a group must be active; every lane returns the whole H.
+__device__ __forceinline__ double group_sum8(double t)
+{
+    double s = 0.0;                          // the scalar loop's order: 0 + t[0] + t[1] + ... + t[7]
+#pragma unroll
+    for (int k = 0; k < 8; k++) s += __shfl(t, k, 8);
+    return s;
+}
+__device__ inline void homography_jacobi_group8(const float from[8], const float to[8], double H[9])
+{
+    const int k = (int)(threadIdx.x & 7);          // this lane's column (equation)
+    const int pt = k & 3;
+    const float fx = from[2 * pt], fy = from[2 * pt + 1], tx = to[2 * pt], ty = to[2 * pt + 1];
+    const bool low = k < 4;
+    double At[8], Vt[8], W[8];
+    At[0] = low ? fx : 0; At[1] = low ? fy : 0; At[2] = low ? 1 : 0;
+    At[3] = low ? 0 : fx; At[4] = low ? 0 : fy; At[5] = low ? 0 : 1;
+    At[6] = low ? (double)(-fx * tx) : (double)(-fx * ty);      // float products, as cv::Point2f arithmetic forms them
+    At[7] = low ? (double)(-fy * tx) : (double)(-fy * ty);
+    const double b = low ? tx : ty;
+    const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        W[i] = group_sum8(At[i] * At[i]);
+        Vt[i] = i == k ? 1 : 0;
+    }
+    bool active = true;
+    for (int iter = 0; iter < 30; iter++) {
+        if (active) {
+            bool changed = false;
+#pragma unroll
+            for (int i = 0; i < 7; i++)
+#pragma unroll
+                for (int j = i + 1; j < 8; j++) {
+                    double a = W[i], bb = W[j];
+                    double p = group_sum8(At[i] * At[j]);
+                    if (!(fabs(p) <= eps * sqrt(a * bb))) {
+                        double c, sn;
+                        p *= 2;
+                        const double beta = a - bb, gamma = vk_hypot(p, beta);
+                        if (beta < 0) {
+                            const double delta = (gamma - beta) * 0.5;
+                            sn = sqrt(delta / gamma);
+                            c = p / (gamma * sn * 2);
+                        } else {
+                            c = sqrt((gamma + beta) / (gamma * 2));
+                            sn = p / (gamma * c * 2);
+                        }
+                        const double t0 = c * At[i] + sn * At[j];
+                        const double t1 = -sn * At[i] + c * At[j];
+                        At[i] = t0; At[j] = t1;
+                        W[i] = group_sum8(t0 * t0);
+                        W[j] = group_sum8(t1 * t1);
+                        changed = true;
+                        const double v0 = c * Vt[i] + sn * Vt[j];
+                        const double v1 = -sn * Vt[i] + c * Vt[j];
+                        Vt[i] = v0; Vt[j] = v1;
+                    }
+                }
+            if (!changed) active = false;
+        }
+        if (!__any(active)) break;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) W[i] = sqrt(group_sum8(At[i] * At[i]));
+    // selection sort, descending (strict <, first maximum wins): the row swaps as predicated exchanges -- the rows are
+    // registers, so the value of W[j] travels beside the runtime index j
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        int j = i;
+        double wj = W[i];
+#pragma unroll
+        for (int q = i + 1; q < 8; q++)
+            if (wj < W[q]) { j = q; wj = W[q]; }
+#pragma unroll
+        for (int q = i + 1; q < 8; q++)
+            if (j == q) {
+                double t = W[i]; W[i] = W[q]; W[q] = t;
+                t = At[i]; At[i] = At[q]; At[q] = t;
+                t = Vt[i]; Vt[i] = Vt[q]; Vt[q] = t;
+            }
+    }
+    double threshold = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const double sd = W[i];
+        const double s = sd > minval ? 1 / sd : 0.;
+        At[i] *= s;
+        threshold += W[i];
+    }
+    threshold *= DBL_EPSILON * 2;
+    double x = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        double wi = W[i];
+        if (fabs(wi) <= threshold) continue;
+        wi = 1 / wi;
+        double acc = group_sum8(At[i] * b);
+        acc *= wi;
+        x = x + acc * Vt[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) H[i] = __shfl(x, i, 8);
+    H[8] = 1.;
+}
+
 __device__ __noinline__ void homography_jacobi(const float from[8], const float to[8], double H[9])
 {
     double ws[kJacobiWs];
@@ -200,7 +311,7 @@ static_assert(sizeof(CellC) == 128, "CellC layout");
 // Builds the record of cell `cell` (row-major index over (rows-1) x (cols-1)) and returns its bounding box.
 // MODE kCellDirectOnly: the closed-form solver only; returns false (record incomplete) when the cell's quads are
 // not in general position, so that a caller can leave the register-hungry SVD to a second, rarely busy kernel.
-enum { kCellDirectOnly = 0, kCellJacobiPrivate = 1, kCellJacobiWorkspace = 2 };
+enum { kCellDirectOnly = 0, kCellJacobiPrivate = 1, kCellJacobiWorkspace = 2, kCellJacobiGroup8 = 3 };
 template <int MODE = kCellJacobiPrivate>
 __device__ inline bool build_cell(const int32_t *__restrict__ src_v, const int32_t *__restrict__ dst_v, int rows, int cols,
                                   int cell, CellC &rec, int &xmin, int &xmax, int &ymin, int &ymax,
@@ -225,7 +336,8 @@ __device__ inline bool build_cell(const int32_t *__restrict__ src_v, const int32
     }
     if (!homography_direct(qf, qt, H)) {
         if (MODE == kCellDirectOnly) return false;
-        if (MODE == kCellJacobiWorkspace) homography_jacobi_ws(from, to, H, jacobi_ws);
+        if (MODE == kCellJacobiGroup8) homography_jacobi_group8(from, to, H);      // all 8 lanes of the group are here
+        else if (MODE == kCellJacobiWorkspace) homography_jacobi_ws(from, to, H, jacobi_ws);
         else homography_jacobi(from, to, H);
     }
     for (int i = 0; i < 8; i++) rec.H[i] = H[i];
