@@ -172,6 +172,47 @@ def test_batch_of_streams_device_resident():
         ctx.free(bufs[i])
 
 
+def test_large_call_runs_in_pipelined_chunks():
+    """A call of 64 jobs or more runs as chunks of 32 on two streams with alternating scratch slots (nprand.hip): ragged
+    streams, int16 planes and the in-place add onto uint8 pixels, results through a page-locked buffer (written by the last
+    workgroup of each chunk) and through a pageable one (copied back), twice in a row on the same context."""
+    ctx = N.default_ctx()
+    rng = np.random.default_rng(77)
+    B = 83
+    sizes = [int(v) for v in rng.integers(1, 400_000, B)]
+    sizes[5], sizes[40], sizes[82] = 1, 1024, 1_500_001
+    stds = [float(v) for v in rng.uniform(0.5, 30.0, B)]
+    for kind in (N.NP_NORMAL_I16, N.NP_NORMAL_ADD_U8):
+        for pinned in (True, False):
+            jobs = (N.VkxNpJob * B)()
+            res = N.NpResults(ctx, B) if pinned else None
+            res_array = res.array if pinned else (N.VkxNpResult * B)()
+            planes, pixels = [], []
+            for i in range(B):
+                if kind == N.NP_NORMAL_I16:
+                    d = ctx.dev_empty((sizes[i],), np.int16)
+                    jobs[i] = N.np_job(kind, N.np_stream(np.random.default_rng(300 + i)), sizes[i], stds[i], dst=d.ptr)
+                else:
+                    px = np.random.default_rng(900 + i).integers(0, 256, sizes[i], dtype=np.uint8)
+                    d = ctx.to_device(px)
+                    pixels.append(px)
+                    jobs[i] = N.np_job(kind, N.np_stream(np.random.default_rng(300 + i)), sizes[i], stds[i], src=d.ptr, dst=d.ptr)
+                planes.append(d)
+            for _rep in range(2 if kind == N.NP_NORMAL_I16 else 1):
+                N.check(N.lib().vkx_np_draw_batch_dev(ctx.handle, jobs, B, res_array))
+            ctx.sync()
+            for i in range(B):
+                ref = np.random.default_rng(300 + i)
+                noise = np.round(ref.normal(0, stds[i], sizes[i])).astype(np.int16)
+                got = planes[i].host()
+                if kind == N.NP_NORMAL_I16:
+                    assert (got == noise).all(), (i, sizes[i])
+                else:
+                    assert (got == np.clip(pixels[i].astype(np.int16) + noise, 0, 255).astype(np.uint8)).all(), (i, sizes[i])
+                assert res_array[i].flags == 0 and res_array[i].samples >= sizes[i]
+                assert N.pcg64_jump(*N.np_stream(np.random.default_rng(300 + i)), res_array[i].draws) == ref.bit_generator.state['state']['state']
+
+
 def test_a_billion_samples():
     """>= 1e9 samples over seeds / lengths / deviations, every one compared with numpy (about a minute of host draws)."""
     ctx = N.default_ctx()
