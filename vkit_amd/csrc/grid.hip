@@ -177,7 +177,10 @@ __global__ void __launch_bounds__(64) k_project_points(const int32_t *__restrict
                                                        const double *__restrict__ pts_s, int n, double *__restrict__ out,
                                                        int *__restrict__ bad)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // eight lanes per point: a cell whose quads are not in general position is solved by the eight-lane Jacobi solver
+    // (vkc::homography_jacobi_group8: registers only, no scratch segment); the closed form is computed by all eight alike
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const bool writer = (threadIdx.x & 7) == 0;
     if (i >= n) return;
     const int px = pts_i[2 * i], py = pts_i[2 * i + 1];
     // python floor division
@@ -185,8 +188,10 @@ __global__ void __launch_bounds__(64) k_project_points(const int32_t *__restrict
     if (py % grid_size != 0 && (py < 0) != (grid_size < 0)) r--;
     if (px % grid_size != 0 && (px < 0) != (grid_size < 0)) c--;
     if (r < 0 || c < 0 || r >= rows - 1 || c >= cols - 1) {      // the reference indexes out of its cell table here
-        atomicExch(bad, i + 1);
-        out[2 * i] = 0.0; out[2 * i + 1] = 0.0;
+        if (writer) {
+            atomicExch(bad, i + 1);
+            out[2 * i] = 0.0; out[2 * i + 1] = 0.0;
+        }
         return;
     }
     const int idx[4] = {r * cols + c, r * cols + c + 1, (r + 1) * cols + c + 1, (r + 1) * cols + c};
@@ -198,7 +203,8 @@ __global__ void __launch_bounds__(64) k_project_points(const int32_t *__restrict
         qf[2 * k] = from[2 * k]; qf[2 * k + 1] = from[2 * k + 1];
         qt[2 * k] = to[2 * k]; qt[2 * k + 1] = to[2 * k + 1];
     }
-    if (!vkc::homography_direct(qf, qt, H)) vkc::homography_jacobi(from, to, H);
+    if (!vkc::homography_direct(qf, qt, H)) vkc::homography_jacobi_group8(from, to, H);
+    if (!writer) return;
     const double sx = pts_s[2 * i], sy = pts_s[2 * i + 1];
     const double tx = fma(H[2], 1.0, fma(H[0], sx, H[1] * sy));
     const double ty = fma(H[5], 1.0, fma(H[3], sx, H[4] * sy));
@@ -229,7 +235,7 @@ VKX_EXPORT int vkx_grid_project_points(vkx_ctx *ctx, const int32_t *src_vertices
     VKX_HIP(hipMemcpyAsync(base + off_pi, pts_xy_host, ibytes, hipMemcpyHostToDevice, ctx->stream));
     VKX_HIP(hipMemcpyAsync(base + off_ps, pts_smooth_xy_host, dbytes, hipMemcpyHostToDevice, ctx->stream));
     VKX_HIP(hipMemsetAsync(base + off_bad, 0, sizeof(int), ctx->stream));
-    { VKX_TIMED(ctx, "k_project_points"); k_project_points<<<vkx_blocks((size_t)n, 64), 64, 0, ctx->stream>>>((const int32_t *)base, (const int32_t *)(base + off_dv), rows, cols, grid_size, (const int32_t *)(base + off_pi), (const double *)(base + off_ps), n, (double *)(base + off_out), (int *)(base + off_bad)); }
+    { VKX_TIMED(ctx, "k_project_points"); k_project_points<<<vkx_blocks((size_t)n * 8, 64), 64, 0, ctx->stream>>>((const int32_t *)base, (const int32_t *)(base + off_dv), rows, cols, grid_size, (const int32_t *)(base + off_pi), (const double *)(base + off_ps), n, (double *)(base + off_out), (int *)(base + off_bad)); }
     VKX_LAUNCH_CHECK();
     int bad = 0;
     VKX_HIP(hipMemcpyAsync(out_xy_host, base + off_out, dbytes, hipMemcpyDeviceToHost, ctx->stream));
