@@ -10,6 +10,8 @@ from typing import Iterable, Optional, Tuple, Union
 import attrs
 import numpy as np
 
+from vkit_amd import _native
+
 from .opt import (
     DeviceWindow,
     _deferred_stack,
@@ -223,6 +225,35 @@ class Box(Shapable):
                            keep_min_value=keep_min_value)
 
     def fill_image(self, image: 'Image', value, image_mask=None, alpha: Union['ScoreMap', np.ndarray, float] = 1.0):
+        # The layers of a page recorded by an open deferred composite on a uint8 image without a box of its own: the record
+        # the generic path below builds (same geometry, planes and checks), built directly.
+        target = image._mat
+        if image.box is None and target.dtype == np.uint8 and target.ndim == 3:
+            stack = _deferred_stack()
+            if (stack and stack[-1].base is target and 0 <= self.up <= self.down < target.shape[0]
+                    and 0 <= self.left <= self.right < target.shape[1]):
+                shape = self.shape
+                plane = value._mat if isinstance(value, Image) else value
+                ok = isinstance(plane, tuple) or (isinstance(plane, np.ndarray) and plane.dtype == np.uint8
+                                                 and plane.shape == shape + (target.shape[2],))
+                mask_plane = None
+                if image_mask is not None:
+                    mask_plane = image_mask._mat if isinstance(image_mask, Mask) else image_mask
+                    ok = ok and isinstance(mask_plane, np.ndarray) and mask_plane.shape == shape and mask_plane.dtype in (np.uint8, np.bool_)
+                    if ok and mask_plane.dtype == np.bool_:
+                        mask_plane = mask_plane.view(np.uint8)
+                weight = alpha
+                if isinstance(alpha, ScoreMap):
+                    ok = ok and alpha.is_prob
+                    weight = alpha._mat
+                if isinstance(weight, np.ndarray):
+                    ok = ok and weight.shape == shape and weight.dtype == np.float32
+                else:
+                    ok = ok and type(weight) is float and 0.0 <= weight <= 1.0
+                if ok:
+                    stack[-1].layers.append(_native.make_layer((self.up, self.left) + shape, target.shape[2], plane, mask=mask_plane,
+                                                               alpha=weight))
+                    return
         self._fill_element(image, value, Image, image_mask, alpha=alpha)
 
 

@@ -8,8 +8,9 @@ from typing import Optional, Tuple
 import attrs
 import numpy as np
 
+from vkit_amd import _native
 from ._writable import LazyMat, WritableContext
-from .opt import generate_shape_and_resized_shape
+from .opt import _deferred_stack, generate_shape_and_resized_shape
 from .type import ElementSetOperationMode, Shapable
 
 
@@ -73,7 +74,6 @@ class ScoreMap(LazyMat, Shapable):
     def to_resized_score_map(self, resized_height: Optional[int] = None, resized_width: Optional[int] = None,
                              cv_resize_interpolation: int = 2):
         """cv.resize (any cv2 code 0..6), clipped back to [0, 1] for probability maps (reference score_map.py:616-637)."""
-        from vkit_amd import _native
         assert not self.box
         if cv_resize_interpolation not in range(7):
             raise ValueError(f'unknown cv2 interpolation code {cv_resize_interpolation}')
@@ -109,6 +109,18 @@ class ScoreMap(LazyMat, Shapable):
                                           keep_min_value=keep_min_value)
 
     def fill_image(self, image: 'Image', value):
+        # The text lines of a page: a box-attached probability map and a constant colour recorded by an open deferred
+        # composite on a uint8 image.  Same layer as the generic path below records (box geometry, the map as alpha plane,
+        # no selection plane), without its five calls per layer.
+        box, target, alpha = self.box, image._mat, self._mat
+        if (box is not None and image.box is None and type(value) is tuple and self.is_prob and isinstance(alpha, np.ndarray)
+                and target.dtype == np.uint8 and target.ndim == 3 and len(value) == target.shape[2]):
+            stack = _deferred_stack()
+            if (stack and stack[-1].base is target and 0 <= box.up <= box.down < target.shape[0]
+                    and 0 <= box.left <= box.right < target.shape[1]):
+                stack[-1].layers.append(_native.make_layer((box.up, box.left, alpha.shape[0], alpha.shape[1]), len(value), value,
+                                                           alpha=alpha))
+                return
         self.equivalent_box.fill_image(image, value, alpha=self)
 
 
