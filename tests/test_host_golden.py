@@ -508,3 +508,61 @@ def test_layer_records_of_the_composite(monkeypatch):
         N.make_layer((0, 0, 2, 2), 3, (300, 0, 0))
     layer, keep = N.make_layer((0, 0, 2, 2), 1, 7.9)
     assert layer.value_const[0] == 7
+
+
+def test_direct_layer_records_equal_the_generic_path():
+    """``ScoreMap.fill_image`` / ``Box.fill_image`` / ``Mask.fill_image`` build the record of an open deferred composite
+    directly; the generic path (``Box._fill_element`` -> ``Box.fill_np_array`` -> ``opt.fill_np_array``) must produce the very
+    same bytes, and whatever the direct path does not take (an image with a box, a wrong plane, an int alpha) reaches it."""
+    import ctypes
+    from vkit_amd.element import Box, Image, Mask, ScoreMap
+    from vkit_amd.element.opt import deferred_fill
+    rng = default_rng(8)
+    page = Image(mat=rng.integers(0, 256, (50, 70, 3), dtype=np.uint8))
+    box = Box(up=5, down=16, left=9, right=28)
+    alpha = rng.random(box.shape, dtype=np.float32)
+    value = Image(mat=rng.integers(0, 256, box.shape + (3,), dtype=np.uint8))
+    mask = Mask(mat=(rng.random(box.shape) < 0.5).astype(np.uint8), box=box)
+    smap = ScoreMap(mat=alpha, box=box)
+
+    class Abandon(Exception):
+        pass
+
+    def record(fn):
+        with pytest.raises(Abandon):
+            with page.writable_context, deferred_fill(page.mat) as session:
+                fn()
+                layers = []
+                for layer, keep in session.layers:
+                    # the selection plane: the generic path hands over a fresh boolean copy, the direct one the mask's own
+                    # bytes -- the composite selects where the byte is non-zero, so compare that
+                    selection = None
+                    if layer.mask:
+                        plane = next(p for p in keep if p.__array_interface__['data'][0] == layer.mask)
+                        selection = (np.asarray(plane) > 0).tobytes()
+                        layer.mask = 1
+                    layers.append((bytes(ctypes.string_at(ctypes.addressof(layer), ctypes.sizeof(layer))), selection))
+                raise Abandon()
+        return layers
+
+    direct = record(lambda: (smap.fill_image(page, (1, 2, 3)), box.fill_image(page, value, alpha=0.5),
+                             box.fill_image(page, (9, 8, 7), image_mask=mask, alpha=1.0), mask.fill_image(page, value),
+                             box.fill_image(page, value, alpha=smap)))
+    generic = record(lambda: (box._fill_element(page, (1, 2, 3), Image, None, alpha=smap),
+                              box._fill_element(page, value, Image, None, alpha=0.5),
+                              box._fill_element(page, (9, 8, 7), Image, mask, alpha=1.0),
+                              box._fill_element(page, value, Image, mask, alpha=1.0),
+                              box._fill_element(page, value, Image, None, alpha=smap)))
+    assert len(direct) == 5 and direct == generic
+    # not taken by the direct path: errors are the generic path's
+    with pytest.raises(AttributeError):
+        record(lambda: box.fill_image(page, value, alpha=1))
+    with pytest.raises(RuntimeError):
+        record(lambda: box.fill_image(page, value, alpha=1.5))
+    attached = Image(mat=page.mat, box=Box(up=100, down=149, left=200, right=269))
+    with pytest.raises(Abandon):
+        with attached.writable_context, deferred_fill(attached.mat) as session:
+            ScoreMap(mat=alpha, box=Box(up=105, down=116, left=209, right=228)).fill_image(attached, (1, 2, 3))
+            layer = session.layers[0][0]
+            assert (layer.up, layer.left, layer.height, layer.width) == (5, 9, 12, 20)
+            raise Abandon()
