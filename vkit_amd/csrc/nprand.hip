@@ -726,6 +726,42 @@ __device__ __forceinline__ TileDraws load_tile_i16(const int16_t *__restrict__ r
     for (int q = 0; q < kRounds / 2; q++) d.v[q] = vals[64 * q + lane];
     return d;
 }
+// The same compaction with the records parked in the staging row first (8 elements further up, so that a rank -- at most
+// shift + position, shift < 8 -- never overtakes a record that has not been read): per round two v_readlane (the round's mask
+// lives in lane r), two v_mbcnt whose addend carries the running count, one address op, a 2-byte LDS read and a write that is
+// masked through exec instead of a per-lane bit test -- a quarter of the VALU instructions of the register form below, in a
+// pass that shares the SIMDs with the draw pass of the next chunk.
+constexpr int kRawOff = 8;
+__device__ __forceinline__ uint32_t lds_offset(const void *p)
+{
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+__device__ __forceinline__ uint32_t stage_tile_lds(const TileDraws &d, uint64_t m, uint32_t shift, int16_t *st)
+{
+    const uint32_t lane = (uint32_t)__lane_id();
+    uint32_t *raw32 = (uint32_t *)(st + kRawOff);
+#pragma unroll
+    for (int q = 0; q < kRounds / 2; q++) raw32[64 * q + lane] = d.v[q];
+    __builtin_amdgcn_wave_barrier();
+    const int16_t *raw = st + kRawOff;
+    const uint32_t st_addr = lds_offset(st);
+    uint32_t run = shift;
+#pragma unroll
+    for (int r = 0; r < kRounds; r++) {
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)m, r), hi = (uint32_t)__builtin_amdgcn_readlane((int)(m >> 32), r);
+        const uint32_t rank = (uint32_t)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, run));
+        const uint32_t v = (uint16_t)raw[64 * r + lane];
+        const uint32_t addr = st_addr + 2 * rank;
+        const uint64_t mask = ((uint64_t)hi << 32) | lo;
+        uint64_t saved;
+        asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[m]\n\tds_write_b16 %[a], %[v]\n\ts_mov_b64 exec, %[sv]"
+                     : [sv] "=&s"(saved) : [m] "s"(mask), [a] "v"(addr), [v] "v"(v) : "memory");
+        run += (uint32_t)__builtin_popcountll(mask);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return run - shift;
+}
+
 __device__ __forceinline__ uint32_t stage_tile_i16(const TileDraws &d, uint64_t m, uint32_t shift, int16_t *st)
 {
     const int lane = __lane_id();
@@ -757,7 +793,7 @@ struct Placer<EmitI16> {
     __device__ static void place(const NpJob &job, const Draws &d, const int16_t *, uint64_t m, long long prefix, int16_t *st, uint32_t &)
 {
     const uint32_t shift = (uint32_t)prefix & 1u;
-    uint32_t total = stage_tile_i16(d, m, shift, st);
+    uint32_t total = stage_tile_lds(d, m, shift, st);
     if (prefix + total > job.n) total = (uint32_t)(job.n - prefix);
     finish(job, total, shift, prefix, st);
 }
@@ -800,7 +836,7 @@ struct Placer<EmitAddU8> {
         px[i] = 0;
         if (first + 4 * (long long)(lane + 64 * i) + 3 < job.n) px[i] = src32[64 * i];
     }
-    uint32_t total = stage_tile_i16(d, m, shift, st);
+    uint32_t total = stage_tile_lds(d, m, shift, st);
     if (prefix + total > job.n) total = (uint32_t)(job.n - prefix);
     finish_px(job, total, shift, prefix, st, px);
 }
