@@ -726,11 +726,12 @@ __device__ __forceinline__ TileDraws load_tile_i16(const int16_t *__restrict__ r
     for (int q = 0; q < kRounds / 2; q++) d.v[q] = vals[64 * q + lane];
     return d;
 }
-// The same compaction with the records parked in the staging row first (8 elements further up, so that a rank -- at most
+// The compaction, with the records parked in the staging row first (8 elements further up, so that a rank -- at most
 // shift + position, shift < 8 -- never overtakes a record that has not been read): per round two v_readlane (the round's mask
 // lives in lane r), two v_mbcnt whose addend carries the running count, one address op, a 2-byte LDS read and a write that is
-// masked through exec instead of a per-lane bit test -- a quarter of the VALU instructions of the register form below, in a
-// pass that shares the SIMDs with the draw pass of the next chunk.
+// masked through exec instead of a per-lane bit test -- a quarter of the VALU instructions of a compaction out of registers
+// (rank of each of a lane's two draws by popcounts and selects), in a pass that shares the SIMDs with the draw pass of the
+// next chunk.
 constexpr int kRawOff = 8;
 __device__ __forceinline__ uint32_t lds_offset(const void *p)
 {
@@ -762,29 +763,6 @@ __device__ __forceinline__ uint32_t stage_tile_lds(const TileDraws &d, uint64_t 
     return run - shift;
 }
 
-__device__ __forceinline__ uint32_t stage_tile_i16(const TileDraws &d, uint64_t m, uint32_t shift, int16_t *st)
-{
-    const int lane = __lane_id();
-    const int b = (2 * lane) & 63;
-    uint32_t count = 0;
-#pragma unroll
-    for (int q = 0; q < kRounds / 2; q++) {
-        const uint32_t v = d.v[q];
-        const uint64_t ma = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(m >> 32), 2 * q) << 32) |
-                            (uint32_t)__builtin_amdgcn_readlane((int)m, 2 * q);
-        const uint64_t mb = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(m >> 32), 2 * q + 1) << 32) |
-                            (uint32_t)__builtin_amdgcn_readlane((int)m, 2 * q + 1);
-        const uint32_t ca = (uint32_t)__builtin_popcountll(ma);
-        const uint64_t mine = lane < 32 ? ma : mb;
-        const uint32_t rank = shift + count + (lane < 32 ? 0u : ca) + (uint32_t)__builtin_popcountll(mine & ((1ull << b) - 1));
-        const uint32_t e0 = (uint32_t)(mine >> b) & 1u, e1 = (uint32_t)(mine >> (b + 1)) & 1u;
-        if (e0) st[rank] = (int16_t)v;
-        if (e1) st[rank + e0] = (int16_t)(v >> 16);
-        count += ca + (uint32_t)__builtin_popcountll(mb);
-    }
-    __builtin_amdgcn_wave_barrier();
-    return count;
-}
 
 template <>
 struct Placer<EmitI16> {
