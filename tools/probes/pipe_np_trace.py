@@ -19,7 +19,7 @@ for i in range(n_img):
     pinned.append(a)
 gen = P_mls.SimilarityMlsConfigGenerator(P_mls.SimilarityMlsConfigGeneratorConfig(), 5)
 states = [D.similarity_mls.generate_state(gen((S, S), default_rng(i)), (S, S)) for i in range(n_img)]
-pipe = HostPipeline(ctx, depth=8)
+pipe = HostPipeline(ctx, depth=int(os.environ.get('DEPTH', '8')), lanes=int(os.environ.get('LANES', '8')))
 if os.environ.get('TIMING'):
     for lane in pipe.lanes:
         lane.set_timing(True)
@@ -36,7 +36,7 @@ for rep in range(2):
     tickets = []
     for i in range(24):
         tickets.append(submit(i))
-        if len(tickets) >= 8:
+        if len(tickets) >= len(pipe.slots):
             pipe.result(tickets.pop(0))
     for t in tickets:
         pipe.result(t)
