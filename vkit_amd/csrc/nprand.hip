@@ -40,7 +40,15 @@ namespace {
 typedef unsigned __int128 u128;
 #define VKX_GLOBAL __attribute__((address_space(1)))
 
-constexpr int kRounds = 16;               // rounds of 64 draws per tile
+// Rounds of 64 draws per tile.  The attempts of a tile that are not a fast accept (1.5 % of its draws) are evaluated densely, one
+// per lane, and their starts resolved by one pass over the lanes: with 16 rounds those passes ran at a quarter of the
+// wavefront's width (15 events); 48 rounds give them 46 +- 7 events -- under the 64 the lane-parallel resolution takes -- and
+// spread the per-tile fixed work (state jump, start resolution, bookkeeping) over three times the draws.
+#ifndef VKX_NP_ROUNDS
+#define VKX_NP_ROUNDS 48
+#endif
+constexpr int kRounds = VKX_NP_ROUNDS;    // even, <= 64 (lane r holds the masks of round r)
+static_assert(kRounds % 2 == 0 && kRounds >= 2 && kRounds <= 64, "rounds per tile");
 constexpr int kTile = 64 * kRounds;       // raw draws per tile
 constexpr double kNorR = 3.6541528853610087963519472518;
 constexpr double kNorInvR = 0.27366123732975827203338247596;
@@ -190,7 +198,7 @@ struct EmitSpeckle {   // uint8(clip(px + px * (0 + std * z), 0, 255)) in float6
 
 // Per-wavefront LDS workspace of a tile walk.
 constexpr int kEvCap = 128;      // attempts per tile that are not a fast accept: mean 15.4, sigma 3.9
-template <typename Val>
+template <typename Val, bool WITH_VAL>
 struct WaveWork {
     uint64_t ev_s[kEvCap][2];    // LCG state of the event's draw; after evaluation [0] holds the bits of a tail sample
     uint16_t ev_pos[kEvCap];     // 64 * round + lane
@@ -198,8 +206,7 @@ struct WaveWork {
     uint64_t slow[kRounds];      // per round: the lanes whose attempt is not a fast accept
     uint64_t semit[kRounds];     // per round: the events that emit a sample, as a lane mask
     uint64_t cov[kRounds];       // per round: the draws consumed by an attempt that started earlier
-    Val val[kRounds + 1][64];    // what every draw would emit as a fast accept (int16 steps, or the float64 draw); pass 2
-                                 // stages a tile's compacted samples here (one spare row: the alignment shift)
+    Val val[WITH_VAL ? kRounds : 1][64];   // kEmit: what every draw would emit as a fast accept (int16 steps, or the float64 draw)
 };
 
 __device__ __forceinline__ uint64_t rfl64(uint64_t v)
@@ -225,7 +232,7 @@ __device__ __forceinline__ int mbcnt64(uint64_t m)
 enum { kCount = 0, kRecord = 1, kEmit = 2 };
 template <class Emit, int MODE>
 __device__ void walk_tile(const NpJob &job, const JumpTabs &g_jump, const uint4 *__restrict__ zig /* LDS: ki | wi */, const double *__restrict__ fi /* LDS */,
-                          WaveWork<typename Emit::Store> &ws, u128 base, uint32_t c_in, long long prefix, long long draw_base,
+                          WaveWork<typename Emit::Store, MODE == kEmit> &ws, u128 base, uint32_t c_in, long long prefix, long long draw_base,
                           typename Emit::Store VKX_GLOBAL *rec_val, uint64_t VKX_GLOBAL *rec_mask,
                           uint32_t &count_out, uint32_t &carry_out, uint64_t &start0, uint64_t &emit0, bool &has_tail, uint32_t &flags,
                           unsigned long long *draws_used)
@@ -257,7 +264,7 @@ __device__ void walk_tile(const NpJob &job, const JumpTabs &g_jump, const uint4 
             x = __longlong_as_double(__double_as_longlong(x) | ((long long)((uint32_t)u << 23 & 0x80000000u) << 32));
             const typename Emit::Store v = (typename Emit::Store)Emit::make(job, x, false, flags);
             if (MODE == kRecord) rec_val[64 * r + lane] = v;
-            else ws.val[r][lane] = v;
+            else if (MODE == kEmit) ws.val[r][lane] = v;
         }
         const uint64_t slow = __ballot(rabs >= ki);
         if (lane == 0) ws.slow[r] = slow;
@@ -435,7 +442,13 @@ __device__ void walk_tile(const NpJob &job, const JumpTabs &g_jump, const uint4 
     count += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)count, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
     count += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)count, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
     count += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)count, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
-    count = (uint32_t)__builtin_amdgcn_readlane((int)count, 15);
+    {   // lane 15 of every row of 16 lanes holds the row's sum
+        uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)count, 15);
+        if (kRounds > 16) total += (uint32_t)__builtin_amdgcn_readlane((int)count, 31);
+        if (kRounds > 32) total += (uint32_t)__builtin_amdgcn_readlane((int)count, 47);
+        if (kRounds > 48) total += (uint32_t)__builtin_amdgcn_readlane((int)count, 63);
+        count = total;
+    }
     if (MODE == kEmit) {
         uint32_t done = 0, ebase = 0;
 #pragma unroll 1
@@ -557,7 +570,7 @@ __global__ void __launch_bounds__(256) k_np_draw(const NpJob *__restrict__ jobs,
 {
     __shared__ uint4 zig[256];
     __shared__ double fi[256];
-    __shared__ WaveWork<typename Emit::Store> work[4];
+    __shared__ WaveWork<typename Emit::Store, false> work[4];
     load_tables(zig, fi, tabs);
     const JumpTabs &g_jump = tabs->jump;
     const long long n_waves = (long long)gridDim.x * 4;
@@ -586,7 +599,7 @@ __global__ void __launch_bounds__(1024) k_np_resolve(const NpJob *__restrict__ j
 {
     __shared__ uint4 zig[256];
     __shared__ double fi[256];
-    __shared__ WaveWork<int16_t> work[1];
+    __shared__ WaveWork<int16_t, false> work[1];
     __shared__ unsigned long long part[1024];
     __shared__ uint32_t n_irregular;
     extern __shared__ uint64_t irregular[];     // one bit per tile
@@ -908,8 +921,9 @@ __global__ void __launch_bounds__(256) k_np_place(const NpJob *__restrict__ jobs
     if (flags) atomicOr(&results[j].flags, flags);
 }
 
+// (one wavefront per workgroup: the kEmit workspace of a float64 emitter is 26 KB)
 template <class Emit>
-__global__ void __launch_bounds__(256) k_np_place_walk(const NpJob *__restrict__ jobs, int n_jobs, long long total_tiles,
+__global__ void __launch_bounds__(64) k_np_place_walk(const NpJob *__restrict__ jobs, int n_jobs, long long total_tiles,
                                                        const uint64_t *__restrict__ states, const TileInfo *__restrict__ info,
                                                        const TilePlan *__restrict__ plan, vkx_np_result *__restrict__ results,
                                                        unsigned *__restrict__ done, vkx_np_result *__restrict__ results_host,
@@ -917,13 +931,13 @@ __global__ void __launch_bounds__(256) k_np_place_walk(const NpJob *__restrict__
 {
     __shared__ uint4 zig[256];
     __shared__ double fi[256];
-    __shared__ __attribute__((aligned(16))) WaveWork<typename Emit::Store> work[4];
+    __shared__ __attribute__((aligned(16))) WaveWork<typename Emit::Store, true> work[1];
     load_tables(zig, fi, tabs);
     const JumpTabs &g_jump = tabs->jump;
     const int lane = __lane_id();
-    const long long n_waves = (long long)gridDim.x * 4;
+    const long long n_waves = (long long)gridDim.x;
     // 64 tiles per step: a lane looks at one plan, the wavefront then walks the few tiles that asked for it
-    for (long long t0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64; t0 < total_tiles; t0 += n_waves * 64) {
+    for (long long t0 = (long long)blockIdx.x * 64; t0 < total_tiles; t0 += n_waves * 64) {
         const long long mine = t0 + lane;
         bool want = false;
         if (mine < total_tiles) {
@@ -942,7 +956,7 @@ __global__ void __launch_bounds__(256) k_np_place_walk(const NpJob *__restrict__
             uint32_t count, carry, flags = 0;
             uint64_t start0, emit0;
             bool ht;
-            walk_tile<Emit, kEmit>(job, g_jump, zig, fi, work[threadIdx.x >> 6], mk128(&states[2 * tile]), p.c_in & ~kIrregular,
+            walk_tile<Emit, kEmit>(job, g_jump, zig, fi, work[0], mk128(&states[2 * tile]), p.c_in & ~kIrregular,
                                    (long long)p.prefix, (tile - job.tile_base) * kTile, nullptr, nullptr, count, carry, start0, emit0, ht,
                                    flags, &results[j].draws);
             if (flags) atomicOr(&results[j].flags, flags);
@@ -1183,13 +1197,13 @@ static int np_chunk_back(vkx_ctx *ctx, NpChunk &c)
     }
     {
         VKX_TIMED(ctx, "k_np_place_walk");
-        const unsigned wg2 = (unsigned)std::min<long long>((total_tiles + 255) / 256, 256 * 4);
+        const unsigned wg2 = (unsigned)std::min<long long>((total_tiles + 63) / 64, 256 * 16);
         if (kind == VKX_NP_SPECKLE_U8)
-            k_np_place_walk<EmitSpeckle><<<wg2, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, done, c.res_mapped, tabs);
+            k_np_place_walk<EmitSpeckle><<<wg2, 64, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, done, c.res_mapped, tabs);
         else if (kind == VKX_NP_NORMAL_ADD_U8)
-            k_np_place_walk<EmitAddU8><<<wg2, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, done, c.res_mapped, tabs);
+            k_np_place_walk<EmitAddU8><<<wg2, 64, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, done, c.res_mapped, tabs);
         else
-            k_np_place_walk<EmitI16><<<wg2, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, done, c.res_mapped, tabs);
+            k_np_place_walk<EmitI16><<<wg2, 64, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, done, c.res_mapped, tabs);
         VKX_LAUNCH_CHECK();
     }
     if (!c.res_mapped)
