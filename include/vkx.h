@@ -487,6 +487,13 @@ int vkx_paint_polys(vkx_ctx *ctx, const int32_t *pts_host, const int32_t *poly_o
  *   VKX_NP_SPECKLE_U8     dst uint8 [n]  = uint8(clip(src + src * rng.normal(0, scale, n), 0, 255)) in float64
  *   VKX_NP_CHOICE3_U8     dst uint8 [n]  = rng.choice((0, 1, 2), n, p) as #{k : cdf[k] <= rng.random()}, cdf = cumsum(p) / sum
  *   VKX_NP_IMPULSE_U8     dst uint8 [n, cn] = src with salt (255) where the selector is 1, pepper (0) where it is 2
+ *   VKX_NP_NORMAL_TILES   dst = a TILE BUFFER of vkx_np_tiles_layout(n) bytes (256-byte aligned) standing for the int16 plane of
+ *                         VKX_NP_NORMAL_I16 without ever forming it: the generator works in tiles of 3072 raw draws, and a tile's
+ *                         samples stay where the draw pass left them, squeezed together in the tile's slot; a table gives the
+ *                         index of every tile's first sample.  vkx_chain_item.noise takes such a buffer (noise_tiled = 1): the
+ *                         chain kernel looks its samples up in the slots, so gaussion_noise costs one 2-byte read per sample
+ *                         instead of a placement pass (2 bytes per raw draw read, 2 bytes per sample written) plus that read.
+ *                         vkx_np_tiles_expand_dev turns a buffer into the plane it stands for.
  * src / dst are dense device arrays (vkx_np_draw_batch_dev: asynchronous on the ctx stream, results_host is valid after a
  * synchronisation).  exp() / log1p() of the device differ from glibc's in the last bits: a decision or an
  * emitted integer that could depend on them sets VKX_NP_AMBIGUOUS in the job's result (the caller then redraws that plane
@@ -497,6 +504,7 @@ int vkx_paint_polys(vkx_ctx *ctx, const int32_t *pts_host, const int32_t *poly_o
 #define VKX_NP_SPECKLE_U8 2
 #define VKX_NP_CHOICE3_U8 3
 #define VKX_NP_IMPULSE_U8 4
+#define VKX_NP_NORMAL_TILES 5
 #define VKX_NP_DEBUG_WIDE_MARGIN 0x100 /* or-ed into kind: every wedge test counts as ambiguous (exercises the fallback in tests) */
 #define VKX_NP_AMBIGUOUS 1u
 #define VKX_NP_SHORT 2u
@@ -516,6 +524,14 @@ typedef struct vkx_np_result {
     uint32_t flags, reserved;
 } vkx_np_result;
 int vkx_np_draw_batch_dev(vkx_ctx *ctx, const vkx_np_job *jobs_host, int n_jobs, vkx_np_result *results_host);
+/* Tile buffer of a VKX_NP_NORMAL_TILES job of n samples: `bytes` in all; a 16-byte header (uint32 tiles, uint32 slot elements,
+ * uint64 samples the tiles hold), at table_offset [n_tiles + 1] x (uint32 index of the tile's first sample, uint32 first valid
+ * element of its slot), at slots_offset n_tiles slots of slot_elems int16.  Sample i of the plane, with
+ * table[t].first <= i < table[t + 1].first, is slot t's element table[t].skip + i - table[t].first; samples i + 1 and i + 2 follow
+ * it in the same slot (a slot ends with the first two samples of its successor).  Any output pointer may be NULL. */
+int vkx_np_tiles_layout(int64_t n, int64_t *n_tiles, int64_t *slot_elems, int64_t *table_offset, int64_t *slots_offset, int64_t *bytes);
+/* dst int16 [n] (device, 8-byte aligned) = the plane a finished tile buffer stands for; asynchronous on the ctx stream */
+int vkx_np_tiles_expand_dev(vkx_ctx *ctx, const void *tiles, int64_t n, int16_t *dst);
 /* one job whose src / dst are HOST arrays; synchronous */
 int vkx_np_draw(vkx_ctx *ctx, const vkx_np_job *job, vkx_np_result *result_host);
 
@@ -556,7 +572,8 @@ typedef struct vkx_chain_item {
     const int32_t *src_vertices;   /* int32 [rows, cols, 2] (x, y) */
     const int32_t *dst_vertices;
     int32_t rows, cols;
-    const int16_t *noise;          /* optional int16 [dh, dw, 3]; NULL = no noise stage */
+    const int16_t *noise;          /* optional int16 [dh, dw, 3]; NULL = no noise stage.  noise_tiled: the tile buffer of a
+                                      VKX_NP_NORMAL_TILES job of dh * dw * 3 samples instead (noise_stride_el unused) */
     ptrdiff_t noise_stride_el;
     double blur_sigma;
     int32_t blur_ksize;            /* <= 1 = no blur stage */
@@ -566,7 +583,7 @@ typedef struct vkx_chain_item {
     int32_t streak_thickness, streak_gap, streak_dash_thickness, streak_dash_gap;
     int32_t streak_enable_vert, streak_enable_hori;
     uint8_t streak_color[4];
-    int32_t reserved;
+    int32_t noise_tiled;           /* 0: `noise` is a plane */
     double streak_alpha;           /* in [0, 1] */
 } vkx_chain_item;
 int vkx_chain_rgb_batch_dev(vkx_ctx *ctx, const vkx_chain_item *items, int n_items);

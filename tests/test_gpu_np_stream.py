@@ -29,6 +29,66 @@ def test_rounded_normal_plane_matches_numpy(seed, n, std):
     assert _same_state(rng, ref)
 
 
+@pytest.mark.parametrize('seed,n,std', [(20, 1, 1.0), (21, 2, 3.0), (22, 3005, 10.0), (23, 3007, 10.0), (24, 70_001, 10.0),
+                                        (25, 3 * 1024 * 1024, 0.0), (26, 2047 * 2049 * 3, 12.0), (27, 12_582_912, 255.0)])
+def test_tile_buffer_stands_for_the_plane(seed, n, std):
+    """VKX_NP_NORMAL_TILES: the samples stay in the generator's tile slots; the table places them.  The buffer read back through
+    the documented layout, and through vkx_np_tiles_expand_dev, is numpy's plane; every slot ends with the first two samples of
+    its successor; the draw count moves the generator to numpy's state."""
+    ctx = N.default_ctx()
+    rng, ref = np.random.default_rng(seed), np.random.default_rng(seed)
+    want = np.round(ref.normal(0, std, n)).astype(np.int16)
+    tiles, slot, table_off, slots_off, nbytes = N.np_tiles_layout(n)
+    buf = np.zeros(nbytes, np.uint8)
+    job = N.np_job(N.NP_NORMAL_TILES, N.np_stream(rng), n, std, dst=N._ptr(buf))
+    res = N.VkxNpResult()
+    N.check(N.lib().vkx_np_draw(ctx.handle, ctypes.byref(job), ctypes.byref(res)))
+    assert res.flags == 0 and res.samples >= n
+    assert (N.np_tiles_plane(buf, n) == want).all()
+    N.np_consume(rng, res.draws)
+    assert _same_state(rng, ref)
+    header = buf[:16].view(np.uint32)
+    assert header[0] == tiles and header[1] == slot and int(buf[8:16].view(np.uint64)[0]) == res.samples
+    table = buf[table_off:table_off + 8 * (tiles + 1)].view(np.uint32).reshape(tiles + 1, 2)
+    slots = buf[slots_off:slots_off + tiles * slot * 2].view(np.int16).reshape(tiles, slot)
+    assert table[0, 0] == 0 and table[tiles, 0] == res.samples and (np.diff(table[:, 0].astype(np.int64)) >= 0).all()
+    for t in range(tiles - 1):
+        nxt = int(table[t + 1, 0])
+        if nxt + 2 > n:
+            break
+        end = int(table[t, 1]) + nxt - int(table[t, 0])
+        assert (slots[t, end:end + 2] == want[nxt:nxt + 2]).all(), t
+    # on the device
+    dbuf = ctx.to_device(buf)
+    plane = ctx.dev_empty((n,), np.int16)
+    N.check(N.lib().vkx_np_tiles_expand_dev(ctx.handle, ctypes.c_void_p(dbuf.ptr), n, ctypes.c_void_p(plane.ptr)))
+    assert (plane.host() == want).all()
+
+
+def test_tile_buffers_of_a_batch():
+    """Several VKX_NP_NORMAL_TILES streams of one device call, sizes around the tile and chunk boundaries."""
+    ctx = N.default_ctx()
+    sizes = [1, 5, 3006, 3072, 6013, 50_000, 123_457] + [40_000 + 977 * k for k in range(70)]
+    B = len(sizes)
+    jobs = (N.VkxNpJob * B)()
+    res = N.NpResults(ctx, B)
+    bufs = []
+    for i, n in enumerate(sizes):
+        d = ctx.dev_empty((N.np_tiles_layout(n)[4],), np.uint8)
+        bufs.append(d)
+        jobs[i] = N.np_job(N.NP_NORMAL_TILES, N.np_stream(np.random.default_rng(700 + i)), n, 3.0 + i % 7, dst=d.ptr)
+    N.check(N.lib().vkx_np_draw_batch_dev(ctx.handle, jobs, B, res.array))
+    ctx.sync()
+    for i, n in enumerate(sizes):
+        ref = np.random.default_rng(700 + i)
+        want = np.round(ref.normal(0, 3.0 + i % 7, n)).astype(np.int16)
+        assert res[i].flags == 0
+        assert (N.np_tiles_plane(bufs[i].host(), n) == want).all(), (i, n)
+        chk = np.random.default_rng(700 + i)
+        N.np_consume(chk, res[i].draws)
+        assert _same_state(chk, ref)
+
+
 def test_stream_continues_across_calls_and_other_draws():
     rng, ref = np.random.default_rng(77), np.random.default_rng(77)
     for r in (rng, ref):

@@ -471,7 +471,16 @@ def test_chain_batch_staged_path_subprocess(N):
         "g = {}; sv, dv, ds = T.synthetic_grid(300, 420, 15, 7.0, seed=5); g['a'] = (sv, dv, ds, (300, 420));"
         "from vkit_amd.mechanism.distortion import LineStreakConfig as L;"
         "T._chain_case(N, g, ['a'], 17, [1.0], [37], [True], [L(thickness=2, gap=9, alpha=0.4, color=(9, 200, 30))]);"
-        "T._chain_case(N, g, ['a'], 18, [None], [None], [True]); print('ok')")
+        "T._chain_case(N, g, ['a'], 18, [None], [None], [True]);"
+        # a numpy stream kept as the generator's tile buffer: the staged path expands it to its plane
+        "import oracle as O; from vkit_amd.batch import ChainBatch; from types import SimpleNamespace as NS;"
+        "img = np.random.default_rng(3).integers(0, 256, (300, 420, 3), dtype=np.uint8);"
+        "st = NS(result_shape=ds, src_image_grid=NS(vertices=sv), dst_image_grid=NS(vertices=dv));"
+        "b = ChainBatch(); b.add(img, st, blur_sigma=1.0, hue_delta=37, noise_std=9.0, noise_rng=np.random.default_rng(4)); b.run();"
+        "assert b._items[0].noise_tiled == 1;"
+        "mx, my = O.grid_to_map(sv, dv, ds); pl = np.round(np.random.default_rng(4).normal(0, 9.0, tuple(ds) + (3,))).astype(np.int16);"
+        "assert (b.result(0) == O.add_noise_i16(O.color_shift_rgb(O.gaussian_blur(O.remap(img, mx, my), 5, 1.0), 37), pl)).all();"
+        "print('ok')")
     env = dict(os.environ, VKX_CHAIN_STAGED='1')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=600)

@@ -7,7 +7,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in sorted(glob.glob(os.path.join(ROOT, 'gpurun_out', f'pmc_{tag}', 'p*', '**', '*counter_collection.csv'), recursive=True)):
     for r in csv.DictReader(open(path)):
         name = r['Kernel_Name']
-        for key in ('k_np_draw', 'k_np_place<', 'k_np_resolve', 'k_np_fused'):
+        for key in ('k_np_draw', 'k_np_place<', 'k_np_resolve', 'k_np_fused', 'k_np_apply', 'k_np_place_walk', 'k_np_tiles_finish'):
             if key in name:
                 acc[key][r['Counter_Name']].append(float(r['Counter_Value']))
                 acc[key]['ns'].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))

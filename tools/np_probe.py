@@ -47,6 +47,10 @@ res = (N.VkxNpResult * B)()
 bufs = []
 for i in range(B):
     r = np.random.default_rng(5000 + i)
+    if os.environ.get('NP_KIND') == 'tiles':
+        p = ctx.malloc(N.np_tiles_layout(n)[4]); bufs.append(p)
+        jobs[i] = N.np_job(N.NP_NORMAL_TILES, N.np_stream(r), n, 10.0, dst=p)
+        continue
     p = ctx.malloc(n * 2); bufs.append(p)
     jobs[i] = N.np_job(N.NP_NORMAL_I16, N.np_stream(r), n, 10.0, dst=p)
 for it in range(2):
@@ -60,7 +64,11 @@ ctx.sync()
 for k, (ms, cnt) in ctx.timings().items():
     print(f'{k}: {ms / cnt:.3f} ms x {cnt}')
 print('flags', [res[i].flags for i in range(min(B, 8))], 'draws/n', res[0].draws / n)
-out = np.empty(n, np.int16); ctx.download(bufs[3], out)
 w = np.round(np.random.default_rng(5003).normal(0, 10.0, n)).astype(np.int16)
+if os.environ.get('NP_KIND') == 'tiles':
+    raw = np.empty(N.np_tiles_layout(n)[4], np.uint8); ctx.download(bufs[3], raw)
+    out = N.np_tiles_plane(raw, n)
+else:
+    out = np.empty(n, np.int16); ctx.download(bufs[3], out)
 print('batch plane 3 exact', (out == w).all())
 print('ALL OK' if ok_all else 'FAILURES')

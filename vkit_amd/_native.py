@@ -70,7 +70,7 @@ class VkxChainItem(ctypes.Structure):
         ('streak_enable_vert', ctypes.c_int32),
         ('streak_enable_hori', ctypes.c_int32),
         ('streak_color', ctypes.c_uint8 * 4),
-        ('reserved', ctypes.c_int32),
+        ('noise_tiled', ctypes.c_int32),
         ('streak_alpha', c_double),
     ]
 
@@ -143,7 +143,7 @@ class VkxNpResult(ctypes.Structure):
     ]
 
 
-NP_NORMAL_I16, NP_NORMAL_ADD_U8, NP_SPECKLE_U8, NP_CHOICE3_U8, NP_IMPULSE_U8 = 0, 1, 2, 3, 4
+NP_NORMAL_I16, NP_NORMAL_ADD_U8, NP_SPECKLE_U8, NP_CHOICE3_U8, NP_IMPULSE_U8, NP_NORMAL_TILES = 0, 1, 2, 3, 4, 5
 NP_AMBIGUOUS, NP_SHORT = 1, 2
 
 FILL_PLAIN, FILL_KEEP_MAX, FILL_KEEP_MIN = 0, 1, 2
@@ -169,6 +169,8 @@ _SIGNATURES = {
     'vkx_noise_normal_i16': [c_void_p, c_void_p, c_ssize, c_int, c_int, c_int, c_double, ctypes.c_uint64],
     'vkx_noise_normal_i16_batch_dev': [c_void_p, ctypes.POINTER(VkxNoisePlane), c_int, c_double],
     'vkx_np_draw_batch_dev': [c_void_p, ctypes.POINTER(VkxNpJob), c_int, ctypes.POINTER(VkxNpResult)],
+    'vkx_np_tiles_layout': [ctypes.c_int64] + [ctypes.POINTER(ctypes.c_int64)] * 5,
+    'vkx_np_tiles_expand_dev': [c_void_p, c_void_p, ctypes.c_int64, c_void_p],
     'vkx_np_draw': [c_void_p, ctypes.POINTER(VkxNpJob), ctypes.POINTER(VkxNpResult)],
     'vkx_host_alloc': [c_void_p, c_size, ctypes.POINTER(c_void_p)],
     'vkx_host_free': [c_void_p, c_void_p],
@@ -1308,6 +1310,28 @@ def np_draw(kind, rng, out_shape, out_dtype, src=None, scale=0.0, cdf=(2.0, 2.0,
         return None
     np_consume(rng, res.draws)
     return dst
+
+
+def np_tiles_layout(n):
+    """(tiles, slot elements, table offset, slots offset, bytes) of the tile buffer of a ``NP_NORMAL_TILES`` job of ``n`` samples."""
+    vals = [ctypes.c_int64() for _ in range(5)]
+    check(lib().vkx_np_tiles_layout(int(n), *[ctypes.byref(v) for v in vals]))
+    return tuple(int(v.value) for v in vals)
+
+
+def np_tiles_plane(buffer, n):
+    """numpy restatement of ``vkx_np_tiles_expand_dev``: the int16 plane a finished tile buffer (host copy, uint8) stands for."""
+    tiles, slot, table_off, slots_off, _bytes = np_tiles_layout(n)
+    table = buffer[table_off:table_off + 8 * (tiles + 1)].view(np.uint32).reshape(tiles + 1, 2)
+    slots = buffer[slots_off:slots_off + tiles * slot * 2].view(np.int16).reshape(tiles, slot)
+    out = np.empty(n, np.int16)
+    for t in range(tiles):
+        first, skip = int(table[t, 0]), int(table[t, 1])
+        if first >= n:
+            break
+        count = min(int(table[t + 1, 0]), n) - first
+        out[first:first + count] = slots[t, skip:skip + count]
+    return out
 
 
 def np_gaussion_noise(img, std, rng, ctx=None):

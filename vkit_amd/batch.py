@@ -17,14 +17,24 @@ from vkit_amd.mechanism.distortion.photometric.blur import _estimate_gaussian_ke
 
 class ChainBatch:
 
-    def __init__(self, ctx: Optional[_native.Context] = None, stream_noise_planes: bool = False):
-        """``stream_noise_planes``: keep an int16 plane in HBM for every ``noise_rng`` image and let the chain kernel add it
-        (the form of rounds 1 - 2, and what ``run(draw_streams=False)`` re-reads).  By default the noise of such an image is
-        added by the generator itself, after the chain: the pass that puts the samples at their final index adds them to
-        the chain's output in place (``VKX_NP_NORMAL_ADD_U8``) -- same pixels, no 6-byte-per-pixel plane to write and read.
-        Images with a ``streak`` stage keep a plane either way (the streak is drawn over the noise)."""
+    def __init__(self, ctx: Optional[_native.Context] = None, stream_noise_planes: bool = False,
+                 stream_noise_mode: Optional[str] = None):
+        """How the noise of a ``noise_rng`` image (the caller's numpy stream, drawn on the device) reaches the chain --
+        the same pixels in every mode:
+
+        ``'tiles'`` (default): the generator leaves its samples in its own tile slots (``VKX_NP_NORMAL_TILES``) and the chain
+        kernel looks them up there (``vkx_chain_item.noise_tiled``): no placement pass, one 2-byte read per sample.
+        ``'planes'`` (= ``stream_noise_planes=True``): an int16 plane in HBM that the chain kernel adds (rounds 1 - 2).
+        ``'late'``: the generator adds its samples to the chain's output in place, after the chain (``VKX_NP_NORMAL_ADD_U8``,
+        round 3); images with a ``streak`` stage take the tile form instead (the streak is drawn over the noise).
+        ``run(draw_streams=False)`` re-reads what the previous run drew (tiles or planes)."""
         self.ctx = ctx or _native.default_ctx()
-        self.stream_noise_planes = bool(stream_noise_planes)
+        if stream_noise_mode is None:
+            stream_noise_mode = 'planes' if stream_noise_planes else 'tiles'
+        if stream_noise_mode not in ('tiles', 'planes', 'late'):
+            raise ValueError(f'stream_noise_mode={stream_noise_mode!r}')
+        self.stream_noise_mode = stream_noise_mode
+        self.stream_noise_planes = stream_noise_mode == 'planes' 
         self._items: List[_native.VkxChainItem] = []
         self._owned: List[int] = []
         self._dst_shapes: List[Tuple[int, int]] = []
@@ -77,8 +87,13 @@ class ChainBatch:
         if noise_std is not None:
             if noise is not None:
                 raise ValueError('pass either a noise plane or noise_std with noise_seed / noise_rng')
-            late = noise_rng is not None and streak is None and not self.stream_noise_planes
-            if not late:
+            late = noise_rng is not None and streak is None and self.stream_noise_mode == 'late'
+            tiled = noise_rng is not None and not late and self.stream_noise_mode != 'planes'
+            if tiled:
+                item.noise = self.ctx.malloc(_native.np_tiles_layout(dh * dw * 3)[4])
+                self._owned.append(item.noise)
+                item.noise_tiled = 1
+            elif not late:
                 item.noise = self.ctx.malloc(dh * dw * 3 * 2)
                 self._owned.append(item.noise)
                 item.noise_stride_el = dw * 3
@@ -187,17 +202,23 @@ class ChainBatch:
         item = self._items[index]
         if late:
             return _native.np_job(_native.NP_NORMAL_ADD_U8, stream, n, std, src=item.dst, dst=item.dst)
+        if item.noise_tiled:
+            return _native.np_job(_native.NP_NORMAL_TILES, stream, n, std, dst=item.noise)
         return _native.np_job(_native.NP_NORMAL_I16, stream, n, std, dst=item.noise)
 
     def _build_jobs(self, entries):
         chunks = []
         step = max(1, self.stream_chunk)
-        for k in range(0, len(entries), step):
-            part = entries[k:k + step]
-            jobs = (_native.VkxNpJob * len(part))()
-            for t, entry in enumerate(part):
-                jobs[t] = self._job(entry)
-            chunks.append((jobs, _native.NpResults(self.ctx, len(part)), part))
+        # the jobs of one call share a kind
+        tiled = [e for e in entries if self._items[e[0]].noise_tiled]
+        plain = [e for e in entries if not self._items[e[0]].noise_tiled]
+        for group in (tiled, plain):
+            for k in range(0, len(group), step):
+                part = group[k:k + step]
+                jobs = (_native.VkxNpJob * len(part))()
+                for t, entry in enumerate(part):
+                    jobs[t] = self._job(entry)
+                chunks.append((jobs, _native.NpResults(self.ctx, len(part)), part))
         return chunks
 
     def _launch(self, chunks):
@@ -230,10 +251,11 @@ class ChainBatch:
             rng.bit_generator.state = st
             plane = np.round(rng.normal(0, std, n)).astype(np.int16)
             item = self._items[index]
-            if late:
+            if late or item.noise_tiled:
                 item.noise = self.ctx.malloc(plane.nbytes)
                 self._owned.append(item.noise)
                 item.noise_stride_el = int(item.dw) * 3
+                item.noise_tiled = 0
             self.ctx.upload(item.noise, plane)
             self.stream_fallbacks += 1
         self._stream_noise = kept

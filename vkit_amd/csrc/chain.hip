@@ -81,7 +81,16 @@ VKX_EXPORT int vkx_chain_rgb_batch_dev(vkx_ctx *ctx, const vkx_chain_item *items
             remaining--;
             uint8_t *out; ptrdiff_t ostride;
             next_out(out, ostride);
-            rc = vkx_add_noise_i16_dev(ctx, cur, it.dh, it.dw, 3, cur_stride, it.noise, it.noise_stride_el, out, ostride);
+            const int16_t *plane = it.noise;
+            ptrdiff_t plane_stride = it.noise_stride_el;
+            if (it.noise_tiled) {      // the generator's tile buffer: as the plane it stands for
+                const long long n = (long long)it.dh * it.dw * 3;
+                if ((rc = vkx_scratch_reserve(ctx, &ctx->chain[2], (size_t)n * 2))) return rc;
+                if ((rc = vkx_np_tiles_expand_dev(ctx, it.noise, n, (int16_t *)ctx->chain[2].ptr))) return rc;
+                plane = (const int16_t *)ctx->chain[2].ptr;
+                plane_stride = (ptrdiff_t)it.dw * 3;
+            }
+            rc = vkx_add_noise_i16_dev(ctx, cur, it.dh, it.dw, 3, cur_stride, plane, plane_stride, out, ostride);
             if (rc) return rc;
             cur = out; cur_stride = ostride;
         }

@@ -68,6 +68,7 @@ VKX_EXPORT int vkx_ctx_destroy(vkx_ctx *ctx)
     for (auto &s : ctx->chain) scratch_release(&s);
     scratch_release(&ctx->noise_table);
     scratch_release(&ctx->np_tabs);
+    scratch_release(&ctx->noise_rows);
     scratch_release(&ctx->np_work[0]);
     scratch_release(&ctx->np_work[1]);
     for (auto &t : ctx->resize_tabs) scratch_release(&t.buf);

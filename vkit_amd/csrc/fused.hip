@@ -81,6 +81,12 @@ struct ItemDev {
     // element mode (k_tile_remap): the same tile machinery gathers up to four elements of any supported type through
     // the shared lattice instead of running the RGB chain
     int n_elems, pad_;
+    // noise as the generator's tile buffer (VKX_NP_NORMAL_TILES, nprand.hip): `noise` then points at the slots
+    const uint2 *noise_table;     // [noise_tiles + 1] x (index of the tile's first sample, its first valid slot element)
+    int noise_tiled, noise_tiles, noise_slot;
+    float noise_tiles_per_sample;
+    const uint2 *noise_rows;      // [dh][tiles_x] x (slot offset of the row's first sample in that tile column, samples before the next
+                                  // generator tile begins | step of the offset beyond them << 16): k_chain_noise_rows
     struct Elem {
         const void *src;
         void *dst;
@@ -362,7 +368,8 @@ constexpr size_t kLdsCellH = sizeof(double) * 9 * NLDSCELL;     // 72-byte pitch
                                                                 // cells on different LDS banks
 constexpr size_t kLdsLut = sizeof(int) * 512;
 constexpr size_t kLdsSel = sizeof(uint32_t) * 8;              // byte-permute selectors of the six hue sectors, then one flag word
-constexpr size_t kFusedLds = kLdsOwn + kLdsHbB + kLdsCellR + kLdsCellH + kLdsLut + kLdsSel + 16;
+constexpr size_t kLdsNoiseRows = sizeof(uint32_t) * 2 * W;    // tiled noise: (slot offset, samples before the next tile | step into it << 16) per output row
+constexpr size_t kFusedLds = kLdsOwn + kLdsHbB + kLdsCellR + kLdsCellH + kLdsLut + kLdsSel + 16 + kLdsNoiseRows;
 
 typedef const double __attribute__((address_space(3))) *lds_cdouble_t;
 
@@ -396,6 +403,7 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tx, cons
     int *lhdiv = lsdiv + 256;
     uint32_t *lsel = (uint32_t *)(lhdiv + 256);      // [8] hue sector selectors (vkd::kHsvSelectors)
     int *lflag = (int *)(lsel + 8);                  // != 0: a candidate cell's projective denominator may vanish
+    uint32_t *lnrow = (uint32_t *)(smem + kLdsOwn + kLdsHbB + kLdsCellR + kLdsCellH + kLdsLut + kLdsSel + 16);   // [64 rows][2]
 
     // the wavefront index is uniform: read it into an SGPR so that every row index, row address and row predicate
     // derived from it is scalar arithmetic instead of per-lane (64-bit, quarter-rate) multiplies
@@ -455,6 +463,15 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tx, cons
         chunk_store(cn_, v);
     };
 
+    // Tiled noise (the numpy stream's own tile slots instead of a plane, nprand.hip): k_chain_noise_rows has looked up, for
+    // every output row and tile column, where the row's first sample sits in the slots.  Lane = output row of the tile: one
+    // 8-byte load per lane of wavefront 0 at the head of the tile, parked in LDS for phase E once the ownership plane is clear.
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 nrec = {0u, 0u};
+    const bool nrows_here = !(KIND == 3) && wave == 0 && it.noise_rows != nullptr;
+    if (nrows_here && lane < th)
+        nrec = ((const u32x2 VKX_GLOBAL *)it.noise_rows)[(size_t)(y0 + lane) * (size_t)it.tiles_x + (size_t)tx];
+
     uint32_t kq[2 * RMAX + 1];
 #pragma unroll
     for (int i = 0; i < 2 * RMAX + 1; i++) kq[i] = (R > 0 && i < K) ? it.kq[i < K - 1 - i ? i : K - 1 - i] : 0;   // symmetric (checked on the host)
@@ -476,6 +493,7 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tx, cons
             if (tid < 8) lsel[tid] = selv;
         }
         if (tid == 0) *lflag = 0;
+        if (nrows_here) *(u32x2 *)(lnrow + 2 * lane) = nrec;
         // (an interior tile has at most NLDSCELL candidates: one pass, no loop)
         for (int base = 0; base < (INTERIOR ? 1 : max(nc, 1)); base += NLDSCELL) {
             const int cn_ = INTERIOR ? nc : min(NLDSCELL, nc - base);
@@ -875,12 +893,29 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tx, cons
     const ptrdiff_t dstride = (ptrdiff_t)uniform64((uint64_t)ite.dstride), nstride = (ptrdiff_t)uniform64((uint64_t)ite.nstride);
     uint32_t nzA[ROWS_PER_WAVE];
     uint32_t nzB[ROWS_PER_WAVE];
+    // (as the other descriptor fields of this phase: read again here rather than kept in SGPRs through phases A - D)
+    const bool tiled = noise && __builtin_amdgcn_readfirstlane(ite.noise_tiled) != 0;
+    if constexpr (EMPTY) {                   // (no phase A: parked here)
+        if (nrows_here) *(u32x2 *)(lnrow + 2 * lane) = nrec;
+        if (tiled) __syncthreads();
+    }
+    const uint32_t k3 = (uint32_t)(ocx * 3);
+    u32x2 nrow = {0u, 0u};           // lane r < 8: the parked record of this wavefront's row r
+    if (tiled) nrow = *(const u32x2 *)(lnrow + 2 * (wave + NWAVES * (lane & 7)));
 #pragma unroll
     for (int i = 0; i < ROWS_PER_WAVE; i++) {
         nzA[i] = 0; nzB[i] = 0;
         const int cy = wave + NWAVES * i;
         if (noise && ocol && cy < th) {
-            const int16_t VKX_GLOBAL *np_ = noise + (ptrdiff_t)(y0 + cy) * nstride + (ptrdiff_t)(x0 + ocx) * 3;
+            const int16_t VKX_GLOBAL *np_;
+            if (tiled) {
+                uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)nrow.x, i) + k3;
+                const uint32_t sd = (uint32_t)__builtin_amdgcn_readlane((int)nrow.y, i);
+                if ((sd & 0xffffu) < 3u * W) off += k3 >= (sd & 0xffffu) ? (uint32_t)((int)sd >> 16) : 0u;   // the row runs into the next tile
+                np_ = noise + (size_t)off;
+            } else {
+                np_ = noise + (ptrdiff_t)(y0 + cy) * nstride + (ptrdiff_t)(x0 + ocx) * 3;
+            }
             nzA[i] = *(const u32_u1 VKX_GLOBAL *)np_;
             nzB[i] = *(const u16_u1 VKX_GLOBAL *)(np_ + 2);
         }
@@ -1081,6 +1116,46 @@ __global__ void __launch_bounds__(NTHREADS, 4) k_tile_remap(const ItemDev *__res
     chain_tile<3>(it, tx, ty, cells, bin, nullptr, 0);
 }
 
+// Tiled noise: where the first sample of every (output row, tile column) of every image sits in the generator's slots.
+// Sample i of the dense [dh, dw, 3] plane lives in the slot of the generator tile t with table[t].first <= i < table[t + 1].first:
+// the expected tile from the mean yield of a tile, four table entries around it in one round trip, a walk along the table should
+// they not bracket it.  One lane per record; 8 bytes per 64-pixel row segment against the 360 bytes of noise it places.
+__global__ void __launch_bounds__(256) k_chain_noise_rows(const ItemDev *__restrict__ items, const long long *__restrict__ row_prefix, int n_items,
+                                                          long long total)
+{
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    int lo = 0, hi = n_items - 1;                  // largest i with row_prefix[i] <= gid
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (row_prefix[mid] <= gid) lo = mid; else hi = mid - 1;
+    }
+    const ItemDev &it = items[lo];
+    if (!it.noise_rows) return;
+    const uint32_t k = (uint32_t)(gid - row_prefix[lo]);
+    const uint32_t y = k / (uint32_t)it.tiles_x, tx = k - y * (uint32_t)it.tiles_x;
+    const u32x2 VKX_GLOBAL *tab = (const u32x2 VKX_GLOBAL *)it.noise_table;
+    const uint32_t T = (uint32_t)it.noise_tiles, slot = (uint32_t)it.noise_slot;
+    const uint32_t i0 = (y * (uint32_t)it.dw + tx * (uint32_t)tile_side(it.R)) * 3u;
+    const uint32_t g = min((uint32_t)((float)i0 * it.noise_tiles_per_sample), T - 1);
+    const uint32_t gb = g > 0 ? g - 1 : 0;
+    const u32x2 e0 = tab[min(gb, T)], e1 = tab[min(gb + 1, T)], e2 = tab[min(gb + 2, T)], e3 = tab[min(gb + 3, T)];
+    uint32_t t;
+    u32x2 a, b;
+    if (i0 >= e2.x) { t = gb + 2; a = e2; b = e3; }
+    else if (i0 >= e1.x) { t = gb + 1; a = e1; b = e2; }
+    else { t = gb; a = e0; b = e1; }
+    while (a.x > i0 && t > 0) { t--; b = a; a = tab[t]; }
+    while (b.x <= i0 && t + 1 < T) { t++; a = b; b = tab[t + 1]; }
+    // (the step is kSlot - the tile's samples +- the leading elements two tiles skip: well inside an int16)
+    const uint32_t before = min(b.x - i0, 0xffffu), step = slot + b.y - a.y - (b.x - a.x);
+    u32x2 rec;
+    rec.x = t * slot + a.y + (i0 - a.x);
+    rec.y = before | (step << 16);
+    ((u32x2 VKX_GLOBAL *)it.noise_rows)[k] = rec;
+}
+
 // One dispatch instead of a descriptor copy and three memsets (every dispatch on a pipeline lane's stream costs the
 // pipeline tens of microseconds while other lanes' plane transfers are in flight): the descriptors are read from the
 // page-locked ring through its device mapping, the tile bins start at (min 0x7f7f7f7f, max + 1 = 0), the deferred list
@@ -1099,7 +1174,7 @@ __global__ void __launch_bounds__(256) k_chain_prologue(uint32_t *__restrict__ d
 
 // Shared host tail of the two tile kernels: scratch, descriptor upload, cell setup, launch.
 static int launch_tiles(vkx_ctx *ctx, std::vector<ItemDev> &dev, std::vector<int> &prefix, long long ncells, int max_tiles,
-                        bool elements)
+                        bool elements, const std::vector<long long> *noise_row_prefix = nullptr)
 {
     const int n_items = (int)dev.size();
     int rc;
@@ -1112,16 +1187,20 @@ static int launch_tiles(vkx_ctx *ctx, std::vector<ItemDev> &dev, std::vector<int
     if ((rc = vkx_scratch_reserve(ctx, &ctx->owner, sizeof(TileBin) * nbins))) return rc;
     const size_t items_bytes = sizeof(ItemDev) * (size_t)n_items, prefix_bytes = sizeof(int) * prefix.size();
     const size_t items_off = 0, prefix_off = (items_bytes + 255) & ~(size_t)255;
-    if ((rc = vkx_scratch_reserve(ctx, &ctx->misc, prefix_off + prefix_bytes))) return rc;
+    const size_t rowp_off = (prefix_off + prefix_bytes + 255) & ~(size_t)255;
+    const size_t rowp_bytes = noise_row_prefix ? sizeof(long long) * noise_row_prefix->size() : 0;
+    const size_t misc_bytes = noise_row_prefix ? rowp_off + rowp_bytes : prefix_off + prefix_bytes;
+    if ((rc = vkx_scratch_reserve(ctx, &ctx->misc, misc_bytes))) return rc;
     const HsvLut *lut = nullptr;
     if (!elements && (rc = vkx_hsv_tables(ctx, (const void **)&lut))) return rc;
     unsigned char *misc = (unsigned char *)ctx->misc.ptr;
     // the descriptors travel through the ctx's page-locked ring: the copy is queued and the launch returns without a
     // stream synchronisation (host-array pipelines keep several launches in flight)
     void *ring = nullptr;
-    if ((rc = vkx_desc_ring_take(ctx, prefix_off + prefix_bytes, &ring))) return rc;
+    if ((rc = vkx_desc_ring_take(ctx, misc_bytes, &ring))) return rc;
     memcpy((unsigned char *)ring + items_off, dev.data(), items_bytes);
     memcpy((unsigned char *)ring + prefix_off, prefix.data(), prefix_bytes);
+    if (noise_row_prefix) memcpy((unsigned char *)ring + rowp_off, noise_row_prefix->data(), rowp_bytes);
     const ItemDev *d_items = (const ItemDev *)(misc + items_off);
     const int *d_cell_prefix = (const int *)(misc + prefix_off);
     TileBin *bins = (TileBin *)ctx->owner.ptr;
@@ -1130,7 +1209,7 @@ static int launch_tiles(vkx_ctx *ctx, std::vector<ItemDev> &dev, std::vector<int
     {
         void *ring_dev = nullptr;
         VKX_HIP(hipHostGetDevicePointer(&ring_dev, ring, 0));
-        const size_t n_words = (prefix_off + prefix_bytes + 3) / 4;
+        const size_t n_words = (misc_bytes + 3) / 4;
         k_chain_prologue<<<vkx_blocks(std::max(n_words, nbins), 256), 256, 0, ctx->stream>>>((uint32_t *)misc, (const uint32_t *)ring_dev,
                                                                                             (unsigned)n_words, bins, (unsigned)nbins, deferred);
         VKX_LAUNCH_CHECK();
@@ -1142,6 +1221,12 @@ static int launch_tiles(vkx_ctx *ctx, std::vector<ItemDev> &dev, std::vector<int
     // profiling aids: VKX_FUSED_PHASES=1|2 stops the kernel after phase A | C+D, 10..13 inside phase A (tools/phases_a.sh),
     // 20 writes the horizontal sums of the centre row instead of the finished pixel
     static const int phase_limit = [] { const char *e = getenv("VKX_FUSED_PHASES"); return e ? atoi(e) : 0; }();
+    if (noise_row_prefix && noise_row_prefix->back() > 0) {
+        VKX_TIMED(ctx, "k_chain_noise_rows");
+        const long long total = noise_row_prefix->back();
+        k_chain_noise_rows<<<vkx_blocks((size_t)total, 256), 256, 0, ctx->stream>>>(d_items, (const long long *)(misc + rowp_off), n_items, total);
+        VKX_LAUNCH_CHECK();
+    }
     if (elements) {
         { VKX_TIMED(ctx, "k_tile_remap"); k_tile_remap<<<dim3(slots, n_items), NTHREADS, kFusedLds, ctx->stream>>>(d_items, cells, bins); }
     } else {
@@ -1163,6 +1248,7 @@ int vkx_chain_fused_try(vkx_ctx *ctx, const vkx_chain_item *items, int n_items)
     std::vector<ItemDev> dev(n_items);
     std::vector<int> prefix((size_t)n_items + 1);   // first cell of every image in the batch-wide cell table
     int *cell_prefix = prefix.data();
+    std::vector<long long> row_prefix((size_t)n_items + 1, 0);   // first (row, tile column) record of every image with tiled noise
     long long tiles = 0, ncells = 0;
     int max_tiles = 0;
     for (int i = 0; i < n_items; i++) {
@@ -1174,6 +1260,18 @@ int vkx_chain_fused_try(vkx_ctx *ctx, const vkx_chain_item *items, int n_items)
         ItemDev &d = dev[i];
         d.src = it.src; d.dst = it.dst; d.noise = it.noise; d.sv = it.src_vertices; d.dv = it.dst_vertices;
         d.sstride = it.src_stride; d.dstride = it.dst_stride; d.nstride = it.noise_stride_el;
+        d.noise_table = nullptr; d.noise_tiled = 0; d.noise_tiles = 0; d.noise_slot = 0; d.noise_tiles_per_sample = 0.f;
+        d.noise_rows = nullptr;
+        if (it.noise && it.noise_tiled) {
+            const long long n = (long long)it.dh * it.dw * 3;
+            if (n > 0x7fffffffLL) return VKX_ERR_UNSUPPORTED;
+            const vkx_np_tiles_shape shape = vkx_np_tiles_shape_of(n);
+            if (shape.n_tiles * shape.slot_elems > 0xffffffffLL) return VKX_ERR_UNSUPPORTED;      // 32-bit slot offsets
+            d.noise = (const int16_t *)((const unsigned char *)it.noise + shape.slots_offset);
+            d.noise_table = (const uint2 *)((const unsigned char *)it.noise + shape.table_offset);
+            d.noise_tiled = 1; d.noise_tiles = (int)shape.n_tiles; d.noise_slot = shape.slot_elems;
+            d.noise_tiles_per_sample = (float)(1.0 / shape.samples_per_tile);
+        }
         d.sh = it.sh; d.sw = it.sw; d.dh = it.dh; d.dw = it.dw; d.rows = it.rows; d.cols = it.cols;
         d.R = it.blur_ksize > 1 ? it.blur_ksize / 2 : 0;
         const int Tw = tile_side(d.R);
@@ -1201,14 +1299,21 @@ int vkx_chain_fused_try(vkx_ctx *ctx, const vkx_chain_item *items, int n_items)
         if (it.src_stride <= 0 || it.src_stride >= (1 << 24) || (long long)it.sh * it.src_stride + 8 > 0xffffffffLL) return VKX_ERR_UNSUPPORTED;
         if (it.dst_stride <= 0 || (long long)it.dh * it.dst_stride > 0xffffffffLL) return VKX_ERR_UNSUPPORTED;
         cell_prefix[i] = (int)ncells;
+        row_prefix[i + 1] = row_prefix[i] + (d.noise_tiled ? (long long)it.dh * d.tiles_x : 0);
         tiles += (long long)d.tiles_x * d.tiles_y;
         if (d.tiles_x * d.tiles_y > max_tiles) max_tiles = d.tiles_x * d.tiles_y;
         ncells += (long long)(it.rows - 1) * (it.cols - 1);
         if (tiles > 0x3fffffff || ncells > 0x3fffffff) return VKX_ERR_UNSUPPORTED;
     }
     cell_prefix[n_items] = (int)ncells;
+    if (row_prefix[n_items] > 0) {
+        int rc = vkx_scratch_reserve(ctx, &ctx->noise_rows, (size_t)row_prefix[n_items] * sizeof(uint2));
+        if (rc) return rc;
+        for (int i = 0; i < n_items; i++)
+            if (dev[i].noise_tiled) dev[i].noise_rows = (const uint2 *)ctx->noise_rows.ptr + row_prefix[i];
+    }
 
-    return launch_tiles(ctx, dev, prefix, ncells, max_tiles, false);
+    return launch_tiles(ctx, dev, prefix, ncells, max_tiles, false, &row_prefix);
 }
 
 // vkx_grid_remap through the tile kernel; VKX_ERR_UNSUPPORTED (no error set) for shapes it does not take.

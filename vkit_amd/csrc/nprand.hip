@@ -118,6 +118,8 @@ struct NpJob {
     double cdf[3];
     const uint8_t *src;
     void *dst;
+    int16_t *rec;            // compacted int16 records of the job's tiles, kSlot elements per tile (scratch, or the caller's tile buffer)
+    uint2 *table;            // VKX_NP_NORMAL_TILES: [n_tiles + 1] x (index of the tile's first sample, its first valid slot element)
 };
 
 struct TileInfo {            // pass 1, assuming carry-in 0
@@ -157,24 +159,24 @@ struct EmitNone {
     typedef int Val;
     typedef int16_t Store;
     __device__ static Val make(const NpJob &, double, bool, uint32_t &) { return 0; }
-    __device__ static void store(const NpJob &, long long, Val, bool, uint32_t &) {}
+    __device__ static void store(const NpJob &, void *, long long, Val, bool, uint32_t &) {}
 };
 struct EmitI16 {   // np.round(0 + std * z).astype(int16)
     static constexpr bool kCheckAtStore = false;
     typedef int Val;
     typedef int16_t Store;
     __device__ static Val make(const NpJob &job, double z, bool inexact, uint32_t &flags) { return rounded_step(job, z, inexact, flags); }
-    __device__ static void store(const NpJob &job, long long pos, Val k, bool, uint32_t &) { ((int16_t VKX_GLOBAL *)job.dst)[pos] = (int16_t)k; }
+    __device__ static void store(const NpJob &, void *dst, long long pos, Val k, bool, uint32_t &) { ((int16_t VKX_GLOBAL *)dst)[pos] = (int16_t)k; }
 };
 struct EmitAddU8 {   // clip(int16(px) + noise, 0, 255): the whole gaussion_noise operator
     static constexpr bool kCheckAtStore = false;
     typedef int Val;
     typedef int16_t Store;
     __device__ static Val make(const NpJob &job, double z, bool inexact, uint32_t &flags) { return rounded_step(job, z, inexact, flags); }
-    __device__ static void store(const NpJob &job, long long pos, Val k, bool, uint32_t &)
+    __device__ static void store(const NpJob &job, void *dst, long long pos, Val k, bool, uint32_t &)
     {
         const int s = (int16_t)((int)((const uint8_t VKX_GLOBAL *)job.src)[pos] + k);
-        ((uint8_t VKX_GLOBAL *)job.dst)[pos] = (uint8_t)vkd::clamp_u8(s);
+        ((uint8_t VKX_GLOBAL *)dst)[pos] = (uint8_t)vkd::clamp_u8(s);
     }
 };
 struct EmitSpeckle {   // uint8(clip(px + px * (0 + std * z), 0, 255)) in float64
@@ -182,7 +184,7 @@ struct EmitSpeckle {   // uint8(clip(px + px * (0 + std * z), 0, 255)) in float6
     typedef double Val;
     typedef double Store;
     __device__ static Val make(const NpJob &, double z, bool, uint32_t &) { return z; }
-    __device__ static void store(const NpJob &job, long long pos, Val z, bool inexact, uint32_t &flags)
+    __device__ static void store(const NpJob &job, void *dst, long long pos, Val z, bool inexact, uint32_t &flags)
     {
         const double noise = 0.0 + job.scale * z;
         const double m = (double)((const uint8_t VKX_GLOBAL *)job.src)[pos];
@@ -192,12 +194,12 @@ struct EmitSpeckle {   // uint8(clip(px + px * (0 + std * z), 0, 255)) in float6
         // (a zero pixel stays zero whatever the noise)
         if (inexact && m != 0.0 && fabs(r - rint(r)) < 1e-9) flags |= VKX_NP_AMBIGUOUS;
         r = r < 0.0 ? 0.0 : (r > 255.0 ? 255.0 : r);
-        ((uint8_t VKX_GLOBAL *)job.dst)[pos] = (uint8_t)(int)r;
+        ((uint8_t VKX_GLOBAL *)dst)[pos] = (uint8_t)(int)r;
     }
 };
 
 // Per-wavefront LDS workspace of a tile walk.
-constexpr int kEvCap = 128;      // attempts per tile that are not a fast accept: mean 15.4, sigma 3.9
+constexpr int kEvCap = kRounds <= 48 ? 96 : 128;   // attempts per tile that are not a fast accept: 0.96 per round (48 rounds: 46 +- 7)
 template <typename Val, bool WITH_VAL>
 struct WaveWork {
     uint64_t ev_s[kEvCap][2];    // LCG state of the event's draw; after evaluation [0] holds the bits of a tail sample
@@ -206,7 +208,9 @@ struct WaveWork {
     uint64_t slow[kRounds];      // per round: the lanes whose attempt is not a fast accept
     uint64_t semit[kRounds];     // per round: the events that emit a sample, as a lane mask
     uint64_t cov[kRounds];       // per round: the draws consumed by an attempt that started earlier
-    Val val[WITH_VAL ? kRounds : 1][64];   // kEmit: what every draw would emit as a fast accept (int16 steps, or the float64 draw)
+    // kEmit / kCompact: what every draw would emit as a fast accept (int16 steps, or the float64 draw); kCompact squeezes the
+    // tile's samples together in place and sends them to the tile's slot as 16-byte groups
+    __attribute__((aligned(16))) Val val[WITH_VAL ? kRounds : 1][64];
 };
 
 __device__ __forceinline__ uint64_t rfl64(uint64_t v)
@@ -228,12 +232,57 @@ __device__ __forceinline__ int mbcnt64(uint64_t m)
 //   MODE kCount   the walk only: samples the tile yields and its carry-out for the given carry-in
 //   MODE kRecord  carry-in 0: besides the count, what every draw would emit (`rec_val`, 1024 per tile, in draw order) and
 //                 the 16 emit masks (`rec_mask`) go to global memory for k_np_place
-//   MODE kEmit    the samples are stored at their final index
-enum { kCount = 0, kRecord = 1, kEmit = 2 };
+//   MODE kEmit    the samples are stored at their final index of `emit_dst`
+//   MODE kCompact carry-in 0: the samples the tile yields, squeezed together in LDS, go to the tile's slot `rec_val` as whole
+//                 16-byte groups (int16 emitters; the consumer drops the leading samples a carry-in takes away)
+enum { kCount = 0, kRecord = 1, kEmit = 2, kCompact = 3 };
+
+__device__ __forceinline__ uint32_t lds_offset(const void *p)
+{
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+
+// The samples of a tile parked in draw order (`flat[64 r + l]` = what draw l of round r emits), lane r < kRounds holding round
+// r's emit mask: squeezed together IN PLACE -- a sample's rank never exceeds its draw position, rounds are handled in order
+// and a round reads its 64 elements before it writes.  Per round two v_readlane, two v_mbcnt whose addend carries the running
+// count, one address op, a 2-byte LDS read and a write masked through exec.  Returns the number of samples.
+__device__ __forceinline__ uint32_t compact_tile_lds(int16_t *flat, uint64_t m)
+{
+    const uint32_t lane = (uint32_t)__lane_id();
+    const uint32_t base = lds_offset(flat);
+    uint32_t run = 0;
+    // eight rounds' reads are in flight before the first of their writes (a round's write lands at or below the round's own
+    // elements, never on a later round's): one LDS round trip per eight rounds instead of one per round
+    constexpr int kBatch = 8;
+    static_assert(kRounds % kBatch == 0 || kRounds < kBatch, "rounds per compaction batch");
+#pragma unroll
+    for (int r0 = 0; r0 < kRounds; r0 += kBatch) {
+        uint32_t v[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; j++)
+            if (r0 + j < kRounds) v[j] = (uint16_t)flat[64 * (r0 + j) + lane];
+#pragma unroll
+        for (int j = 0; j < kBatch; j++) {
+            const int r = r0 + j;
+            if (r >= kRounds) break;
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)m, r), hi = (uint32_t)__builtin_amdgcn_readlane((int)(m >> 32), r);
+            const uint32_t rank = (uint32_t)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, run));
+            const uint32_t addr = base + 2 * rank;
+            const uint64_t mask = ((uint64_t)hi << 32) | lo;
+            uint64_t saved;
+            asm volatile("s_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[m]\n\tds_write_b16 %[a], %[v]\n\ts_mov_b64 exec, %[sv]"
+                         : [sv] "=&s"(saved) : [m] "s"(mask), [a] "v"(addr), [v] "v"(v[j]) : "memory");
+            run += (uint32_t)__builtin_popcountll(mask);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return run;
+}
+
 template <class Emit, int MODE>
 __device__ void walk_tile(const NpJob &job, const JumpTabs &g_jump, const uint4 *__restrict__ zig /* LDS: ki | wi */, const double *__restrict__ fi /* LDS */,
-                          WaveWork<typename Emit::Store, MODE == kEmit> &ws, u128 base, uint32_t c_in, long long prefix, long long draw_base,
-                          typename Emit::Store VKX_GLOBAL *rec_val, uint64_t VKX_GLOBAL *rec_mask,
+                          WaveWork<typename Emit::Store, MODE == kEmit || MODE == kCompact> &ws, u128 base, uint32_t c_in, long long prefix,
+                          long long draw_base, typename Emit::Store VKX_GLOBAL *rec_val, uint64_t VKX_GLOBAL *rec_mask, void *emit_dst,
                           uint32_t &count_out, uint32_t &carry_out, uint64_t &start0, uint64_t &emit0, bool &has_tail, uint32_t &flags,
                           unsigned long long *draws_used)
 {
@@ -264,7 +313,7 @@ __device__ void walk_tile(const NpJob &job, const JumpTabs &g_jump, const uint4 
             x = __longlong_as_double(__double_as_longlong(x) | ((long long)((uint32_t)u << 23 & 0x80000000u) << 32));
             const typename Emit::Store v = (typename Emit::Store)Emit::make(job, x, false, flags);
             if (MODE == kRecord) rec_val[64 * r + lane] = v;
-            else if (MODE == kEmit) ws.val[r][lane] = v;
+            else if (MODE == kEmit || MODE == kCompact) ws.val[r][lane] = v;
         }
         const uint64_t slow = __ballot(rabs >= ki);
         if (lane == 0) ws.slow[r] = slow;
@@ -298,7 +347,7 @@ __device__ void walk_tile(const NpJob &job, const JumpTabs &g_jump, const uint4 
     has_tail = false;
     // phase 2
 #pragma unroll
-    for (int q = 0; q < kEvCap / 64; q++) {
+    for (int q = 0; q < (kEvCap + 63) / 64; q++) {
         if ((uint32_t)(64 * q) >= nev) break;
         const uint32_t ev = 64 * q + lane;
         if (ev < nev) {
@@ -348,6 +397,8 @@ __device__ void walk_tile(const NpJob &job, const JumpTabs &g_jump, const uint4 
                 const double z = ((rabs >> 8) & 1) ? -(kNorR + xx) : kNorR + xx;
                 if (MODE == kRecord) {
                     rec_val[pos] = (typename Emit::Store)Emit::make(job, z, true, flags);
+                } else if (MODE == kCompact) {
+                    (&ws.val[0][0])[pos] = (typename Emit::Store)Emit::make(job, z, true, flags);
                 } else if (MODE == kEmit) {
                     const typename Emit::Val v = Emit::make(job, z, true, flags);
                     uint64_t bits = 0;
@@ -473,7 +524,7 @@ __device__ void walk_tile(const NpJob &job, const JumpTabs &g_jump, const uint4 
                         inexact = true;
                     }
                 }
-                Emit::store(job, pos, z, inexact, flags);
+                Emit::store(job, emit_dst, pos, z, inexact, flags);
                 if (pos == job.n - 1)      // write-through: read by the last workgroup of the kernel (np_results_out)
                     __hip_atomic_store(draws_used, (unsigned long long)(draw_base + 64 * r + lane + len), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -482,6 +533,21 @@ __device__ void walk_tile(const NpJob &job, const JumpTabs &g_jump, const uint4 
         }
     }
     if (MODE == kRecord && lane < kRounds) rec_mask[lane] = my_mask;
+    if constexpr (MODE == kCompact) {
+        static_assert(sizeof(typename Emit::Store) == 2, "compact records are int16");
+        int16_t *flat = (int16_t *)&ws.val[0][0];
+        const uint32_t total = compact_tile_lds(flat, my_mask);        // == count
+        const uint32_t groups = (total + 7) >> 3;                      // the last group's surplus elements are never read
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 *f16 = (const u32x4 *)flat;
+        u32x4 VKX_GLOBAL *s16 = (u32x4 VKX_GLOBAL *)rec_val;
+#pragma unroll
+        for (int i = 0; i < kTile / 512; i++) {
+            const uint32_t idx = (uint32_t)lane + 64u * i;
+            if (idx < groups) s16[idx] = f16[idx];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
     count_out = count;
     carry_out = carry;
 }
@@ -582,7 +648,47 @@ __global__ void __launch_bounds__(256) k_np_draw(const NpJob *__restrict__ jobs,
         bool has_tail;
         walk_tile<Emit, kRecord>(job, g_jump, zig, fi, work[threadIdx.x >> 6], mk128(&states[2 * tile]), 0u, 0, 0,
                                  (typename Emit::Store VKX_GLOBAL *)(rec_val + tile * kTile), (uint64_t VKX_GLOBAL *)(rec_mask + tile * kRounds),
-                                 count, carry, start0, emit0, has_tail, flags, nullptr);
+                                 nullptr, count, carry, start0, emit0, has_tail, flags, nullptr);
+        if (__lane_id() == 0) {
+            TileInfo t;
+            t.count0 = count; t.out0 = carry | (has_tail ? 0x80000000u : 0u); t.start0 = start0; t.emit0 = emit0;
+            info[tile] = t;
+        }
+        if (flags) atomicOr(&results[j].flags, flags);
+    }
+}
+
+// The draw pass of the int16 kinds: the same walk, but a tile's samples leave squeezed together (kCompact) for the tile's slot of
+// kSlot elements -- the placement pass that used to read 2 bytes per RAW DRAW plus the emit masks, rank the samples and
+// scatter them is gone: what follows only copies (k_np_apply), or nothing follows at all (VKX_NP_NORMAL_TILES: the chain
+// kernel reads the slots).  kDrawWaves wavefronts share the ziggurat tables: 8 x 9.0 KB + 6 KB per workgroup, two workgroups
+// (16 wavefronts at 112 VGPRs) per CU.
+constexpr int kSlot = kTile + 16;        // elements per slot: the tile's samples, two lent by the next tile, 16-byte group rounding
+#ifndef VKX_NP_DRAW_WAVES
+#define VKX_NP_DRAW_WAVES 8
+#endif
+constexpr int kDrawWaves = VKX_NP_DRAW_WAVES;
+
+template <class Emit>
+__global__ void __launch_bounds__(64 * kDrawWaves) k_np_draw_compact(const NpJob *__restrict__ jobs, int n_jobs, long long total_tiles,
+                                                                    const uint64_t *__restrict__ states, TileInfo *__restrict__ info,
+                                                                    vkx_np_result *__restrict__ results, const NpTabs *__restrict__ tabs)
+{
+    __shared__ uint4 zig[256];
+    __shared__ double fi[256];
+    __shared__ WaveWork<int16_t, true> work[kDrawWaves];
+    load_tables(zig, fi, tabs);
+    const JumpTabs &g_jump = tabs->jump;
+    const long long n_waves = (long long)gridDim.x * kDrawWaves;
+    for (long long tile = (long long)blockIdx.x * kDrawWaves + (threadIdx.x >> 6); tile < total_tiles; tile += n_waves) {
+        const int j = job_of_tile(jobs, n_jobs, tile);
+        const NpJob &job = jobs[j];
+        uint32_t count, carry, flags = 0;
+        uint64_t start0, emit0;
+        bool has_tail;
+        walk_tile<Emit, kCompact>(job, g_jump, zig, fi, work[threadIdx.x >> 6], mk128(&states[2 * tile]), 0u, 0, 0,
+                                  (int16_t VKX_GLOBAL *)(job.rec + (tile - job.tile_base) * kSlot), nullptr, nullptr,
+                                  count, carry, start0, emit0, has_tail, flags, nullptr);
         if (__lane_id() == 0) {
             TileInfo t;
             t.count0 = count; t.out0 = carry | (has_tail ? 0x80000000u : 0u); t.start0 = start0; t.emit0 = emit0;
@@ -655,8 +761,8 @@ __global__ void __launch_bounds__(1024) k_np_resolve(const NpJob *__restrict__ j
                 } else {
                     uint64_t s0, e0;
                     bool ht;
-                    walk_tile<EmitNone, kCount>(job, g_jump, zig, fi, work[0], mk128(&st[2 * j]), c, 0, 0, nullptr, nullptr, count, out, s0, e0,
-                                                ht, flags, nullptr);
+                    walk_tile<EmitNone, kCount>(job, g_jump, zig, fi, work[0], mk128(&st[2 * j]), c, 0, 0, nullptr, nullptr, nullptr, count, out,
+                                                s0, e0, ht, flags, nullptr);
                     simulated = true;
                 }
                 if (threadIdx.x == 0) {
@@ -720,7 +826,7 @@ struct Placer {
         const uint64_t emits = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(m >> 32), r) << 32) |
                                (uint32_t)__builtin_amdgcn_readlane((int)m, r);
         const long long pos = prefix + count + mbcnt64(emits);
-        if (((emits >> lane) & 1) && pos < job.n) Emit::store(job, pos, (typename Emit::Val)vals[64 * r + lane], false, flags);
+        if (((emits >> lane) & 1) && pos < job.n) Emit::store(job, job.dst, pos, (typename Emit::Val)vals[64 * r + lane], false, flags);
         count += (uint32_t)__builtin_popcountll(emits);
     }
 }
@@ -746,10 +852,6 @@ __device__ __forceinline__ TileDraws load_tile_i16(const int16_t *__restrict__ r
 // (rank of each of a lane's two draws by popcounts and selects), in a pass that shares the SIMDs with the draw pass of the
 // next chunk.
 constexpr int kRawOff = 8;
-__device__ __forceinline__ uint32_t lds_offset(const void *p)
-{
-    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
-}
 __device__ __forceinline__ uint32_t stage_tile_lds(const TileDraws &d, uint64_t m, uint32_t shift, int16_t *st)
 {
     const uint32_t lane = (uint32_t)__lane_id();
@@ -921,8 +1023,128 @@ __global__ void __launch_bounds__(256) k_np_place(const NpJob *__restrict__ jobs
     if (flags) atomicOr(&results[j].flags, flags);
 }
 
+// Pass 2 of the compact kinds, one wavefront per tile: the samples of slot elements [skip, skip + count) go to their final
+// index -- a copy (VKX_NP_NORMAL_I16) or clip(uint8 + int16) in place (VKX_NP_NORMAL_ADD_U8), four elements per lane and step
+// (an unaligned 8-byte record load; the destination group is aligned).  `skip` = the samples the recorded chain emitted
+// before the tile's true carry-in.
+template <bool ADD>
+__device__ __forceinline__ void apply_tile(const int16_t VKX_GLOBAL *rec /* the tile's first valid sample */, long long prefix, uint32_t count,
+                                           const uint8_t *src, void *dst)
+{
+    typedef short pk16 __attribute__((ext_vector_type(2)));
+    typedef unsigned long long u64_u2 __attribute__((aligned(2)));
+    const uint32_t lane = (uint32_t)__lane_id();
+    const uint32_t head = min(count, (uint32_t)(-prefix) & 3u);
+    const uint32_t body = (count - head) >> 2, tail = (count - head) & 3u;
+    auto one = [&](uint32_t e) {
+        if (ADD) {
+            const int v = (int16_t)((int)((const uint8_t VKX_GLOBAL *)src)[prefix + e] + (int)rec[e]);
+            ((uint8_t VKX_GLOBAL *)dst)[prefix + e] = (uint8_t)vkd::clamp_u8(v);
+        } else {
+            ((int16_t VKX_GLOBAL *)dst)[prefix + e] = rec[e];
+        }
+    };
+#pragma unroll 4
+    for (uint32_t i = 0; i < (uint32_t)kTile / 256; i++) {
+        if (64u * i >= body) break;
+        const uint32_t g = lane + 64u * i;
+        if (g < body) {
+            const uint32_t e = head + 4u * g;
+            const unsigned long long nz = *(const u64_u2 VKX_GLOBAL *)(rec + e);
+            if (ADD) {
+                const uint32_t px = *(const uint32_t VKX_GLOBAL *)((const uint8_t VKX_GLOBAL *)src + prefix + e);
+                pk16 lo = __builtin_bit_cast(pk16, __builtin_amdgcn_perm(0u, px, 0x0c010c00u));
+                pk16 hi = __builtin_bit_cast(pk16, __builtin_amdgcn_perm(0u, px, 0x0c030c02u));
+                lo += __builtin_bit_cast(pk16, (uint32_t)nz);
+                hi += __builtin_bit_cast(pk16, (uint32_t)(nz >> 32));
+                const pk16 zero = {0, 0}, top = {255, 255};
+                lo = __builtin_elementwise_min(__builtin_elementwise_max(lo, zero), top);
+                hi = __builtin_elementwise_min(__builtin_elementwise_max(hi, zero), top);
+                *(uint32_t VKX_GLOBAL *)((uint8_t VKX_GLOBAL *)dst + prefix + e) =
+                    __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x06040200u);
+            } else {
+                *(unsigned long long VKX_GLOBAL *)((int16_t VKX_GLOBAL *)dst + prefix + e) = nz;
+            }
+        }
+    }
+    if (lane < 8) {
+        const uint32_t k = lane & 3u;
+        if (lane < 4 ? k < head : k < tail) one(lane < 4 ? k : head + 4u * body + k);
+    }
+}
+
+template <bool ADD>
+__global__ void __launch_bounds__(256) k_np_apply(const NpJob *__restrict__ jobs, int n_jobs, long long total_tiles,
+                                                  const TileInfo *__restrict__ info, const TilePlan *__restrict__ plan)
+{
+    const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= total_tiles) return;
+    const TilePlan p = plan[tile];
+    const uint64_t emit0 = info[tile].emit0;
+    const NpJob &job = jobs[job_of_tile(jobs, n_jobs, tile)];
+    const long long prefix = (long long)rfl64(p.prefix);
+    if (prefix >= job.n) return;
+    TilePlan pu;
+    pu.prefix = (unsigned long long)prefix;
+    pu.c_in = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.c_in);
+    pu.count = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.count);
+    if (tile_needs_walk(job, pu, 0u, false)) return;
+    const uint32_t skip = (uint32_t)__builtin_popcountll(rfl64(emit0) & ((1ull << pu.c_in) - 1));
+    // prefix + count < n here (the tile with the last sample is walked)
+    apply_tile<ADD>((const int16_t VKX_GLOBAL *)job.rec + (tile - job.tile_base) * kSlot + skip, prefix, pu.count, job.src, job.dst);
+}
+
+// A finished tile buffer (VKX_NP_NORMAL_TILES) as the int16 plane it stands for: vkx_np_tiles_expand_dev.
+__global__ void __launch_bounds__(256) k_np_tiles_expand(const uint2 *__restrict__ table, const int16_t *__restrict__ slots, int n_tiles,
+                                                         long long n, int16_t *__restrict__ dst)
+{
+    const int t = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (t >= n_tiles) return;
+    const uint2 a = table[t], b = table[t + 1];
+    const long long prefix = (long long)__builtin_amdgcn_readfirstlane((int)a.x) & 0xffffffffLL;
+    const uint32_t next = (uint32_t)__builtin_amdgcn_readfirstlane((int)b.x), skip = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.y);
+    if (prefix >= n) return;
+    uint32_t count = next - (uint32_t)prefix;
+    if (prefix + count > n) count = (uint32_t)(n - prefix);
+    apply_tile<false>((const int16_t VKX_GLOBAL *)slots + (long long)t * kSlot + skip, prefix, count, nullptr, dst);
+}
+
+// VKX_NP_NORMAL_TILES, after the walk: one lane per tile writes the tile's table entry (index of its first sample, first valid
+// slot element) and lends the tile the first two samples of its successor, so that the three samples of a pixel never
+// straddle two slots; the job's last tile also writes the sentinel entry and the header.
+__global__ void __launch_bounds__(256) k_np_tiles_finish(const NpJob *__restrict__ jobs, int n_jobs, long long total_tiles,
+                                                         const TileInfo *__restrict__ info, const TilePlan *__restrict__ plan)
+{
+    const long long tile = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (tile >= total_tiles) return;
+    const NpJob &job = jobs[job_of_tile(jobs, n_jobs, tile)];
+    const long long t = tile - job.tile_base;
+    auto skip_of = [&](long long tl, const TilePlan &p) -> uint32_t {
+        if ((long long)p.prefix < job.n && tile_needs_walk(job, p, 0u, false)) return 0u;     // rewritten from its true carry-in
+        if (p.c_in & kIrregular) return 0u;                                                   // (beyond the samples wanted)
+        return (uint32_t)__builtin_popcountll(info[tl].emit0 & ((1ull << p.c_in) - 1));
+    };
+    const TilePlan p = plan[tile];
+    const uint32_t skip = skip_of(tile, p);
+    job.table[t] = make_uint2((uint32_t)p.prefix, skip);
+    int16_t *rec = job.rec + t * kSlot;
+    if (t + 1 < job.n_tiles) {
+        const TilePlan pn = plan[tile + 1];
+        const int16_t *nxt = rec + kSlot + skip_of(tile + 1, pn);
+        rec[skip + p.count] = nxt[0];
+        rec[skip + p.count + 1] = nxt[1];
+    } else {
+        job.table[t + 1] = make_uint2((uint32_t)(p.prefix + p.count), 0u);
+        uint32_t *header = (uint32_t *)job.table - 4;
+        header[0] = (uint32_t)job.n_tiles;
+        header[1] = (uint32_t)kSlot;
+        *(unsigned long long *)(header + 2) = p.prefix + p.count;
+    }
+}
+
 // (one wavefront per workgroup: the kEmit workspace of a float64 emitter is 26 KB)
-template <class Emit>
+// TILES: the walked tiles rewrite their slot from its first element (their table entry says skip = 0)
+template <class Emit, bool TILES = false>
 __global__ void __launch_bounds__(64) k_np_place_walk(const NpJob *__restrict__ jobs, int n_jobs, long long total_tiles,
                                                        const uint64_t *__restrict__ states, const TileInfo *__restrict__ info,
                                                        const TilePlan *__restrict__ plan, vkx_np_result *__restrict__ results,
@@ -956,8 +1178,10 @@ __global__ void __launch_bounds__(64) k_np_place_walk(const NpJob *__restrict__ 
             uint32_t count, carry, flags = 0;
             uint64_t start0, emit0;
             bool ht;
+            void *dst = job.dst;
+            if (TILES) dst = (void *)((intptr_t)(job.rec + (tile - job.tile_base) * kSlot) - 2 * (intptr_t)p.prefix);
             walk_tile<Emit, kEmit>(job, g_jump, zig, fi, work[0], mk128(&states[2 * tile]), p.c_in & ~kIrregular,
-                                   (long long)p.prefix, (tile - job.tile_base) * kTile, nullptr, nullptr, count, carry, start0, emit0, ht,
+                                   (long long)p.prefix, (tile - job.tile_base) * kTile, nullptr, nullptr, dst, count, carry, start0, emit0, ht,
                                    flags, &results[j].draws);
             if (flags) atomicOr(&results[j].flags, flags);
         }
@@ -1029,11 +1253,45 @@ static int np_tables(vkx_ctx *ctx, const NpTabs **out)
     return VKX_OK;
 }
 
-static long long np_tiles_for(const vkx_np_job &j, bool uniform)
+static long long np_tiles_for_n(long long n, bool uniform)
 {
     // raw draws to provision: the ziggurat uses 1.022 per sample on average
-    const long long draws = uniform ? j.n : j.n + j.n / 32 + 2048;
+    const long long draws = uniform ? n : n + n / 32 + 2048;
     return (draws + kTile - 1) / kTile;
+}
+static long long np_tiles_for(const vkx_np_job &j, bool uniform) { return np_tiles_for_n(j.n, uniform); }
+
+// The tile buffer of a VKX_NP_NORMAL_TILES job of n samples: 16-byte header, the table, the slots.
+vkx_np_tiles_shape vkx_np_tiles_shape_of(long long n)
+{
+    vkx_np_tiles_shape s;
+    s.n_tiles = np_tiles_for_n(n, false);
+    s.slot_elems = kSlot;
+    s.table_offset = 16;
+    s.slots_offset = (16 + 8 * ((size_t)s.n_tiles + 1) + 255) & ~(size_t)255;
+    s.bytes = s.slots_offset + (size_t)s.n_tiles * kSlot * 2;
+    s.samples_per_tile = (double)kTile * 0.97850;      // E[samples per raw draw] of numpy's ziggurat: 0.97850 (measured over 3e6 samples)
+    return s;
+}
+
+VKX_EXPORT int vkx_np_tiles_layout(int64_t n, int64_t *n_tiles, int64_t *slot_elems, int64_t *table_offset, int64_t *slots_offset,
+                                   int64_t *bytes)
+{
+    VKX_REQUIRE(n >= 1 && n <= 0x7fffffffLL, "1 .. 2^31 - 1 samples");
+    const vkx_np_tiles_shape s = vkx_np_tiles_shape_of(n);
+    if (n_tiles) *n_tiles = s.n_tiles;
+    if (slot_elems) *slot_elems = s.slot_elems;
+    if (table_offset) *table_offset = (int64_t)s.table_offset;
+    if (slots_offset) *slots_offset = (int64_t)s.slots_offset;
+    if (bytes) *bytes = (int64_t)s.bytes;
+    return VKX_OK;
+}
+
+// VKX_NP_COMPACT=0: the int16 kinds through the raw-draw records and the placement pass of round 3 (A/B).
+static bool np_compact_records(int kind)
+{
+    static const bool on = [] { const char *e = getenv("VKX_NP_COMPACT"); return !(e && e[0] == '0'); }();
+    return kind == VKX_NP_NORMAL_TILES || (on && (kind == VKX_NP_NORMAL_I16 || kind == VKX_NP_NORMAL_ADD_U8));
 }
 
 // One chunk of a call: its tile arrays in one of the two scratch slots, its jobs, its slice of the results.
@@ -1065,8 +1323,9 @@ static int np_chunk_prepare(vkx_ctx *ctx, NpChunk &c)
     c.o_info = take(uniform ? 0 : (size_t)c.total_tiles * sizeof(TileInfo));
     c.o_plan = take(uniform ? 0 : (size_t)c.total_tiles * sizeof(TilePlan));
     const size_t val_bytes = c.kind == VKX_NP_SPECKLE_U8 ? 8 : 2;
-    c.o_rmask = take(uniform ? 0 : (size_t)c.total_tiles * kRounds * 8);
-    c.o_rval = take(uniform ? 0 : (size_t)c.total_tiles * kTile * val_bytes);
+    const bool compact = !uniform && np_compact_records(c.kind);
+    c.o_rmask = take(uniform || compact ? 0 : (size_t)c.total_tiles * kRounds * 8);
+    c.o_rval = take(uniform || c.kind == VKX_NP_NORMAL_TILES ? 0 : (size_t)c.total_tiles * (compact ? kSlot : kTile) * val_bytes);
     c.o_jobs = take((size_t)c.n_jobs * sizeof(NpJob));
     c.o_results = take((size_t)c.n_jobs * sizeof(vkx_np_result) + sizeof(unsigned));    // + the completion counter
     int rc = vkx_scratch_reserve(ctx, &ctx->np_work[c.slot], off);
@@ -1103,6 +1362,15 @@ static int np_chunk_prepare(vkx_ctx *ctx, NpChunk &c)
         d.cdf[0] = j.cdf[0]; d.cdf[1] = j.cdf[1]; d.cdf[2] = j.cdf[2];
         d.src = (const uint8_t *)j.src;
         d.dst = j.dst;
+        d.rec = nullptr;
+        d.table = nullptr;
+        if (c.kind == VKX_NP_NORMAL_TILES) {
+            const vkx_np_tiles_shape shape = vkx_np_tiles_shape_of(j.n);
+            d.rec = (int16_t *)((unsigned char *)j.dst + shape.slots_offset);
+            d.table = (uint2 *)((unsigned char *)j.dst + shape.table_offset);
+        } else if (compact) {
+            d.rec = (int16_t *)(c.base + c.o_rval) + d.tile_base * kSlot;
+        }
     }
     if (!c.inline_jobs && (rc = vkx_small_to_device(ctx, c.base + c.o_jobs, hj, (size_t)c.n_jobs * sizeof(NpJob)))) return rc;
     // page-locked results: the chunk's last kernel writes them through the mapping
@@ -1129,7 +1397,7 @@ static int np_chunk_front(vkx_ctx *ctx, NpChunk &c)
     // workgroups of a few tiles per wavefront: a chunk's draw shares the device with the placement pass of the chunk before it
     // (2 048 persistent workgroups -- two generations of the 4 096 wavefronts the device holds -- measured 8.3 ms per 256
     // planes, workgroups of 4 tiles per wavefront 7.5 ms: the dispatcher balances them, and the placement pass gets slots)
-    static const int tiles_per_wave = [] { const char *e = getenv("VKX_NP_TPW"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 4; }();
+    static const int tiles_per_wave = [] { const char *e = getenv("VKX_NP_TPW"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2; }();
     const unsigned wg = (unsigned)((total_tiles + 4 * tiles_per_wave - 1) / (4 * tiles_per_wave));
     {
         VKX_TIMED(ctx, "k_np_tile_states");
@@ -1142,6 +1410,14 @@ static int np_chunk_front(vkx_ctx *ctx, NpChunk &c)
     if (c.uniform) {
         VKX_TIMED(ctx, "k_np_choice_impulse");
         k_np_choice_impulse<<<wg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, res, done, c.res_mapped, tabs);
+        VKX_LAUNCH_CHECK();
+        return VKX_OK;
+    }
+    if (np_compact_records(kind)) {
+        // (the emitter only decides how a draw becomes an int16 step: the same for the three int16 kinds)
+        VKX_TIMED(ctx, "k_np_draw");
+        const unsigned wgc = (unsigned)((total_tiles + (long long)kDrawWaves * tiles_per_wave - 1) / ((long long)kDrawWaves * tiles_per_wave));
+        k_np_draw_compact<EmitI16><<<wgc, 64 * kDrawWaves, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, res, tabs);
         VKX_LAUNCH_CHECK();
         return VKX_OK;
     }
@@ -1184,7 +1460,15 @@ static int np_chunk_back(vkx_ctx *ctx, NpChunk &c)
         k_np_resolve<<<n_jobs, 1024, bits, ctx->stream>>>(dj, states, info, plan, res, tabs);
         VKX_LAUNCH_CHECK();
     }
-    {
+    if (np_compact_records(kind)) {
+        const unsigned pg = vkx_blocks((size_t)total_tiles, 4);
+        if (kind != VKX_NP_NORMAL_TILES) {
+            VKX_TIMED(ctx, "k_np_apply");
+            if (kind == VKX_NP_NORMAL_ADD_U8) k_np_apply<true><<<pg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, info, plan);
+            else k_np_apply<false><<<pg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, info, plan);
+            VKX_LAUNCH_CHECK();
+        }
+    } else {
         VKX_TIMED(ctx, "k_np_place");
         const unsigned pg = vkx_blocks((size_t)total_tiles, 4);
         if (kind == VKX_NP_SPECKLE_U8)
@@ -1202,8 +1486,15 @@ static int np_chunk_back(vkx_ctx *ctx, NpChunk &c)
             k_np_place_walk<EmitSpeckle><<<wg2, 64, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, done, c.res_mapped, tabs);
         else if (kind == VKX_NP_NORMAL_ADD_U8)
             k_np_place_walk<EmitAddU8><<<wg2, 64, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, done, c.res_mapped, tabs);
+        else if (kind == VKX_NP_NORMAL_TILES)
+            k_np_place_walk<EmitI16, true><<<wg2, 64, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, done, c.res_mapped, tabs);
         else
             k_np_place_walk<EmitI16><<<wg2, 64, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, done, c.res_mapped, tabs);
+        VKX_LAUNCH_CHECK();
+    }
+    if (kind == VKX_NP_NORMAL_TILES) {
+        VKX_TIMED(ctx, "k_np_tiles_finish");
+        k_np_tiles_finish<<<vkx_blocks((size_t)total_tiles, 256), 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, info, plan);
         VKX_LAUNCH_CHECK();
     }
     if (!c.res_mapped)
@@ -1233,7 +1524,9 @@ VKX_EXPORT int vkx_np_draw_batch_dev(vkx_ctx *ctx, const vkx_np_job *jobs, int n
         const int jkind = j.kind & 0xff;
         switch (jkind) {
         case VKX_NP_NORMAL_I16:
+        case VKX_NP_NORMAL_TILES:
             VKX_REQUIRE(!uniform && jkind == kind, "the jobs of one call share a kind");
+            VKX_REQUIRE(jkind != VKX_NP_NORMAL_TILES || ((uintptr_t)j.dst & 255) == 0, "tile buffers are 256-byte aligned");
             break;
         case VKX_NP_NORMAL_ADD_U8:
         case VKX_NP_SPECKLE_U8:
@@ -1305,6 +1598,7 @@ VKX_EXPORT int vkx_np_draw(vkx_ctx *ctx, const vkx_np_job *job, vkx_np_result *r
     size_t src_bytes = 0, dst_bytes = 0;
     switch (job->kind & 0xff) {
     case VKX_NP_NORMAL_I16: dst_bytes = (size_t)job->n * 2; break;
+    case VKX_NP_NORMAL_TILES: dst_bytes = vkx_np_tiles_shape_of(job->n).bytes; break;     // the raw tile buffer (tests read it back)
     case VKX_NP_NORMAL_ADD_U8: case VKX_NP_SPECKLE_U8: src_bytes = dst_bytes = (size_t)job->n; break;
     case VKX_NP_CHOICE3_U8: dst_bytes = (size_t)job->n; break;
     case VKX_NP_IMPULSE_U8:
@@ -1328,5 +1622,20 @@ VKX_EXPORT int vkx_np_draw(vkx_ctx *ctx, const vkx_np_job *job, vkx_np_result *r
     vkx_device_guard guard(ctx);
     VKX_HIP(hipMemcpyAsync(job->dst, ctx->stage[1].ptr, dst_bytes, hipMemcpyDeviceToHost, ctx->stream));
     VKX_HIP(hipStreamSynchronize(ctx->stream));
+    return VKX_OK;
+}
+
+// The int16 plane a finished VKX_NP_NORMAL_TILES buffer stands for (the staged chain, tests).  Asynchronous on the ctx stream.
+VKX_EXPORT int vkx_np_tiles_expand_dev(vkx_ctx *ctx, const void *tiles, int64_t n, int16_t *dst)
+{
+    VKX_REQUIRE(ctx && tiles && dst, "NULL argument");
+    VKX_REQUIRE(n >= 1 && n <= 0x7fffffffLL, "1 .. 2^31 - 1 samples");
+    const vkx_np_tiles_shape s = vkx_np_tiles_shape_of(n);
+    vkx_device_guard guard(ctx);
+    VKX_TIMED(ctx, "k_np_tiles_expand");
+    k_np_tiles_expand<<<vkx_blocks((size_t)s.n_tiles, 4), 256, 0, ctx->stream>>>((const uint2 *)((const unsigned char *)tiles + s.table_offset),
+                                                                                 (const int16_t *)((const unsigned char *)tiles + s.slots_offset),
+                                                                                 (int)s.n_tiles, n, dst);
+    VKX_LAUNCH_CHECK();
     return VKX_OK;
 }

@@ -56,11 +56,12 @@ struct vkx_ctx {
     vkx_scratch tables;   // constant lookup tables (HSV division LUTs), uploaded once
     bool tables_ready = false;
     vkx_scratch stage[6]; // staging planes of the host-pointer entry points
-    vkx_scratch chain[2]; // ping-pong planes of the batched chain entry point
+    vkx_scratch chain[3]; // ping-pong planes of the batched chain entry point; [2]: a tile buffer expanded to its int16 plane
     vkx_scratch noise_table;          // int16 [65536] inverse-CDF table of vkx_noise_normal_i16 for noise_table_std
     double noise_table_std = 0.0;
     bool noise_table_fits8 = false;
     vkx_scratch np_tabs;              // jump constants + ziggurat tables of the numpy streams (nprand.hip), uploaded once
+    vkx_scratch noise_rows;           // tiled noise of the fused chain: (row, tile column) -> slot offset records (fused.hip)
     vkx_scratch np_work[2];           // tile arrays of the numpy streams: the chunks of a call alternate (nprand.hip)
 
     // Host-array pipelines: two copy streams next to the compute stream (created on first use), a pool of events that
@@ -226,3 +227,11 @@ int vkx_gaussian_kernel_q8_host(int n, double sigma, uint16_t *kq);      // phot
 int vkx_chain_fused_try(vkx_ctx *ctx, const vkx_chain_item *items, int n_items);  // fused.hip
 int vkx_tile_remap_try(vkx_ctx *ctx, const vkx_elem *elems, int n_elems, int sh, int sw, const int32_t *src_vertices,
                        const int32_t *dst_vertices, int rows, int cols, int dh, int dw);  // fused.hip
+// the tile buffer of a VKX_NP_NORMAL_TILES job of n samples (nprand.hip; read by the fused chain kernel)
+struct vkx_np_tiles_shape {
+    long long n_tiles;
+    int slot_elems;
+    size_t table_offset, slots_offset, bytes;
+    double samples_per_tile;     // expectation: the first guess of "which tile holds sample i"
+};
+vkx_np_tiles_shape vkx_np_tiles_shape_of(long long n);
