@@ -160,6 +160,9 @@ def main():
     ap.add_argument('--noise-planes', type=int, default=0,
                     help='1: keep an int16 noise plane per image in HBM and add it inside k_chain_fused (the form of rounds 1 - 2) '
                          'instead of letting the generator add its samples to the chain output')
+    ap.add_argument('--lanes', type=int, default=2,
+                    help='HIP streams the batch is dealt over (ChainLanes): the microsecond kernels of one lane run under the large '
+                         'kernels of the other')
     ap.add_argument('--noise-workers', type=int, default=0, help='unused since round 3 (the planes are drawn on the device); kept for old command lines')
     args = ap.parse_args()
 
@@ -203,12 +206,12 @@ def main():
     group = shard.Group(backend=backend, device=torch.device('cuda', device_index))
 
     from vkit_amd import _native
-    from vkit_amd.batch import ChainBatch
+    from vkit_amd.batch import ChainBatch, ChainLanes
     ctx = _native.Context(device_index)
     # the noise member: the numpy stream of image i is drawn on the device every step and added to the chain's output by
     # the pass that puts the samples at their final index (ChainBatch's default); --noise-planes 1 keeps the int16 planes of
     # rounds 1 - 2 in HBM and lets k_chain_fused add them
-    batch = ChainBatch(ctx, stream_noise_planes=bool(args.noise_planes))
+    batch = ChainLanes(device_index, lanes=args.lanes, stream_noise_mode={0: 'tiles', 1: 'planes', 2: 'late'}[args.noise_planes])
     images = []
     for j in range(B):
         image = np.random.default_rng(1000 + first + j).integers(0, 256, (size, size, 3), dtype=np.uint8)
@@ -218,6 +221,7 @@ def main():
     t_setup = time.perf_counter() - t_setup
 
     def full_sync():
+        batch.sync()
         ctx.sync()
         torch.cuda.synchronize()
 
@@ -225,19 +229,18 @@ def main():
     for _ in range(args.warmup):
         batch.run()
     full_sync()
-    ctx.set_timing(True)
-    ctx.reset_timings()
+    batch.set_timing(True)
     elapsed = shard.timed_steps(group, batch.run, steps=args.steps, warmup=0, device_sync=full_sync)
-    kernel_times = ctx.timings()
-    ctx.set_timing(False)
+    kernel_times = batch.timings()
+    batch.set_timing(False)
     group.close()  # every rank is past the closing barrier and the MAX reduction: nothing collective is left
 
     # ---- the chain alone on the planes the last step drew (r2's headline mode: planes resident in HBM), for continuity --
     planes_resident = None
     if world == 1 and args.extra_legs:
         rsteps = max(1, min(args.steps, 50))
-        pbatch = batch
-        if not args.noise_planes:
+        pbatch = None
+        if True:
             pbatch = ChainBatch(ctx, stream_noise_planes=True)
             for j in range(B):
                 pbatch.add(images[j], states[j], blur_sigma=BLUR_SIGMA, hue_delta=HUE_DELTA, noise_std=NOISE_STD,
@@ -253,8 +256,7 @@ def main():
                            'ms_per_step': rdt / rsteps * 1e3,
                            'note': 'the chain on int16 planes resident in HBM (drawn once, added inside k_chain_fused; no '
                                    'drawing inside the step): the mode the round-1 / round-2 headline was measured in'}
-        if pbatch is not batch:
-            pbatch.close()
+        pbatch.close()
     del images
 
     # ---- parity spot check of this very batch against the oracle (outside the timed region) -------------------------

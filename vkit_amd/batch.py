@@ -322,3 +322,74 @@ class ChainBatch:
             self.close()
         except Exception:
             pass
+
+
+class ChainLanes:
+    """``lanes`` ``ChainBatch`` objects, each on a context (HIP stream + scratch) of its own, behind the interface of one: images
+    are dealt round robin, ``run`` enqueues every lane.  The lanes share the device: while one lane is between its large
+    kernels -- the carry resolution of its numpy streams, its cell setup: microsecond kernels of a few workgroups -- the other
+    lane's draw pass or chain kernel has the CUs, so the step costs the sum of the large kernels instead of the sum of all."""
+
+    def __init__(self, device: Optional[int] = None, lanes: int = 2, **kwargs):
+        base = _native.default_ctx() if device is None else None
+        dev = base.device if base is not None else int(device)
+        self.contexts = [_native.Context(dev) for _ in range(max(1, int(lanes)))]
+        self.lanes = [ChainBatch(ctx, **kwargs) for ctx in self.contexts]
+        self._where = []
+
+    def add(self, *args, **kwargs):
+        lane = len(self._where) % len(self.lanes)
+        self._where.append((lane, self.lanes[lane].add(*args, **kwargs)))
+        return len(self._where) - 1
+
+    def run(self, **kwargs):
+        for lane in self.lanes:
+            if len(lane):
+                lane.run(**kwargs)
+
+    def sync(self):
+        for ctx in self.contexts:
+            ctx.sync()
+
+    def result(self, index: int) -> np.ndarray:
+        lane, k = self._where[index]
+        return self.lanes[lane].result(k)
+
+    def __len__(self):
+        return len(self._where)
+
+    @property
+    def source_pixels(self) -> int:
+        return sum(lane.source_pixels for lane in self.lanes)
+
+    @property
+    def result_pixels(self) -> int:
+        return sum(lane.result_pixels for lane in self.lanes)
+
+    @property
+    def stream_fallbacks(self) -> int:
+        return sum(lane.stream_fallbacks for lane in self.lanes)
+
+    def set_timing(self, on: bool):
+        for ctx in self.contexts:
+            ctx.set_timing(on)
+            if on:
+                ctx.reset_timings()
+
+    def timings(self):
+        """kernel -> (total ms, launches) summed over the lanes (their intervals overlap on the device)."""
+        out = {}
+        for ctx in self.contexts:
+            for name, (ms, count) in ctx.timings().items():
+                t, c = out.get(name, (0.0, 0))
+                out[name] = (t + ms, c + count)
+        return out
+
+    def close(self):
+        for lane in self.lanes:
+            lane.close()
+        for ctx in self.contexts:
+            try:
+                ctx.close()
+            except Exception:
+                pass

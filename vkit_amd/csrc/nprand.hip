@@ -141,6 +141,60 @@ __device__ __forceinline__ uint64_t pcg_out(u128 s)
     const unsigned r = (unsigned)(hi >> 58);
     return (x >> r) | (x << ((64 - r) & 63));
 }
+// s -> a s + c (mod 2^128) for a wave-uniform (a, c): the stride step of the draw pass, 27 of its 52 instructions per round as the
+// compiler expands the __int128 expression (4 v_mul_lo + 6 v_mad_u64_u32 + 2 v_add3 + 4 v_mov + 2 64-bit adds + 4 carry adds: gfx950
+// wants 64-bit operands in even-aligned register pairs, so every "high half of a product, zero extended" costs a move).  Here by
+// columns: the products of limb columns 0, 1 and 2 as three kinds of 64-bit accumulators that cannot overflow (a 32 x 32 product
+// plus two 32-bit addends fits 64 bits) or may wrap (column 2: bits 128 and up are dropped anyway), the four products of column 3
+// as a multiply-add chain of which the low word counts, and ONE carry chain over 32-bit halves, which need no alignment: 16.
+struct LcgStride {
+    uint32_t a0, a1, a2, a3;      // multiplier limbs
+    uint64_t c0, c1, c23;         // addend: limb 0, limb 1 (zero extended), limbs 2-3
+};
+__device__ __forceinline__ LcgStride lcg_stride(u128 a, u128 c)
+{
+    LcgStride k;
+    k.a0 = (uint32_t)a; k.a1 = (uint32_t)(a >> 32); k.a2 = (uint32_t)(a >> 64); k.a3 = (uint32_t)(a >> 96);
+    k.c0 = (uint32_t)c; k.c1 = (uint32_t)(c >> 32); k.c23 = (uint64_t)(c >> 64);
+    return k;
+}
+// (all operands in VGPRs: see the note on "s" operands in fused.hip; the carry-out the VOP3B encoding asks for goes nowhere)
+__device__ __forceinline__ uint64_t mad_u64_u32_v(uint32_t a, uint32_t b, uint64_t c)
+{
+    uint64_t d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ uint64_t mul_u64_u32_v(uint32_t a, uint32_t b)
+{
+    uint64_t d, carry;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ u128 lcg_step(u128 s, const LcgStride &k)
+{
+    const uint32_t s0 = (uint32_t)s, s1 = (uint32_t)(s >> 32), s2 = (uint32_t)(s >> 64), s3 = (uint32_t)(s >> 96);
+    const uint64_t E = (uint64_t)k.a0 * s0 + k.c0;            // bits 0 .. 63
+    const uint64_t O1 = (uint64_t)k.a0 * s1 + k.c1;           // bits 32 .. 95
+    const uint64_t O2 = (uint64_t)k.a1 * s0;
+    uint64_t F = (uint64_t)k.a0 * s2 + k.c23;                 // bits 64 .. 127
+    F += (uint64_t)k.a1 * s1;
+    F += (uint64_t)k.a2 * s0;
+    uint64_t G = mul_u64_u32_v(k.a0, s3);                     // bits 96 .. 127: the low word
+    G = mad_u64_u32_v(k.a1, s2, G);
+    G = mad_u64_u32_v(k.a2, s1, G);
+    G = mad_u64_u32_v(k.a3, s0, G);
+    unsigned ca, cb, cc, cd;
+    const uint32_t t = __builtin_addc((uint32_t)(E >> 32), (uint32_t)O1, 0u, &ca);
+    const uint32_t r1 = __builtin_addc(t, (uint32_t)O2, 0u, &cb);
+    const uint32_t u = __builtin_addc((uint32_t)F, (uint32_t)(O1 >> 32), ca, &cc);
+    const uint32_t r2 = __builtin_addc(u, (uint32_t)(O2 >> 32), cb, &cd);
+    unsigned ce;
+    const uint32_t w = __builtin_addc((uint32_t)(F >> 32), (uint32_t)G, cc, &ce);
+    const uint32_t r3 = __builtin_addc(w, 0u, cd, &ce);
+    return ((u128)r3 << 96) | ((u128)r2 << 64) | ((u128)r1 << 32) | (uint32_t)E;
+}
+
 __device__ __forceinline__ double u2dbl(uint64_t u) { return (double)(long long)(u >> 11) * (1.0 / 9007199254740992.0); }
 
 // What the samples become.  A draw is reduced to the emitter's `Val` as soon as it exists (an int16 step for the rounded
@@ -329,14 +383,14 @@ __device__ void walk_tile(const NpJob &job, const JumpTabs &g_jump, const uint4 
             nev += (uint32_t)__builtin_popcountll(slow);
         }
     };
-    const u128 a128 = mk128(g_jump.a128), c128 = mk128(job.c128);
+    const LcgStride stride128 = lcg_stride(mk128(g_jump.a128), mk128(job.c128));
     u128 s2 = a64 * s + c64;
 #pragma unroll 1
     for (int r = 0; r < kRounds; r += 2) {
         round(r, s);
         round(r + 1, s2);
-        s = a128 * s + c128;
-        s2 = a128 * s2 + c128;
+        s = lcg_step(s, stride128);
+        s2 = lcg_step(s2, stride128);
     }
     if (nev > (uint32_t)kEvCap) {   // never observed; the job is redrawn on the host
         flags |= VKX_NP_SHORT;
@@ -1551,7 +1605,8 @@ VKX_EXPORT int vkx_np_draw_batch_dev(vkx_ctx *ctx, const vkx_np_job *jobs, int n
     if (rc) return rc;
     vkx_device_guard guard(ctx);
     static const bool pipelined = [] { const char *e = getenv("VKX_NP_PIPELINE"); return !(e && e[0] == '0'); }();
-    const int n_chunks = (!uniform && pipelined && n_jobs >= 2 * kChunkJobs) ? (n_jobs + kChunkJobs - 1) / kChunkJobs : 1;
+    // (tile buffers: what follows the draw pass is a few microseconds per stream and no scratch grows with the records -- one chunk)
+    const int n_chunks = (!uniform && pipelined && kind != VKX_NP_NORMAL_TILES && n_jobs >= 2 * kChunkJobs) ? (n_jobs + kChunkJobs - 1) / kChunkJobs : 1;
     auto chunk_of = [&](int k, NpChunk &c) {
         const int per = (n_jobs + n_chunks - 1) / n_chunks, first = k * per;
         c.jobs = jobs + first;
