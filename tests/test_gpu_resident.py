@@ -88,3 +88,39 @@ def test_random_distortion_resident_equals_host(seed):
     assert (dev.image.mat == host.image.mat).all()
     assert (dev.mask.mat == host.mask.mat).all()
     assert (dev.score_map.mat.view(np.uint32) == host.score_map.mat.view(np.uint32)).all()
+
+
+def _policy_names():
+    f = random_distortion_factory
+    return [p.name for p in f.photometric_policy_factories + f.geometric_policy_factories]
+
+
+@pytest.mark.parametrize('name', _policy_names())
+def test_every_policy_of_the_table_in_resident_mode(name):
+    """Each policy of the default table once, explicitly (a random page draws the rare ones too seldom to trust): in resident
+    mode -- the way ``PageDistortionStep.run`` drives them -- the result equals the host-array run, elements and polygons
+    included, and helpers that post-process a wrapper result with numpy (the motion-blur kernel, ``Polygon.np_mask`` behind the
+    active mask) keep working."""
+    from vkit_amd.element import Polygon
+    f = random_distortion_factory
+    factory = next(p for p in f.photometric_policy_factories + f.geometric_policy_factories if p.name == name)
+    policy = factory.create(None)
+    img = _rgb(7, 192, 224)
+    mask = (np.random.default_rng(8).random(img.shape[:2]) < 0.5).astype(np.uint8)
+    score = np.random.default_rng(9).random(img.shape[:2], dtype=np.float32)
+    polygon = Polygon.from_xy_pairs([(20, 30), (150, 25), (170, 120), (40, 140)])
+    outs = []
+    for res in (False, True):
+        with N.resident(res):
+            for level in (3, 9):
+                r = policy.distort(level, (img.shape[0], img.shape[1]), rng=np.random.default_rng(50 + level), image=Image(mat=img),
+                                   mask=Mask(mat=mask), score_map=ScoreMap(mat=score, is_prob=False), polygon=polygon,
+                                   get_active_mask=True)
+                outs.append((res, level, r))
+    for (_, level, host), (_, _, dev) in zip(outs[:2], outs[2:]):
+        assert dev.shape == host.shape
+        assert (dev.image.mat == host.image.mat).all(), (name, level)
+        assert (dev.mask.mat == host.mask.mat).all(), (name, level)
+        assert (dev.score_map.mat.view(np.uint32) == host.score_map.mat.view(np.uint32)).all(), (name, level)
+        assert (dev.active_mask.mat == host.active_mask.mat).all(), (name, level)
+        assert (dev.polygon.to_np_array() == host.polygon.to_np_array()).all(), (name, level)

@@ -739,8 +739,20 @@ class _Call:
     kind.  ``fn(name)`` is the C entry point of that path (``name`` or ``name + '_dev'``: the two share a signature)."""
 
     def __init__(self, ctx, *arrays):
+        # the call runs on the context of its device inputs (their producer's stream: ordered behind it without a
+        # synchronisation, and temporaries return to the pool whose stream used them).  Inputs of several contexts -- an
+        # element produced on another thread -- are made safe the blunt way: their streams are drained first.
+        owners = []
+        for a in arrays:
+            if isinstance(a, DevArray) and a.ctx is not None and all(a.ctx is not o for o in owners):
+                owners.append(a.ctx)
+        if ctx is None and owners:
+            ctx = owners[0]
         self.ctx = ctx or default_ctx()
-        self.dev = resident_mode() or any(isinstance(a, DevArray) for a in arrays)
+        for o in owners:
+            if o is not self.ctx:
+                o.sync()
+        self.dev = resident_mode() or bool(owners)
         self.keep = []
 
     def fn(self, name):
@@ -812,23 +824,6 @@ def _warp(kind, src, mat, dsize, ctx):
     sh, sw, cn, sstride = _shape_u8(src)
     dst, dptr = call.out((dh, dw) if src.ndim == 2 else (dh, dw, cn), np.uint8)
     check(call.fn(f'vkx_warp_{kind}_u8')(call.ctx.handle, call.src(src), sh, sw, cn, sstride, _ptr(M), dptr, dh, dw, dw * cn))
-    return dst
-
-
-    M = np.ascontiguousarray(np.asarray(mat, dtype=np.float64).reshape(n))
-    if src.dtype == np.float32:
-        src = np.ascontiguousarray(src)
-        if src.ndim != 2:
-            raise ValueError('float32 sources are single channel')
-        sh, sw = src.shape
-        dst = ctx.pinned_empty((dh, dw), np.float32)
-        fn = lib().vkx_warp_affine_f32 if kind == 'affine' else lib().vkx_warp_perspective_f32
-        check(fn(ctx.handle, _ptr(src), sh, sw, sw, _ptr(M), _ptr(dst), dh, dw, dw))
-        return dst
-    src, sh, sw, cn, sstride = _u8_plane(src)
-    dst = _out_like(src, dh, dw, ctx)
-    fn = lib().vkx_warp_affine_u8 if kind == 'affine' else lib().vkx_warp_perspective_u8
-    check(fn(ctx.handle, _ptr(src), sh, sw, cn, sstride, _ptr(M), _ptr(dst), dh, dw, dw * cn))
     return dst
 
 
@@ -1419,12 +1414,13 @@ def ellipse_streak(img, center, axes, thickness, color, alpha, ctx=None):
 
 
 def fill_poly_mask(shape, pts, ctx=None):
-    """cv.fillPoly(zeros(shape, uint8), [pts], 1); pts int (N, 2) as (x, y), all inside the array."""
-    call = _Call(ctx)
+    """cv.fillPoly(zeros(shape, uint8), [pts], 1); pts int (N, 2) as (x, y), all inside the array.  Always a host array (the
+    host entry point clears the raster; its callers -- ``Polygon.np_mask`` -- go on with numpy)."""
+    ctx = ctx or default_ctx()
     h, w = int(shape[0]), int(shape[1])
     pts = np.ascontiguousarray(np.asarray(pts, dtype=np.int32).reshape(-1, 2))
-    mask, mptr = call.out((h, w), np.uint8)
-    check(call.fn('vkx_fill_poly_mask_u8')(call.ctx.handle, _ptr(pts), int(pts.shape[0]), mptr, h, w, w))
+    mask = ctx.pinned_empty((h, w), np.uint8)
+    check(lib().vkx_fill_poly_mask_u8(ctx.handle, _ptr(pts), int(pts.shape[0]), _ptr(mask), h, w, w))
     return mask
 
 
@@ -1485,6 +1481,17 @@ def _paint(flat, offsets, n, values, mask, score, ctx):
         raise ValueError('mask or score is required')
     h, w = plane.shape
     dev = isinstance(plane, DevArray)
+    if dev:
+        # in place: on the stream that produced the planes (a second plane of another context is drained first)
+        owner = plane.ctx
+        for arr in (mask, score):
+            if isinstance(arr, DevArray) and arr.ctx is not owner:
+                arr.ctx.sync()
+        if ctx is not owner:
+            if ctx is not None and ctx is not default_ctx():
+                ctx.sync()
+            ctx = owner
+    ctx = ctx or default_ctx()
     for arr, dt in ((mask, np.uint8), (score, np.float32)):
         if arr is None:
             continue
@@ -1515,14 +1522,14 @@ def paint_polys(polygons, values=None, mask=None, score=None, ctx=None):
     if pts:
         offsets[1:] = np.cumsum([len(p) for p in pts])
     flat = np.ascontiguousarray(np.concatenate(pts, axis=0)) if pts else np.zeros((0, 2), np.int32)
-    _paint(flat, offsets, len(pts), values, mask, score, ctx or default_ctx())
+    _paint(flat, offsets, len(pts), values, mask, score, ctx)
 
 
 def paint_polys_flat(points_xy, offsets, values=None, mask=None, score=None, ctx=None):
     """``paint_polys`` for polygons that already are one int (N, 2) vertex array + (P + 1) offsets (element/soup.py)."""
     flat = np.ascontiguousarray(points_xy, dtype=np.int32).reshape(-1, 2)
     offsets = np.ascontiguousarray(offsets, dtype=np.int32)
-    _paint(flat, offsets, offsets.shape[0] - 1, values, mask, score, ctx or default_ctx())
+    _paint(flat, offsets, offsets.shape[0] - 1, values, mask, score, ctx)
 
 
 def dev_zeros(shape, dtype=np.uint8, ctx=None):
@@ -1603,8 +1610,8 @@ def fill(dst, layers, ctx=None):
     """Applies ``layers`` (list of (layer, keepalive) from make_layer with dst's dtype) to ``dst`` in place: a writable uint8
     or float32 numpy array, or a DevArray (host planes of the layers are then uploaded for the call, DevArray planes are used
     where they are; a host destination takes host planes only)."""
-    ctx = ctx or default_ctx()
     dev = isinstance(dst, DevArray)
+    ctx = ctx or (dst.ctx if dev else None) or default_ctx()     # in place: on the stream that produced the destination
     if np.dtype(dst.dtype) not in (np.uint8, np.float32) or (not dev and (not dst.flags.c_contiguous or not dst.flags.writeable)):
         raise ValueError('dst must be a writable C-contiguous uint8 or float32 array')
     h, w = dst.shape[:2]

@@ -208,9 +208,17 @@ class HostPipeline:
         image = np.ascontiguousarray(image)
         if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
             raise ValueError('submit_chain takes HxWx3 uint8 images')
+        dh, dw = (int(v) for v in state.result_shape)
+        if noise_std is not None and noise is None and noise_rng is not None and _native.np_stream(noise_rng) is None:
+            # not a PCG64 generator (or VKX_HOST_RNG=1): the host draws, the plane travels -- decided BEFORE a slot is taken
+            noise = np.round(_clone_rng(noise_rng).normal(0, noise_std, (dh, dw, 3))).astype(np.int16)
+            noise_std = noise_rng = None
+        return self._chain_on_slot(self._take_slot(), image, state, blur_sigma, hue_delta, noise, streak, noise_std, noise_seed,
+                                   noise_rng)
+
+    def _chain_on_slot(self, slot, image, state, blur_sigma, hue_delta, noise, streak, noise_std, noise_seed, noise_rng) -> int:
         sh, sw = image.shape[:2]
         dh, dw = (int(v) for v in state.result_shape)
-        slot = self._take_slot()
         sv_d, dv_d, rows, cols = self._upload_lattices(slot, state)
         item = _native.VkxChainItem()
         item.src = slot.device('src0', image.nbytes)
@@ -224,10 +232,6 @@ class HostPipeline:
             if noise is not None:
                 raise ValueError('pass either a noise plane or noise_std / noise_seed')
             stream = _native.np_stream(noise_rng) if noise_rng is not None else None
-            if noise_rng is not None and stream is None:
-                # not a PCG64 generator (or VKX_HOST_RNG=1): the host draws, the plane travels
-                return self.submit_chain(image, state, blur_sigma, hue_delta,
-                                         np.round(_clone_rng(noise_rng).normal(0, noise_std, (dh, dw, 3))).astype(np.int16), streak)
             if stream is not None and streak is None:
                 # gaussion_noise is the chain's last member here: the pass that puts the samples at their final index adds
                 # them to the chain's output in place -- same pixels, no int16 plane written and read back
@@ -244,14 +248,15 @@ class HostPipeline:
                 if late_job is None:
                     _native.check(_native.lib().vkx_np_draw_batch_dev(slot.ctx.handle, jobs, 1, results.array))
 
-                def redo(image=image, state=state, stream=stream):
-                    # the device declared a decision of this stream ambiguous in the last bits of exp / log1p: numpy draws
+                def redo(slot, image=image, state=state, stream=stream):
+                    # the device declared a decision of this stream ambiguous in the last bits of exp / log1p: numpy draws, and
+                    # the job runs again ON ITS OWN SLOT (taking another one would evict a job the caller has not read yet)
                     rng = np.random.default_rng()
                     st = rng.bit_generator.state
                     st['state'] = {'state': stream[0], 'inc': stream[1]}
                     rng.bit_generator.state = st
                     plane = np.round(rng.normal(0, noise_std, (dh, dw, 3))).astype(np.int16)
-                    return self.submit_chain(image, state, blur_sigma, hue_delta, plane, streak)
+                    self._chain_on_slot(slot, image, state, blur_sigma, hue_delta, plane, streak, None, None, None)
                 slot.np_check = (jobs, results, redo)
             else:
                 _native.check(_native.lib().vkx_noise_normal_i16_dev(slot.ctx.handle, item.noise, dw * 3, dh, dw, 3,
@@ -337,8 +342,8 @@ class HostPipeline:
             _jobs, results, redo = slot.np_check
             slot.np_check = None
             if results[0].flags:
-                views = [np.array(v) for v in self.result(redo())]     # synchronous, with the host-drawn plane
-                slot.views = views
+                redo(slot)                 # synchronous, with the host-drawn plane
+                slot.wait()
         return slot.views
 
     def drain(self):

@@ -156,7 +156,9 @@ def motion_kernel(radius: int, angle: int, anti_aliasing_sigma: float) -> np.nda
     kernel = np.zeros((kernel_size, kernel_size), np.float32)
     kernel[center, left:left + length] = 1.0
     trans_mat = _rotation_matrix_2d((center, center), 360 - (int(angle) % 360), 1.0)
-    kernel = _native.warp_affine(kernel, trans_mat, kernel.shape)
+    # a kernel of a few dozen taps that numpy goes on with: a host array whatever mode the caller runs in
+    with _native.resident(False):
+        kernel = np.array(_native.host_array(_native.warp_affine(kernel, trans_mat, kernel.shape)))
     kernel /= kernel.sum()
     return _gaussian_blur_f32(kernel, aa_ksize, anti_aliasing_sigma)
 
