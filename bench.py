@@ -7,18 +7,26 @@ Workload (per GPU): B independent 2048x2048 RGB page images, each with its own `
 with the images and integer vertex lattices resident in HBM before the timed region.  The noise of image i is the
 reference's: np.round(default_rng(5000 + i).normal(0, 10, shape)) -- drawn ON THE DEVICE from that numpy stream, value for
 value, INSIDE every timed step (vkx_np_draw_batch_dev: PCG64 jump-ahead + ziggurat); no host-generated plane exists.
-A "step" is one pass over the whole batch: draw the noise planes, run the chain.  Images shard across GPUs without
-any exchange (one process per GPU, weak scaling: every GPU processes its own B images).
+A "step" is one pass over the whole batch: draw the noise of every image (it stays in the generator's tile slots), run the
+chain (k_chain_fused adds the noise, the chain's last member, from those slots).  Images shard across GPUs without any exchange
+(one process per GPU, weak scaling: every GPU processes its own B images).
+
+``python bench.py --gpus N`` from a plain shell launches its own ranks (torch.distributed.run on 127.0.0.1, the way the
+reference's pool forks its own workers, vkit/utility/pool.py:153-243); under torch.distributed.run it is one of the ranks.
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task description):
   value      = source megapixels (H*W per image) processed per second by all ranks together
-  roofline   = algorithmic bytes / HIP-event duration of the dominant kernel, against the 8 TB/s HBM peak
+  roofline   = the kernel with the largest share of the step, algorithmic bytes / HIP-event duration against the 8 TB/s HBM
+               peak; roofline.step prices the whole step (every kernel of it) against the same 3S + 3D, roofline.kernels
+               lists every kernel of the step
   cpu_baseline = the CPU oracle (port of the reference arithmetic, 1 thread) on a bounded sample, rank 0, N=1 only
 """
 import argparse
 import json
 import multiprocessing as mp
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,11 +37,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-# HBM bytes per image from the PMC passes of the current kernel source.  tools/record.sh rewrites this file together
-# with the sha256 of the sources it profiled; a line measured on other sources reports traffic = null instead of a
-# stale figure.
+# HBM bytes and VALU instructions per image from the PMC passes of the current kernel sources.  tools/record.sh rewrites this
+# file together with the sha256 of the sources it profiled; a line measured on other sources reports traffic = null instead
+# of a stale figure.
 TRAFFIC_FILE = os.path.join('profiles', 'current_traffic.json')
-KERNEL_SOURCES = ('vkit_amd/csrc/fused.hip', 'vkit_amd/csrc/vkx_cell.h', 'vkit_amd/csrc/vkx_color.h',
+KERNEL_SOURCES = ('vkit_amd/csrc/fused.hip', 'vkit_amd/csrc/nprand.hip', 'vkit_amd/csrc/vkx_cell.h', 'vkit_amd/csrc/vkx_color.h',
                   'vkit_amd/csrc/vkx_internal.h')
 
 
@@ -95,8 +103,9 @@ def cpu_baseline(size, n_images):
         'unit': 'Mpixels/s',
         'cores': 1,
         'kind': 'port',
-        'sample': f'{n_images} images of the same workload (noise plane drawn from the numpy stream, grid->map, remap, blur, '
-                  f'hue shift, noise add), {dt:.1f} s on 1 thread of {os.cpu_count()} host cores',
+        'sample': f'{n_images} images of the same workload, {dt:.1f} s on 1 thread of {os.cpu_count()} host cores; like the GPU step '
+                  f'the sample draws its noise plane from the numpy stream inside the timed region (since round 3; the round-2 figure '
+                  f'of 17 Mpx/s took the planes as given), then grid->map, remap, blur, hue shift, noise add',
     }
 
 
@@ -139,7 +148,38 @@ def cpu_baseline_all_cores(size, n_procs, per_proc):
         return None
     dt = max(e for _, e in spans) - min(b for b, _ in spans)
     return {'value': n_procs * per_proc * size * size / dt / 1e6, 'unit': 'Mpixels/s', 'cores': n_procs,
-            'sample': f'{n_procs} processes x {per_proc} images, {dt:.1f} s'}
+            'host_cores': os.cpu_count(),
+            'sample': f'{n_procs} single-threaded processes (one per host core) x {per_proc} images, {dt:.1f} s'}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """``python bench.py --gpus N`` without a launcher: start the N ranks (one per GPU) under torch.distributed.run on the
+    loopback address and hand their output through -- rank 0 prints the JSON line; the exit code is the launcher's (non-zero
+    when any rank fails)."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '1')
+    return subprocess.call(cmd, env=env)
+
+
+def _tool_json(name, device_index, timeout, extra=()):
+    """A tools/ script in a process of its own (a clean HIP runtime); its last stdout line is JSON."""
+    try:
+        proc = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', name)] + list(extra), capture_output=True, text=True,
+                              timeout=timeout, env=dict(os.environ, VKX_DEVICE=str(device_index)))
+        if proc.returncode != 0:
+            return {'error': (proc.stderr or proc.stdout)[-400:]}
+        return json.loads(proc.stdout.strip().splitlines()[-1])
+    except Exception as exc:                  # the headline must not depend on a side leg
+        return {'error': repr(exc)}
 
 
 def main():
@@ -152,24 +192,45 @@ def main():
     ap.add_argument('--size', type=int, default=2048)
     ap.add_argument('--cpu-sample', type=int, default=40, help='images timed on the CPU oracle (rank 0, N=1)')
     ap.add_argument('--cpu-procs', type=int, default=-1,
-                    help='processes of the all-cores CPU leg (-1 = min(64, cores), 0 = skip)')
+                    help='processes of the all-cores CPU leg (-1 = one per host core, 0 = skip)')
     ap.add_argument('--verify', type=int, default=4,
                     help='images of the batch checked against the oracle (spread over the batch, the last one included)')
     ap.add_argument('--extra-legs', type=int, default=1,
-                    help='at N=1 also measure the throughput noise mode and the drop-in paths (reported beside, never as value)')
+                    help='at N=1 also measure the other BASELINE configs (C2, C4, C5), the other noise modes and the drop-in paths '
+                         '(reported beside, never as value)')
     ap.add_argument('--noise-planes', type=int, default=0,
-                    help='1: keep an int16 noise plane per image in HBM and add it inside k_chain_fused (the form of rounds 1 - 2) '
-                         'instead of letting the generator add its samples to the chain output')
-    ap.add_argument('--lanes', type=int, default=2,
-                    help='HIP streams the batch is dealt over (ChainLanes): the microsecond kernels of one lane run under the large '
-                         'kernels of the other')
+                    help='how the device-drawn numpy stream reaches the chain: 0 = the generator\'s tile slots, read by k_chain_fused '
+                         '(default); 1 = an int16 plane per image in HBM, added inside k_chain_fused (rounds 1 - 2); 2 = added to the '
+                         'chain output by the generator\'s placement pass (round 3)')
+    ap.add_argument('--lanes', type=int, default=1,
+                    help='HIP streams the batch is dealt over (ChainLanes).  1: every kernel interval of the step is disjoint and '
+                         'the per-kernel figures add up to the step; 2 hides the microsecond kernels of one lane under the other '
+                         'lane\'s (-1 %% of the step)')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='rendezvous, barriers and the MAX reduction of the timing protocol only, over gloo, no GPU: the N > 1 path on '
+                         'a box without GPUs (tests/test_bench_launch.py)')
     ap.add_argument('--noise-workers', type=int, default=0, help='unused since round 3 (the planes are drawn on the device); kept for old command lines')
     args = ap.parse_args()
 
     from vkit_amd import shard
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     rank, local_rank, world = shard.world_from_env()
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+
+    if args.dry_run:
+        group = shard.Group(backend='gloo' if (world > 1 or 'MASTER_ADDR' in os.environ) else None)
+        first, count = shard.weak_span(args.batch, rank)
+        elapsed = shard.timed_steps(group, lambda: time.sleep(0.01 * (1 + rank)), steps=args.steps, warmup=args.warmup,
+                                    device_sync=lambda: None)
+        units = group.sum_int(count * args.steps)
+        group.close()
+        if rank == 0:
+            print(json.dumps({'dry_run': True, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                              'ms_per_step': elapsed / args.steps * 1e3, 'units': units, 'first_image_of_last_rank': (world - 1) * args.batch}))
+            sys.stdout.flush()
+        return
 
     # The libraries are prebuilt in-tree (__graft_entry__.build()); build here only when they are missing, on rank 0,
     # while the other ranks wait -- never relink a library another rank may be loading.
@@ -187,14 +248,14 @@ def main():
     B, size = args.batch, args.size
     first, _ = shard.weak_span(B, rank)  # global index of this rank's first image
 
-    # ---- host-side setup (no GPU yet): states and noise planes -------------------------------------------------
+    # ---- host-side setup (no GPU yet): states ---------------------------------------------------------------------
     t_setup = time.perf_counter()
     states = [make_state(first + j, size) for j in range(B)]
     noise_jobs = [(5000 + first + j, tuple(states[j].result_shape) + (3,)) for j in range(B)]
 
     import torch
     # process -> GPU by the pool's rule (local_rank % visible GPUs): one rank per GPU on the driver's N-GPU node; on a
-    # box with fewer GPUs than ranks (the 2-ranks-on-1-GPU rendezvous check, profiles/r2_torchrun_2ranks_1gpu.log) the
+    # box with fewer GPUs than ranks (the 2-ranks-on-1-GPU rendezvous check, profiles/r4_selflaunch_2ranks_1gpu.log) the
     # ranks share devices and the collectives go through gloo, because RCCL refuses two ranks on one device
     n_dev = torch.cuda.device_count()
     device_index = shard.device_for(local_rank, n_dev)
@@ -208,10 +269,8 @@ def main():
     from vkit_amd import _native
     from vkit_amd.batch import ChainBatch, ChainLanes
     ctx = _native.Context(device_index)
-    # the noise member: the numpy stream of image i is drawn on the device every step and added to the chain's output by
-    # the pass that puts the samples at their final index (ChainBatch's default); --noise-planes 1 keeps the int16 planes of
-    # rounds 1 - 2 in HBM and lets k_chain_fused add them
-    batch = ChainLanes(device_index, lanes=args.lanes, stream_noise_mode={0: 'tiles', 1: 'planes', 2: 'late'}[args.noise_planes])
+    noise_mode = {0: 'tiles', 1: 'planes', 2: 'late'}[args.noise_planes]
+    batch = ChainLanes(device_index, lanes=args.lanes, stream_noise_mode=noise_mode)
     images = []
     for j in range(B):
         image = np.random.default_rng(1000 + first + j).integers(0, 256, (size, size, 3), dtype=np.uint8)
@@ -235,32 +294,35 @@ def main():
     batch.set_timing(False)
     group.close()  # every rank is past the closing barrier and the MAX reduction: nothing collective is left
 
-    # ---- the chain alone on the planes the last step drew (r2's headline mode: planes resident in HBM), for continuity --
+    # ---- the chain alone on noise already in HBM (r2's headline mode, planes resident), for continuity --------------------
     planes_resident = None
     if world == 1 and args.extra_legs:
         rsteps = max(1, min(args.steps, 50))
-        pbatch = None
-        if True:
-            pbatch = ChainBatch(ctx, stream_noise_planes=True)
-            for j in range(B):
-                pbatch.add(images[j], states[j], blur_sigma=BLUR_SIGMA, hue_delta=HUE_DELTA, noise_std=NOISE_STD,
-                           noise_rng=np.random.default_rng(5000 + first + j))
-            pbatch.run()
+        pbatch = ChainBatch(ctx, stream_noise_planes=True)
+        for j in range(B):
+            pbatch.add(images[j], states[j], blur_sigma=BLUR_SIGMA, hue_delta=HUE_DELTA, noise_std=NOISE_STD,
+                       noise_rng=np.random.default_rng(5000 + first + j))
+        pbatch.run()
         full_sync()
+        ctx.set_timing(True)
+        ctx.reset_timings()
         t0 = time.perf_counter()
         for _ in range(rsteps):
             pbatch.run(draw_streams=False)
         full_sync()
         rdt = time.perf_counter() - t0
+        pk = ctx.timings()
+        ctx.set_timing(False)
         planes_resident = {'value': pbatch.source_pixels * rsteps / rdt / 1e6, 'unit': 'Mpixels/s', 'steps': rsteps,
                            'ms_per_step': rdt / rsteps * 1e3,
+                           'kernels_ms_per_step': {k: round(v[0] / rsteps, 3) for k, v in sorted(pk.items())},
                            'note': 'the chain on int16 planes resident in HBM (drawn once, added inside k_chain_fused; no '
                                    'drawing inside the step): the mode the round-1 / round-2 headline was measured in'}
         pbatch.close()
     del images
 
     # ---- parity spot check of this very batch against the oracle (outside the timed region) -------------------------
-    # the expected noise plane comes from numpy ITSELF (_noise_plane): the device-drawn plane has to equal it
+    # the expected noise plane comes from numpy ITSELF (_noise_plane): the device-drawn samples have to equal it
     verified = 0
     if rank == 0 and args.verify > 0:
         import oracle as O
@@ -279,11 +341,16 @@ def main():
     if rank != 0:
         return
 
-    # ---- reported beside the headline, N=1 only: the throughput noise mode and the drop-in paths -----------------------
-    throughput_mode, dropin = None, None
+    src_px = batch.source_pixels            # per rank, per step
+    dst_px = batch.result_pixels
+    fallbacks = batch.stream_fallbacks
+    batch.close()
+
+    # ---- reported beside the headline, N=1 only -----------------------------------------------------------------------
+    throughput_mode, dropin, other_configs = None, None, None
     if world == 1 and args.extra_legs:
         # (a) the same chain with the noise plane drawn on the device every step (vkx_noise_normal_i16_dev: the reference's
-        #     distribution, not numpy's values) instead of a resident numpy plane: no host generation, no 6 D upload
+        #     distribution, not numpy's values) instead of the numpy stream
         tb = ChainBatch(ctx)
         for j in range(B):
             image = np.random.default_rng(1000 + first + j).integers(0, 256, (size, size, 3), dtype=np.uint8)
@@ -308,9 +375,9 @@ def main():
                     'the distribution of the reference, not the values of its numpy stream -- a separately labelled mode',
         }
         tb.close()
-        # (b) host arrays in, host arrays out: tools/dropin.py in a process of its own (a clean HIP runtime: the stream ->
-        #     hardware-queue mapping the overlapped pipeline leans on is a property of the process)
-        import subprocess
+        # (b) host arrays in, host arrays out, and (c) the other BASELINE configs: tools/ scripts in processes of their own (a
+        #     clean HIP runtime: the stream -> hardware-queue mapping the overlapped pipeline leans on is a property of the
+        #     process)
         import tempfile
         with tempfile.TemporaryDirectory() as tmp:
             out_path = os.path.join(tmp, 'dropin.json')
@@ -325,79 +392,80 @@ def main():
                     dropin = {'error': (proc.stderr or proc.stdout)[-400:]}
             except Exception as exc:          # the headline must not depend on this leg
                 dropin = {'error': repr(exc)}
+        other_configs = {
+            'C2_similarity_mls_remap_2048_batch64': _tool_json('c2.py', device_index, 180),
+            'C4_page_synth_1024_64_layers_batch64': _tool_json('c4.py', device_index, 240),
+            'C5_shared_grid_4096_three_elements': _tool_json('c5.py', device_index, 180),
+            'note': 'BASELINE.json configs[1], [3], [4] on this box and clock, device resident (tools/c2.py, c4.py, c5.py): never '
+                    'the headline value',
+        }
 
-    src_px = batch.source_pixels            # per rank, per step
-    dst_px = batch.result_pixels
     total_px = src_px * world * args.steps
     value = total_px / elapsed / 1e6
+    ms_per_step = elapsed / args.steps * 1e3
 
-    # ---- roofline of the dominant kernel: algorithmic bytes per launch / mean HIP-event duration -------------------
+    # ---- roofline: every kernel of the step, the dominant one on top --------------------------------------------------
     S, D = src_px / B, dst_px / B           # mean source / result pixels per image
-    algorithmic = {                         # bytes a launch has to move at the very least
-        'k_owner_remap': 3 * S + 3 * D,     # per-image launches ...
-        # ... and the batch-wide launches: one launch covers all B images.  SURVEY 8(d)'s figure for the fully
-        # fused geo+photo chain is 3S + 3D per image (~6.2 B per source pixel); that is the numerator used here.
-        'k_chain_fused': (3 * S + 3 * D) * B,
-        'k_gaussian_blur': 3 * D + 3 * D,
-        'k_hsv': 3 * D + 3 * D,
-        'k_add_noise': 3 * D + 6 * D + 3 * D,
-        'k_cell_raster': 4 * D,             # the ownership plane it produces
-        'k_cell_setup': 0,
-        'k_chain_setup': 0,
+    chain_bytes = (3 * S + 3 * D) * B       # the fully fused geo + photo chain, per step
+    samples = 3 * D * B                     # noise samples per step
+    # algorithmic bytes per STEP of the kernels that have a figure; None: no mandatory HBM traffic worth a roofline
+    # (the stream kernels are compute: 128-bit LCG + ziggurat)
+    algorithmic = {
+        'k_chain_fused': chain_bytes,
+        'k_np_draw': 2 * samples if noise_mode != 'late' else None,          # the int16 sample it has to leave somewhere
+        'k_np_apply': 2 * samples,                                           # late: 1 byte read + 1 byte written per sample
+        'k_np_place': 2 * samples,
     }
-    # The int16 noise plane is an API input of this workload (host numpy Generator stream, SURVEY 8(d): "+6 D when
-    # host-generated int16 noise is an input"); the kernel has to read it, so it is reported next to the strict figure.
-    noise_input_bytes = 6 * D * B if args.noise_planes else 0
-    # the kernel the roofline is quoted for is the fused geo+photo remap north_star names; the stream kernels are priced
-    # beside it (noise_stream) and the whole step against 3S + 3D (chain_frac)
-    dominant = 'k_chain_fused' if 'k_chain_fused' in kernel_times else max(kernel_times, key=lambda k: kernel_times[k][0])
-    dom_ms, dom_n = kernel_times[dominant]
-    avg_s = dom_ms / 1e3 / max(dom_n, 1)
-    achieved = algorithmic.get(dominant, 0) / avg_s / 1e9 if avg_s > 0 else 0.0
-    achieved_with_noise = ((algorithmic.get(dominant, 0) + (noise_input_bytes if dominant == 'k_chain_fused' else 0))
-                           / avg_s / 1e9 if avg_s > 0 else 0.0)
-    chain_bytes = (3 * S + 3 * D) * B       # the fully fused figure for the whole chain, per step
-    # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), measured in separate
-    # rocprofv3 --pmc passes (profiles/) on the same workload and scaled by the number of images of this launch.
-    traffic, traffic_source, valu_issue = None, None, None
+    tj, traffic_source = None, None
     tpath = os.path.join(ROOT, TRAFFIC_FILE)
-    tj = None
-    if dominant == 'k_chain_fused' and size == 2048 and os.path.exists(tpath):
+    if size == 2048 and os.path.exists(tpath):
         with open(tpath) as fin:
             tj = json.load(fin)
         if tj.get('kernel_source_digest') != kernel_source_digest():
             traffic_source = (f'{TRAFFIC_FILE} was measured on other kernel sources (digest '
                               f'{tj.get("kernel_source_digest")} != {kernel_source_digest()}): not used')
             tj = None
-        elif int(tj.get('noise_planes', 1)) != int(bool(args.noise_planes)):
-            traffic_source = f'{TRAFFIC_FILE} was measured in the other noise mode (--noise-planes): not used'
+        elif tj.get('noise_mode', 'tiles') != noise_mode:
+            traffic_source = f'{TRAFFIC_FILE} was measured in noise mode {tj.get("noise_mode")}: not used'
             tj = None
-    if tj is not None:
-        traffic = tj['hbm_bytes_per_image'] * B
-        traffic_source = f'{TRAFFIC_FILE} <- {tj.get("profile", "?")}'
-        if 'valu_insts_per_image' in tj and avg_s > 0:
-            # why the HBM fraction is what it is: wavefront VALU instructions (PMC, same profile) at one issue per 4 cycles
-            # on 1024 SIMDs (256 CUs x 4) at 2.4 GHz, against the measured launch time
-            floor_s = tj['valu_insts_per_image'] * B / 1024 * 4 / 2.4e9
-            valu_issue = {'insts_per_wavefront': round(tj['valu_insts_per_wavefront']), 'floor_ms': floor_s * 1e3,
-                          'frac_of_launch': floor_s / avg_s}
-    kernel_sum_s = sum(v[0] for v in kernel_times.values()) / 1e3 / args.steps
-    np_ms = {k: v[0] / args.steps for k, v in kernel_times.items() if k.startswith('k_np_')}
-    samples = 3 * D * B
-    noise_stream = {
-        'kernels_ms_per_step': {k: round(v, 3) for k, v in sorted(np_ms.items())},
-        'ms_per_step': elapsed / args.steps * 1e3 - sum(v[0] for k, v in kernel_times.items() if k.startswith('k_chain')) / args.steps,
-        'kernel_intervals_ms_per_step': sum(np_ms.values()),
-        'samples_per_step': samples,
-        'host_fallback_planes': batch.stream_fallbacks,
-        'note': 'ms_per_step = the step minus the chain kernels; the kernel intervals overlap (a call runs in chunks of 32 planes: the '
-                'draw pass of a chunk on the ctx stream, the resolve / place / walk passes of the chunk before it on a second stream). '
-                'np.round(default_rng(5000 + i).normal(0, std, shape)).astype(int16) drawn on the device inside every step, '
-                'value for value numpy\'s (checked against numpy on the verified images): 128-bit LCG + ziggurat, VALU bound, '
-                'not an HBM-bound kernel' + (' -- its only mandatory traffic is the 2-byte sample it writes' if args.noise_planes else
-                '; the samples are added to the chain output in place by the placement pass (clip(uint8 + int16), the '
-                'gaussion_noise operator itself): 1 byte read + 1 byte written per sample, no plane'),
-    }
+        else:
+            traffic_source = f'{TRAFFIC_FILE} <- {tj.get("profile", "?")}'
+    pmc = (tj or {}).get('kernels', {})
+    kernels = {}
+    for name, (ms, launches) in sorted(kernel_times.items()):
+        per_step = ms / args.steps
+        entry = {'ms_per_step': round(per_step, 4), 'launches_per_step': launches / args.steps,
+                 'avg_launch_ms': ms / max(launches, 1), 'frac_of_step': per_step / ms_per_step}
+        alg = algorithmic.get(name)
+        if alg:
+            entry['algorithmic_bytes_per_step'] = alg
+            entry['achieved_gbs'] = alg / (per_step / 1e3) / 1e9 if per_step > 0 else 0.0
+            entry['hbm_frac'] = entry['achieved_gbs'] / HBM_PEAK_GBS
+        p = pmc.get(name)
+        if p:
+            # why a kernel sits where it sits: wavefront VALU instructions (PMC, same sources) at one issue per 4 cycles on
+            # 1024 SIMDs (256 CUs x 4) at 2.4 GHz against the measured time; HBM bytes by FETCH_SIZE x 2 + WRITE_SIZE
+            floor_ms = p['valu_insts_per_image'] * B / 1024 * 4 / 2.4e9 * 1e3
+            entry['valu_issue_frac'] = floor_ms / per_step if per_step > 0 else None
+            entry['valu_insts_per_wavefront'] = round(p.get('valu_insts_per_wavefront', 0))
+            entry['hbm_traffic_bytes_per_step'] = p['hbm_bytes_per_image'] * B
+        kernels[name] = entry
+    dominant = max(kernels, key=lambda k: kernels[k]['ms_per_step'])
+    dom = kernels[dominant]
+    dom_alg = algorithmic.get(dominant) or chain_bytes
+    dom_s = dom['ms_per_step'] / 1e3 / max(dom['launches_per_step'], 1e-9)          # average launch duration
+    dom_bytes_per_launch = dom_alg / max(dom['launches_per_step'], 1e-9)
+    achieved = dom_bytes_per_launch / dom_s / 1e9 if dom_s > 0 else 0.0
+    kernel_sum_ms = sum(k['ms_per_step'] for k in kernels.values())
+    np_ms = sum(v['ms_per_step'] for k, v in kernels.items() if k.startswith('k_np_'))
+    chain_note = {
+        'tiles': 'k_chain_fused is the whole fused geo + photo chain: remap, gaussian_blur, color_shift AND the gaussion_noise add, '
+                 'whose samples it reads from the generator\'s tile slots (2 bytes per sample on top of the 3S + 3D numerator)',
+        'planes': 'k_chain_fused is the whole fused geo + photo chain incl. the gaussion_noise add from an int16 plane (6 D read on top '
+                  'of the 3S + 3D numerator)',
+        'late': 'k_chain_fused ends with color_shift here: the noise member is added to its output by the generator (k_np_apply)',
+    }[noise_mode]
+    dom_traffic = dom.get('hbm_traffic_bytes_per_step')
     result = {
         'metric': 'Mpixels/s (2048^2 RGB, geo+photo chain)',
         'value': value,
@@ -405,7 +473,7 @@ def main():
         'n_gpus': world,
         'steps': args.steps,
         'warmup': args.warmup,
-        'ms_per_step': elapsed / args.steps * 1e3,
+        'ms_per_step': ms_per_step,
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
@@ -419,6 +487,8 @@ def main():
             'batch_per_gpu': B,
             'image': f'{size}x{size}x3',
             'mean_result_pixels': D,
+            'noise_mode': noise_mode,
+            'lanes': args.lanes,
             'sharding': f'{world} process(es), one per GPU, independent images, no collective' +
                         (f' (ranks share {n_dev} GPU(s): rendezvous over {backend})' if shared_devices else ''),
             'verified_against_oracle': verified,
@@ -429,43 +499,54 @@ def main():
             'bound': 'hbm',
             'bound_measured': 'valu',
             'kernel': dominant,
+            'kernel_note': 'the kernel with the largest share of the step.  ' + chain_note,
             'achieved': achieved,
             'peak': HBM_PEAK_GBS,
             'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS,
-            # the north star words the target as "HBM-read roofline": the bytes the kernel must READ (source once, and the
-            # noise plane of this workload) over the same launch time
-            'read_frac': (3 * S * B) / avg_s / 1e9 / HBM_PEAK_GBS if avg_s > 0 else 0.0,
-            'read_frac_incl_noise_input': (3 * S * B + noise_input_bytes) / avg_s / 1e9 / HBM_PEAK_GBS if avg_s > 0 else 0.0,
-            'traffic': traffic,
+            'avg_launch_ms': dom_s * 1e3,
+            'algorithmic_bytes_per_launch': dom_bytes_per_launch,
+            # the north star words the target as "HBM-read roofline": the bytes the chain must READ (the source, once)
+            'read_frac': ((3 * S * B) / (kernels['k_chain_fused']['ms_per_step'] / 1e3) / 1e9 / HBM_PEAK_GBS
+                          if 'k_chain_fused' in kernels else None),
+            'traffic': dom_traffic / max(dom['launches_per_step'], 1e-9) if dom_traffic else None,
             'traffic_source': traffic_source,
-            'valu_issue': valu_issue,
-            'avg_launch_ms': avg_s * 1e3,
-            'algorithmic_bytes_per_launch': algorithmic.get(dominant, 0),
-            'noise_input_bytes_per_launch': noise_input_bytes if dominant == 'k_chain_fused' else 0,
-            'achieved_incl_noise_input': achieved_with_noise,
-            'frac_incl_noise_input': achieved_with_noise / HBM_PEAK_GBS,
-            'traffic_note': 'traffic = FETCH_SIZE x2 + WRITE_SIZE of separate --pmc passes' +
-                            ('; it contains the 6 D noise input that the strict 3S+3D numerator leaves out' if args.noise_planes else
-                             '; k_chain_fused ends with color_shift here: the noise member is added to its output by the '
-                             'generator\'s placement pass (k_np_place, priced in noise_stream), so no noise plane is read'),
-            'chain_frac': chain_bytes / kernel_sum_s / 1e9 / HBM_PEAK_GBS if kernel_sum_s > 0 else 0.0,
-            'kernels_ms_per_step': {k: round(v[0] / args.steps, 3) for k, v in sorted(kernel_times.items())},
+            'traffic_note': 'HBM bytes per launch = FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE of separate --pmc passes on the same '
+                            'sources (digest checked), scaled to this batch',
+            # the figure for "fused geo + photo chain" as a whole: every kernel of the step -- the stream kernels that draw the
+            # noise included -- against the chain's 3S + 3D
+            'step': {'algorithmic_bytes': chain_bytes, 'ms': ms_per_step, 'achieved': chain_bytes / (ms_per_step / 1e3) / 1e9,
+                     'frac': chain_bytes / (ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBS,
+                     'kernel_ms': kernel_sum_ms,
+                     'note': 'elapsed time of the step (barrier to barrier / steps), not a sum of kernel intervals' +
+                             ('' if args.lanes == 1 else '; with several lanes the kernel intervals overlap and kernel_ms exceeds ms')},
+            'kernels': kernels,
+            'kernels_ms_per_step': {k: round(v['ms_per_step'], 3) for k, v in kernels.items()},
+        },
+        'noise_stream': {
+            'kernels_ms_per_step': {k: round(v['ms_per_step'], 3) for k, v in kernels.items() if k.startswith('k_np_')},
+            'ms_per_step': np_ms,
+            'samples_per_step': samples,
+            'gsamples_per_s': samples / (np_ms / 1e3) / 1e9 if np_ms > 0 else None,
+            'host_fallback_planes': fallbacks,
+            'note': 'np.round(default_rng(5000 + i).normal(0, std, shape)).astype(int16) drawn on the device inside every step, value '
+                    'for value numpy\'s (checked against numpy on the verified images): 128-bit LCG + ziggurat, VALU bound, not an '
+                    'HBM-bound kernel',
         },
     }
-    noise_stream['gsamples_per_s'] = samples / (noise_stream['ms_per_step'] / 1e3) / 1e9 if noise_stream['ms_per_step'] > 0 else None
-    result['noise_stream'] = noise_stream
     if planes_resident is not None:
         result['planes_resident'] = planes_resident
     if throughput_mode is not None:
         result['throughput_mode'] = throughput_mode
     if dropin is not None:
         result['dropin'] = dropin
+    if other_configs is not None:
+        result['other_configs'] = other_configs
     if world == 1:
-        result['cpu_baseline'] = cpu_baseline(size, args.cpu_sample)
-        n_procs = min(64, os.cpu_count() or 1) if args.cpu_procs < 0 else args.cpu_procs
+        result['cpu_baseline'] = cpu_baseline(size, args.cpu_sample) if args.cpu_sample > 0 else None
+        n_procs = (os.cpu_count() or 1) if args.cpu_procs < 0 else args.cpu_procs
         if n_procs > 1 and args.cpu_sample > 0:
-            all_cores = cpu_baseline_all_cores(size, n_procs, 4)
+            all_cores = cpu_baseline_all_cores(size, n_procs, 2)
             if all_cores is not None:
                 result['cpu_baseline']['all_cores'] = all_cores
     else:

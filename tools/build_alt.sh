@@ -9,5 +9,5 @@ mkdir -p $C/_alt
 cp "$SRC" $C/_alt_fused.hip
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wno-unused-function "$@" -c $C/_alt_fused.hip -o $C/_alt/fused.o
 rm -f $C/_alt_fused.hip
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/vkit_amd/libvkx_alt.so $C/_build/ctx.o $C/_build/remap.o $C/_build/grid.o $C/_build/mls.o $C/_build/photo.o $C/_build/composite.o $C/_build/polygon.o $C/_build/resize.o $C/_alt/fused.o $C/_build/chain.o $C/_build/host_api.o
-echo built $ROOT/vkit_amd/libvkx_alt.so
+OBJS=$(ls $C/_build/*.o | grep -v fused.o); /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/vkit_amd/libvkx_${ALT_TAG:-alt}.so $OBJS $C/_alt/fused.o
+echo built $ROOT/vkit_amd/libvkx_${ALT_TAG:-alt}.so

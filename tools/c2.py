@@ -16,7 +16,7 @@ from vkit_amd.mechanism import distortion as D
 from vkit_amd.mechanism.distortion_policy.geometric import mls as P_mls
 
 B, SIZE = 64, 2048
-ctx = N.Context(0)
+ctx = N.Context(int(os.environ.get('VKX_DEVICE', 0)))
 gen = P_mls.SimilarityMlsConfigGenerator(P_mls.SimilarityMlsConfigGeneratorConfig(), 5)
 t0 = time.perf_counter()
 states = [D.similarity_mls.generate_state(gen((SIZE, SIZE), default_rng(i)), (SIZE, SIZE)) for i in range(B)]

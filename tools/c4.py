@@ -14,7 +14,7 @@ import numpy as np
 
 from vkit_amd import _native as N
 
-ctx = N.Context(0)
+ctx = N.Context(int(os.environ.get('VKX_DEVICE', 0)))
 rng = np.random.default_rng(0)
 size, n_layers, lh, lw = 1024, 64, 32, 512
 page = np.full((size, size, 3), 200, np.uint8)

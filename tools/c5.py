@@ -15,7 +15,7 @@ from vkit_amd import _native as N
 from vkit_amd.mechanism import distortion as D
 from vkit_amd.mechanism.distortion_policy.geometric import mls as P_mls
 
-ctx = N.Context(0)
+ctx = N.Context(int(os.environ.get('VKX_DEVICE', 0)))
 lib = N.lib()
 res = {}
 for size, label in ((4096, 'C5_4096_three_elements'), (2048, 'C2_2048_image_only')):

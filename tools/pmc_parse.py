@@ -5,7 +5,7 @@ profiles/<tag>_kernel_stats.csv, profiles/<tag>_pmc.md, profiles/<tag>_traffic.j
 HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are collected in
 separate --pmc passes; both are reported in KiB; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 B, so it is
 doubled.  WRITE_SIZE is taken as reported (uncalibrated, stated as such).
-Usage: tools/pmc_parse.py <tag> <images-per-launch> [noise-planes: 1 when the record was taken with bench.py --noise-planes 1]"""
+Usage: tools/pmc_parse.py <tag> <images-per-launch> [bench.py's --noise-planes value of the record: 0 tiles, 1 planes, 2 late]"""
 import csv
 import glob
 import json
@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     tag, images = sys.argv[1], int(sys.argv[2])
-    noise_planes = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    noise_mode = {0: 'tiles', 1: 'planes', 2: 'late'}[int(sys.argv[3]) if len(sys.argv) > 3 else 0]
     out_dir = os.path.join(ROOT, 'profiles')
     stats = os.path.join(ROOT, 'gpurun_out', f'stats_{tag}', 'stats_kernel_stats.csv')
     if os.path.exists(stats):
@@ -36,11 +36,8 @@ def main():
                 name = row['Kernel_Name']
                 if 'k_chain' not in name and 'k_np_' not in name:
                     continue
-                if 'k_np_' in name:
-                    short = re.search(r'k_np_[a-z_]+', name).group(0)
-                else:
-                    short = 'k_chain_fused' if 'k_chain_fused' in name else (
-                        'k_chain_setup_svd' if 'setup_svd' in name else 'k_chain_setup')
+                short = re.search(r'k_(np|chain)_[a-z_]+', name).group(0)
+                short = {'k_np_draw_compact': 'k_np_draw'}.get(short, short)          # (the name the library times it under)
                 sums[short][row['Counter_Name']] += float(row['Counter_Value'])
                 counts[short][row['Counter_Name']] += 1
     lines = [f'# rocprofv3 PMC counters, {tag}, bench.py --batch {images} --steps 2 --warmup 1 (per launch, mean over '
@@ -74,23 +71,27 @@ def main():
                       f'{d["SQ_LDS_BANK_CONFLICT"] / d["SQ_LDS_IDX_ACTIVE"]:.3f}', '']
     with open(os.path.join(out_dir, f'{tag}_pmc_batch{images}.md'), 'w') as fout:
         fout.write('\n'.join(lines))
-    if 'k_chain_fused' in traffic:
-        t = traffic['k_chain_fused']
-        d = {c: sums['k_chain_fused'][c] / counts['k_chain_fused'][c] for c in sums['k_chain_fused']}
+    # what bench.py reads (bench.TRAFFIC_FILE): per kernel of the step, HBM bytes and VALU instructions per image
+    kernels = {}
+    for kernel, t in traffic.items():
+        d = {c: sums[kernel][c] / counts[kernel][c] for c in sums[kernel]}
+        entry = dict(t)
         if 'SQ_INSTS_VALU' in d and 'SQ_WAVES' in d:
-            t.update(valu_insts_per_image=d['SQ_INSTS_VALU'] / images, valu_insts_per_wavefront=d['SQ_INSTS_VALU'] / d['SQ_WAVES'])
-        t.update(source=f'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, batch {images} '
-                        f'(profiles/{tag}_pmc_batch{images}.md); FETCH_SIZE doubled (gfx950), WRITE_SIZE as reported',
-                 images=images, noise_planes=noise_planes)
+            entry.update(valu_insts_per_image=d['SQ_INSTS_VALU'] / images, valu_insts_per_wavefront=d['SQ_INSTS_VALU'] / d['SQ_WAVES'])
+            kernels[kernel] = entry
+    if kernels:
+        out = {'kernels': kernels, 'images': images, 'noise_mode': noise_mode,
+               'source': f'rocprofv3 --pmc, separate passes, batch {images} (profiles/{tag}_pmc_batch{images}.md); FETCH_SIZE doubled '
+                         f'(gfx950), WRITE_SIZE as reported'}
         # the digest of the kernel sources the GPU box profiled (tools/record.sh writes it next to the counters)
         dpath = os.path.join(ROOT, 'gpurun_out', f'digest_{tag}.txt')
         if os.path.exists(dpath):
-            t.update(kernel_source_digest=open(dpath).read().strip(), profile=f'profiles/{tag}_pmc_batch{images}.md')
+            out.update(kernel_source_digest=open(dpath).read().strip(), profile=f'profiles/{tag}_pmc_batch{images}.md')
         with open(os.path.join(out_dir, f'{tag}_traffic.json'), 'w') as fout:
-            json.dump(t, fout, indent=1)
-        if 'kernel_source_digest' in t:        # what bench.py reads (bench.TRAFFIC_FILE)
+            json.dump(out, fout, indent=1)
+        if 'kernel_source_digest' in out:
             with open(os.path.join(out_dir, 'current_traffic.json'), 'w') as fout:
-                json.dump(t, fout, indent=1)
+                json.dump(out, fout, indent=1)
     print('\n'.join(lines))
 
 

@@ -9,10 +9,10 @@ python -c "import bench; print(bench.kernel_source_digest())" > gpurun_out/diges
 timeout 900 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; echo "bench rc=$?"
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/stats_$TAG -o stats -- \
-    python $ROOT/bench.py --batch 64 --steps 3 --warmup 1 --cpu-sample 0 --verify 0 --noise-workers 0 --extra-legs 0 \
+    python $ROOT/bench.py --batch 64 --steps 3 --warmup 1 --cpu-sample 0 --verify 0 --extra-legs 0 \
     > $ROOT/gpurun_out/stats_$TAG.log 2>&1; echo "stats rc=$?"
 # the same summary at the bench's own batch size (256 images per launch): roofline.frac is reproducible from profiles/ alone
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/stats256_$TAG -o stats -- \
-    python $ROOT/bench.py --batch 256 --steps 5 --warmup 1 --cpu-sample 0 --verify 0 --noise-workers 0 --extra-legs 0 \
+    python $ROOT/bench.py --batch 256 --steps 5 --warmup 1 --cpu-sample 0 --verify 0 --extra-legs 0 \
     > $ROOT/gpurun_out/stats256_$TAG.log 2>&1; echo "stats256 rc=$?"
 $ROOT/tools/pmc.sh $TAG 32
