@@ -373,6 +373,7 @@ constexpr size_t kFusedLds = kLdsOwn + kLdsHbB + kLdsCellR + kLdsCellH + kLdsLut
 
 typedef const double __attribute__((address_space(3))) *lds_cdouble_t;
 
+
 // saturating float -> int32 convert of an already integral value (v_cvt_i32_f32: +-big -> INT_MAX / INT_MIN, NaN -> 0)
 __device__ __forceinline__ int cvt_i32_sat(float v)
 {
@@ -909,10 +910,12 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tx, cons
         if (noise && ocol && cy < th) {
             const int16_t VKX_GLOBAL *np_;
             if (tiled) {
-                uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)nrow.x, i) + k3;
+                // (the row's base is a scalar: the loads take it as their SGPR base, the lane's 6 ocx bytes as the offset)
+                const int16_t VKX_GLOBAL *rowp = noise + (size_t)(uint32_t)__builtin_amdgcn_readlane((int)nrow.x, i);
                 const uint32_t sd = (uint32_t)__builtin_amdgcn_readlane((int)nrow.y, i);
+                uint32_t off = k3;
                 if ((sd & 0xffffu) < 3u * W) off += k3 >= (sd & 0xffffu) ? (uint32_t)((int)sd >> 16) : 0u;   // the row runs into the next tile
-                np_ = noise + (size_t)off;
+                np_ = rowp + off;
             } else {
                 np_ = noise + (ptrdiff_t)(y0 + cy) * nstride + (ptrdiff_t)(x0 + ocx) * 3;
             }
