@@ -2,7 +2,8 @@
 
 The build image has no cv2 (and no network), so these tests are skipped there and the parity status stays "unpinned at
 the cv2 boundary" (DESIGN.md section 2).  On any machine with ``opencv-python-headless`` in the reference's version range
-they compare the oracle with cv2 call by call, with the tolerance the restatement documents for each member."""
+they compare the oracle with cv2 call by call, with the tolerance the restatement documents for each member, and leave
+profiles/cv2_pin.json behind: a pass / fail line per call and the two induced counts (tests/cv2_pin.py)."""
 import numpy as np
 import pytest
 from numpy.random import default_rng
@@ -10,6 +11,26 @@ from numpy.random import default_rng
 cv = pytest.importorskip('cv2')
 
 import oracle as O  # noqa: E402
+from cv2_pin import Pin  # noqa: E402
+
+PIN = Pin(cv.__version__)
+
+
+def _equal(name, ours, theirs):
+    ours, theirs = np.asarray(ours), np.asarray(theirs)
+    n = int((ours != theirs).sum()) if ours.shape == theirs.shape else -1
+    assert PIN.call(name, n == 0, f'{n} of {ours.size} elements differ'), name
+
+
+def _close(name, ours, theirs, atol):
+    err = float(np.abs(np.asarray(ours, np.float64) - np.asarray(theirs, np.float64)).max())
+    assert PIN.call(name, err <= atol, f'max abs difference {err:.3e} (bound {atol:.1e})'), name
+
+
+def _lsb(name, ours, theirs, rate):
+    diff = np.abs(np.asarray(ours).astype(int) - np.asarray(theirs).astype(int))
+    frac = float((diff > 0).mean())
+    assert PIN.call(name, diff.max() <= 1 and frac < rate, f'max {int(diff.max())} LSB, {frac:.2e} of the bytes differ (bound 1 LSB, {rate})'), name
 
 
 def _frac_diff(a, b):
@@ -21,43 +42,46 @@ def test_remap_and_warps():
     src = rng.integers(0, 256, (120, 160, 3), dtype=np.uint8)
     mx = rng.uniform(-4, 164, (90, 130)).astype(np.float32)
     my = rng.uniform(-4, 124, (90, 130)).astype(np.float32)
-    np.testing.assert_array_equal(O.remap(src, mx, my), cv.remap(src, mx, my, cv.INTER_LINEAR))
+    _equal('cv.remap INTER_LINEAR uint8 x3 (grid_blender.py:60)', O.remap(src, mx, my), cv.remap(src, mx, my, cv.INTER_LINEAR))
     score = rng.random((120, 160), dtype=np.float32)
-    np.testing.assert_allclose(O.remap(score, mx, my), cv.remap(score, mx, my, cv.INTER_LINEAR), rtol=0, atol=2.4e-7)
+    _close('cv.remap INTER_LINEAR float32 (grid_blender.py:70)', O.remap(score, mx, my), cv.remap(score, mx, my, cv.INTER_LINEAR), 2.4e-7)
     M = np.asarray([[0.8660254, -0.5, 60.0], [0.5, 0.8660254, 0.0]], np.float32)
-    np.testing.assert_array_equal(O.warp_affine(src, M, (200, 180)), cv.warpAffine(src, M, (200, 180)))
+    _equal('cv.warpAffine (affine.py:40)', O.warp_affine(src, M, (200, 180)), cv.warpAffine(src, M, (200, 180)))
     H = np.asarray([[1.02, 0.03, 4], [-0.02, 0.98, 7], [1e-4, -5e-5, 1]], np.float64)
-    np.testing.assert_array_equal(O.warp_perspective(src, H, (170, 140)), cv.warpPerspective(src, H, (170, 140)))
+    _equal('cv.warpPerspective (affine.py:43)', O.warp_perspective(src, H, (170, 140)), cv.warpPerspective(src, H, (170, 140)))
 
 
 def test_fill_poly_and_homography():
     rng = default_rng(1)
+    bad = 0
     for _ in range(200):
         h, w = int(rng.integers(2, 60)), int(rng.integers(2, 60))
         pts = np.stack([rng.integers(0, w, 4), rng.integers(0, h, 4)], axis=1).astype(np.int32)
         want = np.zeros((h, w), np.uint8)
         cv.fillPoly(want, [pts], 1)
-        np.testing.assert_array_equal(O.fill_poly((h, w), pts), want)
+        bad += int((O.fill_poly((h, w), pts) != want).any())
+    assert PIN.call('cv.fillPoly, 200 random quads (polygon.py:75)', bad == 0, f'{bad} of 200 rasters differ')
     a = np.asarray([(0, 0), (20, 1), (21, 22), (-1, 19)], np.float32)
     b = np.asarray([(3, 4), (25, 3), (24, 27), (2, 25)], np.float32)
-    np.testing.assert_allclose(O.get_perspective_transform(a, b, O.SOLVER_HYBRID),
-                               cv.getPerspectiveTransform(a, b, cv.DECOMP_SVD), rtol=0, atol=1e-8)
+    _close('cv.getPerspectiveTransform DECOMP_SVD, matrix entries (type.py:189)', O.get_perspective_transform(a, b, O.SOLVER_HYBRID),
+           cv.getPerspectiveTransform(a, b, cv.DECOMP_SVD), 1e-8)
 
 
 def test_blur_colour_resize():
     rng = default_rng(2)
     src = rng.integers(0, 256, (97, 131, 3), dtype=np.uint8)
     for ksize, sigma in ((3, 0.7), (5, 1.0), (7, 2.0)):
-        np.testing.assert_array_equal(O.gaussian_blur(src, ksize, sigma), cv.GaussianBlur(src, (ksize, ksize), sigma))
-    np.testing.assert_array_equal(O.rgb2hsv_full(src), cv.cvtColor(src, cv.COLOR_RGB2HSV_FULL))
-    np.testing.assert_array_equal(O.rgb2gray(src), cv.cvtColor(src, cv.COLOR_RGB2GRAY))
+        _equal(f'cv.GaussianBlur {ksize}x{ksize} sigma {sigma} (blur.py:65)', O.gaussian_blur(src, ksize, sigma),
+               cv.GaussianBlur(src, (ksize, ksize), sigma))
+    _equal('cv.cvtColor RGB2HSV_FULL (image.py:794)', O.rgb2hsv_full(src), cv.cvtColor(src, cv.COLOR_RGB2HSV_FULL))
+    _equal('cv.cvtColor RGB2GRAY', O.rgb2gray(src), cv.cvtColor(src, cv.COLOR_RGB2GRAY))
     # float formulas: cv2's SIMD lanes may associate differently -> at most 1 LSB on rare pixels
-    for ours, theirs in ((O.hsv2rgb_full(src), cv.cvtColor(src, cv.COLOR_HSV2RGB_FULL)),
-                         (O.rgb2hls_full(src), cv.cvtColor(src, cv.COLOR_RGB2HLS_FULL)),
-                         (O.hls2rgb_full(src), cv.cvtColor(src, cv.COLOR_HLS2RGB_FULL)),
-                         (O.resize_cubic(src, (140, 77)), cv.resize(src, (77, 140), interpolation=cv.INTER_CUBIC))):
-        assert np.abs(ours.astype(int) - theirs.astype(int)).max() <= 1
-        assert _frac_diff(ours, theirs) < 0.02
+    for name, ours, theirs in (('cv.cvtColor HSV2RGB_FULL (image.py:800)', O.hsv2rgb_full(src), cv.cvtColor(src, cv.COLOR_HSV2RGB_FULL)),
+                               ('cv.cvtColor RGB2HLS_FULL', O.rgb2hls_full(src), cv.cvtColor(src, cv.COLOR_RGB2HLS_FULL)),
+                               ('cv.cvtColor HLS2RGB_FULL', O.hls2rgb_full(src), cv.cvtColor(src, cv.COLOR_HLS2RGB_FULL)),
+                               ('cv.resize INTER_CUBIC (image.py:847)', O.resize_cubic(src, (140, 77)),
+                                cv.resize(src, (77, 140), interpolation=cv.INTER_CUBIC))):
+        _lsb(name, ours, theirs, 0.02)
 
 
 def test_cell_homography_definition_vs_cv2_on_reference_lattices(golden_dir, capsys):
@@ -100,7 +124,11 @@ def test_cell_homography_definition_vs_cv2_on_reference_lattices(golden_dir, cap
     with capsys.disabled():
         print(f'\\ncell homography, closed form vs cv2 {cv.__version__} DECOMP_SVD: {flips} of {total} 1/32-px map entries differ '
               f'({flips / max(total, 1):.2e}); largest coordinate difference {worst:.3e} px')
-    assert worst < 1e-3 and flips / max(total, 1) < 1e-3
+    PIN.induced('cell_homography_closed_form_vs_DECOMP_SVD', map_entries_differing=flips, map_entries=total,
+                rate=flips / max(total, 1), largest_coordinate_difference_px=worst,
+                note='1/32-px quantised map entries over the reference-generated lattices (tests/golden/mls_states.npz)')
+    assert PIN.call('induced: cell homographies -> dense map (type.py:209-261)', worst < 1e-3 and flips / max(total, 1) < 1e-3,
+                    f'{flips} of {total} entries differ, worst {worst:.3e} px')
 
 
 def test_hsv2rgb_lsb_rate_vs_cv2(capsys):
@@ -111,6 +139,8 @@ def test_hsv2rgb_lsb_rate_vs_cv2(capsys):
     diff = np.abs(ours.astype(np.int16) - theirs.astype(np.int16))
     with capsys.disabled():
         print(f'\\nHSV2RGB_FULL over the 2^24 cube vs cv2 {cv.__version__}: {int((diff > 0).sum())} of {diff.size} bytes differ, max {int(diff.max())}')
-    assert diff.max() <= 1 and (diff > 0).mean() < 5e-3
-    rt = cv.cvtColor(cube, cv.COLOR_RGB2HSV_FULL)
-    assert (O.rgb2hsv_full(cube) == rt).all()
+    PIN.induced('HSV2RGB_FULL_over_2^24_cube', bytes_differing=int((diff > 0).sum()), bytes=int(diff.size),
+                rate=float((diff > 0).mean()), max_lsb=int(diff.max()))
+    assert PIN.call('induced: HSV2RGB_FULL over the 2^24 cube', diff.max() <= 1 and (diff > 0).mean() < 5e-3,
+                    f'{int((diff > 0).sum())} of {diff.size} bytes differ, max {int(diff.max())} LSB')
+    _equal('cv.cvtColor RGB2HSV_FULL over the 2^24 cube', O.rgb2hsv_full(cube), cv.cvtColor(cube, cv.COLOR_RGB2HSV_FULL))

@@ -6,6 +6,8 @@ import os
 import attrs
 import numpy as np
 import pytest
+
+from vkit_amd.mechanism.distortion.interface import DistortionResult
 from numpy.random import default_rng
 
 from vkit_amd.element import Box, Image, ImageMode, Mask, Point, PointList, PointTuple, Polygon, ScoreMap
@@ -246,10 +248,28 @@ def test_out_of_path_policies_sample_like_the_reference_and_pass_through(golden_
         assert float(rng.random()) == rec['next_random']          # exactly the reference's draws
         assert (res.image.mat == image.mat).all()
         assert any(name in r.getMessage() for r in caplog.records)
+        assert res.meta == {'out_of_path': (name,)}              # ... and the result says that a stage was not applied
         monkeypatch.setenv('VKX_STRICT_UNSUPPORTED', '1')
         with pytest.raises(NotImplementedError):
             policy.distort(level=5, image=image, rng=default_rng(1))
         monkeypatch.delenv('VKX_STRICT_UNSUPPORTED')
+        with photo_opt.out_of_path('raise'), pytest.raises(NotImplementedError):
+            policy.distort(level=5, image=image, rng=default_rng(1))
+    # the factory switch: a RandomDistortion that refuses to skip a stage, and one that records what it skipped (only
+    # jpeg_quality left in the table: no GPU in this test)
+    others = [f.name for f in random_distortion_factory.photometric_policy_factories if f.name != 'jpeg_quality']
+    config = {'prob_photometric': 1.0, 'num_photometric_min': 1, 'num_photometric_max': 1, 'prob_geometric': 0.0,
+              'disabled_policy_names': others}
+    lenient = random_distortion_factory.create(config)
+    out = lenient.distort(default_rng(3), image=image)
+    assert (out.image.mat == image.mat).all() and out.meta == {'out_of_path': ('jpeg_quality',)}
+    strict = random_distortion_factory.create(config, out_of_path='raise')
+    with pytest.raises(NotImplementedError):
+        strict.distort(default_rng(3), image=image)
+    with photo_opt.out_of_path('raise'), pytest.raises(NotImplementedError):
+        lenient.distort(default_rng(3), image=image)
+    with photo_opt.out_of_path('raise'):                 # the factory's own choice wins over the surrounding one
+        assert random_distortion_factory.create(config, out_of_path='pass_through').distort(default_rng(3), image=image).meta
 
 
 def test_default_random_distortion_never_raises_on_sampling():

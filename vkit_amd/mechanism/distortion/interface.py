@@ -383,4 +383,9 @@ class Distortion(Generic[_T_CONFIG, _T_STATE]):
             result.state = internals.state
         if not disable_clip_result_elements:
             self.clip_result_elements(result)
+        # an operator outside the accelerated path that handed its image through says so in the result (photometric/opt.py)
+        from vkit_amd.mechanism.distortion.photometric.opt import take_passed_through
+        passed = take_passed_through()
+        if passed:
+            result.meta = dict(result.meta or {}, out_of_path=tuple(passed))
         return result
