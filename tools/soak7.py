@@ -34,7 +34,7 @@ def state_after(seed, draws):
 while time.time() - t0 < budget:
     if rng.random() < 0.85:
         B = int(rng.choice([1, 2, 7, 8, 9, 40, 63, 64, 65, 97, 150]))
-        kind = int(rng.choice([N.NP_NORMAL_I16, N.NP_NORMAL_ADD_U8, N.NP_SPECKLE_U8, N.NP_CHOICE3_U8, N.NP_IMPULSE_U8]))
+        kind = int(rng.choice([N.NP_NORMAL_I16, N.NP_NORMAL_ADD_U8, N.NP_SPECKLE_U8, N.NP_CHOICE3_U8, N.NP_IMPULSE_U8, N.NP_NORMAL_TILES]))
         big = 400_000 if B <= 9 else 60_000
         sizes = [int(v) for v in rng.integers(1, big, B)]
         seeds = [int(v) for v in rng.integers(0, 2 ** 62, B)]
@@ -48,6 +48,9 @@ while time.time() - t0 < budget:
             stream = N.np_stream(default_rng(seeds[i]))
             if kind == N.NP_NORMAL_I16:
                 d = ctx.dev_empty((sizes[i],), np.int16)
+                jobs[i] = N.np_job(kind, stream, sizes[i], stds[i], dst=d.ptr)
+            elif kind == N.NP_NORMAL_TILES:
+                d = ctx.dev_empty((N.np_tiles_layout(sizes[i])[4],), np.uint8)
                 jobs[i] = N.np_job(kind, stream, sizes[i], stds[i], dst=d.ptr)
             elif kind in (N.NP_NORMAL_ADD_U8, N.NP_SPECKLE_U8):
                 px = default_rng(seeds[i] + 1).integers(0, 256, sizes[i], dtype=np.uint8)
@@ -73,7 +76,7 @@ while time.time() - t0 < budget:
                     d = ctx.dev_empty((sizes[i],), np.uint8)
                     jobs[i] = N.np_job(kind, stream, sizes[i], 0.0, cdf=cdf, dst=d.ptr)
             outs.append(d)
-            if kind in (N.NP_NORMAL_I16, N.NP_CHOICE3_U8):
+            if kind in (N.NP_NORMAL_I16, N.NP_CHOICE3_U8, N.NP_NORMAL_TILES):
                 srcs.append(None)
         N.check(N.lib().vkx_np_draw_batch_dev(ctx.handle, jobs, B, res_array))
         ctx.sync()
@@ -87,6 +90,13 @@ while time.time() - t0 < budget:
             if kind == N.NP_NORMAL_I16:
                 got = [o for o in outs if o.ptr == jobs[i].dst][0].host()
                 assert (got == np.round(ref.normal(0, stds[i], sizes[i])).astype(np.int16)).all(), ('i16', B, i)
+            elif kind == N.NP_NORMAL_TILES:
+                buf = [o for o in outs if o.ptr == jobs[i].dst][0]
+                want = np.round(ref.normal(0, stds[i], sizes[i])).astype(np.int16)
+                assert (N.np_tiles_plane(buf.host(), sizes[i]) == want).all(), ('tiles', B, i)
+                plane = ctx.dev_empty((sizes[i],), np.int16)
+                N.check(N.lib().vkx_np_tiles_expand_dev(ctx.handle, ctypes.c_void_p(buf.ptr), sizes[i], ctypes.c_void_p(plane.ptr)))
+                assert (plane.host() == want).all(), ('tiles expand', B, i)
             elif kind == N.NP_NORMAL_ADD_U8:
                 got = [o for o in outs if o.ptr == jobs[i].dst][0].host()
                 noise = np.round(ref.normal(0, stds[i], sizes[i])).astype(np.int16)
@@ -113,11 +123,14 @@ while time.time() - t0 < budget:
     else:
         from test_gpu_hostpipe import _state, synthetic_grid
         n_img = int(rng.integers(1, 5))
-        batch = ChainBatch(stream_noise_planes=bool(rng.random() < 0.3))
+        mode = str(rng.choice(['tiles', 'tiles', 'planes', 'late']))
+        batch = ChainBatch(stream_noise_mode=mode)
+        big = rng.random() < 0.25            # pages of several generator tiles per row band: rows that straddle two slots
+        from vkit_amd.mechanism.distortion.photometric.streak import LineStreakConfig
         wants = []
         tickets = []
         for k in range(n_img):
-            h, w = int(rng.integers(60, 400)), int(rng.integers(60, 500))
+            h, w = (int(rng.integers(500, 1300)), int(rng.integers(700, 1500))) if big else (int(rng.integers(60, 400)), int(rng.integers(60, 500)))
             sv, dv, dshape = synthetic_grid(h, w, int(rng.integers(8, 40)), float(rng.uniform(1, 9)), seed=int(rng.integers(1 << 30)))
             st = _state(sv, dv, dshape)
             image = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
@@ -125,12 +138,19 @@ while time.time() - t0 < budget:
             mx, my = O.grid_to_map(sv, dv, dshape)
             base = O.color_shift_rgb(O.gaussian_blur(O.remap(image, mx, my), 5, 1.0), 37)
             plane = np.round(default_rng(seed).normal(0, std, tuple(dshape) + (3,))).astype(np.int16)
-            wants.append(O.add_noise_i16(base, plane))
-            batch.add(image, st, blur_sigma=1.0, hue_delta=37, noise_std=std, noise_rng=default_rng(seed))
-            tickets.append(pipe.submit_chain(image, st, blur_sigma=1.0, hue_delta=37, noise_std=std, noise_rng=default_rng(seed)))
+            want = O.add_noise_i16(base, plane)
+            streak = None
+            if rng.random() < 0.3:
+                streak = LineStreakConfig(thickness=int(rng.integers(1, 4)), gap=int(rng.integers(3, 20)), alpha=float(rng.uniform(0.1, 0.9)),
+                                          color=tuple(int(v) for v in rng.integers(0, 256, 3)), enable_vert=True, enable_hori=bool(rng.random() < 0.5))
+                want = O.line_streak(want, streak.thickness, streak.gap, streak.dash_thickness, streak.dash_gap, streak.color, streak.alpha,
+                                     streak.enable_vert, streak.enable_hori)
+            wants.append(want)
+            batch.add(image, st, blur_sigma=1.0, hue_delta=37, noise_std=std, noise_rng=default_rng(seed), streak=streak)
+            tickets.append(pipe.submit_chain(image, st, blur_sigma=1.0, hue_delta=37, noise_std=std, noise_rng=default_rng(seed), streak=streak))
         batch.run()
         for k in range(n_img):
-            assert (batch.result(k) == wants[k]).all(), ('batch', k)
+            assert (batch.result(k) == wants[k]).all(), ('batch', mode, k)
             assert (pipe.result(tickets[k])[0] == wants[k]).all(), ('pipeline', k)
         batch.close()
         counts['chains'] += n_img
