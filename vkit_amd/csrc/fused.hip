@@ -39,11 +39,17 @@ namespace {
 constexpr int W = 64;          // window side = wavefront width
 constexpr int RMAX = 3;        // blur radius limit of the fused path (ksize <= 7)
 constexpr int NLDSCELL = 64;   // candidate cells whose records are cached in LDS at a time
-constexpr int NTHREADS = 512;
-constexpr int NWAVES = NTHREADS / 64;
-constexpr int ROWS_PER_WAVE = W / NWAVES;   // 8
+#ifndef VKX_FUSED_NWAVES
+#define VKX_FUSED_NWAVES 8
+#endif
+constexpr int NWAVES = VKX_FUSED_NWAVES;    // wavefronts per workgroup: 8 -> a 64 x 64 window, 16 -> 64 wide x 128 high
+constexpr int NTHREADS = 64 * NWAVES;
+constexpr int ROWS_PER_WAVE = 8;
+constexpr int WH = NWAVES * ROWS_PER_WAVE;  // window height
 // side of the tile proper: the window minus the blur halo, rounded down to whole 4-pixel (12-byte) store groups
 __host__ __device__ constexpr int tile_side(int R) { return (W - 2 * R) & ~3; }
+// height of the tile proper: the window minus the blur halo (rows need no store-group rounding)
+__host__ __device__ constexpr int tile_height(int R) { return WH == W ? tile_side(R) : WH - 2 * R; }
 #ifndef VKX_FUSED_CGROUP
 #define VKX_FUSED_CGROUP 2
 #endif
@@ -145,8 +151,8 @@ __global__ void __launch_bounds__(256) k_chain_setup(const ItemDev *__restrict__
         else deferred[1 + atomicAdd(&deferred[0], 1)] = gid;
         // the cell belongs to every tile whose window [t*Tw - R, t*Tw + Tw + R) meets its bounding box
         r = cell / (it.cols - 1); c = cell - r * (it.cols - 1);
-        const int Tw = tile_side(it.R);
-        tx0 = (xmin - it.R) / Tw; tx1 = (xmax + it.R) / Tw; ty0 = (ymin - it.R) / Tw; ty1 = (ymax + it.R) / Tw;
+        const int Tw = tile_side(it.R), Th = tile_height(it.R);
+        tx0 = (xmin - it.R) / Tw; tx1 = (xmax + it.R) / Tw; ty0 = (ymin - it.R) / Th; ty1 = (ymax + it.R) / Th;
         if (xmin - it.R < 0) tx0 = 0;
         if (ymin - it.R < 0) ty0 = 0;
         tiles_x = it.tiles_x;
@@ -361,14 +367,14 @@ __device__ __forceinline__ void hue_shift_px(const int *sdiv, const int *hdiv, i
 // vertical pass's v_dot2_u32_u16 -- written by the wavefront that read the tags.
 constexpr int P_ = 97;
 constexpr int kPairPitch = 2 * P_;  // dwords between the plane triples of consecutive row pairs
-constexpr size_t kLdsOwn = sizeof(uint32_t) * W * P_;
+constexpr size_t kLdsOwn = sizeof(uint32_t) * WH * P_;
 constexpr size_t kLdsHbB = 1024;                                 // phase A's work-list prefix sums
 constexpr size_t kLdsCellR = sizeof(CellR) * NLDSCELL;
 constexpr size_t kLdsCellH = sizeof(double) * 9 * NLDSCELL;     // 72-byte pitch keeps same-index reads of different
                                                                 // cells on different LDS banks
 constexpr size_t kLdsLut = sizeof(int) * 512;
 constexpr size_t kLdsSel = sizeof(uint32_t) * 8;              // byte-permute selectors of the six hue sectors, then one flag word
-constexpr size_t kLdsNoiseRows = sizeof(uint32_t) * 2 * W;    // tiled noise: (slot offset, samples before the next tile | step into it << 16) per output row
+constexpr size_t kLdsNoiseRows = sizeof(uint32_t) * 2 * WH;    // tiled noise: (slot offset, samples before the next tile | step into it << 16) per output row
 constexpr size_t kFusedLds = kLdsOwn + kLdsHbB + kLdsCellR + kLdsCellH + kLdsLut + kLdsSel + 16 + kLdsNoiseRows;
 
 typedef const double __attribute__((address_space(3))) *lds_cdouble_t;
@@ -409,13 +415,13 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tx, cons
     // the wavefront index is uniform: read it into an SGPR so that every row index, row address and row predicate
     // derived from it is scalar arithmetic instead of per-lane (64-bit, quarter-rate) multiplies
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int R = RC >= 0 ? RC : it.R, K = 2 * R + 1, Tw = tile_side(R);
+    const int R = RC >= 0 ? RC : it.R, K = 2 * R + 1, Tw = tile_side(R), Th = tile_height(R);
     const int dw = it.dw, dh = it.dh;
-    const int x0 = tx * Tw, y0 = ty * Tw;                         // the tile proper
-    const int tw = INTERIOR ? Tw : min(Tw, dw - x0), th = INTERIOR ? Tw : min(Tw, dh - y0);
+    const int x0 = tx * Tw, y0 = ty * Th;                         // the tile proper
+    const int tw = INTERIOR ? Tw : min(Tw, dw - x0), th = INTERIOR ? Th : min(Th, dh - y0);
     const int wx0 = x0 - R, wy0 = y0 - R;                         // window origin (may be negative)
     const int cx0 = INTERIOR ? wx0 : max(wx0, 0), cx1 = INTERIOR ? wx0 + W : min(wx0 + W, dw);   // window clipped to the image
-    const int cy0 = INTERIOR ? wy0 : max(wy0, 0), cy1 = INTERIOR ? wy0 + W : min(wy0 + W, dh);
+    const int cy0 = INTERIOR ? wy0 : max(wy0, 0), cy1 = INTERIOR ? wy0 + WH : min(wy0 + WH, dh);
 
     const gsrc_t src = (gsrc_t)it.src;
     const ptrdiff_t sstride = it.sstride;
@@ -432,11 +438,12 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tx, cons
     // Candidate records [base, base + cn) go into the two LDS tables, 16 lanes x 8 B per 128-byte record and two records per
     // lane (NLDSCELL = 2 x 32).  Fetch and store are split so that the first chunk's loads are in flight, together with the
     // hue tables, while the ownership plane is being cleared: one memory round trip at the head of the tile instead of three.
-    static_assert(NLDSCELL == 2 * (NTHREADS / 16), "two records per lane and chunk");
+    constexpr int kRecPerLane = NLDSCELL / (NTHREADS / 16);      // 2 (512 lanes) or 1 (1024 lanes)
+    static_assert(NLDSCELL == kRecPerLane * (NTHREADS / 16), "whole records per lane and chunk");
     const float rcp_ncol = __builtin_amdgcn_rcpf((float)max(ncol, 1));
     auto chunk_fetch = [&](int base, int cn_, unsigned long long (&v)[2]) {
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < kRecPerLane; h++) {
             const int rec = (tid >> 4) + h * (NTHREADS / 16);
             v[h] = 0;
             if (rec < cn_) {
@@ -450,7 +457,7 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tx, cons
     };
     auto chunk_store = [&](int cn_, const unsigned long long (&v)[2]) {
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < kRecPerLane; h++) {
             const int rec = (tid >> 4) + h * (NTHREADS / 16), part = tid & 15;
             if (rec < cn_) {
                 if (part < 8) ((unsigned long long *)(lch + rec * 9))[part] = v[h];
@@ -469,9 +476,10 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tx, cons
     // 8-byte load per lane of wavefront 0 at the head of the tile, parked in LDS for phase E once the ownership plane is clear.
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     u32x2 nrec = {0u, 0u};
-    const bool nrows_here = !(KIND == 3) && wave == 0 && it.noise_rows != nullptr;
-    if (nrows_here && lane < th)
-        nrec = ((const u32x2 VKX_GLOBAL *)it.noise_rows)[(size_t)(y0 + lane) * (size_t)it.tiles_x + (size_t)tx];
+    const bool nrows_here = !(KIND == 3) && wave < WH / 64 && it.noise_rows != nullptr;
+    const int nrow_y = wave * 64 + lane;          // (the first WH / 64 wavefronts: one output row per lane)
+    if (nrows_here && nrow_y < th)
+        nrec = ((const u32x2 VKX_GLOBAL *)it.noise_rows)[(size_t)(y0 + nrow_y) * (size_t)it.tiles_x + (size_t)tx];
 
     uint32_t kq[2 * RMAX + 1];
 #pragma unroll
@@ -483,18 +491,18 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tx, cons
         int lutv = 0;
         uint32_t selv = 0;
         if (it.hue_on) {
-            lutv = tid < 256 ? lut->sdiv[tid] : lut->hdiv[tid - 256];
+            if (NTHREADS == 512 || tid < 512) lutv = tid < 256 ? lut->sdiv[tid] : lut->hdiv[tid - 256];
             if (tid < 8) selv = vkd::kHsvSelectors[tid];
         }
 #pragma unroll
-        for (int i = 0; i < (W * P_ / 4 + NTHREADS - 1) / NTHREADS; i++)
-            if (tid + i * NTHREADS < W * P_ / 4) ((uint4 *)own)[tid + i * NTHREADS] = make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < (WH * P_ / 4 + NTHREADS - 1) / NTHREADS; i++)
+            if (tid + i * NTHREADS < WH * P_ / 4) ((uint4 *)own)[tid + i * NTHREADS] = make_uint4(0, 0, 0, 0);
         if (it.hue_on) {
-            lsdiv[tid] = lutv;                       // sdiv[256] and hdiv[256] are adjacent
+            if (NTHREADS == 512 || tid < 512) lsdiv[tid] = lutv;      // sdiv[256] and hdiv[256] are adjacent
             if (tid < 8) lsel[tid] = selv;
         }
         if (tid == 0) *lflag = 0;
-        if (nrows_here) *(u32x2 *)(lnrow + 2 * lane) = nrec;
+        if (nrows_here) *(u32x2 *)(lnrow + 2 * nrow_y) = nrec;
         // (an interior tile has at most NLDSCELL candidates: one pass, no loop)
         for (int base = 0; base < (INTERIOR ? 1 : max(nc, 1)); base += NLDSCELL) {
             const int cn_ = INTERIOR ? nc : min(NLDSCELL, nc - base);
@@ -621,7 +629,7 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tx, cons
                 const bool check = c.flags & 1;
                 if (!check) {
                     for (int s = k0; s <= k1; s++) {
-                        const bool inside = INTERIOR ? (unsigned)(px | py) < (unsigned)W
+                        const bool inside = INTERIOR ? ((unsigned)px < (unsigned)W && (unsigned)py < (unsigned)WH)
                                                      : ((unsigned)(px - lox) < (unsigned)nx_ && (unsigned)(py - loy) < (unsigned)ny_);
                         if (inside) atomicMax(own + py * P_ + px, tag);
                         const bool step = err < 0;
@@ -897,7 +905,7 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tx, cons
     // (as the other descriptor fields of this phase: read again here rather than kept in SGPRs through phases A - D)
     const bool tiled = noise && __builtin_amdgcn_readfirstlane(ite.noise_tiled) != 0;
     if constexpr (EMPTY) {                   // (no phase A: parked here)
-        if (nrows_here) *(u32x2 *)(lnrow + 2 * lane) = nrec;
+        if (nrows_here) *(u32x2 *)(lnrow + 2 * nrow_y) = nrec;
         if (tiled) __syncthreads();
     }
     const uint32_t k3 = (uint32_t)(ocx * 3);
@@ -1070,10 +1078,10 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
     const TileBin bin = bins[tile_id];
     const int ty = __builtin_amdgcn_readfirstlane(div_small(tl, it.tiles_x, __builtin_amdgcn_rcpf((float)it.tiles_x)));
     const int tx = tl - ty * it.tiles_x;
-    const int Tw = tile_side(it.R);
-    const int wx0 = tx * Tw - it.R, wy0 = ty * Tw - it.R;
+    const int Tw = tile_side(it.R), Th = tile_height(it.R);
+    const int wx0 = tx * Tw - it.R, wy0 = ty * Th - it.R;
     const int nc = bin.rmax1 > 0 ? max(0, bin.rmax1 - bin.rmin) * max(0, bin.cmax1 - bin.cmin) : 0;
-    const bool interior = wx0 >= 0 && wy0 >= 0 && wx0 + W <= it.dw && wy0 + W <= it.dh && nc <= NLDSCELL && phase_limit != 3;
+    const bool interior = wx0 >= 0 && wy0 >= 0 && wx0 + W <= it.dw && wy0 + WH <= it.dh && nc <= NLDSCELL && phase_limit != 3;
 #ifdef VKX_FUSED_CENSUS
     // tools/isa_census.py: only the hot variant (interior window, 5-tap blur) so that its ISA can be read in isolation
     (void)interior;
@@ -1123,20 +1131,13 @@ __global__ void __launch_bounds__(NTHREADS, 4) k_tile_remap(const ItemDev *__res
 // Sample i of the dense [dh, dw, 3] plane lives in the slot of the generator tile t with table[t].first <= i < table[t + 1].first:
 // the expected tile from the mean yield of a tile, four table entries around it in one round trip, a walk along the table should
 // they not bracket it.  One lane per record; 8 bytes per 64-pixel row segment against the 360 bytes of noise it places.
-__global__ void __launch_bounds__(256) k_chain_noise_rows(const ItemDev *__restrict__ items, const long long *__restrict__ row_prefix, int n_items,
-                                                          long long total)
+__global__ void __launch_bounds__(256) k_chain_noise_rows(const ItemDev *__restrict__ items)
 {
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= total) return;
-    int lo = 0, hi = n_items - 1;                  // largest i with row_prefix[i] <= gid
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (row_prefix[mid] <= gid) lo = mid; else hi = mid - 1;
-    }
-    const ItemDev &it = items[lo];
+    const ItemDev &it = items[blockIdx.y];         // grid = (records of the largest image / 256, images)
     if (!it.noise_rows) return;
-    const uint32_t k = (uint32_t)(gid - row_prefix[lo]);
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= (uint32_t)it.dh * (uint32_t)it.tiles_x) return;
     const uint32_t y = k / (uint32_t)it.tiles_x, tx = k - y * (uint32_t)it.tiles_x;
     const u32x2 VKX_GLOBAL *tab = (const u32x2 VKX_GLOBAL *)it.noise_table;
     const uint32_t T = (uint32_t)it.noise_tiles, slot = (uint32_t)it.noise_slot;
@@ -1190,9 +1191,7 @@ static int launch_tiles(vkx_ctx *ctx, std::vector<ItemDev> &dev, std::vector<int
     if ((rc = vkx_scratch_reserve(ctx, &ctx->owner, sizeof(TileBin) * nbins))) return rc;
     const size_t items_bytes = sizeof(ItemDev) * (size_t)n_items, prefix_bytes = sizeof(int) * prefix.size();
     const size_t items_off = 0, prefix_off = (items_bytes + 255) & ~(size_t)255;
-    const size_t rowp_off = (prefix_off + prefix_bytes + 255) & ~(size_t)255;
-    const size_t rowp_bytes = noise_row_prefix ? sizeof(long long) * noise_row_prefix->size() : 0;
-    const size_t misc_bytes = noise_row_prefix ? rowp_off + rowp_bytes : prefix_off + prefix_bytes;
+    const size_t misc_bytes = prefix_off + prefix_bytes;
     if ((rc = vkx_scratch_reserve(ctx, &ctx->misc, misc_bytes))) return rc;
     const HsvLut *lut = nullptr;
     if (!elements && (rc = vkx_hsv_tables(ctx, (const void **)&lut))) return rc;
@@ -1203,7 +1202,6 @@ static int launch_tiles(vkx_ctx *ctx, std::vector<ItemDev> &dev, std::vector<int
     if ((rc = vkx_desc_ring_take(ctx, misc_bytes, &ring))) return rc;
     memcpy((unsigned char *)ring + items_off, dev.data(), items_bytes);
     memcpy((unsigned char *)ring + prefix_off, prefix.data(), prefix_bytes);
-    if (noise_row_prefix) memcpy((unsigned char *)ring + rowp_off, noise_row_prefix->data(), rowp_bytes);
     const ItemDev *d_items = (const ItemDev *)(misc + items_off);
     const int *d_cell_prefix = (const int *)(misc + prefix_off);
     TileBin *bins = (TileBin *)ctx->owner.ptr;
@@ -1226,8 +1224,9 @@ static int launch_tiles(vkx_ctx *ctx, std::vector<ItemDev> &dev, std::vector<int
     static const int phase_limit = [] { const char *e = getenv("VKX_FUSED_PHASES"); return e ? atoi(e) : 0; }();
     if (noise_row_prefix && noise_row_prefix->back() > 0) {
         VKX_TIMED(ctx, "k_chain_noise_rows");
-        const long long total = noise_row_prefix->back();
-        k_chain_noise_rows<<<vkx_blocks((size_t)total, 256), 256, 0, ctx->stream>>>(d_items, (const long long *)(misc + rowp_off), n_items, total);
+        long long most = 0;                      // records of the largest image
+        for (int i = 0; i < n_items; i++) most = std::max(most, (*noise_row_prefix)[i + 1] - (*noise_row_prefix)[i]);
+        k_chain_noise_rows<<<dim3(vkx_blocks((size_t)most, 256), n_items), 256, 0, ctx->stream>>>(d_items);
         VKX_LAUNCH_CHECK();
     }
     if (elements) {
@@ -1277,8 +1276,8 @@ int vkx_chain_fused_try(vkx_ctx *ctx, const vkx_chain_item *items, int n_items)
         }
         d.sh = it.sh; d.sw = it.sw; d.dh = it.dh; d.dw = it.dw; d.rows = it.rows; d.cols = it.cols;
         d.R = it.blur_ksize > 1 ? it.blur_ksize / 2 : 0;
-        const int Tw = tile_side(d.R);
-        d.tiles_x = (it.dw + Tw - 1) / Tw; d.tiles_y = (it.dh + Tw - 1) / Tw;
+        const int Tw = tile_side(d.R), Th = tile_height(d.R);
+        d.tiles_x = (it.dw + Tw - 1) / Tw; d.tiles_y = (it.dh + Th - 1) / Th;
         d.cell_base = (int)ncells;
         d.hue_on = it.hue_enabled; d.hue_delta = it.hue_delta;
         d.streak_on = it.streak_enabled && it.streak_alpha != 0.0 && (it.streak_enable_vert || it.streak_enable_hori);
@@ -1332,8 +1331,8 @@ int vkx_tile_remap_try(vkx_ctx *ctx, const vkx_elem *elems, int n_elems, int sh,
     d.sv = src_vertices; d.dv = dst_vertices;
     d.sh = sh; d.sw = sw; d.dh = dh; d.dw = dw; d.rows = rows; d.cols = cols;
     d.R = 0;
-    const int Tw = tile_side(0);
-    d.tiles_x = (dw + Tw - 1) / Tw; d.tiles_y = (dh + Tw - 1) / Tw;
+    const int Tw = tile_side(0), Th = tile_height(0);
+    d.tiles_x = (dw + Tw - 1) / Tw; d.tiles_y = (dh + Th - 1) / Th;
     d.cell_base = 0;
     d.n_elems = n_elems;
     for (int e = 0; e < n_elems; e++) {

@@ -1166,13 +1166,13 @@ __global__ void __launch_bounds__(256) k_np_tiles_expand(const uint2 *__restrict
 // VKX_NP_NORMAL_TILES, after the walk: one lane per tile writes the tile's table entry (index of its first sample, first valid
 // slot element) and lends the tile the first two samples of its successor, so that the three samples of a pixel never
 // straddle two slots; the job's last tile also writes the sentinel entry and the header.
-__global__ void __launch_bounds__(256) k_np_tiles_finish(const NpJob *__restrict__ jobs, int n_jobs, long long total_tiles,
-                                                         const TileInfo *__restrict__ info, const TilePlan *__restrict__ plan)
+__global__ void __launch_bounds__(256) k_np_tiles_finish(const NpJob *__restrict__ jobs, const TileInfo *__restrict__ info,
+                                                         const TilePlan *__restrict__ plan)
 {
-    const long long tile = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (tile >= total_tiles) return;
-    const NpJob &job = jobs[job_of_tile(jobs, n_jobs, tile)];
-    const long long t = tile - job.tile_base;
+    const NpJob &job = jobs[blockIdx.y];           // grid = (tiles of the longest stream / 256, streams)
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= job.n_tiles) return;
+    const long long tile = job.tile_base + t;
     auto skip_of = [&](long long tl, const TilePlan &p) -> uint32_t {
         if ((long long)p.prefix < job.n && tile_needs_walk(job, p, 0u, false)) return 0u;     // rewritten from its true carry-in
         if (p.c_in & kIrregular) return 0u;                                                   // (beyond the samples wanted)
@@ -1548,7 +1548,7 @@ static int np_chunk_back(vkx_ctx *ctx, NpChunk &c)
     }
     if (kind == VKX_NP_NORMAL_TILES) {
         VKX_TIMED(ctx, "k_np_tiles_finish");
-        k_np_tiles_finish<<<vkx_blocks((size_t)total_tiles, 256), 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, info, plan);
+        k_np_tiles_finish<<<dim3(vkx_blocks((size_t)c.max_tiles, 256), n_jobs), 256, 0, ctx->stream>>>(dj, info, plan);
         VKX_LAUNCH_CHECK();
     }
     if (!c.res_mapped)
