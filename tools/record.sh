@@ -1,11 +1,15 @@
 #!/bin/bash
-# Round record on the GPU box: default bench line, rocprofv3 kernel stats (batch 64), PMC passes (batch 32).
-# Usage (through gpurun): ./tools/record.sh <tag>
+# Round record on the GPU box: PMC passes (batch 32) first -- their summary is what the bench line's roofline.traffic / valu_issue_frac
+# read, tied to the kernel sources by a digest --, then the default bench line, then rocprofv3 kernel stats at batch 64 and 256.
+# Usage (through gpurun): ./tools/record.sh <tag>     (afterwards, here: tools/pmc_parse.py <tag> 32 regenerates profiles/<tag>_*)
 TAG=${1:-r1}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $ROOT/gpurun_out
 cd $ROOT
 python -c "import bench; print(bench.kernel_source_digest())" > gpurun_out/digest_$TAG.txt
+$ROOT/tools/pmc.sh $TAG 32
+python $ROOT/tools/pmc_parse.py $TAG 32 0 > /dev/null          # writes profiles/current_traffic.json on this box for the bench below
+cd $ROOT
 timeout 900 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; echo "bench rc=$?"
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/stats_$TAG -o stats -- \
@@ -15,4 +19,3 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/stats256_$TAG -o stats -- \
     python $ROOT/bench.py --batch 256 --steps 5 --warmup 1 --cpu-sample 0 --verify 0 --extra-legs 0 \
     > $ROOT/gpurun_out/stats256_$TAG.log 2>&1; echo "stats256 rc=$?"
-$ROOT/tools/pmc.sh $TAG 32
