@@ -268,6 +268,19 @@ int vkx_pointwise_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptr
  * equalisation (numpy arithmetic of :222-243 per distinct value), cv.equalizeHist's cumulative table for the other. */
 int vkx_histogram_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride, int32_t *hist);
 int vkx_histogram_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride, int32_t *hist);
+/* std_shift's mean (photometric/color.py:165-210): sums_host [n_sel] = the float32 sums numpy forms inside np.mean of the float32
+ * copy, value for value, including the roundings once a running sum has left the exactly representable range (2^24):
+ *   sequential = 0  np.mean(mat) of a single plane, and the channels picked with mat[:, :, channels] (numpy lays that copy out
+ *                   channel first): per channel, pieces of 8 192 contiguous elements summed exactly, accumulated in float32 one
+ *                   after the other;
+ *   sequential = 1  np.mean(mat.reshape(-1, C), axis=0) of ALL C >= 2 channels of an interleaved image: a sequential float32
+ *                   accumulation over the pixels, per channel.
+ * The mean is sums / float32(h * w).  h * w <= 2^22.  Synchronous (the caller builds its tables from the values); *_dev: src is a
+ * device plane. */
+int vkx_sum_f32_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride, const int32_t *channels_host,
+                       int n_sel, int sequential, float *sums_host);
+int vkx_sum_f32_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride, const int32_t *channels_host,
+                   int n_sel, int sequential, float *sums_host);
 int vkx_apply_lut_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
                          const uint8_t *lut_host, unsigned channel_mask, uint8_t *dst, ptrdiff_t dst_stride);
 int vkx_apply_lut_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,

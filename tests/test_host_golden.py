@@ -463,6 +463,7 @@ def test_std_shift_tables_match_reference(golden_dir, monkeypatch):
         return out
 
     monkeypatch.setattr(_native, 'apply_lut', lut_on_host)
+    monkeypatch.setenv('VKX_HOST_MEAN', '1')     # no GPU here: numpy's mean (the device's is checked against numpy in test_gpu_reduce.py)
     n = 0
     for case, mat, want, hist, head in _std_shift_cases(golden_dir):
         got = D.std_shift.distort(D.StdShiftConfig(scale=case['scale'], channels=case['channels']), image=Image(mat=mat)).image.mat

@@ -219,6 +219,7 @@ for _sfx in ('', '_dev'):
     _SIGNATURES['vkx_brightness_shift_rgb' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_int, c_void_p, c_ssize]
     _SIGNATURES['vkx_color_balance_rgb' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_double, c_void_p, c_ssize]
     _SIGNATURES['vkx_histogram_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p]
+    _SIGNATURES['vkx_sum_f32_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_int, c_int, c_void_p]
     _SIGNATURES['vkx_apply_lut_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_uint, c_void_p, c_ssize]
     _SIGNATURES['vkx_gather_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_void_p, c_ssize, c_void_p, c_int, c_int, c_ssize]
     _SIGNATURES['vkx_pointwise_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_int, c_int, c_int, c_uint, c_void_p, c_ssize]
@@ -1122,6 +1123,27 @@ def histogram(img, ctx=None):
         hist[...] = 0
     check(call.fn('vkx_histogram_u8')(call.ctx.handle, call.src(img), h, w, cn, stride, hptr))
     return np.array(host_array(hist))
+
+
+def mean_f32_u8(img, channels=None, ctx=None):
+    """``np.mean`` of the float32 copy of a uint8 image, the way ``std_shift`` takes it (photometric/color.py:165-210) and with
+    numpy's own roundings: ``np.mean(mat)`` for an H x W image (a numpy float32 scalar), ``np.mean(mat.reshape(-1, k), axis=0)`` for
+    the ``k`` selected channels of an H x W x C one (float32 [k]); ``channels`` = None: all.  None when the image is outside the
+    device path's limits (more than 2^22 pixels): the caller takes numpy."""
+    h, w, cn, stride = _shape_u8(img)
+    if h * w == 0 or h * w > (1 << 22):
+        return None
+    sel = list(range(cn)) if channels is None else [int(c) for c in channels]
+    if not 1 <= len(sel) <= 4:
+        return None
+    call = _Call(ctx, img)
+    idx = np.asarray(sel, dtype=np.int32)
+    sums = np.zeros(len(sel), np.float32)
+    # all channels of an interleaved image reduce along the outer axis (sequentially); a plane and picked channels piecewise
+    sequential = int(channels is None and img.ndim == 3 and cn >= 2)
+    check(call.fn('vkx_sum_f32_u8')(call.ctx.handle, call.src(img), h, w, cn, stride, _ptr(idx), len(sel), sequential, _ptr(sums)))
+    mean = sums / (h * w)        # float32 / int, as np.mean divides (um.true_divide(ret, rcount)): float32
+    return np.float32(mean[0]) if img.ndim == 2 else mean
 
 
 def filter2d(img, kernel, ctx=None):

@@ -3,9 +3,11 @@ photometric/color.py:32-116) and the integer per-value members ``complement``, `
 ``channel_permutation`` (:299-357, :400-432), ``brightness_shift`` (:125-160), ``color_balance`` (:360-397) and the two
 equalisations (:205-285): a per-channel histogram on the GPU (exact integer reduction), a 256-entry table per channel
 built on the host with the reference's arithmetic, and a table pass on the GPU.  ``std_shift`` (:165-210) takes its
-per-channel float32 mean from numpy on the host -- an order-dependent float32 reduction, evaluated by the same numpy call
-as the reference -- and then is a table pass like the others."""
+per-channel float32 mean -- an order-dependent float32 reduction -- from ``vkx_sum_f32_u8``, which adds in numpy's order with
+numpy's roundings (csrc/reduce.hip), and then is a table pass like the others."""
 from typing import Any, Mapping, Optional, Sequence
+
+import os
 
 import attrs
 import numpy as np
@@ -220,22 +222,28 @@ class StdShiftConfig(DistortionConfig):
 def std_shift_image(config: StdShiftConfig, state, image: Image, rng: Optional[RandomGenerator]):
     """``round(v * scale - mean * (scale - 1))`` clipped to uint8, per selected channel (reference color.py:165-203).
 
-    The mean is the reference's own expression on the host array: ``np.mean`` of the float32 copy, over the flattened
-    pixels with ``axis=0`` for colour images -- a float32 accumulation whose value depends on the summation order, so it
-    is left to numpy.  Everything per pixel depends on the grey level and the channel only: the float32 expression is
-    evaluated for the 256 levels and applied as a table on the GPU."""
+    The mean is the reference's expression, ``np.mean`` of the float32 copy -- over the flattened pixels with ``axis=0`` for colour
+    images: a float32 accumulation whose value depends on the order of the additions.  ``vkx_sum_f32_u8`` forms it on the device in
+    numpy's order, rounding for rounding (csrc/reduce.hip; 5 ms of a host core per 1024^2 page before); images beyond its limits
+    take numpy.  Everything per pixel depends on the grey level and the channel only: the float32 expression is evaluated for the
+    256 levels and applied as a table on the GPU."""
     assert config.scale > 0
-    mat = image.mat[:, :, list(config.channels)] if config.channels else image.mat
-    mat = mat.astype(np.float32)
-    if mat.ndim == 2:
-        mean = np.mean(mat)
-    elif mat.ndim == 3:
-        mean = np.mean(mat.reshape(-1, mat.shape[-1]), axis=0)
-    else:
-        raise NotImplementedError()
+    ndim = image.arr.ndim
+    mean = None
+    if os.environ.get('VKX_HOST_MEAN') != '1' and ndim in (2, 3):
+        mean = _native.mean_f32_u8(image.arr, list(config.channels) if (config.channels and ndim == 3) else None)
+    if mean is None:
+        mat = image.mat[:, :, list(config.channels)] if config.channels else image.mat
+        mat = mat.astype(np.float32)
+        if mat.ndim == 2:
+            mean = np.mean(mat)
+        elif mat.ndim == 3:
+            mean = np.mean(mat.reshape(-1, mat.shape[-1]), axis=0)
+        else:
+            raise NotImplementedError()
     selected = _selected_channels(image, config.channels)
     levels = np.arange(256, dtype=np.float32)
-    if mat.ndim == 3:
+    if ndim == 3:
         values = levels.reshape(-1, 1) * config.scale - mean * (config.scale - 1)       # (256, k), float32
     else:
         values = (levels * config.scale - mean * (config.scale - 1)).reshape(-1, 1)
