@@ -504,6 +504,35 @@ def gen_std_shift():
     np.savez_compressed(os.path.join(HERE, 'std_shift.npz'), **out)
 
 
+def gen_gcn():
+    """The float32 ``*_GCN`` image modes (vkit/element/image.py:733-768; numpy only).  ``to_gcn_image`` cannot succeed in the
+    reference -- ``ImageMode.supports_gcn_mode`` is inverted (image.py:69-72), so every mode that has a GCN twin raises and every
+    other one fails the table look-up -- which is recorded here as behaviour; a GCN image therefore only exists when a caller builds
+    one (``Image(mat=float32, mode=RGB_GCN)``), and what the reference does with it on this path is ``to_non_gcn_image``: the
+    min / max rescale to uint8 whose outputs are kept."""
+    from vkit.element.image import ImageMode
+    out, cases = {}, []
+    rng = default_rng(77)
+    raised = {}
+    for mode in (ImageMode.RGB, ImageMode.GRAYSCALE, ImageMode.HSV, ImageMode.HSL, ImageMode.RGBA):
+        shape = (5, 4) if mode == ImageMode.GRAYSCALE else (5, 4, 4 if mode == ImageMode.RGBA else 3)
+        try:
+            Image(mat=np.zeros(shape, np.uint8), mode=mode).to_gcn_image()
+            raised[mode.value] = None
+        except Exception as exc:
+            raised[mode.value] = type(exc).__name__
+    specs = [((41, 37, 3), 'rgb_gcn', 1.0, 0.0), ((33, 64), 'grayscale_gcn', 3.5, -2.0), ((57, 43, 3), 'hsv_gcn', 0.01, 7.0),
+             ((57, 43, 3), 'hsl_gcn', 1000.0, 0.0), ((2, 2, 3), 'rgb_gcn', 1.0, 0.0)]
+    for i, (shape, mode, spread, offset) in enumerate(specs):
+        mat = (rng.standard_normal(shape) * spread + offset).astype(np.float32)
+        back = Image(mat=mat, mode=ImageMode(mode)).to_non_gcn_image()
+        cases.append({'shape': list(shape), 'mode': mode, 'back_mode': back.mode.value})
+        out[f'in_{i}'] = mat
+        out[f'back_{i}'] = back.mat
+    out['cases_json'] = np.frombuffer(json.dumps({'cases': cases, 'to_gcn_image_raises': raised}).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, 'gcn.npz'), **out)
+
+
 def gen_page_resizing():
     """PageResizingStep.run of the reference on recording stand-ins for the page elements: which size and which
     interpolation every element is asked to take, for seeded rngs (pipeline/text_detection/page_resizing.py:86-181)."""
@@ -638,5 +667,6 @@ if __name__ == '__main__':
     gen_structure_oracle_patched()
     gen_page_resizing()
     gen_std_shift()
+    gen_gcn()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

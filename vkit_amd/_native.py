@@ -866,6 +866,20 @@ def grid_remap(mats, src_vertices, dst_vertices, dst_shape, ctx=None):
         raise ValueError('source / destination grids differ in shape')
     rows, cols = sv.shape[:2]
     dh, dw = int(dst_shape[0]), int(dst_shape[1])
+    if any(np.dtype(m.dtype) == np.float32 and m.ndim == 3 for m in mats):
+        # float32 colour images (the *_GCN modes): cv.remap treats the channels alike -- every channel as a float32 plane of the
+        # same call, the results stacked on the host
+        flat, counts = [], []
+        for m in mats:
+            if np.dtype(m.dtype) == np.float32 and m.ndim == 3:
+                hm = host_array(m)
+                flat += [np.ascontiguousarray(hm[:, :, c]) for c in range(hm.shape[2])]
+                counts.append(hm.shape[2])
+            else:
+                flat.append(m)
+                counts.append(0)
+        res = iter(grid_remap(flat, src_vertices, dst_vertices, dst_shape, ctx))
+        return [np.stack([host_array(next(res)) for _ in range(n)], axis=-1) if n else next(res) for n in counts]
     call = _Call(ctx, *mats)
     sv_p, dv_p = call.src(sv), call.src(dv)         # the device entry point reads the lattices on the device
     outs = []

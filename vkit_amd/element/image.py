@@ -50,7 +50,10 @@ class ImageMode(Enum):
         return 3
 
     def supports_gcn_mode(self):
-        return self in _TO_GCN
+        # the reference's test is inverted (vkit/element/image.py:69-72: ``self not in _IMAGE_MODE_NON_GCN_TO_GCN``): a mode WITH a
+        # GCN twin answers False -- to_gcn_mode() and with it to_gcn_image() raise RuntimeError for RGB / GRAYSCALE / HSV / HSL, and
+        # KeyError for the rest.  Kept: a drop-in behaves like what it replaces (tests/golden/gcn.npz records the reference's answers)
+        return self not in _TO_GCN
 
     def to_gcn_mode(self):
         if not self.supports_gcn_mode():
@@ -186,10 +189,13 @@ class Image(LazyMat, Shapable):
         from vkit_amd import _native
         if cv_resize_interpolation not in range(7):
             raise ValueError(f'unknown cv2 interpolation code {cv_resize_interpolation}')
-        if self._mat.dtype != np.uint8:
-            raise NotImplementedError('float32 image modes are outside the accelerated path')
         _, _, resized_height, resized_width = generate_shape_and_resized_shape(
             shapable_or_shape=self, resized_height=resized_height, resized_width=resized_width)
+        if self._mat.dtype == np.float32 and self._mat.ndim == 3:
+            # a float32 (*_GCN) colour image: cv.resize treats the channels alike, so plane by plane through the float32 kernels
+            planes = [_native.host_array(_native.resize(np.ascontiguousarray(self.mat[:, :, c]), (resized_height, resized_width),
+                                                        cv_resize_interpolation)) for c in range(self._mat.shape[2])]
+            return attrs.evolve(self, mat=np.stack(planes, axis=-1))
         return attrs.evolve(self, mat=_native.resize(self.arr, (resized_height, resized_width), cv_resize_interpolation))
 
     def to_conducted_resized_image(self, shapable_or_shape, resized_height: Optional[int] = None,
@@ -214,12 +220,44 @@ class Image(LazyMat, Shapable):
         right = right or self.width - 1
         return attrs.evolve(self, mat=self.mat[up:down + 1, left:right + 1])
 
+    def to_gcn_image(self, lamb: float = 0, eps: float = 1E-8, scale: float = 1.0):
+        """Global contrast normalisation to the float32 twin of the mode (reference image.py:733-756, numpy only).  As in the
+        reference the call cannot get past ``to_gcn_mode()`` (see ``ImageMode.supports_gcn_mode``); the arithmetic below is the
+        reference's and is what a fixed reference would compute."""
+        mode = self.mode.to_gcn_mode()
+        mat = self.mat.astype(np.float32)
+        mean = np.mean(mat)
+        mat -= mean
+        std = np.sqrt(lamb + np.mean(mat**2))
+        mat /= max(eps, std)
+        if scale != 1.0:
+            mat *= scale
+        return Image(mat=mat, mode=mode)
+
+    def to_non_gcn_image(self):
+        """float32 ``*_GCN`` image -> its uint8 mode: shift to zero, stretch the range to 255, round, clip (reference
+        image.py:758-768; numpy expressions, pinned by tests/golden/gcn.npz)."""
+        mode = self.mode.to_non_gcn_mode()
+        assert self.mat.dtype == np.float32
+        val_min = np.min(self.mat)
+        mat = self.mat - val_min
+        gap = np.max(mat)
+        mat = mat / gap * 255.0
+        mat = np.round(mat)
+        mat = np.clip(mat, 0, 255).astype(np.uint8)
+        return Image(mat=mat, mode=mode)
+
     def to_target_mode_image(self, target_mode: ImageMode):
         """cv.cvtColor chain of the reference (image.py:771-814) among GRAYSCALE / RGB / RGBA / HSV / HSL: the two shortcuts
         GRAYSCALE <-> RGBA, otherwise source -> RGB -> target, HSL stored as HLS with the last two channels swapped.  The
-        conversions run on the GPU; the float32 ``*_GCN`` modes are outside the accelerated path."""
+        conversions run on the GPU.  A float32 ``*_GCN`` source is taken to its uint8 mode first (``to_non_gcn_image``), as in the
+        reference; a ``*_GCN`` target is as impossible here as there (the reference's conversion table has none)."""
         if target_mode == self.mode:
             return self
+        if self.mode.in_gcn_mode():
+            self = self.to_non_gcn_image()
+            if self.mode == target_mode:
+                return self
         from vkit_amd import _native
         supported = (ImageMode.GRAYSCALE, ImageMode.RGB, ImageMode.RGBA, ImageMode.HSV, ImageMode.HSL)
         if self.mode not in supported or target_mode not in supported:
