@@ -922,7 +922,10 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tx, cons
                 const int16_t VKX_GLOBAL *rowp = noise + (size_t)(uint32_t)__builtin_amdgcn_readlane((int)nrow.x, i);
                 const uint32_t sd = (uint32_t)__builtin_amdgcn_readlane((int)nrow.y, i);
                 uint32_t off = k3;
-                if ((sd & 0xffffu) < 3u * W) off += k3 >= (sd & 0xffffu) ? (uint32_t)((int)sd >> 16) : 0u;   // the row runs into the next tile
+                if ((sd & 0xffffu) < 3u * W) {       // the row runs into the next generator tile (6 % of the rows)
+                    asm volatile("" ::: "memory");   // (a real branch: as a select the common rows would pay for the rare ones)
+                    off += k3 >= (sd & 0xffffu) ? (uint32_t)((int)sd >> 16) : 0u;
+                }
                 np_ = rowp + off;
             } else {
                 np_ = noise + (ptrdiff_t)(y0 + cy) * nstride + (ptrdiff_t)(x0 + ocx) * 3;
