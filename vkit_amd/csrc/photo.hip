@@ -159,57 +159,87 @@ template <int R>
 __global__ void __launch_bounds__(256) k_gaussian_blur_rgb(const uint8_t *__restrict__ src, int h, int w, ptrdiff_t sstride,
                                                            uint8_t *__restrict__ dst, ptrdiff_t dstride, BlurKernel K)
 {
-    constexpr int KS = 2 * R + 1, TW = 64 - 2 * R;
-    __shared__ uint32_t hrb[(kBlurTileH + 2 * R) * 64];      // r sum | b sum << 16 (8.8 each)
-    __shared__ uint16_t hg[(kBlurTileH + 2 * R) * 64];
+    // Round 4: no LDS, no barrier.  A wavefront owns 8 output rows of a 64-column window (lane = column, the middle 64 - 2 R are
+    // outputs): it loads the 8 + 2 R rows it needs -- one unaligned dword per pixel --, runs their horizontal passes with
+    // whole-wavefront DPP shifts (the LDS pipe, which ds_bpermute taps and the staging of the sums kept busy, was the bound of the
+    // round-2 kernel), keeps the 8.8 sums of consecutive row PAIRS packed per channel (row | next row << 16) in registers, and takes
+    // the vertical pass two taps at a time with v_dot2_u32_u16 -- the register form of phases D / E of the fused chain kernel.
+    constexpr int KS = 2 * R + 1, TW = 64 - 2 * R, NR = 8 + 2 * R, NP = NR / 2;
+    static_assert(NR % 2 == 0, "whole row pairs");
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * kBlurTileH;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * kBlurTileH + 8 * wave;
+    if (y0 >= h) return;
     const int gx = reflect101(x0 - R + lane, w);
-    const int rows = min(kBlurTileH, h - y0) + 2 * R;
+    const bool last = gx == w - 1;          // the image's last column reads the dword that ENDS with its pixel
     uint32_t kq[KS];
-    int from[KS];
 #pragma unroll
-    for (int i = 0; i < KS; i++) {
-        kq[i] = K.k[i];
-        from[i] = min(max(lane + i - R, 0), 63) << 2;
+    for (int i = 0; i < KS; i++) kq[i] = K.k[i];
+    int ry[NR];                                      // wavefront-uniform: the reflection loop only runs on the image's first / last bands
+    if (y0 - R >= 0 && y0 + 8 + R <= h) {
+#pragma unroll
+        for (int r = 0; r < NR; r++) ry[r] = y0 - R + r;
+    } else {
+#pragma unroll
+        for (int r = 0; r < NR; r++) ry[r] = reflect101(y0 - R + r, h);
     }
-    for (int row = wave; row < rows; row += 4) {
-        const uint8_t *p = src + (ptrdiff_t)reflect101(y0 - R + row, h) * sstride + (ptrdiff_t)gx * 3;
-        const uint32_t rb = (uint32_t)p[0] | ((uint32_t)p[2] << 16), g = p[1];
-        uint32_t arb = 0, ag = 0;
+    const uint32_t voff = (uint32_t)gx * 3u - (last ? 1u : 0u);       // scalar row base + 32-bit lane offset: saddr loads
+    uint32_t px[NR];
 #pragma unroll
-        for (int i = 0; i < KS; i++) {
-            const uint32_t vrb = i == R ? rb : (uint32_t)__builtin_amdgcn_ds_bpermute(from[i], (int)rb);
-            const uint32_t vg = i == R ? g : (uint32_t)__builtin_amdgcn_ds_bpermute(from[i], (int)g);
-            arb += __umul24(kq[i], vrb);  // both halves at once: k <= 256, each half <= 255, the operand fits 24 bits
-            ag += __umul24(kq[i], vg);
+    for (int r = 0; r < NR; r++) px[r] = *(const blur_u32_u1 *)(src + (ptrdiff_t)ry[r] * sstride + voff);
+    uint32_t pr[NP], pg[NP], pb[NP];                 // per row pair: (row 2 j | row 2 j + 1 << 16) of the horizontal sums
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+        uint32_t arb[2], ag[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint32_t v = last ? px[2 * j + u] >> 8 : px[2 * j + u];
+            const uint32_t rb = v & 0x00ff00ffu, g = (v >> 8) & 0xffu;
+            uint32_t srb = __umul24(kq[R], rb), sg = __umul24(kq[R], g);      // both halves at once: k <= 256, each half <= 255
+            uint32_t lrb = rb, lg = g, rrb = rb, rg = g;
+#pragma unroll
+            for (int d = 1; d <= R; d++) {
+                lrb = (uint32_t)__builtin_amdgcn_mov_dpp((int)lrb, 0x138 /* wave_shr:1: from lane - 1; lane 0 reads 0 */, 0xf, 0xf, true);
+                lg = (uint32_t)__builtin_amdgcn_mov_dpp((int)lg, 0x138, 0xf, 0xf, true);
+                rrb = (uint32_t)__builtin_amdgcn_mov_dpp((int)rrb, 0x130 /* wave_shl:1: from lane + 1; lane 63 reads 0 */, 0xf, 0xf, true);
+                rg = (uint32_t)__builtin_amdgcn_mov_dpp((int)rg, 0x130, 0xf, 0xf, true);
+                srb += __umul24(kq[R - d], lrb) + __umul24(kq[R + d], rrb);
+                sg += __umul24(kq[R - d], lg) + __umul24(kq[R + d], rg);
+            }
+            arb[u] = srb; ag[u] = sg;                // lanes the shifts ran dry on (0 .. R - 1, 64 - R .. 63) are halo columns
         }
-        hrb[row * 64 + lane] = arb;
-        hg[row * 64 + lane] = (uint16_t)ag;
+        pr[j] = __builtin_amdgcn_perm(arb[1], arb[0], 0x05040100u);     // low halves: r of both rows
+        pb[j] = __builtin_amdgcn_perm(arb[1], arb[0], 0x07060302u);     // high halves: b
+        pg[j] = ag[0] | (ag[1] << 16);
     }
-    __syncthreads();
     const int ox = lane - R, x = x0 + ox;
     const bool ocol = ox >= 0 && ox < TW && x < w;
     const int full4 = x0 + ((min(TW, w - x0) >> 2) << 2);    // columns of this tile covered by whole 4-pixel groups (TW % 4 == 2 for R = 1, 3)
-    for (int orow = wave; orow < rows - 2 * R; orow += 4) {
+    // 12-byte groups start at the tile's first output column (lane R): m = group phase of this lane
+    const int m = ox & 3;
+    const bool grouped = ocol && x < full4, gstore = grouped && m < 3, bstore = ocol && !grouped;
+    const uint32_t goff = (uint32_t)(x0 * 3 + (ox >> 2) * 12 + m * 4), boff = (uint32_t)x * 3u;
+    const uint32_t sh0 = 8 * m, sh1 = 24 - 8 * m;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        // taps kq[0 .. KS) sit on rows t .. t + 2 R of the loaded ones: pair (t + i) >> 1, half (t + i) & 1
         uint32_t ar = 32768u, ag = 32768u, ab = 32768u;
 #pragma unroll
-        for (int j = 0; j < KS; j++) {
-            const uint32_t vrb = hrb[(orow + j) * 64 + lane], vg = hg[(orow + j) * 64 + lane];
-            ar += __umul24(kq[j], vrb & 0xffffu);
-            ab += __umul24(kq[j], vrb >> 16);
-            ag += __umul24(kq[j], vg);
+        for (int q = 0; q <= R; q++) {
+            const int i0 = 2 * q - (t & 1), i1 = i0 + 1;             // tap indices of the pair's low / high half
+            const uint32_t wq = (i0 >= 0 && i0 < KS ? kq[i0 < 0 ? 0 : i0] : 0u) | ((i1 < KS ? kq[i1 < KS ? i1 : 0] : 0u) << 16);
+            const int j = (t >> 1) + q;
+            ar = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, wq), __builtin_bit_cast(us2, pr[j]), ar, false);
+            ag = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, wq), __builtin_bit_cast(us2, pg[j]), ag, false);
+            ab = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, wq), __builtin_bit_cast(us2, pb[j]), ab, false);
         }
         const uint32_t P = (ar >> 16) | ((ag >> 16) << 8) | (ab & 0xff0000u);     // sums stay below 2^24: no clamp needed
-        // 12-byte groups start at the tile's first output column (lane R): group phase of this lane
-        const int m = ox & 3;
-        const uint32_t Pn = (uint32_t)__builtin_amdgcn_ds_bpermute(min(lane + 1, 63) << 2, (int)P);
-        if (!ocol) continue;
-        uint8_t *drow = dst + (ptrdiff_t)(y0 + orow) * dstride;
-        if (x < full4) {
-            if (m < 3) *(blur_u32_u1 *)(drow + (ptrdiff_t)x0 * 3 + (ox >> 2) * 12 + m * 4) = (P >> (8 * m)) | (Pn << (24 - 8 * m));
-        } else {
-            uint8_t *d = drow + (ptrdiff_t)x * 3;
+        const uint32_t Pn = (uint32_t)__builtin_amdgcn_mov_dpp((int)P, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+        if (y0 + t >= h) break;                      // wavefront-uniform
+        uint8_t *drow = dst + (ptrdiff_t)(y0 + t) * dstride;
+        if (gstore) *(blur_u32_u1 *)(drow + goff) = (P >> sh0) | (Pn << sh1);
+        if (bstore) {
+            uint8_t *d = drow + boff;
             d[0] = (uint8_t)P; d[1] = (uint8_t)(P >> 8); d[2] = (uint8_t)(P >> 16);
         }
     }
@@ -969,7 +999,8 @@ VKX_EXPORT int vkx_gaussian_blur_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h,
         switch (cn) {
         case 1: k_gaussian_blur_tiled<1><<<tgrid, 256, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K); break;
         case 3:
-            if (K.kw == 3) k_gaussian_blur_rgb<1><<<tgrid, 256, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K);
+            if (w < 2) k_gaussian_blur_tiled<3><<<tgrid, 256, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K);   // the rgb kernel loads dwords
+            else if (K.kw == 3) k_gaussian_blur_rgb<1><<<tgrid, 256, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K);
             else if (K.kw == 5) k_gaussian_blur_rgb<2><<<tgrid, 256, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K);
             else k_gaussian_blur_rgb<3><<<tgrid, 256, 0, ctx->stream>>>(src, h, w, src_stride, dst, dst_stride, K);
             break;
