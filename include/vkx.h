@@ -548,6 +548,26 @@ int vkx_np_tiles_expand_dev(vkx_ctx *ctx, const void *tiles, int64_t n, int16_t 
 /* one job whose src / dst are HOST arrays; synchronous */
 int vkx_np_draw(vkx_ctx *ctx, const vkx_np_job *job, vkx_np_result *result_host);
 
+/* rng.poisson(lam) with lam = the bytes of a uint8 array (vkit poisson_noise, photometric/noise.py:81-90: `rng.poisson(mat as float32)`
+ * + clip to uint8), value for value numpy 2.2.6's random_poisson per element in C order (distributions.c: nothing for lam 0, the
+ * multiplication method below 10, PTRS from 10 up), drawn on the device from the PCG64 stream (state, inc) although every element takes
+ * a data-dependent number of draws: windows of candidate stream positions per block of 32 elements, resolved superblock by superblock
+ * (vkit_amd/csrc/poisson.hip).  dst uint8 [n] = min(sample, 255); *consumed_host = the raw 64-bit draws numpy would have made.
+ * *flags_host != 0: the result is NOT to be used and the stream not to be moved (the caller draws with numpy on the host): a PTRS
+ * comparison fell within 1e-11 of equality (device log vs glibc log), a start left its 6-sigma window, or k left the loggam table.
+ * Synchronous.  _dev: device arrays, src 16-byte aligned. */
+#define VKX_NP_POISSON_AMBIGUOUS 1u
+#define VKX_NP_POISSON_TABLE 2u
+#define VKX_NP_POISSON_WINDOW 4u
+#define VKX_NP_POISSON_MISMATCH 8u
+#define VKX_NP_POISSON_DRAWS 16u
+int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const uint64_t *inc, const uint8_t *src, long long n, uint8_t *dst,
+                          long long *consumed_host, unsigned *flags_host);
+int vkx_np_poisson_u8(vkx_ctx *ctx, const uint64_t *state, const uint64_t *inc, const uint8_t *src_host, long long n, uint8_t *dst_host,
+                      long long *consumed_host, unsigned *flags_host);
+/* out[x - 1] = numpy's random_loggam(x), x = 1 .. n, as the library tabulates it on the host (tests compare it with libnpyrandom.a) */
+int vkx_np_poisson_loggam_table(double *out, int n);
+
 /* ---- throughput-mode noise plane ---------------------------------------------------------------
  * gaussion_noise (photometric/noise.py:44-54) adds np.round(rng.normal(0, std, shape)) drawn from the caller's numpy
  * Generator; the parity path takes that int16 plane from the caller (vkx_add_noise_i16, vkx_chain_item.noise).

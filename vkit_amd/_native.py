@@ -172,6 +172,7 @@ _SIGNATURES = {
     'vkx_np_tiles_layout': [ctypes.c_int64] + [ctypes.POINTER(ctypes.c_int64)] * 5,
     'vkx_np_tiles_expand_dev': [c_void_p, c_void_p, ctypes.c_int64, c_void_p],
     'vkx_np_draw': [c_void_p, ctypes.POINTER(VkxNpJob), ctypes.POINTER(VkxNpResult)],
+    'vkx_np_poisson_loggam_table': [c_void_p, c_int],
     'vkx_host_alloc': [c_void_p, c_size, ctypes.POINTER(c_void_p)],
     'vkx_host_free': [c_void_p, c_void_p],
     'vkx_upload_async': [c_void_p, c_void_p, c_void_p, c_size],
@@ -220,6 +221,7 @@ for _sfx in ('', '_dev'):
     _SIGNATURES['vkx_color_balance_rgb' + _sfx] = [c_void_p, c_void_p, c_int, c_int, c_ssize, c_double, c_void_p, c_ssize]
     _SIGNATURES['vkx_histogram_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p]
     _SIGNATURES['vkx_sum_f32_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_int, c_int, c_void_p]
+    _SIGNATURES['vkx_np_poisson_u8' + _sfx] = [c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_void_p, c_void_p, c_void_p]
     _SIGNATURES['vkx_apply_lut_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_uint, c_void_p, c_ssize]
     _SIGNATURES['vkx_gather_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_void_p, c_void_p, c_ssize, c_void_p, c_int, c_int, c_ssize]
     _SIGNATURES['vkx_pointwise_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_int, c_int, c_int, c_uint, c_void_p, c_ssize]
@@ -1379,6 +1381,32 @@ def np_normal_i16(shape, std, rng, ctx=None):
 def np_speckle_noise(img, std, rng, ctx=None):
     """``uint8(clip(img + img * rng.normal(0, std, img.shape), 0, 255))`` (photometric/noise.py:172-183)."""
     return np_draw(NP_SPECKLE_U8, rng, img.shape, np.uint8, img, scale=std, ctx=ctx)
+
+
+def np_poisson_u8(img, rng, ctx=None):
+    """``clip(rng.poisson(img.astype(float32)), 0, 255).astype(uint8)`` (photometric/noise.py:81-90) with every sample drawn on the
+    device from ``rng``'s stream, value for value numpy's (``vkx_np_poisson_u8``), and ``rng`` moved past the draws numpy would have
+    made.  None -- ``rng`` untouched -- when the generator is not PCG64 or the device declines (``np_poisson_flags`` says why): the
+    caller then calls ``rng.poisson`` itself."""
+    global np_poisson_flags
+    stream = np_stream(rng)
+    if stream is None or img.dtype != np.uint8 or img.size == 0 or img.size > (1 << 30):
+        return None
+    call = _Call(ctx, img)
+    dst, dptr = call.out(img.shape, np.uint8)
+    state, inc = stream
+    st = (ctypes.c_uint64 * 2)(state & _M64, state >> 64)
+    ic = (ctypes.c_uint64 * 2)(inc & _M64, inc >> 64)
+    consumed, flags = ctypes.c_longlong(0), ctypes.c_uint(0)
+    check(call.fn('vkx_np_poisson_u8')(call.ctx.handle, st, ic, call.src(img), int(img.size), dptr, ctypes.byref(consumed), ctypes.byref(flags)))
+    np_poisson_flags = int(flags.value)
+    if flags.value:
+        return None
+    np_consume(rng, consumed.value)
+    return dst
+
+
+np_poisson_flags = 0
 
 
 def _choice_cdf(p):

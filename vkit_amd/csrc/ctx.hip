@@ -71,6 +71,9 @@ VKX_EXPORT int vkx_ctx_destroy(vkx_ctx *ctx)
     scratch_release(&ctx->noise_rows);
     scratch_release(&ctx->np_work[0]);
     scratch_release(&ctx->np_work[1]);
+    scratch_release(&ctx->pz_tabs);
+    scratch_release(&ctx->pz_work);
+    scratch_release(&ctx->pz_draws);
     for (auto &t : ctx->resize_tabs) scratch_release(&t.buf);
     for (auto &l : ctx->launches) { (void)hipEventDestroy(l.start); (void)hipEventDestroy(l.stop); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);

@@ -63,6 +63,8 @@ struct vkx_ctx {
     vkx_scratch np_tabs;              // jump constants + ziggurat tables of the numpy streams (nprand.hip), uploaded once
     vkx_scratch noise_rows;           // tiled noise of the fused chain: (row, tile column) -> slot offset records (fused.hip)
     vkx_scratch np_work[2];           // tile arrays of the numpy streams: the chunks of a call alternate (nprand.hip)
+    vkx_scratch pz_tabs, pz_work, pz_draws;   // rng.poisson on the device (poisson.hip): per-lam constants; block plan; raw draws + E rows
+    bool pz_tabs_ready = false;
 
     // Host-array pipelines: two copy streams next to the compute stream (created on first use), a pool of events that
     // order them, and a page-locked ring through which the launch descriptors of the tile kernels reach the device

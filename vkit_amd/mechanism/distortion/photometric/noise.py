@@ -1,6 +1,6 @@
 """``gaussion_noise`` (sic, reference: photometric/noise.py:25-61), ``impulse_noise`` (:100-157) and
-``speckle_noise`` (:160-190) and ``poisson_noise`` (:64-98), which is one ``rng.poisson`` call on the caller's stream
-plus a saturating narrow on the GPU.
+``speckle_noise`` (:160-190) and ``poisson_noise`` (:64-98): ``rng.poisson`` of the image's own values on the caller's stream
+plus a saturating narrow.
 
 The samples are the caller-visible numpy Generator stream -- ``np.round(rng.normal(0, std, shape))`` in C order, one
 draw per channel value -- so that a stored ``config.rng_state`` reproduces the same pixels.  For the default bit
@@ -156,8 +156,13 @@ class PoissonNoiseConfig(DistortionConfig):
 def poisson_noise_image(config: PoissonNoiseConfig, state, image: Image, rng: Optional[RandomGenerator]):
     """Every value is replaced by a Poisson draw with that value as its mean (float32 rates, C order)."""
     assert rng
-    samples = rng.poisson(image.mat.astype(np.float32))
-    return Image(mat=_native.saturate_i64(samples))
+    # the caller's PCG64 stream drawn on the device, value for value numpy's although every element takes a data-dependent number of
+    # draws (vkx_np_poisson_u8); None: another bit generator, or one of the device path's rare refusals -- numpy draws, as before
+    mat = _native.np_poisson_u8(image.arr, rng) if image.arr.dtype == np.uint8 else None
+    if mat is None:
+        samples = rng.poisson(image.mat.astype(np.float32))
+        mat = _native.saturate_i64(samples)
+    return Image(mat=mat)
 
 
 poisson_noise = Distortion(
