@@ -58,16 +58,16 @@ def test_resident_input_and_the_distortion_member():
     from vkit_amd.element import Image
     from vkit_amd.mechanism import distortion as D
     img = default_rng(5).integers(0, 256, (400, 300, 3), dtype=np.uint8)
-    want = np.clip(default_rng(9).poisson(img.astype(np.float32)), 0, 255).astype(np.uint8)
-    r = default_rng(9)
-    out = D.poisson_noise.distort({}, image=Image(mat=img), rng=r).image
+    r_np = default_rng(9)
+    want = np.clip(r_np.poisson(img.astype(np.float32)), 0, 255).astype(np.uint8)
+    out = D.poisson_noise.distort({}, image=Image(mat=img), rng=default_rng(9)).image
     np.testing.assert_array_equal(out.mat, want)
     with N.resident(True):
         r2 = default_rng(9)
         got = N.np_poisson_u8(N.default_ctx().to_device(img), r2)
         assert isinstance(got, N.DevArray)
         np.testing.assert_array_equal(np.asarray(N.host_array(got)), want)
-    assert r.bit_generator.state == r2.bit_generator.state
+    assert r_np.bit_generator.state == r2.bit_generator.state
 
 
 def test_other_bit_generators_take_numpy(monkeypatch):

@@ -27,6 +27,8 @@
 #include "vkx_internal.h"
 
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <vector>
@@ -39,7 +41,7 @@ typedef unsigned __int128 u128;
 constexpr int kB = 32;              // elements per block
 constexpr int kMaxBlocks = 256;     // blocks per superblock
 constexpr int kBandMax = 3400;      // positions of a block's band (LDS: 8 bytes of draw + kB bytes of table each)
-constexpr int kChainCap = kB * 3400 / 2 - 16;    // E entries the chain stages at a time (the LDS of the tables)
+constexpr int kChainCap = kB * 3400 / 2 - 16 - 4096;    // E entries the chain stages at a time (the LDS of the tables)
 constexpr int kKMax = 1024;         // loggam table: k + 1 <= kKMax
 constexpr double kSigmas = 6.0;
 constexpr int kCandThreads = 1024;
@@ -256,23 +258,52 @@ __device__ __forceinline__ bool pz_attempt(const PzLam &L, const double *__restr
 
 constexpr uint8_t kCodeInvalid = 0xfe;
 
+// The attempt that starts at (d0, d1) as the table pass evaluates it: straight-line code (every lane takes the division, the float32
+// logarithms and the loggam lookup, so that the compiler can overlap the states of consecutive elements), the double logarithms only for
+// the lanes the float32 screen leaves open.  Same decisions as pz_attempt: it is the same arithmetic.
+__device__ __forceinline__ bool pz_attempt_table(const PzLam &L, const double *__restrict__ lgam /* LDS */, double d0, double d1)
+{
+    const double U = d0 - 0.5, V = d1, us = 0.5 - fabs(U);
+    const bool fast = us >= 0.07 && V <= L.vr;
+    const double kd = floor((L.a2 / us + L.b) * U + L.lam + 0.43);
+    const bool rej = kd < 0.0 || (us < 0.013 && V > us);
+    const bool big = !(kd < (double)kKMax);
+    const int ki = (int)fmin(fmax(kd, 0.0), (double)(kKMax - 1));
+    const double rhs = -L.lam + kd * L.loglam - lgam[ki + 1];
+    const float usf = (float)us;
+    const float lhs_f = (__log2f((float)V) - __log2f(__fdividef((float)L.a, usf * usf) + (float)L.b)) * 0.69314718f;
+    const double d = ((double)lhs_f + L.log_invalpha) - rhs;
+    bool acc = fast || (!rej && d < 0.0);
+    if (!fast && !rej && (big || !(fabs(d) > 1e-3))) {
+        double kk;
+        int flags = 0;
+        acc = pz_attempt<false>(L, lgam, d0, d1, kk, flags);
+    }
+    return acc;
+}
+
 // One superblock: workgroup = block (table, candidate walks, its E row); the workgroup that finishes last follows the exact start through
 // the rows (staged through the LDS the tables occupied) and leaves the exact start of every block and of the next superblock.
+// Between the workgroups of the launch the E rows travel as agent-scope stores and loads (write-through, past the per-XCD L2s): a
+// __threadfence() here writes the L2 back, 25 - 40 us per workgroup.
 __global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__restrict__ src, long long n, const PzBlock *__restrict__ blocks,
                                                            int first_block, int n_blocks, int end_lo_rel, int end_W, int chunk_blocks, int e_total,
                                                            long long *__restrict__ pos /* [0]: this superblock's start, [1]: the next one's */,
                                                            const double *__restrict__ draws, long long M, const PzTabs *__restrict__ T,
-                                                           uint16_t *E, long long *__restrict__ blk_pos, unsigned *__restrict__ counter,
-                                                           int *__restrict__ fail)
+                                                           uint16_t *E, long long *__restrict__ blk_pos, unsigned *counter,
+                                                           int *__restrict__ fail, long long *__restrict__ probe)
 {
+#define PZ_STAMP(k) do { if (probe && tid == 0 && ((k) >= 4 || (int)blockIdx.x + 1 == n_blocks)) probe[k] = (long long)wall_clock64(); } while (0)
     __shared__ double ld[kBandMax + 2];
     __shared__ __attribute__((aligned(16))) uint8_t tab[kB * kBandMax];
     __shared__ double lgam[kKMax + 1];
+    __shared__ PzLam lL[kB];
     __shared__ int l_off[kMaxBlocks + 1], l_lo[kMaxBlocks], l_idx[kMaxBlocks];
-    __shared__ uint8_t llam[kB];
+    __shared__ uint8_t llam[kB], rowof[kB];
     __shared__ int s_last, s_idx;
     const int tid = threadIdx.x;
     const long long p0 = pos[0];
+    PZ_STAMP(0);
     {
         const int j = first_block + blockIdx.x;
         const PzBlock blk = blocks[j];
@@ -283,27 +314,34 @@ __global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__rest
         const long long p_lo = p0 + blk.lo_rel;
         const int band = blk.band;
         if (tid < kB) llam[tid] = tid < n_el ? src[e0 + tid] : 0;
+        if (tid < kB * 8) {                                       // the elements' constants: 8 doubles each
+            const int t = tid >> 3;
+            const int lam = t < n_el ? src[e0 + t] : 0;
+            ((double *)lL)[tid] = ((const double *)&T->lam[lam])[tid & 7];
+        }
         for (int o = tid; o < band + 2; o += kCandThreads) {
             const long long p = p_lo + o;
             ld[o] = p >= 0 && p < M ? draws[p] : -1.0;          // -1: no such draw
         }
         for (int o = tid; o <= kKMax; o += kCandThreads) lgam[o] = T->loggam[o];
         __syncthreads();
+        if (tid < kB) {                                           // elements of one value share a table row
+            int r = tid;
+            for (int t = tid - 1; t >= 0; t--) r = llam[t] == llam[tid] ? t : r;
+            rowof[tid] = (uint8_t)r;
+        }
+        __syncthreads();
+        PZ_STAMP(1);
         for (int t = 0; t < n_el; t++) {
             const int lam = llam[t];
-            if (lam == 0) continue;
-            const PzLam &L = T->lam[lam];
+            if (lam == 0 || rowof[t] != t) continue;
+            const PzLam &L = lL[t];
             uint8_t *row = tab + t * band;
             if (lam >= 10) {
                 for (int o = tid; o < band; o += kCandThreads) {
                     const double d0 = ld[o], d1 = ld[o + 1];
-                    uint8_t code = kCodeInvalid;
-                    if (d0 >= 0.0 && d1 >= 0.0) {
-                        double kd;
-                        int flags = 0;
-                        code = pz_attempt<false>(L, lgam, d0, d1, kd, flags) ? 2 : 0;
-                    }
-                    row[o] = code;
+                    const bool acc = pz_attempt_table(L, lgam, d0, d1);
+                    row[o] = d0 >= 0.0 && d1 >= 0.0 ? (acc ? 2 : 0) : kCodeInvalid;
                 }
             } else {
                 const double enlam = L.enlam;
@@ -326,34 +364,47 @@ __global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__rest
             }
         }
         __syncthreads();
-        for (int c = tid; c < blk.W; c += kCandThreads) {
+        PZ_STAMP(2);
+        const int Wpad = (blk.W + 1) & ~1;                        // rows are stored as pairs (e_off is even)
+        // the elements' values and table rows as wave-uniform words: the walk's only dependent LDS read is the table byte
+        uint32_t lam_w[kB / 4], row_w[kB / 4];
+#pragma unroll
+        for (int q = 0; q < kB / 4; q++) {
+            lam_w[q] = __builtin_amdgcn_readfirstlane(((const uint32_t *)llam)[q]);
+            row_w[q] = __builtin_amdgcn_readfirstlane(((const uint32_t *)rowof)[q]);
+        }
+        for (int c0 = 0; c0 < Wpad; c0 += kCandThreads) {
+            const int c = c0 + tid;
             int o = c;
-            bool ok = true;
-            for (int t = 0; t < n_el && ok; t++) {
-                const int lam = llam[t];
+            bool ok = c < blk.W;
+#pragma unroll
+            for (int t = 0; t < kB; t++) {
+                const int lam = (lam_w[t >> 2] >> (8 * (t & 3))) & 0xff;      // 0 beyond n_el
                 if (lam == 0) continue;
-                const uint8_t *row = tab + t * band;
-                if (o >= band) { ok = false; break; }
-                uint8_t code = row[o];
+                const uint8_t *row = tab + ((row_w[t >> 2] >> (8 * (t & 3))) & 0xff) * band;
+                uint8_t code = ok && o < band ? row[o] : kCodeInvalid;
                 while (code == 0) {                  // a rejected PTRS attempt: the next one starts two draws on
                     o += 2;
-                    if (o >= band) { code = kCodeInvalid; break; }
-                    code = row[o];
+                    code = o < band ? row[o] : kCodeInvalid;
                 }
-                if (code == kCodeInvalid) ok = false;
-                else o += code;
+                ok = ok && code != kCodeInvalid;
+                o += code;
             }
             const int e = o + blk.lo_rel - next_lo_rel;
-            E[blk.e_off + c] = ok && e >= 0 && e < next_W ? (uint16_t)e : (uint16_t)0xffff;
+            const uint32_t mine = ok && e >= 0 && e < next_W ? (uint32_t)e : 0xffffu;
+            const uint32_t right = (uint32_t)__shfl_down((int)mine, 1);
+            if (!(c & 1) && c < Wpad)
+                __hip_atomic_store((uint32_t *)E + ((blk.e_off + c) >> 1), mine | (right << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     // the last workgroup to get here chains
-    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) s_last = atomicAdd(counter, 1u) == (unsigned)(n_blocks - 1);
+    PZ_STAMP(3);
+    if (tid == 0) s_last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(n_blocks - 1);
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
+    PZ_STAMP(4);
     uint16_t *le = (uint16_t *)tab;
     for (int b = tid; b < n_blocks; b += kCandThreads) {
         l_off[b] = blocks[first_block + b].e_off;
@@ -364,24 +415,53 @@ __global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__rest
         s_idx = 0;
     }
     __syncthreads();
+    constexpr int kPer = (kChainCap * 2 / 8 + kCandThreads - 1) / kCandThreads + 1;      // 8-byte loads per thread and chunk
+    uint64_t nextv[kPer];
+    int next_n8 = 0;
+    auto fetch = [&](int b0) {
+        const int b1 = min(n_blocks, b0 + chunk_blocks);
+        const int off0 = l_off[b0] & ~3, cnt = l_off[b1] - off0;
+        const uint64_t *eg = (const uint64_t *)(E + off0);
+        next_n8 = (cnt + 3) / 4;
+#pragma unroll
+        for (int q = 0; q < kPer; q++) {
+            const int i = tid + q * kCandThreads;
+            nextv[q] = i < next_n8 ? __hip_atomic_load(eg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        }
+    };
+    fetch(0);
     for (int b0 = 0; b0 < n_blocks; b0 += chunk_blocks) {
         const int b1 = min(n_blocks, b0 + chunk_blocks);
-        const int off0 = l_off[b0] & ~7, cnt = l_off[b1] - off0;         // rows start anywhere: copy from the 16-byte group below
-        typedef uint32_t pz_u32x4 __attribute__((ext_vector_type(4)));
-        const pz_u32x4 *eg = (const pz_u32x4 *)(E + off0);          // written by the other workgroups of this launch: past the L1
-        for (int i = tid; i < (cnt + 7) / 8; i += kCandThreads) ((pz_u32x4 *)le)[i] = __builtin_nontemporal_load(eg + i);
+        const int off0 = l_off[b0] & ~3;
+#pragma unroll
+        for (int q = 0; q < kPer; q++)
+            if (tid + q * kCandThreads < next_n8) ((uint64_t *)le)[tid + q * kCandThreads] = nextv[q];
         __syncthreads();
-        if (tid == 0) {
-            int idx = s_idx;
-            for (int b = b0; b < b1; b++) {
-                l_idx[b] = idx;
-                const uint16_t e = le[l_off[b] - off0 + max(idx, 0)];
-                idx = idx < 0 || e == 0xffff ? -1 : (int)e;
+        if (b1 < n_blocks) fetch(b1);                 // the next chunk's rows travel while lane 0 walks this one's
+        if (tid < 64) {
+            // Wavefront 0 walks the chunk: the dependent chain of a step is one add and one LDS read (every lane reads the same entry).
+            // The rows' offsets sit in a vector register, one per lane, and come out with v_readlane; the starts found go back the same
+            // way; a miss (0xffff) is noted on the side and the walk goes on with the index masked into the staged range.
+            uint32_t cur = (uint32_t)max(s_idx, 0);
+            bool bad = s_idx < 0;
+            for (int bb = b0; bb < b1; bb += 64) {
+                const int offv = l_off[min(bb + tid, n_blocks)] - off0;
+                int idxv = -1;
+#pragma unroll
+                for (int i = 0; i < 64; i++) {
+                    if (bb + i >= b1) break;
+                    const int off = __builtin_amdgcn_readlane(offv, i);
+                    idxv = tid == i ? (bad ? -1 : (int)cur) : idxv;
+                    cur = le[off + (cur & 0xfffu)];
+                    bad = bad || cur == 0xffffu;
+                }
+                if (bb + tid < b1) l_idx[bb + tid] = idxv;
             }
-            s_idx = idx;
+            if (tid == 0) s_idx = bad ? -1 : (int)cur;
         }
         __syncthreads();
     }
+    PZ_STAMP(5);
     for (int b = tid; b < n_blocks; b += kCandThreads) blk_pos[first_block + b] = l_idx[b] < 0 ? -1 : p0 + l_lo[b] + l_idx[b];
     if (tid == 0) {
         if (s_idx < 0) {
@@ -513,6 +593,8 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
     long long *d_bpos = (long long *)(work + o_bpos), *d_pos = (long long *)(work + o_pos);
     PzReply *d_reply = (PzReply *)(work + o_reply);
     unsigned *d_counter = (unsigned *)(work + o_counter);
+    static const bool probing = getenv("VKX_PZ_PROBE") != nullptr;       // phase timestamps of every superblock (tools/poisson_probe.py)
+    long long *d_probe = nullptr;
 
     { VKX_TIMED(ctx, "k_pz_stats"); k_pz_stats<<<vkx_blocks((size_t)n_blk, 256), 256, 0, ctx->stream>>>(src, n, tabs, d_mean, d_var); }
     VKX_LAUNCH_CHECK();
@@ -544,7 +626,7 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
             b.W = W;
             b.band = std::min(band, kBandMax);
             b.e_off = (int)e_off;
-            e_off += W;
+            e_off += (W + 1) & ~1;          // rows start at even offsets: the entries are stored in pairs
             max_band = std::max(max_band, b.band);
             last_W = W;
             cm += bmean[j];
@@ -554,7 +636,7 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
         const int H = (int)ceil(kSigmas * sqrt(cv)) + 3;
         S.end_lo_rel = (int)llround(cm) - H;
         S.end_W = 2 * H + 1;
-        S.chunk_blocks = std::max(1, kChainCap / last_W);
+        S.chunk_blocks = std::max(1, (kChainCap - 8) / (last_W + 1));
         S.max_band = max_band;
         S.e_total = e_off;
         e_max = std::max(e_max, e_off);
@@ -567,6 +649,11 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
     if ((rc = vkx_scratch_reserve(ctx, &ctx->pz_draws, sizeof(double) * (size_t)(M + 2) + up(sizeof(uint16_t) * (size_t)e_max + 16)))) return rc;
     double *d_draws = (double *)ctx->pz_draws.ptr;
     uint16_t *d_E = (uint16_t *)((unsigned char *)ctx->pz_draws.ptr + up(sizeof(double) * (size_t)(M + 2)));
+    if (probing) {
+        if ((rc = vkx_scratch_reserve(ctx, &ctx->misc, 64 * supers.size() + 64))) return rc;
+        d_probe = (long long *)ctx->misc.ptr;
+        VKX_HIP(hipMemsetAsync(d_probe, 0, 64 * supers.size(), ctx->stream));
+    }
     VKX_HIP(hipMemcpyAsync(d_plan, plan.data(), sizeof(PzBlock) * n_blk, hipMemcpyHostToDevice, ctx->stream));
     VKX_HIP(hipMemsetAsync(d_pos, 0, sizeof(long long), ctx->stream));
     VKX_HIP(hipMemsetAsync(d_reply, 0, sizeof(PzReply), ctx->stream));
@@ -585,7 +672,8 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
         const PzSuper &S = supers[s];
         VKX_TIMED(ctx, "k_pz_super");
         k_pz_super<<<S.n_blocks, kCandThreads, 0, ctx->stream>>>(src, n, d_plan, S.first_block, S.n_blocks, S.end_lo_rel, S.end_W, S.chunk_blocks,
-                                                                 (int)S.e_total, d_pos + s, d_draws, M, tabs, d_E, d_bpos, d_counter + s, &d_reply->fail);
+                                                                 (int)S.e_total, d_pos + s, d_draws, M, tabs, d_E, d_bpos, d_counter + s, &d_reply->fail,
+                                                                 d_probe ? d_probe + 8 * s : nullptr);
     }
     VKX_LAUNCH_CHECK();
     { VKX_TIMED(ctx, "k_pz_final");
@@ -594,6 +682,16 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
     PzReply reply;
     VKX_HIP(hipMemcpyAsync(&reply, d_reply, sizeof(reply), hipMemcpyDeviceToHost, ctx->stream));
     VKX_HIP(hipStreamSynchronize(ctx->stream));
+    if (probing) {
+        std::vector<long long> pr(8 * supers.size());
+        VKX_HIP(hipMemcpy(pr.data(), d_probe, 64 * supers.size(), hipMemcpyDeviceToHost));
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        for (size_t q = 0; q < supers.size(); q++)
+            for (int k = 1; k < 6; k++) acc[k] += (double)(pr[8 * q + k] - pr[8 * q + k - 1]);
+        fprintf(stderr, "pz probe (%zu superblocks, mean us, 100 MHz clock): stage %.2f table %.2f walk %.2f wait-for-last %.2f chain %.2f; last superblock: blocks %d band %d W %d chunk %d\n",
+                supers.size(), acc[1] / supers.size() / 100, acc[2] / supers.size() / 100, acc[3] / supers.size() / 100, acc[4] / supers.size() / 100,
+                acc[5] / supers.size() / 100, supers.back().n_blocks, supers.back().max_band, supers.back().end_W, supers.back().chunk_blocks);
+    }
     *consumed_host = reply.consumed;
     *flags_host = (unsigned)reply.fail;
     return VKX_OK;
