@@ -77,3 +77,31 @@ def test_other_bit_generators_take_numpy(monkeypatch):
     assert N.np_poisson_u8(img, Generator(Philox(3))) is None
     monkeypatch.setenv('VKX_HOST_RNG', '1')
     assert N.np_poisson_u8(img, default_rng(3)) is None
+
+
+def test_a_refused_image_leaves_the_generator_alone_and_numpy_draws():
+    """VKX_PZ_SIGMAS=0.3 makes the windows far too narrow (a separate process: the library reads it once): the device must refuse
+    (WINDOW flag), leave the generator where it was, and poisson_noise must come out as numpy's all the same."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np
+from numpy.random import default_rng
+from vkit_amd import _native as N
+from vkit_amd.element import Image
+from vkit_amd.mechanism import distortion as D
+img = default_rng(5).integers(0, 256, (300, 400, 3), dtype=np.uint8)
+r = default_rng(9)
+before = r.bit_generator.state
+assert N.np_poisson_u8(img, r) is None and N.np_poisson_flags & 4, N.np_poisson_flags
+assert r.bit_generator.state == before
+want = np.clip(default_rng(9).poisson(img.astype(np.float32)), 0, 255).astype(np.uint8)
+out = D.poisson_noise.distort({}, image=Image(mat=img), rng=default_rng(9)).image
+assert np.array_equal(out.mat, want)
+print('refused and redrawn')
+'''
+    env = dict(os.environ, VKX_PZ_SIGMAS='0.3')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-c', code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and 'refused and redrawn' in out.stdout, out.stdout + out.stderr

@@ -447,9 +447,8 @@ __global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__rest
             for (int bb = b0; bb < b1; bb += 64) {
                 const int offv = l_off[min(bb + tid, n_blocks)] - off0;
                 int idxv = -1;
-#pragma unroll
-                for (int i = 0; i < 64; i++) {
-                    if (bb + i >= b1) break;
+                const int rows = min(64, b1 - bb);
+                for (int i = 0; i < rows; i++) {
                     const int off = __builtin_amdgcn_readlane(offv, i);
                     idxv = tid == i ? (bad ? -1 : (int)cur) : idxv;
                     cur = le[off + (cur & 0xfffu)];
@@ -603,7 +602,8 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
     VKX_HIP(hipMemcpyAsync(bvar.data(), d_var, sizeof(float) * n_blk, hipMemcpyDeviceToHost, ctx->stream));
     VKX_HIP(hipStreamSynchronize(ctx->stream));
 
-    // the plan: superblocks and windows
+    // the plan: superblocks and windows (VKX_PZ_SIGMAS: narrower windows, to exercise the WINDOW refusal in tests)
+    static const double sigmas = getenv("VKX_PZ_SIGMAS") ? atof(getenv("VKX_PZ_SIGMAS")) : kSigmas;
     std::vector<PzBlock> plan((size_t)n_blk);
     std::vector<PzSuper> supers;
     double total_m = 0.0, total_v = 0.0;
@@ -616,7 +616,7 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
         int max_band = 0, last_W = 1;
         long long j = s0;
         for (; j < n_blk && j - s0 < kMaxBlocks; j++) {
-            const int H = j == s0 ? 0 : (int)ceil(kSigmas * sqrt(cv)) + 3;
+            const int H = j == s0 ? 0 : (int)ceil(sigmas * sqrt(cv)) + 3;
             const int W = 2 * H + 1;
             const int span = (int)ceil((double)bmean[j] + kSigmas * sqrt((double)bvar[j])) + 24;
             const int band = W + span;
@@ -633,7 +633,7 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
             cv += bvar[j];
         }
         S.n_blocks = (int)(j - s0);
-        const int H = (int)ceil(kSigmas * sqrt(cv)) + 3;
+        const int H = (int)ceil(sigmas * sqrt(cv)) + 3;
         S.end_lo_rel = (int)llround(cm) - H;
         S.end_W = 2 * H + 1;
         S.chunk_blocks = std::max(1, (kChainCap - 8) / (last_W + 1));
