@@ -9,8 +9,10 @@ struct CoordMap {      // cv.remap: coordinates come from two float planes
     const float *mx, *my;
     ptrdiff_t stride;
     struct Column {};
+    struct Rows {};
     __device__ __forceinline__ Column column(int) const { return Column(); }
-    __device__ __forceinline__ void at(const Column &, int x, int y, int &X, int &Y) const { (*this)(x, y, X, Y); }
+    __device__ __forceinline__ Rows rows(int, int) const { return Rows(); }
+    __device__ __forceinline__ void at(const Column &, const Rows &, int, int x, int y, int &X, int &Y) const { (*this)(x, y, X, Y); }
     __device__ __forceinline__ void operator()(int x, int y, int &X, int &Y) const
     {
         X = vkd::cv_round(mx[(ptrdiff_t)y * stride + x] * 32.f);
@@ -27,12 +29,18 @@ struct CoordAffine {   // warpAffine: inverse matrix, AB_BITS = 10 fixed point
     {
         return Column{vkd::cv_round(m[0] * x * 1024), vkd::cv_round(m[3] * x * 1024)};
     }
-    __device__ __forceinline__ void at(const Column &c, int, int y, int &X, int &Y) const
+    // X0 / Y0 of cv::warpAffine depend on the row only: lane r of the wavefront computes those of row y0 + r (one double
+    // evaluation per wavefront instead of one per row), every lane reads them back with v_readlane
+    struct Rows { int X0, Y0; };
+    __device__ __forceinline__ Rows rows(int y0, int lane) const
     {
-        const int X0 = vkd::cv_round((m[1] * y + m[2]) * 1024) + 16;
-        const int Y0 = vkd::cv_round((m[4] * y + m[5]) * 1024) + 16;
-        X = (X0 + c.adelta) >> 5;
-        Y = (Y0 + c.bdelta) >> 5;
+        const int y = y0 + (lane & 7);
+        return Rows{vkd::cv_round((m[1] * y + m[2]) * 1024) + 16, vkd::cv_round((m[4] * y + m[5]) * 1024) + 16};
+    }
+    __device__ __forceinline__ void at(const Column &c, const Rows &r, int rr, int, int, int &X, int &Y) const
+    {
+        X = (__builtin_amdgcn_readlane(r.X0, rr) + c.adelta) >> 5;
+        Y = (__builtin_amdgcn_readlane(r.Y0, rr) + c.bdelta) >> 5;
     }
     __device__ __forceinline__ void operator()(int x, int y, int &X, int &Y) const
     {
@@ -49,8 +57,10 @@ struct CoordPerspective { // warpPerspective: inverse matrix, per pixel in doubl
     double m[9];
     int bw0;
     struct Column {};
+    struct Rows {};
     __device__ __forceinline__ Column column(int) const { return Column(); }
-    __device__ __forceinline__ void at(const Column &, int x, int y, int &X, int &Y) const { (*this)(x, y, X, Y); }
+    __device__ __forceinline__ Rows rows(int, int) const { return Rows(); }
+    __device__ __forceinline__ void at(const Column &, const Rows &, int, int x, int y, int &X, int &Y) const { (*this)(x, y, X, Y); }
     __device__ __forceinline__ void operator()(int x, int y, int &X, int &Y) const
     {
         const int xb = (x / bw0) * bw0, x1 = x - xb;
@@ -87,37 +97,54 @@ __global__ void __launch_bounds__(256) k_sample_u8(const uint8_t *__restrict__ s
         const int lane = threadIdx.x;
         const bool active = x < dw;
         const typename Coord::Column col = coord.column(x);
+        const int y0 = (blockIdx.y * 4 + threadIdx.y) * kRgbRows;
+        if (y0 >= dh) return;                   // uniform over the wavefront
+        const typename Coord::Rows rws = coord.rows(y0, lane);
+        // all rows' coordinates and tap loads first (eight 8-byte loads in flight per lane), the arithmetic after
+        int Xs[kRgbRows], Ys[kRgbRows];
+        unsigned long long ta[kRgbRows], tb[kRgbRows];
+        bool inside[kRgbRows];
+#pragma unroll
         for (int rr = 0; rr < kRgbRows; rr++) {
-            const int yy = (blockIdx.y * 4 + threadIdx.y) * kRgbRows + rr;
+            const int yy = min(y0 + rr, dh - 1);
+            Xs[rr] = Ys[rr] = 0;
+            if (active) coord.at(col, rws, rr, x, yy, Xs[rr], Ys[rr]);
+            const int sx = Xs[rr] >> 5, sy = Ys[rr] >> 5;
+            inside[rr] = active && (unsigned)sx < (unsigned)max(sw - 2, 0) && (unsigned)sy < (unsigned)(sh - 1);
+            ta[rr] = tb[rr] = 0;
+            if (inside[rr]) {
+                const uint8_t *q = src + (ptrdiff_t)sy * sstride + (ptrdiff_t)sx * 3;   // 3 sx + 8 <= 3 sw
+                ta[rr] = *(const u64_u1 *)q;
+                tb[rr] = *(const u64_u1 *)(q + sstride);
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < kRgbRows; rr++) {
+            const int yy = y0 + rr;
             if (yy >= dh) break;                // uniform over the wavefront
             uint32_t P = 0;                     // r | g << 8 | b << 16
-            if (active) {
-                int X, Y;
-                coord.at(col, x, yy, X, Y);
-                const int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
-                if ((unsigned)sx < (unsigned)max(sw - 2, 0) && (unsigned)sy < (unsigned)(sh - 1)) {
-                    const uint8_t *q = src + (ptrdiff_t)sy * sstride + (ptrdiff_t)sx * 3;   // 3 sx + 8 <= 3 sw
-                    const unsigned long long ta = *(const u64_u1 *)q, tb = *(const u64_u1 *)(q + sstride);
-                    const uint32_t wx = (uint32_t)(32 - fx) | ((uint32_t)fx << 24);
-                    const uint32_t t0 = (uint32_t)ta, t1 = (uint32_t)(ta >> 32), b0 = (uint32_t)tb, b1 = (uint32_t)(tb >> 32);
-                    const uint32_t ar = __builtin_amdgcn_udot4(t0, wx, 0u, false);
-                    const uint32_t ag = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t1, t0, 1), wx, 0u, false);
-                    const uint32_t ab = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t1, t0, 2), wx, 0u, false);
-                    const uint32_t br = __builtin_amdgcn_udot4(b0, wx, 0u, false);
-                    const uint32_t bg = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b1, b0, 1), wx, 0u, false);
-                    const uint32_t bb = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b1, b0, 2), wx, 0u, false);
-                    const uint32_t wy0 = (uint32_t)(32 - fy), wy1 = (uint32_t)fy;
-                    const uint32_t r = (__umul24(br, wy1) + __umul24(ar, wy0) + 512u) >> 10;
-                    const uint32_t g = (__umul24(bg, wy1) + __umul24(ag, wy0) + 512u) >> 10;
-                    const uint32_t b = (__umul24(bb, wy1) + __umul24(ab, wy0) + 512u) >> 10;
-                    P = r | (g << 8) | (b << 16);
-                } else {
-                    uint8_t px[3];
-                    vkd::sample_u8<3>(src, sh, sw, sstride, X, Y, px);
-                    P = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);
-                }
+            if (inside[rr]) {
+                const int fx = Xs[rr] & 31, fy = Ys[rr] & 31;
+                const uint32_t wx = (uint32_t)(32 - fx) | ((uint32_t)fx << 24);
+                const uint32_t t0 = (uint32_t)ta[rr], t1 = (uint32_t)(ta[rr] >> 32), b0 = (uint32_t)tb[rr], b1 = (uint32_t)(tb[rr] >> 32);
+                const uint32_t ar = __builtin_amdgcn_udot4(t0, wx, 0u, false);
+                const uint32_t ag = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t1, t0, 1), wx, 0u, false);
+                const uint32_t ab = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t1, t0, 2), wx, 0u, false);
+                const uint32_t wy0 = (uint32_t)(32 - fy), wy1 = (uint32_t)fy;
+                const uint32_t br = __builtin_amdgcn_udot4(b0, wx, 0u, false);
+                const uint32_t bg = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b1, b0, 1), wx, 0u, false);
+                const uint32_t bb = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b1, b0, 2), wx, 0u, false);
+                const uint32_t r = (__umul24(br, wy1) + __umul24(ar, wy0) + 512u) >> 10;
+                const uint32_t g = (__umul24(bg, wy1) + __umul24(ag, wy0) + 512u) >> 10;
+                const uint32_t b = (__umul24(bb, wy1) + __umul24(ab, wy0) + 512u) >> 10;
+                P = r | (g << 8) | (b << 16);
+            } else if (active) {
+                uint8_t px[3];
+                vkd::sample_u8<3>(src, sh, sw, sstride, Xs[rr], Ys[rr], px);
+                P = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);
             }
-            const uint32_t Pn = (uint32_t)__builtin_amdgcn_ds_bpermute(min(lane + 1, 63) << 2, (int)P);
+            // lane 63 (x & 3 == 3) never uses its neighbour's pixel
+            const uint32_t Pn = (uint32_t)__builtin_amdgcn_mov_dpp((int)P, 0x130 /* wave_shl:1: from lane + 1 */, 0xf, 0xf, true);
             if (!active) continue;
             uint8_t *drow = dst + (ptrdiff_t)yy * dstride;
             const int m = x & 3;
