@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256) k_resize_cubic_u8(const uint8_t *__restri
             unsigned hsum = 0; // int32 with wrap, like the int accumulators of the reference implementation
 #pragma unroll
             for (int j = 0; j < 4; j++) hsum += (unsigned)((int)row[sx[j] + c] * ax[j]);
-            acc[c] += hsum * (unsigned)b;
+            acc[c] += (unsigned)__mul24((int)hsum, b);      // |hsum| < 2^20: same low 32 bits as the 32-bit product
         }
     }
     uint8_t *out = dst + (ptrdiff_t)dy * dstride + (ptrdiff_t)dx * CN;
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(256) k_resize_lanczos4_u8(const uint8_t *__res
             unsigned hsum = 0;
 #pragma unroll
             for (int j = 0; j < 8; j++) hsum += (unsigned)((int)row[sx[j] + c] * ax[j]);
-            acc[c] += hsum * (unsigned)b;
+            acc[c] += (unsigned)__mul24((int)hsum, b);      // |hsum| < 2^20: same low 32 bits as the 32-bit product
         }
     }
     uint8_t *out = dst + (ptrdiff_t)dy * dstride + (ptrdiff_t)dx * CN;
@@ -660,13 +660,13 @@ int resize_area(vkx_ctx *ctx, const void *src, int sh, int sw, int cn, ptrdiff_t
 // need more than kSepRows source rows (a shrink by more than ~2x) is left to the direct kernels.
 constexpr int kSepTileW = 64, kSepTileH = 16, kSepRows = 40;
 
-template <typename T, typename CT, typename AT, int CN, int KS>
+template <typename T, typename CT, typename AT, int CN, int KS, int ROWS = kSepRows>
 __global__ void __launch_bounds__(256) k_resize_sep(const T *__restrict__ src, int sh, int sw, ptrdiff_t sstride,
                                                     T *__restrict__ dst, int dh, int dw, ptrdiff_t dstride,
                                                     const int *__restrict__ xofs, const CT *__restrict__ xa,
                                                     const int *__restrict__ yofs, const CT *__restrict__ yb)
 {
-    __shared__ AT hbuf[kSepRows * kSepTileW * CN];
+    __shared__ AT hbuf[ROWS * kSepTileW * CN];      // ROWS: 40, or 24 when no tile needs more (twice the workgroups per CU)
     constexpr int LEFT = KS / 2 - 1;          // taps s - LEFT .. s + KS / 2
     const int x0 = blockIdx.x * kSepTileW, y0 = blockIdx.y * kSepTileH;
     const int ylast = min(y0 + kSepTileH, dh) - 1;
@@ -684,33 +684,48 @@ __global__ void __launch_bounds__(256) k_resize_sep(const T *__restrict__ src, i
             const bool whole = s0 >= 0 && s0 + KS <= sw;
             constexpr int NB = KS * CN, ND = (NB + 3) / 4;
             typedef uint32_t u32_unaligned __attribute__((aligned(1)));
-            for (int r = threadIdx.x >> 6; r < nrows; r += 4) {
-                const uint8_t *row = (const uint8_t *)src + (ptrdiff_t)(rmin + r) * sstride;
-                int hsum[CN];
+            // (the last dword may reach up to 3 bytes past the taps: only inside the row, never past the plane)
+            const bool fast = whole && (ptrdiff_t)(s0 * CN + ND * 4) <= (ptrdiff_t)sw * CN;
+            // The rows of a wavefront in batches of kBatch: all tap loads of a batch are issued before the first sum -- the tile used
+            // to pay one memory round trip per source row (five in a row for a 1.05 x cubic: the kernel ran at the latency of its
+            // loads, 13 % of the HBM roofline).
+            constexpr int kBatch = 5;
+            for (int rb = threadIdx.x >> 6; rb < nrows; rb += 4 * kBatch) {
+                uint32_t w[kBatch][ND];
 #pragma unroll
-                for (int c = 0; c < CN; c++) hsum[c] = 0;
-                // (the last dword may reach up to 3 bytes past the taps: only inside the row, never past the plane)
-                if (whole && (ptrdiff_t)(s0 * CN + ND * 4) <= (ptrdiff_t)sw * CN) {
-                    uint32_t w[ND];
+                for (int u = 0; u < kBatch; u++) {
+                    const int r = min(rb + 4 * u, nrows - 1);
+                    const uint8_t *row = (const uint8_t *)src + (ptrdiff_t)(rmin + r) * sstride;
 #pragma unroll
-                    for (int q = 0; q < ND; q++) w[q] = *(const u32_unaligned *)(row + (ptrdiff_t)s0 * CN + 4 * q);
-#pragma unroll
-                    for (int j = 0; j < KS; j++)
-#pragma unroll
-                        for (int c = 0; c < CN; c++) {
-                            const int b = j * CN + c;
-                            hsum[c] += (int)((w[b >> 2] >> (8 * (b & 3))) & 0xffu) * a[j];
-                        }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < KS; j++) {
-                        const int sx = clip_index(s0 + j, sw) * CN;
-#pragma unroll
-                        for (int c = 0; c < CN; c++) hsum[c] += (int)row[sx + c] * a[j];
-                    }
+                    for (int q = 0; q < ND; q++) w[u][q] = fast ? *(const u32_unaligned *)(row + (ptrdiff_t)s0 * CN + 4 * q) : 0u;
                 }
 #pragma unroll
-                for (int c = 0; c < CN; c++) hbuf[(r * kSepTileW + hx) * CN + c] = (AT)hsum[c];
+                for (int u = 0; u < kBatch; u++) {
+                    const int r = rb + 4 * u;
+                    if (r >= nrows) break;
+                    int hsum[CN];
+#pragma unroll
+                    for (int c = 0; c < CN; c++) hsum[c] = 0;
+                    if (fast) {
+#pragma unroll
+                        for (int j = 0; j < KS; j++)
+#pragma unroll
+                            for (int c = 0; c < CN; c++) {
+                                const int bb = j * CN + c;
+                                hsum[c] += (int)((w[u][bb >> 2] >> (8 * (bb & 3))) & 0xffu) * a[j];
+                            }
+                    } else {
+                        const uint8_t *row = (const uint8_t *)src + (ptrdiff_t)(rmin + r) * sstride;
+#pragma unroll
+                        for (int j = 0; j < KS; j++) {
+                            const int sx = clip_index(s0 + j, sw) * CN;
+#pragma unroll
+                            for (int c = 0; c < CN; c++) hsum[c] += (int)row[sx + c] * a[j];
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < CN; c++) hbuf[(r * kSepTileW + hx) * CN + c] = (AT)hsum[c];
+                }
             }
         }
     } else {
@@ -751,7 +766,7 @@ __global__ void __launch_bounds__(256) k_resize_sep(const T *__restrict__ src, i
                 const AT *h = hbuf + ((clip_index(t0 + k, sh) - rmin) * kSepTileW + lx) * 3;
                 const int b = (int)yb[y * KS + k];
 #pragma unroll
-                for (int c = 0; c < 3; c++) acc[c] += (int)h[c] * b;
+                for (int c = 0; c < 3; c++) acc[c] += __mul24((int)h[c], b);      // |h| < 2^20 (255 x the taps' |coefficients|): the 24-bit multiply is the 32-bit one, at full rate
             }
             uint32_t P = 0;
 #pragma unroll
@@ -783,7 +798,7 @@ __global__ void __launch_bounds__(256) k_resize_sep(const T *__restrict__ src, i
 #pragma unroll
             for (int c = 0; c < CN; c++) {
                 if constexpr (sizeof(T) == 1) {
-                    const AT term = h[c] * (AT)(int)b;
+                    const AT term = (AT)__mul24((int)h[c], (int)b);
                     acc[c] = k == 0 ? term : acc[c] + term;
                 } else {
                     const AT term = h[c] * b;
@@ -805,24 +820,36 @@ __global__ void __launch_bounds__(256) k_resize_sep(const T *__restrict__ src, i
 }
 
 // can every 16-row destination tile keep its source rows in LDS?
-bool separable_fits(const std::vector<int> &yofs, int sh, int dh, int ks)
+// the most source rows a tile of the separable form needs; 0: more than kSepRows somewhere (the direct kernels take the call)
+int separable_rows(const std::vector<int> &yofs, int sh, int dh, int ks)
 {
     static const bool force_direct = getenv("VKX_RESIZE_DIRECT") != nullptr;   // parity aid: the two forms must agree
-    if (force_direct) return false;
+    if (force_direct) return 0;
     const int left = ks / 2 - 1;
     auto clip = [sh](int v) { return v < 0 ? 0 : (v >= sh ? sh - 1 : v); };
+    int most = 1;
     for (int y0 = 0; y0 < dh; y0 += kSepTileH) {
         const int ylast = std::min(y0 + kSepTileH, dh) - 1;
-        if (clip(yofs[ylast] + ks / 2) - clip(yofs[y0] - left) + 1 > kSepRows) return false;
+        most = std::max(most, clip(yofs[ylast] + ks / 2) - clip(yofs[y0] - left) + 1);
     }
-    return true;
+    return most > kSepRows ? 0 : most;
 }
+bool separable_fits(const std::vector<int> &yofs, int sh, int dh, int ks) { return separable_rows(yofs, sh, dh, ks) != 0; }
+constexpr int kSepRowsSmall = 24;
 
 template <int KS>
 void launch_sep_u8(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_t sstride, uint8_t *dst, int dh, int dw,
-                   ptrdiff_t dstride, const int *xofs, const short *xa, const int *yofs, const short *yb)
+                   ptrdiff_t dstride, const int *xofs, const short *xa, const int *yofs, const short *yb, int rows = kSepRows)
 {
     dim3 grid(vkx_blocks(dw, kSepTileW), vkx_blocks(dh, kSepTileH));
+    if (rows <= kSepRowsSmall) {
+        switch (cn) {
+        case 1: k_resize_sep<uint8_t, short, unsigned, 1, KS, kSepRowsSmall><<<grid, 256, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, xofs, xa, yofs, yb); break;
+        case 3: k_resize_sep<uint8_t, short, unsigned, 3, KS, kSepRowsSmall><<<grid, 256, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, xofs, xa, yofs, yb); break;
+        default: k_resize_sep<uint8_t, short, unsigned, 4, KS, kSepRowsSmall><<<grid, 256, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, xofs, xa, yofs, yb); break;
+        }
+        return;
+    }
     switch (cn) {
     case 1: k_resize_sep<uint8_t, short, unsigned, 1, KS><<<grid, 256, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, xofs, xa, yofs, yb); break;
     case 3: k_resize_sep<uint8_t, short, unsigned, 3, KS><<<grid, 256, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, xofs, xa, yofs, yb); break;
@@ -900,8 +927,8 @@ VKX_EXPORT int vkx_resize_cubic_u8_dev(vkx_ctx *ctx, const uint8_t *src, int sh,
     if (rc) return rc;
     dim3 grid(vkx_blocks(dw, 64), vkx_blocks(dh, 4));
     VKX_TIMED(ctx, "k_resize_cubic");
-    if (separable_fits(*yh, sh, dh, 4)) {
-        launch_sep_u8<4>(ctx, src, sh, sw, cn, src_stride, dst, dh, dw, dst_stride, xofs, (const short *)xa, yofs, (const short *)yb);
+    if (const int rows = separable_rows(*yh, sh, dh, 4)) {
+        launch_sep_u8<4>(ctx, src, sh, sw, cn, src_stride, dst, dh, dw, dst_stride, xofs, (const short *)xa, yofs, (const short *)yb, rows);
         VKX_LAUNCH_CHECK();
         return VKX_OK;
     }
@@ -968,8 +995,8 @@ VKX_EXPORT int vkx_resize_u8_dev(vkx_ctx *ctx, const uint8_t *src, int sh, int s
         int rc = resize_tables(ctx, 8, true, sh, sw, dh, dw, &xofs, &xa, &yofs, &yb, &yh);
         if (rc) return rc;
         VKX_TIMED(ctx, "k_resize_lanczos4");
-        if (separable_fits(*yh, sh, dh, 8)) {
-            launch_sep_u8<8>(ctx, src, sh, sw, cn, src_stride, dst, dh, dw, dst_stride, xofs, (const short *)xa, yofs, (const short *)yb);
+        if (const int rows = separable_rows(*yh, sh, dh, 8)) {
+            launch_sep_u8<8>(ctx, src, sh, sw, cn, src_stride, dst, dh, dw, dst_stride, xofs, (const short *)xa, yofs, (const short *)yb, rows);
             VKX_LAUNCH_CHECK();
             return VKX_OK;
         }
