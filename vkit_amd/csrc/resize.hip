@@ -672,6 +672,17 @@ __global__ void __launch_bounds__(256) k_resize_sep(const T *__restrict__ src, i
     const int ylast = min(y0 + kSepTileH, dh) - 1;
     const int rmin = clip_index(yofs[y0] - LEFT, sh), rmax = clip_index(yofs[ylast] + KS / 2, sh);
     const int nrows = rmax - rmin + 1;
+    // the vertical pass's row offsets and coefficients (wave-uniform) are fetched now: their latency hides under the horizontal pass
+    const int wave0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int vt0[kSepTileH / 4];
+    CT vb[kSepTileH / 4][KS];
+#pragma unroll
+    for (int i = 0; i < kSepTileH / 4; i++) {
+        const int y = min(y0 + wave0 + 4 * i, dh - 1);
+        vt0[i] = yofs[y] - LEFT;
+#pragma unroll
+        for (int k = 0; k < KS; k++) vb[i][k] = yb[y * KS + k];
+    }
     if constexpr (sizeof(T) == 1) {
         // uint8: a thread keeps its column -- tap offset and the KS coefficients are loaded once, not once per source row --
         // and, when no tap is clipped, fetches the KS x CN consecutive source bytes of a row as whole dwords
@@ -758,13 +769,16 @@ __global__ void __launch_bounds__(256) k_resize_sep(const T *__restrict__ src, i
         typedef uint32_t u32_unaligned __attribute__((aligned(1)));
         const int tw = min(kSepTileW, dw - x0), full4 = (tw >> 2) << 2;
         const int right4 = min(lx + 1, 63) << 2;
-        for (int y = y0 + wave; y <= ylast; y += 4) {
-            const int t0 = yofs[y] - LEFT;
+#pragma unroll
+        for (int i = 0; i < kSepTileH / 4; i++) {
+            const int y = y0 + wave + 4 * i;
+            if (y > ylast) break;
+            const int t0 = vt0[i];
             int acc[3] = {0, 0, 0};
 #pragma unroll
             for (int k = 0; k < KS; k++) {
                 const AT *h = hbuf + ((clip_index(t0 + k, sh) - rmin) * kSepTileW + lx) * 3;
-                const int b = (int)yb[y * KS + k];
+                const int b = (int)vb[i][k];
 #pragma unroll
                 for (int c = 0; c < 3; c++) acc[c] += __mul24((int)h[c], b);      // |h| < 2^20 (255 x the taps' |coefficients|): the 24-bit multiply is the 32-bit one, at full rate
             }
@@ -788,13 +802,16 @@ __global__ void __launch_bounds__(256) k_resize_sep(const T *__restrict__ src, i
         return;
     }
     if (dx >= dw) return;
-    for (int y = y0 + wave; y <= ylast; y += 4) {
-        const int t0 = yofs[y] - LEFT;
+#pragma unroll
+    for (int i = 0; i < kSepTileH / 4; i++) {
+        const int y = y0 + wave + 4 * i;
+        if (y > ylast) break;
+        const int t0 = vt0[i];
         AT acc[CN];
 #pragma unroll
         for (int k = 0; k < KS; k++) {
             const AT *h = hbuf + ((clip_index(t0 + k, sh) - rmin) * kSepTileW + lx) * CN;
-            const CT b = yb[y * KS + k];
+            const CT b = vb[i][k];
 #pragma unroll
             for (int c = 0; c < CN; c++) {
                 if constexpr (sizeof(T) == 1) {
