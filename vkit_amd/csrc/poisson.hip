@@ -11,12 +11,12 @@
 //                their prefix sums into SUPERBLOCKS of <= 256 blocks and, per block, the WINDOW of stream positions its first element
 //                can start at: predicted position +- 6 sigma, relative to the exact start of the superblock;
 //   k_pz_raw     the raw stream as doubles (next_double), positions 0 .. M;
-//   per superblock, in stream order (its exact start is the previous one's result, on the device):
-//   k_pz_cand    one workgroup per block: the outcome of EVERY (element, position) state of the block's band evaluated once into LDS
-//                (PTRS: accept / reject of the attempt that starts there; lam < 10: the draws the element takes from there), then one
-//                lane per candidate start walks the 32 elements through that table: E[block][candidate] = where the next block starts;
-//   k_pz_chain   one workgroup follows the exact start through the E rows (staged through LDS): the exact start of every block and of
-//                the next superblock;
+//   k_pz_super   one launch per superblock, workgroup = block: the outcome of EVERY (element, position) state of the block's band is
+//                evaluated once into LDS (PTRS: accept / reject of the attempt that starts there; lam < 10: the draws the element takes
+//                from there), then one lane per candidate start walks the 32 elements through that table: E[block][candidate] = where
+//                the next block starts; the workgroup that finishes last follows the exact start through the E rows (staged through
+//                LDS): the exact start of every block and of the next superblock.  Launches of up to three superblocks are in flight
+//                (windows relative to an earlier superblock's start; see the host code);
 //   k_pz_final   one lane per block walks its 32 elements from the exact start, now computing the values, and checks that it ends
 //                where the next block begins.
 // Every decision is numpy's: the per-lam constants, exp(-lam) and the loggam table are computed on the HOST with the same libm numpy
@@ -288,7 +288,8 @@ __device__ __forceinline__ bool pz_attempt_table(const PzLam &L, const double *_
 // __threadfence() here writes the L2 back, 25 - 40 us per workgroup.
 __global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__restrict__ src, long long n, const PzBlock *__restrict__ blocks,
                                                            int first_block, int n_blocks, int end_lo_rel, int end_W, int chunk_blocks, int e_total,
-                                                           long long *__restrict__ pos /* [0]: this superblock's start, [1]: the next one's */,
+                                                           const long long *pos_base /* the exact start the windows are relative to */,
+                                                           long long *pos_cur /* this superblock's exact start (pos_base, or published by the superblock before) */,
                                                            const double *__restrict__ draws, long long M, const PzTabs *__restrict__ T,
                                                            uint16_t *E, long long *__restrict__ blk_pos, unsigned *counter,
                                                            int *__restrict__ fail, long long *__restrict__ probe)
@@ -302,7 +303,7 @@ __global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__rest
     __shared__ uint8_t llam[kB], rowof[kB];
     __shared__ int s_last, s_idx;
     const int tid = threadIdx.x;
-    const long long p0 = pos[0];
+    const long long p0 = *pos_base;
     PZ_STAMP(0);
     {
         const int j = first_block + blockIdx.x;
@@ -412,7 +413,19 @@ __global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__rest
     }
     if (tid == 0) {
         l_off[n_blocks] = e_total;
-        s_idx = 0;
+        // This superblock's exact start: the base itself, or (windows relative to the superblock BEFORE the previous one, so that this
+        // launch's tables ran while the previous launch was still chaining) the value that launch publishes -- a bounded wait: launches
+        // are queued in stream order, the publisher never waits for this one.
+        long long ps = p0;
+        if (pos_cur != pos_base) {
+            ps = __hip_atomic_load(pos_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int spin = 0; ps < 0 && spin < (1 << 22); spin++) {
+                __builtin_amdgcn_s_sleep(16);
+                ps = __hip_atomic_load(pos_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        const long long i0 = ps - (p0 + blocks[first_block].lo_rel);
+        s_idx = ps >= 0 && i0 >= 0 && i0 < blocks[first_block].W ? (int)i0 : -1;
     }
     __syncthreads();
     constexpr int kPer = (kChainCap * 2 / 8 + kCandThreads - 1) / kCandThreads + 1;      // 8-byte loads per thread and chunk
@@ -463,12 +476,9 @@ __global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__rest
     PZ_STAMP(5);
     for (int b = tid; b < n_blocks; b += kCandThreads) blk_pos[first_block + b] = l_idx[b] < 0 ? -1 : p0 + l_lo[b] + l_idx[b];
     if (tid == 0) {
-        if (s_idx < 0) {
-            atomicOr(fail, kFlagWindow);
-            pos[1] = p0;
-        } else {
-            pos[1] = p0 + end_lo_rel + s_idx;
-        }
+        if (s_idx < 0) atomicOr(fail, kFlagWindow);
+        // (a failed superblock publishes a start all the same: its successors must not wait for it)
+        __hip_atomic_store(pos_cur + 1, s_idx < 0 ? p0 : p0 + end_lo_rel + s_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -604,9 +614,21 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
 
     // the plan: superblocks and windows (VKX_PZ_SIGMAS: narrower windows, to exercise the WINDOW refusal in tests)
     static const double sigmas = getenv("VKX_PZ_SIGMAS") ? atof(getenv("VKX_PZ_SIGMAS")) : kSigmas;
+    // Depth 1: windows relative to the superblock's own start, launches strictly one after the other.  Depth d > 1: relative to the start
+    // of the superblock d - 1 before; launches go round d streams and the chain of one runs under the tables of the next d - 1 (the last
+    // workgroup of a launch waits for the start its predecessor publishes).  Wider windows are the price -- sqrt(d) more table states --,
+    // so dark images (the multiplication method: a variance of lam per element against PTRS's 0.7 - 1.8) stay shallow.  1024^2 RGB
+    // page: 25.3 / 17.4 / 13.9 ms at depth 1 / 2 / 3; 512^2 x 3 of lam = 9: 9.0 / 9.5 / 11.5.  VKX_PZ_DEPTH overrides.
+    static const int depth_env = getenv("VKX_PZ_DEPTH") ? std::max(1, std::min(3, atoi(getenv("VKX_PZ_DEPTH")))) : 0;
+    double var_sum = 0.0;
+    for (long long b = 0; b < n_blk; b++) var_sum += bvar[(size_t)b];
+    const double var_per_element = var_sum / (double)n;
+    const int depth = depth_env ? depth_env : (var_per_element > 7.0 ? 1 : (var_per_element > 2.5 ? 2 : 3));
+    const int max_blocks = kMaxBlocks - (depth - 1);      // CUs stay free for the workgroups still chaining
+    std::vector<std::pair<double, double>> before;         // (mean, variance) of the depth - 1 superblocks before this one
     std::vector<PzBlock> plan((size_t)n_blk);
     std::vector<PzSuper> supers;
-    double total_m = 0.0, total_v = 0.0;
+    double total_m = 0.0, total_v = 0.0, base_m = 0.0, base_v = 0.0;      // base: the superblock before (depth 2)
     long long e_max = 0;
     for (long long s0 = 0; s0 < n_blk;) {
         PzSuper S;
@@ -615,14 +637,16 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
         long long e_off = 0;
         int max_band = 0, last_W = 1;
         long long j = s0;
-        for (; j < n_blk && j - s0 < kMaxBlocks; j++) {
-            const int H = j == s0 ? 0 : (int)ceil(sigmas * sqrt(cv)) + 3;
+        for (; j < n_blk && j - s0 < max_blocks; j++) {
+            const bool exact = j == s0 && base_v == 0.0 && base_m == 0.0 && supers.empty();      // the stream's own start
+            const int H = (j == s0 && depth == 1) || exact ? 0 : (int)ceil(sigmas * sqrt(base_v + cv)) + 3;
             const int W = 2 * H + 1;
             const int span = (int)ceil((double)bmean[j] + kSigmas * sqrt((double)bvar[j])) + 24;
             const int band = W + span;
-            if (j > s0 && band > kBandMax) break;
+            // (the variance cap keeps the first window of the NEXT superblock inside the band limit)
+            if (j > s0 && (band > kBandMax || (depth > 1 && cv > 20000.0 / (depth - 1)))) break;
             PzBlock &b = plan[(size_t)j];
-            b.lo_rel = (int)llround(cm) - H;
+            b.lo_rel = (int)llround(base_m + cm) - H;
             b.W = W;
             b.band = std::min(band, kBandMax);
             b.e_off = (int)e_off;
@@ -633,8 +657,8 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
             cv += bvar[j];
         }
         S.n_blocks = (int)(j - s0);
-        const int H = (int)ceil(sigmas * sqrt(cv)) + 3;
-        S.end_lo_rel = (int)llround(cm) - H;
+        const int H = (int)ceil(sigmas * sqrt(base_v + cv)) + 3;
+        S.end_lo_rel = (int)llround(base_m + cm) - H;
         S.end_W = 2 * H + 1;
         S.chunk_blocks = std::max(1, (kChainCap - 8) / (last_W + 1));
         S.max_band = max_band;
@@ -642,11 +666,17 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
         e_max = std::max(e_max, e_off);
         total_m += cm;
         total_v += cv;
+        if (depth > 1) {
+            before.emplace_back(cm, cv);
+            if ((int)before.size() > depth - 1) before.erase(before.begin());
+            base_m = base_v = 0.0;
+            for (const auto &q : before) { base_m += q.first; base_v += q.second; }
+        }
         supers.push_back(S);
         s0 = j;
     }
     const long long M = (long long)ceil(total_m + (kSigmas + 1.0) * sqrt(total_v)) + 8192;
-    if ((rc = vkx_scratch_reserve(ctx, &ctx->pz_draws, sizeof(double) * (size_t)(M + 2) + up(sizeof(uint16_t) * (size_t)e_max + 16)))) return rc;
+    if ((rc = vkx_scratch_reserve(ctx, &ctx->pz_draws, sizeof(double) * (size_t)(M + 2) + 3 * up(sizeof(uint16_t) * (size_t)e_max + 16)))) return rc;
     double *d_draws = (double *)ctx->pz_draws.ptr;
     uint16_t *d_E = (uint16_t *)((unsigned char *)ctx->pz_draws.ptr + up(sizeof(double) * (size_t)(M + 2)));
     if (probing) {
@@ -655,6 +685,7 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
         VKX_HIP(hipMemsetAsync(d_probe, 0, 64 * supers.size(), ctx->stream));
     }
     VKX_HIP(hipMemcpyAsync(d_plan, plan.data(), sizeof(PzBlock) * n_blk, hipMemcpyHostToDevice, ctx->stream));
+    VKX_HIP(hipMemsetAsync(d_pos, 0xff, sizeof(long long) * (supers.size() + 1), ctx->stream));      // -1: not published yet
     VKX_HIP(hipMemsetAsync(d_pos, 0, sizeof(long long), ctx->stream));
     VKX_HIP(hipMemsetAsync(d_reply, 0, sizeof(PzReply), ctx->stream));
     VKX_HIP(hipMemsetAsync(d_counter, 0, sizeof(unsigned) * supers.size(), ctx->stream));
@@ -668,14 +699,35 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
                                                 (uint64_t)(cT >> 64), M, d_draws);
     }
     VKX_LAUNCH_CHECK();
-    for (size_t s = 0; s < supers.size(); s++) {
-        const PzSuper &S = supers[s];
-        VKX_TIMED(ctx, "k_pz_super");
-        k_pz_super<<<S.n_blocks, kCandThreads, 0, ctx->stream>>>(src, n, d_plan, S.first_block, S.n_blocks, S.end_lo_rel, S.end_W, S.chunk_blocks,
-                                                                 (int)S.e_total, d_pos + s, d_draws, M, tabs, d_E, d_bpos, d_counter + s, &d_reply->fail,
-                                                                 d_probe ? d_probe + 8 * s : nullptr);
+    {
+        hipStream_t main_stream = ctx->stream;
+        hipStream_t lanes[3] = {main_stream, main_stream, main_stream};
+        const int n_lanes = (int)std::min<size_t>((size_t)depth, supers.size());
+        for (int k = 1; k < n_lanes; k++) {
+            lanes[k] = vkx_stream_by_id(ctx, k == 1 ? VKX_STREAM_COPY_IN : VKX_STREAM_COPY_OUT, &rc);
+            if (rc) return rc;
+            if ((rc = vkx_stream_order(ctx, lanes[k], main_stream))) return rc;
+        }
+        const size_t e_stride = up(sizeof(uint16_t) * (size_t)e_max + 16) / sizeof(uint16_t);
+        for (size_t s = 0; s < supers.size(); s++) {
+            const PzSuper &S = supers[s];
+            ctx->stream = lanes[s % (size_t)n_lanes];
+            const size_t base = s >= (size_t)(depth - 1) ? s - (size_t)(depth - 1) : 0;
+            {
+                VKX_TIMED(ctx, "k_pz_super");
+                k_pz_super<<<S.n_blocks, kCandThreads, 0, ctx->stream>>>(src, n, d_plan, S.first_block, S.n_blocks, S.end_lo_rel, S.end_W, S.chunk_blocks,
+                                                                         (int)S.e_total, d_pos + base, d_pos + s, d_draws, M, tabs, d_E + (s % 3) * e_stride,
+                                                                         d_bpos, d_counter + s, &d_reply->fail, d_probe ? d_probe + 8 * s : nullptr);
+            }
+            ctx->stream = main_stream;
+            if (hipGetLastError() != hipSuccess) {
+                vkx_set_error("k_pz_super: launch failed");
+                return VKX_ERR_HIP;
+            }
+        }
+        for (int k = 1; k < n_lanes; k++)
+            if ((rc = vkx_stream_order(ctx, main_stream, lanes[k]))) return rc;
     }
-    VKX_LAUNCH_CHECK();
     { VKX_TIMED(ctx, "k_pz_final");
       k_pz_final<<<vkx_blocks((size_t)n_blk, 64), 64, 0, ctx->stream>>>(src, n, n_blk, d_bpos, d_draws, M, tabs, dst, &d_reply->consumed, &d_reply->fail); }
     VKX_LAUNCH_CHECK();
