@@ -49,7 +49,8 @@ def _worker(rank, n_workers, pages, mode, no_poisson, barrier, queue):
     for s in range(3):
         page(10_000 * rank + s)          # warm up: library, pools, tables
     ctx.sync()
-    ctx.set_timing(True)
+    if os.environ.get('VKX_POOL_TIMING', '1') != '0':      # 0: no per-launch events (gpu_busy_share reads 0): the pages/s of an uninstrumented worker
+        ctx.set_timing(True)
     ctx.reset_timings()
     barrier.wait()
     t0 = time.time()

@@ -617,13 +617,15 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
     // Depth 1: windows relative to the superblock's own start, launches strictly one after the other.  Depth d > 1: relative to the start
     // of the superblock d - 1 before; launches go round d streams and the chain of one runs under the tables of the next d - 1 (the last
     // workgroup of a launch waits for the start its predecessor publishes).  Wider windows are the price -- sqrt(d) more table states --,
-    // so dark images (the multiplication method: a variance of lam per element against PTRS's 0.7 - 1.8) stay shallow.  1024^2 RGB
-    // page: 25.3 / 17.4 / 13.9 ms at depth 1 / 2 / 3; 512^2 x 3 of lam = 9: 9.0 / 9.5 / 11.5.  VKX_PZ_DEPTH overrides.
+    // so dark images (the multiplication method: a variance of lam per element against PTRS's 0.7 - 1.8) stay at depth 1.  1024^2 RGB
+    // page: 25.3 / 17.4 / 13.9 ms at depth 1 / 2 / 3; 512^2 x 3 of lam = 9: 9.0 / 9.5 / 11.5.  Default 2: with eight worker processes
+    // sharing the GPU (tools/pool_scale.py) depth 3's extra table work and third stream cost more than its shorter critical path
+    // gives (pipeline pages/s at 1 / 8 workers: depth 1 183 / 473, depth 2 192 / 540, depth 3 164 / 377).  VKX_PZ_DEPTH overrides.
     static const int depth_env = getenv("VKX_PZ_DEPTH") ? std::max(1, std::min(3, atoi(getenv("VKX_PZ_DEPTH")))) : 0;
     double var_sum = 0.0;
     for (long long b = 0; b < n_blk; b++) var_sum += bvar[(size_t)b];
     const double var_per_element = var_sum / (double)n;
-    const int depth = depth_env ? depth_env : (var_per_element > 7.0 ? 1 : (var_per_element > 2.5 ? 2 : 3));
+    const int depth = depth_env ? depth_env : (var_per_element > 7.0 ? 1 : 2);
     const int max_blocks = kMaxBlocks - (depth - 1);      // CUs stay free for the workgroups still chaining
     std::vector<std::pair<double, double>> before;         // (mean, variance) of the depth - 1 superblocks before this one
     std::vector<PzBlock> plan((size_t)n_blk);
