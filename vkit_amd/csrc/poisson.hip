@@ -247,7 +247,7 @@ __device__ __forceinline__ bool pz_attempt(const PzLam &L, const double *__restr
     const double rhs = -L.lam + kd * L.loglam - lg;
     if (tol == 1e-11) {
         const float usf = (float)us;
-        const float lhs_f = (__log2f((float)V) - __log2f(__fdividef((float)L.a, usf * usf) + (float)L.b)) * 0.69314718f;
+        const float lhs_f = (__log2f((float)V) - __log2f((float)L.a * __builtin_amdgcn_rcpf(usf * usf) + (float)L.b)) * 0.69314718f;
         const double d = ((double)lhs_f + L.log_invalpha) - rhs;
         if (fabs(d) > 1e-3) return d < 0.0;
     }
@@ -271,7 +271,7 @@ __device__ __forceinline__ bool pz_attempt_table(const PzLam &L, const double *_
     const int ki = (int)fmin(fmax(kd, 0.0), (double)(kKMax - 1));
     const double rhs = -L.lam + kd * L.loglam - lgam[ki + 1];
     const float usf = (float)us;
-    const float lhs_f = (__log2f((float)V) - __log2f(__fdividef((float)L.a, usf * usf) + (float)L.b)) * 0.69314718f;
+    const float lhs_f = (__log2f((float)V) - __log2f((float)L.a * __builtin_amdgcn_rcpf(usf * usf) + (float)L.b)) * 0.69314718f;
     const double d = ((double)lhs_f + L.log_invalpha) - rhs;
     bool acc = fast || (!rej && d < 0.0);
     if (!fast && !rej && (big || !(fabs(d) > 1e-3))) {
