@@ -300,8 +300,8 @@ __global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__rest
     __shared__ double lgam[kKMax + 1];
     __shared__ PzLam lL[kB];
     __shared__ int l_off[kMaxBlocks + 1], l_lo[kMaxBlocks], l_idx[kMaxBlocks];
-    __shared__ uint8_t llam[kB], rowof[kB];
-    __shared__ int s_last, s_idx;
+    __shared__ uint8_t llam[kB], rowof[kB], rowlist[kB];
+    __shared__ int s_last, s_idx, s_rows;
     const int tid = threadIdx.x;
     const long long p0 = *pos_base;
     PZ_STAMP(0);
@@ -326,30 +326,37 @@ __global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__rest
         }
         for (int o = tid; o <= kKMax; o += kCandThreads) lgam[o] = T->loggam[o];
         __syncthreads();
-        if (tid < kB) {                                           // elements of one value share a table row
+        if (tid < 64) {                                           // elements of one value share a table row
             int r = tid;
-            for (int t = tid - 1; t >= 0; t--) r = llam[t] == llam[tid] ? t : r;
-            rowof[tid] = (uint8_t)r;
+            const int mine = tid < kB ? llam[tid] : 0;
+            for (int t = min(tid, kB) - 1; t >= 0; t--) r = llam[t] == mine ? t : r;
+            if (tid < kB) rowof[tid] = (uint8_t)r;
+            const bool is_row = tid < kB && r == tid && mine != 0;
+            const unsigned long long rows_mask = __ballot(is_row);
+            if (is_row) rowlist[__popcll(rows_mask & ((1ull << tid) - 1ull))] = (uint8_t)tid;
+            if (tid == 0) s_rows = __popcll(rows_mask);
         }
         __syncthreads();
         PZ_STAMP(1);
-        for (int t = 0; t < n_el; t++) {
-            const int lam = llam[t];
-            if (lam == 0 || rowof[t] != t) continue;
-            const PzLam &L = lL[t];
-            uint8_t *row = tab + t * band;
-            if (lam >= 10) {
-                for (int o = tid; o < band; o += kCandThreads) {
+        // the states of all rows as one index space, dealt round the lanes: every wavefront gets the same number of states whatever the
+        // band's length (row by row, a band of 1 227 positions gave four of the sixteen wavefronts twice the others' work)
+        {
+            const int total = s_rows * band;
+            int k = 0, o = tid;
+            while (o >= band && k < s_rows) { o -= band; k++; }
+            for (int idx = tid; idx < total; idx += kCandThreads) {
+                const int t = rowlist[k];
+                const int lam = llam[t];
+                const PzLam &L = lL[t];
+                uint8_t code = kCodeInvalid;
+                if (lam >= 10) {
                     const double d0 = ld[o], d1 = ld[o + 1];
                     const bool acc = pz_attempt_table(L, lgam, d0, d1);
-                    row[o] = d0 >= 0.0 && d1 >= 0.0 ? (acc ? 2 : 0) : kCodeInvalid;
-                }
-            } else {
-                const double enlam = L.enlam;
-                for (int o = tid; o < band; o += kCandThreads) {
+                    code = d0 >= 0.0 && d1 >= 0.0 ? (acc ? 2 : 0) : kCodeInvalid;
+                } else {
+                    const double enlam = L.enlam;
                     double prod = 1.0;
                     int c = 0;
-                    uint8_t code = kCodeInvalid;
                     while (o + c < band + 2 && c < 250) {
                         const double d = ld[o + c];
                         if (d < 0.0) break;
@@ -360,8 +367,10 @@ __global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__rest
                             break;
                         }
                     }
-                    row[o] = code;
                 }
+                tab[t * band + o] = code;
+                o += kCandThreads;
+                while (o >= band) { o -= band; k++; }
             }
         }
         __syncthreads();
