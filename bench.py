@@ -396,8 +396,10 @@ def main():
             'C2_similarity_mls_remap_2048_batch64': _tool_json('c2.py', device_index, 180),
             'C4_page_synth_1024_64_layers_batch64': _tool_json('c4.py', device_index, 240),
             'C5_shared_grid_4096_three_elements': _tool_json('c5.py', device_index, 180),
+            'poisson_noise_1024': _tool_json('poisson_probe.py', device_index, 180, ('1024',)),
             'note': 'BASELINE.json configs[1], [3], [4] on this box and clock, device resident (tools/c2.py, c4.py, c5.py): never '
-                    'the headline value',
+                    'the headline value; poisson_noise_1024: rng.poisson(image) drawn on the device against numpy itself (values and stream '
+                    'position, tools/poisson_probe.py), host arrays in and out',
         }
 
     total_px = src_px * world * args.steps

@@ -12,7 +12,7 @@ from numpy.random import default_rng
 from vkit_amd import _native as N
 
 SIZE = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-ctx = N.default_ctx()
+ctx = N.Context(int(os.environ['VKX_DEVICE'])) if 'VKX_DEVICE' in os.environ else N.default_ctx()
 
 
 def cases():
@@ -39,10 +39,10 @@ for name, img in cases():
     t0 = time.perf_counter()
     want = np.clip(r_np.poisson(img.astype(np.float32)), 0, 255).astype(np.uint8)
     t_np = time.perf_counter() - t0
-    N.np_poisson_u8(img, default_rng(5))      # warm-up: tables, scratch
+    N.np_poisson_u8(img, default_rng(5), ctx=ctx)      # warm-up: tables, scratch
     ctx.set_timing(True); ctx.reset_timings()
     t0 = time.perf_counter()
-    got = N.np_poisson_u8(img, r_dev)
+    got = N.np_poisson_u8(img, r_dev, ctx=ctx)
     t_dev = time.perf_counter() - t0
     k = ctx.timings(); ctx.set_timing(False)
     row = {'case': name, 'n': int(img.size), 'flags': N.np_poisson_flags, 'numpy_ms': round(t_np * 1e3, 2), 'device_ms': round(t_dev * 1e3, 2)}
@@ -56,3 +56,6 @@ for name, img in cases():
     print(json.dumps(row), flush=True)
 ok = all(r.get('equal') and r.get('stream_equal') for r in rows)
 print('ALL EQUAL' if ok else 'MISMATCH')
+# last line: the summary bench.py's other_configs takes
+print(json.dumps({'rng_poisson_on_device': {r['case']: {'n': r['n'], 'numpy_ms': r['numpy_ms'], 'device_ms': r['device_ms'], 'equal_to_numpy': bool(r.get('equal') and r.get('stream_equal'))}
+                                            for r in rows if not r['case'].startswith('n=')}, 'all_equal': ok}))
