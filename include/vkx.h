@@ -561,6 +561,7 @@ int vkx_np_draw(vkx_ctx *ctx, const vkx_np_job *job, vkx_np_result *result_host)
 #define VKX_NP_POISSON_WINDOW 4u
 #define VKX_NP_POISSON_MISMATCH 8u
 #define VKX_NP_POISSON_DRAWS 16u
+#define VKX_NP_POISSON_SIZE 32u   /* the stream would take more than 2^29 raw draws (4 GB of scratch) */
 int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const uint64_t *inc, const uint8_t *src, long long n, uint8_t *dst,
                           long long *consumed_host, unsigned *flags_host);
 int vkx_np_poisson_u8(vkx_ctx *ctx, const uint64_t *state, const uint64_t *inc, const uint8_t *src_host, long long n, uint8_t *dst_host,

@@ -46,7 +46,7 @@ constexpr int kKMax = 1024;         // loggam table: k + 1 <= kKMax
 constexpr double kSigmas = 6.0;
 constexpr int kCandThreads = 1024;
 
-enum { kFlagAmbiguous = 1, kFlagTable = 2, kFlagWindow = 4, kFlagMismatch = 8, kFlagDraws = 16 };
+enum { kFlagAmbiguous = 1, kFlagTable = 2, kFlagWindow = 4, kFlagMismatch = 8, kFlagDraws = 16, kFlagSize = 32 };
 
 struct PzLam {                      // one per lam = 0 .. 255 (random_poisson_ptrs' locals; enlam of random_poisson_mult)
     double enlam, b, a, a2, vr, log_invalpha, loglam, lam;
@@ -687,6 +687,11 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
         s0 = j;
     }
     const long long M = (long long)ceil(total_m + (kSigmas + 1.0) * sqrt(total_v)) + 8192;
+    if (M > (1ll << 29)) {          // more than 4 GB of raw draws: declined (the caller draws with numpy)
+        *consumed_host = 0;
+        *flags_host = kFlagSize;
+        return VKX_OK;
+    }
     if ((rc = vkx_scratch_reserve(ctx, &ctx->pz_draws, sizeof(double) * (size_t)(M + 2) + 3 * up(sizeof(uint16_t) * (size_t)e_max + 16)))) return rc;
     double *d_draws = (double *)ctx->pz_draws.ptr;
     uint16_t *d_E = (uint16_t *)((unsigned char *)ctx->pz_draws.ptr + up(sizeof(double) * (size_t)(M + 2)));
