@@ -343,25 +343,47 @@ __global__ void __launch_bounds__(256) k_hsv(const uint8_t *__restrict__ src, in
 }
 
 // RGB2HLS_f / HLS2RGB_f through the 8-bit wrappers (color_hsv.simd.hpp, scalar path), hrange 256, no FMA.
+// a / b correctly rounded for NORMAL operands whose quotient is normal too (here: 1/255 <= b <= 2, 0 < a <= 60): the core of the
+// sequence the compiler emits for an IEEE float32 division -- reciprocal, one Newton step, quotient, two residual corrections --
+// without the operand scaling and the special-case fix-up, which these ranges never need (tests/test_gpu_hls_exhaustive.py runs all
+// 2^24 colours against the oracle's plain division).
+__device__ __forceinline__ float div_normal(float a, float b)
+{
+    float y = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, y, 1.0f);
+    y = __builtin_fmaf(e, y, y);
+    float q = a * y;
+    const float r = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(r, y, q);
+    const float r2 = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(r2, y, q);
+}
+
+// cvRound of a value known to lie within int32: round half to even
+__device__ __forceinline__ int round_small(float v) { return __float2int_rn(v); }
+
 __device__ __forceinline__ void rgb2hls_px(int R, int G, int B, int &H, int &L, int &S)
 {
     const float r = R * (1.f / 255.f), g = G * (1.f / 255.f), b = B * (1.f / 255.f);
     float h = 0.f, s = 0.f;
     const float vmax = fmaxf(r, fmaxf(g, b)), vmin = fminf(r, fminf(g, b));
     float diff = vmax - vmin;
-    const float l = (vmax + vmin) * 0.5f;
+    const float sum = vmax + vmin;
+    const float l = sum * 0.5f;
     if (diff > FLT_EPSILON) {
-        s = l < 0.5f ? diff / (vmax + vmin) : diff / (2 - vmax - vmin);
-        diff = 60.f / diff;
+        // one division serves both branches of s: the denominator is selected first (2 - vmax - vmin rounds as the reference's)
+        const float den = l < 0.5f ? sum : (2 - vmax - vmin);
+        s = div_normal(diff, den);
+        diff = div_normal(60.f, diff);
         if (vmax == r) h = (g - b) * diff;
         else if (vmax == g) h = (b - r) * diff + 120.f;
         else h = (r - g) * diff + 240.f;
         if (h < 0.f) h += 360.f;
     }
     const float hscale = 256.f / 360.f;
-    H = vkd::clamp_u8(vkd::cv_round(h * hscale));
-    L = vkd::clamp_u8(vkd::cv_round(l * 255.f));
-    S = vkd::clamp_u8(vkd::cv_round(s * 255.f));
+    H = min(round_small(h * hscale), 255);      // 0 <= h < 360 + ulps: only the upper clamp can act
+    L = round_small(l * 255.f);                 // 0 <= l, s <= 1 (s up to an ulp above): the rounded product is 0 .. 255
+    S = min(round_small(s * 255.f), 255);
 }
 
 __device__ __forceinline__ void hls2rgb_px(int H, int L, int S, int &R, int &G, int &B)
@@ -374,21 +396,22 @@ __device__ __forceinline__ void hls2rgb_px(int H, int L, int S, int &R, int &G, 
         const float p2 = l <= 0.5f ? l * (1 + s) : l + s - l * s;
         const float p1 = 2 * l - p2;
         h *= hscale;               // 0 <= h < 6 for every 8-bit hue
-        const int sector = (int)floorf(h);
-        h -= sector;
-        const float t0 = p2, t1 = p1, t2 = p1 + (p2 - p1) * (1 - h), t3 = p1 + (p2 - p1) * h;
-        switch (sector) {          // sector_data (b, g, r), the table of the HSV inverse
-        case 0: b = t1; g = t3; r = t0; break;
-        case 1: b = t1; g = t0; r = t2; break;
-        case 2: b = t3; g = t0; r = t1; break;
-        case 3: b = t0; g = t2; r = t1; break;
-        case 4: b = t0; g = t1; r = t3; break;
-        default: b = t2; g = t1; r = t0; break;
-        }
+        const int sector = (int)h; // h >= 0: truncation is the floor
+        h -= (float)sector;
+        // sector_data (b, g, r), the table of the HSV inverse: 0 (t1,t3,t0) 1 (t1,t0,t2) 2 (t3,t0,t1) 3 (t0,t2,t1) 4 (t0,t1,t3) 5 (t2,t1,t0)
+        // = (t1, odd ? t0 : t3, odd ? t2 : t0) rotated by sector / 2; t2 = p1 + (p2 - p1)(1 - h) serves the odd sectors only, t3 the even
+        const bool odd = sector & 1;
+        const int rot = sector >> 1;
+        const float t0 = p2, t1 = p1, tt = p1 + (p2 - p1) * (odd ? 1 - h : h);
+        const float u0 = t1, u1 = odd ? t0 : tt, u2 = odd ? tt : t0;
+        b = rot == 0 ? u0 : (rot == 1 ? u1 : u2);
+        g = rot == 0 ? u1 : (rot == 1 ? u2 : u0);
+        r = rot == 0 ? u2 : (rot == 1 ? u0 : u1);
     }
-    R = vkd::clamp_u8(vkd::cv_round(r * 255.f));
-    G = vkd::clamp_u8(vkd::cv_round(g * 255.f));
-    B = vkd::clamp_u8(vkd::cv_round(b * 255.f));
+    // the channels lie in [0, 1] up to a few ulps: the rounded product needs the clamp only in name
+    R = vkd::clamp_u8(round_small(r * 255.f));
+    G = vkd::clamp_u8(round_small(g * 255.f));
+    B = vkd::clamp_u8(round_small(b * 255.f));
 }
 
 // RGB2Gray<uchar>: 15-bit fixed point
