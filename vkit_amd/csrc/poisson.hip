@@ -31,6 +31,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -589,11 +590,8 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
     // scratch: tables | block stats | block plan | positions | reply
     if (!ctx->pz_tabs_ready) {
         static PzTabs host_tabs;
-        static bool host_ready = false;
-        if (!host_ready) {
-            build_tabs(host_tabs);
-            host_ready = true;
-        }
+        static std::once_flag host_once;              // contexts of several threads may get here together
+        std::call_once(host_once, [] { build_tabs(host_tabs); });
         if ((rc = vkx_scratch_reserve(ctx, &ctx->pz_tabs, sizeof(PzTabs)))) return rc;
         VKX_HIP(hipMemcpyAsync(ctx->pz_tabs.ptr, &host_tabs, sizeof(PzTabs), hipMemcpyHostToDevice, ctx->stream));
         ctx->pz_tabs_ready = true;
