@@ -569,6 +569,17 @@ int vkx_np_poisson_u8(vkx_ctx *ctx, const uint64_t *state, const uint64_t *inc, 
 /* out[x - 1] = numpy's random_loggam(x), x = 1 .. n, as the library tabulates it on the host (tests compare it with libnpyrandom.a) */
 int vkx_np_poisson_loggam_table(double *out, int n);
 
+/* The fog density field of `fog` (reference photometric/effect.py:89-216) on the device: the diamond-square lattice of
+ * generate_diamond_square_mask -- (2^levels + 1)^2 float32, field 4-byte aligned device memory whose four corners the caller drew
+ * (corners_host: [0, 0], [0, -1], [-1, -1], [-1, 0]) -- filled level by level with numpy's float32 / float64 roundings from the PCG64
+ * stream (state, inc) positioned AFTER the corner draws; noise_weight_host[l] = roughness ** l as Python computes it.
+ * *consumed_host = the raw draws taken (the caller moves its generator, then draws the crop offsets).  Asynchronous on the ctx stream.
+ * vkx_fog_stretch_f32_dev: mask float32 [h, w] = the crop (up, left) stretched like the reference: x - min, / max, * float32(span),
+ * + float32(lo).  (vkit_amd/csrc/fog.hip) */
+int vkx_fog_field_f32_dev(vkx_ctx *ctx, const uint64_t *state, const uint64_t *inc, int levels, const double *noise_weight_host,
+                          const float *corners_host, float *field, long long *consumed_host);
+int vkx_fog_stretch_f32_dev(vkx_ctx *ctx, const float *field, int size, int up, int left, int h, int w, double span, double lo, float *mask);
+
 /* ---- throughput-mode noise plane ---------------------------------------------------------------
  * gaussion_noise (photometric/noise.py:44-54) adds np.round(rng.normal(0, std, shape)) drawn from the caller's numpy
  * Generator; the parity path takes that int16 plane from the caller (vkx_add_noise_i16, vkx_chain_item.noise).

@@ -173,6 +173,8 @@ _SIGNATURES = {
     'vkx_np_tiles_expand_dev': [c_void_p, c_void_p, ctypes.c_int64, c_void_p],
     'vkx_np_draw': [c_void_p, ctypes.POINTER(VkxNpJob), ctypes.POINTER(VkxNpResult)],
     'vkx_np_poisson_loggam_table': [c_void_p, c_int],
+    'vkx_fog_field_f32_dev': [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    'vkx_fog_stretch_f32_dev': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_double, ctypes.c_double, c_void_p],
     'vkx_host_alloc': [c_void_p, c_size, ctypes.POINTER(c_void_p)],
     'vkx_host_free': [c_void_p, c_void_p],
     'vkx_upload_async': [c_void_p, c_void_p, c_void_p, c_size],
@@ -1407,6 +1409,35 @@ def np_poisson_u8(img, rng, ctx=None):
 
 
 np_poisson_flags = 0
+
+
+def np_fog_mask(shape, roughness, ratio_min, ratio_max, rng, ctx=None):
+    """The fog density plane of ``fog`` (reference photometric/effect.py:89-216): ``generate_diamond_square_mask(shape, roughness, rng)``
+    stretched to ``[ratio_min, ratio_max]``, float32 ``(H, W)`` as a DevArray, with ``rng`` left where the reference leaves it.  The four
+    corner draws and the two crop offsets are ``rng``'s own calls on the host; the ~``size^2`` uniform draws of the lattice levels are
+    taken from its PCG64 stream on the device (``vkx_fog_field_f32_dev``).  None -- ``rng`` untouched -- for another bit generator or a
+    lattice without levels: the caller builds the field with numpy."""
+    height, width = int(shape[0]), int(shape[1])
+    size = int(2**np.ceil(np.log2(max(height, width))) + 1)
+    levels = int(round(np.log2(size - 1))) if size > 2 else 0
+    if np_stream(rng) is None or levels < 1 or levels > 14 or (1 << levels) + 1 != size:
+        return None
+    ctx = ctx or default_ctx()
+    corners = np.array([rng.uniform(0.0, 1.0) for _ in range(4)]).astype(np.float32)      # field[0, 0], [0, -1], [-1, -1], [-1, 0]
+    state, inc = np_stream(rng)
+    st = (ctypes.c_uint64 * 2)(state & _M64, state >> 64)
+    ic = (ctypes.c_uint64 * 2)(inc & _M64, inc >> 64)
+    noise_weight = np.array([roughness**level for level in range(levels)], dtype=np.float64)
+    field = ctx.dev_empty((size, size), np.float32)
+    consumed = ctypes.c_longlong(0)
+    check(lib().vkx_fog_field_f32_dev(ctx.handle, st, ic, levels, _ptr(noise_weight), _ptr(corners), c_void_p(field.ptr), ctypes.byref(consumed)))
+    np_consume(rng, consumed.value)
+    up = int(rng.integers(0, size - height + 1))
+    left = int(rng.integers(0, size - width + 1))
+    mask = ctx.dev_empty((height, width), np.float32)
+    check(lib().vkx_fog_stretch_f32_dev(ctx.handle, c_void_p(field.ptr), size, up, left, height, width, float(ratio_max - ratio_min), float(ratio_min),
+                                        c_void_p(mask.ptr)))
+    return mask
 
 
 def _choice_cdf(p):

@@ -570,6 +570,21 @@ struct PzReply { long long consumed; int fail; int pad; };
 
 }   // namespace
 
+// out[i] = next_double of the PCG64 stream (state, inc) at its (i + 1)-th step, i = 0 .. M - 1; asynchronous on the ctx stream
+int vkx_pcg64_doubles_dev(vkx_ctx *ctx, const uint64_t *state, const uint64_t *inc, long long M, double *out)
+{
+    if (M <= 0) return VKX_OK;
+    const int grid = (int)std::min<long long>(1024, (M + 255) / 256);
+    u128 aT, gT;
+    jump_consts((u128)grid * 256, &aT, &gT);
+    const u128 inc128 = ((u128)inc[1] << 64) | inc[0], cT = inc128 * gT;
+    VKX_TIMED(ctx, "k_pz_raw");
+    k_pz_raw<<<grid, 256, 0, ctx->stream>>>(state[0], state[1], inc[0], inc[1], (uint64_t)aT, (uint64_t)(aT >> 64), (uint64_t)cT, (uint64_t)(cT >> 64),
+                                            M, out);
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
 VKX_EXPORT int vkx_np_poisson_loggam_table(double *out, int n)
 {
     if (!out || n < 1) return VKX_ERR_INVALID;
@@ -703,16 +718,7 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
     VKX_HIP(hipMemsetAsync(d_pos, 0, sizeof(long long), ctx->stream));
     VKX_HIP(hipMemsetAsync(d_reply, 0, sizeof(PzReply), ctx->stream));
     VKX_HIP(hipMemsetAsync(d_counter, 0, sizeof(unsigned) * supers.size(), ctx->stream));
-    {
-        const int grid = (int)std::min<long long>(1024, (M + 255) / 256);
-        u128 aT, gT;
-        jump_consts((u128)grid * 256, &aT, &gT);
-        const u128 inc128 = ((u128)inc[1] << 64) | inc[0], cT = inc128 * gT;
-        VKX_TIMED(ctx, "k_pz_raw");
-        k_pz_raw<<<grid, 256, 0, ctx->stream>>>(state[0], state[1], inc[0], inc[1], (uint64_t)aT, (uint64_t)(aT >> 64), (uint64_t)cT,
-                                                (uint64_t)(cT >> 64), M, d_draws);
-    }
-    VKX_LAUNCH_CHECK();
+    if ((rc = vkx_pcg64_doubles_dev(ctx, state, inc, M, d_draws))) return rc;
     {
         hipStream_t main_stream = ctx->stream;
         hipStream_t lanes[3] = {main_stream, main_stream, main_stream};

@@ -63,6 +63,7 @@ struct vkx_ctx {
     vkx_scratch np_tabs;              // jump constants + ziggurat tables of the numpy streams (nprand.hip), uploaded once
     vkx_scratch noise_rows;           // tiled noise of the fused chain: (row, tile column) -> slot offset records (fused.hip)
     vkx_scratch np_work[2];           // tile arrays of the numpy streams: the chunks of a call alternate (nprand.hip)
+    vkx_scratch fog_work;                     // fog field (fog.hip): raw draws + the float64 centres of a level
     vkx_scratch pz_tabs, pz_work, pz_draws;   // rng.poisson on the device (poisson.hip): per-lam constants; block plan; raw draws + E rows
     bool pz_tabs_ready = false;
 
@@ -132,6 +133,8 @@ int vkx_small_to_device(vkx_ctx *ctx, void *dev, const void *ring_host, size_t b
 int vkx_small_to_host(vkx_ctx *ctx, void *host, const void *dev, size_t bytes);
 hipStream_t vkx_stream_by_id(vkx_ctx *ctx, int id, int *rc);
 int vkx_stream_order(vkx_ctx *ctx, hipStream_t later, hipStream_t earlier);
+// out[i] = next_double of the PCG64 stream (state, inc) at its (i + 1)-th step (poisson.hip); asynchronous on the ctx stream
+int vkx_pcg64_doubles_dev(vkx_ctx *ctx, const uint64_t *state, const uint64_t *inc, long long M, double *out);
 
 // Plane copies between host and device staging: hipMemcpy2DAsync is an order of magnitude slower than a linear copy on
 // this stack (12 ms instead of 1 ms for a 2048^2 RGB plane), so planes whose rows follow each other without gaps -- every

@@ -1,5 +1,6 @@
 """``fog`` (reference: photometric/effect.py:89-216).  The fog density field is a diamond-square fractal drawn from the
-caller-visible numpy Generator stream on the host (like every random plane of the path); the per-pixel work -- blend
+caller-visible numpy Generator stream -- on the device for PCG64 (``_native.np_fog_mask``: numpy's float32 / float64 roundings level
+by level), with numpy itself otherwise (``generate_diamond_square_mask``, the statement-by-statement restatement); the per-pixel work -- blend
 every pixel towards the fog colour with the field as float32 alpha, ``uint8(clip((1 - a) * px + a * fog))`` -- is the
 alpha composite ``vkx_fill_u8`` with one page-sized layer.  ``pixelation`` (:56-86) shrinks with ``cv.resize``
 INTER_LINEAR and grows back with INTER_NEAREST (``vkx_resize_u8``).  ``jpeg_quality`` (:25-53, an encoder round trip
@@ -127,14 +128,19 @@ def fog_image(config: FogConfig, state, image: Image, rng: Optional[RandomGenera
     if mode not in (ImageMode.GRAYSCALE, ImageMode.RGB):
         image = image.to_rgb_image()
     assert rng is not None
-    mask = generate_diamond_square_mask(image.shape, config.roughness, rng)
-    # stretch the field to [ratio_min, ratio_max] (float32 in place, like the reference)
-    mask = np.array(mask, dtype=np.float32)
-    mask -= mask.min()
-    mask /= mask.max()
     assert config.ratio_min < config.ratio_max
-    mask *= (config.ratio_max - config.ratio_min)
-    mask += config.ratio_min
+    # the lattice levels and the stretch on the device, from the caller's PCG64 stream (vkx_fog_field_f32_dev); None: numpy below
+    mask = _native.np_fog_mask(image.shape, config.roughness, config.ratio_min, config.ratio_max, rng)
+    if mask is not None:
+        mask = _native.host_array(mask)
+    else:
+        mask = generate_diamond_square_mask(image.shape, config.roughness, rng)
+        # stretch the field to [ratio_min, ratio_max] (float32 in place, like the reference)
+        mask = np.array(mask, dtype=np.float32)
+        mask -= mask.min()
+        mask /= mask.max()
+        mask *= (config.ratio_max - config.ratio_min)
+        mask += config.ratio_min
 
     if image.mode == ImageMode.GRAYSCALE:
         # the grey fog value is fractional (reference effect.py:194-197): float32(0.2126 R + 0.7152 G + 0.0722 B)
