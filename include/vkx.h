@@ -580,6 +580,16 @@ int vkx_fog_field_f32_dev(vkx_ctx *ctx, const uint64_t *state, const uint64_t *i
                           const float *corners_host, float *field, long long *consumed_host);
 int vkx_fog_stretch_f32_dev(vkx_ctx *ctx, const float *field, int size, int up, int left, int h, int w, double span, double lo, float *mask);
 
+/* glass_blur's shuffle planes (reference photometric/blur.py:204-250) kept on the device: pos_y / pos_x int32 [h, w] dense planes, the
+ * operands of vkx_gather_u8_dev.  vkx_glass_init_dev: the identity (and the context's scratch for the rounds).  vkx_glass_round_dev: one
+ * round of swaps -- centres at rows r0 + i pitch (i < n_rows), columns c0 + j pitch (j < n_cols); centre k = i n_cols + j exchanges its
+ * entry with the one at clip(its current source position + (jump_y[k], jump_x[k])) with numpy's semantics of
+ * `pos[centres], pos[to] = pos[to], pos[centres]` (right sides first, the last centre in C order wins a shared `to`).  The jumps are host
+ * arrays (the caller's rng.integers draws); synchronous on return.  (vkit_amd/csrc/fog.hip) */
+int vkx_glass_init_dev(vkx_ctx *ctx, int32_t *pos_y, int32_t *pos_x, int h, int w);
+int vkx_glass_round_dev(vkx_ctx *ctx, int32_t *pos_y, int32_t *pos_x, int h, int w, int r0, int c0, int pitch, int n_rows, int n_cols,
+                        const int32_t *jump_y_host, const int32_t *jump_x_host);
+
 /* ---- throughput-mode noise plane ---------------------------------------------------------------
  * gaussion_noise (photometric/noise.py:44-54) adds np.round(rng.normal(0, std, shape)) drawn from the caller's numpy
  * Generator; the parity path takes that int16 plane from the caller (vkx_add_noise_i16, vkx_chain_item.noise).

@@ -173,6 +173,8 @@ _SIGNATURES = {
     'vkx_np_tiles_expand_dev': [c_void_p, c_void_p, ctypes.c_int64, c_void_p],
     'vkx_np_draw': [c_void_p, ctypes.POINTER(VkxNpJob), ctypes.POINTER(VkxNpResult)],
     'vkx_np_poisson_loggam_table': [c_void_p, c_int],
+    'vkx_glass_init_dev': [c_void_p, c_void_p, c_void_p, c_int, c_int],
+    'vkx_glass_round_dev': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     'vkx_fog_field_f32_dev': [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     'vkx_fog_stretch_f32_dev': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, ctypes.c_double, ctypes.c_double, c_void_p],
     'vkx_host_alloc': [c_void_p, c_size, ctypes.POINTER(c_void_p)],
@@ -1190,18 +1192,42 @@ def apply_lut(img, lut, channels=None, ctx=None):
 
 
 def gather(img, pos_y, pos_x, ctx=None):
-    """img[pos_y, pos_x] for two integer index planes of one shape."""
-    call = _Call(ctx, img)
+    """img[pos_y, pos_x] for two integer index planes of one shape (host arrays, or int32 DevArrays as glass_shuffle_planes_dev leaves them)."""
+    call = _Call(ctx, img, pos_y, pos_x)
     h, w, cn, stride = _shape_u8(img)
-    pos_y = np.ascontiguousarray(pos_y, dtype=np.int32)
-    pos_x = np.ascontiguousarray(pos_x, dtype=np.int32)
-    if pos_y.ndim != 2 or pos_y.shape != pos_x.shape:
-        raise ValueError('index planes must be 2-D and of one shape')
+    if not isinstance(pos_y, DevArray):
+        pos_y = np.ascontiguousarray(pos_y, dtype=np.int32)
+    if not isinstance(pos_x, DevArray):
+        pos_x = np.ascontiguousarray(pos_x, dtype=np.int32)
+    if len(pos_y.shape) != 2 or tuple(pos_y.shape) != tuple(pos_x.shape) or np.dtype(pos_y.dtype) != np.int32 or np.dtype(pos_x.dtype) != np.int32:
+        raise ValueError('index planes must be 2-D int32 and of one shape')
     dh, dw = pos_y.shape
     dst, dptr = call.out((dh, dw) + tuple(img.shape[2:]), np.uint8)
     check(call.fn('vkx_gather_u8')(call.ctx.handle, call.src(img), h, w, cn, stride, call.src(pos_y), call.src(pos_x), dw, dptr, dh, dw,
                                    dw * cn))
     return dst
+
+
+def glass_shuffle_planes_dev(shape, delta, loop, rng, ctx=None):
+    """The (row, column) source planes of glass_blur's shuffle (reference photometric/blur.py:204-250) as int32 DevArrays: the lattice
+    phases and jumps are ``rng``'s own draws, call for call the reference's; the swaps -- numpy's tuple assignment with its order of
+    duplicates -- run on the device (``vkx_glass_round_dev``), the planes never exist on the host."""
+    ctx = ctx or default_ctx()
+    height, width = int(shape[0]), int(shape[1])
+    pos_y, pos_x = ctx.dev_empty((height, width), np.int32), ctx.dev_empty((height, width), np.int32)
+    check(lib().vkx_glass_init_dev(ctx.handle, c_void_p(pos_y.ptr), c_void_p(pos_x.ptr), height, width))
+    pitch = 2 * delta + 1
+    for _ in range(loop):
+        r0 = int(rng.integers(0, pitch))
+        n_rows = len(range(r0, height - delta, pitch))
+        c0 = int(rng.integers(0, pitch))
+        n_cols = len(range(c0, width - delta, pitch))
+        grid = (n_rows, n_cols)
+        jump_y = np.ascontiguousarray(rng.integers(-delta, delta + 1, grid), dtype=np.int32)
+        jump_x = np.ascontiguousarray(rng.integers(-delta, delta + 1, grid), dtype=np.int32)
+        check(lib().vkx_glass_round_dev(ctx.handle, c_void_p(pos_y.ptr), c_void_p(pos_x.ptr), height, width, r0, c0, pitch, n_rows, n_cols,
+                                        _ptr(jump_y), _ptr(jump_x)))
+    return pos_y, pos_x
 
 
 def saturate_i64(samples, ctx=None):

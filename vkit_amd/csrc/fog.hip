@@ -167,3 +167,112 @@ VKX_EXPORT int vkx_fog_stretch_f32_dev(vkx_ctx *ctx, const float *field, int siz
     VKX_LAUNCH_CHECK();
     return VKX_OK;
 }
+
+// ---- glass_blur's shuffle planes (reference photometric/blur.py:204-250; mirror: glass_shuffle_planes) on the device -------------
+// pos_y / pos_x int32 [h, w]: the source position every pixel currently shows.  One ROUND: a lattice of centres (rows r0 + i pitch,
+// columns c0 + j pitch, pitch = 2 delta + 1); centre k = (i, j) in C order takes `to` = clip(its CURRENT source position + jump_k) and
+// the two entries are exchanged the way numpy's tuple assignment does it:
+//     pos[centres], pos[to] = pos[to], pos[centres]
+// -- both right sides are read first; then every centre takes what its `to` showed; then every `to` takes what its centre showed, IN
+// ORDER of k, so that of several centres with one `to` the last wins and a `to` that is itself a centre is overwritten.  The jumps are
+// the caller's rng.integers draws (host: a few thousand values per round); the planes never leave the device.
+namespace {
+
+__global__ void __launch_bounds__(256) k_glass_init(int *__restrict__ pos_y, int *__restrict__ pos_x, int h, int w)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)h * w) return;
+    const int y = (int)(i / w);
+    pos_y[i] = y;
+    pos_x[i] = (int)(i - (long long)y * w);
+}
+
+__global__ void __launch_bounds__(256) k_glass_read(const int *__restrict__ pos_y, const int *__restrict__ pos_x, int h, int w, int r0, int c0, int pitch,
+                                                    int n_rows, int n_cols, const int *__restrict__ jump_y, const int *__restrict__ jump_x,
+                                                    int *__restrict__ to, uint32_t *__restrict__ from_to, uint32_t *__restrict__ from_centre)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_rows * n_cols) return;
+    const int i = k / n_cols, j = k - i * n_cols;
+    const long long centre = (long long)(r0 + i * pitch) * w + c0 + j * pitch;
+    const int cy = pos_y[centre], cx = pos_x[centre];
+    const int ty = min(max(cy + jump_y[k], 0), h - 1), tx = min(max(cx + jump_x[k], 0), w - 1);
+    const int t = ty * w + tx;
+    to[k] = t;
+    from_to[k] = ((uint32_t)pos_y[t] << 16) | (uint32_t)pos_x[t];
+    from_centre[k] = ((uint32_t)cy << 16) | (uint32_t)cx;
+}
+
+__global__ void __launch_bounds__(256) k_glass_write(int *__restrict__ pos_y, int *__restrict__ pos_x, int w, int r0, int c0, int pitch, int n_rows,
+                                                     int n_cols, const int *__restrict__ to, const uint32_t *__restrict__ from_to,
+                                                     const uint32_t *__restrict__ from_centre, unsigned long long *__restrict__ win)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_rows * n_cols) return;
+    const int i = k / n_cols, j = k - i * n_cols;
+    const long long centre = (long long)(r0 + i * pitch) * w + c0 + j * pitch;
+    pos_y[centre] = (int)(from_to[k] >> 16);
+    pos_x[centre] = (int)(from_to[k] & 0xffffu);
+    atomicMax(&win[to[k]], ((unsigned long long)(k + 1) << 32) | from_centre[k]);       // the last centre in C order wins its `to`
+}
+
+__global__ void __launch_bounds__(256) k_glass_resolve(int *__restrict__ pos_y, int *__restrict__ pos_x, int n, const int *__restrict__ to,
+                                                       const unsigned long long *__restrict__ win)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const unsigned long long v = win[to[k]];          // centres that share a `to` write the same winner
+    pos_y[to[k]] = (int)((uint32_t)v >> 16);
+    pos_x[to[k]] = (int)((uint32_t)v & 0xffffu);
+}
+
+__global__ void __launch_bounds__(256) k_glass_clear(int n, const int *__restrict__ to, unsigned long long *__restrict__ win)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < n) win[to[k]] = 0ull;
+}
+
+}   // namespace
+
+VKX_EXPORT int vkx_glass_init_dev(vkx_ctx *ctx, int32_t *pos_y, int32_t *pos_x, int h, int w)
+{
+    VKX_REQUIRE(ctx && pos_y && pos_x && h >= 1 && w >= 1 && h <= 32767 && w <= 32767, "bad argument");
+    vkx_device_guard guard(ctx);
+    int rc;
+    if ((rc = vkx_scratch_reserve(ctx, &ctx->glass_win, sizeof(unsigned long long) * (size_t)h * w))) return rc;
+    VKX_HIP(hipMemsetAsync(ctx->glass_win.ptr, 0, sizeof(unsigned long long) * (size_t)h * w, ctx->stream));
+    { VKX_TIMED(ctx, "k_glass_init"); k_glass_init<<<vkx_blocks((size_t)h * w, 256), 256, 0, ctx->stream>>>(pos_y, pos_x, h, w); }
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_glass_round_dev(vkx_ctx *ctx, int32_t *pos_y, int32_t *pos_x, int h, int w, int r0, int c0, int pitch, int n_rows, int n_cols,
+                                   const int32_t *jump_y_host, const int32_t *jump_x_host)
+{
+    VKX_REQUIRE(ctx && pos_y && pos_x && h >= 1 && w >= 1 && pitch >= 1 && r0 >= 0 && c0 >= 0 && n_rows >= 0 && n_cols >= 0, "bad argument");
+    const long long n = (long long)n_rows * n_cols;
+    if (n == 0) return VKX_OK;
+    VKX_REQUIRE(jump_y_host && jump_x_host, "NULL jumps");
+    VKX_REQUIRE(r0 + (long long)(n_rows - 1) * pitch < h && c0 + (long long)(n_cols - 1) * pitch < w && n < (1ll << 31), "lattice outside the plane");
+    VKX_REQUIRE(ctx->glass_win.ptr && ctx->glass_win.cap >= sizeof(unsigned long long) * (size_t)h * w, "vkx_glass_init_dev first");
+    vkx_device_guard guard(ctx);
+    int rc;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t part = up(sizeof(int) * (size_t)n);
+    if ((rc = vkx_scratch_reserve(ctx, &ctx->fog_work, 5 * part))) return rc;
+    unsigned char *base = (unsigned char *)ctx->fog_work.ptr;
+    int *d_jy = (int *)base, *d_jx = (int *)(base + part), *d_to = (int *)(base + 2 * part);
+    uint32_t *d_ft = (uint32_t *)(base + 3 * part), *d_fc = (uint32_t *)(base + 4 * part);
+    VKX_HIP(hipMemcpyAsync(d_jy, jump_y_host, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    VKX_HIP(hipMemcpyAsync(d_jx, jump_x_host, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    unsigned long long *win = (unsigned long long *)ctx->glass_win.ptr;
+    const unsigned grid = (unsigned)vkx_blocks((size_t)n, 256);
+    VKX_TIMED(ctx, "k_glass_round");
+    k_glass_read<<<grid, 256, 0, ctx->stream>>>(pos_y, pos_x, h, w, r0, c0, pitch, n_rows, n_cols, d_jy, d_jx, d_to, d_ft, d_fc);
+    k_glass_write<<<grid, 256, 0, ctx->stream>>>(pos_y, pos_x, w, r0, c0, pitch, n_rows, n_cols, d_to, d_ft, d_fc, win);
+    k_glass_resolve<<<grid, 256, 0, ctx->stream>>>(pos_y, pos_x, (int)n, d_to, win);
+    k_glass_clear<<<grid, 256, 0, ctx->stream>>>((int)n, d_to, win);
+    VKX_LAUNCH_CHECK();
+    VKX_HIP(hipStreamSynchronize(ctx->stream));       // the host jump arrays are the caller's
+    return VKX_OK;
+}

@@ -7,6 +7,7 @@ and ``glass_blur`` (:186-258): that blur followed by a random local pixel shuffl
 no fused multiply-add).  ``zoom_in_blur`` (:264-323) averages the image with centred crops of its bicubic
 enlargements (``vkx_zoom_in_blur_u8``)."""
 import math
+import os
 from typing import Any, Mapping, Optional
 
 import attrs
@@ -221,7 +222,11 @@ def glass_blur_image(config: GlassBlurConfig, state, image: Image, rng: Optional
     image = to_rgb_image(image, mode)
     assert rng is not None
     mat = _native.gaussian_blur(image.arr, _estimate_gaussian_kernel_size(config.sigma), config.sigma)
-    pos_y, pos_x = glass_shuffle_planes(image.shape, config.delta, config.loop, rng)
+    # the shuffle planes stay on the device: the jumps are rng's draws, the swap rounds run there (VKX_HOST_SHUFFLE=1: numpy's planes)
+    if os.environ.get('VKX_HOST_SHUFFLE', '') == '1' or max(image.shape) > 32767:
+        pos_y, pos_x = glass_shuffle_planes(image.shape, config.delta, config.loop, rng)
+    else:
+        pos_y, pos_x = _native.glass_shuffle_planes_dev(image.shape, config.delta, config.loop, rng)
     mat = _native.gather(mat, pos_y, pos_x)
     return to_original_image(attrs.evolve(image, mat=mat), mode)
 
