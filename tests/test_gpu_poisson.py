@@ -105,3 +105,26 @@ print('refused and redrawn')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, '-c', code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and 'refused and redrawn' in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize('depth', ['1', '3'])
+def test_other_pipeline_depths(depth):
+    """VKX_PZ_DEPTH (read once per process): launches strictly in sequence, and three superblock launches in flight."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np
+from numpy.random import default_rng
+from vkit_amd import _native as N
+g = default_rng(1)
+for img in (g.integers(0, 256, (300, 400, 3), dtype=np.uint8), np.full((257, 513, 3), 250, np.uint8), g.integers(0, 14, (200, 300, 3), dtype=np.uint8)):
+    r_np, r_dev = default_rng(9), default_rng(9)
+    want = np.clip(r_np.poisson(img.astype(np.float32)), 0, 255).astype(np.uint8)
+    got = N.np_poisson_u8(img, r_dev)
+    assert got is not None and np.array_equal(np.asarray(N.host_array(got)), want) and r_np.bit_generator.state == r_dev.bit_generator.state
+print('depth ok')
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, VKX_PZ_DEPTH=depth), cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and 'depth ok' in out.stdout, out.stdout + out.stderr
