@@ -21,8 +21,8 @@
 //                where the next block begins.
 // Every decision is numpy's: the per-lam constants, exp(-lam) and the loggam table are computed on the HOST with the same libm numpy
 // calls (tests pin the table against numpy's own libnpyrandom.a); products, quotients, floor are IEEE double without contraction.  The
-// two logarithms of the PTRS squeeze-free test are the device's (<= 1 ulp, like glibc's): a comparison closer than 1e-11 -- some 10^3
-// times both error bounds -- raises VKX_NP_POISSON_AMBIGUOUS instead of guessing, as does a start that leaves its window (6 sigma), and
+// two logarithms of the PTRS squeeze-free test are the device's (<= 1 ulp, like glibc's): a comparison closer than 2e-13 -- five times
+// the worst-case sum of both error bounds -- raises VKX_NP_POISSON_AMBIGUOUS instead of guessing, as does a start that leaves its window (6 sigma), and
 // the caller draws that image with numpy on the host.
 #include "vkx_internal.h"
 
@@ -224,10 +224,12 @@ __device__ __forceinline__ double pz_loggam_dev(double x0)
     return gl0 / x0 + 0.5 * 1.8378770664093453e+00 + (x0 - 0.5) * log(x0) - x0;
 }
 
+__device__ double pz_dbg[8];
+
 // One attempt of random_poisson_ptrs' loop on the draws (d0, d1).  NEED_K: the value on the fast accept too.
 // The comparison log(V) + log(invalpha) - log(a / us^2 + b) <= -lam + k log(lam) - loggam(k + 1) is first taken with float32 logarithms
 // (v_log_f32; the left side is then within 3e-5 of the double one: |log V| <= 37, the other logarithm <= 74, both to 2e-7 relative):
-// a difference beyond 1e-3 decides; the few per thousand inside it take the double logarithms, and those within 1e-11 of equality --
+// a difference beyond 1e-3 decides; the few per thousand inside it take the double logarithms, and those within 2e-13 of equality --
 // where the device's log and glibc's could disagree -- raise the ambiguity flag.
 template <bool NEED_K>
 __device__ __forceinline__ bool pz_attempt(const PzLam &L, const double *__restrict__ loggam, double d0, double d1, double &kd, int &flags)
@@ -238,7 +240,10 @@ __device__ __forceinline__ bool pz_attempt(const PzLam &L, const double *__restr
     kd = floor((L.a2 / us + L.b) * U + L.lam + 0.43);       // us == 0: -inf, rejected below like numpy's (int64)(-inf) < 0
     if (fast) return true;
     if (kd < 0.0 || (us < 0.013 && V > us)) return false;
-    double lg, tol = 1e-11;
+    // the margin inside which the device's logarithms and glibc's could order the two sides differently: each library is within 1 ulp,
+    // |log V| <= 37 and the other logarithm <= 74 (ulps of 7e-15 and 1.4e-14), so the two left sides differ by at most 4.2e-14
+    constexpr double kTie = 2e-13;
+    double lg, tol = kTie;
     if (kd < (double)kKMax) {
         lg = loggam[(int)kd + 1];
     } else {
@@ -246,14 +251,17 @@ __device__ __forceinline__ bool pz_attempt(const PzLam &L, const double *__restr
         tol = 1e-12 * kd * log(kd + 1.0) + 1e-9;
     }
     const double rhs = -L.lam + kd * L.loglam - lg;
-    if (tol == 1e-11) {
+    if (tol == kTie) {
         const float usf = (float)us;
         const float lhs_f = (__log2f((float)V) - __log2f((float)L.a * __builtin_amdgcn_rcpf(usf * usf) + (float)L.b)) * 0.69314718f;
         const double d = ((double)lhs_f + L.log_invalpha) - rhs;
         if (fabs(d) > 1e-3) return d < 0.0;
     }
     const double lhs = log(V) + L.log_invalpha - log(L.a / (us * us) + L.b);
-    if (fabs(lhs - rhs) < tol) flags |= kFlagAmbiguous;
+    if (fabs(lhs - rhs) < tol) {
+        flags |= kFlagAmbiguous;
+        pz_dbg[0] = L.lam; pz_dbg[1] = d0; pz_dbg[2] = d1; pz_dbg[3] = lhs; pz_dbg[4] = rhs; pz_dbg[5] = kd;      // VKX_PZ_PROBE prints the last one
+    }
     return lhs <= rhs;
 }
 
@@ -754,6 +762,11 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
     PzReply reply;
     VKX_HIP(hipMemcpyAsync(&reply, d_reply, sizeof(reply), hipMemcpyDeviceToHost, ctx->stream));
     VKX_HIP(hipStreamSynchronize(ctx->stream));
+    if (probing && (reply.fail & kFlagAmbiguous)) {
+        double dbg[8];
+        VKX_HIP(hipMemcpyFromSymbol(dbg, HIP_SYMBOL(pz_dbg), sizeof(dbg)));
+        fprintf(stderr, "pz ambiguous: lam %.0f d0 %.17g d1 %.17g lhs %.17g rhs %.17g k %.0f\n", dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5]);
+    }
     if (probing) {
         std::vector<long long> pr(8 * supers.size());
         VKX_HIP(hipMemcpy(pr.data(), d_probe, 64 * supers.size(), hipMemcpyDeviceToHost));
