@@ -554,10 +554,10 @@ int vkx_np_draw(vkx_ctx *ctx, const vkx_np_job *job, vkx_np_result *result_host)
  * a data-dependent number of draws: windows of candidate stream positions per block of 32 elements, resolved superblock by superblock
  * (vkit_amd/csrc/poisson.hip).  dst uint8 [n] = min(sample, 255); *consumed_host = the raw 64-bit draws numpy would have made.
  * *flags_host != 0: the result is NOT to be used and the stream not to be moved (the caller draws with numpy on the host): a PTRS
- * comparison fell within 2e-13 of equality (device log vs glibc log), a start left its 6-sigma window, or k left the loggam table.
+ * comparison fell within 2e-13 of equality (device log vs glibc log), a start left its 6-sigma window, or the stream would need more than 2^29 raw draws.
  * Synchronous.  _dev: device arrays, src 16-byte aligned. */
 #define VKX_NP_POISSON_AMBIGUOUS 1u
-#define VKX_NP_POISSON_TABLE 2u
+#define VKX_NP_POISSON_TABLE 2u     /* not raised any more: k + 1 beyond the loggam table takes random_loggam with the device log */
 #define VKX_NP_POISSON_WINDOW 4u
 #define VKX_NP_POISSON_MISMATCH 8u
 #define VKX_NP_POISSON_DRAWS 16u

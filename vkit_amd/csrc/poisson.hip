@@ -500,6 +500,8 @@ __global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__rest
     }
 }
 
+#undef PZ_STAMP
+
 __global__ void __launch_bounds__(64) k_pz_final(const uint8_t *__restrict__ src, long long n, long long n_blk, const long long *__restrict__ blk_pos,
                                                  const double *__restrict__ draws, long long M, const PzTabs *__restrict__ T,
                                                  uint8_t *__restrict__ dst, long long *__restrict__ consumed, int *__restrict__ fail)
