@@ -1198,7 +1198,7 @@ __global__ void __launch_bounds__(256) k_np_tiles_finish(const NpJob *__restrict
 
 // (one wavefront per workgroup: the kEmit workspace of a float64 emitter is 26 KB)
 // TILES: the walked tiles rewrite their slot from its first element (their table entry says skip = 0)
-template <class Emit, bool TILES = false>
+template <class Emit, bool TILES = false, int STEP = 64>
 __global__ void __launch_bounds__(64) k_np_place_walk(const NpJob *__restrict__ jobs, int n_jobs, long long total_tiles,
                                                        const uint64_t *__restrict__ states, const TileInfo *__restrict__ info,
                                                        const TilePlan *__restrict__ plan, vkx_np_result *__restrict__ results,
@@ -1212,11 +1212,12 @@ __global__ void __launch_bounds__(64) k_np_place_walk(const NpJob *__restrict__ 
     const JumpTabs &g_jump = tabs->jump;
     const int lane = __lane_id();
     const long long n_waves = (long long)gridDim.x;
-    // 64 tiles per step: a lane looks at one plan, the wavefront then walks the few tiles that asked for it
-    for (long long t0 = (long long)blockIdx.x * 64; t0 < total_tiles; t0 += n_waves * 64) {
+    // STEP tiles per step: a lane looks at one plan, the wavefront then walks the few tiles that asked for it (STEP = 64 where walks are
+    // rare; the speckle records are walked wherever a tile holds a tail draw -- 43 % of the 3 072-draw tiles --: 4 tiles per wavefront)
+    for (long long t0 = (long long)blockIdx.x * STEP; t0 < total_tiles; t0 += n_waves * STEP) {
         const long long mine = t0 + lane;
         bool want = false;
-        if (mine < total_tiles) {
+        if (lane < STEP && mine < total_tiles) {
             const NpJob &jb = jobs[job_of_tile(jobs, n_jobs, mine)];
             const TilePlan p = plan[mine];
             want = (long long)p.prefix < jb.n && tile_needs_walk(jb, p, info[mine].out0, Emit::kCheckAtStore);
@@ -1537,7 +1538,8 @@ static int np_chunk_back(vkx_ctx *ctx, NpChunk &c)
         VKX_TIMED(ctx, "k_np_place_walk");
         const unsigned wg2 = (unsigned)std::min<long long>((total_tiles + 63) / 64, 256 * 16);
         if (kind == VKX_NP_SPECKLE_U8)
-            k_np_place_walk<EmitSpeckle><<<wg2, 64, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, done, c.res_mapped, tabs);
+            k_np_place_walk<EmitSpeckle, false, 4><<<(unsigned)std::min<long long>((total_tiles + 3) / 4, 256 * 16), 64, 0, ctx->stream>>>(
+                dj, n_jobs, total_tiles, states, info, plan, res, done, c.res_mapped, tabs);
         else if (kind == VKX_NP_NORMAL_ADD_U8)
             k_np_place_walk<EmitAddU8><<<wg2, 64, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, plan, res, done, c.res_mapped, tabs);
         else if (kind == VKX_NP_NORMAL_TILES)
