@@ -78,7 +78,7 @@ def test_random_distortion_resident_equals_host(seed):
     mask = np.ones(img.shape[:2], np.uint8)
     mask[:3] = 0
     score = np.random.default_rng(seed).random(img.shape[:2], dtype=np.float32)
-    rd = random_distortion_factory.create({'disabled_policy_names': ['poisson_noise']})
+    rd = random_distortion_factory.create()        # poisson_noise included: drawn on the device since round 4
     host = rd.distort(np.random.default_rng(seed), image=Image(mat=img), mask=Mask(mat=mask),
                       score_map=ScoreMap(mat=score, is_prob=False))
     with N.resident():
