@@ -31,3 +31,29 @@ def test_member_matches_host_planes(monkeypatch):
     monkeypatch.setenv('VKX_HOST_SHUFFLE', '1')
     b = np.asarray(D.glass_blur.distort(cfg, image=Image(mat=img), rng=default_rng(4)).image.mat)
     np.testing.assert_array_equal(a, b)
+
+
+def test_argument_errors_are_reported():
+    """The new entry points refuse what they cannot take, with a message, instead of launching."""
+    import ctypes
+    from vkit_amd import _native as N
+    ctx = N.Context(0)
+    lib = N.lib()
+    pos = ctx.dev_empty((8, 8), np.int32)
+    jumps = np.zeros(4, np.int32)
+    p = ctypes.c_void_p(pos.ptr)
+    # a round before vkx_glass_init_dev sized the winner plane of this context
+    assert lib.vkx_glass_round_dev(ctx.handle, p, p, 8, 8, 0, 0, 3, 2, 2, N._ptr(jumps), N._ptr(jumps)) == N.ERR_INVALID
+    assert b'vkx_glass_init_dev' in lib.vkx_last_error()
+    assert lib.vkx_glass_init_dev(ctx.handle, p, p, 8, 8) == 0
+    assert lib.vkx_glass_round_dev(ctx.handle, p, p, 8, 8, 0, 0, 3, 4, 4, N._ptr(jumps), N._ptr(jumps)) == N.ERR_INVALID     # lattice outside the plane
+    field = ctx.dev_empty((3, 3), np.float32)
+    st = (ctypes.c_uint64 * 2)(1, 2)
+    nw = np.ones(1)
+    corners = np.zeros(4, np.float32)
+    consumed = ctypes.c_longlong()
+    assert lib.vkx_fog_field_f32_dev(ctx.handle, st, st, 0, N._ptr(nw), N._ptr(corners), ctypes.c_void_p(field.ptr), ctypes.byref(consumed)) == N.ERR_INVALID
+    assert lib.vkx_fog_stretch_f32_dev(ctx.handle, ctypes.c_void_p(field.ptr), 3, 2, 2, 2, 2, 1.0, 0.0, ctypes.c_void_p(field.ptr)) == N.ERR_INVALID
+    img16 = np.zeros((4, 4), np.int16)
+    assert N.np_poisson_u8(img16, default_rng(1)) is None
+    ctx.sync()
