@@ -473,24 +473,38 @@ __global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__rest
             // Wavefront 0 walks the chunk: the dependent chain of a step is one add and one LDS read (every lane reads the same entry).
             // The rows' offsets sit in a vector register, one per lane, and come out with v_readlane; the starts found go back the same
             // way; a miss (0xffff) is noted on the side and the walk goes on with the index masked into the staged range.
-            uint32_t cur = (uint32_t)max(s_idx, 0);
-            bool bad = s_idx < 0;
+            // Per step nothing but the offset (v_readlane), the masked add, the read and a fire-and-forget store of the index found: what
+            // a miss (0xffff) means for the rows after it is sorted out when all chunks are done.
+            uint32_t cur = s_idx < 0 ? 0xffffu : (uint32_t)s_idx;
             for (int bb = b0; bb < b1; bb += 64) {
                 const int offv = l_off[min(bb + tid, n_blocks)] - off0;
-                int idxv = -1;
                 const int rows = min(64, b1 - bb);
+                int *out = l_idx + bb;
                 for (int i = 0; i < rows; i++) {
                     const int off = __builtin_amdgcn_readlane(offv, i);
-                    idxv = tid == i ? (bad ? -1 : (int)cur) : idxv;
+                    out[i] = (int)cur;
                     cur = le[off + (cur & 0xfffu)];
-                    bad = bad || cur == 0xffffu;
                 }
-                if (bb + tid < b1) l_idx[bb + tid] = idxv;
             }
-            if (tid == 0) s_idx = bad ? -1 : (int)cur;
+            if (tid == 0) s_idx = cur == 0xffffu ? -1 : (int)cur;
         }
         __syncthreads();
     }
+    // a row whose start is the miss marker, and every row after it, has no start
+    if (tid < 64) {
+        int first_bad = n_blocks;
+        for (int b = tid; b < n_blocks; b += 64)
+            if (l_idx[b] == 0xffff) first_bad = min(first_bad, b);
+        for (int o = 32; o; o >>= 1) first_bad = min(first_bad, __shfl_xor(first_bad, o));
+        if (tid == 0) {
+            s_rows = first_bad;
+            if (first_bad < n_blocks) s_idx = -1;
+        }
+    }
+    __syncthreads();
+    for (int b = tid; b < n_blocks; b += kCandThreads)
+        if (b >= s_rows) l_idx[b] = -1;
+    __syncthreads();
     PZ_STAMP(5);
     for (int b = tid; b < n_blocks; b += kCandThreads) blk_pos[first_block + b] = l_idx[b] < 0 ? -1 : p0 + l_lo[b] + l_idx[b];
     if (tid == 0) {
