@@ -642,10 +642,26 @@ typedef struct vkx_chain_item {
     double streak_alpha;           /* in [0, 1] */
 } vkx_chain_item;
 int vkx_chain_rgb_batch_dev(vkx_ctx *ctx, const vkx_chain_item *items, int n_items);
+/* The numpy streams of a batch's gaussion_noise members and its chain in ONE call: jobs = VKX_NP_NORMAL_TILES jobs, each drawing the
+ * tile buffer that is the `noise` (noise_tiled = 1) of one item, in item order.  Same results as vkx_np_draw_batch_dev(jobs) followed
+ * by vkx_chain_rgb_batch_dev(items); the library cuts the batch into chunks of images and runs the microsecond kernels of either
+ * call (carry resolution, tile tables, cell setup, noise row records: eight launches of a few workgroups) on the context's two other
+ * streams, under the draw pass of the next chunk or the pixel kernel of the first one (vkit_amd/csrc/chain.hip).  Jobs of another
+ * kind, or items the fused kernel declines, make it exactly the two calls.  Asynchronous on the ctx stream. */
+int vkx_chain_rgb_batch_np_dev(vkx_ctx *ctx, const vkx_chain_item *items, int n_items, const vkx_np_job *jobs_host, int n_jobs,
+                               vkx_np_result *results_host);
+/* The cell setup of a chain call (one lane per lattice cell: homographies, edge tables, tile bins) reads nothing but the vertex
+ * lattices and runs on a side stream of the context.  By default it starts after everything queued on the ctx stream before the
+ * chain call.  A caller whose lattices are complete earlier says so once: this call marks the current point of the ctx stream, and
+ * the setups of the chain calls that follow wait for THAT point only (e.g. under a page composite queued between the mark and the
+ * chain call).  Call it again after queuing anything that writes lattices. */
+int vkx_chain_lattices_ready(vkx_ctx *ctx);
 
 /* ---- per-kernel timing -----------------------------------------------------------------
  * When enabled, every kernel launch is bracketed by a hipEvent pair recorded on the ctx
- * stream; vkx_ctx_collect_timings synchronises and folds them into per-kernel totals. */
+ * stream; vkx_ctx_collect_timings synchronises and folds them into per-kernel totals.
+ * enabled = 2: only the large kernels (k_chain_fused, k_np_draw) are bracketed -- an event pair costs a few microseconds of
+ * stream time, which a step of a dozen microsecond kernels notices. */
 int vkx_ctx_set_timing(vkx_ctx *ctx, int enabled);
 int vkx_ctx_collect_timings(vkx_ctx *ctx, int *n_kernels);
 int vkx_ctx_get_timing(vkx_ctx *ctx, int index, const char **name, double *total_ms, long long *launches);

@@ -164,6 +164,9 @@ _SIGNATURES = {
     'vkx_download': [c_void_p, c_void_p, c_void_p, c_size],
     'vkx_memset': [c_void_p, c_void_p, c_int, c_size],
     'vkx_chain_rgb_batch_dev': [c_void_p, ctypes.POINTER(VkxChainItem), c_int],
+    'vkx_chain_rgb_batch_np_dev': [c_void_p, ctypes.POINTER(VkxChainItem), c_int, ctypes.POINTER(VkxNpJob), c_int,
+                                   ctypes.POINTER(VkxNpResult)],
+    'vkx_chain_lattices_ready': [c_void_p],
     'vkx_noise_normal_table': [c_double, c_void_p],
     'vkx_noise_normal_i16_dev': [c_void_p, c_void_p, c_ssize, c_int, c_int, c_int, c_double, ctypes.c_uint64],
     'vkx_noise_normal_i16': [c_void_p, c_void_p, c_ssize, c_int, c_int, c_int, c_double, ctypes.c_uint64],
@@ -342,7 +345,7 @@ class Context:
         check(lib().vkx_ctx_set_stream(self.handle, c_void_p(stream_ptr) if stream_ptr else None))
 
     def set_timing(self, enabled):
-        check(lib().vkx_ctx_set_timing(self.handle, int(bool(enabled))))
+        check(lib().vkx_ctx_set_timing(self.handle, 2 if enabled == 2 else int(bool(enabled))))
 
     def reset_timings(self):
         check(lib().vkx_ctx_reset_timings(self.handle))

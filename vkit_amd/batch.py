@@ -6,6 +6,7 @@ planes) and issues the whole batch with ONE ``vkx_chain_rgb_batch_dev`` call.  I
 giving every process (one per GPU) its own ``ChainBatch``; there is no exchange step.
 """
 import ctypes
+import os
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -46,6 +47,8 @@ class ChainBatch:
         self.stream_chunk = 4096     # planes per vkx_np_draw_batch_dev call (the library pipelines a call in chunks of 32 planes)
         self.stream_fallbacks = 0    # planes the device declared ambiguous and the host drew instead
         self._runs = 0
+        self.joint_call = os.environ.get('VKX_CHAIN_JOINT', '1') != '0'       # tile-buffer streams + chain through vkx_chain_rgb_batch_np_dev (False: two calls, as in round 4)
+        self._marked = False
         self._page_layers = {}       # item index -> [VkxLayer with device planes]: assembled into the source before the chain
         self._layer_tables = None
 
@@ -126,6 +129,7 @@ class ChainBatch:
         self._items.append(item)
         self._dst_shapes.append((dh, dw))
         self._array = None
+        self._marked = False
         return len(self._items) - 1
 
     def set_layers(self, index: int, layers):
@@ -275,8 +279,16 @@ class ChainBatch:
         if first:
             self._stream_jobs = self._build_jobs([e for e in self._stream_noise if not e[4]])
             self._late_jobs = self._build_jobs([e for e in self._stream_noise if e[4]])
-        if self._stream_noise and (draw_streams or first):
-            self._launch(self._stream_jobs)
+        # the tile-buffer streams and the chain as ONE call (vkx_chain_rgb_batch_np_dev): the library knows which image waits for
+        # which stream and hides the small kernels of either under the large kernels of the other
+        joint = None
+        if self._stream_noise and (draw_streams or first) and self._stream_jobs:
+            jobs, _results, part = self._stream_jobs[0]
+            if self._items[part[0][0]].noise_tiled and not self._device_noise and self.joint_call:
+                joint = self._stream_jobs[0]
+                self._launch(self._stream_jobs[1:])
+            else:
+                self._launch(self._stream_jobs)
         if self._device_noise:
             # the planes that share a deviation in one launch (its inverse-CDF table is staged once per workgroup)
             by_std = {}
@@ -291,8 +303,15 @@ class ChainBatch:
                 _native.check(lib.vkx_noise_normal_i16_batch_dev(self.ctx.handle, planes, len(members), std))
         self._runs += 1
         if self._page_layers:
+            if not self._marked:     # the lattices were uploaded by add(): the chain's cell setup need not wait for the composite
+                _native.check(lib.vkx_chain_lattices_ready(self.ctx.handle))
+                self._marked = True
             self._composite()
-        _native.check(lib.vkx_chain_rgb_batch_dev(self.ctx.handle, self._array, len(self._items)))
+        if joint is not None:
+            jobs, results, _part = joint
+            _native.check(lib.vkx_chain_rgb_batch_np_dev(self.ctx.handle, self._array, len(self._items), jobs, len(jobs), results.array))
+        else:
+            _native.check(lib.vkx_chain_rgb_batch_dev(self.ctx.handle, self._array, len(self._items)))
         if self._stream_noise and self._late_jobs:
             self._launch(self._late_jobs)
         if first and self._verify_streams():

@@ -60,12 +60,20 @@ VKX_EXPORT int vkx_ctx_destroy(vkx_ctx *ctx)
     if (!ctx) return VKX_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (auto &st : ctx->copy_stream)
+        if (st) (void)hipStreamSynchronize(st);
     scratch_release(&ctx->owner);
     scratch_release(&ctx->cells);
     scratch_release(&ctx->misc);
     scratch_release(&ctx->tables);
     for (auto &s : ctx->stage) scratch_release(&s);
     for (auto &s : ctx->chain) scratch_release(&s);
+    scratch_release(&ctx->chain_cells);
+    scratch_release(&ctx->chain_bins);
+    scratch_release(&ctx->chain_misc);
+    if (ctx->chain_done) (void)hipEventDestroy(ctx->chain_done);
+    if (ctx->chain_setup_done) (void)hipEventDestroy(ctx->chain_setup_done);
+    if (ctx->lattices_ready) (void)hipEventDestroy(ctx->lattices_ready);
     scratch_release(&ctx->noise_table);
     scratch_release(&ctx->np_tabs);
     scratch_release(&ctx->noise_rows);
@@ -137,8 +145,12 @@ int vkx_scratch_reserve(vkx_ctx *ctx, vkx_scratch *s, size_t bytes)
     if (bytes <= s->cap) return VKX_OK;
     vkx_device_guard guard(ctx);
     if (s->ptr) {
-        // the old block may still be in use by work queued on the stream
+        // the old block may still be in use by work queued on the stream -- or on the context's other streams (the side
+        // passes of the numpy streams and of the chain setup)
         VKX_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->own_stream && ctx->own_stream != ctx->stream) VKX_HIP(hipStreamSynchronize(ctx->own_stream));
+        for (hipStream_t st : ctx->copy_stream)
+            if (st && st != ctx->stream) VKX_HIP(hipStreamSynchronize(st));
         VKX_HIP(hipFree(s->ptr));
         s->ptr = nullptr;
         s->cap = 0;
@@ -232,9 +244,12 @@ int vkx_desc_ring_take(vkx_ctx *ctx, size_t bytes, void **hptr)
 }
 
 namespace {
+// (one word per lane: a lane's read of page-locked host memory is a round trip over the link -- a single workgroup looping over
+// 35 KB of job records took 60 us)
 __global__ void k_small_copy(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, unsigned n_words)
 {
-    for (unsigned i = threadIdx.x; i < n_words; i += blockDim.x) dst[i] = src[i];
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words) dst[i] = src[i];
 }
 }  // namespace
 
@@ -246,7 +261,7 @@ int vkx_small_to_device(vkx_ctx *ctx, void *dev, const void *ring_host, size_t b
         VKX_HIP(hipMemcpyAsync(dev, ring_host, bytes, hipMemcpyHostToDevice, ctx->stream));
         return VKX_OK;
     }
-    k_small_copy<<<1, 256, 0, ctx->stream>>>((uint32_t *)dev, (const uint32_t *)mapped, (unsigned)(bytes / 4));
+    k_small_copy<<<vkx_blocks(bytes / 4, 256), 256, 0, ctx->stream>>>((uint32_t *)dev, (const uint32_t *)mapped, (unsigned)(bytes / 4));
     VKX_LAUNCH_CHECK();
     return VKX_OK;
 }
@@ -259,7 +274,7 @@ int vkx_small_to_host(vkx_ctx *ctx, void *host, const void *dev, size_t bytes)
         VKX_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
         return VKX_OK;
     }
-    k_small_copy<<<1, 256, 0, ctx->stream>>>((uint32_t *)mapped, (const uint32_t *)dev, (unsigned)(bytes / 4));
+    k_small_copy<<<vkx_blocks(bytes / 4, 256), 256, 0, ctx->stream>>>((uint32_t *)mapped, (const uint32_t *)dev, (unsigned)(bytes / 4));
     VKX_LAUNCH_CHECK();
     return VKX_OK;
 }
@@ -276,7 +291,18 @@ hipStream_t vkx_stream_by_id(vkx_ctx *ctx, int id, int *rc)
     hipStream_t &st = ctx->copy_stream[id - VKX_STREAM_COPY_IN];
     if (!st) {
         vkx_device_guard guard(ctx);
-        hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        // the two side streams carry copies and the microsecond kernels that run UNDER a large kernel of the compute stream
+        // (carry resolution of the numpy streams, cell setup of the chain): highest priority, so that their few workgroups
+        // are placed as soon as any CU has room instead of after the large kernel has drained
+        static const bool prio = [] { const char *e = getenv("VKX_SIDE_PRIORITY"); return !(e && e[0] == '0'); }();
+        int least = 0, greatest = 0;
+        hipError_t e = hipErrorUnknown;
+        if (prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+            e = hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        }
         if (e != hipSuccess) {
             vkx_set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
             *rc = VKX_ERR_HIP;
@@ -386,6 +412,15 @@ int vkx_stream_order(vkx_ctx *ctx, hipStream_t later, hipStream_t earlier)
     return VKX_OK;
 }
 
+VKX_EXPORT int vkx_chain_lattices_ready(vkx_ctx *ctx)
+{
+    VKX_REQUIRE(ctx != nullptr, "ctx is NULL");
+    vkx_device_guard guard(ctx);
+    if (!ctx->lattices_ready) VKX_HIP(hipEventCreateWithFlags(&ctx->lattices_ready, hipEventDisableTiming));
+    VKX_HIP(hipEventRecord(ctx->lattices_ready, ctx->stream));
+    return VKX_OK;
+}
+
 VKX_EXPORT int vkx_ctx_sync_stream(vkx_ctx *ctx, int stream)
 {
     VKX_REQUIRE(ctx != nullptr, "ctx is NULL");
@@ -438,9 +473,9 @@ static hipEvent_t take_event(vkx_ctx *ctx)
     return e;
 }
 
-vkx_timed::vkx_timed(vkx_ctx *c, const char *kernel_name) : guard(c), ctx(c), slot(-1)
+vkx_timed::vkx_timed(vkx_ctx *c, const char *kernel_name, bool major) : guard(c), ctx(c), slot(-1)
 {
-    if (!ctx || !ctx->timing) return;
+    if (!ctx || !ctx->timing || (ctx->timing == 2 && !major)) return;
     int id = -1;
     for (size_t i = 0; i < ctx->timing_names.size(); i++)
         if (ctx->timing_names[i] == kernel_name) { id = (int)i; break; }
@@ -465,7 +500,7 @@ vkx_timed::~vkx_timed()
 VKX_EXPORT int vkx_ctx_set_timing(vkx_ctx *ctx, int enabled)
 {
     VKX_REQUIRE(ctx != nullptr, "ctx is NULL");
-    ctx->timing = enabled != 0;
+    ctx->timing = enabled == 2 ? 2 : (enabled != 0);
     return VKX_OK;
 }
 

@@ -31,6 +31,7 @@
 #include "vkx_color.h"
 
 #include <float.h>
+#include <memory>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1179,81 +1180,125 @@ __global__ void __launch_bounds__(256) k_chain_prologue(uint32_t *__restrict__ d
 
 } // namespace
 
-// Shared host tail of the two tile kernels: scratch, descriptor upload, cell setup, launch.
-static int launch_tiles(vkx_ctx *ctx, std::vector<ItemDev> &dev, std::vector<int> &prefix, long long ncells, int max_tiles,
-                        bool elements, const std::vector<long long> *noise_row_prefix = nullptr)
+// Shared host side of the two tile kernels.  A PLAN holds the device descriptors of a batch; its three steps may be queued on
+// different streams by the caller (vkx_chain_rgb_batch_np_dev, chain.hip): `setup` (descriptor copy, cell records, tile bins:
+// independent of the pixels and of the noise), `noise_rows` (per image range: after the generator's tile tables) and `tiles`
+// (per image range: the pixel kernel).  Every step launches on ctx->stream as it is when the step is called.
+struct vkx_chain_plan {
+    std::vector<ItemDev> dev;
+    std::vector<int> prefix;                  // first cell of every image in the batch-wide cell table
+    std::vector<long long> row_prefix;        // first (row, tile column) record of every image with tiled noise
+    long long ncells = 0;
+    int max_tiles = 0, slots = 0;
+    bool elements = false, streak = false;
+    const ItemDev *d_items = nullptr;
+    const int *d_cell_prefix = nullptr;
+    TileBin *bins = nullptr;
+    vkc::CellC *cells = nullptr;
+    int *deferred = nullptr;
+    const HsvLut *lut = nullptr;
+};
+
+void vkx_chain_plan_free(vkx_chain_plan *p) { delete p; }
+int vkx_chain_plan_items(const vkx_chain_plan *p) { return (int)p->dev.size(); }
+
+// scratch + descriptors + prologue / cell setup kernels.  The chain mode keeps its own scratch (chain_cells / chain_bins /
+// chain_misc): its setup may run on a side stream while other entry points use the shared slots on the compute stream.
+int vkx_chain_plan_setup(vkx_ctx *ctx, vkx_chain_plan *p)
 {
-    const int n_items = (int)dev.size();
+    const int n_items = (int)p->dev.size();
     int rc;
+    vkx_scratch *s_cells = p->elements ? &ctx->cells : &ctx->chain_cells;
+    vkx_scratch *s_bins = p->elements ? &ctx->owner : &ctx->chain_bins;
+    vkx_scratch *s_misc = p->elements ? &ctx->misc : &ctx->chain_misc;
     // device scratch: cell table, tile bins, item descriptors + prefix arrays, HSV tables
-    const size_t cells_bytes = sizeof(vkc::CellC) * (size_t)ncells;   // then the deferred list: count + ids
-    if ((rc = vkx_scratch_reserve(ctx, &ctx->cells, cells_bytes + sizeof(int) * ((size_t)ncells + 1)))) return rc;
-    const int slots = ((max_tiles + 7) / 8) * 8;          // tile slots per image in the launch grid
-    const size_t nbins = (size_t)slots * n_items;
+    const size_t cells_bytes = sizeof(vkc::CellC) * (size_t)p->ncells;   // then the deferred list: count + ids
+    if ((rc = vkx_scratch_reserve(ctx, s_cells, cells_bytes + sizeof(int) * ((size_t)p->ncells + 1)))) return rc;
+    p->slots = ((p->max_tiles + 7) / 8) * 8;              // tile slots per image in the launch grid
+    const size_t nbins = (size_t)p->slots * n_items;
     if (n_items > 65535) return VKX_ERR_UNSUPPORTED;      // gridDim.y
-    if ((rc = vkx_scratch_reserve(ctx, &ctx->owner, sizeof(TileBin) * nbins))) return rc;
-    const size_t items_bytes = sizeof(ItemDev) * (size_t)n_items, prefix_bytes = sizeof(int) * prefix.size();
+    if ((rc = vkx_scratch_reserve(ctx, s_bins, sizeof(TileBin) * nbins))) return rc;
+    const size_t items_bytes = sizeof(ItemDev) * (size_t)n_items, prefix_bytes = sizeof(int) * p->prefix.size();
     const size_t items_off = 0, prefix_off = (items_bytes + 255) & ~(size_t)255;
     const size_t misc_bytes = prefix_off + prefix_bytes;
-    if ((rc = vkx_scratch_reserve(ctx, &ctx->misc, misc_bytes))) return rc;
-    const HsvLut *lut = nullptr;
-    if (!elements && (rc = vkx_hsv_tables(ctx, (const void **)&lut))) return rc;
-    unsigned char *misc = (unsigned char *)ctx->misc.ptr;
+    if ((rc = vkx_scratch_reserve(ctx, s_misc, misc_bytes))) return rc;
+    if (!p->elements && (rc = vkx_hsv_tables(ctx, (const void **)&p->lut))) return rc;
+    unsigned char *misc = (unsigned char *)s_misc->ptr;
     // the descriptors travel through the ctx's page-locked ring: the copy is queued and the launch returns without a
     // stream synchronisation (host-array pipelines keep several launches in flight)
     void *ring = nullptr;
     if ((rc = vkx_desc_ring_take(ctx, misc_bytes, &ring))) return rc;
-    memcpy((unsigned char *)ring + items_off, dev.data(), items_bytes);
-    memcpy((unsigned char *)ring + prefix_off, prefix.data(), prefix_bytes);
-    const ItemDev *d_items = (const ItemDev *)(misc + items_off);
-    const int *d_cell_prefix = (const int *)(misc + prefix_off);
-    TileBin *bins = (TileBin *)ctx->owner.ptr;
-    vkc::CellC *cells = (vkc::CellC *)ctx->cells.ptr;
-    int *deferred = (int *)((unsigned char *)ctx->cells.ptr + cells_bytes);
+    memcpy((unsigned char *)ring + items_off, p->dev.data(), items_bytes);
+    memcpy((unsigned char *)ring + prefix_off, p->prefix.data(), prefix_bytes);
+    p->d_items = (const ItemDev *)(misc + items_off);
+    p->d_cell_prefix = (const int *)(misc + prefix_off);
+    p->bins = (TileBin *)s_bins->ptr;
+    p->cells = (vkc::CellC *)s_cells->ptr;
+    p->deferred = (int *)((unsigned char *)s_cells->ptr + cells_bytes);
     {
         void *ring_dev = nullptr;
         VKX_HIP(hipHostGetDevicePointer(&ring_dev, ring, 0));
         const size_t n_words = (misc_bytes + 3) / 4;
+        VKX_TIMED(ctx, "k_chain_prologue");
         k_chain_prologue<<<vkx_blocks(std::max(n_words, nbins), 256), 256, 0, ctx->stream>>>((uint32_t *)misc, (const uint32_t *)ring_dev,
-                                                                                            (unsigned)n_words, bins, (unsigned)nbins, deferred);
+                                                                                            (unsigned)n_words, p->bins, (unsigned)nbins, p->deferred);
         VKX_LAUNCH_CHECK();
     }
-    { VKX_TIMED(ctx, "k_chain_setup"); k_chain_setup<<<vkx_blocks((size_t)ncells, 256), 256, 0, ctx->stream>>>(d_items, d_cell_prefix, n_items, (int)ncells, slots, cells, bins, deferred); }
+    { VKX_TIMED(ctx, "k_chain_setup"); k_chain_setup<<<vkx_blocks((size_t)p->ncells, 256), 256, 0, ctx->stream>>>(p->d_items, p->d_cell_prefix, n_items, (int)p->ncells, p->slots, p->cells, p->bins, p->deferred); }
     VKX_LAUNCH_CHECK();
-    { VKX_TIMED(ctx, "k_chain_setup_svd"); k_chain_setup_svd<<<128, 64, 0, ctx->stream>>>(d_items, d_cell_prefix, n_items, cells, deferred); }
+    { VKX_TIMED(ctx, "k_chain_setup_svd"); k_chain_setup_svd<<<128, 64, 0, ctx->stream>>>(p->d_items, p->d_cell_prefix, n_items, p->cells, p->deferred); }
     VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
+// the (row, tile column) records of the images [first, first + count) whose noise is a generator's tile buffer
+int vkx_chain_plan_noise_rows(vkx_ctx *ctx, vkx_chain_plan *p, int first, int count)
+{
+    if (p->row_prefix.empty() || count <= 0) return VKX_OK;
+    long long most = 0;                      // records of the largest image of the range
+    for (int i = first; i < first + count; i++) most = std::max(most, p->row_prefix[i + 1] - p->row_prefix[i]);
+    if (most <= 0) return VKX_OK;
+    VKX_TIMED(ctx, "k_chain_noise_rows");
+    k_chain_noise_rows<<<dim3(vkx_blocks((size_t)most, 256), count), 256, 0, ctx->stream>>>(p->d_items + first);
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
+// the pixel kernel over the images [first, first + count)
+int vkx_chain_plan_tiles(vkx_ctx *ctx, vkx_chain_plan *p, int first, int count)
+{
+    if (count <= 0) return VKX_OK;
     // profiling aids: VKX_FUSED_PHASES=1|2 stops the kernel after phase A | C+D, 10..13 inside phase A (tools/phases_a.sh),
     // 20 writes the horizontal sums of the centre row instead of the finished pixel
     static const int phase_limit = [] { const char *e = getenv("VKX_FUSED_PHASES"); return e ? atoi(e) : 0; }();
-    if (noise_row_prefix && noise_row_prefix->back() > 0) {
-        VKX_TIMED(ctx, "k_chain_noise_rows");
-        long long most = 0;                      // records of the largest image
-        for (int i = 0; i < n_items; i++) most = std::max(most, (*noise_row_prefix)[i + 1] - (*noise_row_prefix)[i]);
-        k_chain_noise_rows<<<dim3(vkx_blocks((size_t)most, 256), n_items), 256, 0, ctx->stream>>>(d_items);
-        VKX_LAUNCH_CHECK();
-    }
-    if (elements) {
-        { VKX_TIMED(ctx, "k_tile_remap"); k_tile_remap<<<dim3(slots, n_items), NTHREADS, kFusedLds, ctx->stream>>>(d_items, cells, bins); }
+    const ItemDev *items = p->d_items + first;
+    const TileBin *bins = p->bins + (size_t)first * p->slots;      // bins are laid out [image][slot]
+    const dim3 grid(p->slots, count);
+    if (p->elements) {
+        VKX_TIMED(ctx, "k_tile_remap");
+        k_tile_remap<<<grid, NTHREADS, kFusedLds, ctx->stream>>>(items, p->cells, bins);
     } else {
-        bool streak = false;
-        for (const ItemDev &d : dev) streak = streak || d.streak_on != 0;
-        VKX_TIMED(ctx, "k_chain_fused");
-        if (streak) k_chain_fused<true><<<dim3(slots, n_items), NTHREADS, kFusedLds, ctx->stream>>>(d_items, cells, bins, lut, phase_limit);
-        else k_chain_fused<false><<<dim3(slots, n_items), NTHREADS, kFusedLds, ctx->stream>>>(d_items, cells, bins, lut, phase_limit);
+        VKX_TIMED_MAJOR(ctx, "k_chain_fused");
+        if (p->streak) k_chain_fused<true><<<grid, NTHREADS, kFusedLds, ctx->stream>>>(items, p->cells, bins, p->lut, phase_limit);
+        else k_chain_fused<false><<<grid, NTHREADS, kFusedLds, ctx->stream>>>(items, p->cells, bins, p->lut, phase_limit);
     }
     VKX_LAUNCH_CHECK();
     return VKX_OK;
 }
 
-// Returns VKX_ERR_UNSUPPORTED (without setting an error) when the batch has a shape the fused path does not
-// take; the caller then runs the per-stage kernels.
-int vkx_chain_fused_try(vkx_ctx *ctx, const vkx_chain_item *items, int n_items)
+// Builds the plan of a chain batch.  Returns VKX_ERR_UNSUPPORTED (without setting an error) when the batch has a shape the
+// fused path does not take; the caller then runs the per-stage kernels.
+int vkx_chain_plan_build(vkx_ctx *ctx, const vkx_chain_item *items, int n_items, vkx_chain_plan **out)
 {
+    *out = nullptr;
     if (n_items <= 0) return VKX_OK;
-    std::vector<ItemDev> dev(n_items);
-    std::vector<int> prefix((size_t)n_items + 1);   // first cell of every image in the batch-wide cell table
-    int *cell_prefix = prefix.data();
-    std::vector<long long> row_prefix((size_t)n_items + 1, 0);   // first (row, tile column) record of every image with tiled noise
+    std::unique_ptr<vkx_chain_plan> plan(new vkx_chain_plan());
+    std::vector<ItemDev> &dev = plan->dev;
+    dev.resize(n_items);
+    plan->prefix.resize((size_t)n_items + 1);
+    int *cell_prefix = plan->prefix.data();
+    std::vector<long long> &row_prefix = plan->row_prefix;
+    row_prefix.assign((size_t)n_items + 1, 0);
     long long tiles = 0, ncells = 0;
     int max_tiles = 0;
     for (int i = 0; i < n_items; i++) {
@@ -1263,6 +1308,7 @@ int vkx_chain_fused_try(vkx_ctx *ctx, const vkx_chain_item *items, int n_items)
         if (it.rows < 2 || it.cols < 2) return VKX_ERR_UNSUPPORTED;
         if (it.blur_ksize > 1 && (it.dh == 1 || it.dw == 1)) return VKX_ERR_UNSUPPORTED; // kernel collapses per axis
         ItemDev &d = dev[i];
+        memset(&d, 0, sizeof(d));
         d.src = it.src; d.dst = it.dst; d.noise = it.noise; d.sv = it.src_vertices; d.dv = it.dst_vertices;
         d.sstride = it.src_stride; d.dstride = it.dst_stride; d.nstride = it.noise_stride_el;
         d.noise_table = nullptr; d.noise_tiled = 0; d.noise_tiles = 0; d.noise_slot = 0; d.noise_tiles_per_sample = 0.f;
@@ -1309,16 +1355,72 @@ int vkx_chain_fused_try(vkx_ctx *ctx, const vkx_chain_item *items, int n_items)
         if (d.tiles_x * d.tiles_y > max_tiles) max_tiles = d.tiles_x * d.tiles_y;
         ncells += (long long)(it.rows - 1) * (it.cols - 1);
         if (tiles > 0x3fffffff || ncells > 0x3fffffff) return VKX_ERR_UNSUPPORTED;
+        plan->streak = plan->streak || d.streak_on != 0;
     }
     cell_prefix[n_items] = (int)ncells;
+    if (n_items > 65535) return VKX_ERR_UNSUPPORTED;
     if (row_prefix[n_items] > 0) {
         int rc = vkx_scratch_reserve(ctx, &ctx->noise_rows, (size_t)row_prefix[n_items] * sizeof(uint2));
         if (rc) return rc;
         for (int i = 0; i < n_items; i++)
             if (dev[i].noise_tiled) dev[i].noise_rows = (const uint2 *)ctx->noise_rows.ptr + row_prefix[i];
+    } else {
+        row_prefix.clear();
     }
+    plan->ncells = ncells;
+    plan->max_tiles = max_tiles;
+    *out = plan.release();
+    return VKX_OK;
+}
 
-    return launch_tiles(ctx, dev, prefix, ncells, max_tiles, false, &row_prefix);
+// The cell setup of a chain batch depends on nothing but the lattices: it runs on the context's side stream, after the pixel
+// kernel of the previous chain call (which reads the scratch it writes) and after the point of the compute stream the caller
+// marked with vkx_chain_lattices_ready (by default: after everything queued on the compute stream before this call), so that it
+// shares the device with whatever large kernel the compute stream is running (a composite, the generator's draw pass).
+int vkx_chain_plan_setup_aside(vkx_ctx *ctx, vkx_chain_plan *p, hipEvent_t *done)
+{
+    static const bool aside = [] { const char *e = getenv("VKX_CHAIN_SETUP_ASIDE"); return !(e && e[0] == '0'); }();
+    *done = nullptr;
+    if (!aside) return vkx_chain_plan_setup(ctx, p);
+    int rc;
+    hipStream_t main_stream = ctx->stream;
+    hipStream_t side = vkx_stream_by_id(ctx, VKX_STREAM_COPY_OUT, &rc);
+    if (rc) return rc;
+    vkx_device_guard guard(ctx);
+    if (ctx->lattices_ready) VKX_HIP(hipStreamWaitEvent(side, ctx->lattices_ready, 0));
+    else if ((rc = vkx_stream_order(ctx, side, main_stream))) return rc;
+    if (ctx->chain_done) VKX_HIP(hipStreamWaitEvent(side, ctx->chain_done, 0));
+    ctx->stream = side;
+    rc = vkx_chain_plan_setup(ctx, p);
+    ctx->stream = main_stream;
+    if (rc) return rc;
+    if (!ctx->chain_setup_done) VKX_HIP(hipEventCreateWithFlags(&ctx->chain_setup_done, hipEventDisableTiming));
+    VKX_HIP(hipEventRecord(ctx->chain_setup_done, side));
+    *done = ctx->chain_setup_done;       // the caller's pixel kernels wait for it (hipStreamWaitEvent) where they are queued
+    return VKX_OK;
+}
+
+// the pixel kernel of a chain call has been queued on `stream`: the next call's setup waits for it
+int vkx_chain_mark_done(vkx_ctx *ctx, hipStream_t stream)
+{
+    if (!ctx->chain_done) VKX_HIP(hipEventCreateWithFlags(&ctx->chain_done, hipEventDisableTiming));
+    VKX_HIP(hipEventRecord(ctx->chain_done, stream));
+    return VKX_OK;
+}
+
+int vkx_chain_fused_try(vkx_ctx *ctx, const vkx_chain_item *items, int n_items)
+{
+    vkx_chain_plan *raw = nullptr;
+    int rc = vkx_chain_plan_build(ctx, items, n_items, &raw);
+    if (rc || !raw) return rc;
+    std::unique_ptr<vkx_chain_plan, void (*)(vkx_chain_plan *)> plan(raw, vkx_chain_plan_free);
+    hipEvent_t setup_done = nullptr;
+    if ((rc = vkx_chain_plan_setup_aside(ctx, raw, &setup_done))) return rc;
+    if (setup_done) VKX_HIP(hipStreamWaitEvent(ctx->stream, setup_done, 0));      // (the device copy of the descriptors is the prologue's)
+    if ((rc = vkx_chain_plan_noise_rows(ctx, raw, 0, n_items))) return rc;
+    if ((rc = vkx_chain_plan_tiles(ctx, raw, 0, n_items))) return rc;
+    vkx_device_guard guard(ctx);
+    return vkx_chain_mark_done(ctx, ctx->stream);
 }
 
 // vkx_grid_remap through the tile kernel; VKX_ERR_UNSUPPORTED (no error set) for shapes it does not take.
@@ -1327,9 +1429,11 @@ int vkx_tile_remap_try(vkx_ctx *ctx, const vkx_elem *elems, int n_elems, int sh,
 {
     if (n_elems < 1 || n_elems > 4 || rows < 2 || cols < 2) return VKX_ERR_UNSUPPORTED;
     if (sh > 32767 || sw > 32767 || dh > 32767 || dw > 32767 || sh < 1 || sw < 1 || dh < 1 || dw < 1) return VKX_ERR_UNSUPPORTED;
-    std::vector<ItemDev> dev(1);
-    std::vector<int> prefix(2);
-    ItemDev &d = dev[0];
+    vkx_chain_plan plan;
+    plan.dev.resize(1);
+    plan.prefix.resize(2);
+    std::vector<int> &prefix = plan.prefix;
+    ItemDev &d = plan.dev[0];
     memset(&d, 0, sizeof(d));
     d.sv = src_vertices; d.dv = dst_vertices;
     d.sh = sh; d.sw = sw; d.dh = dh; d.dw = dw; d.rows = rows; d.cols = cols;
@@ -1349,5 +1453,10 @@ int vkx_tile_remap_try(vkx_ctx *ctx, const vkx_elem *elems, int n_elems, int sh,
     const long long ncells = (long long)(rows - 1) * (cols - 1);
     if ((long long)d.tiles_x * d.tiles_y > 0x3fffffff || ncells > 0x3fffffff) return VKX_ERR_UNSUPPORTED;
     prefix[0] = 0; prefix[1] = (int)ncells;
-    return launch_tiles(ctx, dev, prefix, ncells, d.tiles_x * d.tiles_y, true);
+    plan.elements = true;
+    plan.ncells = ncells;
+    plan.max_tiles = d.tiles_x * d.tiles_y;
+    int rc = vkx_chain_plan_setup(ctx, &plan);
+    if (rc) return rc;
+    return vkx_chain_plan_tiles(ctx, &plan, 0, 1);
 }

@@ -1470,7 +1470,7 @@ static int np_chunk_front(vkx_ctx *ctx, NpChunk &c)
     }
     if (np_compact_records(kind)) {
         // (the emitter only decides how a draw becomes an int16 step: the same for the three int16 kinds)
-        VKX_TIMED(ctx, "k_np_draw");
+        VKX_TIMED_MAJOR(ctx, "k_np_draw");
         const unsigned wgc = (unsigned)((total_tiles + (long long)kDrawWaves * tiles_per_wave - 1) / ((long long)kDrawWaves * tiles_per_wave));
         k_np_draw_compact<EmitI16><<<wgc, 64 * kDrawWaves, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, res, tabs);
         VKX_LAUNCH_CHECK();
@@ -1478,7 +1478,7 @@ static int np_chunk_front(vkx_ctx *ctx, NpChunk &c)
     }
     uint64_t *rmask = (uint64_t *)(base + c.o_rmask);
     void *rval = base + c.o_rval;
-    VKX_TIMED(ctx, "k_np_draw");
+    VKX_TIMED_MAJOR(ctx, "k_np_draw");
     if (kind == VKX_NP_SPECKLE_U8)
         k_np_draw<EmitSpeckle><<<wg, 256, 0, ctx->stream>>>(dj, n_jobs, total_tiles, states, info, (double *)rval, rmask, res, tabs);
     else if (kind == VKX_NP_NORMAL_ADD_U8)
@@ -1567,9 +1567,9 @@ static int np_chunk_back(vkx_ctx *ctx, NpChunk &c)
 // between two scratch slots, and the ctx stream continues after the last chunk has been placed.
 constexpr int kChunkJobs = 32;
 
-VKX_EXPORT int vkx_np_draw_batch_dev(vkx_ctx *ctx, const vkx_np_job *jobs, int n_jobs, vkx_np_result *results_host)
+int vkx_np_jobs_check(const vkx_np_job *jobs, int n_jobs, const vkx_np_result *results_host)
 {
-    VKX_REQUIRE(ctx && jobs && results_host, "NULL argument");
+    VKX_REQUIRE(jobs && results_host, "NULL argument");
     VKX_REQUIRE(n_jobs >= 1 && n_jobs <= 65535, "1 .. 65535 jobs per call");
     const int kind = jobs[0].kind & 0xff;
     const bool uniform = kind == VKX_NP_CHOICE3_U8 || kind == VKX_NP_IMPULSE_U8;
@@ -1602,9 +1602,50 @@ VKX_EXPORT int vkx_np_draw_batch_dev(vkx_ctx *ctx, const vkx_np_job *jobs, int n
         if (!uniform) VKX_REQUIRE(j.scale >= 0.0 && j.scale < 400.0, "scale outside [0, 400)");   // |z| < 40: int16 holds it
         VKX_REQUIRE(np_tiles_for(j, uniform) <= 262144, "stream too long for one job (2.6e8 samples)");
     }
+    return VKX_OK;
+}
+
+// One chunk of checked jobs for callers that pipeline the passes themselves (vkx_chain_rgb_batch_np_dev, chain.hip).
+struct vkx_np_chunk { NpChunk c; };
+
+int vkx_np_chunk_begin(vkx_ctx *ctx, const vkx_np_job *jobs, int n_jobs, vkx_np_result *results_host, int slot, vkx_np_chunk **out)
+{
+    *out = nullptr;
     const NpTabs *tabs = nullptr;
     int rc = np_tables(ctx, &tabs);
     if (rc) return rc;
+    vkx_np_chunk *h = new (std::nothrow) vkx_np_chunk();
+    if (!h) { vkx_set_error("out of host memory"); return VKX_ERR_NOMEM; }
+    NpChunk &c = h->c;
+    c.jobs = jobs; c.n_jobs = n_jobs;
+    c.kind = jobs[0].kind & 0xff;
+    c.uniform = c.kind == VKX_NP_CHOICE3_U8 || c.kind == VKX_NP_IMPULSE_U8;
+    c.slot = slot & 1;
+    c.results_host = results_host;
+    c.tabs = tabs;
+    vkx_device_guard guard(ctx);
+    if ((rc = np_chunk_prepare(ctx, c)) || (rc = np_chunk_front(ctx, c))) { delete h; return rc; }
+    *out = h;
+    return VKX_OK;
+}
+
+int vkx_np_chunk_finish(vkx_ctx *ctx, vkx_np_chunk *h)
+{
+    vkx_device_guard guard(ctx);
+    return np_chunk_back(ctx, h->c);
+}
+
+void vkx_np_chunk_free(vkx_np_chunk *h) { delete h; }
+
+VKX_EXPORT int vkx_np_draw_batch_dev(vkx_ctx *ctx, const vkx_np_job *jobs, int n_jobs, vkx_np_result *results_host)
+{
+    VKX_REQUIRE(ctx && jobs && results_host, "NULL argument");
+    int rc = vkx_np_jobs_check(jobs, n_jobs, results_host);
+    if (rc) return rc;
+    const int kind = jobs[0].kind & 0xff;
+    const bool uniform = kind == VKX_NP_CHOICE3_U8 || kind == VKX_NP_IMPULSE_U8;
+    const NpTabs *tabs = nullptr;
+    if ((rc = np_tables(ctx, &tabs))) return rc;
     vkx_device_guard guard(ctx);
     static const bool pipelined = [] { const char *e = getenv("VKX_NP_PIPELINE"); return !(e && e[0] == '0'); }();
     // (tile buffers: what follows the draw pass is a few microseconds per stream and no scratch grows with the records -- one chunk)

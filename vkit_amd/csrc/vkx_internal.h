@@ -57,6 +57,11 @@ struct vkx_ctx {
     bool tables_ready = false;
     vkx_scratch stage[6]; // staging planes of the host-pointer entry points
     vkx_scratch chain[3]; // ping-pong planes of the batched chain entry point; [2]: a tile buffer expanded to its int16 plane
+    vkx_scratch chain_cells, chain_bins, chain_misc;   // cell records / tile bins / descriptors of the fused chain: its setup kernels
+                                                       // run on the side stream while the shared slots above serve the compute stream
+    hipEvent_t chain_setup_done = nullptr; // the side stream past the setup kernels of the current chain call
+    hipEvent_t chain_done = nullptr;       // the pixel kernel of the last chain call (reads the three slots above)
+    hipEvent_t lattices_ready = nullptr;   // vkx_chain_lattices_ready: the point of the compute stream the lattices are complete at
     vkx_scratch noise_table;          // int16 [65536] inverse-CDF table of vkx_noise_normal_i16 for noise_table_std
     double noise_table_std = 0.0;
     bool noise_table_fits8 = false;
@@ -89,7 +94,7 @@ struct vkx_ctx {
     unsigned long resize_clock = 0;
 
     // Optional per-kernel timing with HIP events recorded on the launch stream (vkx_ctx_set_timing).
-    bool timing = false;
+    int timing = 0;                           // 0 off, 1 every kernel, 2 only the large kernels (VKX_TIMED_MAJOR)
     struct TimedLaunch { int name_id; hipEvent_t start, stop; };
     std::vector<TimedLaunch> launches;       // recorded, not yet folded into the totals
     std::vector<hipEvent_t> event_pool;      // reusable events
@@ -116,10 +121,11 @@ struct vkx_timed {
     vkx_device_guard guard;
     vkx_ctx *ctx;
     int slot;
-    vkx_timed(vkx_ctx *ctx, const char *kernel_name);
+    vkx_timed(vkx_ctx *ctx, const char *kernel_name, bool major = false);
     ~vkx_timed();
 };
 #define VKX_TIMED(ctx, name) vkx_timed timed_scope__(ctx, name)
+#define VKX_TIMED_MAJOR(ctx, name) vkx_timed timed_scope__(ctx, name, true)
 
 int vkx_scratch_reserve(vkx_ctx *ctx, vkx_scratch *s, size_t bytes);
 // `bytes` of page-locked host memory that stays untouched until everything queued on ctx->stream so far has run
@@ -231,6 +237,21 @@ __device__ __forceinline__ float sample_f32(PTR src, int sh, int sw, ptrdiff_t s
 int vkx_hsv_tables(vkx_ctx *ctx, const void **out);                      // photo.hip
 int vkx_gaussian_kernel_q8_host(int n, double sigma, uint16_t *kq);      // photo.hip
 int vkx_chain_fused_try(vkx_ctx *ctx, const vkx_chain_item *items, int n_items);  // fused.hip
+// the steps of the fused chain, for callers that queue them on streams of their choice (chain.hip); fused.hip
+struct vkx_chain_plan;
+int vkx_chain_plan_build(vkx_ctx *ctx, const vkx_chain_item *items, int n_items, vkx_chain_plan **out);   // VKX_ERR_UNSUPPORTED: not for the fused path
+void vkx_chain_plan_free(vkx_chain_plan *p);
+int vkx_chain_plan_setup_aside(vkx_ctx *ctx, vkx_chain_plan *p, hipEvent_t *done);      // side stream; *done (may be NULL: ran on ctx->stream): what the pixel kernels wait for
+int vkx_chain_plan_noise_rows(vkx_ctx *ctx, vkx_chain_plan *p, int first, int count);   // on ctx->stream
+int vkx_chain_plan_tiles(vkx_ctx *ctx, vkx_chain_plan *p, int first, int count);        // on ctx->stream
+int vkx_chain_mark_done(vkx_ctx *ctx, hipStream_t stream);
+// one chunk of VKX_NP_NORMAL_TILES jobs (nprand.hip): begin = tile states + draw pass, finish = carries, walks, tables; each on
+// ctx->stream as it is when called.  `slot`: which of the two tile-array scratch slots the chunk uses.
+struct vkx_np_chunk;
+int vkx_np_jobs_check(const vkx_np_job *jobs, int n_jobs, const vkx_np_result *results_host);
+int vkx_np_chunk_begin(vkx_ctx *ctx, const vkx_np_job *jobs, int n_jobs, vkx_np_result *results_host, int slot, vkx_np_chunk **out);
+int vkx_np_chunk_finish(vkx_ctx *ctx, vkx_np_chunk *c);
+void vkx_np_chunk_free(vkx_np_chunk *c);
 int vkx_tile_remap_try(vkx_ctx *ctx, const vkx_elem *elems, int n_elems, int sh, int sw, const int32_t *src_vertices,
                        const int32_t *dst_vertices, int rows, int cols, int dh, int dw);  // fused.hip
 // the tile buffer of a VKX_NP_NORMAL_TILES job of n samples (nprand.hip; read by the fused chain kernel)
