@@ -247,3 +247,65 @@ def test_operator_api_on_the_overlapped_path():
     with HostPipeline() as pipe:
         with pytest.raises(TypeError):
             pipe.submit_distortion(D.rotate, {'angle': 3}, image=jobs[0][2])
+
+
+def test_joint_stream_and_chain_call_in_chunks():
+    """``vkx_chain_rgb_batch_np_dev``: 20 tile-buffer streams (two chunks inside the library: post passes and cell setup on the
+    side streams) between images that carry a caller's plane, no noise at all, or a streak -- the same pixels as the two separate
+    calls (``joint_call=False``) and as the oracle fed numpy's own planes; every run repeats them."""
+    from vkit_amd.batch import ChainBatch
+    from vkit_amd.mechanism.distortion.photometric.streak import LineStreakConfig
+    streak = LineStreakConfig(thickness=2, gap=9, dash_thickness=3, dash_gap=5, alpha=0.6, color=(10, 200, 30), enable_vert=True,
+                              enable_hori=True)
+    geoms = [(150 + 7 * k, 200 - 5 * k, 12 + k % 5, 4.0 + k % 3, 40 + k) for k in range(6)]
+    grids = []
+    for h, w, step, amp, seed in geoms:
+        sv, dv, dshape = synthetic_grid(h, w, step, amp, seed=seed)
+        image = default_rng(70 + seed).integers(0, 256, (h, w, 3), dtype=np.uint8)
+        mx, my = O.grid_to_map(sv, dv, dshape)
+        grids.append((image, _state(sv, dv, dshape), dshape, O.remap(image, mx, my)))
+
+    def build(joint):
+        batch = ChainBatch()
+        batch.joint_call = joint
+        wants = []
+        for k in range(26):
+            image, st, dshape, remapped = grids[k % len(grids)]
+            shape = tuple(dshape) + (3,)
+            if k in (0, 9, 25):         # no noise member / a caller's plane: no stream job
+                if k == 9:
+                    plane = np.round(default_rng(3000 + k).normal(0, 7.0, shape)).astype(np.int16)
+                    batch.add(image, st, blur_sigma=1.0, hue_delta=11, noise=plane)
+                    wants.append(O.add_noise_i16(O.color_shift_rgb(O.gaussian_blur(remapped, 5, 1.0), 11), plane))
+                else:
+                    batch.add(image, st, blur_sigma=None, hue_delta=None)
+                    wants.append(remapped)
+                continue
+            blur = 1.0 if k % 3 else None
+            hue = 37 if k % 4 else None
+            base = remapped
+            if blur:
+                base = O.gaussian_blur(base, 5, blur)
+            if hue:
+                base = O.color_shift_rgb(base, hue)
+            plane = np.round(default_rng(3000 + k).normal(0, 9.0, shape)).astype(np.int16)
+            want = O.add_noise_i16(base, plane)
+            sk = streak if k == 13 else None
+            if sk:
+                want = O.line_streak(want, 2, 9, 3, 5, (10, 200, 30), 0.6, True, True)
+            batch.add(image, st, blur_sigma=blur, hue_delta=hue, noise_std=9.0, noise_rng=default_rng(3000 + k), streak=sk)
+            wants.append(want)
+        return batch, wants
+
+    joint, wants = build(True)
+    apart, _ = build(False)
+    for _ in range(3):
+        joint.run()
+    apart.run()
+    assert joint.stream_fallbacks == 0
+    for k, want in enumerate(wants):
+        got = joint.result(k)
+        assert (got == want).all(), k
+        assert (apart.result(k) == got).all(), k
+    joint.close()
+    apart.close()

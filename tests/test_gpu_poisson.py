@@ -15,7 +15,7 @@ def _check(img, seed=11, skip=3):
     r_np.random(skip); r_dev.random(skip)          # a stream that is not at its origin
     want = np.clip(r_np.poisson(img.astype(np.float32)), 0, 255).astype(np.uint8)
     got = N.np_poisson_u8(img, r_dev)
-    assert got is not None, f'device path declined: flags {N.np_poisson_flags}'
+    assert got is not None, f'device path declined: flags {N.np_poisson_last_flags()}'
     np.testing.assert_array_equal(np.asarray(N.host_array(got)), want)
     assert r_np.bit_generator.state == r_dev.bit_generator.state
     assert r_np.random() == r_dev.random()
@@ -94,7 +94,7 @@ from vkit_amd.mechanism import distortion as D
 img = default_rng(5).integers(0, 256, (300, 400, 3), dtype=np.uint8)
 r = default_rng(9)
 before = r.bit_generator.state
-assert N.np_poisson_u8(img, r) is None and N.np_poisson_flags & 4, N.np_poisson_flags
+assert N.np_poisson_u8(img, r) is None and N.np_poisson_last_flags() & 4, N.np_poisson_last_flags()
 assert r.bit_generator.state == before
 want = np.clip(default_rng(9).poisson(img.astype(np.float32)), 0, 255).astype(np.uint8)
 out = D.poisson_noise.distort({}, image=Image(mat=img), rng=default_rng(9)).image

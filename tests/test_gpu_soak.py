@@ -1,0 +1,64 @@
+"""Bounded soaks inside ``-m gpu``: the randomized end-to-end comparisons of tools/soak*.py (the runs that found the project's one
+real parity bug, > 128 MLS handles in round 2) with fixed seeds and a budget of seconds each, so that the strongest parity
+evidence also runs on a box the builder does not control.  Every soak compares the device path with the oracle / numpy itself /
+the host restatement on inputs drawn from its seed and exits non-zero on the first mismatch; the budgets bound the TIME, so the
+number of cases depends on the box (printed, and collected in gpurun_out/soak_summary.json when that directory exists).
+
+Reference: the policy table the soaks sample from, vkit/mechanism/distortion_policy/random_distortion.py:395-671."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+# (script, arguments, what it covers)
+SOAKS = [
+    ('soak3.py', ['8', '501'], 'ordered polygon paint + composite layer lists on every destination type vs the sequential oracle fills'),
+    ('soak4.py', ['14', '502'], 'the ten geometric operators through DistortionPolicy.distort (Image + Mask + ScoreMap + points) vs the oracle'),
+    ('soak5.py', ['14', '503'], 'the seventeen deterministic photometric operators through DistortionPolicy.distort vs the oracle'),
+    ('soak7.py', ['20', '504'], 'the numpy streams (every kind, 1 .. 150 ragged streams per call, chains with noise_rng) vs numpy itself'),
+    ('soak8.py', ['160'], 'rng.poisson on the device vs numpy: values and stream position; declined images are counted'),
+    ('soak9.py', ['8', '506'], 'fog field and glass_blur shuffle planes vs their host restatements, planes and stream position'),
+]
+
+
+def _record(name, entry):
+    out_dir = os.path.join(ROOT, 'gpurun_out')
+    if not os.path.isdir(out_dir):
+        return
+    path = os.path.join(out_dir, 'soak_summary.json')
+    try:
+        with open(path) as f:
+            data = json.load(f)
+    except Exception:
+        data = {}
+    data[name] = entry
+    with open(path, 'w') as f:
+        json.dump(data, f, indent=1, sort_keys=True)
+
+
+@pytest.mark.parametrize('script,argv,what', SOAKS, ids=[s[0][:-3] for s in SOAKS])
+def test_bounded_soak(script, argv, what):
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', script)] + argv, capture_output=True, text=True,
+                          timeout=240, cwd=ROOT)
+    tail = (proc.stdout.strip().splitlines() or [''])[-1]
+    print(f'{script}: {tail}')
+    assert proc.returncode == 0, f'{script} {argv} ({what}) failed:\n{proc.stdout[-2000:]}\n{proc.stderr[-4000:]}'
+    entry = {'argv': argv, 'covers': what, 'result': tail}
+    if script in ('soak8.py', 'soak9.py'):
+        report = json.loads(tail)
+        entry['result'] = report
+        if script == 'soak8.py':
+            # a declined image (near tie of the PTRS comparison, a start outside its 6-sigma window) falls back to numpy: correct,
+            # and rare -- one image in ~3 000 in the builder's 4 G-element soak
+            assert report['declined'] <= 3, report
+            assert report['elements_equal_to_numpy'] > 0
+        else:
+            assert min(report['equal_to_host_restatement'].values()) > 0, report
+    else:
+        assert ' ok ' in f' {tail} ', tail
+    _record(script[:-3], entry)

@@ -45,7 +45,7 @@ for name, img in cases():
     got = N.np_poisson_u8(img, r_dev, ctx=ctx)
     t_dev = time.perf_counter() - t0
     k = ctx.timings(); ctx.set_timing(False)
-    row = {'case': name, 'n': int(img.size), 'flags': N.np_poisson_flags, 'numpy_ms': round(t_np * 1e3, 2), 'device_ms': round(t_dev * 1e3, 2)}
+    row = {'case': name, 'n': int(img.size), 'flags': N.np_poisson_last_flags(), 'numpy_ms': round(t_np * 1e3, 2), 'device_ms': round(t_dev * 1e3, 2)}
     if got is not None:
         got = np.asarray(N.host_array(got))
         row['equal'] = bool(np.array_equal(got, want))

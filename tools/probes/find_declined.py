@@ -15,8 +15,8 @@ for k in range(3000):
     r = default_rng(seed); r.random(skip)
     got = N.np_poisson_u8(img, r)
     if got is None:
-        print('declined', k, img.shape, 'kind', k % 7, 'flags', N.np_poisson_flags, 'seed', seed, 'skip', skip, 'min/max', int(img.min()), int(img.max()))
+        print('declined', k, img.shape, 'kind', k % 7, 'flags', N.np_poisson_last_flags(), 'seed', seed, 'skip', skip, 'min/max', int(img.min()), int(img.max()))
         # repeat: deterministic?
         r2 = default_rng(seed); r2.random(skip)
-        print('again', N.np_poisson_u8(img, r2) is None, N.np_poisson_flags)
+        print('again', N.np_poisson_u8(img, r2) is None, N.np_poisson_last_flags())
         break

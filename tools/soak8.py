@@ -53,7 +53,7 @@ for k in range(IMAGES):
     got = N.np_poisson_u8(img, r_dev)
     if got is None:
         declined += 1
-        flags_seen[str(N.np_poisson_flags)] = flags_seen.get(str(N.np_poisson_flags), 0) + 1
+        flags_seen[str(N.np_poisson_last_flags())] = flags_seen.get(str(N.np_poisson_last_flags()), 0) + 1
         continue
     want = np.clip(r_np.poisson(img.astype(np.float32)), 0, 255).astype(np.uint8)
     assert np.array_equal(np.asarray(N.host_array(got)), want), f'image {k} {img.shape}: values differ'

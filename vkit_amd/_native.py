@@ -590,6 +590,18 @@ def resident_mode():
     return getattr(_RESIDENT, 'on', False)
 
 
+def device_copy(array, ctx=None):
+    """A fresh DevArray of ``ctx`` holding a copy of ``array`` (numpy: uploaded; DevArray: copied on the device, asynchronously on
+    the compute stream)."""
+    ctx = ctx or (array.ctx if isinstance(array, DevArray) else default_ctx())
+    if not isinstance(array, DevArray):
+        return ctx.to_device(np.ascontiguousarray(array))
+    out = ctx.dev_empty(array.shape, array.dtype)
+    if array.nbytes:
+        check(lib().vkx_memcpy_async(ctx.handle, STREAM_COMPUTE, c_void_p(out.ptr), c_void_p(array.ptr), int(array.nbytes), 2))
+    return out
+
+
 def host_array(a):
     """numpy view of ``a`` (DevArray -> its host copy)."""
     return a.host() if isinstance(a, DevArray) else a
@@ -1417,9 +1429,9 @@ def np_speckle_noise(img, std, rng, ctx=None):
 def np_poisson_u8(img, rng, ctx=None):
     """``clip(rng.poisson(img.astype(float32)), 0, 255).astype(uint8)`` (photometric/noise.py:81-90) with every sample drawn on the
     device from ``rng``'s stream, value for value numpy's (``vkx_np_poisson_u8``), and ``rng`` moved past the draws numpy would have
-    made.  None -- ``rng`` untouched -- when the generator is not PCG64 or the device declines (``np_poisson_flags`` says why): the
-    caller then calls ``rng.poisson`` itself."""
-    global np_poisson_flags
+    made.  None -- ``rng`` untouched -- when the generator is not PCG64 or the device declines (``np_poisson_last_flags()`` says why,
+    per calling thread): the caller then calls ``rng.poisson`` itself."""
+    _poisson_tls.flags = 0
     stream = np_stream(rng)
     if stream is None or img.dtype != np.uint8 or img.size == 0 or img.size > (1 << 30):
         return None
@@ -1430,14 +1442,25 @@ def np_poisson_u8(img, rng, ctx=None):
     ic = (ctypes.c_uint64 * 2)(inc & _M64, inc >> 64)
     consumed, flags = ctypes.c_longlong(0), ctypes.c_uint(0)
     check(call.fn('vkx_np_poisson_u8')(call.ctx.handle, st, ic, call.src(img), int(img.size), dptr, ctypes.byref(consumed), ctypes.byref(flags)))
-    np_poisson_flags = int(flags.value)
+    _poisson_tls.flags = int(flags.value)
     if flags.value:
         return None
     np_consume(rng, consumed.value)
     return dst
 
 
-np_poisson_flags = 0
+_poisson_tls = threading.local()
+
+
+def np_poisson_last_flags() -> int:
+    """VKX_NP_POISSON_* flags of the calling thread's last ``np_poisson_u8`` call (0: the device result stood, or the call never
+    reached the device).  Thread-local: pipelines that draw from several threads do not see each other's refusals."""
+    return getattr(_poisson_tls, 'flags', 0)
+
+
+# fog lattices up to (2^12 + 1)^2 on the device: the context keeps 3 size^2 doubles of level scratch (1.6 GB at level 12) for its
+# lifetime; a page beyond 4096 px per side (level 13: 6.4 GB, level 14: 26 GB) takes the numpy path instead of pinning that
+FOG_DEVICE_MAX_LEVELS = 12
 
 
 def np_fog_mask(shape, roughness, ratio_min, ratio_max, rng, ctx=None):
@@ -1449,7 +1472,7 @@ def np_fog_mask(shape, roughness, ratio_min, ratio_max, rng, ctx=None):
     height, width = int(shape[0]), int(shape[1])
     size = int(2**np.ceil(np.log2(max(height, width))) + 1)
     levels = int(round(np.log2(size - 1))) if size > 2 else 0
-    if np_stream(rng) is None or levels < 1 or levels > 14 or (1 << levels) + 1 != size:
+    if np_stream(rng) is None or levels < 1 or levels > FOG_DEVICE_MAX_LEVELS or (1 << levels) + 1 != size:
         return None
     ctx = ctx or default_ctx()
     corners = np.array([rng.uniform(0.0, 1.0) for _ in range(4)]).astype(np.float32)      # field[0, 0], [0, -1], [-1, -1], [-1, 0]

@@ -131,9 +131,8 @@ def fog_image(config: FogConfig, state, image: Image, rng: Optional[RandomGenera
     assert config.ratio_min < config.ratio_max
     # the lattice levels and the stretch on the device, from the caller's PCG64 stream (vkx_fog_field_f32_dev); None: numpy below
     mask = _native.np_fog_mask(image.shape, config.roughness, config.ratio_min, config.ratio_max, rng)
-    if mask is not None:
-        mask = _native.host_array(mask)
-    else:
+    on_device = mask is not None      # a DevArray: it stays in HBM as the alpha plane of the blend
+    if not on_device:
         mask = generate_diamond_square_mask(image.shape, config.roughness, rng)
         # stretch the field to [ratio_min, ratio_max] (float32 in place, like the reference)
         mask = np.array(mask, dtype=np.float32)
@@ -146,9 +145,14 @@ def fog_image(config: FogConfig, state, image: Image, rng: Optional[RandomGenera
         # the grey fog value is fractional (reference effect.py:194-197): float32(0.2126 R + 0.7152 G + 0.0722 B)
         val = 0.2126 * config.fog_rgb[0] + 0.7152 * config.fog_rgb[1] + 0.0722 * config.fog_rgb[2]
         return attrs.evolve(image, mat=_native.fog_f32(image.arr, mask, [np.float32(val)]))
-    mat = np.array(image.mat)
+    if on_device:
+        mat = _native.device_copy(image.arr, mask.ctx)
+    else:
+        mat = np.array(image.mat)
     layer = _native.make_layer((0, 0, image.height, image.width), 3, tuple(int(v) for v in config.fog_rgb), alpha=mask)
     _native.fill(mat, [layer])
+    if on_device and not _native.resident_mode() and not isinstance(image.arr, _native.DevArray):
+        mat = np.array(mat.host())        # host in, host out
     image = attrs.evolve(image, mat=mat)
     if mode != ImageMode.RGB:
         image = image.to_target_mode_image(mode)

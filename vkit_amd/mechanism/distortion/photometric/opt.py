@@ -52,6 +52,11 @@ def out_of_path_behaviour() -> str:
     return 'raise' if os.environ.get('VKX_STRICT_UNSUPPORTED', '') == '1' else 'pass_through'
 
 
+def out_of_path_context_choice():
+    """What a surrounding ``with out_of_path(...)`` of this thread chose, or None."""
+    return getattr(_choice, 'value', None)
+
+
 class out_of_path:
     """``with out_of_path('raise'):`` / ``with out_of_path('pass_through'):`` -- the behaviour for the calls inside (this thread)."""
 
