@@ -34,9 +34,9 @@ def to_original_image(image: Image, mode: ImageMode):
 #                             through such an operator says so: ``DistortionResult.meta['out_of_path'] = ('jpeg_quality',)``
 #                             (RandomDistortion collects the names of all its stages there)
 #   'raise'                   NotImplementedError: for callers that must not miss a stage
-# chosen, in this order, by ``with out_of_path('raise'):`` around the call, by ``random_distortion_factory.create(config,
-# out_of_path='raise')`` / ``RandomDistortion(..., out_of_path='raise')``, by the environment (VKX_OUT_OF_PATH=raise|pass_through;
-# VKX_STRICT_UNSUPPORTED=1 is the older spelling of 'raise').
+# chosen, in this order, by ``random_distortion_factory.create(config, out_of_path='raise')`` / ``RandomDistortion(...,
+# out_of_path='raise')`` (the object's own setting wins inside its ``distort``), by ``with out_of_path('raise'):`` around the call,
+# by the environment (VKX_OUT_OF_PATH=raise|pass_through; VKX_STRICT_UNSUPPORTED=1 is the older spelling of 'raise').
 OUT_OF_PATH_OPERATORS = ('jpeg_quality',)
 _warned = set()
 _choice = threading.local()

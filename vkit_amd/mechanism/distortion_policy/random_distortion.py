@@ -234,10 +234,10 @@ class RandomDistortion:
                                   polygon=polygon)
         if polygons:
             result.polygons = polygons if isinstance(polygons, PolygonSoup) else tuple(polygons)
-        # precedence as documented: a surrounding ``with out_of_path(...)`` of the caller first, then this object's own setting,
-        # then the environment
-        from vkit_amd.mechanism.distortion.photometric.opt import out_of_path, out_of_path_context_choice
-        with out_of_path(None if out_of_path_context_choice() else self.out_of_path):
+        # precedence: this object's own setting (when given) over a surrounding ``with out_of_path(...)`` of the caller, over
+        # the environment (tests/test_host_golden.py pins it)
+        from vkit_amd.mechanism.distortion.photometric.opt import out_of_path
+        with out_of_path(self.out_of_path):
             for stage in self.stages:
                 result = stage.apply_distortions(result, self.level_min, self.level_max, rng, debug=debug)
         return self.trim_distortion_result(result)
