@@ -657,6 +657,50 @@ int vkx_chain_rgb_batch_np_dev(vkx_ctx *ctx, const vkx_chain_item *items, int n_
  * chain call).  Call it again after queuing anything that writes lattices. */
 int vkx_chain_lattices_ready(vkx_ctx *ctx);
 
+/* ---- camera-model states built on the device ------------------------------------------------------------------------
+ * The state of camera_plane_only / camera_cubic_curve (mechanism/distortion/geometric/camera.py:58-265, 324-423: CameraModel,
+ * the 2-D -> 3-D strategies, cv.Rodrigues / cv.projectPoints; grid_rendering/grid_creator.py:44-115: source lattice, projection,
+ * shift by the rounded minimum; element/point.py:31-47: rounding) for a BATCH of configs: the dozen scalars of a state on the host
+ * in C (vkx_camera_model_host: float32 / float64 exactly where numpy computes in them, libm's sin / cos / tan like Python's math
+ * module), the per-vertex work on the device, one workgroup per state.  The vertex lattices come out bit for bit the host
+ * operator's (tests/golden/camera_states.npz).  vkit_amd/csrc/camera.hip */
+#define VKX_CAMERA_PLANE_ONLY 0
+#define VKX_CAMERA_CUBIC_CURVE 1
+typedef struct vkx_camera_config {
+    int32_t kind, height, width, grid_size;
+    double rotation_unit_vec[3];
+    double rotation_theta;
+    double focal_length, camera_distance;   /* 0 = not given: completed from the shape like the reference */
+    double principal_point[3];
+    int32_t principal_point_len;            /* 0 = not given; 2 or 3 */
+    int32_t reserved;
+    double curve_alpha, curve_beta, curve_direction, curve_scale;     /* VKX_CAMERA_CUBIC_CURVE */
+} vkx_camera_config;
+typedef struct vkx_camera_model {           /* what the per-vertex kernel consumes; exposed for the parity tests */
+    double R[9], t[3];                      /* float64 Rodrigues matrix of the float32 rotation vector; float32 translation as double */
+    double fx, fy, cx, cy;
+    float a0, a1, along_min, along_range;   /* cubic curve: first row of the float32 direction matrix, extent of the page along it */
+    double poly[4], curve_scale;
+    int32_t rows, cols;                     /* lattice shape */
+    int32_t points_f32, reserved;           /* the projected points take float32 (plane only: float32 3-D points) */
+} vkx_camera_model;
+#define VKX_GRID_STATE_NAN 1u               /* a projected vertex is NaN (the reference raises ValueError in Point's round()) */
+#define VKX_GRID_STATE_INF 2u               /* ... infinite (OverflowError) */
+#define VKX_GRID_STATE_RANGE 4u             /* the lattice leaves int32 */
+typedef struct vkx_grid_state {
+    int32_t rows, cols, dh, dw;             /* lattice shape; result shape = extent of the destination lattice */
+    int32_t shift_y, shift_x;               /* DistortionStateImageGridBased.shift_amount_* */
+    uint32_t flags, reserved;
+} vkx_grid_state;
+int vkx_camera_model_host(const vkx_camera_config *config, vkx_camera_model *out);
+/* src_vertices / dst_vertices: HOST arrays of n DEVICE pointers to int32 [rows, cols, 2] (x, y) lattices (rows / cols of a config:
+ * vkx_camera_model_host).  stream: VKX_STREAM_*: on which of the context's streams the states are built -- a side stream builds
+ * the states of the next batch while the compute stream still runs the current one.  states_host (page-locked memory for an
+ * asynchronous copy) is valid after vkx_ctx_sync_stream(ctx, stream).  The chain calls that follow start their cell setup after
+ * this call's kernel (it records the lattices-ready point of vkx_chain_lattices_ready). */
+int vkx_camera_states_dev(vkx_ctx *ctx, const vkx_camera_config *configs_host, int n, int32_t *const *src_vertices,
+                          int32_t *const *dst_vertices, vkx_grid_state *states_host, int stream);
+
 /* ---- per-kernel timing -----------------------------------------------------------------
  * When enabled, every kernel launch is bracketed by a hipEvent pair recorded on the ctx
  * stream; vkx_ctx_collect_timings synchronises and folds them into per-kernel totals.

@@ -650,6 +650,50 @@ def gen_structure_oracle_patched():
     np.savez_compressed(os.path.join(HERE, 'structure_oracle_patched.npz'), **out)
 
 
+def gen_camera_states():
+    """Camera states for the device-built path (vkx_camera_states_dev, csrc/camera.hip): the REFERENCE's own state constructors
+    (CameraModel, the 2-D -> 3-D strategies, create_src_image_grid, create_dst_image_grid_and_shift_amounts_and_resize_ratios, Point
+    rounding) on configs from its policy generators and on hand-made ones; cv.Rodrigues / cv.projectPoints are the oracle's
+    restatements (cv2 is absent here), everything else -- numpy / OpenBLAS float32 and float64 arithmetic included -- runs for real.
+    Stored: the config scalars as arrays, the destination lattice (rounded vertices), result shape and shift amounts."""
+    _patch_cv2_with_oracle()
+    out = {}
+    cases = []
+    rng = default_rng(2025)
+    plan = [('cubic', (2048, 2048), 5), ('cubic', (2048, 2048), 9), ('plane', (2048, 2048), 7), ('cubic', (3072, 4096), 4)]
+    for k in range(20):
+        plan.append(('cubic' if k % 3 else 'plane', (int(rng.integers(40, 900)), int(rng.integers(40, 900))), int(rng.integers(1, 11))))
+    for k, (kind, shape, level) in enumerate(plan):
+        seed = 100 + k
+        if kind == 'cubic':
+            cfg = P_cam.CameraCubicCurveConfigGenerator(P_cam.CameraCubicCurveConfigGeneratorConfig(), level)(shape, default_rng(seed))
+        else:
+            cfg = P_cam.CameraPlaneOnlyConfigGenerator(P_cam.CameraPlaneOnlyConfigGeneratorConfig(), level)(shape, default_rng(seed))
+        if k % 5 == 4:      # explicit camera model fields instead of the completion from the shape
+            cm = cfg.camera_model_config
+            cm.principal_point = [float(shape[1]) * 0.4, float(shape[0]) * 0.55] + ([3.5] if k % 2 else [])
+            cm.focal_length = float(max(shape)) * 1.3
+            cm.camera_distance = float(max(shape)) * 0.9
+        if k % 7 == 6:
+            cfg.grid_size = 7   # a fine lattice: many pieces of the pairwise mean
+        state_cls = G_cam.CameraCubicCurveState if kind == 'cubic' else G_cam.CameraPlaneOnlyState
+        st = state_cls(cfg, shape, None)
+        _, d_int = grid_to_arrays(st.dst_image_grid)
+        cm = cfg.camera_model_config
+        pp = list(cm.principal_point) if cm.principal_point else []
+        cases.append([1.0 if kind == 'cubic' else 0.0, shape[0], shape[1], cfg.grid_size] + [float(v) for v in cm.rotation_unit_vec] +
+                     [float(cm.rotation_theta), float(cm.focal_length or 0.0), float(cm.camera_distance or 0.0), float(len(pp))] +
+                     [float(v) for v in (pp + [0.0, 0.0, 0.0])[:3]] +
+                     ([float(cfg.curve_alpha), float(cfg.curve_beta), float(cfg.curve_direction), float(cfg.curve_scale)] if kind == 'cubic'
+                      else [0.0, 0.0, 0.0, 0.0]))
+        out[f'dst_{k}'] = np.asarray(d_int, np.int32)
+        out[f'meta_{k}'] = np.asarray([st.result_shape[0], st.result_shape[1], st.shift_amount_y, st.shift_amount_x], np.int64)
+    out['configs'] = np.asarray(cases, np.float64)
+    out['columns'] = np.asarray(['cubic', 'height', 'width', 'grid_size', 'unit_x', 'unit_y', 'unit_z', 'theta', 'focal_length',
+                                 'camera_distance', 'pp_len', 'pp0', 'pp1', 'pp2', 'curve_alpha', 'curve_beta', 'curve_direction', 'curve_scale'])
+    np.savez_compressed(os.path.join(HERE, 'camera_states.npz'), **out)
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1:                      # regenerate only the named fixtures: make_golden.py gen_mls_lattices ...
         for name in sys.argv[1:]:
@@ -668,5 +712,6 @@ if __name__ == '__main__':
     gen_page_resizing()
     gen_std_shift()
     gen_gcn()
+    gen_camera_states()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

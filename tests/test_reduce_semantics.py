@@ -90,3 +90,17 @@ def test_picked_channels_reduce_piecewise():
         want = np.mean(mat.reshape(-1, mat.shape[-1]), axis=0)
         for k, c in enumerate(channels):
             assert f32(pieces_sum(img[:, :, c]) / (1300 * 1100)) == want[k], (channels, c)
+
+
+def test_device_mean_is_gated_on_numpy_adding_in_the_restated_order():
+    """``_native.numpy_reduce_order_ok``: true on the numpy the kernel was written against, false as soon as the reduction buffer
+    is not the default one (std_shift then takes np.mean itself)."""
+    from vkit_amd import _native as N
+    assert N.numpy_reduce_order_ok()
+    old = np.getbufsize()
+    try:
+        np.setbufsize(16384)
+        assert not N.numpy_reduce_order_ok()
+    finally:
+        np.setbufsize(old)
+    assert N.numpy_reduce_order_ok()

@@ -125,6 +125,39 @@ class VkxNpJob(ctypes.Structure):
     ]
 
 
+class VkxCameraConfig(ctypes.Structure):
+    _fields_ = [
+        ('kind', ctypes.c_int32), ('height', ctypes.c_int32), ('width', ctypes.c_int32), ('grid_size', ctypes.c_int32),
+        ('rotation_unit_vec', c_double * 3),
+        ('rotation_theta', c_double),
+        ('focal_length', c_double), ('camera_distance', c_double),
+        ('principal_point', c_double * 3),
+        ('principal_point_len', ctypes.c_int32), ('reserved', ctypes.c_int32),
+        ('curve_alpha', c_double), ('curve_beta', c_double), ('curve_direction', c_double), ('curve_scale', c_double),
+    ]
+
+
+class VkxCameraModel(ctypes.Structure):
+    _fields_ = [
+        ('R', c_double * 9), ('t', c_double * 3),
+        ('fx', c_double), ('fy', c_double), ('cx', c_double), ('cy', c_double),
+        ('a0', ctypes.c_float), ('a1', ctypes.c_float), ('along_min', ctypes.c_float), ('along_range', ctypes.c_float),
+        ('poly', c_double * 4), ('curve_scale', c_double),
+        ('rows', ctypes.c_int32), ('cols', ctypes.c_int32), ('points_f32', ctypes.c_int32), ('reserved', ctypes.c_int32),
+    ]
+
+
+class VkxGridState(ctypes.Structure):
+    _fields_ = [
+        ('rows', ctypes.c_int32), ('cols', ctypes.c_int32), ('dh', ctypes.c_int32), ('dw', ctypes.c_int32),
+        ('shift_y', ctypes.c_int32), ('shift_x', ctypes.c_int32), ('flags', ctypes.c_uint32), ('reserved', ctypes.c_uint32),
+    ]
+
+
+CAMERA_PLANE_ONLY, CAMERA_CUBIC_CURVE = 0, 1
+GRID_STATE_NAN, GRID_STATE_INF, GRID_STATE_RANGE = 1, 2, 4
+
+
 class VkxNoisePlane(ctypes.Structure):
     _fields_ = [
         ('dst', ctypes.c_void_p),
@@ -167,6 +200,8 @@ _SIGNATURES = {
     'vkx_chain_rgb_batch_np_dev': [c_void_p, ctypes.POINTER(VkxChainItem), c_int, ctypes.POINTER(VkxNpJob), c_int,
                                    ctypes.POINTER(VkxNpResult)],
     'vkx_chain_lattices_ready': [c_void_p],
+    'vkx_camera_model_host': [ctypes.POINTER(VkxCameraConfig), ctypes.POINTER(VkxCameraModel)],
+    'vkx_camera_states_dev': [c_void_p, ctypes.POINTER(VkxCameraConfig), c_int, c_void_p, c_void_p, c_void_p, c_int],
     'vkx_noise_normal_table': [c_double, c_void_p],
     'vkx_noise_normal_i16_dev': [c_void_p, c_void_p, c_ssize, c_int, c_int, c_int, c_double, ctypes.c_uint64],
     'vkx_noise_normal_i16': [c_void_p, c_void_p, c_ssize, c_int, c_int, c_int, c_double, ctypes.c_uint64],
@@ -588,6 +623,58 @@ class resident:
 
 def resident_mode():
     return getattr(_RESIDENT, 'on', False)
+
+
+_CT_NP = {ctypes.c_void_p: np.uint64, ctypes.c_int32: np.int32, ctypes.c_uint32: np.uint32, ctypes.c_int64: np.int64,
+          ctypes.c_uint64: np.uint64, ctypes.c_double: np.float64, ctypes.c_float: np.float32, ctypes.c_uint8: np.uint8,
+          ctypes.c_ssize_t: np.int64, ctypes.c_size_t: np.uint64, ctypes.c_int: np.int32, ctypes.c_uint: np.uint32}
+
+
+def struct_view(array):
+    """A numpy structured view of a ctypes array of Structures (pointers as uint64): whole-batch field updates without a Python
+    loop over the records.  The view aliases the ctypes memory."""
+    cls = array._type_
+    fields = []
+    for name, ct in cls._fields_:
+        if hasattr(ct, '_length_') and hasattr(ct, '_type_') and not issubclass(ct, ctypes.Structure):
+            fields.append((name, _CT_NP[ct._type_], (ct._length_,)))
+        else:
+            fields.append((name, _CT_NP[ct]))
+    offsets = [getattr(cls, name).offset for name, _ in cls._fields_]
+    dt = np.dtype({'names': [f[0] for f in fields], 'formats': [f[1] if len(f) == 2 else (f[1], f[2]) for f in fields],
+                   'offsets': offsets, 'itemsize': ctypes.sizeof(cls)})
+    return np.frombuffer(array, dtype=dt)
+
+
+def camera_config(config, shape) -> VkxCameraConfig:
+    """The C record of a ``CameraPlaneOnlyConfig`` / ``CameraCubicCurveConfig`` for an image of ``shape`` (vkx_camera_states_dev)."""
+    rec = VkxCameraConfig()
+    cubic = hasattr(config, 'curve_scale')
+    rec.kind = CAMERA_CUBIC_CURVE if cubic else CAMERA_PLANE_ONLY
+    rec.height, rec.width, rec.grid_size = int(shape[0]), int(shape[1]), int(config.grid_size)
+    cm = config.camera_model_config
+    for k in range(3):
+        rec.rotation_unit_vec[k] = float(cm.rotation_unit_vec[k])
+    rec.rotation_theta = float(cm.rotation_theta)
+    rec.focal_length = float(cm.focal_length or 0.0)
+    rec.camera_distance = float(cm.camera_distance or 0.0)
+    pp = list(cm.principal_point) if cm.principal_point else []
+    if len(pp) not in (0, 2, 3):
+        raise ValueError('principal_point: two or three coordinates')
+    rec.principal_point_len = len(pp)
+    for k, v in enumerate(pp):
+        rec.principal_point[k] = float(v)
+    if cubic:
+        rec.curve_alpha, rec.curve_beta = float(config.curve_alpha), float(config.curve_beta)
+        rec.curve_direction, rec.curve_scale = float(config.curve_direction), float(config.curve_scale)
+    return rec
+
+
+def camera_model_host(config, shape) -> VkxCameraModel:
+    """The host scalars of a camera state as the library computes them (parity tests)."""
+    rec, out = camera_config(config, shape), VkxCameraModel()
+    check(lib().vkx_camera_model_host(ctypes.byref(rec), ctypes.byref(out)))
+    return out
 
 
 def device_copy(array, ctx=None):
@@ -1160,13 +1247,53 @@ def histogram(img, ctx=None):
     return np.array(host_array(hist))
 
 
+_reduce_order_ok = None
+
+
+def numpy_reduce_order_ok() -> bool:
+    """csrc/reduce.hip adds in the order THIS numpy adds when it reduces a float32 array -- pieces of its 8 192-element reduction
+    buffer for a contiguous axis, one element after the other along the outer axis of an interleaved image -- which is an
+    implementation detail of numpy (2.2.x here), not a contract: ``np.setbufsize`` or another release may change it, and beyond 2^24
+    the float32 sum then differs in its last bits.  One probe per process whose sums leave the exact range compares numpy with the
+    two orders restated in plain numpy; the device mean is used only while they agree and the buffer size is the default."""
+    global _reduce_order_ok
+    if np.getbufsize() != 8192:
+        return False
+    if _reduce_order_ok is None:
+        rng = np.random.default_rng(20240917)
+        px = (rng.integers(0, 128, (200_003, 3)) * 2 + 1).astype(np.uint8)       # odd values: ties in every binade; sums ~ 2.5e7 > 2^24
+        f = px.astype(np.float32)
+
+        def pieces(col):
+            total = np.float32(0)
+            flat = col.astype(np.int64)
+            for lo in range(0, flat.size, 8192):
+                total = np.float32(total + np.float32(int(flat[lo:lo + 8192].sum())))
+            return total
+
+        ok = True
+        sequential = np.mean(f.reshape(-1, 3), axis=0)
+        for c in range(3):
+            ok = ok and np.float32(np.cumsum(f[:, c], dtype=np.float32)[-1] / np.float32(px.shape[0])) == sequential[c]
+        plane = px[:182_000, 0].reshape(2000, 91)
+        ok = ok and np.float32(pieces(plane.reshape(-1)) / plane.size) == np.mean(plane.astype(np.float32))
+        img = px[:199_800].reshape(600, 333, 3)
+        picked = img[:, :, [2, 0]].astype(np.float32)
+        want = np.mean(picked.reshape(-1, 2), axis=0)
+        for k, c in enumerate((2, 0)):
+            ok = ok and np.float32(pieces(img[:, :, c].reshape(-1)) / (600 * 333)) == want[k]
+        _reduce_order_ok = bool(ok)
+    return _reduce_order_ok
+
+
 def mean_f32_u8(img, channels=None, ctx=None):
     """``np.mean`` of the float32 copy of a uint8 image, the way ``std_shift`` takes it (photometric/color.py:165-210) and with
     numpy's own roundings: ``np.mean(mat)`` for an H x W image (a numpy float32 scalar), ``np.mean(mat.reshape(-1, k), axis=0)`` for
     the ``k`` selected channels of an H x W x C one (float32 [k]); ``channels`` = None: all.  None when the image is outside the
-    device path's limits (more than 2^22 pixels): the caller takes numpy."""
+    device path's limits (more than 2^22 pixels) or the installed numpy does not add in the order the kernel restates
+    (``numpy_reduce_order_ok``): the caller takes numpy."""
     h, w, cn, stride = _shape_u8(img)
-    if h * w == 0 or h * w > (1 << 22):
+    if h * w == 0 or h * w > (1 << 22) or not numpy_reduce_order_ok():
         return None
     sel = list(range(cn)) if channels is None else [int(c) for c in channels]
     if not 1 <= len(sel) <= 4:

@@ -49,6 +49,9 @@ class ChainBatch:
         self._runs = 0
         self.joint_call = os.environ.get('VKX_CHAIN_JOINT', '1') != '0'       # tile-buffer streams + chain through vkx_chain_rgb_batch_np_dev (False: two calls, as in round 4)
         self._marked = False
+        self._cam = []               # (item index, VkxCameraConfig, noise std or None, stream): items whose state is built on the device
+        self._cam_state = None       # _CameraStates: records, lattice sets, page-locked results
+        self.state_stream = _native.STREAM_COPY_OUT   # where the states are built: a side stream, ahead of the compute stream
         self._page_layers = {}       # item index -> [VkxLayer with device planes]: assembled into the source before the chain
         self._layer_tables = None
 
@@ -131,6 +134,118 @@ class ChainBatch:
         self._array = None
         self._marked = False
         return len(self._items) - 1
+
+    def add_config(self, image: np.ndarray, config, blur_sigma: Optional[float] = None, hue_delta: Optional[int] = None, streak=None,
+                   noise_std: Optional[float] = None, noise_rng=None):
+        """Like ``add``, from the CONFIG of a ``camera_plane_only`` / ``camera_cubic_curve`` distortion instead of its state: every
+        ``run`` builds the vertex lattices of all such items on the device (``vkx_camera_states_dev``: the reference's
+        ``generate_state`` -- CameraModel, 2-D -> 3-D lift, cv.projectPoints, the shift by the rounded minimum -- scalars in C on
+        the host, vertices on the GPU), reads the result shapes back and lays out destinations and noise buffers for them.  The
+        state of the reference is built inside ``Distortion.distort`` (mechanism/distortion/interface.py:318-347); here it is
+        inside ``run``.  ``noise_std`` + ``noise_rng``: as in ``add`` (the stream is drawn for the shape the state turns out to
+        have); a caller's plane cannot be given before the shape is known."""
+        if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
+            raise ValueError('ChainBatch takes HxWx3 uint8 images')
+        if (noise_std is None) != (noise_rng is None):
+            raise ValueError('add_config: noise_std together with noise_rng')
+        if self.stream_noise_mode != 'tiles' and noise_rng is not None:
+            raise ValueError("add_config draws its noise into tile buffers (stream_noise_mode='tiles')")
+        sh, sw = image.shape[:2]
+        item = _native.VkxChainItem()
+        item.src = self._put(image)
+        item.src_stride = sw * 3
+        item.sh, item.sw = sh, sw
+        stream = None
+        if noise_rng is not None:
+            stream = _native.np_stream(noise_rng)
+            if stream is None:
+                raise ValueError('noise_rng must be a numpy Generator over PCG64 (numpy.random.default_rng)')
+            item.noise_tiled = 1
+        if blur_sigma is not None:
+            item.blur_sigma = float(blur_sigma)
+            item.blur_ksize = _estimate_gaussian_kernel_size(blur_sigma)
+        if hue_delta is not None:
+            item.hue_delta, item.hue_enabled = int(hue_delta), 1
+        if streak is not None:
+            item.streak_enabled = 1
+            item.streak_thickness, item.streak_gap = int(streak.thickness), int(streak.gap)
+            item.streak_dash_thickness, item.streak_dash_gap = int(streak.dash_thickness), int(streak.dash_gap)
+            item.streak_enable_vert, item.streak_enable_hori = int(streak.enable_vert), int(streak.enable_hori)
+            for c in range(3):
+                item.streak_color[c] = int(streak.color[c])
+            item.streak_alpha = float(streak.alpha)
+        self._cam.append((len(self._items), _native.camera_config(config, (sh, sw)), None if noise_std is None else float(noise_std), stream))
+        self._cam_state = None
+        self._items.append(item)
+        self._dst_shapes.append((0, 0))
+        self._array = None
+        self._stream_jobs = self._late_jobs = None
+        return len(self._items) - 1
+
+    def set_config(self, index: int, config):
+        """Replaces the config of an ``add_config`` item (the next ``run`` builds its state)."""
+        for k, (i, _rec, std, stream) in enumerate(self._cam):
+            if i == index:
+                it = self._items[index]
+                self._cam[k] = (i, _native.camera_config(config, (int(it.sh), int(it.sw))), std, stream)
+                if self._cam_state is not None:
+                    self._cam_state.records[k] = self._cam[k][1]
+                    self._cam_state.refresh_lattice_shapes(self.ctx)
+                return
+        raise KeyError(f'item {index} was not added with add_config')
+
+    def _ensure_array(self):
+        """The contiguous descriptor array of the batch; ``self._items`` become views of its records (one copy of every field)."""
+        if self._array is None:
+            self._array = (_native.VkxChainItem * max(len(self._items), 1))(*self._items)
+            self._items = [self._array[i] for i in range(len(self._items))]
+        return self._array
+
+    def _build_states(self):
+        """States of the ``add_config`` items for this run, on the side stream: lattices (one of two sets: the previous run's may
+        still be read by its pixel kernel), shapes back, destinations / noise buffers / stream jobs laid out for them -- whole-batch
+        numpy operations on views of the descriptor arrays, no Python loop over the images."""
+        cs = self._cam_state
+        if cs is None:
+            cs = self._cam_state = _CameraStates(self.ctx, [rec for _i, rec, _s, _st in self._cam])
+            cs.index = np.asarray([i for i, _r, _s, _st in self._cam], np.int64)
+            cs.noisy = np.asarray([st is not None for _i, _r, _s, st in self._cam], bool)
+        which = self._runs & 1
+        states = cs.build(self.ctx, which, self.state_stream)          # synchronises the side stream; raises like the reference
+        self._ensure_array()
+        view = _native.struct_view(self._array)
+        idx = cs.index
+        dh, dw = states['dh'].astype(np.int64), states['dw'].astype(np.int64)
+        if cs.last_shapes is None or not (np.array_equal(cs.last_shapes[0], dh) and np.array_equal(cs.last_shapes[1], dw)):
+            # new shapes: destinations and tile buffers from one arena, 256-byte aligned
+            n = dh * dw * 3
+            dst_bytes = (n + 255) & ~255
+            tiles = (n + n // 32 + 2048 + cs.tile_draws - 1) // cs.tile_draws
+            slots_off = (16 + 8 * (tiles + 1) + 255) & ~255
+            tile_bytes = np.where(cs.noisy, slots_off + tiles * cs.slot_elems * 2, 0)
+            sizes = np.stack([dst_bytes, (tile_bytes + 255) & ~255], axis=1).reshape(-1)
+            offsets = np.concatenate([[0], np.cumsum(sizes)])
+            base = cs.arena(self.ctx, int(offsets[-1]))
+            cs.dst_ptr = (base + offsets[0:-1:2]).astype(np.uint64)
+            cs.noise_ptr = np.where(cs.noisy, base + offsets[1::2], 0).astype(np.uint64)
+            cs.last_shapes = (dh, dw)
+            for k, i in enumerate(idx):
+                self._dst_shapes[int(i)] = (int(dh[k]), int(dw[k]))
+            # the stream entries (index, std, stream, samples, late) of these items follow their shapes
+            cam_items = set(int(i) for i in idx)
+            self._stream_noise = [e for e in self._stream_noise if e[0] not in cam_items]
+            for k, (i, _rec, std, stream) in enumerate(self._cam):
+                if stream is not None:
+                    self._stream_noise.append((i, std, stream, int(n[k]), False))
+            self._stream_noise.sort(key=lambda e: e[0])
+            self._stream_jobs = self._late_jobs = None
+        view['dh'][idx], view['dw'][idx] = dh, dw
+        view['dst_stride'][idx] = dw * 3
+        view['rows'][idx], view['cols'][idx] = states['rows'], states['cols']
+        view['src_vertices'][idx], view['dst_vertices'][idx] = cs.sv_ptr[which], cs.dv_ptr[which]
+        view['dst'][idx] = cs.dst_ptr
+        view['noise'][idx] = cs.noise_ptr
+        return states
 
     def set_layers(self, index: int, layers):
         """The text / image layers of page ``index`` (``_native.make_layer`` records for its source shape, in paint order:
@@ -263,7 +378,8 @@ class ChainBatch:
             self.ctx.upload(item.noise, plane)
             self.stream_fallbacks += 1
         self._stream_noise = kept
-        self._array = (_native.VkxChainItem * max(len(self._items), 1))(*self._items)
+        self._array = None
+        self._ensure_array()
         self._stream_jobs = self._build_jobs([e for e in kept if not e[4]])
         self._late_jobs = self._build_jobs([e for e in kept if e[4]])
         return True
@@ -272,8 +388,9 @@ class ChainBatch:
         """Enqueues the chain for every image on the ctx stream (asynchronous).  ``draw_streams=False`` leaves the PLANES of
         the ``noise_rng`` items as the previous run drew them (they are the same every run); noise that the generator adds
         after the chain is always drawn."""
-        if self._array is None:
-            self._array = (_native.VkxChainItem * max(len(self._items), 1))(*self._items)
+        if self._cam:
+            self._build_states()
+        self._ensure_array()
         lib = _native.lib()
         first = self._stream_noise and self._stream_jobs is None
         if first:
@@ -335,12 +452,98 @@ class ChainBatch:
         self._page_layers.clear()
         self._layer_tables = None
         self._array = None
+        if self._cam_state is not None:
+            self._cam_state.close(self.ctx)
+            self._cam_state = None
+        self._cam.clear()
 
     def __del__(self):
         try:
             self.close()
         except Exception:
             pass
+
+
+class _CameraStates:
+    """The device side of ``ChainBatch.add_config``: the config records, two sets of lattice buffers, the page-locked result records
+    and the arena the destinations / tile buffers of the batch live in."""
+
+    def __init__(self, ctx, records):
+        n = len(records)
+        self.n = n
+        self.records = (_native.VkxCameraConfig * n)(*records)
+        self._out_ptr = ctx.host_alloc(n * ctypes.sizeof(_native.VkxGridState))
+        self.out = (_native.VkxGridState * n).from_address(self._out_ptr)
+        self.states = _native.struct_view(self.out)
+        self.sets = [None, None]
+        self.sv_ptr = [None, None]
+        self.dv_ptr = [None, None]
+        self._sv_c = [None, None]
+        self._dv_c = [None, None]
+        self._arena = 0
+        self._arena_cap = 0
+        self.last_shapes = None
+        self.dst_ptr = self.noise_ptr = None
+        shape = [ctypes.c_int64() for _ in range(5)]
+        _native.check(_native.lib().vkx_np_tiles_layout(1 << 20, *[ctypes.byref(v) for v in shape]))
+        self.slot_elems = int(shape[1].value)
+        self.tile_draws = 3072          # raw draws per generator tile (csrc/nprand.hip kTile; tests/test_camera_states.py checks the layout formula)
+        self.refresh_lattice_shapes(ctx)
+
+    def refresh_lattice_shapes(self, ctx):
+        lib = _native.lib()
+        model = _native.VkxCameraModel()
+        cells = np.empty(self.n, np.int64)
+        for k in range(self.n):
+            _native.check(lib.vkx_camera_model_host(ctypes.byref(self.records[k]), ctypes.byref(model)))
+            cells[k] = model.rows * model.cols
+        lattice_bytes = (cells * 8 + 255) & ~255
+        offsets = np.concatenate([[0], np.cumsum(np.repeat(lattice_bytes, 2))])
+        total = int(offsets[-1])
+        for which in (0, 1):
+            if self.sets[which]:
+                ctx.free(self.sets[which])
+            base = self.sets[which] = ctx.malloc(max(total, 256))
+            self.sv_ptr[which] = (base + offsets[0:-1:2]).astype(np.uint64)
+            self.dv_ptr[which] = (base + offsets[1::2]).astype(np.uint64)
+            self._sv_c[which] = (ctypes.c_void_p * self.n)(*[int(v) for v in self.sv_ptr[which]])
+            self._dv_c[which] = (ctypes.c_void_p * self.n)(*[int(v) for v in self.dv_ptr[which]])
+        self.last_shapes = None
+
+    def build(self, ctx, which, stream):
+        _native.check(_native.lib().vkx_camera_states_dev(ctx.handle, self.records, self.n, self._sv_c[which], self._dv_c[which],
+                                                          ctypes.c_void_p(self._out_ptr), int(stream)))
+        ctx.sync_stream(stream)
+        states = self.states
+        flags = states['flags']
+        if flags.any():
+            # the reference builds a Point per vertex and fails in its round() (element/point.py:31-47)
+            if (flags & _native.GRID_STATE_NAN).any():
+                raise ValueError('cannot convert float NaN to integer')
+            if (flags & _native.GRID_STATE_INF).any():
+                raise OverflowError('cannot convert float infinity to integer')
+            raise OverflowError('destination lattice outside the int32 range')
+        return states
+
+    def arena(self, ctx, nbytes):
+        if nbytes > self._arena_cap:
+            if self._arena:
+                ctx.free(self._arena)          # (synchronises the compute stream)
+            self._arena_cap = nbytes + nbytes // 16
+            self._arena = ctx.malloc(self._arena_cap)
+        return self._arena
+
+    def close(self, ctx):
+        for which in (0, 1):
+            if self.sets[which]:
+                ctx.free(self.sets[which])
+                self.sets[which] = None
+        if self._arena:
+            ctx.free(self._arena)
+            self._arena = 0
+        if self._out_ptr:
+            ctx.host_free(self._out_ptr)
+            self._out_ptr = 0
 
 
 class ChainLanes:

@@ -853,10 +853,16 @@ __global__ void __launch_bounds__(1024) k_np_resolve(const NpJob *__restrict__ j
         __syncthreads();
     }
     unsigned long long run = part[threadIdx.x] - sum;
+    bool short_tile = false;
     for (int j = j0; j < j1; j++) {
         plan[j].prefix = run;
+        // consumers of tile buffers assume that a row segment of 64 pixels (192 samples) meets at most two tiles and that a tile
+        // can lend its predecessor two samples: a tile inside the wanted range that yields fewer (of 3 072 draws: never observed,
+        // ~1e-3000) hands the stream to the host like any other refusal
+        short_tile = short_tile || ((long long)run < job.n && j + 1 < T && plan[j].count < 192u);
         run += plan[j].count;
     }
+    if (short_tile && job.kind == VKX_NP_NORMAL_TILES) atomicOr(&results[blockIdx.x].flags, VKX_NP_SHORT);
     if (threadIdx.x == 1023) {
         results[blockIdx.x].samples = part[1023];
         if ((long long)part[1023] < job.n) atomicOr(&results[blockIdx.x].flags, VKX_NP_SHORT);
