@@ -4,11 +4,14 @@
 Workload (per GPU): B independent 2048x2048 RGB page images, each with its own ``camera_cubic_curve`` state
 (config from the reference-compatible generator at level 5, seed = image index), through
     image-grid remap  ->  gaussian_blur(sigma=1.0, k=5)  ->  color_shift(delta=37)  ->  gaussion_noise(std=10)
-with the images and integer vertex lattices resident in HBM before the timed region.  The noise of image i is the
+with the images resident in HBM before the timed region.  Since round 5 a step starts from the CONFIGS: the camera_cubic_curve states
+of the batch (CameraModel, 2-D -> 3-D lift, projection, shift, rounding: the reference's generate_state) are built inside every
+step, scalars in C on the host and vertices on the device (ChainBatch.add_config -> vkx_camera_states_dev); ``--states host`` keeps
+the lattices of host-built states resident as in rounds 1 - 4 (reported beside as ``lattices_resident``).  The noise of image i is the
 reference's: np.round(default_rng(5000 + i).normal(0, 10, shape)) -- drawn ON THE DEVICE from that numpy stream, value for
 value, INSIDE every timed step (vkx_np_draw_batch_dev: PCG64 jump-ahead + ziggurat); no host-generated plane exists.
-A "step" is one pass over the whole batch: draw the noise of every image (it stays in the generator's tile slots), run the
-chain (k_chain_fused adds the noise, the chain's last member, from those slots).  Images shard across GPUs without any exchange
+A "step" is one pass over the whole batch: build the states, draw the noise of every image (it stays in the generator's tile
+slots), run the chain (k_chain_fused adds the noise, the chain's last member, from those slots).  Images shard across GPUs without any exchange
 (one process per GPU, weak scaling: every GPU processes its own B images).
 
 ``python bench.py --gpus N`` from a plain shell launches its own ranks (torch.distributed.run on 127.0.0.1, the way the
@@ -64,13 +67,17 @@ def _noise_plane(args):
     return np.round(np.random.default_rng(seed).normal(0, NOISE_STD, shape)).astype(np.int16)
 
 
-def make_state(index, size):
+def make_config(index, size):
     from numpy.random import default_rng
-    from vkit_amd.mechanism import distortion as D
     from vkit_amd.mechanism.distortion_policy.geometric import camera as P_cam
     gen = P_cam.CameraCubicCurveConfigGenerator(P_cam.CameraCubicCurveConfigGeneratorConfig(), LEVEL)
-    cfg = gen((size, size), default_rng(index))
-    return D.camera_cubic_curve.generate_state(cfg, (size, size))
+    return gen((size, size), default_rng(index))
+
+
+def make_state(index, size):
+    """The host operator's state (numpy): the CPU baseline, the resident-lattice leg and the check of the device-built lattices."""
+    from vkit_amd.mechanism import distortion as D
+    return D.camera_cubic_curve.generate_state(make_config(index, size), (size, size))
 
 
 def _oracle_noise(O, seed, shape):
@@ -202,6 +209,11 @@ def main():
                     help='how the device-drawn numpy stream reaches the chain: 0 = the generator\'s tile slots, read by k_chain_fused '
                          '(default); 1 = an int16 plane per image in HBM, added inside k_chain_fused (rounds 1 - 2); 2 = added to the '
                          'chain output by the generator\'s placement pass (round 3)')
+    ap.add_argument('--states', default='device', choices=('device', 'host'),
+                    help='device (default): the timed step starts from the CONFIGS -- every step builds the camera_cubic_curve states of '
+                         'the batch on the device (ChainBatch.add_config -> vkx_camera_states_dev), as the reference builds the state '
+                         'inside Distortion.distort; host: the lattices of host-built states are resident before the timed region '
+                         '(rounds 1 - 4)')
     ap.add_argument('--lanes', type=int, default=1,
                     help='HIP streams the batch is dealt over (ChainLanes).  1: every kernel interval of the step is disjoint and '
                          'the per-kernel figures add up to the step; 2 hides the microsecond kernels of one lane under the other '
@@ -250,8 +262,9 @@ def main():
 
     # ---- host-side setup (no GPU yet): states ---------------------------------------------------------------------
     t_setup = time.perf_counter()
-    states = [make_state(first + j, size) for j in range(B)]
-    noise_jobs = [(5000 + first + j, tuple(states[j].result_shape) + (3,)) for j in range(B)]
+    configs = [make_config(first + j, size) for j in range(B)]
+    from_configs = args.states == 'device' and args.lanes == 1 and args.noise_planes == 0
+    states = None if from_configs else [make_state(first + j, size) for j in range(B)]
 
     import torch
     # process -> GPU by the pool's rule (local_rank % visible GPUs): one rank per GPU on the driver's N-GPU node; on a
@@ -275,8 +288,13 @@ def main():
     for j in range(B):
         image = np.random.default_rng(1000 + first + j).integers(0, 256, (size, size, 3), dtype=np.uint8)
         images.append(image)
-        batch.add(image, states[j], blur_sigma=BLUR_SIGMA, hue_delta=HUE_DELTA, noise_std=NOISE_STD,
-                  noise_rng=np.random.default_rng(5000 + first + j))
+        if from_configs:
+            batch.lanes[0].add_config(image, configs[j], blur_sigma=BLUR_SIGMA, hue_delta=HUE_DELTA, noise_std=NOISE_STD,
+                                      noise_rng=np.random.default_rng(5000 + first + j))
+            batch._where.append((0, j))
+        else:
+            batch.add(image, states[j], blur_sigma=BLUR_SIGMA, hue_delta=HUE_DELTA, noise_std=NOISE_STD,
+                      noise_rng=np.random.default_rng(5000 + first + j))
     t_setup = time.perf_counter() - t_setup
 
     def full_sync():
@@ -311,6 +329,24 @@ def main():
             kernel_times[name] = (ms / breakdown_steps * args.steps, launches / breakdown_steps * args.steps, 'breakdown pass')
         for name, (ms, launches) in major_times.items():
             kernel_times[name] = (ms, launches, 'timed region')
+
+    state_build = None
+    if from_configs:
+        cb = batch.lanes[0]
+        state_build = {'host_ms_per_step': cb.state_build_s / max(cb.state_builds, 1) * 1e3, 'builds': cb.state_builds,
+                       'note': 'host time of ChainBatch._build_states per step, INSIDE the timed region: 256 x vkx_camera_model_host '
+                               '(C), one k_camera_states launch on the side stream, the wait for the result shapes, whole-array layout '
+                               'of destinations / tile buffers / stream jobs; it runs while the compute stream still executes the '
+                               'previous step'}
+        # the host operator's states: CPU legs below, and how many device-built lattices equal them on THIS box
+        states = [make_state(first + j, size) for j in range(B)]
+        equal = 0
+        for j in sorted({0, B // 3, (2 * B) // 3, B - 1}):
+            sv, dv = cb.lattices(j)
+            equal += int(np.array_equal(sv, states[j].src_image_grid.vertices) and np.array_equal(dv, states[j].dst_image_grid.vertices)
+                         and tuple(states[j].result_shape) == cb._dst_shapes[j])
+        state_build['lattices_equal_host_operator'] = f'{equal} of 4 checked'
+    noise_jobs = [(5000 + first + j, tuple(states[j].result_shape) + (3,)) for j in range(B)]
 
     # ---- the chain alone on noise already in HBM (r2's headline mode, planes resident), for continuity --------------------
     planes_resident = None
@@ -348,10 +384,15 @@ def main():
         for j in picks:
             st = states[j]
             img = np.random.default_rng(1000 + first + j).integers(0, 256, (size, size, 3), dtype=np.uint8)
-            mx, my = O.grid_to_map(st.src_image_grid.vertices, st.dst_image_grid.vertices, st.result_shape)
-            want = O.add_noise_i16(O.color_shift_rgb(O.gaussian_blur(O.remap(img, mx, my), 5, BLUR_SIGMA), HUE_DELTA),
-                                   _noise_plane(noise_jobs[j]))
             got = batch.result(j)
+            if from_configs:      # the pixels against the oracle on the lattices the device built (those against the host operator: above)
+                sv, dv = batch.lanes[0].lattices(j)
+                shape = got.shape[:2]
+            else:
+                sv, dv, shape = st.src_image_grid.vertices, st.dst_image_grid.vertices, st.result_shape
+            mx, my = O.grid_to_map(sv, dv, shape)
+            want = O.add_noise_i16(O.color_shift_rgb(O.gaussian_blur(O.remap(img, mx, my), 5, BLUR_SIGMA), HUE_DELTA),
+                                   _noise_plane((5000 + first + j, tuple(shape) + (3,))))
             if not (got == want).all():
                 raise SystemExit(f'bench: image {j} differs from the oracle ({int((got != want).sum())} bytes)')
             verified += 1
@@ -362,6 +403,35 @@ def main():
     src_px = batch.source_pixels            # per rank, per step
     dst_px = batch.result_pixels
     fallbacks = batch.stream_fallbacks
+    lattices_resident = None
+    # ---- round 4's headline mode: the same step with the lattices of host-built states resident before the timed region ------
+    if world == 1 and args.extra_legs and from_configs:
+        rsteps = max(1, min(args.steps, 30))
+        main_ctx = batch.contexts[0]
+        batch.lanes[0].close()            # the buffers of the timed batch; its context (streams, scratch) serves this leg
+        lb = ChainBatch(main_ctx)
+        for j in range(B):
+            image = np.random.default_rng(1000 + first + j).integers(0, 256, (size, size, 3), dtype=np.uint8)
+            lb.add(image, states[j], blur_sigma=BLUR_SIGMA, hue_delta=HUE_DELTA, noise_std=NOISE_STD,
+                   noise_rng=np.random.default_rng(5000 + first + j))
+        lb.run()
+        main_ctx.sync()
+        main_ctx.set_timing(2)
+        main_ctx.reset_timings()
+        t0 = time.perf_counter()
+        for _ in range(rsteps):
+            lb.run()
+        main_ctx.sync()
+        ldt = time.perf_counter() - t0
+        lk = main_ctx.timings()
+        main_ctx.set_timing(False)
+        lattices_resident = {'value': lb.source_pixels * rsteps / ldt / 1e6, 'unit': 'Mpixels/s', 'steps': rsteps,
+                             'ms_per_step': ldt / rsteps * 1e3,
+                             'kernels_ms_per_step': {k: round(v[0] / rsteps, 3) for k, v in sorted(lk.items())},
+                             'note': 'the step of rounds 3 - 4: noise drawn inside the step, vertex lattices of host-built states '
+                                     'resident in HBM before the timed region (state construction excluded)'}
+        lb.close()
+
     batch.close()
 
     # ---- reported beside the headline, N=1 only -----------------------------------------------------------------------
@@ -506,12 +576,14 @@ def main():
         'config': {
             'workload': f'C3 fused chain: camera_cubic_curve remap (level {LEVEL}) + gaussian_blur(sigma={BLUR_SIGMA}) + '
                         f'color_shift({HUE_DELTA}) + gaussion_noise(std={NOISE_STD}, the numpy stream default_rng(5000 + i) drawn on '
-                        f'the device inside every step), '
+                        f'the device inside every step), ' + ('states built from the configs inside every step, ' if from_configs else '') +
                         f'{size}x{size}x3 uint8, batch {B} per GPU',
             'batch_per_gpu': B,
             'image': f'{size}x{size}x3',
             'mean_result_pixels': D,
             'noise_mode': noise_mode,
+            'states': ('built on the device from the configs inside every step (vkx_camera_states_dev)' if from_configs
+                       else 'host-built, lattices resident before the timed region'),
             'lanes': args.lanes,
             'sharding': f'{world} process(es), one per GPU, independent images, no collective' +
                         (f' (ranks share {n_dev} GPU(s): rendezvous over {backend})' if shared_devices else ''),
@@ -560,6 +632,10 @@ def main():
                     'HBM-bound kernel',
         },
     }
+    if state_build is not None:
+        result['state_construction'] = state_build
+    if lattices_resident is not None:
+        result['lattices_resident'] = lattices_resident
     if planes_resident is not None:
         result['planes_resident'] = planes_resident
     if throughput_mode is not None:

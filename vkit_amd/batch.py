@@ -7,6 +7,7 @@ giving every process (one per GPU) its own ``ChainBatch``; there is no exchange 
 """
 import ctypes
 import os
+import time
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -51,6 +52,8 @@ class ChainBatch:
         self._marked = False
         self._cam = []               # (item index, VkxCameraConfig, noise std or None, stream): items whose state is built on the device
         self._cam_state = None       # _CameraStates: records, lattice sets, page-locked results
+        self.state_build_s = 0.0     # host time spent in _build_states (C scalars, launch, the wait for the shapes, layout)
+        self.state_builds = 0
         self.state_stream = _native.STREAM_COPY_OUT   # where the states are built: a side stream, ahead of the compute stream
         self._page_layers = {}       # item index -> [VkxLayer with device planes]: assembled into the source before the chain
         self._layer_tables = None
@@ -205,6 +208,7 @@ class ChainBatch:
         """States of the ``add_config`` items for this run, on the side stream: lattices (one of two sets: the previous run's may
         still be read by its pixel kernel), shapes back, destinations / noise buffers / stream jobs laid out for them -- whole-batch
         numpy operations on views of the descriptor arrays, no Python loop over the images."""
+        t0 = time.perf_counter()
         cs = self._cam_state
         if cs is None:
             cs = self._cam_state = _CameraStates(self.ctx, [rec for _i, rec, _s, _st in self._cam])
@@ -245,7 +249,19 @@ class ChainBatch:
         view['src_vertices'][idx], view['dst_vertices'][idx] = cs.sv_ptr[which], cs.dv_ptr[which]
         view['dst'][idx] = cs.dst_ptr
         view['noise'][idx] = cs.noise_ptr
+        self.state_build_s += time.perf_counter() - t0
+        self.state_builds += 1
         return states
+
+    def lattices(self, index: int):
+        """(source, destination) vertex lattices of item ``index`` as the last run used them: int32 [rows, cols, 2] host arrays."""
+        self.ctx.sync()
+        it = self._items[index]
+        shape = (int(it.rows), int(it.cols), 2)
+        sv, dv = np.empty(shape, np.int32), np.empty(shape, np.int32)
+        self.ctx.download(it.src_vertices, sv)
+        self.ctx.download(it.dst_vertices, dv)
+        return sv, dv
 
     def set_layers(self, index: int, layers):
         """The text / image layers of page ``index`` (``_native.make_layer`` records for its source shape, in paint order:

@@ -292,10 +292,13 @@ hipStream_t vkx_stream_by_id(vkx_ctx *ctx, int id, int *rc)
     hipStream_t &st = ctx->copy_stream[id - VKX_STREAM_COPY_IN];
     if (!st) {
         vkx_device_guard guard(ctx);
-        // the two side streams carry copies and the microsecond kernels that run UNDER a large kernel of the compute stream
-        // (carry resolution of the numpy streams, cell setup of the chain): highest priority, so that their few workgroups
-        // are placed as soon as any CU has room instead of after the large kernel has drained
-        static const bool prio = [] { const char *e = getenv("VKX_SIDE_PRIORITY"); return !(e && e[0] == '0'); }();
+        // The side streams carry copies and the microsecond kernels that run UNDER a large kernel of the compute stream (carry
+        // resolution of the numpy streams, cell setup of the chain).  VKX_SIDE_PRIORITY=1 creates them with the highest priority.
+        // Measured (tools/probes/alloc_order.py): no gain for the first context of a process -- the dispatcher places the few
+        // workgroups of a side kernel as CU slots free up either way (C3 step 16.54 vs 16.57 ms) -- and a SECOND context with
+        // priority streams runs its large kernels 12 - 15 % slower (k_chain_fused 4.06 vs 3.53 ms per 96 pages; the process has
+        // more priority streams than the device has priority queues).  Off by default.
+        static const bool prio = [] { const char *e = getenv("VKX_SIDE_PRIORITY"); return e && e[0] == '1'; }();
         int least = 0, greatest = 0;
         hipError_t e = hipErrorUnknown;
         if (prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
