@@ -189,6 +189,61 @@ def _tool_json(name, device_index, timeout, extra=()):
         return {'error': repr(exc)}
 
 
+def dropin_mode(args, group, rank, world, device_index, first, affinity):
+    """The PCIe-inclusive leg at N ranks: every rank sends ``--batch`` pages per step through ``HostPipeline.submit_chain`` -- page-
+    locked host arrays in, page-locked host views out, 8 lanes --, camera_cubic_curve remap + blur + hue + the numpy noise stream of
+    the page drawn on the device (value-exact).  Weak scaling like the resident mode; the link and the host's memory bandwidth are
+    what the ranks share."""
+    from vkit_amd import _native, shard
+    from vkit_amd.hostpipe import HostPipeline
+    B, size = args.batch, args.size
+    ctx = _native.Context(device_index)
+    n_img = min(B, 8)
+    pinned = []
+    for j in range(n_img):
+        a = ctx.pinned_empty((size, size, 3), np.uint8)
+        a[...] = np.random.default_rng(1000 + first + j).integers(0, 256, (size, size, 3), dtype=np.uint8)
+        pinned.append(a)
+    states = [make_state(first + j, size) for j in range(n_img)]
+    pipe = HostPipeline(ctx)
+    result_bytes = [int(np.prod(st.result_shape)) * 3 for st in states]
+
+    def step():
+        tickets = []
+        for k in range(B):
+            i = k % n_img
+            tickets.append(pipe.submit_chain(pinned[i], states[i], blur_sigma=BLUR_SIGMA, hue_delta=HUE_DELTA, noise_std=NOISE_STD,
+                                             noise_rng=np.random.default_rng(5000 + first + i)))
+            if k >= 7:
+                pipe.result(tickets[k - 7])
+        pipe.drain()
+
+    def sync():
+        pipe.drain()
+        ctx.sync()
+
+    elapsed = shard.timed_steps(group, step, steps=args.steps, warmup=args.warmup, device_sync=sync)
+    group.close()
+    pipe.close()
+    if rank != 0:
+        return
+    total_px = B * size * size * world * args.steps
+    link_bytes = sum((size * size * 3 + result_bytes[k % n_img]) for k in range(B)) * world * args.steps
+    print(json.dumps({
+        'metric': 'Mpixels/s (2048^2 RGB, geo+photo chain), host arrays in and out (PCIe inclusive)',
+        'mode': 'dropin', 'value': total_px / elapsed / 1e6, 'unit': 'Mpixels/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
+        'config': {'workload': f'C3 chain per page through HostPipeline.submit_chain (8 lanes): page-locked {size}x{size}x3 page in, '
+                               f'result out, noise drawn on the device from the page\'s numpy stream; {B} pages per step and GPU',
+                   'batch_per_gpu': B, 'affinity': affinity},
+        'link_gb_per_s_all_ranks': link_bytes / elapsed / 1e9,
+        'note': 'never the headline: the resident mode (default) is; this leg exists so that the first 8-GPU run yields the '
+                'PCIe-inclusive curve beside the resident one',
+    }))
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -218,6 +273,10 @@ def main():
                     help='HIP streams the batch is dealt over (ChainLanes).  1: every kernel interval of the step is disjoint and '
                          'the per-kernel figures add up to the step; 2 hides the microsecond kernels of one lane under the other '
                          'lane\'s (-1 %% of the step)')
+    ap.add_argument('--mode', default='resident', choices=('resident', 'dropin'),
+                    help='resident (default, the headline): images resident in HBM.  dropin: the PCIe-inclusive curve -- every rank '
+                         'sends its images through HostPipeline.submit_chain, host arrays in and host arrays out (page-locked), the '
+                         'noise of every image drawn on the device from its numpy stream; never the headline value')
     ap.add_argument('--dry-run', action='store_true',
                     help='rendezvous, barriers and the MAX reduction of the timing protocol only, over gloo, no GPU: the N > 1 path on '
                          'a box without GPUs (tests/test_bench_launch.py)')
@@ -239,7 +298,7 @@ def main():
         units = group.sum_int(count * args.steps)
         group.close()
         if rank == 0:
-            print(json.dumps({'dry_run': True, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            print(json.dumps({'dry_run': True, 'mode': args.mode, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                               'ms_per_step': elapsed / args.steps * 1e3, 'units': units, 'first_image_of_last_rank': (world - 1) * args.batch}))
             sys.stdout.flush()
         return
@@ -281,6 +340,17 @@ def main():
 
     from vkit_amd import _native
     from vkit_amd.batch import ChainBatch, ChainLanes
+    # CPU placement next to the GPU: the cores of the GPU's NUMA node, shared out among the ranks whose GPUs hang off the same node
+    try:
+        bus_ids = [_native.device_pci_bus_id(d) for d in range(n_dev)]
+        pos, sharing = shard.ranks_sharing_numa(bus_ids, device_index)
+        bound = shard.bind_to_device_numa(bus_ids[device_index], pos, sharing if world > 1 else 1)
+        affinity = {'pci_bus_id': bus_ids[device_index], 'cpus': len(bound) if bound else None,
+                    'numa_share': f'{pos + 1} of {sharing}' if bound and world > 1 else None}
+    except Exception as exc:                    # placement is an optimisation: never a reason to fail
+        affinity = {'error': repr(exc)}
+    if args.mode == 'dropin':
+        return dropin_mode(args, group, rank, world, device_index, first, affinity)
     ctx = _native.Context(device_index)
     noise_mode = {0: 'tiles', 1: 'planes', 2: 'late'}[args.noise_planes]
     batch = ChainLanes(device_index, lanes=args.lanes, stream_noise_mode=noise_mode)
@@ -588,6 +658,7 @@ def main():
             'sharding': f'{world} process(es), one per GPU, independent images, no collective' +
                         (f' (ranks share {n_dev} GPU(s): rendezvous over {backend})' if shared_devices else ''),
             'verified_against_oracle': verified,
+            'affinity': affinity,
             'kernel_source_digest': kernel_source_digest(),
             'setup_s': round(t_setup, 1),
         },

@@ -43,6 +43,8 @@ typedef struct vkx_ctx vkx_ctx;
 int vkx_version(void);
 const char *vkx_last_error(void);
 int vkx_device_count(int *count);
+/* "0000:c1:00.0" of visible device `device` (hipDeviceGetPCIBusId): process placement next to the GPU's NUMA node (vkit_amd/shard.py) */
+int vkx_device_pci_bus_id(int device, char *buf, int len);
 int vkx_ctx_create(int device, vkx_ctx **out);
 int vkx_ctx_destroy(vkx_ctx *ctx);
 int vkx_ctx_sync(vkx_ctx *ctx);

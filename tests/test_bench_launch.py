@@ -39,3 +39,19 @@ def test_single_rank_dry_run_needs_no_launcher():
     assert out.returncode == 0, out.stdout + out.stderr
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec['n_gpus'] == 1 and rec['units'] == 8
+
+
+def test_eight_ranks_rendezvous_and_reduce():
+    """The launch the scaling bench makes on the 8-GPU node (``python bench.py --gpus 8``), protocol only: eight ranks over gloo on the
+    loopback address, one JSON line from rank 0, units summed and times maximised over all eight; the same for the PCIe-inclusive mode's
+    command line (``--mode dropin``; a dry run stops before any device work)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    for extra in ([], ['--mode', 'dropin']):
+        out = _run(['--gpus', '8', '--dry-run', '--steps', '2', '--warmup', '1', '--batch', '3'] + extra, env)
+        assert out.returncode == 0, out.stdout + out.stderr
+        lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+        assert len(lines) == 1, out.stdout
+        rec = json.loads(lines[0])
+        assert rec['n_gpus'] == 8 and rec['units'] == 8 * 3 * 2 and rec['first_image_of_last_rank'] == 21
+        assert rec['ms_per_step'] >= 80.0                  # rank 7 sleeps 80 ms per step
+        assert rec['mode'] == (extra[1] if extra else 'resident')

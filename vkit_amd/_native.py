@@ -187,6 +187,7 @@ STREAM_COMPUTE, STREAM_COPY_IN, STREAM_COPY_OUT = 0, 1, 2
 _PLANE_U8 = [c_void_p, c_int, c_int, c_int, c_ssize]  # ptr, h, w, cn, stride
 _SIGNATURES = {
     'vkx_device_count': [ctypes.POINTER(c_int)],
+    'vkx_device_pci_bus_id': [c_int, ctypes.c_char_p, c_int],
     'vkx_ctx_create': [c_int, ctypes.POINTER(c_void_p)],
     'vkx_ctx_destroy': [c_void_p],
     'vkx_ctx_sync': [c_void_p],
@@ -675,6 +676,12 @@ def camera_model_host(config, shape) -> VkxCameraModel:
     rec, out = camera_config(config, shape), VkxCameraModel()
     check(lib().vkx_camera_model_host(ctypes.byref(rec), ctypes.byref(out)))
     return out
+
+
+def device_pci_bus_id(device: int) -> str:
+    buf = ctypes.create_string_buffer(32)
+    check(lib().vkx_device_pci_bus_id(int(device), buf, 32))
+    return buf.value.decode()
 
 
 def device_copy(array, ctx=None):

@@ -24,6 +24,13 @@ VKX_EXPORT int vkx_device_count(int *count)
     return VKX_OK;
 }
 
+VKX_EXPORT int vkx_device_pci_bus_id(int device, char *buf, int len)
+{
+    VKX_REQUIRE(buf != nullptr && len >= 16, "buffer of at least 16 bytes");
+    VKX_HIP(hipDeviceGetPCIBusId(buf, len, device));
+    return VKX_OK;
+}
+
 VKX_EXPORT int vkx_ctx_create(int device, vkx_ctx **out)
 {
     VKX_REQUIRE(out != nullptr, "out is NULL");
