@@ -102,6 +102,14 @@ struct ItemDev {
     } el[4];
 };
 
+// The element descriptors of k_tile_remap travel as a KERNEL ARGUMENT: read from the descriptor in global memory, every field was
+// re-loaded after every store of the row loop (a store through el.dst may alias the descriptor as far as the compiler can tell:
+// 120 scalar loads per wavefront, 66 % of the wavefront cycles waiting); kernel arguments are constant memory.
+struct ElemPack {
+    ItemDev::Elem el[4];
+    int n;
+};
+
 struct TileBin {       // candidate cell rectangle of one tile: [rmin, rmax] x [cmin, cmax]
     int rmin, cmin;    // atomicMin, initialised to 0x7f7f7f7f
     int rmax1, cmax1;  // atomicMax of (index + 1), initialised to 0
@@ -398,7 +406,7 @@ __device__ __forceinline__ int cvt_i32_sat(float v)
 template <int KIND, bool STREAK = false, int RC = -1>   // 0 generic, 1 interior, 2 empty, 3 element remap (any element types)
 __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tx, const int ty,
                                            const vkc::CellC *__restrict__ cells, const TileBin &bin,
-                                           const HsvLut *__restrict__ lut, int phase_limit)
+                                           const HsvLut *__restrict__ lut, int phase_limit, const ElemPack *els = nullptr)
 {
     constexpr bool INTERIOR = KIND == 1, EMPTY = KIND == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -733,8 +741,10 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tx, cons
                     const int sx = X[u] >> 5, sy = Y[u] >> 5, fx = X[u] & 31, fy = Y[u] & 31;
                     const bool inner = (unsigned)sx < fast_xlim && (unsigned)sy < fast_ylim;
                     const int w00 = (32 - fy) * (32 - fx), w01 = (32 - fy) * fx, w10 = fy * (32 - fx), w11 = fy * fx;
-                    for (int e = 0; e < it.n_elems; e++) {
-                        const ItemDev::Elem &el = it.el[e];
+                    // (byte stores for RGB: packing four pixels into three dword stores -- the chain kernel's store -- measured
+                    //  0.206 against 0.177 ms here: the shuffle and the group logic cost registers this variant does not have)
+                    for (int e = 0; e < els->n; e++) {
+                        const ItemDev::Elem el = els->el[e];
                         if (el.is_f32) {
                             float v;
                             if (inner) {
@@ -1113,9 +1123,9 @@ __global__ void __launch_bounds__(NTHREADS, VKX_FUSED_WAVES_PER_EU) k_chain_fuse
 
 // Element mode of the same tile machinery: Image / Mask / ScoreMap (uint8 x 1, 3, 4 channels, float32) of one call
 // gathered through the shared lattice in one launch -- ownership in LDS, no dense map, no int32 ownership plane in HBM.
-__global__ void __launch_bounds__(NTHREADS, 4) k_tile_remap(const ItemDev *__restrict__ items,
+__global__ void __launch_bounds__(NTHREADS, 8) k_tile_remap(const ItemDev *__restrict__ items,
                                                            const vkc::CellC *__restrict__ cells,
-                                                           const TileBin *__restrict__ bins)
+                                                           const TileBin *__restrict__ bins, const ElemPack pack)
 {
     const int slots = gridDim.x;
     const ItemDev &it = items[blockIdx.y];
@@ -1128,7 +1138,7 @@ __global__ void __launch_bounds__(NTHREADS, 4) k_tile_remap(const ItemDev *__res
     const TileBin bin = bins[tile_id];
     const int ty = __builtin_amdgcn_readfirstlane(div_small(tl, it.tiles_x, __builtin_amdgcn_rcpf((float)it.tiles_x)));
     const int tx = tl - ty * it.tiles_x;
-    chain_tile<3>(it, tx, ty, cells, bin, nullptr, 0);
+    chain_tile<3>(it, tx, ty, cells, bin, nullptr, 0, &pack);
 }
 
 // Tiled noise: where the first sample of every (output row, tile column) of every image sits in the generator's slots.
@@ -1276,7 +1286,11 @@ int vkx_chain_plan_tiles(vkx_ctx *ctx, vkx_chain_plan *p, int first, int count)
     const dim3 grid(p->slots, count);
     if (p->elements) {
         VKX_TIMED(ctx, "k_tile_remap");
-        k_tile_remap<<<grid, NTHREADS, kFusedLds, ctx->stream>>>(items, p->cells, bins);
+        ElemPack pack;
+        memset(&pack, 0, sizeof(pack));
+        pack.n = p->dev[first].n_elems;
+        for (int e = 0; e < 4; e++) pack.el[e] = p->dev[first].el[e];
+        k_tile_remap<<<grid, NTHREADS, kFusedLds, ctx->stream>>>(items, p->cells, bins, pack);
     } else {
         VKX_TIMED_MAJOR(ctx, "k_chain_fused");
         if (p->streak) k_chain_fused<true><<<grid, NTHREADS, kFusedLds, ctx->stream>>>(items, p->cells, bins, p->lut, phase_limit);
