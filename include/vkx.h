@@ -654,9 +654,9 @@ int vkx_chain_rgb_batch_np_dev(vkx_ctx *ctx, const vkx_chain_item *items, int n_
                                vkx_np_result *results_host);
 /* The cell setup of a chain call (one lane per lattice cell: homographies, edge tables, tile bins) reads nothing but the vertex
  * lattices and runs on a side stream of the context.  By default it starts after everything queued on the ctx stream before the
- * chain call.  A caller whose lattices are complete earlier says so once: this call marks the current point of the ctx stream, and
- * the setups of the chain calls that follow wait for THAT point only (e.g. under a page composite queued between the mark and the
- * chain call).  Call it again after queuing anything that writes lattices. */
+ * chain call.  A caller whose lattices are complete earlier says so: this call marks the current point of the ctx stream, and the
+ * setup of the NEXT chain call waits for that point only (e.g. it then runs under a page composite queued between the mark and the
+ * chain call).  One chain call per mark: a mark never outlives the lattices it spoke of. */
 int vkx_chain_lattices_ready(vkx_ctx *ctx);
 
 /* ---- camera-model states built on the device ------------------------------------------------------------------------

@@ -436,9 +436,8 @@ class ChainBatch:
                 _native.check(lib.vkx_noise_normal_i16_batch_dev(self.ctx.handle, planes, len(members), std))
         self._runs += 1
         if self._page_layers:
-            if not self._marked:     # the lattices were uploaded by add(): the chain's cell setup need not wait for the composite
-                _native.check(lib.vkx_chain_lattices_ready(self.ctx.handle))
-                self._marked = True
+            if not self._cam:        # the lattices were uploaded by add(): the chain's cell setup need not wait for the composite
+                _native.check(lib.vkx_chain_lattices_ready(self.ctx.handle))      # (one chain call per mark)
             self._composite()
         if joint is not None:
             jobs, results, _part = joint

@@ -380,5 +380,6 @@ VKX_EXPORT int vkx_camera_states_dev(vkx_ctx *ctx, const vkx_camera_config *conf
     if (rc) return rc;
     if (!ctx->lattices_ready) VKX_HIP(hipEventCreateWithFlags(&ctx->lattices_ready, hipEventDisableTiming));
     VKX_HIP(hipEventRecord(ctx->lattices_ready, st));
+    ctx->lattices_armed = true;
     return VKX_OK;
 }

@@ -429,6 +429,7 @@ VKX_EXPORT int vkx_chain_lattices_ready(vkx_ctx *ctx)
     vkx_device_guard guard(ctx);
     if (!ctx->lattices_ready) VKX_HIP(hipEventCreateWithFlags(&ctx->lattices_ready, hipEventDisableTiming));
     VKX_HIP(hipEventRecord(ctx->lattices_ready, ctx->stream));
+    ctx->lattices_armed = true;
     return VKX_OK;
 }
 

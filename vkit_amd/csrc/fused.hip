@@ -1395,14 +1395,23 @@ int vkx_chain_plan_setup_aside(vkx_ctx *ctx, vkx_chain_plan *p, hipEvent_t *done
 {
     static const bool aside = [] { const char *e = getenv("VKX_CHAIN_SETUP_ASIDE"); return !(e && e[0] == '0'); }();
     *done = nullptr;
-    if (!aside) return vkx_chain_plan_setup(ctx, p);
+    if (!aside) {
+        if (ctx->lattices_armed) {       // the lattices may be the product of another stream (vkx_camera_states_dev)
+            vkx_device_guard guard(ctx);
+            VKX_HIP(hipStreamWaitEvent(ctx->stream, ctx->lattices_ready, 0));
+            ctx->lattices_armed = false;
+        }
+        return vkx_chain_plan_setup(ctx, p);
+    }
     int rc;
     hipStream_t main_stream = ctx->stream;
     hipStream_t side = vkx_stream_by_id(ctx, VKX_STREAM_COPY_OUT, &rc);
     if (rc) return rc;
     vkx_device_guard guard(ctx);
-    if (ctx->lattices_ready) VKX_HIP(hipStreamWaitEvent(side, ctx->lattices_ready, 0));
-    else if ((rc = vkx_stream_order(ctx, side, main_stream))) return rc;
+    if (ctx->lattices_armed) {
+        VKX_HIP(hipStreamWaitEvent(side, ctx->lattices_ready, 0));
+        ctx->lattices_armed = false;      // one chain call per mark
+    } else if ((rc = vkx_stream_order(ctx, side, main_stream))) return rc;
     if (ctx->chain_done) VKX_HIP(hipStreamWaitEvent(side, ctx->chain_done, 0));
     ctx->stream = side;
     rc = vkx_chain_plan_setup(ctx, p);

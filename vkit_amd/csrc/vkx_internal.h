@@ -61,7 +61,8 @@ struct vkx_ctx {
                                                        // run on the side stream while the shared slots above serve the compute stream
     hipEvent_t chain_setup_done = nullptr; // the side stream past the setup kernels of the current chain call
     hipEvent_t chain_done = nullptr;       // the pixel kernel of the last chain call (reads the three slots above)
-    hipEvent_t lattices_ready = nullptr;   // vkx_chain_lattices_ready: the point of the compute stream the lattices are complete at
+    hipEvent_t lattices_ready = nullptr;   // vkx_chain_lattices_ready: the point of a stream the lattices are complete at
+    bool lattices_armed = false;           // ... for the NEXT chain call only (a stale mark must not outlive the lattices it spoke of)
     vkx_scratch noise_table;          // int16 [65536] inverse-CDF table of vkx_noise_normal_i16 for noise_table_std
     double noise_table_std = 0.0;
     bool noise_table_fits8 = false;
