@@ -482,7 +482,9 @@ int vkx_fill_poly_mask_u8(vkx_ctx *ctx, const int32_t *pts_host, int npts, uint8
  * pts_host: HOST int32 [total_pts, 2] (x, y) in plane coordinates (parts outside the plane are clipped);
  * poly_offsets_host: HOST int32 [n_polys + 1]; values_host: HOST float32 [n_polys] (required with score).
  * mask / score: either may be NULL.  A polygon with more than 64 crossings on one scanline is refused
- * (VKX_ERR_UNSUPPORTED; paint such polygons one by one through vkx_fill_poly_mask_u8 + vkx_fill_*). */
+ * (VKX_ERR_UNSUPPORTED; paint such polygons one by one through vkx_fill_poly_mask_u8 + vkx_fill_*).
+ * _dev: asynchronous on the ctx stream when no polygon has more than 64 vertices (none can then exceed the crossing limit: the
+ * tables travel through the context's page-locked ring); with larger polygons the call waits for the overflow flag. */
 int vkx_paint_polys_dev(vkx_ctx *ctx, const int32_t *pts_host, const int32_t *poly_offsets_host, int n_polys,
                         const float *values_host, uint8_t *mask, ptrdiff_t mask_stride, float *score,
                         ptrdiff_t score_stride_el, int h, int w);

@@ -113,3 +113,22 @@ def test_affine_on_arrays_is_the_reference_construction(seed):
         want_points = PointTuple.from_np_array(A.affine_np_points(trans_mat, points.to_smooth_np_array()))
         _same_points(A.affine_points(trans_mat, points), want_points)
         _same_points(A.affine_points(trans_mat, PointArray.from_points(points)), want_points)
+
+
+def test_group_means_equal_the_slice_means():
+    """``page_distortion._group_means``: the text-line heights of a page as whole-array arithmetic, bit for bit ``slice.mean()``
+    (float32 and float64, groups of 1 .. 7 elements vectorised, larger groups through the slices)."""
+    from numpy.random import default_rng
+    from vkit_amd.pipeline.text_detection.page_distortion import _group_means
+    rng = default_rng(0)
+    for dtype in (np.float32, np.float64):
+        for hi in (8, 40):
+            for _ in range(200):
+                sizes = [int(v) for v in rng.integers(1, hi, int(rng.integers(1, 80)))]
+                values = (rng.random(sum(sizes)) * 100).astype(dtype)
+                want, begin = [], 0
+                for size in sizes:
+                    want.append(float(values[begin:begin + size].mean()))
+                    begin += size
+                assert _group_means(values, sizes) == want
+    assert _group_means(np.zeros(0), []) == []

@@ -6,6 +6,9 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# (VKX_CHAIN_CHUNKS=1: one k_np_draw / k_chain_fused launch per batch, so that "per launch" is "per batch" in tools/pmc_parse.py; the
+#  counters per image do not depend on how the library cuts the batch into chunks)
+export VKX_CHAIN_CHUNKS=1
 BENCH="python $ROOT/bench.py --batch $BATCH --steps 2 --warmup 1 --cpu-sample 0 --verify 0 --extra-legs 0"
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \

@@ -10,6 +10,7 @@ python -c "import bench; print(bench.kernel_source_digest())" > gpurun_out/diges
 $ROOT/tools/pmc.sh $TAG 32
 python $ROOT/tools/pmc_parse.py $TAG 32 0 > /dev/null          # writes profiles/current_traffic.json on this box for the bench below
 cd $ROOT
+unset VKX_CHAIN_CHUNKS
 timeout 900 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err; echo "bench rc=$?"
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/stats_$TAG -o stats -- \
@@ -19,3 +20,9 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/stats256_$TAG -o stats -- \
     python $ROOT/bench.py --batch 256 --steps 5 --warmup 1 --cpu-sample 0 --verify 0 --extra-legs 0 \
     > $ROOT/gpurun_out/stats256_$TAG.log 2>&1; echo "stats256 rc=$?"
+# the timeline of one step (which kernel runs under which): rocprofv3 --kernel-trace of a short run, tools/timeline.py
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $ROOT/gpurun_out/tl_$TAG -o tl -- \
+    python $ROOT/bench.py --steps 6 --warmup 2 --cpu-sample 0 --verify 0 --extra-legs 0 > /dev/null 2>&1
+f=$(find $ROOT/gpurun_out/tl_$TAG -name "*kernel_trace.csv" | head -1)
+[ -n "$f" ] && VKX_TL_CAMERA=1 python $ROOT/tools/timeline.py $f 2 > $ROOT/gpurun_out/${TAG}_timeline.txt
+rm -rf $ROOT/gpurun_out/tl_$TAG

@@ -64,11 +64,16 @@ __device__ __forceinline__ double pairwise_block(const double *__restrict__ a, i
 // sum(a, n) = sum(a, n2) + sum(a + n2, n - n2), n2 = n / 2 rounded down to a multiple of 8, down to blocks of <= 128: the
 // traversal as an explicit stack; `leaf(lo, n)` returns the value of a block (pass 1 records the blocks and returns 0, pass 2
 // hands back the sums the lanes formed in between)
-template <typename F>
-__device__ __forceinline__ double pairwise_walk(int n, F leaf)
-{
+struct WalkStack {          // in LDS: indexed private arrays would live in scratch memory (a round trip to HBM per access)
     int lo_s[8], n_s[8], stage[8];
-    double left[8], res = 0.;
+    double left[8];
+};
+
+template <typename F>
+__device__ __forceinline__ double pairwise_walk(int n, WalkStack &ws, F leaf)
+{
+    int *lo_s = ws.lo_s, *n_s = ws.n_s, *stage = ws.stage;
+    double *left = ws.left, res = 0.;
     int sp = 1;
     lo_s[0] = 0; n_s[0] = n; stage[0] = 0;
     while (sp > 0) {
@@ -127,6 +132,7 @@ __global__ void __launch_bounds__(256) k_camera_states(const StateDev *__restric
     __shared__ int leaf_lo[kLeaves], leaf_n[kLeaves];
     __shared__ double leaf_sum[kLeaves];
     __shared__ int n_leaves;
+    __shared__ WalkStack walk;
     __shared__ double s_mean;
     __shared__ double red[4][4];
     __shared__ unsigned bad;
@@ -164,7 +170,7 @@ __global__ void __launch_bounds__(256) k_camera_states(const StateDev *__restric
             const int n = min(kPiece, N - lo);
             if (tid == 0) {
                 int count = 0;
-                pairwise_walk(n, [&](int l, int k) { leaf_lo[count] = l; leaf_n[count] = k; count++; return 0.; });
+                pairwise_walk(n, walk, [&](int l, int k) { leaf_lo[count] = l; leaf_n[count] = k; count++; return 0.; });
                 n_leaves = count;
             }
             __syncthreads();
@@ -172,7 +178,7 @@ __global__ void __launch_bounds__(256) k_camera_states(const StateDev *__restric
             __syncthreads();
             if (tid == 0) {
                 int next = 0;
-                total = total + pairwise_walk(n, [&](int, int) { return leaf_sum[next++]; });
+                total = total + pairwise_walk(n, walk, [&](int, int) { return leaf_sum[next++]; });
             }
             __syncthreads();
         }

@@ -91,11 +91,16 @@ class ElementFlattener(Generic[_E]):
     def flatten_polygons(self) -> PolygonSoup:
         """The groups as ONE array-backed sequence of polygons (element/soup.py): the chain's geometric operators, its
         clipping and the label paint then work on the vertex array and build no ``Point`` / ``Polygon`` object."""
-        return PolygonSoup.concatenate([PolygonSoup.from_polygons(group) for group in self.grouped_elements])
+        if any(isinstance(group, PolygonSoup) for group in self.grouped_elements):
+            return PolygonSoup.concatenate([PolygonSoup.from_polygons(group) for group in self.grouped_elements])
+        return PolygonSoup.from_polygons(itertools.chain.from_iterable(self.grouped_elements))     # one pass, one concatenate
 
     def flatten_points(self) -> PointArray:
-        groups = [PointArray.from_points(group) for group in self.grouped_elements]
-        return PointArray(np.concatenate([g.smooth_xy for g in groups], axis=0) if groups else np.zeros((0, 2)))
+        if any(isinstance(group, PointArray) for group in self.grouped_elements):
+            groups = [PointArray.from_points(group) for group in self.grouped_elements]
+            return PointArray(np.concatenate([g.smooth_xy for g in groups], axis=0) if groups else np.zeros((0, 2)))
+        flat = PointArray.from_points(itertools.chain.from_iterable(self.grouped_elements))
+        return PointArray(flat.smooth_xy)
 
     def unflatten(self, flattened_elements: Sequence[_E]) -> Sequence[Sequence[_E]]:
         assert len(flattened_elements) == sum(self.group_sizes)
@@ -137,6 +142,32 @@ def _heights(points_up: PointList, points_down: PointList):
     return np_heights
 
 
+def _group_means(values: np.ndarray, group_sizes: Sequence[int]) -> List[float]:
+    """``values[begin:begin + size].mean()`` per group (reference page_distortion.py:188-196), for all groups at once when every
+    group has fewer than 8 elements: ``.mean()`` then adds its slice one element after the other starting from 0 (numpy's pairwise
+    sum starts at 8 elements), so the groups are laid out as rows of a zero-padded matrix and the columns added in order -- the same
+    additions (x + 0.0 is x), then the same division by the count; tests/test_soup.py compares the two forms.  Larger or empty groups
+    take the slice form.  (``np.add.reduceat`` associates differently: first element + sum of the rest.)"""
+    sizes = np.asarray(group_sizes, dtype=np.int64)
+    if sizes.size == 0:
+        return []
+    if (sizes <= 0).any() or (sizes >= 8).any() or values.dtype not in (np.float32, np.float64):
+        out, begin = [], 0
+        for size in group_sizes:
+            out.append(float(values[begin:begin + size].mean()))
+            begin += size
+        return out
+    starts = np.cumsum(sizes) - sizes
+    width = int(sizes.max())
+    cols = np.arange(width)
+    padded = np.where(cols[None, :] < sizes[:, None], values[np.minimum(starts[:, None] + cols[None, :], values.shape[0] - 1)],
+                      values.dtype.type(0))
+    acc = np.zeros(sizes.shape[0], values.dtype)
+    for c in range(width):
+        acc = acc + padded[:, c]
+    return [float(v) for v in (acc / sizes.astype(values.dtype))]
+
+
 class PageDistortionStep(PipelineStep[PageDistortionStepConfig, PageDistortionStepInput, PageDistortionStepOutput]):
 
     def __init__(self, config: PageDistortionStepConfig):
@@ -173,10 +204,7 @@ class PageDistortionStep(PipelineStep[PageDistortionStepConfig, PageDistortionSt
         if self.config.enable_distorted_text_line_height_score_map:
             np_heights = _heights(text_line_height_points_up, text_line_height_points_down)
             assert sum(text_line_height_points_group_sizes) == np_heights.shape[0]
-            text_line_heights, begin = [], 0
-            for group_size in text_line_height_points_group_sizes:
-                text_line_heights.append(float(np_heights[begin:begin + group_size].mean()))
-                begin += group_size
+            text_line_heights = _group_means(np_heights, text_line_height_points_group_sizes)
         text_line_mask, text_line_height_score_map = None, None
         if self.config.enable_distorted_text_line_mask or text_line_heights is not None:
             text_line_mask, text_line_height_score_map = paint_polygons(
