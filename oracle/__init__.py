@@ -23,7 +23,7 @@ SOLVER_JACOBI = 1  # restatement of OpenCV's built-in DECOMP_SVD path for every 
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, 'vkx_oracle.c'), os.path.join(_HERE, 'np_random.c')]
+    srcs = [os.path.join(_HERE, 'vkx_oracle.c'), os.path.join(_HERE, 'np_random.c'), os.path.join(_HERE, 'vkx_cpu.c')]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.run(['make', '-C', _HERE], check=True, capture_output=True)
     return _LIB_PATH
