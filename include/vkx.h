@@ -691,6 +691,7 @@ typedef struct vkx_camera_model {           /* what the per-vertex kernel consum
 #define VKX_GRID_STATE_NAN 1u               /* a projected vertex is NaN (the reference raises ValueError in Point's round()) */
 #define VKX_GRID_STATE_INF 2u               /* ... infinite (OverflowError) */
 #define VKX_GRID_STATE_RANGE 4u             /* the lattice leaves int32 */
+#define VKX_GRID_STATE_DIVIDE 8u            /* similarity_mls: a vertex on an integer handle position (the reference raises FloatingPointError) */
 typedef struct vkx_grid_state {
     int32_t rows, cols, dh, dw;             /* lattice shape; result shape = extent of the destination lattice */
     int32_t shift_y, shift_x;               /* DistortionStateImageGridBased.shift_amount_* */
@@ -704,6 +705,19 @@ int vkx_camera_model_host(const vkx_camera_config *config, vkx_camera_model *out
  * this call's kernel (it records the lattices-ready point of vkx_chain_lattices_ready). */
 int vkx_camera_states_dev(vkx_ctx *ctx, const vkx_camera_config *configs_host, int n, int32_t *const *src_vertices,
                           int32_t *const *dst_vertices, vkx_grid_state *states_host, int stream);
+
+/* SimilarityMlsState (geometric/mls.py:140-157; SimilarityMlsPointProjector.project_point :38-135 per lattice vertex, then
+ * grid_rendering/grid_creator.py:44-115 with resize_as_src = False, the operator's default) for a BATCH of configs: handle tables are
+ * HOST arrays -- float32 [n, 2] integer positions (PointTuple.to_smooth_np_array) and float64 [n, 2] smooth positions of the source and
+ * destination handles --, the lattices DEVICE buffers as for vkx_camera_states_dev, to which everything else said there applies.
+ * (vkit_amd/csrc/mls.hip) */
+typedef struct vkx_mls_config {
+    int32_t height, width, grid_size, n_handles;
+    const float *src_handles, *dst_handles;
+    const double *src_handles_smooth, *dst_handles_smooth;
+} vkx_mls_config;
+int vkx_mls_states_dev(vkx_ctx *ctx, const vkx_mls_config *configs_host, int n, int32_t *const *src_vertices,
+                       int32_t *const *dst_vertices, vkx_grid_state *states_host, int stream);
 
 /* ---- per-kernel timing -----------------------------------------------------------------
  * When enabled, every kernel launch is bracketed by a hipEvent pair recorded on the ctx

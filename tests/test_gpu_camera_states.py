@@ -163,3 +163,120 @@ def test_chain_batch_builds_its_states_inside_run():
     assert (got_batch.result(7) == want[7]).all()
     for b in (want_batch, got_batch, single):
         b.close()
+
+
+# ---------------------------------------------------------------------------------------------- similarity_mls, batched
+def _build_mls(N, ctx, cases, stream=0):
+    """cases: (SimilarityMlsConfig, shape); returns (lattice DevArrays, result tuples) of ONE vkx_mls_states_dev call."""
+    n = len(cases)
+    recs, keep = zip(*[N.mls_config(cfg, shape) for cfg, shape in cases])
+    records = (N.VkxMlsConfig * n)(*recs)
+    lattices = []
+    for rec in recs:
+        rows, cols = N.lattice_shape(rec.height, rec.width, rec.grid_size)
+        lattices.append((ctx.dev_empty((rows, cols, 2), np.int32), ctx.dev_empty((rows, cols, 2), np.int32)))
+    sv = (ctypes.c_void_p * n)(*[a.ptr for a, _b in lattices])
+    dv = (ctypes.c_void_p * n)(*[b.ptr for _a, b in lattices])
+    out_ptr = ctx.host_alloc(n * ctypes.sizeof(N.VkxGridState))
+    out = (N.VkxGridState * n).from_address(out_ptr)
+    N.check(N.lib().vkx_mls_states_dev(ctx.handle, records, n, sv, dv, ctypes.c_void_p(out_ptr), stream))
+    ctx.sync_stream(stream)
+    states = [(out[k].rows, out[k].cols, out[k].dh, out[k].dw, out[k].shift_y, out[k].shift_x, out[k].flags) for k in range(n)]
+    ctx.host_free(out_ptr)
+    del keep
+    return lattices, states
+
+
+def test_mls_states_batch_equals_the_reference_goldens(golden_dir):
+    """All twelve similarity_mls goldens of the imported reference (five small states, 1024^2, the C2 / C5 sizes 2048^2 and 4096^2) in
+    ONE vkx_mls_states_dev call: lattices, result shapes and shifts bit for bit."""
+    import json
+    import os
+    from vkit_amd import _native as N
+    from vkit_amd.element import Point, PointTuple
+    from vkit_amd.mechanism import distortion as D
+    cases, wants = [], []
+    for fname in ('mls_states.npz', 'mls_lattices.npz'):
+        M = np.load(os.path.join(golden_dir, fname))
+        for m in json.loads(bytes(M['meta_json'])):
+            k = m['key']
+            if k + '_src_handles' not in M.files:
+                continue
+            cfg = D.SimilarityMlsConfig(
+                src_handle_points=PointTuple(Point.create(y=y, x=x) for x, y in M[k + '_src_handles']),
+                dst_handle_points=PointTuple(Point.create(y=y, x=x) for x, y in M[k + '_dst_handles']),
+                grid_size=m['grid_size'])
+            cases.append((cfg, (m['h'], m['w'])))
+            wants.append((np.asarray(M[k + '_dst_grid'], np.int32), tuple(m['result_shape']), m['shift']))
+    assert len(cases) == 12
+    for stream in (0, 2):
+        lattices, states = _build_mls(N, N.default_ctx(), cases, stream)
+        for k, ((_sv, dv), st, (want, shape, shift)) in enumerate(zip(lattices, states, wants)):
+            assert st[6] == 0 and (st[2], st[3]) == shape and [st[4], st[5]] == shift, (k, st)
+            assert np.array_equal(dv.host(), want), k
+
+
+def test_mls_states_batch_equals_the_host_operator(monkeypatch):
+    """Policy configs at random levels on random page shapes -- elongated pages included (hundreds of handles: the pairwise sums and the
+    sgemv kernel switch) -- in one call, against the operator's own state (which projects lattice by lattice)."""
+    from vkit_amd import _native as N
+    from vkit_amd.mechanism import distortion as D
+    from vkit_amd.mechanism.distortion_policy.geometric import mls as P_mls
+    monkeypatch.delenv('VKX_MLS_HOST_PROJECTION', raising=False)
+    rng = default_rng(31)
+    cases, hosts = [], []
+    for k in range(60):
+        shape = (int(rng.integers(60, 900)), int(rng.integers(60, 900))) if k % 6 else (int(rng.integers(1500, 2600)), int(rng.integers(90, 160)))
+        cfg = P_mls.SimilarityMlsConfigGenerator(P_mls.SimilarityMlsConfigGeneratorConfig(), int(rng.integers(1, 11)))(shape, rng)
+        cases.append((cfg, shape))
+        hosts.append(D.similarity_mls.generate_state(cfg, shape))
+    lattices, states = _build_mls(N, N.default_ctx(), cases)
+    for k, (st, (sv, dv), got) in enumerate(zip(hosts, lattices, states)):
+        assert got[6] == 0 and got[2:6] == (st.result_shape[0], st.result_shape[1], st.shift_amount_y, st.shift_amount_x), (k, got)
+        assert np.array_equal(dv.host(), st.dst_image_grid.vertices) and np.array_equal(sv.host(), st.src_image_grid.vertices), k
+
+
+def test_chain_batch_mixes_camera_and_mls_configs():
+    """``add_config`` with similarity_mls and camera configs in one batch (two state calls, one layout) against ``add`` on host-built
+    states; a vertex ON an integer handle position raises FloatingPointError like the reference's np.errstate(divide='raise')."""
+    from vkit_amd.batch import ChainBatch
+    from vkit_amd.element import Point, PointTuple
+    from vkit_amd.mechanism import distortion as D
+    from vkit_amd.mechanism.distortion_policy.geometric import camera as P_cam, mls as P_mls
+    rng = default_rng(8)
+    items = []
+    for k in range(18):
+        shape = (int(rng.integers(70, 300)), int(rng.integers(70, 300)))
+        level = int(rng.integers(1, 11))
+        if k % 2:
+            cfg, op = P_mls.SimilarityMlsConfigGenerator(P_mls.SimilarityMlsConfigGeneratorConfig(), level)(shape, rng), D.similarity_mls
+        else:
+            cfg, op = P_cam.CameraCubicCurveConfigGenerator(P_cam.CameraCubicCurveConfigGeneratorConfig(), level)(shape, rng), D.camera_cubic_curve
+        items.append((rng.integers(0, 256, shape + (3,), dtype=np.uint8), cfg, op))
+
+    def run(from_config):
+        batch = ChainBatch()
+        for k, (image, cfg, op) in enumerate(items):
+            kwargs = dict(blur_sigma=1.0, hue_delta=21, noise_std=7.0, noise_rng=default_rng(300 + k))
+            if from_config:
+                batch.add_config(image, cfg, **kwargs)
+            else:
+                batch.add(image, op.generate_state(cfg, image.shape[:2]), **kwargs)
+        batch.run()
+        batch.run()
+        out = [batch.result(k) for k in range(len(items))]
+        batch.close()
+        return out
+
+    for k, (g, w) in enumerate(zip(run(True), run(False))):
+        assert g.shape == w.shape and (g == w).all(), k
+    # a lattice vertex (0, 0) on an integer handle position whose smooth position differs: 1 / 0 in the weights
+    handles = PointTuple([Point.create(y=0.2, x=0.3), Point.create(y=40, x=50), Point.create(y=10, x=60)])
+    cfg = D.SimilarityMlsConfig(src_handle_points=handles, dst_handle_points=handles, grid_size=16)
+    batch = ChainBatch()
+    batch.add_config(np.zeros((64, 80, 3), np.uint8), cfg)
+    with pytest.raises(FloatingPointError):
+        batch.run()
+    batch.close()
+    with pytest.raises(FloatingPointError):
+        D.similarity_mls.generate_state(cfg, (64, 80))

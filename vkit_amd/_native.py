@@ -147,6 +147,14 @@ class VkxCameraModel(ctypes.Structure):
     ]
 
 
+class VkxMlsConfig(ctypes.Structure):
+    _fields_ = [
+        ('height', ctypes.c_int32), ('width', ctypes.c_int32), ('grid_size', ctypes.c_int32), ('n_handles', ctypes.c_int32),
+        ('src_handles', c_void_p), ('dst_handles', c_void_p),
+        ('src_handles_smooth', c_void_p), ('dst_handles_smooth', c_void_p),
+    ]
+
+
 class VkxGridState(ctypes.Structure):
     _fields_ = [
         ('rows', ctypes.c_int32), ('cols', ctypes.c_int32), ('dh', ctypes.c_int32), ('dw', ctypes.c_int32),
@@ -155,7 +163,7 @@ class VkxGridState(ctypes.Structure):
 
 
 CAMERA_PLANE_ONLY, CAMERA_CUBIC_CURVE = 0, 1
-GRID_STATE_NAN, GRID_STATE_INF, GRID_STATE_RANGE = 1, 2, 4
+GRID_STATE_NAN, GRID_STATE_INF, GRID_STATE_RANGE, GRID_STATE_DIVIDE = 1, 2, 4, 8
 
 
 class VkxNoisePlane(ctypes.Structure):
@@ -203,6 +211,7 @@ _SIGNATURES = {
     'vkx_chain_lattices_ready': [c_void_p],
     'vkx_camera_model_host': [ctypes.POINTER(VkxCameraConfig), ctypes.POINTER(VkxCameraModel)],
     'vkx_camera_states_dev': [c_void_p, ctypes.POINTER(VkxCameraConfig), c_int, c_void_p, c_void_p, c_void_p, c_int],
+    'vkx_mls_states_dev': [c_void_p, ctypes.POINTER(VkxMlsConfig), c_int, c_void_p, c_void_p, c_void_p, c_int],
     'vkx_noise_normal_table': [c_double, c_void_p],
     'vkx_noise_normal_i16_dev': [c_void_p, c_void_p, c_ssize, c_int, c_int, c_int, c_double, ctypes.c_uint64],
     'vkx_noise_normal_i16': [c_void_p, c_void_p, c_ssize, c_int, c_int, c_int, c_double, ctypes.c_uint64],
@@ -669,6 +678,33 @@ def camera_config(config, shape) -> VkxCameraConfig:
         rec.curve_alpha, rec.curve_beta = float(config.curve_alpha), float(config.curve_beta)
         rec.curve_direction, rec.curve_scale = float(config.curve_direction), float(config.curve_scale)
     return rec
+
+
+def mls_config(config, shape):
+    """(VkxMlsConfig, keepalive arrays) of a ``SimilarityMlsConfig`` for an image of ``shape`` (vkx_mls_states_dev): the float32
+    integer handle positions the reference feeds its arithmetic (``PointTuple.to_smooth_np_array``) and the float64 smooth ones."""
+    if getattr(config, 'resize_as_src', False):
+        raise ValueError('the batched similarity_mls states take resize_as_src=False (the default)')
+    src, dst = config.src_handle_points, config.dst_handle_points
+    if len(src) != len(dst) or len(src) < 1:
+        raise ValueError('handle lists differ in length')
+    p = np.ascontiguousarray(src.to_smooth_np_array(), dtype=np.float32).reshape(-1, 2)
+    q = np.ascontiguousarray(dst.to_smooth_np_array(), dtype=np.float32).reshape(-1, 2)
+    ps = np.asarray([(h.smooth_x, h.smooth_y) for h in src], dtype=np.float64).reshape(-1, 2)
+    qs = np.asarray([(h.smooth_x, h.smooth_y) for h in dst], dtype=np.float64).reshape(-1, 2)
+    rec = VkxMlsConfig()
+    rec.height, rec.width, rec.grid_size, rec.n_handles = int(shape[0]), int(shape[1]), int(config.grid_size), p.shape[0]
+    rec.src_handles, rec.dst_handles = p.ctypes.data, q.ctypes.data
+    rec.src_handles_smooth, rec.dst_handles_smooth = ps.ctypes.data, qs.ctypes.data
+    return rec, (p, q, ps, qs)
+
+
+def lattice_shape(height, width, grid_size):
+    """(rows, cols) of the source lattice: a vertex every ``grid_size`` pixels plus the last row / column (grid_creator.py:22-41)."""
+    def ticks(length):
+        n = (length + grid_size - 1) // grid_size
+        return n + 1 if (n - 1) * grid_size != length - 1 else n
+    return ticks(int(height)), ticks(int(width))
 
 
 def camera_model_host(config, shape) -> VkxCameraModel:

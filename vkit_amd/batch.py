@@ -177,7 +177,7 @@ class ChainBatch:
             for c in range(3):
                 item.streak_color[c] = int(streak.color[c])
             item.streak_alpha = float(streak.alpha)
-        self._cam.append((len(self._items), _native.camera_config(config, (sh, sw)), None if noise_std is None else float(noise_std), stream))
+        self._cam.append((len(self._items), self._state_record(config, (sh, sw)), None if noise_std is None else float(noise_std), stream))
         self._cam_state = None
         self._items.append(item)
         self._dst_shapes.append((0, 0))
@@ -190,12 +190,25 @@ class ChainBatch:
         for k, (i, _rec, std, stream) in enumerate(self._cam):
             if i == index:
                 it = self._items[index]
-                self._cam[k] = (i, _native.camera_config(config, (int(it.sh), int(it.sw))), std, stream)
-                if self._cam_state is not None:
-                    self._cam_state.records[k] = self._cam[k][1]
-                    self._cam_state.refresh_lattice_shapes(self.ctx)
+                self._cam[k] = (i, self._state_record(config, (int(it.sh), int(it.sw))), std, stream)
+                if self._cam_state is not None:        # rebuilt on the next run (new lattice buffers, new layout)
+                    self.ctx.sync()
+                    self._cam_state.close(self.ctx)
+                    self._cam_state = None
                 return
         raise KeyError(f'item {index} was not added with add_config')
+
+    @staticmethod
+    def _state_record(config, shape):
+        """The C record of a config whose state the device builds: ('camera', VkxCameraConfig) for camera_plane_only /
+        camera_cubic_curve, ('mls', VkxMlsConfig, keepalive) for similarity_mls."""
+        if hasattr(config, 'src_handle_points'):
+            rec, keep = _native.mls_config(config, shape)
+            return ('mls', rec, keep)
+        if hasattr(config, 'camera_model_config') and not hasattr(config, 'fold_point') and not hasattr(config, 'curve_point'):
+            return ('camera', _native.camera_config(config, shape))
+        raise TypeError(f'{type(config).__name__}: states built on the device exist for camera_plane_only, camera_cubic_curve and '
+                        'similarity_mls (build the state with the operator and use add())')
 
     def _ensure_array(self):
         """The contiguous descriptor array of the batch; ``self._items`` become views of its records (one copy of every field)."""
@@ -211,7 +224,7 @@ class ChainBatch:
         t0 = time.perf_counter()
         cs = self._cam_state
         if cs is None:
-            cs = self._cam_state = _CameraStates(self.ctx, [rec for _i, rec, _s, _st in self._cam])
+            cs = self._cam_state = _DeviceStates(self.ctx, [rec for _i, rec, _s, _st in self._cam])
             cs.index = np.asarray([i for i, _r, _s, _st in self._cam], np.int64)
             cs.noisy = np.asarray([st is not None for _i, _r, _s, st in self._cam], bool)
         which = self._runs & 1
@@ -479,22 +492,27 @@ class ChainBatch:
             pass
 
 
-class _CameraStates:
-    """The device side of ``ChainBatch.add_config``: the config records, two sets of lattice buffers, the page-locked result records
-    and the arena the destinations / tile buffers of the batch live in."""
+class _DeviceStates:
+    """The device side of ``ChainBatch.add_config``: the config records (camera and similarity_mls kinds, each kind one call), two sets
+    of lattice buffers, the page-locked result records and the arena the destinations / tile buffers of the batch live in."""
 
     def __init__(self, ctx, records):
         n = len(records)
         self.n = n
-        self.records = (_native.VkxCameraConfig * n)(*records)
+        self.kinds = [r[0] for r in records]
+        self.keep = [r[2:] for r in records]
+        self.groups = {}         # kind -> (positions in the batch, ctypes record array)
+        for kind, cls in (('camera', _native.VkxCameraConfig), ('mls', _native.VkxMlsConfig)):
+            pos = [k for k, r in enumerate(records) if r[0] == kind]
+            if pos:
+                self.groups[kind] = (pos, (cls * len(pos))(*[records[k][1] for k in pos]))
         self._out_ptr = ctx.host_alloc(n * ctypes.sizeof(_native.VkxGridState))
         self.out = (_native.VkxGridState * n).from_address(self._out_ptr)
         self.states = _native.struct_view(self.out)
         self.sets = [None, None]
         self.sv_ptr = [None, None]
         self.dv_ptr = [None, None]
-        self._sv_c = [None, None]
-        self._dv_c = [None, None]
+        self._ptr_c = {}
         self._arena = 0
         self._arena_cap = 0
         self.last_shapes = None
@@ -503,36 +521,49 @@ class _CameraStates:
         _native.check(_native.lib().vkx_np_tiles_layout(1 << 20, *[ctypes.byref(v) for v in shape]))
         self.slot_elems = int(shape[1].value)
         self.tile_draws = 3072          # raw draws per generator tile (csrc/nprand.hip kTile; tests/test_camera_states.py checks the layout formula)
-        self.refresh_lattice_shapes(ctx)
-
-    def refresh_lattice_shapes(self, ctx):
-        lib = _native.lib()
-        model = _native.VkxCameraModel()
-        cells = np.empty(self.n, np.int64)
-        for k in range(self.n):
-            _native.check(lib.vkx_camera_model_host(ctypes.byref(self.records[k]), ctypes.byref(model)))
-            cells[k] = model.rows * model.cols
+        # lattice buffers: the states of a kind are contiguous in the result records (camera first), `order` maps batch position -> record
+        cells = np.empty(n, np.int64)
+        for k, r in enumerate(records):
+            rec = r[1]
+            rows, cols = _native.lattice_shape(rec.height, rec.width, rec.grid_size)
+            cells[k] = rows * cols
         lattice_bytes = (cells * 8 + 255) & ~255
         offsets = np.concatenate([[0], np.cumsum(np.repeat(lattice_bytes, 2))])
         total = int(offsets[-1])
+        self.order = np.empty(n, np.int64)
+        first = 0
+        for kind in ('camera', 'mls'):
+            if kind in self.groups:
+                pos = self.groups[kind][0]
+                self.order[pos] = first + np.arange(len(pos))
+                first += len(pos)
         for which in (0, 1):
-            if self.sets[which]:
-                ctx.free(self.sets[which])
             base = self.sets[which] = ctx.malloc(max(total, 256))
             self.sv_ptr[which] = (base + offsets[0:-1:2]).astype(np.uint64)
             self.dv_ptr[which] = (base + offsets[1::2]).astype(np.uint64)
-            self._sv_c[which] = (ctypes.c_void_p * self.n)(*[int(v) for v in self.sv_ptr[which]])
-            self._dv_c[which] = (ctypes.c_void_p * self.n)(*[int(v) for v in self.dv_ptr[which]])
-        self.last_shapes = None
+            for kind, (pos, _recs) in self.groups.items():
+                self._ptr_c[(which, kind)] = ((ctypes.c_void_p * len(pos))(*[int(self.sv_ptr[which][k]) for k in pos]),
+                                              (ctypes.c_void_p * len(pos))(*[int(self.dv_ptr[which][k]) for k in pos]))
 
     def build(self, ctx, which, stream):
-        _native.check(_native.lib().vkx_camera_states_dev(ctx.handle, self.records, self.n, self._sv_c[which], self._dv_c[which],
-                                                          ctypes.c_void_p(self._out_ptr), int(stream)))
+        lib = _native.lib()
+        first = 0
+        size = ctypes.sizeof(_native.VkxGridState)
+        for kind, fn in (('camera', lib.vkx_camera_states_dev), ('mls', lib.vkx_mls_states_dev)):
+            if kind not in self.groups:
+                continue
+            pos, recs = self.groups[kind]
+            sv, dv = self._ptr_c[(which, kind)]
+            _native.check(fn(ctx.handle, recs, len(pos), sv, dv, ctypes.c_void_p(self._out_ptr + first * size), int(stream)))
+            first += len(pos)
         ctx.sync_stream(stream)
-        states = self.states
+        states = self.states[self.order]          # in batch order
         flags = states['flags']
         if flags.any():
-            # the reference builds a Point per vertex and fails in its round() (element/point.py:31-47)
+            # the reference builds a Point per vertex and fails in its round() (element/point.py:31-47); similarity_mls divides by a
+            # zero distance under np.errstate(divide='raise') when a vertex sits on an integer handle position
+            if (flags & _native.GRID_STATE_DIVIDE).any():
+                raise FloatingPointError('divide by zero encountered in divide')
             if (flags & _native.GRID_STATE_NAN).any():
                 raise ValueError('cannot convert float NaN to integer')
             if (flags & _native.GRID_STATE_INF).any():

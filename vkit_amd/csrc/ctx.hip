@@ -87,6 +87,7 @@ VKX_EXPORT int vkx_ctx_destroy(vkx_ctx *ctx)
     scratch_release(&ctx->np_work[0]);
     scratch_release(&ctx->np_work[1]);
     scratch_release(&ctx->camera_work);
+    scratch_release(&ctx->mls_work);
     scratch_release(&ctx->fog_work);
     scratch_release(&ctx->glass_win);
     scratch_release(&ctx->pz_tabs);

@@ -69,6 +69,7 @@ struct vkx_ctx {
     vkx_scratch np_tabs;              // jump constants + ziggurat tables of the numpy streams (nprand.hip), uploaded once
     vkx_scratch noise_rows;           // tiled noise of the fused chain: (row, tile column) -> slot offset records (fused.hip)
     vkx_scratch np_work[2];           // tile arrays of the numpy streams: the chunks of a call alternate (nprand.hip)
+    vkx_scratch mls_work;                     // batched similarity_mls states (mls.hip): descriptors, handle tables, projected positions
     vkx_scratch camera_work;                  // camera states (camera.hip): descriptors, results, the depth values of the cubic curve
     vkx_scratch fog_work;                     // fog field (fog.hip): raw draws + the float64 centres of a level; a glass round's temporaries
     vkx_scratch glass_win;                    // glass shuffle: the winner plane of a round's scatter (uint64 [h, w], zero between rounds)
