@@ -118,3 +118,39 @@ def test_torch_device_memory_and_stream_interop(N):
     np.testing.assert_array_equal(t_dst.cpu().numpy(), want)
     np.testing.assert_array_equal(doubled.cpu().numpy(), want.astype(np.int32) * 2)
     ctx.close()
+
+
+def test_warp_affine_rgb_on_misaligned_device_planes():
+    """The RGB warp reads its taps as aligned dwords from the aligned-down base of the source (csrc/remap.hip): sources that start 1, 2
+    and 3 bytes into a device buffer, with a pitch that is not a multiple of 4, ending exactly at the end of the allocation; rotations,
+    shears and a shrink, against the oracle."""
+    import ctypes
+    import oracle as O
+    from vkit_amd import _native as N
+    ctx = N.default_ctx()
+    rng = np.random.default_rng(12)
+    for k, (h, w, pad) in enumerate([(61, 83, 0), (40, 129, 5), (97, 64, 2), (33, 47, 7)]):
+        pitch = w * 3 + pad
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        host = np.zeros((h, pitch), np.uint8)
+        host[:, :w * 3] = img.reshape(h, w * 3)
+        for off in (0, 1, 2, 3):
+            nbytes = off + (h - 1) * pitch + w * 3           # the last row ends the allocation
+            flat = np.zeros(nbytes, np.uint8)
+            for y in range(h):
+                flat[off + y * pitch: off + y * pitch + w * 3] = host[y, :w * 3]
+            d_src = ctx.malloc(nbytes)
+            ctx.upload(d_src, flat)
+            for M in ([0.9, -0.35, 7.0, 0.3, 1.05, -4.0], [1.0, 0.0, 0.0, 0.0, 1.0, 0.0], [0.5, 0.8, 3.0, -0.8, 0.5, 40.0],
+                      [1.7, 0.0, -20.5, 0.2, 1.3, 2.25]):
+                dh, dw = h + 11, w + 6
+                d_dst = ctx.malloc(dh * dw * 3)
+                Mc = (ctypes.c_double * 6)(*M)
+                N.check(N.lib().vkx_warp_affine_u8_dev(ctx.handle, ctypes.c_void_p(d_src + off), h, w, 3, pitch, Mc, ctypes.c_void_p(d_dst),
+                                                      dh, dw, dw * 3))
+                got = np.empty((dh, dw, 3), np.uint8)
+                ctx.download(d_dst, got)
+                want = O.warp_affine(img, np.asarray(M, np.float64).reshape(2, 3), (dw, dh))
+                assert (got == want).all(), (k, off, M)
+                ctx.free(d_dst)
+            ctx.free(d_src)

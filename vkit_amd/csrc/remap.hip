@@ -6,6 +6,7 @@
 namespace {
 
 struct CoordMap {      // cv.remap: coordinates come from two float planes
+    static constexpr bool kTile2D = false;      // the map is read row-major: a wavefront walks 64 columns of a row
     const float *mx, *my;
     ptrdiff_t stride;
     struct Column {};
@@ -21,6 +22,10 @@ struct CoordMap {      // cv.remap: coordinates come from two float planes
 };
 
 struct CoordAffine {   // warpAffine: inverse matrix, AB_BITS = 10 fixed point
+    // a rotated / sheared source footprint: 64 destination pixels of ONE row reach a slanted strip of the source (6 degrees:
+    // 8 source rows, ~32 cache lines per tap-load instruction); a wavefront therefore takes 16 columns x 4 rows per instruction
+    // (5 - 6 lines), four wavefronts side by side so that their 48-byte row segments complete cache lines on the way out
+    static constexpr bool kTile2D = true;
     double m[6];
     // adelta[x] / bdelta[x] of cv::warpAffine depend on the column only: a lane that walks several rows of its column
     // computes them once
@@ -34,13 +39,14 @@ struct CoordAffine {   // warpAffine: inverse matrix, AB_BITS = 10 fixed point
     struct Rows { int X0, Y0; };
     __device__ __forceinline__ Rows rows(int y0, int lane) const
     {
-        const int y = y0 + (lane & 7);
+        const int y = y0 + (lane & 15);
         return Rows{vkd::cv_round((m[1] * y + m[2]) * 1024) + 16, vkd::cv_round((m[4] * y + m[5]) * 1024) + 16};
     }
-    __device__ __forceinline__ void at(const Column &c, const Rows &r, int rr, int, int, int &X, int &Y) const
+    // `row`: the lane's row inside the tile (0 .. 15), per lane: the row terms come from the lane that computed them
+    __device__ __forceinline__ void at(const Column &c, const Rows &r, int row, int, int, int &X, int &Y) const
     {
-        X = (__builtin_amdgcn_readlane(r.X0, rr) + c.adelta) >> 5;
-        Y = (__builtin_amdgcn_readlane(r.Y0, rr) + c.bdelta) >> 5;
+        X = (__builtin_amdgcn_ds_bpermute(row << 2, r.X0) + c.adelta) >> 5;
+        Y = (__builtin_amdgcn_ds_bpermute(row << 2, r.Y0) + c.bdelta) >> 5;
     }
     __device__ __forceinline__ void operator()(int x, int y, int &X, int &Y) const
     {
@@ -54,6 +60,7 @@ struct CoordAffine {   // warpAffine: inverse matrix, AB_BITS = 10 fixed point
 };
 
 struct CoordPerspective { // warpPerspective: inverse matrix, per pixel in double, 32x32 blocks
+    static constexpr bool kTile2D = true;
     double m[9];
     int bw0;
     struct Column {};
@@ -81,7 +88,100 @@ typedef uint32_t u32_u1 __attribute__((aligned(1)));
 
 constexpr int kRgbRows = 4;      // rows a wavefront of the RGB path walks
 
-template <int CN, class Coord>
+// The RGB path for coordinate generators with a slanted footprint (Coord::kTile2D): a workgroup covers 64 x 16 destination pixels,
+// wavefront w the columns [16 w, 16 w + 16); lane = (column lane & 15, row lane >> 4) and a lane walks the rows 4 rr + (lane >> 4),
+// rr = 0 .. 3: every tap-load instruction of a wavefront reaches a 16 x 4 block of the destination.  Arithmetic and stores as in the
+// row-major path below.
+// OFF32: both planes are smaller than 4 GiB and the source pitch is below 2^24 (checked on the host): byte offsets are formed with
+// full-rate 24-bit multiplies in 32 bits on the uniform base pointers instead of 64-bit multiply-adds per lane.
+template <class Coord, bool OFF32>
+__device__ __forceinline__ void sample_rgb_tile2d(const uint8_t *__restrict__ src, int sh, int sw, ptrdiff_t sstride,
+                                                  uint8_t *__restrict__ dst, int dh, int dw, ptrdiff_t dstride, const Coord &coord)
+{
+    const int lane = threadIdx.x, lx = lane & 15, ly = lane >> 4;
+    const int x = blockIdx.x * 64 + threadIdx.y * 16 + lx;
+    const int y0 = blockIdx.y * 4 * kRgbRows;
+    if (y0 >= dh) return;                       // uniform over the workgroup
+    const bool active = x < dw;
+    const typename Coord::Column col = coord.column(x);
+    const typename Coord::Rows rws = coord.rows(y0, lane);
+    const uint32_t src_mis = (uint32_t)(uintptr_t)src & 3u;       // (uniform)
+    const uint8_t *src4 = src - src_mis;
+    int Xs[kRgbRows], Ys[kRgbRows];
+    unsigned long long ta[kRgbRows], tb[kRgbRows];
+    bool inside[kRgbRows];
+#pragma unroll
+    for (int rr = 0; rr < kRgbRows; rr++) {
+        const int row = 4 * rr + ly, yy = min(y0 + row, dh - 1);
+        Xs[rr] = Ys[rr] = 0;
+        coord.at(col, rws, row, x, yy, Xs[rr], Ys[rr]);       // (every lane: the row terms travel by a wavefront shuffle)
+        const int sx = Xs[rr] >> 5, sy = Ys[rr] >> 5;
+        inside[rr] = active && (unsigned)sx < (unsigned)max(sw - (OFF32 ? 3 : 2), 0) && (unsigned)sy < (unsigned)(sh - 1);
+        ta[rr] = tb[rr] = 0;
+        if (inside[rr]) {
+            if constexpr (OFF32) {
+                // 0 <= sy < 2^15, 0 < sstride < 2^24, sh * sstride + 8 <= 2^32
+                const uint32_t o0 = __umul24((uint32_t)sy, (uint32_t)sstride) + __umul24((uint32_t)sx, 3u);
+                // The six tap bytes of a row as three ALIGNED dwords + a byte alignment in registers: an 8-byte load at an arbitrary
+                // byte address costs the texture addresser several accesses per lane (warpAffine 8192^2: 0.216 ms with the
+                // unaligned pair, 0.179 with this).  `inside` leaves the last three source columns to the rim sampler, so the
+                // twelve bytes stay inside the row; a source that is not 4-byte aligned is read from its aligned-down base.
+                typedef uint32_t u32x3 __attribute__((ext_vector_type(3), aligned(4)));
+                const uint32_t oa = o0 + src_mis, ob = oa + (uint32_t)sstride;
+                const u32x3 a = *(const u32x3 *)(src4 + (size_t)(oa & ~3u)), b = *(const u32x3 *)(src4 + (size_t)(ob & ~3u));
+                ta[rr] = (uint64_t)__builtin_amdgcn_alignbyte(a.y, a.x, oa & 3u) | ((uint64_t)__builtin_amdgcn_alignbyte(a.z, a.y, oa & 3u) << 32);
+                tb[rr] = (uint64_t)__builtin_amdgcn_alignbyte(b.y, b.x, ob & 3u) | ((uint64_t)__builtin_amdgcn_alignbyte(b.z, b.y, ob & 3u) << 32);
+            } else {
+                const uint8_t *q = src + (ptrdiff_t)sy * sstride + (ptrdiff_t)sx * 3;   // 3 sx + 8 <= 3 sw
+                ta[rr] = *(const u64_u1 *)q;
+                tb[rr] = *(const u64_u1 *)(q + sstride);
+            }
+        }
+    }
+#pragma unroll
+    for (int rr = 0; rr < kRgbRows; rr++) {
+        const int yy = y0 + 4 * rr + ly;
+        const bool row_ok = active && yy < dh;
+        uint32_t P = 0;                     // r | g << 8 | b << 16
+        if (inside[rr]) {
+            const int fx = Xs[rr] & 31, fy = Ys[rr] & 31;
+            const uint32_t wx = (uint32_t)(32 - fx) | ((uint32_t)fx << 24);
+            const uint32_t t0 = (uint32_t)ta[rr], t1 = (uint32_t)(ta[rr] >> 32), b0 = (uint32_t)tb[rr], b1 = (uint32_t)(tb[rr] >> 32);
+            const uint32_t ar = __builtin_amdgcn_udot4(t0, wx, 0u, false);
+            const uint32_t ag = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t1, t0, 1), wx, 0u, false);
+            const uint32_t ab = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(t1, t0, 2), wx, 0u, false);
+            const uint32_t wy0 = (uint32_t)(32 - fy), wy1 = (uint32_t)fy;
+            const uint32_t br = __builtin_amdgcn_udot4(b0, wx, 0u, false);
+            const uint32_t bg = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b1, b0, 1), wx, 0u, false);
+            const uint32_t bb = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b1, b0, 2), wx, 0u, false);
+            const uint32_t r = (__umul24(br, wy1) + __umul24(ar, wy0) + 512u) >> 10;
+            const uint32_t g = (__umul24(bg, wy1) + __umul24(ag, wy0) + 512u) >> 10;
+            const uint32_t b = (__umul24(bb, wy1) + __umul24(ab, wy0) + 512u) >> 10;
+            P = r | (g << 8) | (b << 16);
+        } else if (row_ok) {
+            uint8_t px[3];
+            vkd::sample_u8<3>(src, sh, sw, sstride, Xs[rr], Ys[rr], px);
+            P = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);
+        }
+        // (lanes with x & 3 == 3 -- the last of every 16-lane row among them -- never use their neighbour's pixel)
+        const uint32_t Pn = (uint32_t)__builtin_amdgcn_mov_dpp((int)P, 0x130 /* wave_shl:1: from lane + 1 */, 0xf, 0xf, true);
+        if (!row_ok) continue;
+        const int m = x & 3;
+        if (x < (dw & ~3)) {
+            if (m < 3) {
+                const uint32_t wv = (P >> (8 * m)) | (Pn << (24 - 8 * m));
+                // byte 3 x + m of the row: (x >> 2) * 12 + 4 m
+                if constexpr (OFF32) *(u32_u1 *)(dst + (size_t)((uint32_t)yy * (uint32_t)dstride + (uint32_t)(3 * x + m))) = wv;
+                else *(u32_u1 *)(dst + (ptrdiff_t)yy * dstride + (ptrdiff_t)(x >> 2) * 12 + m * 4) = wv;
+            }
+        } else {
+            uint8_t *d = dst + (ptrdiff_t)yy * dstride + (ptrdiff_t)x * 3;
+            d[0] = (uint8_t)P; d[1] = (uint8_t)(P >> 8); d[2] = (uint8_t)(P >> 16);
+        }
+    }
+}
+
+template <int CN, class Coord, bool OFF32 = false>
 __global__ void __launch_bounds__(256) k_sample_u8(const uint8_t *__restrict__ src, int sh, int sw, ptrdiff_t sstride,
                                                    uint8_t *__restrict__ dst, int dh, int dw, ptrdiff_t dstride,
                                                    Coord coord)
@@ -95,6 +195,10 @@ __global__ void __launch_bounds__(256) k_sample_u8(const uint8_t *__restrict__ s
         // neighbouring lanes write their 12 bytes as three dwords.
         // a wavefront walks kRgbRows consecutive rows of its 64 columns: per-column coordinate terms are computed once
         const int lane = threadIdx.x;
+        if constexpr (Coord::kTile2D) {
+            sample_rgb_tile2d<Coord, OFF32>(src, sh, sw, sstride, dst, dh, dw, dstride, coord);
+            return;
+        }
         const bool active = x < dw;
         const typename Coord::Column col = coord.column(x);
         const int y0 = (blockIdx.y * 4 + threadIdx.y) * kRgbRows;
@@ -192,7 +296,14 @@ int launch_u8(vkx_ctx *ctx, const uint8_t *src, int sh, int sw, int cn, ptrdiff_
     dim3 block(64, 4), grid(vkx_blocks(dw, 64), vkx_blocks(dh, 4));
     switch (cn) {
     case 1: { VKX_TIMED(ctx, "k_sample_u8"); k_sample_u8<1, Coord><<<grid, block, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, coord); } break;
-    case 3: { VKX_TIMED(ctx, "k_sample_u8"); k_sample_u8<3, Coord><<<dim3(grid.x, vkx_blocks(dh, 4 * kRgbRows)), block, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, coord); } break;
+    case 3: {
+        VKX_TIMED(ctx, "k_sample_u8");
+        const dim3 g3(grid.x, vkx_blocks(dh, 4 * kRgbRows));
+        const bool off32 = Coord::kTile2D && sstride > 0 && sstride < (1 << 24) && dstride > 0 && (long long)sh * sstride + 16 <= 0xffffffffLL &&
+                           (long long)dh * dstride + 4 <= 0xffffffffLL;
+        if (off32) k_sample_u8<3, Coord, true><<<g3, block, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, coord);
+        else k_sample_u8<3, Coord><<<g3, block, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, coord);
+    } break;
     case 4: { VKX_TIMED(ctx, "k_sample_u8"); k_sample_u8<4, Coord><<<grid, block, 0, ctx->stream>>>(src, sh, sw, sstride, dst, dh, dw, dstride, coord); } break;
     default: vkx_set_error("unsupported channel count %d", cn); return VKX_ERR_UNSUPPORTED;
     }
