@@ -820,6 +820,10 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tx, cons
                     // sy < 2^15, sstride < 2^24 and sh * sstride < 2^32 (checked on the host): full-rate 24-bit multiplies
                     // and a 32-bit lane offset on the uniform base pointer
                     const uint32_t o0 = __umul24((uint32_t)sy, (uint32_t)sstride) + __umul24((uint32_t)sx, 3u);
+                    // (the tap rows as ALIGNED dwords + a byte alignment in registers -- worth 17 % to remap.hip's warp kernel, whose
+                    //  gather is bound by the texture addresser -- measured here: k_chain_fused 9.27 against 9.14 ms, C2 unchanged
+                    //  (eight more VALU instructions per row in a VALU-bound kernel, 12 bytes of scratch); in the element mode
+                    //  of k_tile_remap 0.174 against 0.177 ms on C5: inside the run-to-run spread.  Not adopted in either.)
                     ta[u] = *(const u64_u1 VKX_GLOBAL *)(src + (size_t)o0);
                     tb[u] = *(const u64_u1 VKX_GLOBAL *)(src + (size_t)(o0 + (uint32_t)sstride));
                 }
