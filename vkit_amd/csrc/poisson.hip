@@ -33,6 +33,7 @@
 #include <algorithm>
 #include <mutex>
 #include <vector>
+#include <type_traits>
 
 namespace {
 
@@ -46,6 +47,8 @@ constexpr int kChainCap = kB * 3400 / 2 - 16 - 4096;    // E entries the chain s
 constexpr int kKMax = 1024;         // loggam table: k + 1 <= kKMax
 constexpr double kSigmas = 6.0;
 constexpr int kCandThreads = 1024;
+constexpr int kSlots = 8;           // rings of E / P / G rows: superblocks whose rows may exist at a time
+constexpr int kGroupMax = 16;       // blocks per group of the two-level chain
 
 enum { kFlagAmbiguous = 1, kFlagTable = 2, kFlagWindow = 4, kFlagMismatch = 8, kFlagDraws = 16, kFlagSize = 32 };
 
@@ -58,15 +61,19 @@ struct PzTabs {
     double loggam[kKMax + 1];       // random_loggam(x), x = 1 .. kKMax
 };
 struct PzBlock {
-    int lo_rel;                     // first position of the window, relative to the superblock's exact start
-    int W, band, e_off;             // candidates; positions the table covers; offset of the block's row in E
+    int lo_rel;                     // first position of the window, relative to the exact start the superblock's windows refer to
+    int W, band, e_off;             // candidates; positions the table covers; offset of the block's row in E (and of its row in P)
+    int sup;                        // its superblock
+    int g_off;                      // first block of a group: offset of the group's row in G
 };
 struct PzSuper {
     int first_block, n_blocks;
     int end_lo_rel, end_W;          // the window of the NEXT superblock's start
-    int chunk_blocks;               // rows the chain kernel stages at a time
-    int max_band;
-    long long e_total;
+    int grp_rows, n_groups;         // blocks per group (the last group may hold fewer); groups
+    int base;                       // the superblock whose exact start the windows are relative to (itself at depth 1)
+    int grp0;                       // index of its first group counter
+    int e_total, g_total;           // entries of its E rows; of its G rows
+    int max_band, pad;
 };
 
 // ---- host: numpy's constants --------------------------------------------------------------------------------------
@@ -266,6 +273,7 @@ __device__ __forceinline__ bool pz_attempt(const PzLam &L, const double *__restr
 }
 
 constexpr uint8_t kCodeInvalid = 0xfe;
+constexpr int kResolveRows = 12;         // table rows up to which the rejected PTRS states are resolved in the table (see k_pz_super)
 
 // The attempt that starts at (d0, d1) as the table pass evaluates it: straight-line code (every lane takes the division, the float32
 // logarithms and the loggam lookup, so that the compiler can overlap the states of consecutive elements), the double logarithms only for
@@ -291,226 +299,350 @@ __device__ __forceinline__ bool pz_attempt_table(const PzLam &L, const double *_
     return acc;
 }
 
-// One superblock: workgroup = block (table, candidate walks, its E row); the workgroup that finishes last follows the exact start through
-// the rows (staged through the LDS the tables occupied) and leaves the exact start of every block and of the next superblock.
-// Between the workgroups of the launch the E rows travel as agent-scope stores and loads (write-through, past the per-XCD L2s): a
-// __threadfence() here writes the L2 back, 25 - 40 us per workgroup.
-__global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__restrict__ src, long long n, const PzBlock *__restrict__ blocks,
-                                                           int first_block, int n_blocks, int end_lo_rel, int end_W, int chunk_blocks, int e_total,
-                                                           const long long *pos_base /* the exact start the windows are relative to */,
-                                                           long long *pos_cur /* this superblock's exact start (pos_base, or published by the superblock before) */,
-                                                           const double *__restrict__ draws, long long M, const PzTabs *__restrict__ T,
-                                                           uint16_t *E, long long *__restrict__ blk_pos, unsigned *counter,
-                                                           int *__restrict__ fail, long long *__restrict__ probe)
+// All superblocks in ONE launch of persistent workgroups.  A workgroup takes the next block in stream order (a ticket), waits -- bounded --
+// for the exact start its superblock's windows are relative to, and does the block: table, candidate walks, its E row.  The chain over
+// a superblock's rows has two levels:
+//   group   the workgroup that finishes last among the <= 16 blocks of a group stages the group's E rows in LDS (where its table was) and
+//           walks EVERY candidate of the group's first window through them, one lane per candidate: P[row][c] = where candidate c stands at
+//           that row, G[group][c] = where it enters the next group (16 dependent LDS reads, all candidates side by side);
+//   top     the group that finishes last follows the superblock's exact start through the G rows (<= 16 dependent reads where the
+//           one-level chain had 256), publishes the next superblock's start, and reads every block's start out of P in one round trip.
+// A workgroup only ever waits for results of LOWER tickets, whose holders are running or done: no launch order, residency or grid size
+// can deadlock it.  Between workgroups the rows travel as agent-scope stores and loads (write-through, past the per-XCD L2s; a
+// __threadfence() here writes the L2 back, 25 - 40 us); E / P / G live in rings of kSlots superblocks, a slot is taken again when
+// the superblock kSlots before has read its last row (`done`).
+__device__ __forceinline__ long long pz_wait_ll(const long long *p, bool &timed_out)
 {
-#define PZ_STAMP(k) do { if (probe && tid == 0 && ((k) >= 4 || (int)blockIdx.x + 1 == n_blocks)) probe[k] = (long long)wall_clock64(); } while (0)
+    long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int spin = 0; v < 0 && spin < (1 << 22); spin++) {
+        __builtin_amdgcn_s_sleep(8);
+        v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (v < 0) timed_out = true;
+    return v;
+}
+
+__global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__restrict__ src, long long n, int n_blk, const PzBlock *__restrict__ blocks,
+                                                           const PzSuper *__restrict__ supers, long long *pos /* exact starts of the superblocks; -1: not yet */,
+                                                           const double *__restrict__ draws, long long M, const PzTabs *__restrict__ T,
+                                                           uint16_t *E, uint16_t *P, uint16_t *G, long long e_stride /* entries per ring slot */,
+                                                           long long *__restrict__ blk_pos, unsigned *ticket, unsigned *grp_counter, unsigned *sup_counter,
+                                                           unsigned *done, int *__restrict__ fail, long long *__restrict__ probe)
+{
+#define PZ_STAMP(k) do { if (probe && tid == 0) probe[8 * sup + (k)] = (long long)wall_clock64(); } while (0)
     __shared__ double ld[kBandMax + 2];
-    __shared__ __attribute__((aligned(16))) uint8_t tab[kB * kBandMax];
+    __shared__ __attribute__((aligned(16))) uint8_t tab[kB * (kBandMax + 1)];      // a row: band states + a sentinel
     __shared__ double lgam[kKMax + 1];
     __shared__ PzLam lL[kB];
-    __shared__ int l_off[kMaxBlocks + 1], l_lo[kMaxBlocks], l_idx[kMaxBlocks];
+    __shared__ int l_off[kMaxBlocks + 1], l_idx[kMaxBlocks];
     __shared__ uint8_t llam[kB], rowof[kB], rowlist[kB];
     __shared__ int s_last, s_idx, s_rows;
+    __shared__ unsigned s_ticket;
+    __shared__ long long s_p0;
     const int tid = threadIdx.x;
-    const long long p0 = *pos_base;
-    PZ_STAMP(0);
-    {
-        const int j = first_block + blockIdx.x;
+    for (int o = tid; o <= kKMax; o += kCandThreads) lgam[o] = T->loggam[o];
+    for (;;) {
+        __syncthreads();                                              // the LDS of the block before is free
+        if (tid == 0) s_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned tk = (unsigned)__builtin_amdgcn_readfirstlane((int)s_ticket);
+        if (tk >= (unsigned)n_blk) return;
+        const int j = (int)tk;
         const PzBlock blk = blocks[j];
-        const bool last = (int)blockIdx.x + 1 == n_blocks;
-        const int next_lo_rel = last ? end_lo_rel : blocks[j + 1].lo_rel, next_W = last ? end_W : blocks[j + 1].W;
-        const long long e0 = (long long)j * kB;
-        const int n_el = (int)min((long long)kB, n - e0);
-        const long long p_lo = p0 + blk.lo_rel;
-        const int band = blk.band;
-        if (tid < kB) llam[tid] = tid < n_el ? src[e0 + tid] : 0;
-        if (tid < kB * 8) {                                       // the elements' constants: 8 doubles each
-            const int t = tid >> 3;
-            const int lam = t < n_el ? src[e0 + t] : 0;
-            ((double *)lL)[tid] = ((const double *)&T->lam[lam])[tid & 7];
-        }
-        for (int o = tid; o < band + 2; o += kCandThreads) {
-            const long long p = p_lo + o;
-            ld[o] = p >= 0 && p < M ? draws[p] : -1.0;          // -1: no such draw
-        }
-        for (int o = tid; o <= kKMax; o += kCandThreads) lgam[o] = T->loggam[o];
-        __syncthreads();
-        if (tid < 64) {                                           // elements of one value share a table row
-            int r = tid;
-            const int mine = tid < kB ? llam[tid] : 0;
-            for (int t = min(tid, kB) - 1; t >= 0; t--) r = llam[t] == mine ? t : r;
-            if (tid < kB) rowof[tid] = (uint8_t)r;
-            const bool is_row = tid < kB && r == tid && mine != 0;
-            const unsigned long long rows_mask = __ballot(is_row);
-            if (is_row) rowlist[__popcll(rows_mask & ((1ull << tid) - 1ull))] = (uint8_t)tid;
-            if (tid == 0) s_rows = __popcll(rows_mask);
+        const int sup = blk.sup;
+        const PzSuper S = supers[sup];
+        const int slot = sup % kSlots;
+        uint16_t *Es = E + (long long)slot * e_stride, *Ps = P + (long long)slot * e_stride, *Gs = G + (long long)slot * e_stride;
+        if (tid == 0) {
+            bool timed_out = false;
+            const long long ps = pz_wait_ll(pos + S.base, timed_out);
+            if (sup >= kSlots) {
+                const unsigned *dp = done + (sup - kSlots);
+                unsigned d = __hip_atomic_load(dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int spin = 0; !d && spin < (1 << 22); spin++) {
+                    __builtin_amdgcn_s_sleep(8);
+                    d = __hip_atomic_load(dp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (!d) timed_out = true;
+            }
+            if (timed_out) atomicOr(fail, kFlagWindow);
+            s_p0 = timed_out ? 0 : ps;
         }
         __syncthreads();
-        PZ_STAMP(1);
-        // the states of all rows as one index space, dealt round the lanes: every wavefront gets the same number of states whatever the
-        // band's length (row by row, a band of 1 227 positions gave four of the sixteen wavefronts twice the others' work)
+        const long long p0 = s_p0;
+        const bool last_of_super = j + 1 == S.first_block + S.n_blocks;
+        if (last_of_super) PZ_STAMP(0);
         {
-            const int total = s_rows * band;
-            int k = 0, o = tid;
-            while (o >= band && k < s_rows) { o -= band; k++; }
-            for (int idx = tid; idx < total; idx += kCandThreads) {
-                const int t = rowlist[k];
-                const int lam = llam[t];
-                const PzLam &L = lL[t];
-                uint8_t code = kCodeInvalid;
-                if (lam >= 10) {
-                    const double d0 = ld[o], d1 = ld[o + 1];
-                    const bool acc = pz_attempt_table(L, lgam, d0, d1);
-                    code = d0 >= 0.0 && d1 >= 0.0 ? (acc ? 2 : 0) : kCodeInvalid;
-                } else {
-                    const double enlam = L.enlam;
-                    double prod = 1.0;
-                    int c = 0;
-                    while (o + c < band + 2 && c < 250) {
-                        const double d = ld[o + c];
-                        if (d < 0.0) break;
-                        c++;
-                        prod *= d;
-                        if (!(prod > enlam)) {
-                            code = (uint8_t)c;
-                            break;
+            const int next_lo_rel = last_of_super ? S.end_lo_rel : blocks[j + 1].lo_rel, next_W = last_of_super ? S.end_W : blocks[j + 1].W;
+            const long long e0 = (long long)j * kB;
+            const int n_el = (int)min((long long)kB, n - e0);
+            const long long p_lo = p0 + blk.lo_rel;
+            const int band = blk.band, stride = band + 1;
+            if (tid < kB) llam[tid] = tid < n_el ? src[e0 + tid] : 0;
+            if (tid < kB * 8) {                                       // the elements' constants: 8 doubles each
+                const int t = tid >> 3;
+                const int lam = t < n_el ? src[e0 + t] : 0;
+                ((double *)lL)[tid] = ((const double *)&T->lam[lam])[tid & 7];
+            }
+            for (int o = tid; o < band + 2; o += kCandThreads) {
+                const long long p = p_lo + o;
+                ld[o] = p >= 0 && p < M ? draws[p] : -1.0;          // -1: no such draw
+            }
+            __syncthreads();
+            if (tid < 64) {                                           // elements of one value share a table row
+                int r = tid;
+                const int mine = tid < kB ? llam[tid] : 0;
+                for (int t = min(tid, kB) - 1; t >= 0; t--) r = llam[t] == mine ? t : r;
+                if (tid < kB) rowof[tid] = (uint8_t)r;
+                const bool is_row = tid < kB && r == tid && mine != 0;
+                const unsigned long long rows_mask = __ballot(is_row);
+                if (is_row) rowlist[__popcll(rows_mask & ((1ull << tid) - 1ull))] = (uint8_t)tid;
+                if (tid == 0) s_rows = __popcll(rows_mask);
+            }
+            __syncthreads();
+            if (last_of_super) PZ_STAMP(1);
+            // the states of all rows as one index space, dealt round the lanes: every wavefront gets the same number of states whatever the
+            // band's length (row by row, a band of 1 227 positions gave four of the sixteen wavefronts twice the others' work)
+            {
+                const int total = s_rows * band;
+                int k = 0, o = tid;
+                while (o >= band && k < s_rows) { o -= band; k++; }
+                for (int idx = tid; idx < total; idx += kCandThreads) {
+                    const int t = rowlist[k];
+                    const int lam = llam[t];
+                    const PzLam &L = lL[t];
+                    uint8_t code = kCodeInvalid;
+                    if (lam >= 10) {
+                        const double d0 = ld[o], d1 = ld[o + 1];
+                        const bool acc = pz_attempt_table(L, lgam, d0, d1);
+                        code = d0 >= 0.0 && d1 >= 0.0 ? (acc ? 2 : 0) : kCodeInvalid;
+                    } else {
+                        const double enlam = L.enlam;
+                        double prod = 1.0;
+                        int c = 0;
+                        while (o + c < band + 2 && c < 250) {
+                            const double d = ld[o + c];
+                            if (d < 0.0) break;
+                            c++;
+                            prod *= d;
+                            if (!(prod > enlam)) {
+                                code = (uint8_t)c;
+                                break;
+                            }
+                        }
+                    }
+                    tab[t * stride + o] = code;
+                    o += kCandThreads;
+                    while (o >= band) { o -= band; k++; }
+                }
+            }
+            if (tid < s_rows) tab[rowlist[tid] * stride + band] = kCodeInvalid;      // the sentinel a clamped position reads
+            __syncthreads();
+            // Few rows (a page: one or two values per block): every rejected PTRS state takes over the draws up to the accepted attempt of its
+            // chain, in place -- a state read while its lane rewrites it is either still 0 (go on) or already its own total (add and stop) --,
+            // and the walks below read ONE byte per element instead of one per attempt of the wavefront's unluckiest lane.  With many rows
+            // (noise: 32 values per block) the pass costs more than the walks save.
+            const bool resolved = s_rows <= kResolveRows;
+            if (resolved) {
+                for (int k = 0; k < s_rows; k++) {
+                    const int t = rowlist[k];
+                    if (llam[t] < 10) continue;
+                    uint8_t *row = tab + t * stride;
+                    for (int o = tid; o < band; o += kCandThreads) {
+                        if (row[o] != 0) continue;
+                        int oo = o, tot = 0;
+                        uint32_t c = 0;
+                        while (c == 0 && tot < 200) {
+                            tot += 2;
+                            oo += 2;
+                            c = oo < band ? row[oo] : kCodeInvalid;
+                        }
+                        row[o] = c == 0 || c == kCodeInvalid || tot + (int)c > 250 ? kCodeInvalid : (uint8_t)(tot + (int)c);
+                    }
+                }
+                __syncthreads();
+            }
+            if (last_of_super) PZ_STAMP(2);
+            const int Wpad = (blk.W + 1) & ~1;                        // rows are stored as pairs (e_off is even)
+            // Walks: lane = candidate start, NC per lane side by side (a window of 3 300 candidates costs the latency of one pass; the walk is
+            // a chain of dependent LDS reads and the workgroup has four wavefronts per SIMD).  The elements' values and table rows sit in
+            // wave-uniform registers.  RESOLVED (the table holds the draws up to the accepted attempt): one read per element, the position
+            // clamped onto the row's sentinel instead of a range test.
+            uint32_t lam_w[kB / 4], row_w[kB / 4];
+#pragma unroll
+            for (int q = 0; q < kB / 4; q++) {
+                lam_w[q] = __builtin_amdgcn_readfirstlane(((const uint32_t *)llam)[q]);
+                row_w[q] = __builtin_amdgcn_readfirstlane(((const uint32_t *)rowof)[q]);
+            }
+            auto walks = [&](auto nc_tag, auto res_tag) {
+                constexpr int NC = decltype(nc_tag)::value;
+                constexpr bool RESOLVED = decltype(res_tag)::value;
+                int o[NC];
+                bool ok[NC];
+#pragma unroll
+                for (int q = 0; q < NC; q++) {
+                    const int c = tid + q * kCandThreads;
+                    o[q] = c;
+                    ok[q] = c < blk.W;
+                }
+#pragma unroll
+                for (int t = 0; t < kB; t++) {
+                    const int lam = (lam_w[t >> 2] >> (8 * (t & 3))) & 0xff;      // 0 beyond n_el
+                    if (lam == 0) continue;
+                    const uint8_t *row = tab + ((row_w[t >> 2] >> (8 * (t & 3))) & 0xff) * stride;
+                    if (RESOLVED) {
+                        uint32_t code[NC];
+#pragma unroll
+                        for (int q = 0; q < NC; q++) code[q] = row[min(o[q], band)];
+#pragma unroll
+                        for (int q = 0; q < NC; q++) {
+                            ok[q] = ok[q] && code[q] != kCodeInvalid;
+                            o[q] += (int)code[q];
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < NC; q++) {
+                            uint8_t code = ok[q] && o[q] < band ? row[o[q]] : kCodeInvalid;
+                            while (code == 0) {                  // a rejected PTRS attempt: the next one starts two draws on
+                                o[q] += 2;
+                                code = o[q] < band ? row[o[q]] : kCodeInvalid;
+                            }
+                            ok[q] = ok[q] && code != kCodeInvalid;
+                            o[q] += code;
                         }
                     }
                 }
-                tab[t * band + o] = code;
-                o += kCandThreads;
-                while (o >= band) { o -= band; k++; }
-            }
-        }
-        __syncthreads();
-        PZ_STAMP(2);
-        const int Wpad = (blk.W + 1) & ~1;                        // rows are stored as pairs (e_off is even)
-        // the elements' values and table rows as wave-uniform words: the walk's only dependent LDS read is the table byte
-        uint32_t lam_w[kB / 4], row_w[kB / 4];
 #pragma unroll
-        for (int q = 0; q < kB / 4; q++) {
-            lam_w[q] = __builtin_amdgcn_readfirstlane(((const uint32_t *)llam)[q]);
-            row_w[q] = __builtin_amdgcn_readfirstlane(((const uint32_t *)rowof)[q]);
-        }
-        for (int c0 = 0; c0 < Wpad; c0 += kCandThreads) {
-            const int c = c0 + tid;
-            int o = c;
-            bool ok = c < blk.W;
-#pragma unroll
-            for (int t = 0; t < kB; t++) {
-                const int lam = (lam_w[t >> 2] >> (8 * (t & 3))) & 0xff;      // 0 beyond n_el
-                if (lam == 0) continue;
-                const uint8_t *row = tab + ((row_w[t >> 2] >> (8 * (t & 3))) & 0xff) * band;
-                uint8_t code = ok && o < band ? row[o] : kCodeInvalid;
-                while (code == 0) {                  // a rejected PTRS attempt: the next one starts two draws on
-                    o += 2;
-                    code = o < band ? row[o] : kCodeInvalid;
+                for (int q = 0; q < NC; q++) {
+                    const int c = tid + q * kCandThreads;
+                    const int e = o[q] + blk.lo_rel - next_lo_rel;
+                    const uint32_t mine = ok[q] && e >= 0 && e < next_W ? (uint32_t)e : 0xffffu;
+                    const uint32_t right = (uint32_t)__shfl_down((int)mine, 1);
+                    if (!(c & 1) && c < Wpad)
+                        __hip_atomic_store((uint32_t *)Es + ((blk.e_off + c) >> 1), mine | (right << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                ok = ok && code != kCodeInvalid;
-                o += code;
-            }
-            const int e = o + blk.lo_rel - next_lo_rel;
-            const uint32_t mine = ok && e >= 0 && e < next_W ? (uint32_t)e : 0xffffu;
-            const uint32_t right = (uint32_t)__shfl_down((int)mine, 1);
-            if (!(c & 1) && c < Wpad)
-                __hip_atomic_store((uint32_t *)E + ((blk.e_off + c) >> 1), mine | (right << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    // the last workgroup to get here chains
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    PZ_STAMP(3);
-    if (tid == 0) s_last = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(n_blocks - 1);
-    __syncthreads();
-    if (!s_last) return;
-    PZ_STAMP(4);
-    uint16_t *le = (uint16_t *)tab;
-    for (int b = tid; b < n_blocks; b += kCandThreads) {
-        l_off[b] = blocks[first_block + b].e_off;
-        l_lo[b] = blocks[first_block + b].lo_rel;
-    }
-    if (tid == 0) {
-        l_off[n_blocks] = e_total;
-        // This superblock's exact start: the base itself, or (windows relative to the superblock BEFORE the previous one, so that this
-        // launch's tables ran while the previous launch was still chaining) the value that launch publishes -- a bounded wait: launches
-        // are queued in stream order, the publisher never waits for this one.
-        long long ps = p0;
-        if (pos_cur != pos_base) {
-            ps = __hip_atomic_load(pos_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int spin = 0; ps < 0 && spin < (1 << 22); spin++) {
-                __builtin_amdgcn_s_sleep(16);
-                ps = __hip_atomic_load(pos_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            };
+            typedef std::integral_constant<int, 1> N1;
+            typedef std::integral_constant<int, 2> N2;
+            typedef std::integral_constant<int, 4> N4;
+            if (resolved) {
+                if (Wpad <= kCandThreads) walks(N1(), std::true_type());
+                else if (Wpad <= 2 * kCandThreads) walks(N2(), std::true_type());
+                else walks(N4(), std::true_type());
+            } else {
+                if (Wpad <= kCandThreads) walks(N1(), std::false_type());
+                else if (Wpad <= 2 * kCandThreads) walks(N2(), std::false_type());
+                else walks(N4(), std::false_type());
             }
         }
-        const long long i0 = ps - (p0 + blocks[first_block].lo_rel);
-        s_idx = ps >= 0 && i0 >= 0 && i0 < blocks[first_block].W ? (int)i0 : -1;
-    }
-    __syncthreads();
-    constexpr int kPer = (kChainCap * 2 / 8 + kCandThreads - 1) / kCandThreads + 1;      // 8-byte loads per thread and chunk
-    uint64_t nextv[kPer];
-    int next_n8 = 0;
-    auto fetch = [&](int b0) {
-        const int b1 = min(n_blocks, b0 + chunk_blocks);
-        const int off0 = l_off[b0] & ~3, cnt = l_off[b1] - off0;
-        const uint64_t *eg = (const uint64_t *)(E + off0);
-        next_n8 = (cnt + 3) / 4;
-#pragma unroll
-        for (int q = 0; q < kPer; q++) {
-            const int i = tid + q * kCandThreads;
-            nextv[q] = i < next_n8 ? __hip_atomic_load(eg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-        }
-    };
-    fetch(0);
-    for (int b0 = 0; b0 < n_blocks; b0 += chunk_blocks) {
-        const int b1 = min(n_blocks, b0 + chunk_blocks);
-        const int off0 = l_off[b0] & ~3;
-#pragma unroll
-        for (int q = 0; q < kPer; q++)
-            if (tid + q * kCandThreads < next_n8) ((uint64_t *)le)[tid + q * kCandThreads] = nextv[q];
+        // the last workgroup of the group to get here walks the group's rows
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (b1 < n_blocks) fetch(b1);                 // the next chunk's rows travel while lane 0 walks this one's
+        if (last_of_super) PZ_STAMP(3);
+        const int grp = (j - S.first_block) / S.grp_rows, r0 = grp * S.grp_rows, cnt = min(S.grp_rows, S.n_blocks - r0);
+        if (tid == 0) s_last = __hip_atomic_fetch_add(grp_counter + S.grp0 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(cnt - 1);
+        __syncthreads();
+        if (!s_last) continue;
+        uint16_t *le = (uint16_t *)tab;
+        {
+            const PzBlock fb = blocks[S.first_block + r0];
+            const int base = fb.e_off & ~3, shift = fb.e_off - base;          // 8-byte loads
+            if (tid <= cnt) {
+                const int r = r0 + tid;
+                l_off[tid] = (r < S.n_blocks ? blocks[S.first_block + r].e_off : S.e_total) - base;
+            }
+            __syncthreads();
+            const int n8 = (l_off[cnt] + 3) >> 2;
+            const uint64_t *eg = (const uint64_t *)(Es + base);
+            for (int i = tid; i < n8; i += kCandThreads) ((uint64_t *)le)[i] = __hip_atomic_load(eg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const int W0 = fb.W, W0pad = (W0 + 1) & ~1;
+            for (int c0 = 0; c0 < W0pad; c0 += kCandThreads) {
+                const int c = c0 + tid;
+                uint32_t cur = c < W0 ? (uint32_t)c : 0xffffu;
+                for (int r = 0; r < cnt; r++) {
+                    const int off = l_off[r];
+                    const uint32_t right = (uint32_t)__shfl_down((int)cur, 1);
+                    if (!(c & 1) && c < W0pad)
+                        __hip_atomic_store((uint32_t *)Ps + ((base + off + c) >> 1), cur | (right << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t nx = le[off + (cur == 0xffffu ? 0u : cur)];
+                    cur = cur == 0xffffu ? 0xffffu : nx;
+                }
+                const uint32_t right = (uint32_t)__shfl_down((int)cur, 1);
+                if (!(c & 1) && c < W0pad)
+                    __hip_atomic_store((uint32_t *)Gs + ((fb.g_off + c) >> 1), cur | (right << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            (void)shift;
+        }
+        // the last group of the superblock chains the G rows
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) s_last = __hip_atomic_fetch_add(sup_counter + sup, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(S.n_groups - 1);
+        __syncthreads();
+        if (!s_last) continue;
+        PZ_STAMP(4);
+        const bool g_in_lds = S.g_total <= kB * kBandMax / 2 - 8;
+        for (int g = tid; g < S.n_groups; g += kCandThreads) l_off[g] = blocks[S.first_block + g * S.grp_rows].g_off;
+        if (g_in_lds) {
+            const int n8 = (S.g_total + 3) >> 2;
+            const uint64_t *gg = (const uint64_t *)Gs;
+            for (int i = tid; i < n8; i += kCandThreads) ((uint64_t *)le)[i] = __hip_atomic_load(gg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid == 0) {
+            // This superblock's exact start: the base itself, or (windows relative to an earlier superblock, so that this one's tables ran
+            // while the one before was still chaining) the value the superblock before publishes -- a bounded wait for a lower ticket.
+            long long ps = p0;
+            bool timed_out = false;
+            if (S.base != sup) ps = pz_wait_ll(pos + sup, timed_out);
+            const long long i0 = ps - (p0 + blocks[S.first_block].lo_rel);
+            s_idx = !timed_out && ps >= 0 && i0 >= 0 && i0 < blocks[S.first_block].W ? (int)i0 : -1;
+        }
+        __syncthreads();
         if (tid < 64) {
-            // Wavefront 0 walks the chunk: the dependent chain of a step is one add and one LDS read (every lane reads the same entry).
-            // The rows' offsets sit in a vector register, one per lane, and come out with v_readlane; the starts found go back the same
-            // way; a miss (0xffff) is noted on the side and the walk goes on with the index masked into the staged range.
-            // Per step nothing but the offset (v_readlane), the masked add, the read and a fire-and-forget store of the index found: what
-            // a miss (0xffff) means for the rows after it is sorted out when all chunks are done.
+            // wavefront 0 follows the start through the G rows: per step the row's offset (v_readlane), the read, a select
             uint32_t cur = s_idx < 0 ? 0xffffu : (uint32_t)s_idx;
-            for (int bb = b0; bb < b1; bb += 64) {
-                const int offv = l_off[min(bb + tid, n_blocks)] - off0;
-                const int rows = min(64, b1 - bb);
-                int *out = l_idx + bb;
+            for (int gb = 0; gb < S.n_groups; gb += 64) {
+                const int offv = l_off[min(gb + tid, S.n_groups - 1)];
+                const int rows = min(64, S.n_groups - gb);
                 for (int i = 0; i < rows; i++) {
                     const int off = __builtin_amdgcn_readlane(offv, i);
-                    out[i] = (int)cur;
-                    cur = le[off + (cur & 0xfffu)];
+                    l_idx[gb + i] = (int)cur;
+                    const uint32_t at = (uint32_t)off + (cur == 0xffffu ? 0u : cur);
+                    uint32_t nx;
+                    if (g_in_lds) {
+                        nx = le[at];
+                    } else {
+                        const uint32_t w = __hip_atomic_load((const uint32_t *)Gs + (at >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        nx = (at & 1) ? w >> 16 : w & 0xffffu;
+                    }
+                    cur = cur == 0xffffu ? 0xffffu : nx;
                 }
             }
-            if (tid == 0) s_idx = cur == 0xffffu ? -1 : (int)cur;
+            if (tid == 0) {
+                s_idx = cur == 0xffffu ? -1 : (int)cur;
+                if (s_idx < 0) atomicOr(fail, kFlagWindow);
+                // (a failed superblock publishes a start all the same: its successors must not wait for it)
+                __hip_atomic_store(pos + sup + 1, s_idx < 0 ? p0 : p0 + S.end_lo_rel + s_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         __syncthreads();
-    }
-    // a row whose start is the miss marker, and every row after it, has no start
-    if (tid < 64) {
-        int first_bad = n_blocks;
-        for (int b = tid; b < n_blocks; b += 64)
-            if (l_idx[b] == 0xffff) first_bad = min(first_bad, b);
-        for (int o = 32; o; o >>= 1) first_bad = min(first_bad, __shfl_xor(first_bad, o));
-        if (tid == 0) {
-            s_rows = first_bad;
-            if (first_bad < n_blocks) s_idx = -1;
+        PZ_STAMP(5);
+        // every block's exact start: one read of P at its group's start
+        for (int b = tid; b < S.n_blocks; b += kCandThreads) {
+            const uint32_t gi = (uint32_t)l_idx[b / S.grp_rows];
+            long long v = -1;
+            if (gi != 0xffffu) {
+                const PzBlock bb = blocks[S.first_block + b];
+                const uint32_t w = __hip_atomic_load((const uint32_t *)Ps + ((bb.e_off + (int)gi) >> 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t e = (gi & 1) ? w >> 16 : w & 0xffffu;
+                if (e != 0xffffu) v = p0 + bb.lo_rel + (long long)e;
+            }
+            blk_pos[S.first_block + b] = v;
         }
-    }
-    __syncthreads();
-    for (int b = tid; b < n_blocks; b += kCandThreads)
-        if (b >= s_rows) l_idx[b] = -1;
-    __syncthreads();
-    PZ_STAMP(5);
-    for (int b = tid; b < n_blocks; b += kCandThreads) blk_pos[first_block + b] = l_idx[b] < 0 ? -1 : p0 + l_lo[b] + l_idx[b];
-    if (tid == 0) {
-        if (s_idx < 0) atomicOr(fail, kFlagWindow);
-        // (a failed superblock publishes a start all the same: its successors must not wait for it)
-        __hip_atomic_store(pos_cur + 1, s_idx < 0 ? p0 : p0 + end_lo_rel + s_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(done + sup, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        PZ_STAMP(6);
     }
 }
 
@@ -640,7 +772,8 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
     const size_t o_mean = 0, o_var = o_mean + up(sizeof(float) * n_blk), o_plan = o_var + up(sizeof(float) * n_blk),
                  o_bpos = o_plan + up(sizeof(PzBlock) * n_blk), o_pos = o_bpos + up(sizeof(long long) * (n_blk + 1));
     // superblocks hold at least one block each: n_blk + 2 positions always suffice
-    const size_t o_counter = o_pos + up(sizeof(long long) * (n_blk + 2)), o_reply = o_counter + up(sizeof(unsigned) * (n_blk + 2)), work_bytes = o_reply + 256;
+    // counters: the ticket | per superblock: groups done, `done` flag | per group: blocks done
+    const size_t o_counter = o_pos + up(sizeof(long long) * (n_blk + 2)), o_reply = o_counter + up(sizeof(unsigned) * (3 * (size_t)n_blk + 8)), work_bytes = o_reply + 256;
     if ((rc = vkx_scratch_reserve(ctx, &ctx->pz_work, work_bytes))) return rc;
     unsigned char *work = (unsigned char *)ctx->pz_work.ptr;
     float *d_mean = (float *)(work + o_mean), *d_var = (float *)(work + o_var);
@@ -660,26 +793,25 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
 
     // the plan: superblocks and windows (VKX_PZ_SIGMAS: narrower windows, to exercise the WINDOW refusal in tests)
     static const double sigmas = getenv("VKX_PZ_SIGMAS") ? atof(getenv("VKX_PZ_SIGMAS")) : kSigmas;
-    // Depth 1: windows relative to the superblock's own start, launches strictly one after the other.  Depth d > 1: relative to the start
-    // of the superblock d - 1 before; launches go round d streams and the chain of one runs under the tables of the next d - 1 (the last
-    // workgroup of a launch waits for the start its predecessor publishes).  Wider windows are the price -- sqrt(d) more table states --,
-    // so dark images (the multiplication method: a variance of lam per element against PTRS's 0.7 - 1.8) stay at depth 1.  1024^2 RGB
-    // page: 25.3 / 17.4 / 13.9 ms at depth 1 / 2 / 3; 512^2 x 3 of lam = 9: 9.0 / 9.5 / 11.5.  Default 2: with eight worker processes
-    // sharing the GPU (tools/pool_scale.py) depth 3's extra table work and third stream cost more than its shorter critical path
-    // gives (pipeline pages/s at 1 / 8 workers: depth 1 183 / 473, depth 2 192 / 540, depth 3 164 / 377).  VKX_PZ_DEPTH overrides.
+    // Depth 1: windows relative to the superblock's own start: its blocks begin when the superblock before has chained.  Depth d > 1:
+    // relative to the start of the superblock d - 1 before, so that the tables and walks of d superblocks are in flight and a chain runs
+    // under the tables of the next d - 1.  Wider windows are the price -- sqrt(d) more table states --, so dark images (the multiplication
+    // method: a variance of lam per element against PTRS's 0.7 - 1.8) stay at depth 1.  VKX_PZ_DEPTH overrides.
     static const int depth_env = getenv("VKX_PZ_DEPTH") ? std::max(1, std::min(3, atoi(getenv("VKX_PZ_DEPTH")))) : 0;
     double var_sum = 0.0;
     for (long long b = 0; b < n_blk; b++) var_sum += bvar[(size_t)b];
     const double var_per_element = var_sum / (double)n;
     const int depth = depth_env ? depth_env : (var_per_element > 7.0 ? 1 : 2);
-    const int max_blocks = kMaxBlocks - (depth - 1);      // CUs stay free for the workgroups still chaining
+    const int max_blocks = kMaxBlocks;
     std::vector<std::pair<double, double>> before;         // (mean, variance) of the depth - 1 superblocks before this one
     std::vector<PzBlock> plan((size_t)n_blk);
     std::vector<PzSuper> supers;
     double total_m = 0.0, total_v = 0.0, base_m = 0.0, base_v = 0.0;      // base: the superblock before (depth 2)
     long long e_max = 0;
+    int n_groups_total = 0;
     for (long long s0 = 0; s0 < n_blk;) {
         PzSuper S;
+        memset(&S, 0, sizeof(S));
         S.first_block = (int)s0;
         double cm = 0.0, cv = 0.0;
         long long e_off = 0;
@@ -698,6 +830,8 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
             b.W = W;
             b.band = std::min(band, kBandMax);
             b.e_off = (int)e_off;
+            b.sup = (int)supers.size();
+            b.g_off = 0;
             e_off += (W + 1) & ~1;          // rows start at even offsets: the entries are stored in pairs
             max_band = std::max(max_band, b.band);
             last_W = W;
@@ -708,9 +842,21 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
         const int H = (int)ceil(sigmas * sqrt(base_v + cv)) + 3;
         S.end_lo_rel = (int)llround(base_m + cm) - H;
         S.end_W = 2 * H + 1;
-        S.chunk_blocks = std::max(1, (kChainCap - 8) / (last_W + 1));
+        // groups of the two-level chain: as many rows as the LDS of a table holds (windows grow along the superblock: the last is the widest)
+        S.grp_rows = std::max(1, std::min(kGroupMax, (kChainCap - 8) / (last_W + 1)));
+        S.n_groups = (S.n_blocks + S.grp_rows - 1) / S.grp_rows;
+        S.grp0 = n_groups_total;
+        n_groups_total += S.n_groups;
+        int g_off = 0;
+        for (int g = 0; g < S.n_groups; g++) {
+            PzBlock &fb = plan[(size_t)(s0 + (long long)g * S.grp_rows)];
+            fb.g_off = g_off;
+            g_off += (fb.W + 1) & ~1;
+        }
+        S.g_total = g_off;
+        S.base = (int)supers.size() >= depth - 1 ? (int)supers.size() - (depth - 1) : 0;
         S.max_band = max_band;
-        S.e_total = e_off;
+        S.e_total = (int)e_off;
         e_max = std::max(e_max, e_off);
         total_m += cm;
         total_v += cv;
@@ -729,49 +875,40 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
         *flags_host = kFlagSize;
         return VKX_OK;
     }
-    if ((rc = vkx_scratch_reserve(ctx, &ctx->pz_draws, sizeof(double) * (size_t)(M + 2) + 3 * up(sizeof(uint16_t) * (size_t)e_max + 16)))) return rc;
+    const size_t e_slot_bytes = up(sizeof(uint16_t) * (size_t)e_max + 16), e_stride = e_slot_bytes / sizeof(uint16_t);
+    const size_t draws_bytes = up(sizeof(double) * (size_t)(M + 2)), sup_bytes = up(sizeof(PzSuper) * supers.size());
+    if ((rc = vkx_scratch_reserve(ctx, &ctx->pz_draws, draws_bytes + 3 * kSlots * e_slot_bytes + sup_bytes))) return rc;
     double *d_draws = (double *)ctx->pz_draws.ptr;
-    uint16_t *d_E = (uint16_t *)((unsigned char *)ctx->pz_draws.ptr + up(sizeof(double) * (size_t)(M + 2)));
+    uint16_t *d_E = (uint16_t *)((unsigned char *)ctx->pz_draws.ptr + draws_bytes);
+    uint16_t *d_P = d_E + kSlots * e_stride, *d_G = d_P + kSlots * e_stride;
+    PzSuper *d_sup = (PzSuper *)((unsigned char *)ctx->pz_draws.ptr + draws_bytes + 3 * kSlots * e_slot_bytes);
     if (probing) {
         if ((rc = vkx_scratch_reserve(ctx, &ctx->misc, 64 * supers.size() + 64))) return rc;
         d_probe = (long long *)ctx->misc.ptr;
         VKX_HIP(hipMemsetAsync(d_probe, 0, 64 * supers.size(), ctx->stream));
     }
+    unsigned *d_ticket = d_counter, *d_supcnt = d_counter + 4, *d_done = d_supcnt + supers.size(), *d_grpcnt = d_done + supers.size();
     VKX_HIP(hipMemcpyAsync(d_plan, plan.data(), sizeof(PzBlock) * n_blk, hipMemcpyHostToDevice, ctx->stream));
+    VKX_HIP(hipMemcpyAsync(d_sup, supers.data(), sizeof(PzSuper) * supers.size(), hipMemcpyHostToDevice, ctx->stream));
     VKX_HIP(hipMemsetAsync(d_pos, 0xff, sizeof(long long) * (supers.size() + 1), ctx->stream));      // -1: not published yet
     VKX_HIP(hipMemsetAsync(d_pos, 0, sizeof(long long), ctx->stream));
     VKX_HIP(hipMemsetAsync(d_reply, 0, sizeof(PzReply), ctx->stream));
-    VKX_HIP(hipMemsetAsync(d_counter, 0, sizeof(unsigned) * supers.size(), ctx->stream));
+    VKX_HIP(hipMemsetAsync(d_counter, 0, sizeof(unsigned) * (4 + 2 * supers.size() + (size_t)n_groups_total), ctx->stream));
     if ((rc = vkx_pcg64_doubles_dev(ctx, state, inc, M, d_draws))) return rc;
     {
-        hipStream_t main_stream = ctx->stream;
-        hipStream_t lanes[3] = {main_stream, main_stream, main_stream};
-        const int n_lanes = (int)std::min<size_t>((size_t)depth, supers.size());
-        for (int k = 1; k < n_lanes; k++) {
-            lanes[k] = vkx_stream_by_id(ctx, k == 1 ? VKX_STREAM_COPY_IN : VKX_STREAM_COPY_OUT, &rc);
-            if (rc) return rc;
-            if ((rc = vkx_stream_order(ctx, lanes[k], main_stream))) return rc;
-        }
-        const size_t e_stride = up(sizeof(uint16_t) * (size_t)e_max + 16) / sizeof(uint16_t);
-        for (size_t s = 0; s < supers.size(); s++) {
-            const PzSuper &S = supers[s];
-            ctx->stream = lanes[s % (size_t)n_lanes];
-            const size_t base = s >= (size_t)(depth - 1) ? s - (size_t)(depth - 1) : 0;
-            {
-                VKX_TIMED(ctx, "k_pz_super");
-                k_pz_super<<<S.n_blocks, kCandThreads, 0, ctx->stream>>>(src, n, d_plan, S.first_block, S.n_blocks, S.end_lo_rel, S.end_W, S.chunk_blocks,
-                                                                         (int)S.e_total, d_pos + base, d_pos + s, d_draws, M, tabs, d_E + (s % 3) * e_stride,
-                                                                         d_bpos, d_counter + s, &d_reply->fail, d_probe ? d_probe + 8 * s : nullptr);
-            }
-            ctx->stream = main_stream;
-            if (hipGetLastError() != hipSuccess) {
-                vkx_set_error("k_pz_super: launch failed");
-                return VKX_ERR_HIP;
-            }
-        }
-        for (int k = 1; k < n_lanes; k++)
-            if ((rc = vkx_stream_order(ctx, main_stream, lanes[k]))) return rc;
+        // persistent workgroups: one per CU (the tables take most of a CU's LDS); fewer blocks than CUs: one each
+        static const int n_cu = [] {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
+            return v;
+        }();
+        static const int grid_env = getenv("VKX_PZ_GRID") ? atoi(getenv("VKX_PZ_GRID")) : 0;
+        const int grid = (int)std::min<long long>(n_blk, grid_env > 0 ? grid_env : n_cu);
+        VKX_TIMED(ctx, "k_pz_super");
+        k_pz_super<<<grid, kCandThreads, 0, ctx->stream>>>(src, n, (int)n_blk, d_plan, d_sup, d_pos, d_draws, M, tabs, d_E, d_P, d_G, (long long)e_stride, d_bpos,
+                                                          d_ticket, d_grpcnt, d_supcnt, d_done, &d_reply->fail, d_probe);
     }
+    VKX_LAUNCH_CHECK();
     { VKX_TIMED(ctx, "k_pz_final");
       k_pz_final<<<vkx_blocks((size_t)n_blk, 64), 64, 0, ctx->stream>>>(src, n, n_blk, d_bpos, d_draws, M, tabs, dst, &d_reply->consumed, &d_reply->fail); }
     VKX_LAUNCH_CHECK();
@@ -786,12 +923,15 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
     if (probing) {
         std::vector<long long> pr(8 * supers.size());
         VKX_HIP(hipMemcpy(pr.data(), d_probe, 64 * supers.size(), hipMemcpyDeviceToHost));
-        double acc[6] = {0, 0, 0, 0, 0, 0};
+        double acc[7] = {0, 0, 0, 0, 0, 0, 0};
         for (size_t q = 0; q < supers.size(); q++)
-            for (int k = 1; k < 6; k++) acc[k] += (double)(pr[8 * q + k] - pr[8 * q + k - 1]);
-        fprintf(stderr, "pz probe (%zu superblocks, mean us, 100 MHz clock): stage %.2f table %.2f walk %.2f wait-for-last %.2f chain %.2f; last superblock: blocks %d band %d W %d chunk %d\n",
-                supers.size(), acc[1] / supers.size() / 100, acc[2] / supers.size() / 100, acc[3] / supers.size() / 100, acc[4] / supers.size() / 100,
-                acc[5] / supers.size() / 100, supers.back().n_blocks, supers.back().max_band, supers.back().end_W, supers.back().chunk_blocks);
+            for (int k = 1; k < 7; k++) acc[k] += (double)(pr[8 * q + k] - pr[8 * q + k - 1]);
+        const double span = (double)(pr[8 * (supers.size() - 1) + 6] - pr[0]) / 100.0;
+        fprintf(stderr, "pz probe (%zu superblocks, depth %d, mean us, 100 MHz clock): stage %.2f table %.2f walk %.2f groups %.2f chain %.2f fill %.2f; "
+                        "first stamp to last %.1f us = %.2f per superblock; last superblock: blocks %d band %d W %d group rows %d\n",
+                supers.size(), depth, acc[1] / supers.size() / 100, acc[2] / supers.size() / 100, acc[3] / supers.size() / 100, acc[4] / supers.size() / 100,
+                acc[5] / supers.size() / 100, acc[6] / supers.size() / 100, span, span / supers.size(), supers.back().n_blocks, supers.back().max_band,
+                supers.back().end_W, supers.back().grp_rows);
     }
     *consumed_host = reply.consumed;
     *flags_host = (unsigned)reply.fail;
