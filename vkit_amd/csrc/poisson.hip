@@ -337,6 +337,8 @@ __global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__rest
     __shared__ int l_off[kMaxBlocks + 1], l_idx[kMaxBlocks];
     __shared__ uint8_t llam[kB], rowof[kB], rowlist[kB];
     __shared__ int s_last, s_idx, s_rows;
+    __shared__ struct { double vr; int t, lam; } rinfo[kB];
+    __shared__ uint32_t pq[kCandThreads / 64][128];                   // per wavefront: PTRS states past the squeeze, waiting for the full test
     __shared__ unsigned s_ticket;
     __shared__ long long s_p0;
     const int tid = threadIdx.x;
@@ -396,45 +398,81 @@ __global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__rest
                 if (tid < kB) rowof[tid] = (uint8_t)r;
                 const bool is_row = tid < kB && r == tid && mine != 0;
                 const unsigned long long rows_mask = __ballot(is_row);
-                if (is_row) rowlist[__popcll(rows_mask & ((1ull << tid) - 1ull))] = (uint8_t)tid;
+                if (is_row) {
+                    const int kk = __popcll(rows_mask & ((1ull << tid) - 1ull));
+                    rowlist[kk] = (uint8_t)tid;
+                    rinfo[kk].vr = lL[tid].vr;                        // what the table pass needs of a row, in one read
+                    rinfo[kk].t = tid;
+                    rinfo[kk].lam = mine;
+                }
                 if (tid == 0) s_rows = __popcll(rows_mask);
             }
             __syncthreads();
             if (last_of_super) PZ_STAMP(1);
             // the states of all rows as one index space, dealt round the lanes: every wavefront gets the same number of states whatever the
-            // band's length (row by row, a band of 1 227 positions gave four of the sixteen wavefronts twice the others' work)
+            // band's length (row by row, a band of 1 227 positions gave four of the sixteen wavefronts twice the others' work).  PTRS states:
+            // the squeeze (us >= 0.07 and V <= vr: 80 - 87 % of the attempts accept right there) costs four double operations; the others
+            // are queued per wavefront -- (row << 16 | position) words in LDS -- and evaluated 64 at a time with every lane busy: the
+            // division, the two float32 logarithms and the loggam lookup run for the one state in seven that needs them.
             {
-                const int total = s_rows * band;
+                const int total = s_rows * band, wave = tid >> 6, lane = tid & 63;
+                uint32_t *q = pq[wave];
+                int qn = 0;                                           // wave-uniform
+                auto drain = [&](int first, int count) {
+                    if (lane < count) {
+                        const uint32_t w = q[first + lane];
+                        const int t = (int)(w >> 16), o = (int)(w & 0xffffu);
+                        const bool acc = pz_attempt_table(lL[t], lgam, ld[o], ld[o + 1]);
+                        tab[t * stride + o] = acc ? 2 : 0;
+                    }
+                };
                 int k = 0, o = tid;
                 while (o >= band && k < s_rows) { o -= band; k++; }
-                for (int idx = tid; idx < total; idx += kCandThreads) {
-                    const int t = rowlist[k];
-                    const int lam = llam[t];
-                    const PzLam &L = lL[t];
-                    uint8_t code = kCodeInvalid;
-                    if (lam >= 10) {
-                        const double d0 = ld[o], d1 = ld[o + 1];
-                        const bool acc = pz_attempt_table(L, lgam, d0, d1);
-                        code = d0 >= 0.0 && d1 >= 0.0 ? (acc ? 2 : 0) : kCodeInvalid;
-                    } else {
-                        const double enlam = L.enlam;
-                        double prod = 1.0;
-                        int c = 0;
-                        while (o + c < band + 2 && c < 250) {
-                            const double d = ld[o + c];
-                            if (d < 0.0) break;
-                            c++;
-                            prod *= d;
-                            if (!(prod > enlam)) {
-                                code = (uint8_t)c;
-                                break;
+                for (int base = 0; base < total; base += kCandThreads) {
+                    const bool live = base + tid < total;
+                    bool pend = false;
+                    int t = 0;
+                    if (live) {
+                        const double vr = rinfo[k].vr;                // (one round trip: the row's record and the two draws together)
+                        t = rinfo[k].t;
+                        const int lam = rinfo[k].lam;
+                        uint8_t code = kCodeInvalid;
+                        if (lam >= 10) {
+                            const double d0 = ld[o], d1 = ld[o + 1];
+                            const double us = 0.5 - fabs(d0 - 0.5);
+                            const bool fast = us >= 0.07 && d1 <= vr, valid = d0 >= 0.0 && d1 >= 0.0;
+                            code = valid ? (fast ? 2 : 0) : kCodeInvalid;
+                            pend = valid && !fast;
+                        } else {
+                            const double enlam = lL[t].enlam;
+                            double prod = 1.0;
+                            int c = 0;
+                            while (o + c < band + 2 && c < 250) {
+                                const double d = ld[o + c];
+                                if (d < 0.0) break;
+                                c++;
+                                prod *= d;
+                                if (!(prod > enlam)) {
+                                    code = (uint8_t)c;
+                                    break;
+                                }
                             }
                         }
+                        tab[t * stride + o] = code;
                     }
-                    tab[t * stride + o] = code;
+                    const unsigned long long pm = __ballot(pend);
+                    if (pm) {
+                        if (pend) q[qn + __popcll(pm & ((1ull << lane) - 1ull))] = ((uint32_t)t << 16) | (uint32_t)o;
+                        qn += __popcll(pm);
+                        if (qn >= 64) {
+                            qn -= 64;
+                            drain(qn, 64);
+                        }
+                    }
                     o += kCandThreads;
                     while (o >= band) { o -= band; k++; }
                 }
+                drain(0, qn);
             }
             if (tid < s_rows) tab[rowlist[tid] * stride + band] = kCodeInvalid;      // the sentinel a clamped position reads
             __syncthreads();
