@@ -8,7 +8,10 @@
 // untouched pixels are neither read nor written.
 #include "vkx_internal.h"
 
+#include <stdlib.h>
 #include <string.h>
+
+#include <algorithm>
 
 #include <vector>
 
@@ -201,82 +204,148 @@ __device__ __forceinline__ RgbFetch rgb_fetch(const LayerDev<uint8_t> &L, int x0
     return f;
 }
 
+// One layer applied to a lane's four pixels (three dwords): blend_px / the copy rules of k_composite on all twelve bytes, then the bytes
+// of the pixels the layer selects replace the lane's.  `copy` and `mode` are wave-uniform.
+__device__ __forceinline__ void rgb_apply(uint32_t (&px)[3], const RgbFetch &cur, int copy, int mode)
+{
+    const uint32_t s0 = 0u - (cur.sel & 1u), s1 = 0u - ((cur.sel >> 1) & 1u), s2 = 0u - ((cur.sel >> 2) & 1u), s3 = 0u - ((cur.sel >> 3) & 1u);
+    const uint32_t m[3] = {(s0 & 0x00ffffffu) | (s1 & 0xff000000u), (s1 & 0x0000ffffu) | (s2 & 0xffff0000u), (s2 & 0x000000ffu) | (s3 & 0xffffff00u)};
+    uint32_t nv[3];
+    if (copy) {
+        if (mode == VKX_FILL_PLAIN) {
+            nv[0] = cur.v[0]; nv[1] = cur.v[1]; nv[2] = cur.v[2];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                uint32_t r = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const uint32_t d = (px[q] >> (8 * b)) & 0xffu, v = (cur.v[q] >> (8 * b)) & 0xffu;
+                    r |= (mode == VKX_FILL_KEEP_MAX ? (d < v ? v : d) : (d > v ? v : d)) << (8 * b);
+                }
+                nv[q] = r;
+            }
+        }
+    } else {
+        float w1[4], w0[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            w1[i] = cur.a[i];
+            w0[i] = 1.0f - w1[i];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            uint32_t r = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int i = (4 * q + b) / 3;                        // the pixel of byte 4 q + b
+                const float d = (float)((px[q] >> (8 * b)) & 0xffu), v = (float)((cur.v[q] >> (8 * b)) & 0xffu);
+                const float t0 = w0[i] * d, t1 = w1[i] * v;
+                r |= ((uint32_t)(int)(t0 + t1) & 0xffu) << (8 * b);  // (uint8_t)(float): blend_px
+            }
+            nv[q] = r;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++) px[q] = (px[q] & ~m[q]) | (nv[q] & m[q]);
+}
+
+// A workgroup owns a RUN of kRgbRun consecutive tile slots: the tables of the whole run arrive in three round trips (slots' ids and
+// ranges; the layer indices; the layer records, staged in LDS by all lanes) instead of three per tile, and the (tile, layer) pairs of the
+// run are walked as ONE list -- the planes of pair n + 1, which may belong to the next tile, are requested before pair n is blended, a
+// tile's pixels are initialised at its first pair and stored at its last.  (Round 5: one tile per workgroup spent 60 % of its
+// wavefront cycles waiting on four dependent round trips for 1 024 pixels.)
+constexpr int kRgbRun = 8;
 __global__ void __launch_bounds__(256) k_composite_rgb(uint8_t *dst, ptrdiff_t dstride, int h, int w,
                                                        const LayerDev<uint8_t> *__restrict__ layers,
                                                        const int *__restrict__ tile_ids, const int *__restrict__ tile_begin,
                                                        const int *__restrict__ tile_layers, int tiles_x,
-                                                       uint8_t *const *__restrict__ pages, int tiles_per_page)
+                                                       uint8_t *const *__restrict__ pages, int tiles_per_page, int n_tiles, int run)
 {
     __shared__ LayerDev<uint8_t> recs[kRgbRecs];
-    int tile = tile_ids[blockIdx.x];
-    if (pages) {
-        const int page = tile / tiles_per_page;
-        tile -= page * tiles_per_page;
-        dst = pages[page];
+    __shared__ int s_begin[kRgbRun + 1], s_x[kRgbRun], s_y[kRgbRun];
+    __shared__ uint8_t *s_dst[kRgbRun];
+    const int t0 = blockIdx.x * run, nt = min(run, n_tiles - t0);
+    if ((int)threadIdx.x <= nt) s_begin[threadIdx.x] = tile_begin[t0 + threadIdx.x];
+    if ((int)threadIdx.x < nt) {
+        int tile = tile_ids[t0 + threadIdx.x];
+        uint8_t *d = dst;
+        if (pages) {
+            const int page = tile / tiles_per_page;
+            tile -= page * tiles_per_page;
+            d = pages[page];
+        }
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        s_x[threadIdx.x] = tx * kTileW;
+        s_y[threadIdx.x] = ty * kTileH;
+        s_dst[threadIdx.x] = d;
     }
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int x0 = tx * kTileW + 4 * (threadIdx.x & 15);
-    const int y = ty * kTileH + (threadIdx.x >> 4);
-    const bool in_page = x0 < w && y < h;       // w % 4 == 0: a group is inside or outside as a whole
-    const int lb = tile_begin[blockIdx.x], le = tile_begin[blockIdx.x + 1];
-    uint32_t *drow = (uint32_t *)(dst + (ptrdiff_t)y * dstride + (ptrdiff_t)x0 * 3);
+    __syncthreads();
+    const int lb = s_begin[0], le = s_begin[nt];
+    const int lx = 4 * (threadIdx.x & 15), ly = threadIdx.x >> 4;
     uint32_t px[3] = {0, 0, 0};
-    bool have = false, dirty = false;
+    bool dirty = false;
+    int k = 0;                                   // slot of the current pair's tile (wave-uniform, like every index below)
     for (int base = lb; base < le; base += kRgbRecs) {
         const int n = min(kRgbRecs, le - base);
-        __syncthreads();
-        // the records of this pass: n * 24 dwords, one per thread and step
+        if (base != lb) __syncthreads();
+        // the records of this pass: n * 20 dwords, one per thread and step
         constexpr int kDw = (int)(sizeof(LayerDev<uint8_t>) / 4);
         for (int i = threadIdx.x; i < n * kDw; i += 256) {
             const int r = i / kDw, d = i - r * kDw;
             ((uint32_t *)&recs[r])[d] = ((const uint32_t *)&layers[tile_layers[base + r]])[d];
         }
         __syncthreads();
-        if (!in_page) continue;
-        if (base == lb) {
-            // the destination is needed unless the first layer writes all four pixels unconditionally
-            const LayerDev<uint8_t> &F = recs[0];
-            const bool covers = F.copy && F.mode == VKX_FILL_PLAIN && !F.mask && y >= F.up && y < F.up + F.height &&
-                                x0 >= F.left && x0 + 3 < F.left + F.width;
-            if (!covers) {
-                px[0] = drow[0]; px[1] = drow[1]; px[2] = drow[2];
-                have = true;
-            }
-        }
-        RgbFetch cur = rgb_fetch(recs[0], x0, y);
+        int x0 = s_x[k] + lx, y = s_y[k] + ly;
+        bool in_page = x0 < w && y < h;         // w % 4 == 0: a group is inside or outside as a whole
+        const LayerDev<uint8_t> *Lp = &recs[0];
+        RgbFetch cur;
+        cur.sel = 0;
+        if (in_page) cur = rgb_fetch(*Lp, x0, y);
         for (int li = 0; li < n; li++) {
-            const LayerDev<uint8_t> &L = recs[li];
+            const int gi = base + li;
+            const LayerDev<uint8_t> &L = *Lp;
+            const bool last_of_tile = gi + 1 == s_begin[k + 1];
+            int xn = x0, yn = y;
+            bool in_next = in_page;
             RgbFetch nxt;
             nxt.sel = 0;
-            if (li + 1 < n) nxt = rgb_fetch(recs[li + 1], x0, y);
-            if (__ballot(cur.sel != 0)) {
-                if (cur.sel) {
-                    uint8_t pb[12], vb[12];
-                    for (int i = 0; i < 12; i++) {
-                        pb[i] = (uint8_t)(px[i >> 2] >> (8 * (i & 3)));
-                        vb[i] = (uint8_t)(cur.v[i >> 2] >> (8 * (i & 3)));
-                    }
-                    for (int i = 0; i < 4; i++) {
-                        if (!((cur.sel >> i) & 1)) continue;
-                        if (L.copy) {
-                            for (int c = 0; c < 3; c++) {
-                                const uint8_t val = vb[3 * i + c], d = pb[3 * i + c];
-                                if (L.mode == VKX_FILL_PLAIN || (L.mode == VKX_FILL_KEEP_MAX ? d < val : d > val)) pb[3 * i + c] = val;
-                            }
-                        } else {
-                            const float w1 = cur.a[i], w0 = 1.0f - w1;
-                            for (int c = 0; c < 3; c++) pb[3 * i + c] = blend_px(w0, w1, pb[3 * i + c], vb[3 * i + c]);
-                        }
-                    }
-                    for (int k = 0; k < 3; k++) px[k] = pb[4 * k] | (pb[4 * k + 1] << 8) | (pb[4 * k + 2] << 16) | ((uint32_t)pb[4 * k + 3] << 24);
-                    dirty = true;
+            if (li + 1 < n) {
+                if (last_of_tile) {
+                    xn = s_x[k + 1] + lx;
+                    yn = s_y[k + 1] + ly;
+                    in_next = xn < w && yn < h;
                 }
+                if (in_next) nxt = rgb_fetch(recs[li + 1], xn, yn);
+            } else if (last_of_tile && k + 1 < nt) {                 // the next pass starts with the next tile
+                xn = s_x[k + 1] + lx;
+                yn = s_y[k + 1] + ly;
+                in_next = xn < w && yn < h;
+            }
+            uint32_t *drow = (uint32_t *)(s_dst[k] + (ptrdiff_t)y * dstride + (ptrdiff_t)x0 * 3);
+            if (gi == s_begin[k]) {
+                px[0] = px[1] = px[2] = 0;
+                dirty = false;
+                // the destination is needed unless the first layer writes all four pixels unconditionally
+                const bool covers = L.copy && L.mode == VKX_FILL_PLAIN && !L.mask && y >= L.up && y < L.up + L.height &&
+                                    x0 >= L.left && x0 + 3 < L.left + L.width;
+                if (in_page && !covers) { px[0] = drow[0]; px[1] = drow[1]; px[2] = drow[2]; }
+            }
+            if (__ballot(cur.sel != 0)) {
+                // the layer's kind is wave-uniform: one branch per layer, straight-line arithmetic for the four pixels, the pixels the layer
+                // does not select put back by a byte mask
+                rgb_apply(px, cur, __builtin_amdgcn_readfirstlane(L.copy), __builtin_amdgcn_readfirstlane(L.mode));
+                dirty = dirty || cur.sel != 0;
+            }
+            if (last_of_tile) {
+                if (in_page && dirty) { drow[0] = px[0]; drow[1] = px[1]; drow[2] = px[2]; }
+                k++;
             }
             cur = nxt;
+            Lp = &recs[li + 1 < n ? li + 1 : li];
+            x0 = xn; y = yn; in_page = in_next;
         }
     }
-    (void)have;
-    if (in_page && dirty) { drow[0] = px[0]; drow[1] = px[1]; drow[2] = px[2]; }
 }
 
 // The 4-pixel-group kernel for uint8 RGB when every destination is dword aligned with whole groups per row.
@@ -299,9 +368,12 @@ bool composite_rgb_groups<uint8_t, 3>(vkx_ctx *ctx, uint8_t *dst, ptrdiff_t dstr
         return false;
     }
     VKX_TIMED(ctx, "k_composite_rgb");
-    k_composite_rgb<<<(unsigned)n_tiles, 256, 0, ctx->stream>>>(
+    // tile slots per workgroup: long runs where the launch has workgroups to spare, one tile each for a single page
+    static const int run_env = getenv("VKX_RGB_RUN") ? atoi(getenv("VKX_RGB_RUN")) : 0;
+    const int run = run_env > 0 ? std::min(run_env, kRgbRun) : (n_tiles >= 32768 ? kRgbRun : n_tiles >= 8192 ? 4 : n_tiles >= 4096 ? 2 : 1);
+    k_composite_rgb<<<(unsigned)((n_tiles + run - 1) / run), 256, 0, ctx->stream>>>(
         dst, dstride, h, w, (const LayerDev<uint8_t> *)(base + o0), (const int *)(base + o1), (const int *)(base + o2),
-        (const int *)(base + o3), tiles_x, pages ? (uint8_t *const *)(base + o4) : nullptr, tiles_pp);
+        (const int *)(base + o3), tiles_x, pages ? (uint8_t *const *)(base + o4) : nullptr, tiles_pp, (int)n_tiles, run);
     return hipGetLastError() == hipSuccess;
 }
 
