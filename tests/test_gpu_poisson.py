@@ -128,3 +128,35 @@ print('depth ok')
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, VKX_PZ_DEPTH=depth), cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and 'depth ok' in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize('env', [{'VKX_PZ_GRID': '1'}, {'VKX_PZ_GRID': '3', 'VKX_PZ_DEPTH': '3'}, {'VKX_PZ_GRID': '7', 'VKX_PZ_DEPTH': '1'},
+                                 {'VKX_PZ_G_GLOBAL': '1'}, {'VKX_PZ_G_GLOBAL': '1', 'VKX_PZ_DEPTH': '3', 'VKX_PZ_GRID': '5'}])
+def test_persistent_kernel_structure(env):
+    """The one-launch kernel (round 5): a workgroup waits only for results of lower tickets, so ANY number of persistent workgroups must
+    finish -- one workgroup does every block, group walk and chain itself, a handful interleave superblocks at every depth --; the top
+    chain reading its G rows from global memory (VKX_PZ_G_GLOBAL: the path taken when they outgrow LDS); more superblocks than ring
+    slots; groups of fewer than sixteen blocks; dark images whose superblocks close early."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np
+from numpy.random import default_rng
+from vkit_amd import _native as N
+g = default_rng(2)
+page = np.full((400, 520, 3), 255, np.uint8)
+page[40:60, 30:480] = g.integers(0, 80, (20, 450, 3), dtype=np.uint8)
+cases = (g.integers(0, 256, (260, 333, 3), dtype=np.uint8), page, g.integers(0, 14, (150, 210, 3), dtype=np.uint8),
+         np.full((97,), 10, np.uint8), np.full((32 * 16 + 5,), 200, np.uint8), np.zeros((700,), np.uint8), np.full((32 * 17,), 9, np.uint8))
+for k, img in enumerate(cases):
+    r_np, r_dev = default_rng(30 + k), default_rng(30 + k)
+    want = np.clip(r_np.poisson(img.astype(np.float32)), 0, 255).astype(np.uint8)
+    got = N.np_poisson_u8(img, r_dev)
+    assert got is not None, (k, N.np_poisson_last_flags())
+    assert np.array_equal(np.asarray(N.host_array(got)), want) and r_np.bit_generator.state == r_dev.bit_generator.state, k
+print('structure ok')
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, **env), cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and 'structure ok' in out.stdout, out.stdout + out.stderr

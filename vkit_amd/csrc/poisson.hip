@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__rest
                                                            const double *__restrict__ draws, long long M, const PzTabs *__restrict__ T,
                                                            uint16_t *E, uint16_t *P, uint16_t *G, long long e_stride /* entries per ring slot */,
                                                            long long *__restrict__ blk_pos, unsigned *ticket, unsigned *grp_counter, unsigned *sup_counter,
-                                                           unsigned *done, int *__restrict__ fail, long long *__restrict__ probe)
+                                                           unsigned *done, int *__restrict__ fail, long long *__restrict__ probe, int g_rows_global)
 {
 #define PZ_STAMP(k) do { if (probe && tid == 0) probe[8 * sup + (k)] = (long long)wall_clock64(); } while (0)
     __shared__ double ld[kBandMax + 2];
@@ -619,7 +619,7 @@ __global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__rest
         __syncthreads();
         if (!s_last) continue;
         PZ_STAMP(4);
-        const bool g_in_lds = S.g_total <= kB * kBandMax / 2 - 8;
+        const bool g_in_lds = !g_rows_global && S.g_total <= kB * kBandMax / 2 - 8;      // (VKX_PZ_G_GLOBAL: the path of G rows beyond LDS, for tests)
         for (int g = tid; g < S.n_groups; g += kCandThreads) l_off[g] = blocks[S.first_block + g * S.grp_rows].g_off;
         if (g_in_lds) {
             const int n8 = (S.g_total + 3) >> 2;
@@ -940,11 +940,12 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
             return v;
         }();
-        static const int grid_env = getenv("VKX_PZ_GRID") ? atoi(getenv("VKX_PZ_GRID")) : 0;
+        static const int grid_env = getenv("VKX_PZ_GRID") ? atoi(getenv("VKX_PZ_GRID")) : 0;      // fewer workgroups than CUs: every wait of the kernel is exercised
+        static const int g_global = getenv("VKX_PZ_G_GLOBAL") ? atoi(getenv("VKX_PZ_G_GLOBAL")) : 0;
         const int grid = (int)std::min<long long>(n_blk, grid_env > 0 ? grid_env : n_cu);
         VKX_TIMED(ctx, "k_pz_super");
         k_pz_super<<<grid, kCandThreads, 0, ctx->stream>>>(src, n, (int)n_blk, d_plan, d_sup, d_pos, d_draws, M, tabs, d_E, d_P, d_G, (long long)e_stride, d_bpos,
-                                                          d_ticket, d_grpcnt, d_supcnt, d_done, &d_reply->fail, d_probe);
+                                                          d_ticket, d_grpcnt, d_supcnt, d_done, &d_reply->fail, d_probe, g_global);
     }
     VKX_LAUNCH_CHECK();
     { VKX_TIMED(ctx, "k_pz_final");
