@@ -23,6 +23,7 @@ SOAKS = [
     ('soak7.py', ['20', '504'], 'the numpy streams (every kind, 1 .. 150 ragged streams per call, chains with noise_rng) vs numpy itself'),
     ('soak8.py', ['160'], 'rng.poisson on the device vs numpy: values and stream position; declined images are counted'),
     ('soak9.py', ['8', '506'], 'fog field and glass_blur shuffle planes vs their host restatements, planes and stream position'),
+    ('soak10.py', ['8', '507'], 'k_composite_rgb (batched RGB pages of whole 4-pixel groups, every layer kind, stacked layers) vs the sequential oracle fills'),
 ]
 
 
@@ -49,10 +50,12 @@ def test_bounded_soak(script, argv, what):
     print(f'{script}: {tail}')
     assert proc.returncode == 0, f'{script} {argv} ({what}) failed:\n{proc.stdout[-2000:]}\n{proc.stderr[-4000:]}'
     entry = {'argv': argv, 'covers': what, 'result': tail}
-    if script in ('soak8.py', 'soak9.py'):
+    if script in ('soak8.py', 'soak9.py', 'soak10.py'):
         report = json.loads(tail)
         entry['result'] = report
-        if script == 'soak8.py':
+        if script == 'soak10.py':
+            assert report['soak10'] == 'ok' and report['layers'] > 0, report
+        elif script == 'soak8.py':
             # a declined image (near tie of the PTRS comparison, a start outside its 6-sigma window) falls back to numpy: correct,
             # and rare -- one image in ~3 000 in the builder's 4 G-element soak
             assert report['declined'] <= 3, report
