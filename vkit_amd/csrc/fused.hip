@@ -447,10 +447,10 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tx, cons
     // Candidate records [base, base + cn) go into the two LDS tables, 16 lanes x 8 B per 128-byte record and two records per
     // lane (NLDSCELL = 2 x 32).  Fetch and store are split so that the first chunk's loads are in flight, together with the
     // hue tables, while the ownership plane is being cleared: one memory round trip at the head of the tile instead of three.
-    constexpr int kRecPerLane = NLDSCELL / (NTHREADS / 16);      // 2 (512 lanes) or 1 (1024 lanes)
+    constexpr int kRecPerLane = NLDSCELL / (NTHREADS / 16);      // 4 (256 lanes: fused_nw4.hip), 2 (512 lanes) or 1 (1024 lanes)
     static_assert(NLDSCELL == kRecPerLane * (NTHREADS / 16), "whole records per lane and chunk");
     const float rcp_ncol = __builtin_amdgcn_rcpf((float)max(ncol, 1));
-    auto chunk_fetch = [&](int base, int cn_, unsigned long long (&v)[2]) {
+    auto chunk_fetch = [&](int base, int cn_, unsigned long long (&v)[kRecPerLane]) {
 #pragma unroll
         for (int h = 0; h < kRecPerLane; h++) {
             const int rec = (tid >> 4) + h * (NTHREADS / 16);
@@ -464,7 +464,7 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tx, cons
             }
         }
     };
-    auto chunk_store = [&](int cn_, const unsigned long long (&v)[2]) {
+    auto chunk_store = [&](int cn_, const unsigned long long (&v)[kRecPerLane]) {
 #pragma unroll
         for (int h = 0; h < kRecPerLane; h++) {
             const int rec = (tid >> 4) + h * (NTHREADS / 16), part = tid & 15;
@@ -475,7 +475,7 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tx, cons
         }
     };
     auto load_chunk = [&](int base, int cn_) {
-        unsigned long long v[2];
+        unsigned long long v[kRecPerLane];
         chunk_fetch(base, cn_, v);
         chunk_store(cn_, v);
     };
@@ -495,7 +495,7 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tx, cons
     for (int i = 0; i < 2 * RMAX + 1; i++) kq[i] = (R > 0 && i < K) ? it.kq[i < K - 1 - i ? i : K - 1 - i] : 0;   // symmetric (checked on the host)
     if constexpr (!EMPTY) {
         // ---- A: clear the ownership plane, then rasterise the candidates chunk by chunk out of LDS
-        unsigned long long first[2];
+        unsigned long long first[kRecPerLane];
         chunk_fetch(0, min(NLDSCELL, nc), first);
         int lutv = 0;
         uint32_t selv = 0;
