@@ -11,12 +11,15 @@
 //                their prefix sums into SUPERBLOCKS of <= 256 blocks and, per block, the WINDOW of stream positions its first element
 //                can start at: predicted position +- 6 sigma, relative to the exact start of the superblock;
 //   k_pz_raw     the raw stream as doubles (next_double), positions 0 .. M;
-//   k_pz_super   one launch per superblock, workgroup = block: the outcome of EVERY (element, position) state of the block's band is
-//                evaluated once into LDS (PTRS: accept / reject of the attempt that starts there; lam < 10: the draws the element takes
-//                from there), then one lane per candidate start walks the 32 elements through that table: E[block][candidate] = where
-//                the next block starts; the workgroup that finishes last follows the exact start through the E rows (staged through
-//                LDS): the exact start of every block and of the next superblock.  Launches of up to three superblocks are in flight
-//                (windows relative to an earlier superblock's start; see the host code);
+//   k_pz_super   ONE launch of persistent workgroups (round 5; through round 4: one launch per superblock).  A workgroup takes the next
+//                block in stream order: the outcome of EVERY (element, position) state of the block's band is evaluated once into LDS
+//                (PTRS: accept / reject of the attempt that starts there -- the squeeze for all, the full test for the queued rest; lam < 10:
+//                the draws the element takes from there), then one lane per candidate start walks the 32 elements through that table:
+//                E[block][candidate] = where the next block starts.  The last block of a group of <= 16 walks all candidates of the group's
+//                first window through the group's E rows (P: where a candidate stands at every row; G: where it enters the next group), the
+//                last group of the superblock follows the exact start through the <= 16 G rows, publishes the next superblock's start and
+//                reads every block's start out of P.  Windows relative to the start of the superblock `depth - 1` before keep the blocks of
+//                `depth` superblocks in flight (see the host code);
 //   k_pz_final   one lane per block walks its 32 elements from the exact start, now computing the values, and checks that it ends
 //                where the next block begins.
 // Every decision is numpy's: the per-lam constants, exp(-lam) and the loggam table are computed on the HOST with the same libm numpy
