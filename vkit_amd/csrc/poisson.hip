@@ -34,6 +34,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <vector>
 #include <type_traits>
@@ -185,7 +186,7 @@ __global__ void __launch_bounds__(256) k_pz_raw(uint64_t s_lo, uint64_t s_hi, ui
 }
 
 __global__ void __launch_bounds__(256) k_pz_stats(const uint8_t *__restrict__ src, long long n, const PzTabs *__restrict__ T,
-                                                  float *__restrict__ bmean, float *__restrict__ bvar)
+                                                  float *__restrict__ bmean, float *__restrict__ bvar, float *__restrict__ brows)
 {
     __shared__ float lm[256], lv[256];
     lm[threadIdx.x] = T->mean[threadIdx.x];
@@ -194,6 +195,11 @@ __global__ void __launch_bounds__(256) k_pz_stats(const uint8_t *__restrict__ sr
     const long long blk = (long long)blockIdx.x * 256 + threadIdx.x, e0 = blk * kB;
     if (e0 >= n) return;
     float m = 0.f, v = 0.f;
+    uint32_t seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};          // the block's distinct values: the rows of its table (its cost; the plan deals heavy blocks first)
+    auto mark = [&](int l) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) seen[q] |= (l >> 5) == q ? 1u << (l & 31) : 0u;
+    };
     if (e0 + kB <= n) {
         const uint4 *p = (const uint4 *)(src + e0);
 #pragma unroll
@@ -205,16 +211,23 @@ __global__ void __launch_bounds__(256) k_pz_stats(const uint8_t *__restrict__ sr
                 const int l = (ws[i >> 2] >> (8 * (i & 3))) & 0xff;
                 m += lm[l];
                 v += lv[l];
+                mark(l);
             }
         }
     } else {
         for (long long e = e0; e < n; e++) {
             m += lm[src[e]];
             v += lv[src[e]];
+            mark(src[e]);
         }
     }
+    seen[0] &= ~1u;                                        // (zero takes no draws and has no row)
+    int rows = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) rows += __popc(seen[q]);
     bmean[blk] = m;
     bvar[blk] = v;
+    brows[blk] = (float)rows;
 }
 
 // random_loggam(x) for x >= 7 with the device's log: arguments beyond the host table (k + 1 > kKMax: us below ~1e-3 AND V <= us, a few
@@ -325,7 +338,7 @@ __device__ __forceinline__ long long pz_wait_ll(const long long *p, bool &timed_
     return v;
 }
 
-__global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__restrict__ src, long long n, int n_blk, const PzBlock *__restrict__ blocks,
+__global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__restrict__ src, long long n, int n_blk, const int *__restrict__ order, const PzBlock *__restrict__ blocks,
                                                            const PzSuper *__restrict__ supers, long long *pos /* exact starts of the superblocks; -1: not yet */,
                                                            const double *__restrict__ draws, long long M, const PzTabs *__restrict__ T,
                                                            uint16_t *E, uint16_t *P, uint16_t *G, long long e_stride /* entries per ring slot */,
@@ -352,7 +365,7 @@ __global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__rest
         __syncthreads();
         const unsigned tk = (unsigned)__builtin_amdgcn_readfirstlane((int)s_ticket);
         if (tk >= (unsigned)n_blk) return;
-        const int j = (int)tk;
+        const int j = order[tk];            // (within a superblock the blocks are dealt by decreasing table size: see the host's plan)
         const PzBlock blk = blocks[j];
         const int sup = blk.sup;
         const PzSuper S = supers[sup];
@@ -810,14 +823,16 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
     }
     const PzTabs *tabs = (const PzTabs *)ctx->pz_tabs.ptr;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    const size_t o_mean = 0, o_var = o_mean + up(sizeof(float) * n_blk), o_plan = o_var + up(sizeof(float) * n_blk),
+    const size_t o_mean = 0, o_var = o_mean + up(sizeof(float) * n_blk), o_rows = o_var + up(sizeof(float) * n_blk), o_order = o_rows + up(sizeof(float) * n_blk),
+                 o_plan = o_order + up(sizeof(int) * n_blk),
                  o_bpos = o_plan + up(sizeof(PzBlock) * n_blk), o_pos = o_bpos + up(sizeof(long long) * (n_blk + 1));
     // superblocks hold at least one block each: n_blk + 2 positions always suffice
     // counters: the ticket | per superblock: groups done, `done` flag | per group: blocks done
     const size_t o_counter = o_pos + up(sizeof(long long) * (n_blk + 2)), o_reply = o_counter + up(sizeof(unsigned) * (3 * (size_t)n_blk + 8)), work_bytes = o_reply + 256;
     if ((rc = vkx_scratch_reserve(ctx, &ctx->pz_work, work_bytes))) return rc;
     unsigned char *work = (unsigned char *)ctx->pz_work.ptr;
-    float *d_mean = (float *)(work + o_mean), *d_var = (float *)(work + o_var);
+    float *d_mean = (float *)(work + o_mean), *d_var = (float *)(work + o_var), *d_rows = (float *)(work + o_rows);
+    int *d_order = (int *)(work + o_order);
     PzBlock *d_plan = (PzBlock *)(work + o_plan);
     long long *d_bpos = (long long *)(work + o_bpos), *d_pos = (long long *)(work + o_pos);
     PzReply *d_reply = (PzReply *)(work + o_reply);
@@ -825,12 +840,20 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
     static const bool probing = getenv("VKX_PZ_PROBE") != nullptr;       // phase timestamps of every superblock (tools/poisson_probe.py)
     long long *d_probe = nullptr;
 
-    { VKX_TIMED(ctx, "k_pz_stats"); k_pz_stats<<<vkx_blocks((size_t)n_blk, 256), 256, 0, ctx->stream>>>(src, n, tabs, d_mean, d_var); }
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&](const std::chrono::steady_clock::time_point &t0) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
+    double us_stats = 0, us_plan = 0, us_queue = 0;
+    { VKX_TIMED(ctx, "k_pz_stats"); k_pz_stats<<<vkx_blocks((size_t)n_blk, 256), 256, 0, ctx->stream>>>(src, n, tabs, d_mean, d_var, d_rows); }
     VKX_LAUNCH_CHECK();
-    std::vector<float> bmean((size_t)n_blk), bvar((size_t)n_blk);
+    // (host vectors of a call are kept per thread: a 1024^2 page is 98 k blocks, 4 MB of plan that would otherwise be mapped and faulted in
+    //  anew by every call)
+    static thread_local std::vector<float> bmean, bvar, brows;
+    bmean.resize((size_t)n_blk); bvar.resize((size_t)n_blk); brows.resize((size_t)n_blk);
     VKX_HIP(hipMemcpyAsync(bmean.data(), d_mean, sizeof(float) * n_blk, hipMemcpyDeviceToHost, ctx->stream));
     VKX_HIP(hipMemcpyAsync(bvar.data(), d_var, sizeof(float) * n_blk, hipMemcpyDeviceToHost, ctx->stream));
+    VKX_HIP(hipMemcpyAsync(brows.data(), d_rows, sizeof(float) * n_blk, hipMemcpyDeviceToHost, ctx->stream));
     VKX_HIP(hipStreamSynchronize(ctx->stream));
+    us_stats = since(t_begin);
 
     // the plan: superblocks and windows (VKX_PZ_SIGMAS: narrower windows, to exercise the WINDOW refusal in tests)
     static const double sigmas = getenv("VKX_PZ_SIGMAS") ? atof(getenv("VKX_PZ_SIGMAS")) : kSigmas;
@@ -845,8 +868,10 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
     const int depth = depth_env ? depth_env : (var_per_element > 7.0 ? 1 : 2);
     const int max_blocks = kMaxBlocks;
     std::vector<std::pair<double, double>> before;         // (mean, variance) of the depth - 1 superblocks before this one
-    std::vector<PzBlock> plan((size_t)n_blk);
-    std::vector<PzSuper> supers;
+    static thread_local std::vector<PzBlock> plan;
+    static thread_local std::vector<PzSuper> supers;
+    plan.resize((size_t)n_blk);
+    supers.clear();
     double total_m = 0.0, total_v = 0.0, base_m = 0.0, base_v = 0.0;      // base: the superblock before (depth 2)
     long long e_max = 0;
     int n_groups_total = 0;
@@ -910,12 +935,32 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
         supers.push_back(S);
         s0 = j;
     }
+    // Ticket order: superblock after superblock (a workgroup may only wait for lower tickets), and within a superblock the blocks with
+    // the largest tables first -- a text row's block has up to 32 table rows, a white one a single row: dealt in index order the last heavy
+    // block of a superblock starts when most light ones are done and the superblock's chain waits a whole table pass for it.
+    static thread_local std::vector<int> order;
+    order.resize((size_t)n_blk);
+    static const bool heavy_first = !(getenv("VKX_PZ_ORDER") && atoi(getenv("VKX_PZ_ORDER")) == 0);
+    // (a counting sort by table rows, more rows first; among equals the later block first: its window, hence its band, is the wider)
+    for (const PzSuper &S : supers) {
+        int *o = order.data() + S.first_block;
+        if (!heavy_first) {
+            for (int b = 0; b < S.n_blocks; b++) o[b] = S.first_block + b;
+            continue;
+        }
+        int start[kB + 2];
+        for (int r = 0; r <= kB + 1; r++) start[r] = 0;
+        for (int b = 0; b < S.n_blocks; b++) start[kB - std::min(kB, (int)brows[(size_t)(S.first_block + b)]) + 1]++;
+        for (int r = 1; r <= kB + 1; r++) start[r] += start[r - 1];
+        for (int b = S.n_blocks - 1; b >= 0; b--) o[start[kB - std::min(kB, (int)brows[(size_t)(S.first_block + b)])]++] = S.first_block + b;
+    }
     const long long M = (long long)ceil(total_m + (kSigmas + 1.0) * sqrt(total_v)) + 8192;
     if (M > (1ll << 29)) {          // more than 4 GB of raw draws: declined (the caller draws with numpy)
         *consumed_host = 0;
         *flags_host = kFlagSize;
         return VKX_OK;
     }
+    us_plan = since(t_begin) - us_stats;
     const size_t e_slot_bytes = up(sizeof(uint16_t) * (size_t)e_max + 16), e_stride = e_slot_bytes / sizeof(uint16_t);
     const size_t draws_bytes = up(sizeof(double) * (size_t)(M + 2)), sup_bytes = up(sizeof(PzSuper) * supers.size());
     if ((rc = vkx_scratch_reserve(ctx, &ctx->pz_draws, draws_bytes + 3 * kSlots * e_slot_bytes + sup_bytes))) return rc;
@@ -930,6 +975,7 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
     }
     unsigned *d_ticket = d_counter, *d_supcnt = d_counter + 4, *d_done = d_supcnt + supers.size(), *d_grpcnt = d_done + supers.size();
     VKX_HIP(hipMemcpyAsync(d_plan, plan.data(), sizeof(PzBlock) * n_blk, hipMemcpyHostToDevice, ctx->stream));
+    VKX_HIP(hipMemcpyAsync(d_order, order.data(), sizeof(int) * n_blk, hipMemcpyHostToDevice, ctx->stream));
     VKX_HIP(hipMemcpyAsync(d_sup, supers.data(), sizeof(PzSuper) * supers.size(), hipMemcpyHostToDevice, ctx->stream));
     VKX_HIP(hipMemsetAsync(d_pos, 0xff, sizeof(long long) * (supers.size() + 1), ctx->stream));      // -1: not published yet
     VKX_HIP(hipMemsetAsync(d_pos, 0, sizeof(long long), ctx->stream));
@@ -947,16 +993,20 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
         static const int g_global = getenv("VKX_PZ_G_GLOBAL") ? atoi(getenv("VKX_PZ_G_GLOBAL")) : 0;
         const int grid = (int)std::min<long long>(n_blk, grid_env > 0 ? grid_env : n_cu);
         VKX_TIMED(ctx, "k_pz_super");
-        k_pz_super<<<grid, kCandThreads, 0, ctx->stream>>>(src, n, (int)n_blk, d_plan, d_sup, d_pos, d_draws, M, tabs, d_E, d_P, d_G, (long long)e_stride, d_bpos,
+        k_pz_super<<<grid, kCandThreads, 0, ctx->stream>>>(src, n, (int)n_blk, d_order, d_plan, d_sup, d_pos, d_draws, M, tabs, d_E, d_P, d_G, (long long)e_stride, d_bpos,
                                                           d_ticket, d_grpcnt, d_supcnt, d_done, &d_reply->fail, d_probe, g_global);
     }
     VKX_LAUNCH_CHECK();
     { VKX_TIMED(ctx, "k_pz_final");
       k_pz_final<<<vkx_blocks((size_t)n_blk, 64), 64, 0, ctx->stream>>>(src, n, n_blk, d_bpos, d_draws, M, tabs, dst, &d_reply->consumed, &d_reply->fail); }
     VKX_LAUNCH_CHECK();
+    us_queue = since(t_begin) - us_stats - us_plan;
     PzReply reply;
     VKX_HIP(hipMemcpyAsync(&reply, d_reply, sizeof(reply), hipMemcpyDeviceToHost, ctx->stream));
     VKX_HIP(hipStreamSynchronize(ctx->stream));
+    if (probing)
+        fprintf(stderr, "pz host (us): statistics kernel + read-back %.0f, plan %.0f, uploads + launches queued %.0f, wait for the device %.0f\n", us_stats, us_plan, us_queue,
+                since(t_begin) - us_stats - us_plan - us_queue);
     if (probing && (reply.fail & kFlagAmbiguous)) {
         double dbg[8];
         VKX_HIP(hipMemcpyFromSymbol(dbg, HIP_SYMBOL(pz_dbg), sizeof(dbg)));
