@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__rest
                                                            const double *__restrict__ draws, long long M, const PzTabs *__restrict__ T,
                                                            uint16_t *E, uint16_t *P, uint16_t *G, long long e_stride /* entries per ring slot */,
                                                            long long *__restrict__ blk_pos, unsigned *ticket, unsigned *grp_counter, unsigned *sup_counter,
-                                                           unsigned *done, int *__restrict__ fail, long long *__restrict__ probe, int g_rows_global)
+                                                           unsigned *done, int *__restrict__ fail, long long *__restrict__ probe, int g_rows_global, int resolve_rows)
 {
 #define PZ_STAMP(k) do { if (probe && tid == 0) probe[8 * sup + (k)] = (long long)wall_clock64(); } while (0)
     __shared__ double ld[kBandMax + 2];
@@ -496,7 +496,7 @@ __global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__rest
             // chain, in place -- a state read while its lane rewrites it is either still 0 (go on) or already its own total (add and stop) --,
             // and the walks below read ONE byte per element instead of one per attempt of the wavefront's unluckiest lane.  With many rows
             // (noise: 32 values per block) the pass costs more than the walks save.
-            const bool resolved = s_rows <= kResolveRows;
+            const bool resolved = s_rows <= resolve_rows;
             if (resolved) {
                 for (int k = 0; k < s_rows; k++) {
                     const int t = rowlist[k];
@@ -991,10 +991,11 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
         }();
         static const int grid_env = getenv("VKX_PZ_GRID") ? atoi(getenv("VKX_PZ_GRID")) : 0;      // fewer workgroups than CUs: every wait of the kernel is exercised
         static const int g_global = getenv("VKX_PZ_G_GLOBAL") ? atoi(getenv("VKX_PZ_G_GLOBAL")) : 0;
+        static const int resolve_rows = getenv("VKX_PZ_RESOLVE_ROWS") ? atoi(getenv("VKX_PZ_RESOLVE_ROWS")) : kResolveRows;
         const int grid = (int)std::min<long long>(n_blk, grid_env > 0 ? grid_env : n_cu);
         VKX_TIMED(ctx, "k_pz_super");
         k_pz_super<<<grid, kCandThreads, 0, ctx->stream>>>(src, n, (int)n_blk, d_order, d_plan, d_sup, d_pos, d_draws, M, tabs, d_E, d_P, d_G, (long long)e_stride, d_bpos,
-                                                          d_ticket, d_grpcnt, d_supcnt, d_done, &d_reply->fail, d_probe, g_global);
+                                                          d_ticket, d_grpcnt, d_supcnt, d_done, &d_reply->fail, d_probe, g_global, resolve_rows);
     }
     VKX_LAUNCH_CHECK();
     { VKX_TIMED(ctx, "k_pz_final");
