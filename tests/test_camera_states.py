@@ -120,6 +120,6 @@ def test_tile_buffer_layout_formula():
     for n in [1, 2, 3071, 3072, 3073, 98304, 14_500_000, 0x7fffffff] + [int(v) for v in rng.integers(1, 60_000_000, 200)]:
         vals = [ctypes.c_int64() for _ in range(5)]
         N.check(N.lib().vkx_np_tiles_layout(n, *[ctypes.byref(v) for v in vals]))
-        tiles = (n + n // 32 + 2048 + 3072 - 1) // 3072
+        tiles = (n + n // 45 + 4096 + 3072 - 1) // 3072
         slots_off = (16 + 8 * (tiles + 1) + 255) & ~255
         assert (vals[0].value, vals[2].value, vals[3].value, vals[4].value) == (tiles, 16, slots_off, slots_off + tiles * vals[1].value * 2), n

@@ -237,7 +237,7 @@ class ChainBatch:
             # new shapes: destinations and tile buffers from one arena, 256-byte aligned
             n = dh * dw * 3
             dst_bytes = (n + 255) & ~255
-            tiles = (n + n // 32 + 2048 + cs.tile_draws - 1) // cs.tile_draws
+            tiles = (n + n // 45 + 4096 + cs.tile_draws - 1) // cs.tile_draws      # (csrc/nprand.hip np_tiles_for_n)
             slots_off = (16 + 8 * (tiles + 1) + 255) & ~255
             tile_bytes = np.where(cs.noisy, slots_off + tiles * cs.slot_elems * 2, 0)
             sizes = np.stack([dst_bytes, (tile_bytes + 255) & ~255], axis=1).reshape(-1)

@@ -1316,8 +1316,11 @@ static int np_tables(vkx_ctx *ctx, const NpTabs **out)
 
 static long long np_tiles_for_n(long long n, bool uniform)
 {
-    // raw draws to provision: the ziggurat uses 1.022 per sample on average
-    const long long draws = uniform ? n : n + n / 32 + 2048;
+    // raw draws to provision: numpy's ziggurat takes 1.022025 per sample (2e8 samples of the CPU restatement; 1.02198 .. 1.02205 per 25 M), the count
+    // of a stream of n samples scatters with sigma = 0.146 sqrt(n) (557 at 14.5 M): n / 45 = 0.02222 n plus 4 096 is 12 sigma at 14.5 M samples and more
+    // everywhere else.  (Through round 4: n / 32 + 2 048 -- 0.9 % more tiles for the draw pass to walk.)  A stream that runs short all the same raises
+    // VKX_NP_SHORT and the caller draws with numpy.
+    const long long draws = uniform ? n : n + n / 45 + 4096;
     return (draws + kTile - 1) / kTile;
 }
 static long long np_tiles_for(const vkx_np_job &j, bool uniform) { return np_tiles_for_n(j.n, uniform); }
