@@ -600,7 +600,7 @@ __global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__rest
         uint16_t *le = (uint16_t *)tab;
         {
             const PzBlock fb = blocks[S.first_block + r0];
-            const int base = fb.e_off & ~3, shift = fb.e_off - base;          // 8-byte loads
+            const int base = fb.e_off & ~3;                                   // 8-byte loads: the staged rows start at `base`, row r at l_off[r] from there
             if (tid <= cnt) {
                 const int r = r0 + tid;
                 l_off[tid] = (r < S.n_blocks ? blocks[S.first_block + r].e_off : S.e_total) - base;
@@ -626,7 +626,6 @@ __global__ void __launch_bounds__(kCandThreads) k_pz_super(const uint8_t *__rest
                 if (!(c & 1) && c < W0pad)
                     __hip_atomic_store((uint32_t *)Gs + ((fb.g_off + c) >> 1), cur | (right << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            (void)shift;
         }
         // the last group of the superblock chains the G rows
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
