@@ -368,9 +368,11 @@ bool composite_rgb_groups<uint8_t, 3>(vkx_ctx *ctx, uint8_t *dst, ptrdiff_t dstr
         return false;
     }
     VKX_TIMED(ctx, "k_composite_rgb");
-    // tile slots per workgroup: long runs where the launch has workgroups to spare, one tile each for a single page
+    // tile slots per workgroup: long runs where the launch has workgroups to spare, one tile each for a few pages (swept over 2 .. 64 pages of
+    // 1 024 tiles with runs of 1 / 2 / 4 / 8: 8 pages 0.050 / 0.052 / 0.073 / 0.085 ms, 16 pages 0.086 / 0.084 / 0.090 / 0.124, 32 pages 0.160 / 0.154 / 0.153 / 0.161,
+    // 64 pages 0.325 / - / - / 0.275)
     static const int run_env = getenv("VKX_RGB_RUN") ? atoi(getenv("VKX_RGB_RUN")) : 0;
-    const int run = run_env > 0 ? std::min(run_env, kRgbRun) : (n_tiles >= 32768 ? kRgbRun : n_tiles >= 8192 ? 4 : n_tiles >= 4096 ? 2 : 1);
+    const int run = run_env > 0 ? std::min(run_env, kRgbRun) : (n_tiles >= 49152 ? kRgbRun : n_tiles >= 24576 ? 4 : n_tiles >= 12288 ? 2 : 1);
     k_composite_rgb<<<(unsigned)((n_tiles + run - 1) / run), 256, 0, ctx->stream>>>(
         dst, dstride, h, w, (const LayerDev<uint8_t> *)(base + o0), (const int *)(base + o1), (const int *)(base + o2),
         (const int *)(base + o3), tiles_x, pages ? (uint8_t *const *)(base + o4) : nullptr, tiles_pp, (int)n_tiles, run);
