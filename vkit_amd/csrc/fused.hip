@@ -589,7 +589,16 @@ __device__ __forceinline__ void chain_tile(const ItemDev &it, const int tx, cons
                     const int x1 = max(max((xs[a] + 65535) >> 16, xmin), cx0);
                     const int x2 = min(min(xs[a + 1] >> 16, xmax), cx1 - 1);
                     if (!check) {
-                        for (int x = x1; x <= x2; x++) atomicMax(o + x, tag);
+                        // four pixels per trip at immediate offsets (per pixel the loop spent three vector and three scalar instructions
+                        // beside its ds_max), the last one to three under their own predicates
+                        uint32_t *q = o + x1;
+                        int left = x2 - x1 + 1;
+                        for (; left >= 4; left -= 4, q += 4) {
+                            atomicMax(q, tag); atomicMax(q + 1, tag); atomicMax(q + 2, tag); atomicMax(q + 3, tag);
+                        }
+                        if (left >= 1) atomicMax(q, tag);
+                        if (left >= 2) atomicMax(q + 1, tag);
+                        if (left >= 3) atomicMax(q + 2, tag);
                     } else {
                         for (int x = x1; x <= x2; x++) {
                             if (fma(1.0, 1.0, fma(h7, (double)y, h6 * (double)x)) == 0) continue;
