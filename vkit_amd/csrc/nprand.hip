@@ -1461,7 +1461,11 @@ static int np_chunk_front(vkx_ctx *ctx, NpChunk &c)
     // workgroups of a few tiles per wavefront: a chunk's draw shares the device with the placement pass of the chunk before it
     // (2 048 persistent workgroups -- two generations of the 4 096 wavefronts the device holds -- measured 8.3 ms per 256
     // planes, workgroups of 4 tiles per wavefront 7.5 ms: the dispatcher balances them, and the placement pass gets slots)
-    static const int tiles_per_wave = [] { const char *e = getenv("VKX_NP_TPW"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 2; }();
+    // (round 5, swept again under the joint call: 1 / 2 / 4 tiles per wavefront draw ONE 2048^2 plane in 0.050 / 0.064 / 0.083 ms, four planes in 0.132 /
+    //  0.139 / 0.172, sixteen in 0.475 / 0.466 / 0.471, and the bench's chunk of 128 planes -- with the step's small kernels under it -- in 3.79 / 3.67 / 3.63:
+    //  the step 16.77 / 16.52 / 16.41 ms; 8 and 12: 16.55 / 16.60)
+    static const int tpw_env = [] { const char *e = getenv("VKX_NP_TPW"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+    const int tiles_per_wave = tpw_env ? tpw_env : (total_tiles >= 160000 ? 4 : total_tiles >= 40000 ? 2 : 1);
     const unsigned wg = (unsigned)((total_tiles + 4 * tiles_per_wave - 1) / (4 * tiles_per_wave));
     {
         VKX_TIMED(ctx, "k_np_tile_states");
