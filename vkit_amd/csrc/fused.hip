@@ -1406,7 +1406,14 @@ int vkx_chain_plan_build(vkx_ctx *ctx, const vkx_chain_item *items, int n_items,
 // shares the device with whatever large kernel the compute stream is running (a composite, the generator's draw pass).
 int vkx_chain_plan_setup_aside(vkx_ctx *ctx, vkx_chain_plan *p, hipEvent_t *done)
 {
-    static const bool aside = [] { const char *e = getenv("VKX_CHAIN_SETUP_ASIDE"); return !(e && e[0] == '0'); }();
+    // VKX_CHAIN_SETUP_ASIDE=0 / 1 forces one way.  By default the side stream is for BATCHES (>= kAsideMinItems images: their setup is 0.1 - 0.3 ms
+    // that hides under the draw pass or the composite); a call of a few images -- a HostPipeline lane sends one per call -- keeps its setup on the
+    // compute stream: the events that order two streams cost more than the setup of one image (tens of microseconds), and cross-stream events between a
+    // lane's copies and kernels serialise the two copy directions on this stack (tools/pipe_probe2.py) -- with every lane's setup aside the pipeline's
+    // chain legs ran at half their rate (device noise 8.5 -> 4.1 Gpx/s; found in the round-5 records, profiles/r5a .. r5j `dropin`).
+    static const int aside_env = [] { const char *e = getenv("VKX_CHAIN_SETUP_ASIDE"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    constexpr size_t kAsideMinItems = 16;
+    const bool aside = aside_env >= 0 ? aside_env != 0 : p->dev.size() >= kAsideMinItems;
     *done = nullptr;
     if (!aside) {
         if (ctx->lattices_armed) {       // the lattices may be the product of another stream (vkx_camera_states_dev)
