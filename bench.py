@@ -39,6 +39,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# the CPUs this process was started on, before a rank binds itself to the cores next to its GPU (shard.bind_to_device_numa):
+# the all-cores CPU leg runs on THESE
+START_AFFINITY = sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else None
+
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 # HBM bytes and VALU instructions per image from the PMC passes of the current kernel sources.  tools/record.sh rewrites this
 # file together with the sha256 of the sources it profiled; a line measured on other sources reports traffic = null instead
@@ -116,47 +120,127 @@ def cpu_baseline(size, n_images):
     }
 
 
-def _cpu_worker(rank, n_procs, per_proc, size, barrier, queue):
-    """One process of the all-cores CPU leg: prepares its images, meets the others at the barrier, runs the oracle."""
-    import oracle as O
-    idx = [rank * per_proc + j for j in range(per_proc)]
-    states = [make_state(i, size) for i in idx]
-    images = [np.random.default_rng(1000 + i).integers(0, 256, (size, size, 3), dtype=np.uint8) for i in idx]
-    O.lib()
-    barrier.wait()
-    t0 = time.time()
-    for i, img, st in zip(idx, images, states):
-        noise = _oracle_noise(O, 5000 + i, tuple(st.result_shape) + (3,))
-        mx, my = O.grid_to_map(st.src_image_grid.vertices, st.dst_image_grid.vertices, st.result_shape)
-        O.add_noise_i16(O.color_shift_rgb(O.gaussian_blur(O.remap(img, mx, my), 5, BLUR_SIGMA), HUE_DELTA), noise)
-    queue.put((t0, time.time()))
+def host_cpu_facts():
+    """What this process may actually run on: the affinity mask, the cgroup's CPU quota and cpuset (v2 and v1 paths), the load.
+    os.cpu_count() counts the box's logical CPUs whether or not the container may use them."""
+    facts = {'os_cpu_count': os.cpu_count(), 'sched_getaffinity_at_start': len(START_AFFINITY) if START_AFFINITY else None,
+             'sched_getaffinity_now': len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else None}
+
+    def _read(path):
+        try:
+            with open(path) as f:
+                return f.read().strip()
+        except OSError:
+            return None
+
+    cpu_max = _read('/sys/fs/cgroup/cpu.max')
+    if cpu_max is None:
+        quota, period = _read('/sys/fs/cgroup/cpu/cpu.cfs_quota_us'), _read('/sys/fs/cgroup/cpu/cpu.cfs_period_us')
+        if quota is not None and period is not None:
+            cpu_max = f'{quota} {period}' if int(quota) > 0 else f'max {period}'
+    facts['cgroup_cpu_max'] = cpu_max
+    if cpu_max and not cpu_max.startswith('max'):
+        try:
+            q, per = cpu_max.split()
+            facts['cgroup_quota_cpus'] = int(q) / int(per)
+        except ValueError:
+            pass
+    facts['cgroup_cpuset_effective'] = _read('/sys/fs/cgroup/cpuset.cpus.effective') or _read('/sys/fs/cgroup/cpuset/cpuset.effective_cpus')
+    facts['loadavg'] = _read('/proc/loadavg')
+    return facts
 
 
-def cpu_baseline_all_cores(size, n_procs, per_proc):
-    """The same oracle, one single-threaded process per core, all processes timed between a common barrier and the
-    last one to finish."""
+def _cpu_worker(rank, per_proc, size, points, barrier, queue, cpus):
+    """One process of the all-cores CPU leg: prepares its images once, then for every sweep point ``k`` meets the others at
+    the barrier and -- when its rank is below ``k`` -- runs the oracle on its images; the others sit the point out."""
+    try:
+        if cpus:
+            os.sched_setaffinity(0, cpus)       # the launch-time mask, not the GPU-side NUMA binding the parent took later
+        import oracle as O
+        idx = [rank * per_proc + j for j in range(per_proc)]
+        states = [make_state(i, size) for i in idx]
+        images = [np.random.default_rng(1000 + i).integers(0, 256, (size, size, 3), dtype=np.uint8) for i in idx]
+        O.lib()
+        for k in points:
+            barrier.wait()
+            if rank >= k:
+                continue
+            t0 = time.time()
+            for i, img, st in zip(idx, images, states):
+                noise = _oracle_noise(O, 5000 + i, tuple(st.result_shape) + (3,))
+                mx, my = O.grid_to_map(st.src_image_grid.vertices, st.dst_image_grid.vertices, st.result_shape)
+                O.add_noise_i16(O.color_shift_rgb(O.gaussian_blur(O.remap(img, mx, my), 5, BLUR_SIGMA), HUE_DELTA), noise)
+            queue.put((k, rank, t0, time.time()))
+    except Exception:                          # a broken barrier (the parent gave up) or a failed worker: leave quietly
+        try:
+            barrier.abort()
+        except Exception:
+            pass
+
+
+def sweep_points(limit):
+    """1, 2, 4, ... up to ``limit`` (the limit itself included)."""
+    pts, k = [], 1
+    while k < limit:
+        pts.append(k)
+        k *= 2
+    pts.append(limit)
+    return pts
+
+
+def cpu_baseline_all_cores(size, n_procs, per_proc, single_thread_value=None, budget_s=150.0):
+    """The same oracle as single-threaded processes, swept over 1, 2, 4, ... ``n_procs`` of them (one pool of processes, started
+    and prepared once; each sweep point is timed from the common barrier to the last worker of the point).  Reports the best
+    figure, the ``knee`` (fewest processes within 5 % of the best) and ``effective_cores`` = best / one process: what the box
+    gives this workload however many logical CPUs it lists."""
     ctx = mp.get_context('spawn')
-    barrier, queue = ctx.Barrier(n_procs), ctx.Queue()
-    procs = [ctx.Process(target=_cpu_worker, args=(r, n_procs, per_proc, size, barrier, queue)) for r in range(n_procs)]
+    points = sweep_points(n_procs)
+    barrier, queue = ctx.Barrier(n_procs + 1), ctx.Queue()
+    procs = [ctx.Process(target=_cpu_worker, args=(r, per_proc, size, points, barrier, queue, START_AFFINITY)) for r in range(n_procs)]
     for p in procs:
         p.start()
-    spans, deadline = [], time.time() + 300
-    while len(spans) < n_procs and time.time() < deadline:
-        try:
-            spans.append(queue.get(timeout=1.0))
-        except Exception:                      # queue.Empty: keep waiting while every worker is alive or done cleanly
-            if any(p.exitcode not in (None, 0) for p in procs):
+    sweep, t_begin = [], time.time()
+    try:
+        for k in points:
+            if sweep and time.time() - t_begin > budget_s:
                 break
-    for p in procs:
-        p.join(timeout=5)
-        if p.is_alive():
-            p.terminate()
-    if len(spans) < n_procs:
+            barrier.wait(timeout=300)            # every worker is prepared / done with the point before
+            spans, deadline = [], time.time() + 300
+            while len(spans) < k and time.time() < deadline:
+                try:
+                    spans.append(queue.get(timeout=1.0))
+                except Exception:              # queue.Empty: keep waiting while every worker is alive
+                    if any(p.exitcode not in (None, 0) for p in procs):
+                        break
+            if len(spans) < k:
+                break
+            dt = max(s[3] for s in spans) - min(s[2] for s in spans)
+            sweep.append({'processes': k, 'value': round(k * per_proc * size * size / dt / 1e6, 2), 'seconds': round(dt, 2)})
+    except Exception:
+        pass
+    finally:
+        try:
+            barrier.abort()                      # releases the workers still waiting for points that were not run
+        except Exception:
+            pass
+        for p in procs:
+            p.join(timeout=5)
+            if p.is_alive():
+                p.terminate()
+    if not sweep:
         return None
-    dt = max(e for _, e in spans) - min(b for b, _ in spans)
-    return {'value': n_procs * per_proc * size * size / dt / 1e6, 'unit': 'Mpixels/s', 'cores': n_procs,
-            'host_cores': os.cpu_count(),
-            'sample': f'{n_procs} single-threaded processes (one per host core) x {per_proc} images, {dt:.1f} s'}
+    best = max(sweep, key=lambda e: e['value'])
+    knee = min((e for e in sweep if e['value'] >= 0.95 * best['value']), key=lambda e: e['processes'])
+    one = sweep[0]['value']
+    out = {'value': best['value'], 'unit': 'Mpixels/s', 'cores': best['processes'], 'knee_processes': knee['processes'],
+           'effective_cores': round(best['value'] / one, 1), 'one_process_value': one, 'sweep': sweep, 'host': host_cpu_facts(),
+           'sample': f'single-threaded oracle processes x {per_proc} images each, swept over {[e["processes"] for e in sweep]} processes '
+                     f'of one pool; value = the best point ({best["processes"]} processes, {best["seconds"]} s); effective_cores = best / '
+                     f'the 1-process point: how many cores\' worth of this workload the box delivers (memory bandwidth, cgroup quota '
+                     f'and SMT siblings included), whatever os.cpu_count() says'}
+    if single_thread_value:
+        out['one_process_vs_single_thread_leg'] = round(one / single_thread_value, 3)
+    return out
 
 
 def _free_port():
@@ -244,17 +328,155 @@ def dropin_mode(args, group, rank, world, device_index, first, affinity):
     sys.stdout.flush()
 
 
+def c4_layers(_native, page_index, size=1024, n_layers=64, lh=32, lw=512):
+    """The layer list of synthetic page ``page_index``: gray background ``default_rng(i).integers(127, 256)``, 64 text-line
+    layers of 32 x 512 at seeded positions, float32 alpha with ~30 % non-zero, glyph colour (10, 20, 30) -> (make_layer records, plan for the oracle)."""
+    rng = np.random.default_rng(page_index)
+    gray = int(rng.integers(127, 256))
+    layers = [_native.make_layer((0, 0, size, size), 3, (gray, gray, gray))]
+    plan = [((0, 0, size, size), (gray, gray, gray), None)]
+    for _ in range(n_layers):
+        alpha = (rng.random((lh, lw), dtype=np.float32) * (rng.random((lh, lw)) < 0.3)).astype(np.float32)
+        box = (int(rng.integers(0, size - lh)), int(rng.integers(0, size - lw)), lh, lw)
+        layers.append(_native.make_layer(box, 3, (10, 20, 30), alpha=alpha))
+        plan.append((box, (10, 20, 30), alpha))
+    return layers, plan
+
+
+def c4_mode(args, group, rank, world, device_index, affinity):
+    """BASELINE configs[3] at N ranks: page synthesis at 1024^2, one process per GPU, pages sharded by index, no collective.
+    Leg 1 (value): the resident batch -- per rank ``--batch`` pages (default 64), each = background + 64 text-line layers composited by ONE
+    launch per batch (ChainBatch.set_layers -> vkx_fill_u8_batch_dev) and sent through the C3 chain (camera_cubic_curve + gaussian_blur +
+    color_shift + gaussion_noise from the page's numpy stream, drawn on the device) without leaving HBM; a step = one pass over the batch.
+    Leg 2 (reported beside): the reference's API -- PageAssemblerStep -> PageDistortionStep -> PageResizingStep, host objects in and out,
+    one worker per GPU with the pool's rule for its generator (SeedSequence(seed).spawn(world)[process_idx], vkit/utility/pool.py:85-88;
+    vkit/pipeline/pool.py:44-48), for ``--api-seconds`` seconds between barriers."""
+    from numpy.random import SeedSequence, default_rng
+    from vkit_amd import _native, shard
+    from vkit_amd.batch import ChainBatch
+    from vkit_amd.mechanism import distortion as D
+    from vkit_amd.mechanism.distortion_policy.geometric import camera as P_cam
+    size = 1024
+    B = args.batch if args.batch > 0 else 64
+    first, _ = shard.weak_span(B, rank)
+    ctx = _native.Context(device_index)
+    gen = P_cam.CameraCubicCurveConfigGenerator(P_cam.CameraCubicCurveConfigGeneratorConfig(), LEVEL)
+    batch = ChainBatch(ctx)
+    blank = np.zeros((size, size, 3), np.uint8)
+    states, plans = [], []
+    for j in range(B):
+        g = first + j
+        state = D.camera_cubic_curve.generate_state(gen((size, size), default_rng(g)), (size, size))
+        batch.add(blank, state, blur_sigma=BLUR_SIGMA, hue_delta=HUE_DELTA, noise_std=NOISE_STD, noise_rng=default_rng(5000 + g))
+        layers, plan = c4_layers(_native, g, size)
+        batch.set_layers(j, layers)
+        states.append(state)
+        plans.append(plan)
+
+    def sync():
+        ctx.sync()
+
+    elapsed = shard.timed_steps(group, batch.run, steps=args.steps, warmup=args.warmup, device_sync=sync)
+    pages = group.sum_int(B * args.steps)
+    # kernel times of the step (HIP events, outside the timed region)
+    ctx.set_timing(True)
+    ctx.reset_timings()
+    ksteps = max(1, min(args.steps, 10))
+    for _ in range(ksteps):
+        batch.run()
+    ctx.sync()
+    kernels = {k: round(v[0] / ksteps, 4) for k, v in sorted(ctx.timings().items())}
+    ctx.set_timing(False)
+    # parity of this very batch: the rank's first and last page against the oracle (composite layer by layer, then the chain)
+    verified = 0
+    if args.verify > 0:
+        import oracle as O
+        for j in sorted({0, B - 1}):
+            want_src = np.zeros((size, size, 3), np.uint8)
+            for box, value, alpha in plans[j]:
+                O.fill(want_src, box, value, mask=None, alpha=1.0 if alpha is None else alpha)
+            st = states[j]
+            mx, my = O.grid_to_map(st.src_image_grid.vertices, st.dst_image_grid.vertices, st.result_shape)
+            want = O.add_noise_i16(O.color_shift_rgb(O.gaussian_blur(O.remap(want_src, mx, my), 5, BLUR_SIGMA), HUE_DELTA),
+                                   _noise_plane((5000 + first + j, tuple(st.result_shape) + (3,))))
+            if not ((batch.source(j) == want_src).all() and (batch.result(j) == want).all()):
+                raise SystemExit(f'bench c4: page {first + j} differs from the oracle')
+            verified += 1
+    batch.close()
+
+    # ---- leg 2: the reference's step objects, one worker per GPU ---------------------------------------------------------------------
+    api = None
+    if args.api_seconds > 0:
+        from vkit_amd.pipeline import text_detection as T
+        from vkit_amd.pipeline.text_detection.synthetic_page import synthetic_page_input
+        os.environ['VKX_DEVICE'] = str(device_index)
+        step_input = synthetic_page_input(seed=3 + rank, size=size, n_lines=64)
+        assembler = T.page_assembler_step_factory.create()
+        distortion = T.page_distortion_step_factory.create()
+        resizing = T.page_resizing_step_factory.create()
+        rng = default_rng(SeedSequence(args.seed).spawn(world)[rank])       # the pool's process_idx -> generator rule
+
+        def page():
+            a = assembler.run(step_input, rng)
+            d = distortion.run(T.PageDistortionStepInput(a), rng)
+            r = resizing.run(T.PageResizingStepInput(d), rng)
+            return int(r.page_image.mat[0, 0, 0])
+
+        for _ in range(3):
+            page()
+        wctx = _native.default_ctx()
+        wctx.sync()
+        group.barrier()
+        t0, n, lat = time.perf_counter(), 0, []
+        while time.perf_counter() - t0 < args.api_seconds:
+            t1 = time.perf_counter()
+            page()
+            lat.append(time.perf_counter() - t1)
+            n += 1
+        wctx.sync()
+        group.barrier()
+        api_elapsed = group.max_float(time.perf_counter() - t0)
+        api_pages = group.sum_int(n)
+        lats = sorted(x for part in group.all_gather_object(lat) for x in part)
+        api = {'pages_per_s': api_pages / api_elapsed, 'pages': api_pages, 'seconds': api_elapsed, 'workers': world,
+               'latency_ms': {'mean': sum(lats) / len(lats) * 1e3, 'median': lats[len(lats) // 2] * 1e3, 'p90': lats[int(len(lats) * 0.9)] * 1e3},
+               'note': 'PageAssemblerStep -> PageDistortionStep -> PageResizingStep through the step objects, host objects in and out, ONE '
+                       'worker process per GPU (this rank); rng = default_rng(SeedSequence(seed).spawn(world)[rank]), pages drawn one '
+                       'after the other from it as PipelinePoolWorker.run does'}
+    dist_evidence = group.evidence(device_index=device_index, pci_bus_id=(affinity or {}).get('pci_bus_id'), first_page=first, pages=B)
+    group.close()
+    if rank != 0:
+        return
+    ms_per_step = elapsed / args.steps * 1e3
+    print(json.dumps({
+        'metric': 'pages/s (1024^2 page synth: 64 text layers composited + geo+photo chain)',
+        'value': pages / elapsed, 'unit': 'pages/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
+        'mpixels_per_s': pages * size * size / elapsed / 1e6,
+        'config': {'workload': f'C4 page synthesis, device resident: {B} pages of {size}x{size}x3 per GPU and step, each a gray background + 64 '
+                               f'text-line layers (32x512, float32 alpha) composited by one batched launch, then camera_cubic_curve remap (level '
+                               f'{LEVEL}) + gaussian_blur({BLUR_SIGMA}) + color_shift({HUE_DELTA}) + gaussion_noise({NOISE_STD}, numpy stream drawn on '
+                               f'the device)',
+                   'batch_per_gpu': B, 'verified_against_oracle': verified, 'affinity': affinity, 'distributed': dist_evidence,
+                   'sharding': f'{world} process(es), one per GPU, pages [rank x {B}, (rank + 1) x {B}), no collective'},
+        'kernels_ms_per_step': kernels,
+        'reference_api': api,
+    }))
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200,
                     help='timed passes over the batch (the default keeps the timed region above 2 s)')
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=256, help='images per GPU')
+    ap.add_argument('--batch', type=int, default=0, help='images (pages) per GPU; 0 = the config\'s own: 256 for c3, 64 for c4')
+    ap.add_argument('--seed', type=int, default=0, help='--config c4: rng_seed of the worker pool (SeedSequence(seed).spawn(world)[rank])')
     ap.add_argument('--size', type=int, default=2048)
     ap.add_argument('--cpu-sample', type=int, default=40, help='images timed on the CPU oracle (rank 0, N=1)')
     ap.add_argument('--cpu-procs', type=int, default=-1,
-                    help='processes of the all-cores CPU leg (-1 = one per host core, 0 = skip)')
+                    help='largest process count of the all-cores CPU sweep (-1 = one per CPU of the affinity mask, 0 = skip)')
     ap.add_argument('--verify', type=int, default=4,
                     help='images of the batch checked against the oracle (spread over the batch, the last one included)')
     ap.add_argument('--extra-legs', type=int, default=1,
@@ -277,11 +499,19 @@ def main():
                     help='resident (default, the headline): images resident in HBM.  dropin: the PCIe-inclusive curve -- every rank '
                          'sends its images through HostPipeline.submit_chain, host arrays in and host arrays out (page-locked), the '
                          'noise of every image drawn on the device from its numpy stream; never the headline value')
+    ap.add_argument('--config', default='c3', choices=('c3', 'c4'),
+                    help='c3 (default, the headline): BASELINE configs[2], the fused chain on 2048^2 images.  c4: BASELINE configs[3], page '
+                         'synthesis at 1024^2 -- per rank a resident batch of --batch pages (64 text layers composited + the chain, one launch '
+                         'each) AND the reference-API leg (PageAssemblerStep -> PageDistortionStep -> PageResizingStep, one worker per GPU, '
+                         'the pool\'s process_idx -> rng rule); value = pages/s of the resident batch over all ranks')
+    ap.add_argument('--api-seconds', type=float, default=4.0, help='--config c4: seconds of the reference-API leg per rank')
     ap.add_argument('--dry-run', action='store_true',
                     help='rendezvous, barriers and the MAX reduction of the timing protocol only, over gloo, no GPU: the N > 1 path on '
                          'a box without GPUs (tests/test_bench_launch.py)')
     ap.add_argument('--noise-workers', type=int, default=0, help='unused since round 3 (the planes are drawn on the device); kept for old command lines')
     args = ap.parse_args()
+    if args.batch <= 0:
+        args.batch = 64 if args.config == 'c4' else 256
 
     from vkit_amd import shard
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -296,10 +526,12 @@ def main():
         elapsed = shard.timed_steps(group, lambda: time.sleep(0.01 * (1 + rank)), steps=args.steps, warmup=args.warmup,
                                     device_sync=lambda: None)
         units = group.sum_int(count * args.steps)
+        dist_evidence = group.evidence(first_unit=first, units=count * args.steps)
         group.close()
         if rank == 0:
-            print(json.dumps({'dry_run': True, 'mode': args.mode, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-                              'ms_per_step': elapsed / args.steps * 1e3, 'units': units, 'first_image_of_last_rank': (world - 1) * args.batch}))
+            print(json.dumps({'dry_run': True, 'mode': args.mode, 'config': args.config, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                              'ms_per_step': elapsed / args.steps * 1e3, 'units': units, 'first_image_of_last_rank': (world - 1) * args.batch,
+                              'distributed': dist_evidence}))
             sys.stdout.flush()
         return
 
@@ -349,6 +581,8 @@ def main():
                     'numa_share': f'{pos + 1} of {sharing}' if bound and world > 1 else None}
     except Exception as exc:                    # placement is an optimisation: never a reason to fail
         affinity = {'error': repr(exc)}
+    if args.config == 'c4':
+        return c4_mode(args, group, rank, world, device_index, affinity)
     if args.mode == 'dropin':
         return dropin_mode(args, group, rank, world, device_index, first, affinity)
     ctx = _native.Context(device_index)
@@ -384,6 +618,10 @@ def main():
     elapsed = shard.timed_steps(group, batch.run, steps=args.steps, warmup=0, device_sync=full_sync)
     major_times = batch.timings()
     batch.set_timing(False)
+    # what took part: the pixels every rank really processed (SUM all-reduce, not rank 0's count x world), the backend and world size
+    # the process group reports, the PCI bus id of every rank's GPU
+    total_px = group.sum_int(batch.source_pixels * args.steps)
+    dist_evidence = group.evidence(device_index=device_index, pci_bus_id=(affinity or {}).get('pci_bus_id'), first_image=first, images=B)
     group.close()  # every rank is past the closing barrier and the MAX reduction: nothing collective is left
     breakdown_steps = max(1, min(args.steps, 20))
     kernel_times = {}
@@ -400,7 +638,7 @@ def main():
         for name, (ms, launches) in major_times.items():
             kernel_times[name] = (ms, launches, 'timed region')
 
-    state_build = None
+    state_build, lattices_ok = None, True
     if from_configs:
         cb = batch.lanes[0]
         state_build = {'host_ms_per_step': cb.state_build_s / max(cb.state_builds, 1) * 1e3, 'builds': cb.state_builds,
@@ -411,11 +649,16 @@ def main():
         # the host operator's states: CPU legs below, and how many device-built lattices equal them on THIS box
         states = [make_state(first + j, size) for j in range(B)]
         equal = 0
-        for j in sorted({0, B // 3, (2 * B) // 3, B - 1}):
+        lattice_picks = sorted({0, B // 3, (2 * B) // 3, B - 1})
+        for j in lattice_picks:
             sv, dv = cb.lattices(j)
             equal += int(np.array_equal(sv, states[j].src_image_grid.vertices) and np.array_equal(dv, states[j].dst_image_grid.vertices)
                          and tuple(states[j].result_shape) == cb._dst_shapes[j])
-        state_build['lattices_equal_host_operator'] = f'{equal} of 4 checked'
+        state_build['lattices_equal_host_operator'] = f'{equal} of {len(lattice_picks)} checked'
+        state_build['parts_ms_per_step'] = {k: round(v / max(cb.state_builds, 1) * 1e3, 3) for k, v in cb.state_parts_s.items()}
+        lattices_ok = equal == len(lattice_picks)
+        if not lattices_ok:
+            print(f'bench: WARNING: only {equal} of {len(lattice_picks)} device-built lattices equal the host operator\'s: the line is marked unverified', file=sys.stderr)
     noise_jobs = [(5000 + first + j, tuple(states[j].result_shape) + (3,)) for j in range(B)]
 
     # ---- the chain alone on noise already in HBM (r2's headline mode, planes resident), for continuity --------------------
@@ -447,7 +690,7 @@ def main():
 
     # ---- parity spot check of this very batch against the oracle (outside the timed region) -------------------------
     # the expected noise plane comes from numpy ITSELF (_noise_plane): the device-drawn samples have to equal it
-    verified = 0
+    verified, picks = 0, []
     if rank == 0 and args.verify > 0:
         import oracle as O
         picks = sorted({int(round(k * (B - 1) / max(args.verify - 1, 1))) for k in range(min(args.verify, B))} | {B - 1})
@@ -560,8 +803,7 @@ def main():
                     'position, tools/poisson_probe.py), host arrays in and out',
         }
 
-    total_px = src_px * world * args.steps
-    value = total_px / elapsed / 1e6
+    value = total_px / elapsed / 1e6         # total_px: summed over the ranks before the group closed
     ms_per_step = elapsed / args.steps * 1e3
 
     # ---- roofline: every kernel of the step, the dominant one on top --------------------------------------------------
@@ -658,7 +900,12 @@ def main():
             'sharding': f'{world} process(es), one per GPU, independent images, no collective' +
                         (f' (ranks share {n_dev} GPU(s): rendezvous over {backend})' if shared_devices else ''),
             'verified_against_oracle': verified,
+            # one flag for "this number is a checked number": every picked image equals the oracle AND (from configs) the lattices the
+            # device built equal the host operator's on this box -- a lattice regression must not hide behind pixels checked on the
+            # lattices the device itself produced
+            'verified': bool(verified == len(picks) and verified > 0 and lattices_ok),
             'affinity': affinity,
+            'distributed': dist_evidence,
             'kernel_source_digest': kernel_source_digest(),
             'setup_s': round(t_setup, 1),
         },
@@ -717,9 +964,12 @@ def main():
         result['other_configs'] = other_configs
     if world == 1:
         result['cpu_baseline'] = cpu_baseline(size, args.cpu_sample) if args.cpu_sample > 0 else None
-        n_procs = (os.cpu_count() or 1) if args.cpu_procs < 0 else args.cpu_procs
+        usable = len(START_AFFINITY) if START_AFFINITY else (os.cpu_count() or 1)
+        n_procs = usable if args.cpu_procs < 0 else args.cpu_procs
+        if result['cpu_baseline'] is not None:
+            result['cpu_baseline']['host'] = host_cpu_facts()
         if n_procs > 1 and args.cpu_sample > 0:
-            all_cores = cpu_baseline_all_cores(size, n_procs, 2)
+            all_cores = cpu_baseline_all_cores(size, n_procs, 2, result['cpu_baseline']['value'])
             if all_cores is not None:
                 result['cpu_baseline']['all_cores'] = all_cores
     else:

@@ -46,7 +46,7 @@ def test_eight_ranks_rendezvous_and_reduce():
     loopback address, one JSON line from rank 0, units summed and times maximised over all eight; the same for the PCIe-inclusive mode's
     command line (``--mode dropin``; a dry run stops before any device work)."""
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
-    for extra in ([], ['--mode', 'dropin']):
+    for extra in ([], ['--mode', 'dropin'], ['--config', 'c4']):
         out = _run(['--gpus', '8', '--dry-run', '--steps', '2', '--warmup', '1', '--batch', '3'] + extra, env)
         assert out.returncode == 0, out.stdout + out.stderr
         lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
@@ -54,4 +54,10 @@ def test_eight_ranks_rendezvous_and_reduce():
         rec = json.loads(lines[0])
         assert rec['n_gpus'] == 8 and rec['units'] == 8 * 3 * 2 and rec['first_image_of_last_rank'] == 21
         assert rec['ms_per_step'] >= 80.0                  # rank 7 sleeps 80 ms per step
-        assert rec['mode'] == (extra[1] if extra else 'resident')
+        assert rec['mode'] == (extra[1] if extra and extra[0] == '--mode' else 'resident')
+        assert rec['config'] == (extra[1] if extra and extra[0] == '--config' else 'c3')
+        # the evidence every N > 1 line carries: the backend and world size the process group itself reports, one record per rank
+        ev = rec['distributed']
+        assert ev['backend'] == 'gloo' and ev['world_size'] == 8
+        assert sorted(r['rank'] for r in ev['ranks']) == list(range(8)) and len({r['pid'] for r in ev['ranks']}) == 8
+        assert [r['first_unit'] for r in ev['ranks']] == [3 * k for k in range(8)]

@@ -17,7 +17,7 @@ import attrs
 import numpy as np
 from numpy.random import default_rng
 
-from test_gpu_composite import _synthetic_page_input
+from vkit_amd.pipeline.text_detection.synthetic_page import synthetic_page_input as _synthetic_page_input
 from vkit_amd import _native as N
 from vkit_amd.pipeline import text_detection as T
 

@@ -15,7 +15,7 @@ import numpy as np
 from numpy.random import default_rng
 
 from vkit_amd import _native as N
-from test_gpu_composite import _synthetic_page_input
+from vkit_amd.pipeline.text_detection.synthetic_page import synthetic_page_input as _synthetic_page_input
 from vkit_amd.pipeline import text_detection as T
 
 PAGES = int(sys.argv[1]) if len(sys.argv) > 1 else 48

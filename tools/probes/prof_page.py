@@ -2,7 +2,7 @@ import cProfile, pstats, io, os, sys
 ROOT='/root/repo'
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT,'tests'))
 from numpy.random import default_rng
-from test_gpu_composite import _synthetic_page_input
+from vkit_amd.pipeline.text_detection.synthetic_page import synthetic_page_input as _synthetic_page_input
 from vkit_amd.pipeline import text_detection as T
 from vkit_amd import _native as N
 step_input = _synthetic_page_input(seed=3, size=1024, n_lines=64)

@@ -54,9 +54,12 @@ class ChainBatch:
         self._cam_state = None       # _CameraStates: records, lattice sets, page-locked results
         self.state_build_s = 0.0     # host time spent in _build_states (C scalars, launch, the wait for the shapes, layout)
         self.state_builds = 0
+        self.state_parts_s = {'set_free_wait': 0.0, 'launch': 0.0, 'shape_wait': 0.0, 'layout': 0.0}   # ... and where it goes
+        self._set_events = [None, None]   # the point of the compute stream after which lattice set 0 / 1 is no longer read
         self.state_stream = _native.STREAM_COPY_OUT   # where the states are built: a side stream, ahead of the compute stream
         self._page_layers = {}       # item index -> [VkxLayer with device planes]: assembled into the source before the chain
         self._layer_tables = None
+        self.debug_kind_flags = {}   # tests: item index -> bits or-ed into its stream job's kind (VKX_NP_DEBUG_WIDE_MARGIN forces the fallback)
 
     def _put(self, array: np.ndarray) -> int:
         array = np.ascontiguousarray(array)
@@ -226,15 +229,29 @@ class ChainBatch:
         if cs is None:
             cs = self._cam_state = _DeviceStates(self.ctx, [rec for _i, rec, _s, _st in self._cam])
             cs.index = np.asarray([i for i, _r, _s, _st in self._cam], np.int64)
+            cs.position = {int(i): k for k, i in enumerate(cs.index)}
             cs.noisy = np.asarray([st is not None for _i, _r, _s, st in self._cam], bool)
         which = self._runs & 1
-        states = cs.build(self.ctx, which, self.state_stream)          # synchronises the side stream; raises like the reference
+        # the pixel kernel of run N - 2 read this set: it has to be past it before the set is rebuilt (the host may be several runs
+        # ahead of the device; with immutable configs the rewrite would store the same values, but the buffering must not lean on that)
+        if self._set_events[which] is not None:
+            self.ctx.event_wait(self._set_events[which])
+            self._set_events[which] = None
+        t1 = time.perf_counter()
+        states = cs.build(self.ctx, which, self.state_stream, self.state_parts_s)   # synchronises the side stream; raises like the reference
+        t2 = time.perf_counter()
+        self.state_parts_s['set_free_wait'] += t1 - t0
         self._ensure_array()
         view = _native.struct_view(self._array)
         idx = cs.index
         dh, dw = states['dh'].astype(np.int64), states['dw'].astype(np.int64)
         if cs.last_shapes is None or not (np.array_equal(cs.last_shapes[0], dh) and np.array_equal(cs.last_shapes[1], dw)):
-            # new shapes: destinations and tile buffers from one arena, 256-byte aligned
+            # new shapes: destinations and tile buffers from one arena, 256-byte aligned.  A stream the device declared ambiguous for
+            # the OLD shape (its item then reads an owned plane, _verify_streams) is a stream again: the verdict belongs to the sample
+            # count, and the first run on the new shapes asks the device anew
+            cs.noisy = np.asarray([st is not None for _i, _r, _s, st in self._cam], bool)
+            view['noise_tiled'][idx] = cs.noisy
+            view['noise_stride_el'][idx] = 0
             n = dh * dw * 3
             dst_bytes = (n + 255) & ~255
             tiles = (n + n // 45 + 4096 + cs.tile_draws - 1) // cs.tile_draws      # (csrc/nprand.hip np_tiles_for_n)
@@ -262,7 +279,9 @@ class ChainBatch:
         view['src_vertices'][idx], view['dst_vertices'][idx] = cs.sv_ptr[which], cs.dv_ptr[which]
         view['dst'][idx] = cs.dst_ptr
         view['noise'][idx] = cs.noise_ptr
-        self.state_build_s += time.perf_counter() - t0
+        t3 = time.perf_counter()
+        self.state_parts_s['layout'] += t3 - t2
+        self.state_build_s += t3 - t0
         self.state_builds += 1
         return states
 
@@ -351,7 +370,7 @@ class ChainBatch:
         if late:
             return _native.np_job(_native.NP_NORMAL_ADD_U8, stream, n, std, src=item.dst, dst=item.dst)
         if item.noise_tiled:
-            return _native.np_job(_native.NP_NORMAL_TILES, stream, n, std, dst=item.noise)
+            return _native.np_job(_native.NP_NORMAL_TILES | self.debug_kind_flags.get(index, 0), stream, n, std, dst=item.noise)
         return _native.np_job(_native.NP_NORMAL_I16, stream, n, std, dst=item.noise)
 
     def _build_jobs(self, entries):
@@ -404,6 +423,13 @@ class ChainBatch:
                 self._owned.append(item.noise)
                 item.noise_stride_el = int(item.dw) * 3
                 item.noise_tiled = 0
+                cs = self._cam_state
+                if cs is not None and index in cs.position:
+                    # an add_config item: _build_states rewrites item.noise from cs.noise_ptr on EVERY run -- the owned plane has
+                    # to be what it writes, and the item no longer owns tile slots of the arena
+                    k = cs.position[index]
+                    cs.noisy[k] = False
+                    cs.noise_ptr[k] = item.noise
             self.ctx.upload(item.noise, plane)
             self.stream_fallbacks += 1
         self._stream_noise = kept
@@ -459,6 +485,11 @@ class ChainBatch:
             _native.check(lib.vkx_chain_rgb_batch_dev(self.ctx.handle, self._array, len(self._items)))
         if self._stream_noise and self._late_jobs:
             self._launch(self._late_jobs)
+        if self._cam:            # the lattice set this run read is free once the compute stream is past this point
+            which = (self._runs - 1) & 1
+            if self._set_events[which] is not None:
+                self.ctx.event_wait(self._set_events[which])
+            self._set_events[which] = self.ctx.event_record(_native.STREAM_COMPUTE)
         if first and self._verify_streams():
             self._runs -= 1
             self.run(draw_streams=True)
@@ -545,8 +576,9 @@ class _DeviceStates:
                 self._ptr_c[(which, kind)] = ((ctypes.c_void_p * len(pos))(*[int(self.sv_ptr[which][k]) for k in pos]),
                                               (ctypes.c_void_p * len(pos))(*[int(self.dv_ptr[which][k]) for k in pos]))
 
-    def build(self, ctx, which, stream):
+    def build(self, ctx, which, stream, parts=None):
         lib = _native.lib()
+        t0 = time.perf_counter()
         first = 0
         size = ctypes.sizeof(_native.VkxGridState)
         for kind, fn in (('camera', lib.vkx_camera_states_dev), ('mls', lib.vkx_mls_states_dev)):
@@ -556,7 +588,11 @@ class _DeviceStates:
             sv, dv = self._ptr_c[(which, kind)]
             _native.check(fn(ctx.handle, recs, len(pos), sv, dv, ctypes.c_void_p(self._out_ptr + first * size), int(stream)))
             first += len(pos)
+        t1 = time.perf_counter()
         ctx.sync_stream(stream)
+        if parts is not None:
+            parts['launch'] += t1 - t0
+            parts['shape_wait'] += time.perf_counter() - t1
         states = self.states[self.order]          # in batch order
         flags = states['flags']
         if flags.any():

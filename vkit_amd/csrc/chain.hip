@@ -39,6 +39,8 @@ VKX_EXPORT int vkx_chain_rgb_batch_dev(vkx_ctx *ctx, const vkx_chain_item *items
         const int frc = vkx_chain_fused_try(ctx, items, n_items);
         if (frc != VKX_ERR_UNSUPPORTED) return frc;
     }
+    // the staged kernels run on the compute stream: lattices marked ready on another stream (vkx_camera_states_dev) first
+    if (int mrc = vkx_chain_consume_lattices_mark(ctx)) return mrc;
     for (int k = 0; k < 2; k++) {
         int rc = vkx_scratch_reserve(ctx, &ctx->chain[k], max_plane);
         if (rc) return rc;
@@ -160,6 +162,7 @@ VKX_EXPORT int vkx_chain_rgb_batch_np_dev(vkx_ctx *ctx, const vkx_chain_item *it
         if (rc && rc != VKX_ERR_UNSUPPORTED) return rc;
     }
     if (!raw) {       // shapes the fused path does not take, other job kinds: one call after the other
+        if ((rc = vkx_chain_consume_lattices_mark(ctx))) return rc;
         if ((rc = vkx_np_draw_batch_dev(ctx, jobs, n_jobs, results_host))) return rc;
         return vkx_chain_rgb_batch_dev(ctx, items, n_items);
     }
@@ -183,49 +186,64 @@ VKX_EXPORT int vkx_chain_rgb_batch_np_dev(vkx_ctx *ctx, const vkx_chain_item *it
 
     vkx_device_guard guard(ctx);
     hipStream_t main_stream = ctx->stream;
-    hipStream_t aux = vkx_stream_by_id(ctx, VKX_STREAM_COPY_IN, &rc);
-    if (rc) return rc;
-    hipStream_t side = vkx_stream_by_id(ctx, VKX_STREAM_COPY_OUT, &rc);
-    if (rc) return rc;
-    // what the caller queued before this call (the sources may be its product)
-    hipEvent_t entry = nullptr;
-    if (overlap) {
-        VKX_HIP(hipEventCreateWithFlags(&entry, hipEventDisableTiming));
-        hipError_t e = hipEventRecord(entry, main_stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(side, entry, 0);
-        (void)hipEventDestroy(entry);       // (deferred until the event has completed)
-        VKX_HIP(e);
-    }
-    // side stream: the cell setup of the whole batch (the compute stream is ordered after it by the call)
-    hipEvent_t setup_done = nullptr;
-    if ((rc = vkx_chain_plan_setup_aside(ctx, raw, &setup_done))) return rc;
-    if (setup_done) VKX_HIP(hipStreamWaitEvent(aux, setup_done, 0));     // the noise row records read the descriptors the prologue copies
-    for (int c = 0; c < n_chunks; c++) {
-        Chunk &ch = chunks[c];
-        // the scratch slot's previous tenant (chunk c - 2) must have been posted before its tile arrays are overwritten
-        if (c >= 2) VKX_HIP(hipStreamWaitEvent(main_stream, chunks[c - 2].posted, 0));
-        if ((rc = vkx_np_chunk_begin(ctx, jobs + ch.job0, ch.njobs, results_host + ch.job0, c & 1, &ch.np))) return rc;
-        if ((rc = vkx_stream_order(ctx, aux, main_stream))) return rc;
-        ctx->stream = aux;
-        rc = vkx_np_chunk_finish(ctx, ch.np);
-        if (!rc) rc = vkx_chain_plan_noise_rows(ctx, raw, ch.item0, ch.nitems);
-        ctx->stream = main_stream;
+    // The three-stream schedule.  Every exit of it -- a failing chunk included -- leaves the context with ctx->stream == main_stream and
+    // main_stream ordered after whatever reached aux / side: a caller that goes on using the context after an error cannot race the
+    // kernels this call left in flight (tests/test_gpu_chain_errors.py).
+    const char *fail_env = getenv("VKX_DEBUG_FAIL_CHUNK");      // read per call: tests set and clear it around one call
+    const int fail_chunk = fail_env && fail_env[0] ? atoi(fail_env) : -1;
+    auto schedule = [&]() -> int {
+        int rc = VKX_OK;
+        hipStream_t aux = vkx_stream_by_id(ctx, VKX_STREAM_COPY_IN, &rc);
         if (rc) return rc;
-        VKX_HIP(hipEventCreateWithFlags(&ch.posted, hipEventDisableTiming));
-        VKX_HIP(hipEventRecord(ch.posted, aux));
-    }
-    // VKX_CHAIN_OVERLAP=1: the pixel kernels on the side stream, so that pixels(c) shares the device with draw(c + 1 ..)
-    hipStream_t pix = overlap ? side : main_stream;
-    if (setup_done && pix != side) VKX_HIP(hipStreamWaitEvent(pix, setup_done, 0));
-    for (int c = 0; c < n_chunks; c++) {
-        Chunk &ch = chunks[c];
-        VKX_HIP(hipStreamWaitEvent(pix, ch.posted, 0));
-        ctx->stream = pix;
-        rc = vkx_chain_plan_tiles(ctx, raw, ch.item0, ch.nitems);
-        ctx->stream = main_stream;
+        hipStream_t side = vkx_stream_by_id(ctx, VKX_STREAM_COPY_OUT, &rc);
         if (rc) return rc;
-    }
-    if ((rc = vkx_chain_mark_done(ctx, pix))) return rc;
-    if (pix != main_stream && (rc = vkx_stream_order(ctx, main_stream, pix))) return rc;
-    return VKX_OK;
+        // what the caller queued before this call (the sources may be its product)
+        hipEvent_t entry = nullptr;
+        if (overlap) {
+            VKX_HIP(hipEventCreateWithFlags(&entry, hipEventDisableTiming));
+            hipError_t e = hipEventRecord(entry, main_stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(side, entry, 0);
+            (void)hipEventDestroy(entry);       // (deferred until the event has completed)
+            VKX_HIP(e);
+        }
+        // side stream: the cell setup of the whole batch (the compute stream is ordered after it by the call)
+        hipEvent_t setup_done = nullptr;
+        if ((rc = vkx_chain_plan_setup_aside(ctx, raw, &setup_done))) return rc;
+        if (setup_done) VKX_HIP(hipStreamWaitEvent(aux, setup_done, 0));     // the noise row records read the descriptors the prologue copies
+        for (int c = 0; c < n_chunks; c++) {
+            Chunk &ch = chunks[c];
+            // the scratch slot's previous tenant (chunk c - 2) must have been posted before its tile arrays are overwritten
+            if (c >= 2) VKX_HIP(hipStreamWaitEvent(main_stream, chunks[c - 2].posted, 0));
+            if ((rc = vkx_np_chunk_begin(ctx, jobs + ch.job0, ch.njobs, results_host + ch.job0, c & 1, &ch.np))) return rc;
+            if ((rc = vkx_stream_order(ctx, aux, main_stream))) return rc;
+            ctx->stream = aux;
+            rc = vkx_np_chunk_finish(ctx, ch.np);
+            if (!rc) rc = vkx_chain_plan_noise_rows(ctx, raw, ch.item0, ch.nitems);
+            ctx->stream = main_stream;
+            if (rc) return rc;
+            VKX_HIP(hipEventCreateWithFlags(&ch.posted, hipEventDisableTiming));
+            VKX_HIP(hipEventRecord(ch.posted, aux));
+            if (c == fail_chunk) {       // fault injection (tests): a failure with draw(c) in flight on the compute stream and post(c) on aux
+                vkx_set_error("injected failure in chunk %d (VKX_DEBUG_FAIL_CHUNK)", c);
+                return VKX_ERR_INVALID;
+            }
+        }
+        // VKX_CHAIN_OVERLAP=1: the pixel kernels on the side stream, so that pixels(c) shares the device with draw(c + 1 ..)
+        hipStream_t pix = overlap ? side : main_stream;
+        if (setup_done && pix != side) VKX_HIP(hipStreamWaitEvent(pix, setup_done, 0));
+        for (int c = 0; c < n_chunks; c++) {
+            Chunk &ch = chunks[c];
+            VKX_HIP(hipStreamWaitEvent(pix, ch.posted, 0));
+            ctx->stream = pix;
+            rc = vkx_chain_plan_tiles(ctx, raw, ch.item0, ch.nitems);
+            ctx->stream = main_stream;
+            if (rc) return rc;
+        }
+        if ((rc = vkx_chain_mark_done(ctx, pix))) return rc;
+        if (pix != main_stream && (rc = vkx_stream_order(ctx, main_stream, pix))) return rc;
+        return VKX_OK;
+    };
+    rc = schedule();
+    if (rc) vkx_ctx_join_streams(ctx, main_stream);
+    return rc;
 }

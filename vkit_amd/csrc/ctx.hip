@@ -227,13 +227,26 @@ VKX_EXPORT int vkx_memset(vkx_ctx *ctx, void *dptr, int value, size_t bytes)
 }
 
 // ---- pinned host memory, copy streams, ordering --------------------------------------------------------------------
+// Everything queued on ANY stream of the context has run: the ring's readers are not only on the compute stream (k_chain_prologue
+// reads the mapped ring on the side stream at execution time; vkx_camera_states_dev / vkx_mls_states_dev copy from it on a
+// stream of the caller's choice).
+static int ring_quiesce(vkx_ctx *ctx)
+{
+    VKX_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->own_stream != ctx->stream) VKX_HIP(hipStreamSynchronize(ctx->own_stream));
+    for (hipStream_t s : ctx->copy_stream)
+        if (s && s != ctx->stream) VKX_HIP(hipStreamSynchronize(s));
+    return VKX_OK;
+}
+
 int vkx_desc_ring_take(vkx_ctx *ctx, size_t bytes, void **hptr)
 {
     bytes = (bytes + 255) & ~(size_t)255;
     if (bytes > ctx->desc_cap) {
         // (re)allocate: nothing queued may still read the old ring
         vkx_device_guard guard(ctx);
-        VKX_HIP(hipStreamSynchronize(ctx->stream));
+        int qrc = ring_quiesce(ctx);
+        if (qrc) return qrc;
         if (ctx->desc_ring) VKX_HIP(hipHostFree(ctx->desc_ring));
         ctx->desc_ring = nullptr;
         const size_t cap = bytes * 4 > ((size_t)4 << 20) ? bytes * 4 : ((size_t)4 << 20);
@@ -244,7 +257,8 @@ int vkx_desc_ring_take(vkx_ctx *ctx, size_t bytes, void **hptr)
     if (ctx->desc_off + bytes > ctx->desc_cap) {
         // wrap around: the copies queued from the ring so far must have been issued to the device
         vkx_device_guard guard(ctx);
-        VKX_HIP(hipStreamSynchronize(ctx->stream));
+        int qrc = ring_quiesce(ctx);
+        if (qrc) return qrc;
         ctx->desc_off = 0;
     }
     *hptr = ctx->desc_ring + ctx->desc_off;
@@ -421,6 +435,35 @@ int vkx_stream_order(vkx_ctx *ctx, hipStream_t later, hipStream_t earlier)
     VKX_HIP(hipEventRecord(e, earlier));
     VKX_HIP(hipStreamWaitEvent(later, e, 0));
     ctx->order_events.push_back(e);
+    return VKX_OK;
+}
+
+// Error exits of the calls that spread their work over the context's side streams: `main_stream` continues after everything
+// queued on the side streams so far and is the context's launch stream again, so that the next call on the context cannot race
+// the kernels the failed call left in flight.  Never touches the message of the failure being reported (no vkx_set_error here).
+void vkx_ctx_join_streams(vkx_ctx *ctx, hipStream_t main_stream)
+{
+    vkx_device_guard guard(ctx);
+    ctx->stream = main_stream;
+    for (hipStream_t s : ctx->copy_stream) {
+        if (!s || s == main_stream) continue;
+        hipEvent_t e = take_order_event(ctx);
+        if (!e || hipEventRecord(e, s) != hipSuccess || hipStreamWaitEvent(main_stream, e, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(s);       // no event to order them with: wait on the host
+        }
+        if (e) ctx->order_events.push_back(e);
+    }
+}
+
+// The staged paths run on the compute stream: a pending lattices-ready mark (lattices built on another stream) is consumed
+// there, so that it neither goes unheeded nor outlives the lattices it spoke of.
+int vkx_chain_consume_lattices_mark(vkx_ctx *ctx)
+{
+    if (!ctx->lattices_armed) return VKX_OK;
+    vkx_device_guard guard(ctx);
+    VKX_HIP(hipStreamWaitEvent(ctx->stream, ctx->lattices_ready, 0));
+    ctx->lattices_armed = false;
     return VKX_OK;
 }
 

@@ -1457,13 +1457,20 @@ int vkx_chain_fused_try(vkx_ctx *ctx, const vkx_chain_item *items, int n_items)
     int rc = vkx_chain_plan_build(ctx, items, n_items, &raw);
     if (rc || !raw) return rc;
     std::unique_ptr<vkx_chain_plan, void (*)(vkx_chain_plan *)> plan(raw, vkx_chain_plan_free);
-    hipEvent_t setup_done = nullptr;
-    if ((rc = vkx_chain_plan_setup_aside(ctx, raw, &setup_done))) return rc;
-    if (setup_done) VKX_HIP(hipStreamWaitEvent(ctx->stream, setup_done, 0));      // (the device copy of the descriptors is the prologue's)
-    if ((rc = vkx_chain_plan_noise_rows(ctx, raw, 0, n_items))) return rc;
-    if ((rc = vkx_chain_plan_tiles(ctx, raw, 0, n_items))) return rc;
-    vkx_device_guard guard(ctx);
-    return vkx_chain_mark_done(ctx, ctx->stream);
+    hipStream_t main_stream = ctx->stream;
+    auto schedule = [&]() -> int {
+        int rc;
+        hipEvent_t setup_done = nullptr;
+        if ((rc = vkx_chain_plan_setup_aside(ctx, raw, &setup_done))) return rc;
+        if (setup_done) VKX_HIP(hipStreamWaitEvent(ctx->stream, setup_done, 0));      // (the device copy of the descriptors is the prologue's)
+        if ((rc = vkx_chain_plan_noise_rows(ctx, raw, 0, n_items))) return rc;
+        if ((rc = vkx_chain_plan_tiles(ctx, raw, 0, n_items))) return rc;
+        vkx_device_guard guard(ctx);
+        return vkx_chain_mark_done(ctx, ctx->stream);
+    };
+    rc = schedule();
+    if (rc) vkx_ctx_join_streams(ctx, main_stream);     // a setup left on the side stream must not race the caller's next call
+    return rc;
 }
 
 // vkx_grid_remap through the tile kernel; VKX_ERR_UNSUPPORTED (no error set) for shapes it does not take.

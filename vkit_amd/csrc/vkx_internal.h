@@ -143,6 +143,8 @@ int vkx_small_to_device(vkx_ctx *ctx, void *dev, const void *ring_host, size_t b
 int vkx_small_to_host(vkx_ctx *ctx, void *host, const void *dev, size_t bytes);
 hipStream_t vkx_stream_by_id(vkx_ctx *ctx, int id, int *rc);
 int vkx_stream_order(vkx_ctx *ctx, hipStream_t later, hipStream_t earlier);
+void vkx_ctx_join_streams(vkx_ctx *ctx, hipStream_t main_stream);   // error exits of multi-stream calls: main after the side streams, ctx->stream = main
+int vkx_chain_consume_lattices_mark(vkx_ctx *ctx);                   // staged chain paths: the compute stream waits for a pending lattices-ready mark
 // out[i] = next_double of the PCG64 stream (state, inc) at its (i + 1)-th step (poisson.hip); asynchronous on the ctx stream
 int vkx_pcg64_doubles_dev(vkx_ctx *ctx, const uint64_t *state, const uint64_t *inc, long long M, double *out);
 

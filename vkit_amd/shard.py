@@ -149,6 +149,28 @@ class Group:
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
         return int(t.item())
 
+    def all_gather_object(self, obj):
+        """One picklable object per rank, in rank order, on every rank."""
+        if self._dist is None:
+            return [obj]
+        out = [None] * self.world
+        self._dist.all_gather_object(out, obj)
+        return out
+
+    def evidence(self, **mine):
+        """What a reader of an N > 1 result line needs to see that N ranks on N devices took part: the backend the process group
+        reports, its world size, and one record per rank (rank, local rank, host, pid + whatever the caller adds, e.g. the PCI bus id
+        of its GPU), all-gathered.  A plain launch reports itself as a world of one."""
+        import socket
+        rec = dict(rank=self.rank, local_rank=self.local_rank, host=socket.gethostname(), pid=os.getpid(), **mine)
+        ranks = self.all_gather_object(rec)
+        out = {'backend': self._dist.get_backend() if self._dist is not None else None,
+               'world_size': self._dist.get_world_size() if self._dist is not None else 1, 'ranks': ranks}
+        ids = [r.get('pci_bus_id') for r in ranks if r.get('pci_bus_id')]
+        if ids:
+            out['distinct_devices'] = len({(r['host'], r['pci_bus_id']) for r in ranks if r.get('pci_bus_id')})
+        return out
+
     def close(self):
         if self._dist is not None:
             self._dist.destroy_process_group()
