@@ -641,11 +641,18 @@ def main():
     state_build, lattices_ok = None, True
     if from_configs:
         cb = batch.lanes[0]
-        state_build = {'host_ms_per_step': cb.state_build_s / max(cb.state_builds, 1) * 1e3, 'builds': cb.state_builds,
-                       'note': 'host time of ChainBatch._build_states per step, INSIDE the timed region: 256 x vkx_camera_model_host '
-                               '(C), one k_camera_states launch on the side stream, the wait for the result shapes, whole-array layout '
-                               'of destinations / tile buffers / stream jobs; it runs while the compute stream still executes the '
-                               'previous step'}
+        nb = max(cb.state_builds, 1)
+        parts = {k: v / nb * 1e3 for k, v in cb.state_parts_s.items()}
+        state_build = {'host_ms_per_step': parts['launch'] + parts['layout'], 'builds': cb.state_builds,
+                       'wait_ms_per_step': {'lattice_set_free': parts['set_free_wait'], 'result_shapes': parts['shape_wait']},
+                       'total_ms_per_step_in_build_states': cb.state_build_s / nb * 1e3,
+                       'note': 'ChainBatch._build_states per step, INSIDE the timed region.  host_ms_per_step = the host WORK: 256 x '
+                               'vkx_camera_model_host (C) + one k_camera_states launch on the side stream (launch) and the whole-array layout of '
+                               'destinations / tile buffers / stream jobs (layout).  wait_ms_per_step = time the host is BLOCKED: '
+                               'lattice_set_free = until the pixel kernel of step N - 2 has released the lattice set this step rebuilds (the host '
+                               'runs ahead of the device and is held here: this is the device\'s step time showing through, not host work -- '
+                               'rounds 5\'s "13.35 ms of Python / ctypes" was this wait, then inside the result_shapes sync), result_shapes = '
+                               'until k_camera_states has delivered the shapes'}
         # the host operator's states: CPU legs below, and how many device-built lattices equal them on THIS box
         states = [make_state(first + j, size) for j in range(B)]
         equal = 0
@@ -655,7 +662,6 @@ def main():
             equal += int(np.array_equal(sv, states[j].src_image_grid.vertices) and np.array_equal(dv, states[j].dst_image_grid.vertices)
                          and tuple(states[j].result_shape) == cb._dst_shapes[j])
         state_build['lattices_equal_host_operator'] = f'{equal} of {len(lattice_picks)} checked'
-        state_build['parts_ms_per_step'] = {k: round(v / max(cb.state_builds, 1) * 1e3, 3) for k, v in cb.state_parts_s.items()}
         lattices_ok = equal == len(lattice_picks)
         if not lattices_ok:
             print(f'bench: WARNING: only {equal} of {len(lattice_picks)} device-built lattices equal the host operator\'s: the line is marked unverified', file=sys.stderr)

@@ -343,7 +343,13 @@ int vkx_fill_u8_dev(vkx_ctx *ctx, uint8_t *dst, int h, int w, int cn, ptrdiff_t 
 int vkx_fill_u8(vkx_ctx *ctx, uint8_t *dst, int h, int w, int cn, ptrdiff_t dst_stride,
                 const vkx_layer *layers, int n_layers);
 /* device page, HOST layer planes (page_assembler.py:155-236 onto a device-resident page): the planes are staged for the
- * call, the page stays where it is; asynchronous */
+ * call -- gathered in the context's page-locked ring and read THERE by the composite kernel (every plane byte is read once: no
+ * copy to device memory, no copy dispatch) --, the page stays where it is; asynchronous.  A plane whose VKX_LAYER_*_ON_DEVICE bit
+ * is or-ed into `mode` already lives in device memory and is used where it is (fill_page_inactive_region: a device mask selects,
+ * the host bottom layer is the value). */
+#define VKX_LAYER_MASK_ON_DEVICE 0x100
+#define VKX_LAYER_ALPHA_ON_DEVICE 0x200
+#define VKX_LAYER_VALUE_ON_DEVICE 0x400
 int vkx_fill_u8_dev_host_layers(vkx_ctx *ctx, uint8_t *dst_dev, int h, int w, int cn, ptrdiff_t dst_stride,
                                 const vkx_layer *layers_host_planes, int n_layers);
 /* The layer lists of n_pages equally shaped device destinations in ONE launch (a batch of pages assembled together,
@@ -491,6 +497,12 @@ int vkx_paint_polys_dev(vkx_ctx *ctx, const int32_t *pts_host, const int32_t *po
 int vkx_paint_polys(vkx_ctx *ctx, const int32_t *pts_host, const int32_t *poly_offsets_host, int n_polys,
                     const float *values_host, uint8_t *mask, ptrdiff_t mask_stride, float *score,
                     ptrdiff_t score_stride_el, int h, int w);
+/* The same paint into FRESH planes: mask / score are uninitialised device memory and every pixel of them is written (mask = 0 /
+ * score = 0 outside every polygon) -- what the label rasterisation needs (it starts from np.zeros planes, page_distortion.py:201,
+ * :283) without a memset dispatch per plane. */
+int vkx_paint_polys_fresh_dev(vkx_ctx *ctx, const int32_t *pts_host, const int32_t *poly_offsets_host, int n_polys,
+                              const float *values_host, uint8_t *mask, ptrdiff_t mask_stride, float *score,
+                              ptrdiff_t score_stride_el, int h, int w);
 
 /* ---- the numpy Generator streams of the noise operators, drawn on the device -------------------------------------
  * photometric/noise.py:44-54 (gaussion_noise), :160-190 (speckle_noise), :100-157 (impulse_noise) draw from the

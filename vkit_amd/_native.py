@@ -295,6 +295,7 @@ for _sfx in ('', '_dev'):
     _SIGNATURES['vkx_ellipse_mask_u8' + _sfx] = [c_void_p, c_void_p, c_ssize, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int]
     _SIGNATURES['vkx_ellipse_streak_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_double]
 
+_SIGNATURES['vkx_paint_polys_fresh_dev'] = _SIGNATURES['vkx_paint_polys_dev']
 _SIGNATURES['vkx_fill_u8_dev_host_layers'] = [c_void_p] + _PLANE_U8 + [ctypes.POINTER(VkxLayer), c_int]
 _SIGNATURES['vkx_fill_u8_batch_dev'] = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_ssize, ctypes.POINTER(VkxLayer), c_void_p]
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['vkx_version', 'vkx_last_error', 'vkx_ctx_stream'])
@@ -1792,7 +1793,7 @@ def resize_cubic(src, dsize_hw, ctx=None):
     return dst
 
 
-def _paint(flat, offsets, n, values, mask, score, ctx):
+def _paint(flat, offsets, n, values, mask, score, ctx, fresh=False):
     plane = mask if mask is not None else score
     if plane is None:
         raise ValueError('mask or score is required')
@@ -1823,30 +1824,33 @@ def _paint(flat, offsets, n, values, mask, score, ctx):
             raise ValueError('one value per polygon is required with a score plane')
     pm = (c_void_p(mask.ptr) if dev else _ptr(mask)) if mask is not None else None
     ps = (c_void_p(score.ptr) if dev else _ptr(score)) if score is not None else None
-    fn = lib().vkx_paint_polys_dev if dev else lib().vkx_paint_polys
+    if fresh and not dev:
+        raise ValueError('fresh planes are device planes (host planes are painted in place)')
+    fn = (lib().vkx_paint_polys_fresh_dev if fresh else lib().vkx_paint_polys_dev) if dev else lib().vkx_paint_polys
     check(fn(ctx.handle, _ptr(flat), _ptr(offsets), n, _ptr(vals) if vals is not None else None, pm, w, ps, w, h, w))
     for arr in (mask, score):
         if dev and arr is not None:
             arr.invalidate_host()
 
 
-def paint_polys(polygons, values=None, mask=None, score=None, ctx=None):
+def paint_polys(polygons, values=None, mask=None, score=None, ctx=None, fresh=False):
     """Ordered paint of ``polygons`` (sequence of int (N_i, 2) arrays of (x, y) in plane coordinates) into the
     writable uint8 ``mask`` and / or float32 ``score`` planes (numpy arrays or DevArrays), in place: later polygons win on
-    overlaps."""
+    overlaps.  ``fresh=True`` (DevArrays only): the planes are uninitialised and every pixel of them is written (0 outside every
+    polygon)."""
     pts = [np.asarray(p, dtype=np.int32).reshape(-1, 2) for p in polygons]
     offsets = np.zeros(len(pts) + 1, np.int32)
     if pts:
         offsets[1:] = np.cumsum([len(p) for p in pts])
     flat = np.ascontiguousarray(np.concatenate(pts, axis=0)) if pts else np.zeros((0, 2), np.int32)
-    _paint(flat, offsets, len(pts), values, mask, score, ctx)
+    _paint(flat, offsets, len(pts), values, mask, score, ctx, fresh)
 
 
-def paint_polys_flat(points_xy, offsets, values=None, mask=None, score=None, ctx=None):
+def paint_polys_flat(points_xy, offsets, values=None, mask=None, score=None, ctx=None, fresh=False):
     """``paint_polys`` for polygons that already are one int (N, 2) vertex array + (P + 1) offsets (element/soup.py)."""
     flat = np.ascontiguousarray(points_xy, dtype=np.int32).reshape(-1, 2)
     offsets = np.ascontiguousarray(offsets, dtype=np.int32)
-    _paint(flat, offsets, offsets.shape[0] - 1, values, mask, score, ctx)
+    _paint(flat, offsets, offsets.shape[0] - 1, values, mask, score, ctx, fresh)
 
 
 def dev_zeros(shape, dtype=np.uint8, ctx=None):
@@ -1860,6 +1864,7 @@ def dev_zeros(shape, dtype=np.uint8, ctx=None):
 
 _F32 = np.dtype(np.float32)
 _U8 = np.dtype(np.uint8)
+LAYER_MASK_ON_DEVICE, LAYER_ALPHA_ON_DEVICE, LAYER_VALUE_ON_DEVICE = 0x100, 0x200, 0x400      # include/vkx.h VKX_LAYER_*_ON_DEVICE
 
 
 def _plane(plane, dtype):
@@ -1937,12 +1942,19 @@ def fill(dst, layers, ctx=None):
     cls = VkxLayerF32 if is_f32 else VkxLayer
     arr = (cls * max(len(layers), 1))()
     keep = []
-    if dev and not is_f32 and not any(isinstance(plane, DevArray) for _, planes in layers for plane in planes):
-        # every plane on the host: staged by the library in one transfer, the page stays on the device
+    if dev and not is_f32:
+        # host planes are staged by the library (read in place from its page-locked ring: no copy, no synchronisation), planes that
+        # already are DevArrays are used where they are (their bit in ``mode`` says so); the page stays on the device
         for i, (layer, planes) in enumerate(layers):
             if not isinstance(layer, cls):
                 raise TypeError('layer built for another destination dtype')
             arr[i] = layer
+            for plane in planes:
+                if isinstance(plane, DevArray):
+                    keep.append(plane)
+                    for field, bit in (('mask', LAYER_MASK_ON_DEVICE), ('alpha', LAYER_ALPHA_ON_DEVICE), ('value', LAYER_VALUE_ON_DEVICE)):
+                        if getattr(layer, field) == plane.ptr:
+                            arr[i].mode |= bit
         check(lib().vkx_fill_u8_dev_host_layers(ctx.handle, c_void_p(dst.ptr), h, w, cn, w * cn, arr, len(layers)))
         dst.invalidate_host()
         return dst

@@ -423,20 +423,25 @@ int composite_launch(vkx_ctx *ctx, T *dst, int h, int w, ptrdiff_t dstride, cons
     const size_t o0 = 0, o1 = o0 + up(sizeof(LayerDev<T>) * devl.size()), o2 = o1 + up(sizeof(int) * tile_ids.size());
     const size_t o3 = o2 + up(sizeof(int) * tile_begin.size()), o4 = o3 + up(sizeof(int) * tile_layers.size());
     const size_t bytes = o4 + up(sizeof(T *) * (pages ? (size_t)n_pages : 0));
-    int rc = vkx_scratch_reserve(ctx, &ctx->misc, bytes);
-    if (rc) return rc;
-    unsigned char *base = (unsigned char *)ctx->misc.ptr;
-    // the tables travel as ONE copy out of the ctx's page-locked descriptor ring: the launch returns without a stream
-    // synchronisation (a page assembler issues one such call per page)
+    // the tables travel through the ctx's page-locked descriptor ring: the launch returns without a stream synchronisation (a page
+    // assembler issues one such call per page).  One destination (a page of the operator API): the kernel reads them in the ring, in
+    // place -- a few records per tile, one dispatch less per page; a batch of pages (ChainBatch.set_layers: tens of thousands of
+    // tiles) gets them as ONE copy into device memory
     void *ring = nullptr;
-    if ((rc = vkx_desc_ring_take(ctx, bytes, &ring))) return rc;
+    int rc = vkx_desc_ring_take(ctx, bytes, &ring);
+    if (rc) return rc;
     unsigned char *stage = (unsigned char *)ring;
     memcpy(stage + o0, devl.data(), sizeof(LayerDev<T>) * devl.size());
     memcpy(stage + o1, tile_ids.data(), sizeof(int) * tile_ids.size());
     memcpy(stage + o2, tile_begin.data(), sizeof(int) * tile_begin.size());
     memcpy(stage + o3, tile_layers.data(), sizeof(int) * tile_layers.size());
     if (pages) memcpy(stage + o4, pages, sizeof(T *) * (size_t)n_pages);
-    VKX_HIP(hipMemcpyAsync(base, stage, bytes, hipMemcpyHostToDevice, ctx->stream));
+    unsigned char *base = pages ? nullptr : (unsigned char *)const_cast<void *>(vkx_ring_device_ptr(stage));
+    if (!base) {
+        if ((rc = vkx_scratch_reserve(ctx, &ctx->misc, bytes))) return rc;
+        base = (unsigned char *)ctx->misc.ptr;
+        VKX_HIP(hipMemcpyAsync(base, stage, bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
     if (composite_rgb_groups<T, CN>(ctx, dst, dstride, h, w, base, o0, o1, o2, o3, o4, tile_ids.size(), tiles_x, pages, n_pages, tiles_pp))
         return VKX_OK;
     { VKX_TIMED(ctx, "k_composite");

@@ -70,6 +70,7 @@ VKX_EXPORT int vkx_ctx_destroy(vkx_ctx *ctx)
     for (auto &st : ctx->copy_stream)
         if (st) (void)hipStreamSynchronize(st);
     scratch_release(&ctx->owner);
+    scratch_release(&ctx->paint_owner);
     scratch_release(&ctx->cells);
     scratch_release(&ctx->misc);
     scratch_release(&ctx->tables);
@@ -264,6 +265,21 @@ int vkx_desc_ring_take(vkx_ctx *ctx, size_t bytes, void **hptr)
     *hptr = ctx->desc_ring + ctx->desc_off;
     ctx->desc_off += bytes;
     return VKX_OK;
+}
+
+// The device-side address of a block of the page-locked ring (the ring is mapped: a kernel reads it in place, over the link).
+// For tables a kernel reads ONCE -- a 768-byte LUT staged to LDS per workgroup, an edge table, a layer plane that every pixel touches
+// once -- reading the ring in place costs the link what the copy would have cost it, and saves the copy's dispatch: with several
+// worker processes on one GPU every dispatch costs ~16 us of the device's serial budget whatever its size (profiles/r6b_pool_trace_w8.json),
+// and a C4 page issued 44 runtime copy kernels of 98 dispatches (profiles/r6a_page_dispatches.txt).  nullptr when the mapping fails.
+const void *vkx_ring_device_ptr(const void *ring_host)
+{
+    void *mapped = nullptr;
+    if (hipHostGetDevicePointer(&mapped, const_cast<void *>(ring_host), 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return mapped;
 }
 
 namespace {

@@ -15,6 +15,7 @@
 #include "vkx_cell.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -189,7 +190,7 @@ __global__ void __launch_bounds__(64) k_project_points(const int32_t *__restrict
     if (px % grid_size != 0 && (px < 0) != (grid_size < 0)) c--;
     if (r < 0 || c < 0 || r >= rows - 1 || c >= cols - 1) {      // the reference indexes out of its cell table here
         if (writer) {
-            atomicExch(bad, i + 1);
+            *(volatile int *)bad = i + 1;      // any offending index serves (plain store: the flag may live in mapped host memory)
             out[2 * i] = 0.0; out[2 * i + 1] = 0.0;
         }
         return;
@@ -227,7 +228,33 @@ VKX_EXPORT int vkx_grid_project_points(vkx_ctx *ctx, const int32_t *src_vertices
     const size_t ibytes = sizeof(int32_t) * 2 * (size_t)n, dbytes = sizeof(double) * 2 * (size_t)n;
     const size_t off_dv = (vbytes + 255) & ~(size_t)255, off_pi = off_dv * 2, off_ps = off_pi + ((ibytes + 255) & ~(size_t)255);
     const size_t off_out = off_ps + ((dbytes + 255) & ~(size_t)255), off_bad = off_out + ((dbytes + 255) & ~(size_t)255);
-    int rc = vkx_scratch_reserve(ctx, &ctx->stage[0], off_bad + 256);
+    // Everything the kernel reads, and what it writes, in ONE block of the page-locked (mapped) ring: the lattices and the points are
+    // read once, the results are read by the host right after -- the kernel works on the host block in place and the call is one
+    // dispatch (it was four copies in, a memset, the kernel and two copies out: 5 - 7 dispatches of a page's 98).  The flag is a plain
+    // store (any offending index serves; atomics on host memory need PCIe atomics).
+    void *ring = nullptr;
+    int rc = off_bad + 256 <= ((size_t)8 << 20) ? vkx_desc_ring_take(ctx, off_bad + 256, &ring) : VKX_ERR_UNSUPPORTED;
+    const uint8_t *mapped = rc == VKX_OK ? (const uint8_t *)vkx_ring_device_ptr(ring) : nullptr;
+    if (mapped) {
+        uint8_t *host = (uint8_t *)ring;
+        memcpy(host, src_vertices_host, vbytes);
+        memcpy(host + off_dv, dst_vertices_host, vbytes);
+        memcpy(host + off_pi, pts_xy_host, ibytes);
+        memcpy(host + off_ps, pts_smooth_xy_host, dbytes);
+        *(volatile int *)(host + off_bad) = 0;
+        vkx_device_guard guard(ctx);
+        { VKX_TIMED(ctx, "k_project_points"); k_project_points<<<vkx_blocks((size_t)n * 8, 64), 64, 0, ctx->stream>>>((const int32_t *)mapped, (const int32_t *)(mapped + off_dv), rows, cols, grid_size, (const int32_t *)(mapped + off_pi), (const double *)(mapped + off_ps), n, (double *)(mapped + off_out), (int *)(mapped + off_bad)); }
+        VKX_LAUNCH_CHECK();
+        VKX_HIP(hipStreamSynchronize(ctx->stream));
+        const int bad = *(volatile int *)(host + off_bad);
+        if (bad) {
+            vkx_set_error("point %d lies outside the lattice cells", bad - 1);
+            return VKX_ERR_OUT_OF_LATTICE;
+        }
+        memcpy(out_xy_host, host + off_out, dbytes);
+        return VKX_OK;
+    }
+    rc = vkx_scratch_reserve(ctx, &ctx->stage[0], off_bad + 256);
     if (rc) return rc;
     uint8_t *base = (uint8_t *)ctx->stage[0].ptr;
     VKX_HIP(hipMemcpyAsync(base, src_vertices_host, vbytes, hipMemcpyHostToDevice, ctx->stream));

@@ -2,6 +2,7 @@
 // implementation on the ctx stream, copy the results back and synchronise.  Nothing here computes pixels.
 #include "vkx_internal.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -73,6 +74,30 @@ public:
         }
         VKX_HIP(flush());
         return VKX_OK;
+    }
+
+    // Input planes that the kernel reads ONCE (the layers of a composite: every pixel of a plane is touched by one lane): gathered in
+    // the page-locked ring and read there, in place, over the link -- no copy to device memory at all.  The link carries each byte
+    // once either way; what goes is the copy's dispatches (a C4 page staged 13 MB of layer planes with 9 runtime copy kernels) and,
+    // for pageable sources, the runtime's own staging pass.  false: too large for the ring or not mappable (use commit()).
+    bool commit_mapped()
+    {
+        if (total_ == 0 || total_ > ((size_t)48 << 20)) return false;
+        for (auto &p : planes_)
+            if (p.out) return false;             // outputs need device memory + finish()
+        void *r = nullptr;
+        if (vkx_desc_ring_take(ctx_, total_, &r) != VKX_OK) return false;
+        uint8_t *mapped = (uint8_t *)const_cast<void *>(vkx_ring_device_ptr(r));
+        if (!mapped) return false;
+        uint8_t *ring = (uint8_t *)r;
+        for (auto &p : planes_) {
+            if (!p.in || p.row_bytes == 0 || p.rows <= 0) continue;
+            if ((size_t)p.pitch == p.row_bytes || p.rows == 1) memcpy(ring + p.off, p.in, p.row_bytes * (size_t)p.rows);
+            else
+                for (int row = 0; row < p.rows; row++) memcpy(ring + p.off + (size_t)row * p.row_bytes, (const uint8_t *)p.in + (ptrdiff_t)row * p.pitch, p.row_bytes);
+        }
+        base_ = mapped;
+        return true;
     }
 
     template <class T> T *dev(int id) const { return id < 0 ? nullptr : (T *)(base_ + planes_[id].off); }
@@ -355,22 +380,22 @@ VKX_EXPORT int vkx_fill_u8_dev_host_layers(vkx_ctx *ctx, uint8_t *dst_dev, int h
     VKX_REQUIRE(n_layers >= 0 && (n_layers == 0 || layers), "bad layer list");
     HostStage st(ctx);
     std::vector<int> mid(n_layers, -1), aid(n_layers, -1), vid(n_layers, -1);
+    constexpr int kOnDevice = VKX_LAYER_MASK_ON_DEVICE | VKX_LAYER_ALPHA_ON_DEVICE | VKX_LAYER_VALUE_ON_DEVICE;
     for (int i = 0; i < n_layers; i++) {
         const vkx_layer &l = layers[i];
         VKX_REQUIRE(l.height >= 0 && l.width >= 0, "bad layer box");
-        if (l.mask) mid[i] = st.add(l.mask, nullptr, (size_t)l.width, l.height, l.mask_stride);
-        if (l.alpha) aid[i] = st.add(l.alpha, nullptr, (size_t)l.width * 4, l.height, l.alpha_stride_el * 4);
-        if (l.value) vid[i] = st.add(l.value, nullptr, (size_t)l.width * cn, l.height, l.value_stride);
+        if (l.mask && !(l.mode & VKX_LAYER_MASK_ON_DEVICE)) mid[i] = st.add(l.mask, nullptr, (size_t)l.width, l.height, l.mask_stride);
+        if (l.alpha && !(l.mode & VKX_LAYER_ALPHA_ON_DEVICE)) aid[i] = st.add(l.alpha, nullptr, (size_t)l.width * 4, l.height, l.alpha_stride_el * 4);
+        if (l.value && !(l.mode & VKX_LAYER_VALUE_ON_DEVICE)) vid[i] = st.add(l.value, nullptr, (size_t)l.width * cn, l.height, l.value_stride);
     }
-    VKX_TRY(st.commit());
+    static const bool no_map = [] { const char *e = getenv("VKX_LAYERS_MAPPED"); return e && e[0] == '0'; }();
+    if (no_map || !st.commit_mapped()) VKX_TRY(st.commit());
     std::vector<vkx_layer> dl(layers, layers + n_layers);
     for (int i = 0; i < n_layers; i++) {
-        dl[i].mask = st.dev<uint8_t>(mid[i]);
-        dl[i].mask_stride = layers[i].width;
-        dl[i].alpha = st.dev<float>(aid[i]);
-        dl[i].alpha_stride_el = layers[i].width;
-        dl[i].value = st.dev<uint8_t>(vid[i]);
-        dl[i].value_stride = (ptrdiff_t)layers[i].width * cn;
+        if (mid[i] >= 0) { dl[i].mask = st.dev<uint8_t>(mid[i]); dl[i].mask_stride = layers[i].width; }
+        if (aid[i] >= 0) { dl[i].alpha = st.dev<float>(aid[i]); dl[i].alpha_stride_el = layers[i].width; }
+        if (vid[i] >= 0) { dl[i].value = st.dev<uint8_t>(vid[i]); dl[i].value_stride = (ptrdiff_t)layers[i].width * cn; }
+        dl[i].mode &= ~kOnDevice;
     }
     return vkx_fill_u8_dev(ctx, dst_dev, h, w, cn, dst_stride, dl.data(), n_layers);
 }

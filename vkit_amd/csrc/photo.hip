@@ -789,9 +789,10 @@ __global__ void __launch_bounds__(256) k_pointwise16(const uint8_t *__restrict__
 __global__ void __launch_bounds__(256) k_apply_lut16(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, size_t n, int cn,
                                                      const uint8_t *__restrict__ lut /* [cn][256] */, unsigned chmask)
 {
-    __shared__ uint8_t table[4 * 256];
-    for (int i = threadIdx.x; i < cn * 256; i += 256) table[i] = lut[i];
+    __shared__ uint32_t table_w[256];       // the table may sit in mapped host memory: whole dwords, one round trip per workgroup
+    if ((int)threadIdx.x < cn * 64) table_w[threadIdx.x] = ((const uint32_t *)lut)[threadIdx.x];
     __syncthreads();
+    const uint8_t *table = (const uint8_t *)table_w;
     map_bytes16(src, dst, n, cn, [&](int v, int c, int) {
         return (chmask == 0 || ((chmask >> c) & 1u)) ? (int)table[c * 256 + v] : v;
     });
@@ -1339,22 +1340,29 @@ VKX_EXPORT int vkx_apply_lut_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int
     VKX_REQUIRE(lut_host != nullptr, "NULL table");
     VKX_REQUIRE(cn >= 1 && cn <= 4, "1..4 channels");
     if (h == 0 || w == 0) return VKX_OK;
-    rc = vkx_scratch_reserve(ctx, &ctx->misc, 1024);
-    if (rc) return rc;
-    // the table is the caller's memory: it travels through the page-locked descriptor ring, no stream synchronisation
+    // the table is the caller's memory: it travels through the page-locked descriptor ring, no stream synchronisation.  The dense
+    // kernel stages it to LDS once per workgroup straight from the (mapped) ring: no copy, one dispatch per call instead of two
+    // (PageResizingStep binarises seven planes per page through this entry)
     void *staged = nullptr;
     rc = vkx_desc_ring_take(ctx, (size_t)256 * cn, &staged);
     if (rc) return rc;
     memcpy(staged, lut_host, (size_t)256 * cn);
-    VKX_HIP(hipMemcpyAsync(ctx->misc.ptr, staged, (size_t)256 * cn, hipMemcpyHostToDevice, ctx->stream));
-    if (dense16(src, src_stride, dst, dst_stride, (size_t)w * cn, h)) {
+    const uint8_t *table = (const uint8_t *)vkx_ring_device_ptr(staged);
+    const bool dense = dense16(src, src_stride, dst, dst_stride, (size_t)w * cn, h);
+    if (!table || !dense) {          // the strided kernel reads the table per pixel: from device memory
+        rc = vkx_scratch_reserve(ctx, &ctx->misc, 1024);
+        if (rc) return rc;
+        VKX_HIP(hipMemcpyAsync(ctx->misc.ptr, staged, (size_t)256 * cn, hipMemcpyHostToDevice, ctx->stream));
+        table = (const uint8_t *)ctx->misc.ptr;
+    }
+    if (dense) {
         const size_t n = (size_t)h * w * cn;
-        { VKX_TIMED(ctx, "k_apply_lut"); k_apply_lut16<<<vkx_blocks((n + 15) / 16, 256), 256, 0, ctx->stream>>>(src, dst, n, cn, (const uint8_t *)ctx->misc.ptr, channel_mask); }
+        { VKX_TIMED(ctx, "k_apply_lut"); k_apply_lut16<<<vkx_blocks((n + 15) / 16, 256), 256, 0, ctx->stream>>>(src, dst, n, cn, table, channel_mask); }
         VKX_LAUNCH_CHECK();
         return VKX_OK;
     }
     dim3 block(64, 4), grid(vkx_blocks((size_t)w * cn, 64), vkx_blocks(h, 4));
-    { VKX_TIMED(ctx, "k_apply_lut"); k_apply_lut<<<grid, block, 0, ctx->stream>>>(src, h, w, cn, src_stride, dst, dst_stride, (const uint8_t *)ctx->misc.ptr, channel_mask); }
+    { VKX_TIMED(ctx, "k_apply_lut"); k_apply_lut<<<grid, block, 0, ctx->stream>>>(src, h, w, cn, src_stride, dst, dst_stride, table, channel_mask); }
     VKX_LAUNCH_CHECK();
     return VKX_OK;
 }

@@ -194,7 +194,11 @@ __global__ void __launch_bounds__(256) k_paint_spans(const PolyEdge *__restrict_
     }
 }
 
-__global__ void __launch_bounds__(256) k_paint_resolve(const int *__restrict__ owner, const float *__restrict__ values,
+// FRESH: the output planes are uninitialised memory -- every pixel is written (0 outside every polygon), so the caller needs no
+// memset of its own.  Either way the owner word is cleared as it is read: the raster is all zero again when the kernel is done and
+// the next call needs no memset either (a page paints four label plane sets: 3 - 4 fill dispatches per call were 14 of its 98).
+template <bool FRESH>
+__global__ void __launch_bounds__(256) k_paint_resolve(int *__restrict__ owner, const float *__restrict__ values,
                                                        uint8_t *__restrict__ mask, ptrdiff_t mask_stride,
                                                        float *__restrict__ score, ptrdiff_t score_stride, int h, int w)
 {
@@ -202,22 +206,37 @@ __global__ void __launch_bounds__(256) k_paint_resolve(const int *__restrict__ o
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
     const int o = owner[(size_t)y * w + x];
-    if (o <= 0) return;
+    if (o <= 0) {
+        if (o < 0) owner[(size_t)y * w + x] = 0;
+        if (FRESH) {
+            if (mask) mask[(ptrdiff_t)y * mask_stride + x] = 0;
+            if (score) score[(ptrdiff_t)y * score_stride + x] = 0.0f;
+        }
+        return;
+    }
+    owner[(size_t)y * w + x] = 0;
     if (mask) mask[(ptrdiff_t)y * mask_stride + x] = 1;
     if (score) score[(ptrdiff_t)y * score_stride + x] = values[o - 1];
 }
 
 } // namespace
 
-VKX_EXPORT int vkx_paint_polys_dev(vkx_ctx *ctx, const int32_t *pts_host, const int32_t *poly_offsets_host, int n_polys,
-                                   const float *values_host, uint8_t *mask, ptrdiff_t mask_stride, float *score,
-                                   ptrdiff_t score_stride_el, int h, int w)
+static int paint_polys_dev(vkx_ctx *ctx, const int32_t *pts_host, const int32_t *poly_offsets_host, int n_polys,
+                           const float *values_host, uint8_t *mask, ptrdiff_t mask_stride, float *score,
+                           ptrdiff_t score_stride_el, int h, int w, bool fresh)
 {
     VKX_REQUIRE(ctx && (n_polys == 0 || (pts_host && poly_offsets_host)), "NULL argument");
     VKX_REQUIRE(n_polys >= 0 && h > 0 && w > 0, "bad shape");
     VKX_REQUIRE(mask || score, "no output plane");
-    VKX_REQUIRE(!score || values_host, "score output needs per-polygon values");
-    if (n_polys == 0) return VKX_OK;
+    VKX_REQUIRE(!score || values_host || n_polys == 0, "score output needs per-polygon values");
+    if (n_polys == 0) {
+        if (fresh) {          // nothing to paint: the planes are zero
+            vkx_device_guard guard(ctx);
+            if (mask) VKX_HIP(hipMemset2DAsync(mask, (size_t)mask_stride, 0, (size_t)w, (size_t)h, ctx->stream));
+            if (score) VKX_HIP(hipMemset2DAsync(score, (size_t)score_stride_el * 4, 0, (size_t)w * 4, (size_t)h, ctx->stream));
+        }
+        return VKX_OK;
+    }
     const int total_pts = poly_offsets_host[n_polys];
     VKX_REQUIRE(total_pts >= 0, "bad polygon offsets");
     std::vector<PolyEdge> edges((size_t)total_pts);
@@ -237,14 +256,17 @@ VKX_EXPORT int vkx_paint_polys_dev(vkx_ctx *ctx, const int32_t *pts_host, const 
     const size_t vbytes = ((size_t)n_polys * 4 + 255) & ~(size_t)255;
     int rc = vkx_scratch_reserve(ctx, &ctx->misc, 256 + ebytes + ibytes + vbytes);
     if (rc) return rc;
-    rc = vkx_scratch_reserve(ctx, &ctx->owner, (size_t)h * w * 4);
+    // the ownership raster is the paint's own block: zero at rest (k_paint_resolve clears what it reads), memset only when it grows
+    const size_t owner_bytes = (size_t)h * w * 4;
+    if (owner_bytes > ctx->paint_owner.cap) ctx->paint_owner_zeroed = 0;
+    rc = vkx_scratch_reserve(ctx, &ctx->paint_owner, owner_bytes);
     if (rc) return rc;
     unsigned char *misc = (unsigned char *)ctx->misc.ptr;
     int *overflow = (int *)misc;
     PolyEdge *d_edges = (PolyEdge *)(misc + 256);
     PaintItem *d_items = (PaintItem *)(misc + 256 + ebytes);
     float *d_values = (float *)(misc + 256 + ebytes + ibytes);
-    int *owner = (int *)ctx->owner.ptr;
+    int *owner = (int *)ctx->paint_owner.ptr;
     // The edge / item / value tables travel through the context's page-locked ring as ONE asynchronous copy: the call returns
     // with its kernels queued (a page paints four label planes: two stream synchronisations and a flag read-back per call were
     // 0.45 ms of a 2.2 ms page).  A polygon of at most kPaintCross vertices cannot cross a scanline more often than the span
@@ -258,8 +280,9 @@ VKX_EXPORT int vkx_paint_polys_dev(vkx_ctx *ctx, const int32_t *pts_host, const 
     if (!items.empty()) memcpy((unsigned char *)ring + ebytes, items.data(), sizeof(PaintItem) * items.size());
     if (values_host) memcpy((unsigned char *)ring + ebytes + ibytes, values_host, (size_t)n_polys * 4);
     vkx_device_guard guard(ctx);
-    VKX_HIP(hipMemsetAsync(overflow, 0, sizeof(int), ctx->stream));
-    VKX_HIP(hipMemsetAsync(owner, 0, (size_t)h * w * 4, ctx->stream));
+    if (may_overflow) VKX_HIP(hipMemsetAsync(overflow, 0, sizeof(int), ctx->stream));      // (only such calls can set it, and only they read it)
+    if (ctx->paint_owner_zeroed < owner_bytes) VKX_HIP(hipMemsetAsync(owner, 0, ctx->paint_owner.cap, ctx->stream));
+    ctx->paint_owner_zeroed = 0;          // dirty until the resolve kernel of THIS call has been queued (an error exit in between re-zeroes next time)
     VKX_HIP(hipMemcpyAsync(d_edges, ring, table_bytes, hipMemcpyHostToDevice, ctx->stream));
     if (steps > 0) {
         { VKX_TIMED(ctx, "k_paint_outline"); k_paint_outline<<<vkx_blocks((size_t)steps, 256), 256, 0, ctx->stream>>>(d_edges, total_pts, (int)steps, owner, h, w); }
@@ -271,8 +294,11 @@ VKX_EXPORT int vkx_paint_polys_dev(vkx_ctx *ctx, const int32_t *pts_host, const 
     }
     {
         dim3 grid(vkx_blocks(w, 64), vkx_blocks(h, 4));
-        { VKX_TIMED(ctx, "k_paint_resolve"); k_paint_resolve<<<grid, 256, 0, ctx->stream>>>(owner, values_host ? d_values : nullptr, mask, mask_stride, score, score_stride_el, h, w); }
+        VKX_TIMED(ctx, "k_paint_resolve");
+        if (fresh) k_paint_resolve<true><<<grid, 256, 0, ctx->stream>>>(owner, values_host ? d_values : nullptr, mask, mask_stride, score, score_stride_el, h, w);
+        else k_paint_resolve<false><<<grid, 256, 0, ctx->stream>>>(owner, values_host ? d_values : nullptr, mask, mask_stride, score, score_stride_el, h, w);
         VKX_LAUNCH_CHECK();
+        ctx->paint_owner_zeroed = ctx->paint_owner.cap;
     }
     if (!may_overflow) return VKX_OK;
     int flag = 0;
@@ -283,6 +309,20 @@ VKX_EXPORT int vkx_paint_polys_dev(vkx_ctx *ctx, const int32_t *pts_host, const 
         return VKX_ERR_UNSUPPORTED;
     }
     return VKX_OK;
+}
+
+VKX_EXPORT int vkx_paint_polys_dev(vkx_ctx *ctx, const int32_t *pts_host, const int32_t *poly_offsets_host, int n_polys,
+                                   const float *values_host, uint8_t *mask, ptrdiff_t mask_stride, float *score,
+                                   ptrdiff_t score_stride_el, int h, int w)
+{
+    return paint_polys_dev(ctx, pts_host, poly_offsets_host, n_polys, values_host, mask, mask_stride, score, score_stride_el, h, w, false);
+}
+
+VKX_EXPORT int vkx_paint_polys_fresh_dev(vkx_ctx *ctx, const int32_t *pts_host, const int32_t *poly_offsets_host, int n_polys,
+                                         const float *values_host, uint8_t *mask, ptrdiff_t mask_stride, float *score,
+                                         ptrdiff_t score_stride_el, int h, int w)
+{
+    return paint_polys_dev(ctx, pts_host, poly_offsets_host, n_polys, values_host, mask, mask_stride, score, score_stride_el, h, w, true);
 }
 
 // Host planes: mask / score are updated in place (read, painted, written back).

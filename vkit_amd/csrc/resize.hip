@@ -14,6 +14,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <utility>
 
 namespace {
@@ -571,11 +572,15 @@ int cached_tables(vkx_ctx *ctx, const int key[6], Build build, std::vector<const
         slot->key[0] = -1;
         int rc = vkx_scratch_reserve(ctx, &slot->buf, total ? total : 256);
         if (rc) return rc;
-        for (size_t i = 0; i < arrays.size(); i++)
-            if (arrays[i].second)
-                VKX_HIP(hipMemcpyAsync((unsigned char *)slot->buf.ptr + slot->off[i], arrays[i].first, arrays[i].second,
-                                       hipMemcpyHostToDevice, ctx->stream));
-        VKX_HIP(hipStreamSynchronize(ctx->stream));
+        // the tables travel as ONE copy out of the page-locked ring (which keeps them alive): no copy per table, no stream
+        // synchronisation per cache miss -- every page resizes to a geometry of its own
+        if (total) {
+            void *ring = nullptr;
+            if ((rc = vkx_desc_ring_take(ctx, total, &ring))) return rc;
+            for (size_t i = 0; i < arrays.size(); i++)
+                if (arrays[i].second) memcpy((unsigned char *)ring + slot->off[i], arrays[i].first, arrays[i].second);
+            VKX_HIP(hipMemcpyAsync(slot->buf.ptr, ring, total, hipMemcpyHostToDevice, ctx->stream));
+        }
         slot->yofs.swap(m);
         std::copy(key, key + 6, slot->key);
     }
@@ -910,14 +915,18 @@ int resize_tables(vkx_ctx *ctx, int taps, bool fixed, int sh, int sw, int dh, in
         slot->key[0] = -1;                        // invalid until the upload below has succeeded
         int rc = vkx_scratch_reserve(ctx, &slot->buf, slot->off[3] + up(csz * taps * dh));
         if (rc) return rc;
-        unsigned char *base = (unsigned char *)slot->buf.ptr;
-        VKX_HIP(hipMemcpyAsync(base + slot->off[0], xo.data(), sizeof(int) * dw, hipMemcpyHostToDevice, ctx->stream));
-        VKX_HIP(hipMemcpyAsync(base + slot->off[2], yo.data(), sizeof(int) * dh, hipMemcpyHostToDevice, ctx->stream));
         const void *xsrc = fixed ? (const void *)xi.data() : (const void *)xc.data();
         const void *ysrc = fixed ? (const void *)yi.data() : (const void *)yc.data();
-        VKX_HIP(hipMemcpyAsync(base + slot->off[1], xsrc, csz * taps * dw, hipMemcpyHostToDevice, ctx->stream));
-        VKX_HIP(hipMemcpyAsync(base + slot->off[3], ysrc, csz * taps * dh, hipMemcpyHostToDevice, ctx->stream));
-        VKX_HIP(hipStreamSynchronize(ctx->stream)); // the host tables live on this frame
+        // one copy out of the page-locked ring for the four tables (the ring keeps them alive: no synchronisation)
+        const size_t total = slot->off[3] + up(csz * taps * dh);
+        void *ring = nullptr;
+        if ((rc = vkx_desc_ring_take(ctx, total, &ring))) return rc;
+        unsigned char *stage = (unsigned char *)ring;
+        memcpy(stage + slot->off[0], xo.data(), sizeof(int) * dw);
+        memcpy(stage + slot->off[2], yo.data(), sizeof(int) * dh);
+        memcpy(stage + slot->off[1], xsrc, csz * taps * dw);
+        memcpy(stage + slot->off[3], ysrc, csz * taps * dh);
+        VKX_HIP(hipMemcpyAsync(slot->buf.ptr, stage, total, hipMemcpyHostToDevice, ctx->stream));
         slot->yofs.swap(yo);
         std::copy(key, key + 6, slot->key);
     }
@@ -1061,14 +1070,18 @@ VKX_EXPORT int vkx_resize_u8_dev(vkx_ctx *ctx, const uint8_t *src, int sh, int s
     build_linear_axis(sh, dh, false, &yo, &yb);
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o0 = 0, o1 = o0 + up(sizeof(int) * dw), o2 = o1 + up(sizeof(short) * 2 * dw), o3 = o2 + up(sizeof(int) * dh);
-    int rc = vkx_scratch_reserve(ctx, &ctx->misc, o3 + up(sizeof(short) * 2 * dh));
+    const size_t total = o3 + up(sizeof(short) * 2 * dh);
+    int rc = vkx_scratch_reserve(ctx, &ctx->misc, total);
     if (rc) return rc;
     unsigned char *base = (unsigned char *)ctx->misc.ptr;
-    VKX_HIP(hipMemcpyAsync(base + o0, xo.data(), sizeof(int) * dw, hipMemcpyHostToDevice, ctx->stream));
-    VKX_HIP(hipMemcpyAsync(base + o1, xa.data(), sizeof(short) * 2 * dw, hipMemcpyHostToDevice, ctx->stream));
-    VKX_HIP(hipMemcpyAsync(base + o2, yo.data(), sizeof(int) * dh, hipMemcpyHostToDevice, ctx->stream));
-    VKX_HIP(hipMemcpyAsync(base + o3, yb.data(), sizeof(short) * 2 * dh, hipMemcpyHostToDevice, ctx->stream));
-    VKX_HIP(hipStreamSynchronize(ctx->stream));
+    void *ring = nullptr;
+    if ((rc = vkx_desc_ring_take(ctx, total, &ring))) return rc;      // one copy for the four tables, no synchronisation
+    unsigned char *stage = (unsigned char *)ring;
+    memcpy(stage + o0, xo.data(), sizeof(int) * dw);
+    memcpy(stage + o1, xa.data(), sizeof(short) * 2 * dw);
+    memcpy(stage + o2, yo.data(), sizeof(int) * dh);
+    memcpy(stage + o3, yb.data(), sizeof(short) * 2 * dh);
+    VKX_HIP(hipMemcpyAsync(base, stage, total, hipMemcpyHostToDevice, ctx->stream));
     const int *dxo = (const int *)(base + o0), *dyo = (const int *)(base + o2);
     const short *dxa = (const short *)(base + o1), *dyb = (const short *)(base + o3);
     VKX_TIMED(ctx, "k_resize_linear");

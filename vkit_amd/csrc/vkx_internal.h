@@ -51,6 +51,8 @@ struct vkx_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     vkx_scratch owner;    // int32 [dh, dw]
+    vkx_scratch paint_owner;          // the ownership raster of vkx_paint_polys*_dev: all zero between calls (the resolve kernel clears what it reads)
+    size_t paint_owner_zeroed = 0;    // ... bytes of it known to be zero
     vkx_scratch cells;    // CellRec [n_cells]
     vkx_scratch misc;     // small parameter blocks (layers, element descriptors)
     vkx_scratch tables;   // constant lookup tables (HSV division LUTs), uploaded once
@@ -142,6 +144,7 @@ int vkx_desc_ring_take(vkx_ctx *ctx, size_t bytes, void **hptr);
 int vkx_small_to_device(vkx_ctx *ctx, void *dev, const void *ring_host, size_t bytes);
 int vkx_small_to_host(vkx_ctx *ctx, void *host, const void *dev, size_t bytes);
 hipStream_t vkx_stream_by_id(vkx_ctx *ctx, int id, int *rc);
+const void *vkx_ring_device_ptr(const void *ring_host);              // a ring block as kernels address it (mapped host memory), or nullptr
 int vkx_stream_order(vkx_ctx *ctx, hipStream_t later, hipStream_t earlier);
 void vkx_ctx_join_streams(vkx_ctx *ctx, hipStream_t main_stream);   // error exits of multi-stream calls: main after the side streams, ctx->stream = main
 int vkx_chain_consume_lattices_mark(vkx_ctx *ctx);                   // staged chain paths: the compute stream waits for a pending lattices-ready mark

@@ -264,10 +264,16 @@ class PageAssemblerStep(PipelineStep[PageAssemblerStepConfig, PageAssemblerStepI
         labels = input.page_text_line_label_step_output
 
         assert background_image.mat.shape == (page_layout.height, page_layout.width, 3)
-        # the page is assembled on the device: the upload of the background is the copy the reference makes, the layers'
-        # planes are staged once, and the steps that follow (page distortion, resizing) take the page where it is --
-        # ``.mat`` downloads it on first touch
-        assembled_image = attrs.evolve(background_image, mat=_native.default_ctx().to_device(background_image.mat))
+        # the page is assembled on the device: the background (the copy the reference makes, page_assembler.py:143) is the FIRST layer of the
+        # one composite launch -- a plain full-page copy, read in place from the page-locked ring like every other layer plane, so the
+        # page needs no upload of its own (a synchronous 3 MB copy: three runtime dispatches and a stream synchronisation per page) --
+        # and the steps that follow (page distortion, resizing) take the page where it is: ``.mat`` downloads it on first touch
+        ctx = _native.default_ctx()
+        background_mat = background_image.mat
+        as_layer = (isinstance(background_mat, np.ndarray) and background_mat.dtype == np.uint8 and background_mat.ndim == 3
+                    and background_image.box is None)
+        assembled_image = attrs.evolve(background_image, mat=ctx.dev_empty(background_mat.shape, np.uint8) if as_layer
+                                       else ctx.to_device(background_mat))
 
         # Seal impressions are rotated first (device warps, independent of the page); their layers are recorded
         # last, so the composite order is untouched.
@@ -294,6 +300,9 @@ class PageAssemblerStep(PipelineStep[PageAssemblerStepConfig, PageAssemblerStepI
                 polygon.to_shifted_polygon(offset_y=up, offset_x=left) for polygon in (rotated.polygons or ()))
 
         with deferred_fill(assembled_image.arr):
+            if as_layer:
+                Box(up=0, down=assembled_image.height - 1, left=0, right=assembled_image.width - 1).fill_image(
+                    assembled_image, background_mat, alpha=1.0)
             for page_image in page_image_collection.page_images:
                 page_image.box.fill_image(assembled_image, page_image.image, alpha=page_image.alpha)
             for score_map in barcodes.barcode_qr_score_maps:

@@ -116,8 +116,14 @@ def paint_polygons(shape: Tuple[int, int], polygons: Sequence[Polygon], values: 
     """Sequential ``polygon.fill_mask(mask)`` / ``polygon.fill_score_map(score_map, value)`` over ``polygons`` on
     fresh planes, as one ordered device paint.  Returns (Mask | None, ScoreMap | None)."""
     height, width = shape
-    if _native.resident_mode():
-        # the planes are painted where the page lives and stay there until somebody reads ``.mat``
+    resident = _native.resident_mode()
+    if resident and len(polygons):
+        # the planes are painted where the page lives and stay there until somebody reads ``.mat``; the paint writes every pixel of
+        # them (0 outside every polygon): no memset per plane
+        ctx = _native.default_ctx()
+        np_mask = ctx.dev_empty((height, width), np.uint8) if want_mask else None
+        np_score = ctx.dev_empty((height, width), np.float32) if values is not None else None
+    elif resident:
         np_mask = _native.dev_zeros((height, width), np.uint8) if want_mask else None
         np_score = _native.dev_zeros((height, width), np.float32) if values is not None else None
     else:
@@ -128,9 +134,9 @@ def paint_polygons(shape: Tuple[int, int], polygons: Sequence[Polygon], values: 
         # element/polygon.py:105-138,70-77): shifting them back by the integer box origin gives the integer vertices
         # themselves, so the polygons go to the device as they are (no per-polygon box / relative-polygon objects)
         if isinstance(polygons, PolygonSoup):
-            _native.paint_polys_flat(polygons.int_xy, polygons.offsets, values=values, mask=np_mask, score=np_score)
+            _native.paint_polys_flat(polygons.int_xy, polygons.offsets, values=values, mask=np_mask, score=np_score, fresh=resident)
         else:
-            _native.paint_polys([polygon.to_np_array() for polygon in polygons], values=values, mask=np_mask, score=np_score)
+            _native.paint_polys([polygon.to_np_array() for polygon in polygons], values=values, mask=np_mask, score=np_score, fresh=resident)
     mask = Mask(mat=np_mask) if want_mask else None
     score_map = ScoreMap(mat=np_score, is_prob=False) if values is not None else None
     return mask, score_map
@@ -190,8 +196,9 @@ class PageDistortionStep(PipelineStep[PageDistortionStepConfig, PageDistortionSt
             # the same fill where the page lives: inverted mask (a table look-up) selects, the bottom layer is the value
             ctx = page_image.arr.ctx
             inverted = ctx.to_device(page_active_mask.to_inverted_mask().arr)
+            # (a bottom layer still on the host is read by the fill where it is: staged in the library's page-locked ring, no upload)
             layer = _native.make_layer((0, 0, page_image.height, page_image.width), page_image.arr.shape[2],
-                                       ctx.to_device(page_bottom_layer_image.arr), mask=inverted)
+                                       page_bottom_layer_image.arr, mask=inverted)
             _native.fill(page_image.arr, [layer])
             return
         page_active_mask.to_inverted_mask().fill_image(page_image, page_bottom_layer_image)
@@ -263,12 +270,23 @@ class PageDistortionStep(PipelineStep[PageDistortionStepConfig, PageDistortionSt
         page_random_distortion_debug = RandomDistortionDebug() if self.config.enable_debug_random_distortion else None
 
         # 1-px border off: mitigates cv.remap's border interpolation (reference :357-364)
-        page_active_mask = Mask.from_shapable(page.image, value=1)
-        with page_active_mask.writable_context:
-            page_active_mask.mat[0] = 0
-            page_active_mask.mat[-1] = 0
-            page_active_mask.mat[:, 0] = 0
-            page_active_mask.mat[:, -1] = 0
+        height, width = page.image.shape
+        if page.image.on_device and height >= 3 and width >= 3:
+            # the same mask painted where the page lives (one launch: ones, then the four border strips) instead of a host plane
+            # that the first geometric operator would have to upload
+            ctx = page.image.arr.ctx
+            plane = ctx.dev_empty((height, width), np.uint8)
+            _native.fill(plane, [_native.make_layer(box, 1, value) for box, value in (
+                ((0, 0, height, width), 1), ((0, 0, 1, width), 0), ((height - 1, 0, 1, width), 0), ((0, 0, height, 1), 0),
+                ((0, width - 1, height, 1), 0))])
+            page_active_mask = Mask(mat=plane)
+        else:
+            page_active_mask = Mask.from_shapable(page.image, value=1)
+            with page_active_mask.writable_context:
+                page_active_mask.mat[0] = 0
+                page_active_mask.mat[-1] = 0
+                page_active_mask.mat[:, 0] = 0
+                page_active_mask.mat[:, -1] = 0
 
         # everything from here to the end of the step stays on the device (element ``.mat`` downloads on first touch):
         # the operators of the chain hand DevArrays to each other, the inactive-region fill and the label paint run where
