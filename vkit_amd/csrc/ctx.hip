@@ -41,6 +41,14 @@ VKX_EXPORT int vkx_ctx_create(int device, vkx_ctx **out)
         return VKX_ERR_INVALID;
     }
     VKX_HIP(hipSetDevice(device));
+    // VKX_SYNC=block | yield: how a host thread waits for the device (hipDeviceScheduleBlockingSync / hipDeviceScheduleYield instead of the
+    // runtime's spin).  A pool of workers sharing one GPU spends most of every page waiting for the device: spinning, 12 workers
+    // burn 13 CPUs for 1.5 k pages/s (profiles/r6d_pool_scale_np.json: cpu_ms_per_page 9.1 against 3.7 alone); blocking gives the CPUs
+    // back at the price of a wake-up per wait.  Default: the runtime's own policy.
+    static const int sync_mode = [] { const char *e = getenv("VKX_SYNC"); return !e ? 0 : (e[0] == 'b' ? 1 : (e[0] == 'y' ? 2 : 0)); }();
+    if (sync_mode) {
+        if (hipSetDeviceFlags(sync_mode == 1 ? hipDeviceScheduleBlockingSync : hipDeviceScheduleYield) != hipSuccess) (void)hipGetLastError();
+    }
     vkx_ctx *ctx = new (std::nothrow) vkx_ctx();
     if (!ctx) { vkx_set_error("out of host memory"); return VKX_ERR_NOMEM; }
     ctx->device = device;

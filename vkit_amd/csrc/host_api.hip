@@ -29,17 +29,19 @@ public:
         int rc = vkx_scratch_reserve(ctx_, &ctx_->stage[0], total_ ? total_ : 256);
         if (rc) return rc;
         base_ = (uint8_t *)ctx_->stage[0].ptr;
-        // Small planes (the text-line layers of a page: ~70 planes of 64 KB) are gathered in the page-locked descriptor ring
-        // and travel as ONE copy per run of neighbours: a copy from pageable memory costs ~20 us of staging each, whatever
-        // its size.  Large planes go directly.
-        constexpr size_t kSmall = 256 << 10;
-        size_t small_total = 0;
+        // The input planes are gathered in the page-locked descriptor ring and travel as ONE copy per run of neighbours (normally one
+        // run): a copy from pageable memory is staged by the runtime anyway -- in chunks, each a copy KERNEL on the compute queue (a C4
+        // page's two full-page score maps were 9 such dispatches) --, while one copy out of page-locked memory goes to a DMA engine and
+        // leaves the compute queue to the kernels (of this process and of the other workers sharing the GPU).  Beyond 48 MB of inputs
+        // the planes go directly.
+        constexpr size_t kRingMax = (size_t)48 << 20;
+        size_t in_total = 0;
         for (auto &p : planes_)
-            if (p.in && p.row_bytes && p.rows > 0 && p.row_bytes * (size_t)p.rows <= kSmall) small_total += (p.row_bytes * (size_t)p.rows + 255) & ~(size_t)255;
+            if (p.in && p.row_bytes && p.rows > 0) in_total += (p.row_bytes * (size_t)p.rows + 255) & ~(size_t)255;
         uint8_t *ring = nullptr;
-        if (small_total > kSmall && small_total <= ((size_t)48 << 20)) {       // worth it from a handful of planes on
+        if (in_total > 0 && in_total <= kRingMax) {
             void *r = nullptr;
-            if ((rc = vkx_desc_ring_take(ctx_, small_total, &r))) return rc;
+            if ((rc = vkx_desc_ring_take(ctx_, in_total, &r))) return rc;
             ring = (uint8_t *)r;
         }
         size_t ring_off = 0, run_dev = 0, run_ring = 0, run_bytes = 0;
@@ -52,7 +54,7 @@ public:
         for (auto &p : planes_) {
             if (!p.in || p.row_bytes == 0 || p.rows <= 0) continue;
             const size_t bytes = p.row_bytes * (size_t)p.rows, padded = (bytes + 255) & ~(size_t)255;
-            if (ring && bytes <= kSmall) {
+            if (ring) {
                 // device offsets of consecutive planes are contiguous (add() pads to 256 like the ring does)
                 if (run_bytes && run_dev + run_bytes != p.off) VKX_HIP(flush());
                 if (!run_bytes) { run_dev = p.off; run_ring = ring_off; }
@@ -101,6 +103,7 @@ public:
     }
 
     template <class T> T *dev(int id) const { return id < 0 ? nullptr : (T *)(base_ + planes_[id].off); }
+    size_t total_bytes() const { return total_; }
 
     int finish()
     {
@@ -381,6 +384,31 @@ VKX_EXPORT int vkx_fill_u8_dev_host_layers(vkx_ctx *ctx, uint8_t *dst_dev, int h
     HostStage st(ctx);
     std::vector<int> mid(n_layers, -1), aid(n_layers, -1), vid(n_layers, -1);
     constexpr int kOnDevice = VKX_LAYER_MASK_ON_DEVICE | VKX_LAYER_ALPHA_ON_DEVICE | VKX_LAYER_VALUE_ON_DEVICE;
+    // A layer selected by its alpha plane alone (fill_np_array: np_mask = alpha > 0, element/box.py:329-331) touches nothing in rows whose
+    // alpha is <= 0 throughout: the box shrinks to the rows that select something (a page-sized score map with a bounding-box line or a
+    // barcode in it -- page_assembler.py:167-177 -- is 4 MB of zeros around a few KB), so neither the CPU staging pass nor the link
+    // carries them.  A dense plane costs the scan a few elements at its first and last row.
+    std::vector<vkx_layer> cropped(layers, layers + n_layers);
+    for (int i = 0; i < n_layers; i++) {
+        vkx_layer &l = cropped[i];
+        if (!l.alpha || l.mask || (l.mode & VKX_LAYER_ALPHA_ON_DEVICE) || l.height <= 0 || l.width <= 0) continue;
+        auto selects = [&](int row) {
+            const float *a = l.alpha + (ptrdiff_t)row * l.alpha_stride_el;
+            for (int x = 0; x < l.width; x++)
+                if (a[x] > 0.0f) return true;
+            return false;
+        };
+        int r0 = 0, r1 = l.height;
+        while (r0 < r1 && !selects(r0)) r0++;
+        while (r1 > r0 && !selects(r1 - 1)) r1--;
+        if (r0 == 0 && r1 == l.height) continue;
+        if (r0 == r1) { l.height = 0; continue; }          // selects nothing: dropped by the composite (to_layer_dev)
+        l.alpha += (ptrdiff_t)r0 * l.alpha_stride_el;
+        if (l.value) l.value += (ptrdiff_t)r0 * l.value_stride;
+        l.up += r0;
+        l.height = r1 - r0;
+    }
+    layers = cropped.data();
     for (int i = 0; i < n_layers; i++) {
         const vkx_layer &l = layers[i];
         VKX_REQUIRE(l.height >= 0 && l.width >= 0, "bad layer box");
@@ -388,8 +416,13 @@ VKX_EXPORT int vkx_fill_u8_dev_host_layers(vkx_ctx *ctx, uint8_t *dst_dev, int h
         if (l.alpha && !(l.mode & VKX_LAYER_ALPHA_ON_DEVICE)) aid[i] = st.add(l.alpha, nullptr, (size_t)l.width * 4, l.height, l.alpha_stride_el * 4);
         if (l.value && !(l.mode & VKX_LAYER_VALUE_ON_DEVICE)) vid[i] = st.add(l.value, nullptr, (size_t)l.width * cn, l.height, l.value_stride);
     }
-    static const bool no_map = [] { const char *e = getenv("VKX_LAYERS_MAPPED"); return e && e[0] == '0'; }();
-    if (no_map || !st.commit_mapped()) VKX_TRY(st.commit());
+    // Where the kernel finds the planes: a few KB (a mask strip, a small box) are read in place in the mapped ring -- no copy at all;
+    // a page's worth (MBs) is copied to device memory by a DMA engine (commit(): one copy out of the ring) and read from HBM: the
+    // composite kernel holding CUs for 0.6 ms while 16 MB cross the link was the largest kernel of a page (profiles/r6c_page_dispatches.txt)
+    // and, with several workers on the GPU, compute-queue time is what the workers share.  VKX_LAYERS_MAPPED=1 / 0 forces one way.
+    static const int map_env = [] { const char *e = getenv("VKX_LAYERS_MAPPED"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    const bool mapped = map_env >= 0 ? map_env != 0 : st.total_bytes() <= ((size_t)64 << 10);
+    if (!mapped || !st.commit_mapped()) VKX_TRY(st.commit());
     std::vector<vkx_layer> dl(layers, layers + n_layers);
     for (int i = 0; i < n_layers; i++) {
         if (mid[i] >= 0) { dl[i].mask = st.dev<uint8_t>(mid[i]); dl[i].mask_stride = layers[i].width; }
