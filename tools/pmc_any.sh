@@ -16,13 +16,14 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU S
   echo "pass $i rc=$?"
 done
 python - "$OUT" "$KEY" <<'PY'
-import csv, glob, os, sys, collections
+import csv, glob, os, re, sys, collections
 out, key = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for path in sorted(glob.glob(os.path.join(out, 'p*', '**', '*counter_collection.csv'), recursive=True)):
     for r in csv.DictReader(open(path)):
         if key in r['Kernel_Name']:
-            short = r['Kernel_Name'].split('(')[0][-60:]
+            m_ = re.search(r'\bk_[A-Za-z0-9_]+', r['Kernel_Name'])
+            short = m_.group(0) if m_ else r['Kernel_Name'].split('(')[0][-60:]
             acc[short][r['Counter_Name']].append(float(r['Counter_Value']))
             acc[short]['ns'].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
 for name, d in acc.items():
