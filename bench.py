@@ -804,9 +804,14 @@ def main():
             'C4_page_synth_1024_64_layers_batch64': _tool_json('c4.py', device_index, 240),
             'C5_shared_grid_4096_three_elements': _tool_json('c5.py', device_index, 180),
             'poisson_noise_1024': _tool_json('poisson_probe.py', device_index, 180, ('1024',)),
+            # the reference's own scaling model on one GPU: a pool of worker PROCESSES (vkit/utility/pool.py:153-243), each running whole
+            # C4 pages through PageAssemblerStep -> PageDistortionStep -> PageResizingStep, host objects in and out (tools/pool_scale.py)
+            'C4_reference_api_worker_pool': _tool_json('pool_scale.py', device_index, 240, ('--workers', '1,8', '--seconds', '3', '--modes', 'pipeline')),
             'note': 'BASELINE.json configs[1], [3], [4] on this box and clock, device resident (tools/c2.py, c4.py, c5.py): never '
                     'the headline value; poisson_noise_1024: rng.poisson(image) drawn on the device against numpy itself (values and stream '
-                    'position, tools/poisson_probe.py), host arrays in and out',
+                    'position, tools/poisson_probe.py), host arrays in and out; C4_reference_api_worker_pool: pages/s through the reference\'s '
+                    'step objects with 1 and 8 worker processes sharing this GPU (a worker is bound by its Python, a pool by the kernel time '
+                    'of a page: DESIGN.md section 5, round 6)',
         }
 
     value = total_px / elapsed / 1e6         # total_px: summed over the ranks before the group closed
