@@ -6,6 +6,7 @@ The HIP library is the only implementation of the pixel work: importing this mod
 no CPU fallback.
 """
 import ctypes
+import math
 import os
 import threading
 
@@ -533,7 +534,7 @@ class DevArray:
 
     @property
     def size(self):
-        return int(np.prod(self.shape, dtype=np.int64))
+        return math.prod(self.shape)
 
     @property
     def nbytes(self):
@@ -573,7 +574,7 @@ class DevicePool:
     def empty(self, shape, dtype=np.uint8):
         ctx = self._ctx()
         dtype = np.dtype(dtype)
-        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        nbytes = math.prod(int(v) for v in shape) * dtype.itemsize
         size = max(self.GRANULE, (nbytes + self.GRANULE - 1) // self.GRANULE * self.GRANULE)
         with self._lock:
             blocks = self._free.get(size)
@@ -762,7 +763,7 @@ class PinnedPool:
 
     def empty(self, shape, dtype=np.uint8):
         dtype = np.dtype(dtype)
-        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        nbytes = math.prod(int(v) for v in shape) * dtype.itemsize
         ctx = self._ctx()
         if not self.enabled or nbytes < self.GRANULE or ctx is None or not ctx._h:
             return np.empty(shape, dtype)

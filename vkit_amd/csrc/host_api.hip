@@ -394,6 +394,15 @@ VKX_EXPORT int vkx_fill_u8_dev_host_layers(vkx_ctx *ctx, uint8_t *dst_dev, int h
         if (!l.alpha || l.mask || (l.mode & VKX_LAYER_ALPHA_ON_DEVICE) || l.height <= 0 || l.width <= 0) continue;
         auto selects = [&](int row) {
             const float *a = l.alpha + (ptrdiff_t)row * l.alpha_stride_el;
+            // an all-zero row first, as one OR over its words (no early exit: the compiler vectorises it; a page-sized score map is
+            // 4 MB of exactly that), then the exact test for rows that hold anything
+            uint32_t any = 0;
+            for (int x = 0; x < l.width; x++) {
+                uint32_t bits;
+                memcpy(&bits, a + x, 4);
+                any |= bits;
+            }
+            if (!any) return false;
             for (int x = 0; x < l.width; x++)
                 if (a[x] > 0.0f) return true;
             return false;
