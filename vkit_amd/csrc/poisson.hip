@@ -865,7 +865,8 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
     for (long long b = 0; b < n_blk; b++) var_sum += bvar[(size_t)b];
     const double var_per_element = var_sum / (double)n;
     const int depth = depth_env ? depth_env : (var_per_element > 7.0 ? 1 : 2);
-    const int max_blocks = kMaxBlocks;
+    static const int max_blocks_env = getenv("VKX_PZ_BLOCKS") ? std::max(16, std::min(kMaxBlocks, atoi(getenv("VKX_PZ_BLOCKS")))) : 0;
+    const int max_blocks = max_blocks_env ? max_blocks_env : kMaxBlocks;
     std::vector<std::pair<double, double>> before;         // (mean, variance) of the depth - 1 superblocks before this one
     static thread_local std::vector<PzBlock> plan;
     static thread_local std::vector<PzSuper> supers;
