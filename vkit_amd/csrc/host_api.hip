@@ -24,7 +24,8 @@ public:
         return (int)planes_.size() - 1;
     }
 
-    int commit()
+    // copy_aside: the call is asynchronous (nothing is read back): its staging copy may go to the copy stream (see below)
+    int commit(bool copy_aside = false)
     {
         int rc = vkx_scratch_reserve(ctx_, &ctx_->stage[0], total_ ? total_ : 256);
         if (rc) return rc;
@@ -52,7 +53,9 @@ public:
         // (profiles/r6h0_ / r6h1_page_dispatches.txt).  VKX_STAGE_COPY_STREAM=0 keeps it in line.
         static const bool aside = [] { const char *e = getenv("VKX_STAGE_COPY_STREAM"); return !(e && e[0] == '0'); }();
         hipStream_t copy_stream = ctx_->stream;
-        if (aside && ring && in_total >= ((size_t)256 << 10)) {
+        // (only for calls that return without reading anything back: behind a synchronous call -- similarity_mls.distort on one 2048^2
+        //  image -- the DMA engine's start-up latency is what the caller waits for: 1.5 -> 2.1 ms per call)
+        if (aside && copy_aside && ring && in_total >= ((size_t)256 << 10)) {
             int src = VKX_OK;
             hipStream_t cs = vkx_stream_by_id(ctx_, VKX_STREAM_COPY_IN, &src);
             if (src == VKX_OK && cs && vkx_stream_order(ctx_, cs, ctx_->stream) == VKX_OK) copy_stream = cs;
@@ -444,7 +447,7 @@ VKX_EXPORT int vkx_fill_u8_dev_host_layers(vkx_ctx *ctx, uint8_t *dst_dev, int h
     // and, with several workers on the GPU, compute-queue time is what the workers share.  VKX_LAYERS_MAPPED=1 / 0 forces one way.
     static const int map_env = [] { const char *e = getenv("VKX_LAYERS_MAPPED"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
     const bool mapped = map_env >= 0 ? map_env != 0 : st.total_bytes() <= ((size_t)64 << 10);
-    if (!mapped || !st.commit_mapped()) VKX_TRY(st.commit());
+    if (!mapped || !st.commit_mapped()) VKX_TRY(st.commit(true));
     std::vector<vkx_layer> dl(layers, layers + n_layers);
     for (int i = 0; i < n_layers; i++) {
         if (mid[i] >= 0) { dl[i].mask = st.dev<uint8_t>(mid[i]); dl[i].mask_stride = layers[i].width; }
