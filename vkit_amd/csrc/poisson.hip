@@ -992,7 +992,13 @@ VKX_EXPORT int vkx_np_poisson_u8_dev(vkx_ctx *ctx, const uint64_t *state, const 
         static const int grid_env = getenv("VKX_PZ_GRID") ? atoi(getenv("VKX_PZ_GRID")) : 0;      // fewer workgroups than CUs: every wait of the kernel is exercised
         static const int g_global = getenv("VKX_PZ_G_GLOBAL") ? atoi(getenv("VKX_PZ_G_GLOBAL")) : 0;
         static const int resolve_rows = getenv("VKX_PZ_RESOLVE_ROWS") ? atoi(getenv("VKX_PZ_RESOLVE_ROWS")) : kResolveRows;
-        const int grid = (int)std::min<long long>(n_blk, grid_env > 0 ? grid_env : n_cu);
+        // By default the kernel leaves one CU in eight alone (VKX_PZ_GRID=<CUs> takes them all).  Its workgroups are persistent, hold ~150
+        // of a CU's 160 KB of LDS and spin on each other's published positions for 7 - 9 ms per page: with every CU taken, the kernels of the
+        // OTHER worker processes sharing the GPU (the reference scales by processes) wait that long for a slot.  Measured with 8 workers on
+        // C4 pages (one page in twenty-five draws poisson_noise): grid 256 -> 833 pages/s, 240 -> 807, 224 -> 1 044, 192 -> 1 088, 128 -> 993;
+        // alone the page costs 7.4 ms at 256 and 8.1 at 224 (profiles/r6_poisson_grid_pool.txt).
+        const int grid_default = std::max(1, n_cu - n_cu / 8);
+        const int grid = (int)std::min<long long>(n_blk, grid_env > 0 ? grid_env : grid_default);
         VKX_TIMED(ctx, "k_pz_super");
         k_pz_super<<<grid, kCandThreads, 0, ctx->stream>>>(src, n, (int)n_blk, d_order, d_plan, d_sup, d_pos, d_draws, M, tabs, d_E, d_P, d_G, (long long)e_stride, d_bpos,
                                                           d_ticket, d_grpcnt, d_supcnt, d_done, &d_reply->fail, d_probe, g_global, resolve_rows);
