@@ -282,13 +282,10 @@ def test_paint_polys_page_of_char_boxes(N):
 from vkit_amd.pipeline.text_detection.synthetic_page import synthetic_page_input as _synthetic_page_input  # noqa: E402
 
 
-@pytest.mark.parametrize('size,n_lines', [(256, 24), (1024, 64)])      # (1024, 64): BASELINE config 3's page, 64 text layers
-def test_page_assembler_layer_order(N, size, n_lines):
+def _assembled_reference(step_input):
+    """The page of ``PageAssemblerStep.run`` for ``step_input``, layer by layer with the oracle, in the reference's order
+    (pipeline/text_detection/page_assembler.py:155-236)."""
     from vkit_amd.mechanism.distortion import rotate
-    from vkit_amd.pipeline import text_detection as T
-    step_input = _synthetic_page_input(seed=7, size=size, n_lines=n_lines)
-    page = T.page_assembler_step_factory.create().run(step_input, default_rng(0)).page
-
     # the same layer list applied one by one with the oracle, in the reference's order
     want = step_input.page_background_step_output.background_image.mat.copy()
     full = (0, 0) + want.shape[:2]
@@ -320,10 +317,32 @@ def test_page_assembler_layer_order(N, size, n_lines):
         geo = (up, left, rotated.mask.height, rotated.mask.width)
         O.fill(want, geo, seal.color, mask=rotated.mask.mat, alpha=seal.alpha)
         O.fill(want, geo, seal.color, alpha=rotated.score_map.mat)
+    return want
+
+
+@pytest.mark.parametrize('size,n_lines', [(256, 24), (1024, 64)])      # (1024, 64): BASELINE config 3's page, 64 text layers
+def test_page_assembler_layer_order(N, size, n_lines):
+    from vkit_amd.pipeline import text_detection as T
+    step_input = _synthetic_page_input(seed=7, size=size, n_lines=n_lines)
+    page = T.page_assembler_step_factory.create().run(step_input, default_rng(0)).page
+    want = _assembled_reference(step_input)
     np.testing.assert_array_equal(page.image.mat, want)
     assert len(page.page_seal_impression_char_polygon_collection.char_polygons) == 1
     assert not page.image.mat.flags.writeable
     assert (page.image.mat != step_input.page_background_step_output.background_image.mat).any()
+
+
+def test_page_assembler_many_pages_across_ring_wraps(N):
+    """Thirty C4 pages assembled back to back without a read in between: every page stages ~8 MB of layer planes in the context's
+    page-locked ring (one copy on the copy stream per page), so the ring wraps -- and may grow -- several times while earlier
+    composites are still queued; every page must come out as the oracle's layer-by-layer result."""
+    from vkit_amd.pipeline import text_detection as T
+    assembler = T.page_assembler_step_factory.create()
+    inputs = [_synthetic_page_input(seed=100 + k, size=1024, n_lines=64) for k in range(6)]
+    wants = [_assembled_reference(si) for si in inputs]
+    pages = [assembler.run(inputs[k % 6], default_rng(k)).page for k in range(30)]
+    for k, page in enumerate(pages):
+        np.testing.assert_array_equal(page.image.mat, wants[k % 6], err_msg=f'page {k}')
 
 
 @pytest.mark.parametrize('size,n_lines,seeds', [(256, 24, 6), (1024, 64, 2)])   # (1024, 64): BASELINE config 3's page
