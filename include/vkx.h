@@ -503,6 +503,20 @@ int vkx_paint_polys(vkx_ctx *ctx, const int32_t *pts_host, const int32_t *poly_o
 int vkx_paint_polys_fresh_dev(vkx_ctx *ctx, const int32_t *pts_host, const int32_t *poly_offsets_host, int n_polys,
                               const float *values_host, uint8_t *mask, ptrdiff_t mask_stride, float *score,
                               ptrdiff_t score_stride_el, int h, int w);
+/* ... and the label plane sets of ONE page in one call (page_distortion.py:163-314 paints four: text-line mask + height map, char
+ * mask, seal-impression char mask, char height map): up to 8 sets of one plane shape, each with its own polygon list, values and
+ * fresh output planes; the same pixels as n_sets vkx_paint_polys_fresh_dev calls, with one table copy and three kernels for all. */
+typedef struct vkx_paint_set {
+    const int32_t *pts_host;          /* HOST int32 [total_pts, 2] (x, y) */
+    const int32_t *poly_offsets_host; /* HOST int32 [n_polys + 1] */
+    int32_t n_polys;
+    const float *values_host;         /* HOST float32 [n_polys]; required with score */
+    uint8_t *mask;                    /* device [h, w] or NULL */
+    ptrdiff_t mask_stride;
+    float *score;                     /* device [h, w] or NULL */
+    ptrdiff_t score_stride_el;
+} vkx_paint_set;
+int vkx_paint_poly_sets_fresh_dev(vkx_ctx *ctx, const vkx_paint_set *sets, int n_sets, int h, int w);
 
 /* ---- the numpy Generator streams of the noise operators, drawn on the device -------------------------------------
  * photometric/noise.py:44-54 (gaussion_noise), :160-190 (speckle_noise), :100-157 (impulse_noise) draw from the

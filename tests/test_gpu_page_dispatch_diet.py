@@ -178,3 +178,40 @@ def test_lookup_table_from_the_ring_and_point_projection(N):
         got = o.host() if hasattr(o, 'host') else o
         want = np.stack([t[c][img[..., c]] for c in range(3)], axis=-1)
         np.testing.assert_array_equal(got, want)
+
+
+def test_paint_sets_equal_separate_paints(N):
+    """vkx_paint_poly_sets_fresh_dev: the label plane sets of a page in one call (bands of one ownership raster) == one fresh paint per set --
+    polygons reaching over the plane's top and bottom edge (they must not bleed into the neighbour band), an empty set, mask-only and
+    score-only sets, one to eight sets, twice on the same context with other shapes in between."""
+    ctx = N.default_ctx()
+    rng = default_rng(41)
+    for shape, n_sets in (((120, 200), 4), ((64, 64), 8), ((257, 131), 1), ((120, 200), 5)):
+        sets, want = [], []
+        for k in range(n_sets):
+            polygons, values = _polys(rng, shape, 0 if k == 2 else int(rng.integers(1, 60)))
+            # tall polygons crossing both horizontal edges of the plane
+            for _ in range(3):
+                x = int(rng.integers(0, shape[1] - 8))
+                polygons.append(np.asarray([(x, -30), (x + 7, -25), (x + 9, shape[0] + 20), (x - 3, shape[0] + 33)], np.int32))
+                values.append(float(rng.uniform(1, 9)))
+            want_mask, want_score = (k % 3 != 1), (k % 3 != 0)
+            flat = np.concatenate(polygons, axis=0).astype(np.int32)
+            offsets = np.concatenate([[0], np.cumsum([len(p) for p in polygons])]).astype(np.int32)
+            mask = ctx.to_device(rng.integers(0, 256, shape, dtype=np.uint8)) if want_mask else None
+            score = ctx.to_device(rng.random(shape, dtype=np.float32)) if want_score else None
+            sets.append((flat, offsets, values if want_score else None, mask, score))
+            ref_m = ctx.dev_empty(shape, np.uint8) if want_mask else None
+            ref_s = ctx.dev_empty(shape, np.float32) if want_score else None
+            N.paint_polys_flat(flat, offsets, values=values if want_score else None, mask=ref_m, score=ref_s, fresh=True)
+            want.append((ref_m, ref_s))
+        N.paint_poly_sets_fresh(sets, shape)
+        for k, ((_f, _o, _v, mask, score), (ref_m, ref_s)) in enumerate(zip(sets, want)):
+            if mask is not None:
+                np.testing.assert_array_equal(mask.host(), ref_m.host(), err_msg=f'mask of set {k} {shape}')
+            if score is not None:
+                np.testing.assert_array_equal(score.host(), ref_s.host(), err_msg=f'score of set {k} {shape}')
+    # an empty polygon list: the planes come out zero
+    m = ctx.to_device(rng.integers(1, 256, (40, 50), dtype=np.uint8))
+    N.paint_poly_sets_fresh([(np.zeros((0, 2), np.int32), np.zeros(1, np.int32), None, m, None)], (40, 50))
+    assert not m.host().any()

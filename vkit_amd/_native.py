@@ -76,6 +76,19 @@ class VkxChainItem(ctypes.Structure):
     ]
 
 
+class VkxPaintSet(ctypes.Structure):
+    _fields_ = [
+        ('pts_host', c_void_p),
+        ('poly_offsets_host', c_void_p),
+        ('n_polys', ctypes.c_int32),
+        ('values_host', c_void_p),
+        ('mask', c_void_p),
+        ('mask_stride', c_ssize),
+        ('score', c_void_p),
+        ('score_stride_el', c_ssize),
+    ]
+
+
 class VkxLayer(ctypes.Structure):
     _fields_ = [
         ('up', ctypes.c_int32),
@@ -297,6 +310,7 @@ for _sfx in ('', '_dev'):
     _SIGNATURES['vkx_ellipse_streak_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_double]
 
 _SIGNATURES['vkx_paint_polys_fresh_dev'] = _SIGNATURES['vkx_paint_polys_dev']
+_SIGNATURES['vkx_paint_poly_sets_fresh_dev'] = [c_void_p, ctypes.POINTER(VkxPaintSet), c_int, c_int, c_int]
 _SIGNATURES['vkx_fill_u8_dev_host_layers'] = [c_void_p] + _PLANE_U8 + [ctypes.POINTER(VkxLayer), c_int]
 _SIGNATURES['vkx_fill_u8_batch_dev'] = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_ssize, ctypes.POINTER(VkxLayer), c_void_p]
 EXPORTED_SYMBOLS = sorted(list(_SIGNATURES) + ['vkx_version', 'vkx_last_error', 'vkx_ctx_stream'])
@@ -1845,6 +1859,49 @@ def paint_polys(polygons, values=None, mask=None, score=None, ctx=None, fresh=Fa
         offsets[1:] = np.cumsum([len(p) for p in pts])
     flat = np.ascontiguousarray(np.concatenate(pts, axis=0)) if pts else np.zeros((0, 2), np.int32)
     _paint(flat, offsets, len(pts), values, mask, score, ctx, fresh)
+
+
+def paint_poly_sets_fresh(sets, shape, ctx=None):
+    """The ordered paint of several label plane sets of one ``shape`` in ONE call (vkx_paint_poly_sets_fresh_dev: the four sets of a page).
+    ``sets``: sequence of (points_xy int (N, 2), offsets int (P + 1), values float (P) or None, mask DevArray or None, score DevArray or
+    None); the planes are uninitialised DevArrays of ``shape`` on one context and every pixel of them is written."""
+    h, w = shape
+    n = len(sets)
+    if n == 0:
+        return
+    arr = (VkxPaintSet * n)()
+    keep = []
+    for k, (points_xy, offsets, values, mask, score) in enumerate(sets):
+        flat = np.ascontiguousarray(points_xy, dtype=np.int32).reshape(-1, 2)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        n_polys = offsets.shape[0] - 1
+        rec = arr[k]
+        rec.pts_host, rec.poly_offsets_host, rec.n_polys = flat.ctypes.data, offsets.ctypes.data, n_polys
+        keep += [flat, offsets]
+        if score is not None:
+            vals = np.ascontiguousarray(np.asarray(values if values is not None else (), dtype=np.float32))
+            if vals.shape != (n_polys,):
+                raise ValueError('one value per polygon is required with a score plane')
+            rec.values_host = vals.ctypes.data
+            keep.append(vals)
+        for plane, dt, field, stride in ((mask, np.uint8, 'mask', 'mask_stride'), (score, np.float32, 'score', 'score_stride_el')):
+            if plane is None:
+                continue
+            if not isinstance(plane, DevArray) or np.dtype(plane.dtype) != dt or tuple(plane.shape) != (h, w):
+                raise ValueError(f'planes must be {(h, w)} DevArrays (uint8 mask, float32 score)')
+            if ctx is None:
+                ctx = plane.ctx
+            elif plane.ctx is not ctx:
+                raise ValueError('the planes of one call live on one context')
+            setattr(rec, field, plane.ptr)
+            setattr(rec, stride, w)
+        if mask is None and score is None:
+            raise ValueError('mask or score is required')
+    check(lib().vkx_paint_poly_sets_fresh_dev(ctx.handle, arr, n, h, w))
+    for _p, _o, _v, mask, score in sets:
+        for plane in (mask, score):
+            if plane is not None:
+                plane.invalidate_host()
 
 
 def paint_polys_flat(points_xy, offsets, values=None, mask=None, score=None, ctx=None, fresh=False):

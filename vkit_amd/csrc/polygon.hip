@@ -138,7 +138,8 @@ __global__ void __launch_bounds__(256) k_paint_outline(const PolyEdge *__restric
     const int m = vkc::bres_minor(k, e.dmaj, e.dmin);
     const int x = e.ymajor ? e.lx + m : e.lx + k;
     const int y = e.ymajor ? e.ly + e.sy * k : e.ly + e.sy * m;
-    if ((unsigned)x < (unsigned)w && (unsigned)y < (unsigned)h) atomicMax(&owner[(size_t)y * w + x], e.poly);
+    // (several label plane sets painted by one call live in bands of h rows of one raster: e.pad is the band, the polygon is clipped to it)
+    if ((unsigned)x < (unsigned)w && (unsigned)(y - e.pad * h) < (unsigned)h) atomicMax(&owner[(size_t)y * w + x], e.poly);
 }
 
 constexpr int kPaintCross = 64; // crossings of one polygon on one scanline handled by the batched path
@@ -197,67 +198,109 @@ __global__ void __launch_bounds__(256) k_paint_spans(const PolyEdge *__restrict_
 // FRESH: the output planes are uninitialised memory -- every pixel is written (0 outside every polygon), so the caller needs no
 // memset of its own.  Either way the owner word is cleared as it is read: the raster is all zero again when the kernel is done and
 // the next call needs no memset either (a page paints four label plane sets: 3 - 4 fill dispatches per call were 14 of its 98).
+// blockIdx.z = the band of the raster = the plane set (vkx_paint_poly_sets_fresh_dev: the sets of a page in one call).
+constexpr int kPaintSets = 8;
+struct PaintOut {
+    uint8_t *mask[kPaintSets];
+    float *score[kPaintSets];
+    ptrdiff_t mask_stride[kPaintSets], score_stride[kPaintSets];
+    int value_off[kPaintSets];      // the set's first value in `values`
+};
+
 template <bool FRESH>
-__global__ void __launch_bounds__(256) k_paint_resolve(int *__restrict__ owner, const float *__restrict__ values,
-                                                       uint8_t *__restrict__ mask, ptrdiff_t mask_stride,
-                                                       float *__restrict__ score, ptrdiff_t score_stride, int h, int w)
+__global__ void __launch_bounds__(256) k_paint_resolve(int *__restrict__ owner_all, const float *__restrict__ values, PaintOut out, int h, int w)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int set = blockIdx.z;
     if (x >= w || y >= h) return;
+    int *owner = owner_all + (size_t)set * h * w;
+    uint8_t *mask = out.mask[set];
+    float *score = out.score[set];
     const int o = owner[(size_t)y * w + x];
     if (o <= 0) {
         if (o < 0) owner[(size_t)y * w + x] = 0;
         if (FRESH) {
-            if (mask) mask[(ptrdiff_t)y * mask_stride + x] = 0;
-            if (score) score[(ptrdiff_t)y * score_stride + x] = 0.0f;
+            if (mask) mask[(ptrdiff_t)y * out.mask_stride[set] + x] = 0;
+            if (score) score[(ptrdiff_t)y * out.score_stride[set] + x] = 0.0f;
         }
         return;
     }
     owner[(size_t)y * w + x] = 0;
-    if (mask) mask[(ptrdiff_t)y * mask_stride + x] = 1;
-    if (score) score[(ptrdiff_t)y * score_stride + x] = values[o - 1];
+    if (mask) mask[(ptrdiff_t)y * out.mask_stride[set] + x] = 1;
+    if (score) score[(ptrdiff_t)y * out.score_stride[set] + x] = values[out.value_off[set] + o - 1];
 }
 
 } // namespace
 
-static int paint_polys_dev(vkx_ctx *ctx, const int32_t *pts_host, const int32_t *poly_offsets_host, int n_polys,
-                           const float *values_host, uint8_t *mask, ptrdiff_t mask_stride, float *score,
-                           ptrdiff_t score_stride_el, int h, int w, bool fresh)
+// The ordered paint of up to kPaintSets label plane sets of one shape in ONE call: set k's polygons are shifted into band k (rows
+// [k h, (k + 1) h)) of one ownership raster and clipped to it, so one table copy and three kernels serve all of them (a page paints four
+// sets -- text-line mask + heights, char mask, seal char mask, char heights: 16 dispatches as four calls, 4 as one).
+static int paint_sets_dev(vkx_ctx *ctx, const vkx_paint_set *sets, int n_sets, int h, int w, bool fresh)
 {
-    VKX_REQUIRE(ctx && (n_polys == 0 || (pts_host && poly_offsets_host)), "NULL argument");
-    VKX_REQUIRE(n_polys >= 0 && h > 0 && w > 0, "bad shape");
-    VKX_REQUIRE(mask || score, "no output plane");
-    VKX_REQUIRE(!score || values_host || n_polys == 0, "score output needs per-polygon values");
-    if (n_polys == 0) {
-        if (fresh) {          // nothing to paint: the planes are zero
-            vkx_device_guard guard(ctx);
-            if (mask) VKX_HIP(hipMemset2DAsync(mask, (size_t)mask_stride, 0, (size_t)w, (size_t)h, ctx->stream));
-            if (score) VKX_HIP(hipMemset2DAsync(score, (size_t)score_stride_el * 4, 0, (size_t)w * 4, (size_t)h, ctx->stream));
+    VKX_REQUIRE(ctx && sets, "NULL argument");
+    VKX_REQUIRE(n_sets >= 1 && n_sets <= kPaintSets, "1 .. 8 plane sets per call");
+    VKX_REQUIRE(h > 0 && w > 0 && (long long)h * n_sets < 0x3fffffff, "bad shape");
+    long long total_pts = 0, total_polys = 0;
+    for (int k = 0; k < n_sets; k++) {
+        const vkx_paint_set &S = sets[k];
+        VKX_REQUIRE(S.n_polys >= 0 && (S.n_polys == 0 || (S.pts_host && S.poly_offsets_host)), "bad polygon list");
+        VKX_REQUIRE(S.mask || S.score, "no output plane");
+        VKX_REQUIRE(!S.score || S.values_host || S.n_polys == 0, "score output needs per-polygon values");
+        if (S.n_polys) {
+            VKX_REQUIRE(S.poly_offsets_host[S.n_polys] >= 0, "bad polygon offsets");
+            total_pts += S.poly_offsets_host[S.n_polys];
+            total_polys += S.n_polys;
         }
-        return VKX_OK;
     }
-    const int total_pts = poly_offsets_host[n_polys];
-    VKX_REQUIRE(total_pts >= 0, "bad polygon offsets");
+    VKX_REQUIRE(total_pts < 0x3fffffff, "too many vertices");
+    if (total_polys == 0 && !fresh) return VKX_OK;
     std::vector<PolyEdge> edges((size_t)total_pts);
     std::vector<PaintItem> items;
+    std::vector<float> values((size_t)total_polys);
+    std::vector<int32_t> shifted;
+    PaintOut out;
+    memset(&out, 0, sizeof(out));
     long long steps = 0;
-    for (int p = 0; p < n_polys; p++) {
-        const int b = poly_offsets_host[p], e = poly_offsets_host[p + 1];
-        VKX_REQUIRE(b <= e && e <= total_pts, "bad polygon offsets");
-        if (b == e) continue;
-        int ymin = INT_MAX, ymax = INT_MIN;
-        build_edges(pts_host + 2 * (size_t)b, e - b, p + 1, edges.data() + b, &steps, &ymin, &ymax);
-        VKX_REQUIRE(steps < 0x7fffffff, "polygon outlines too long");
-        for (int y = std::max(ymin, 0); y < std::min(ymax, h); y++) items.push_back(PaintItem{b, e, y, p + 1});
+    bool may_overflow = false, any_values = false;
+    size_t e_base = 0, v_base = 0;
+    for (int k = 0; k < n_sets; k++) {
+        const vkx_paint_set &S = sets[k];
+        out.mask[k] = S.mask; out.mask_stride[k] = S.mask_stride;
+        out.score[k] = S.score; out.score_stride[k] = S.score_stride_el;
+        out.value_off[k] = (int)v_base;
+        if (S.n_polys == 0) continue;
+        const int set_pts = S.poly_offsets_host[S.n_polys];
+        const int y_off = k * h;
+        const int32_t *pts = S.pts_host;
+        if (y_off) {            // the band: the set's vertices moved down by k h rows
+            shifted.resize((size_t)set_pts * 2);
+            for (int i = 0; i < set_pts; i++) { shifted[2 * (size_t)i] = S.pts_host[2 * (size_t)i]; shifted[2 * (size_t)i + 1] = S.pts_host[2 * (size_t)i + 1] + y_off; }
+            pts = shifted.data();
+        }
+        for (int p = 0; p < S.n_polys; p++) {
+            const int b = S.poly_offsets_host[p], e = S.poly_offsets_host[p + 1];
+            VKX_REQUIRE(b <= e && e <= set_pts, "bad polygon offsets");
+            may_overflow = may_overflow || e - b > kPaintCross;
+            if (b == e) continue;
+            int ymin = INT_MAX, ymax = INT_MIN;
+            build_edges(pts + 2 * (size_t)b, e - b, p + 1, edges.data() + e_base + b, &steps, &ymin, &ymax);
+            VKX_REQUIRE(steps < 0x7fffffff, "polygon outlines too long");
+            for (size_t i = e_base + b; i < e_base + e; i++) edges[i].pad = k;
+            for (int y = std::max(ymin, y_off); y < std::min(ymax, y_off + h); y++)
+                items.push_back(PaintItem{(int)e_base + b, (int)e_base + e, y, p + 1});
+        }
+        if (S.values_host) { memcpy(values.data() + v_base, S.values_host, sizeof(float) * (size_t)S.n_polys); any_values = true; }
+        e_base += (size_t)set_pts;
+        v_base += (size_t)S.n_polys;
     }
     const size_t ebytes = (sizeof(PolyEdge) * edges.size() + 255) & ~(size_t)255;
     const size_t ibytes = (sizeof(PaintItem) * items.size() + 255) & ~(size_t)255;
-    const size_t vbytes = ((size_t)n_polys * 4 + 255) & ~(size_t)255;
+    const size_t vbytes = (sizeof(float) * values.size() + 255) & ~(size_t)255;
     int rc = vkx_scratch_reserve(ctx, &ctx->misc, 256 + ebytes + ibytes + vbytes);
     if (rc) return rc;
     // the ownership raster is the paint's own block: zero at rest (k_paint_resolve clears what it reads), memset only when it grows
-    const size_t owner_bytes = (size_t)h * w * 4;
+    const size_t owner_bytes = (size_t)h * w * 4 * (size_t)n_sets;
     if (owner_bytes > ctx->paint_owner.cap) ctx->paint_owner_zeroed = 0;
     rc = vkx_scratch_reserve(ctx, &ctx->paint_owner, owner_bytes);
     if (rc) return rc;
@@ -271,32 +314,32 @@ static int paint_polys_dev(vkx_ctx *ctx, const int32_t *pts_host, const int32_t 
     // with its kernels queued (a page paints four label planes: two stream synchronisations and a flag read-back per call were
     // 0.45 ms of a 2.2 ms page).  A polygon of at most kPaintCross vertices cannot cross a scanline more often than the span
     // kernel holds, so only calls with larger polygons read the overflow flag back (and synchronise for it).
-    bool may_overflow = false;
-    for (int p = 0; p < n_polys; p++) may_overflow = may_overflow || poly_offsets_host[p + 1] - poly_offsets_host[p] > kPaintCross;
     const size_t table_bytes = ebytes + ibytes + vbytes;
-    void *ring = nullptr;
-    if ((rc = vkx_desc_ring_take(ctx, table_bytes, &ring))) return rc;
-    if (!edges.empty()) memcpy(ring, edges.data(), sizeof(PolyEdge) * edges.size());
-    if (!items.empty()) memcpy((unsigned char *)ring + ebytes, items.data(), sizeof(PaintItem) * items.size());
-    if (values_host) memcpy((unsigned char *)ring + ebytes + ibytes, values_host, (size_t)n_polys * 4);
     vkx_device_guard guard(ctx);
+    if (table_bytes) {
+        void *ring = nullptr;
+        if ((rc = vkx_desc_ring_take(ctx, table_bytes, &ring))) return rc;
+        if (!edges.empty()) memcpy(ring, edges.data(), sizeof(PolyEdge) * edges.size());
+        if (!items.empty()) memcpy((unsigned char *)ring + ebytes, items.data(), sizeof(PaintItem) * items.size());
+        if (!values.empty()) memcpy((unsigned char *)ring + ebytes + ibytes, values.data(), sizeof(float) * values.size());
+        VKX_HIP(hipMemcpyAsync(d_edges, ring, table_bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
     if (may_overflow) VKX_HIP(hipMemsetAsync(overflow, 0, sizeof(int), ctx->stream));      // (only such calls can set it, and only they read it)
     if (ctx->paint_owner_zeroed < owner_bytes) VKX_HIP(hipMemsetAsync(owner, 0, ctx->paint_owner.cap, ctx->stream));
     ctx->paint_owner_zeroed = 0;          // dirty until the resolve kernel of THIS call has been queued (an error exit in between re-zeroes next time)
-    VKX_HIP(hipMemcpyAsync(d_edges, ring, table_bytes, hipMemcpyHostToDevice, ctx->stream));
     if (steps > 0) {
-        { VKX_TIMED(ctx, "k_paint_outline"); k_paint_outline<<<vkx_blocks((size_t)steps, 256), 256, 0, ctx->stream>>>(d_edges, total_pts, (int)steps, owner, h, w); }
+        { VKX_TIMED(ctx, "k_paint_outline"); k_paint_outline<<<vkx_blocks((size_t)steps, 256), 256, 0, ctx->stream>>>(d_edges, (int)total_pts, (int)steps, owner, h, w); }
         VKX_LAUNCH_CHECK();
     }
     if (!items.empty()) {
-        { VKX_TIMED(ctx, "k_paint_spans"); k_paint_spans<<<vkx_blocks(items.size(), 4), 256, 0, ctx->stream>>>(d_edges, d_items, (int)items.size(), owner, h, w, overflow); }
+        { VKX_TIMED(ctx, "k_paint_spans"); k_paint_spans<<<vkx_blocks(items.size(), 4), 256, 0, ctx->stream>>>(d_edges, d_items, (int)items.size(), owner, h * n_sets, w, overflow); }
         VKX_LAUNCH_CHECK();
     }
     {
-        dim3 grid(vkx_blocks(w, 64), vkx_blocks(h, 4));
+        dim3 grid(vkx_blocks(w, 64), vkx_blocks(h, 4), n_sets);
         VKX_TIMED(ctx, "k_paint_resolve");
-        if (fresh) k_paint_resolve<true><<<grid, 256, 0, ctx->stream>>>(owner, values_host ? d_values : nullptr, mask, mask_stride, score, score_stride_el, h, w);
-        else k_paint_resolve<false><<<grid, 256, 0, ctx->stream>>>(owner, values_host ? d_values : nullptr, mask, mask_stride, score, score_stride_el, h, w);
+        if (fresh) k_paint_resolve<true><<<grid, 256, 0, ctx->stream>>>(owner, any_values ? d_values : nullptr, out, h, w);
+        else k_paint_resolve<false><<<grid, 256, 0, ctx->stream>>>(owner, any_values ? d_values : nullptr, out, h, w);
         VKX_LAUNCH_CHECK();
         ctx->paint_owner_zeroed = ctx->paint_owner.cap;
     }
@@ -309,6 +352,23 @@ static int paint_polys_dev(vkx_ctx *ctx, const int32_t *pts_host, const int32_t 
         return VKX_ERR_UNSUPPORTED;
     }
     return VKX_OK;
+}
+
+static int paint_polys_dev(vkx_ctx *ctx, const int32_t *pts_host, const int32_t *poly_offsets_host, int n_polys,
+                           const float *values_host, uint8_t *mask, ptrdiff_t mask_stride, float *score,
+                           ptrdiff_t score_stride_el, int h, int w, bool fresh)
+{
+    VKX_REQUIRE(ctx && (n_polys == 0 || (pts_host && poly_offsets_host)), "NULL argument");
+    VKX_REQUIRE(n_polys >= 0 && h > 0 && w > 0, "bad shape");
+    vkx_paint_set S;
+    S.pts_host = pts_host; S.poly_offsets_host = poly_offsets_host; S.n_polys = n_polys; S.values_host = values_host;
+    S.mask = mask; S.mask_stride = mask_stride; S.score = score; S.score_stride_el = score_stride_el;
+    return paint_sets_dev(ctx, &S, 1, h, w, fresh);
+}
+
+VKX_EXPORT int vkx_paint_poly_sets_fresh_dev(vkx_ctx *ctx, const vkx_paint_set *sets, int n_sets, int h, int w)
+{
+    return paint_sets_dev(ctx, sets, n_sets, h, w, true);
 }
 
 VKX_EXPORT int vkx_paint_polys_dev(vkx_ctx *ctx, const int32_t *pts_host, const int32_t *poly_offsets_host, int n_polys,

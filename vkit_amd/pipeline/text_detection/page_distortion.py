@@ -111,12 +111,48 @@ class ElementFlattener(Generic[_E]):
         return grouped
 
 
+class _PaintQueue:
+    """The label paints of one page, gathered: every ``paint_polygons`` call of a page writes fresh planes of the page's shape, so the
+    plane sets are recorded (their device planes exist, uninitialised, and the elements that wrap them are handed out) and painted by
+    ONE ``vkx_paint_poly_sets_fresh_dev`` call when the page's labels are complete -- four sets per page: one table copy and three
+    kernels instead of four times that."""
+
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+        self.sets = []
+
+    def add(self, polygons, values, want_mask):
+        ctx = _native.default_ctx()
+        mask = ctx.dev_empty(self.shape, np.uint8) if want_mask else None
+        score = ctx.dev_empty(self.shape, np.float32) if values is not None else None
+        if isinstance(polygons, PolygonSoup):
+            flat, offsets = polygons.int_xy, polygons.offsets
+        else:
+            pts = [np.asarray(polygon.to_np_array(), dtype=np.int32).reshape(-1, 2) for polygon in polygons]
+            offsets = np.zeros(len(pts) + 1, np.int32)
+            if pts:
+                offsets[1:] = np.cumsum([len(p) for p in pts])
+            flat = np.concatenate(pts, axis=0) if pts else np.zeros((0, 2), np.int32)
+        self.sets.append((flat, offsets, values, mask, score))
+        return mask, score
+
+    def flush(self):
+        sets, self.sets = self.sets, []
+        for k in range(0, len(sets), 8):
+            _native.paint_poly_sets_fresh(sets[k:k + 8], self.shape)
+
+
 def paint_polygons(shape: Tuple[int, int], polygons: Sequence[Polygon], values: Optional[Sequence[float]] = None,
-                   want_mask: bool = True):
+                   want_mask: bool = True, queue: Optional[_PaintQueue] = None):
     """Sequential ``polygon.fill_mask(mask)`` / ``polygon.fill_score_map(score_map, value)`` over ``polygons`` on
-    fresh planes, as one ordered device paint.  Returns (Mask | None, ScoreMap | None)."""
+    fresh planes, as one ordered device paint.  Returns (Mask | None, ScoreMap | None).  With a ``queue`` (device-resident pages) the
+    paint is recorded and runs with the page's other label paints (``_PaintQueue.flush``)."""
     height, width = shape
     resident = _native.resident_mode()
+    if resident and queue is not None and queue.shape == (height, width) and (want_mask or values is not None):
+        np_mask, np_score = queue.add(polygons, values, want_mask)
+        return (Mask(mat=np_mask) if want_mask else None,
+                ScoreMap(mat=np_score, is_prob=False) if values is not None else None)
     if resident and len(polygons):
         # the planes are painted where the page lives and stay there until somebody reads ``.mat``; the paint writes every pixel of
         # them (0 outside every polygon): no memset per plane
@@ -206,7 +242,7 @@ class PageDistortionStep(PipelineStep[PageDistortionStepConfig, PageDistortionSt
     def generate_text_line_labelings(self, distorted_image: Image, text_line_polygons: Sequence[Polygon],
                                      text_line_height_points_up: PointList,
                                      text_line_height_points_down: PointList,
-                                     text_line_height_points_group_sizes: Sequence[int]):
+                                     text_line_height_points_group_sizes: Sequence[int], _paint_queue: Optional[_PaintQueue] = None):
         text_line_heights: Optional[List[float]] = None
         if self.config.enable_distorted_text_line_height_score_map:
             np_heights = _heights(text_line_height_points_up, text_line_height_points_down)
@@ -216,19 +252,20 @@ class PageDistortionStep(PipelineStep[PageDistortionStepConfig, PageDistortionSt
         if self.config.enable_distorted_text_line_mask or text_line_heights is not None:
             text_line_mask, text_line_height_score_map = paint_polygons(
                 distorted_image.shape, text_line_polygons, values=text_line_heights,
-                want_mask=self.config.enable_distorted_text_line_mask)
+                want_mask=self.config.enable_distorted_text_line_mask, queue=_paint_queue)
         return text_line_mask, text_line_height_score_map, text_line_heights, None
 
     def generate_char_labelings(self, distorted_image: Image, char_polygons: Sequence[Polygon],
                                 seal_impression_char_polygons: Sequence[Polygon],
-                                char_height_points_up: PointList, char_height_points_down: PointList):
+                                char_height_points_up: PointList, char_height_points_down: PointList,
+                                _paint_queue: Optional[_PaintQueue] = None):
         char_mask: Optional[Mask] = None
         if self.config.enable_distorted_char_mask:
             # default engine: every polygon.fill_mask(mask, keep_max_value=True) with value 1 == union
-            char_mask, _ = paint_polygons(distorted_image.shape, char_polygons)
+            char_mask, _ = paint_polygons(distorted_image.shape, char_polygons, queue=_paint_queue)
         seal_impression_char_mask: Optional[Mask] = None
         if self.config.enable_distorted_seal_impression_char_mask:
-            seal_impression_char_mask, _ = paint_polygons(distorted_image.shape, seal_impression_char_polygons)
+            seal_impression_char_mask, _ = paint_polygons(distorted_image.shape, seal_impression_char_polygons, queue=_paint_queue)
 
         char_height_score_map: Optional[ScoreMap] = None
         char_heights: Optional[List[float]] = None
@@ -242,7 +279,7 @@ class PageDistortionStep(PipelineStep[PageDistortionStepConfig, PageDistortionSt
             ordered = (char_polygons.reordered(order) if isinstance(char_polygons, PolygonSoup)
                        else [char_polygons[idx] for idx in order])
             _, char_height_score_map = paint_polygons(
-                distorted_image.shape, ordered, values=[char_heights[idx] for idx in order], want_mask=False)
+                distorted_image.shape, ordered, values=[char_heights[idx] for idx in order], want_mask=False, queue=_paint_queue)
         return char_mask, seal_impression_char_mask, char_height_score_map, char_heights, None
 
     def run(self, input: PageDistortionStepInput, rng: RandomGenerator):
@@ -324,8 +361,10 @@ class PageDistortionStep(PipelineStep[PageDistortionStepConfig, PageDistortionSt
         assert len(text_line_polygons) == len(text_line_height_points_group_sizes)
         assert len(text_line_height_points_up) == len(text_line_height_points_down)
 
+        paint_queue = _PaintQueue(result.image.shape)          # the page's label paints as one call
         (text_line_mask, text_line_height_score_map, text_line_heights,
          text_line_heights_debug_image) = self.generate_text_line_labelings(
+            _paint_queue=paint_queue,
             distorted_image=result.image,
             text_line_polygons=text_line_polygons,
             text_line_height_points_up=text_line_height_points_up,
@@ -334,6 +373,7 @@ class PageDistortionStep(PipelineStep[PageDistortionStepConfig, PageDistortionSt
         )
         (char_mask, seal_impression_char_mask, char_height_score_map, char_heights,
          char_heights_debug_image) = self.generate_char_labelings(
+            _paint_queue=paint_queue,
             distorted_image=result.image,
             char_polygons=char_polygons,
             seal_impression_char_polygons=seal_impression_char_polygons,
@@ -341,6 +381,7 @@ class PageDistortionStep(PipelineStep[PageDistortionStepConfig, PageDistortionSt
             char_height_points_down=char_height_points_down,
         )
 
+        paint_queue.flush()
         height, width = result.image.height, result.image.width
         return PageDistortionStepOutput(
             page_image=result.image,
