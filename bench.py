@@ -343,13 +343,48 @@ def c4_layers(_native, page_index, size=1024, n_layers=64, lh=32, lw=512):
     return layers, plan
 
 
+def _c4_api_worker(process_idx, num_processes, seed, device_index, size, seconds, ready, go, results):
+    """One worker of the reference-API leg of --config c4: its own process, context and generator (the pool's rule), whole pages through
+    the three step objects for ``seconds`` after the common start."""
+    os.environ['VKX_DEVICE'] = str(device_index)
+    from numpy.random import SeedSequence, default_rng
+    from vkit_amd import _native
+    from vkit_amd.pipeline import text_detection as T
+    from vkit_amd.pipeline.text_detection.synthetic_page import synthetic_page_input
+    step_input = synthetic_page_input(seed=3 + process_idx, size=size, n_lines=64)
+    assembler = T.page_assembler_step_factory.create()
+    distortion = T.page_distortion_step_factory.create()
+    resizing = T.page_resizing_step_factory.create()
+    rng = default_rng(SeedSequence(seed).spawn(num_processes)[process_idx])       # vkit/utility/pool.py:85-88
+
+    def page():
+        a = assembler.run(step_input, rng)
+        d = distortion.run(T.PageDistortionStepInput(a), rng)
+        r = resizing.run(T.PageResizingStepInput(d), rng)
+        return int(r.page_image.mat[0, 0, 0])
+
+    for _ in range(3):
+        page()
+    _native.default_ctx().sync()
+    ready.wait()
+    go.wait()
+    w0, t0, n, lat = time.time(), time.perf_counter(), 0, []
+    while time.perf_counter() - t0 < seconds:
+        t1 = time.perf_counter()
+        page()
+        lat.append(time.perf_counter() - t1)
+        n += 1
+    _native.default_ctx().sync()
+    results.put((n, lat, w0, time.time()))
+
+
 def c4_mode(args, group, rank, world, device_index, affinity):
     """BASELINE configs[3] at N ranks: page synthesis at 1024^2, one process per GPU, pages sharded by index, no collective.
     Leg 1 (value): the resident batch -- per rank ``--batch`` pages (default 64), each = background + 64 text-line layers composited by ONE
     launch per batch (ChainBatch.set_layers -> vkx_fill_u8_batch_dev) and sent through the C3 chain (camera_cubic_curve + gaussian_blur +
     color_shift + gaussion_noise from the page's numpy stream, drawn on the device) without leaving HBM; a step = one pass over the batch.
     Leg 2 (reported beside): the reference's API -- PageAssemblerStep -> PageDistortionStep -> PageResizingStep, host objects in and out,
-    one worker per GPU with the pool's rule for its generator (SeedSequence(seed).spawn(world)[process_idx], vkit/utility/pool.py:85-88;
+    a pool of ``--api-workers`` processes per GPU with the pool's rule for their generators (SeedSequence(seed).spawn(processes)[process_idx], vkit/utility/pool.py:85-88;
     vkit/pipeline/pool.py:44-48), for ``--api-seconds`` seconds between barriers."""
     from numpy.random import SeedSequence, default_rng
     from vkit_amd import _native, shard
@@ -404,45 +439,35 @@ def c4_mode(args, group, rank, world, device_index, affinity):
             verified += 1
     batch.close()
 
-    # ---- leg 2: the reference's step objects, one worker per GPU ---------------------------------------------------------------------
+    # ---- leg 2: the reference's step objects, a pool of --api-workers processes per GPU ------------------------------------------------
     api = None
     if args.api_seconds > 0:
-        from vkit_amd.pipeline import text_detection as T
-        from vkit_amd.pipeline.text_detection.synthetic_page import synthetic_page_input
-        os.environ['VKX_DEVICE'] = str(device_index)
-        step_input = synthetic_page_input(seed=3 + rank, size=size, n_lines=64)
-        assembler = T.page_assembler_step_factory.create()
-        distortion = T.page_distortion_step_factory.create()
-        resizing = T.page_resizing_step_factory.create()
-        rng = default_rng(SeedSequence(args.seed).spawn(world)[rank])       # the pool's process_idx -> generator rule
-
-        def page():
-            a = assembler.run(step_input, rng)
-            d = distortion.run(T.PageDistortionStepInput(a), rng)
-            r = resizing.run(T.PageResizingStepInput(d), rng)
-            return int(r.page_image.mat[0, 0, 0])
-
-        for _ in range(3):
-            page()
-        wctx = _native.default_ctx()
-        wctx.sync()
+        K = max(1, args.api_workers)
+        ctx_mp = mp.get_context('spawn')
+        ready, go, results = ctx_mp.Barrier(K + 1), ctx_mp.Barrier(K + 1), ctx_mp.Queue()
+        procs = [ctx_mp.Process(target=_c4_api_worker, args=(rank * K + k, world * K, args.seed, device_index, size, args.api_seconds, ready, go, results))
+                 for k in range(K)]
+        for p_ in procs:
+            p_.start()
+        ready.wait(timeout=600)              # every worker of this rank is warm
+        group.barrier()                      # ... and of every other rank
+        go.wait(timeout=60)
+        got = [results.get(timeout=args.api_seconds + 300) for _ in range(K)]
         group.barrier()
-        t0, n, lat = time.perf_counter(), 0, []
-        while time.perf_counter() - t0 < args.api_seconds:
-            t1 = time.perf_counter()
-            page()
-            lat.append(time.perf_counter() - t1)
-            n += 1
-        wctx.sync()
-        group.barrier()
-        api_elapsed = group.max_float(time.perf_counter() - t0)
+        # from the first worker's start to the last worker's last page (the workers' own clocks: one host), MAX over the ranks
+        api_elapsed = group.max_float(max(g[3] for g in got) - min(g[2] for g in got))
+        for p_ in procs:
+            p_.join(timeout=30)
+        n = sum(g[0] for g in got)
+        lat = [x for g in got for x in g[1]]
         api_pages = group.sum_int(n)
         lats = sorted(x for part in group.all_gather_object(lat) for x in part)
-        api = {'pages_per_s': api_pages / api_elapsed, 'pages': api_pages, 'seconds': api_elapsed, 'workers': world,
+        api = {'pages_per_s': api_pages / api_elapsed, 'pages': api_pages, 'seconds': api_elapsed, 'workers': world * K, 'workers_per_gpu': K,
                'latency_ms': {'mean': sum(lats) / len(lats) * 1e3, 'median': lats[len(lats) // 2] * 1e3, 'p90': lats[int(len(lats) * 0.9)] * 1e3},
-               'note': 'PageAssemblerStep -> PageDistortionStep -> PageResizingStep through the step objects, host objects in and out, ONE '
-                       'worker process per GPU (this rank); rng = default_rng(SeedSequence(seed).spawn(world)[rank]), pages drawn one '
-                       'after the other from it as PipelinePoolWorker.run does'}
+               'note': 'PageAssemblerStep -> PageDistortionStep -> PageResizingStep through the step objects, host objects in and out, a pool '
+                       f'of {K} worker process(es) per GPU (the reference scales by processes: vkit/utility/pool.py:153-243); worker process_idx '
+                       '= rank x K + k draws its pages one after the other from default_rng(SeedSequence(seed).spawn(world x K)[process_idx]) as '
+                       'PipelinePoolWorker.run does.  One worker is bound by its Python, a pool by the kernel time of a page (DESIGN.md section 5)'}
     dist_evidence = group.evidence(device_index=device_index, pci_bus_id=(affinity or {}).get('pci_bus_id'), first_page=first, pages=B)
     group.close()
     if rank != 0:
@@ -502,9 +527,10 @@ def main():
     ap.add_argument('--config', default='c3', choices=('c3', 'c4'),
                     help='c3 (default, the headline): BASELINE configs[2], the fused chain on 2048^2 images.  c4: BASELINE configs[3], page '
                          'synthesis at 1024^2 -- per rank a resident batch of --batch pages (64 text layers composited + the chain, one launch '
-                         'each) AND the reference-API leg (PageAssemblerStep -> PageDistortionStep -> PageResizingStep, one worker per GPU, '
-                         'the pool\'s process_idx -> rng rule); value = pages/s of the resident batch over all ranks')
+                         'each) AND the reference-API leg (PageAssemblerStep -> PageDistortionStep -> PageResizingStep, --api-workers processes per '
+                         'GPU, the pool\'s process_idx -> rng rule); value = pages/s of the resident batch over all ranks')
     ap.add_argument('--api-seconds', type=float, default=4.0, help='--config c4: seconds of the reference-API leg per rank')
+    ap.add_argument('--api-workers', type=int, default=4, help='--config c4: worker processes per GPU of the reference-API leg (the pool)')
     ap.add_argument('--dry-run', action='store_true',
                     help='rendezvous, barriers and the MAX reduction of the timing protocol only, over gloo, no GPU: the N > 1 path on '
                          'a box without GPUs (tests/test_bench_launch.py)')

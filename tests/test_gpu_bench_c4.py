@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_c4_mode_one_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--config', 'c4', '--batch', '6', '--steps', '3', '--warmup', '1',
-                          '--api-seconds', '1.0'], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+                          '--api-seconds', '1.0', '--api-workers', '2'], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
     assert rec['unit'] == 'pages/s' and rec['n_gpus'] == 1 and rec['steps'] == 3
@@ -22,6 +22,6 @@ def test_c4_mode_one_gpu():
     assert abs(rec['value'] - 6 * 3 / (rec['ms_per_step'] * 3 / 1e3)) < 1e-6 * rec['value']
     assert 'k_composite_rgb' in rec['kernels_ms_per_step'] and 'k_chain_fused' in rec['kernels_ms_per_step']
     api = rec['reference_api']
-    assert api['pages'] >= 10 and api['workers'] == 1 and api['pages_per_s'] > 20
+    assert api['pages'] >= 10 and api['workers'] == 2 and api['workers_per_gpu'] == 2 and api['pages_per_s'] > 20
     ev = rec['config']['distributed']
     assert ev['world_size'] == 1 and len(ev['ranks']) == 1 and ev['ranks'][0]['pages'] == 6
