@@ -285,6 +285,15 @@ int vkx_sum_f32_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdi
                    int n_sel, int sequential, float *sums_host);
 int vkx_apply_lut_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
                          const uint8_t *lut_host, unsigned channel_mask, uint8_t *dst, ptrdiff_t dst_stride);
+/* The same look-up for up to 8 dense single-channel device planes, each with its own HOST table uint8 [256], in one launch (the four masks
+ * PageResizingStep binarises before and after their resize: Mask.to_resized_mask, element/mask.py:454-479). */
+typedef struct vkx_lut_plane {
+    const uint8_t *src;   /* device, dense, 16-byte aligned */
+    uint8_t *dst;         /* device, dense, 16-byte aligned (may equal src) */
+    size_t n_bytes;
+    const uint8_t *lut_host;
+} vkx_lut_plane;
+int vkx_apply_lut_u8_planes_dev(vkx_ctx *ctx, const vkx_lut_plane *planes, int n_planes);
 int vkx_apply_lut_u8(vkx_ctx *ctx, const uint8_t *src, int h, int w, int cn, ptrdiff_t src_stride,
                      const uint8_t *lut_host, unsigned channel_mask, uint8_t *dst, ptrdiff_t dst_stride);
 

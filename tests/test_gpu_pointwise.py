@@ -317,6 +317,20 @@ def test_page_resizing_step_elements_match_oracle():
             page_text_line_heights=[float(v) for v in rng.uniform(4.0, 30.0, 12)])
         step = PageResizingStep(PageResizingStepConfig(resized_text_line_height_min=3.0, resized_text_line_height_max=24.0))
         out = step.run(PageResizingStepInput(page_distortion_step_output=page), np.random.default_rng(seed))
+        # the same page with its elements resident on the device (what PageDistortionStep hands over: the four masks then go through
+        # two batched look-ups around their resizes) has to give the same planes
+        from vkit_amd import _native
+        ctx = _native.default_ctx()
+        resident = SimpleNamespace(page_text_line_heights=page.page_text_line_heights)
+        for name in ('page_image', 'page_active_mask', 'page_char_mask', 'page_seal_impression_char_mask', 'page_text_line_mask'):
+            element = getattr(page, name)
+            setattr(resident, name, type(element)(mat=ctx.to_device(element.mat)))
+        for name in ('page_char_height_score_map', 'page_text_line_height_score_map'):
+            setattr(resident, name, ScoreMap(mat=ctx.to_device(getattr(page, name).mat), is_prob=False))
+        out_dev = step.run(PageResizingStepInput(page_distortion_step_output=resident), np.random.default_rng(seed))
+        for name in ('page_image', 'page_active_mask', 'page_char_mask', 'page_seal_impression_char_mask', 'page_text_line_mask',
+                     'page_char_height_score_map', 'page_text_line_height_score_map'):
+            assert (getattr(out_dev, name).mat == getattr(out, name).mat).all(), (name, 'device-resident')
         # replay the two draws
         r = np.random.default_rng(seed)
         ratio = r.uniform(3.0, 24.0) / step.get_text_line_heights_min(page.page_text_line_heights)

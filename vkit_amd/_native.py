@@ -76,6 +76,10 @@ class VkxChainItem(ctypes.Structure):
     ]
 
 
+class VkxLutPlane(ctypes.Structure):
+    _fields_ = [('src', c_void_p), ('dst', c_void_p), ('n_bytes', c_size), ('lut_host', c_void_p)]
+
+
 class VkxPaintSet(ctypes.Structure):
     _fields_ = [
         ('pts_host', c_void_p),
@@ -310,6 +314,7 @@ for _sfx in ('', '_dev'):
     _SIGNATURES['vkx_ellipse_streak_u8' + _sfx] = [c_void_p] + _PLANE_U8 + [c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_double]
 
 _SIGNATURES['vkx_paint_polys_fresh_dev'] = _SIGNATURES['vkx_paint_polys_dev']
+_SIGNATURES['vkx_apply_lut_u8_planes_dev'] = [c_void_p, ctypes.POINTER(VkxLutPlane), c_int]
 _SIGNATURES['vkx_paint_poly_sets_fresh_dev'] = [c_void_p, ctypes.POINTER(VkxPaintSet), c_int, c_int, c_int]
 _SIGNATURES['vkx_fill_u8_dev_host_layers'] = [c_void_p] + _PLANE_U8 + [ctypes.POINTER(VkxLayer), c_int]
 _SIGNATURES['vkx_fill_u8_batch_dev'] = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_ssize, ctypes.POINTER(VkxLayer), c_void_p]
@@ -1390,6 +1395,29 @@ def apply_lut(img, lut, channels=None, ctx=None):
     dst, dptr = call.out(img.shape, np.uint8)
     check(call.fn('vkx_apply_lut_u8')(call.ctx.handle, call.src(img), h, w, cn, stride, _ptr(lut), _channel_mask(channels), dptr, stride))
     return dst
+
+
+def apply_lut_planes(planes, luts):
+    """``lut_k[plane_k]`` for up to eight dense single-channel uint8 DevArrays of one context, each with its own table uint8 [256], in ONE
+    launch (vkx_apply_lut_u8_planes_dev) -> new DevArrays."""
+    n = len(planes)
+    if n == 0:
+        return []
+    ctx = planes[0].ctx
+    arr = (VkxLutPlane * n)()
+    outs, keep = [], []
+    for k, (plane, lut) in enumerate(zip(planes, luts)):
+        if not isinstance(plane, DevArray) or np.dtype(plane.dtype) != np.uint8 or plane.ctx is not ctx:
+            raise ValueError('apply_lut_planes takes uint8 DevArrays of one context')
+        table = np.ascontiguousarray(lut, dtype=np.uint8).reshape(-1)
+        if table.shape != (256,):
+            raise ValueError('one table uint8 [256] per plane')
+        out = ctx.dev_empty(plane.shape, np.uint8)
+        arr[k].src, arr[k].dst, arr[k].n_bytes, arr[k].lut_host = plane.ptr, out.ptr, plane.nbytes, table.ctypes.data
+        outs.append(out)
+        keep.append(table)
+    check(lib().vkx_apply_lut_u8_planes_dev(ctx.handle, arr, n))
+    return outs
 
 
 def gather(img, pos_y, pos_x, ctx=None):

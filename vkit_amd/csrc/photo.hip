@@ -798,6 +798,24 @@ __global__ void __launch_bounds__(256) k_apply_lut16(const uint8_t *__restrict__
     });
 }
 
+// ... and up to eight dense single-channel planes, each through its own table, in one launch (blockIdx.y = plane): PageResizingStep
+// binarises four masks before and after their resize -- eight launches of a few microseconds each as two.
+struct LutPlanes {
+    const uint8_t *src[8];
+    uint8_t *dst[8];
+    unsigned long long n[8];
+};
+__global__ void __launch_bounds__(256) k_apply_lut16_planes(LutPlanes P, const uint8_t *__restrict__ luts /* [planes][256] */)
+{
+    __shared__ uint32_t table_w[64];
+    const int p = blockIdx.y;
+    if ((size_t)blockIdx.x * 4096 >= P.n[p]) return;          // (uniform per workgroup: before the barrier)
+    if (threadIdx.x < 64) table_w[threadIdx.x] = ((const uint32_t *)(luts + 256 * p))[threadIdx.x];
+    __syncthreads();
+    const uint8_t *table = (const uint8_t *)table_w;
+    map_bytes16(P.src[p], P.dst[p], (size_t)P.n[p], 1, [&](int v, int, int) { return (int)table[v]; });
+}
+
 __global__ void __launch_bounds__(256) k_add_noise16(const uint8_t *__restrict__ src, const int16_t *__restrict__ noise,
                                                      uint8_t *__restrict__ dst, size_t n)
 {
@@ -1363,6 +1381,38 @@ VKX_EXPORT int vkx_apply_lut_u8_dev(vkx_ctx *ctx, const uint8_t *src, int h, int
     }
     dim3 block(64, 4), grid(vkx_blocks((size_t)w * cn, 64), vkx_blocks(h, 4));
     { VKX_TIMED(ctx, "k_apply_lut"); k_apply_lut<<<grid, block, 0, ctx->stream>>>(src, h, w, cn, src_stride, dst, dst_stride, table, channel_mask); }
+    VKX_LAUNCH_CHECK();
+    return VKX_OK;
+}
+
+VKX_EXPORT int vkx_apply_lut_u8_planes_dev(vkx_ctx *ctx, const vkx_lut_plane *planes, int n_planes)
+{
+    VKX_REQUIRE(ctx && planes, "NULL argument");
+    VKX_REQUIRE(n_planes >= 1 && n_planes <= 8, "1 .. 8 planes per call");
+    LutPlanes P;
+    memset(&P, 0, sizeof(P));
+    size_t n_max = 0;
+    void *staged = nullptr;
+    int rc = vkx_desc_ring_take(ctx, (size_t)256 * n_planes, &staged);
+    if (rc) return rc;
+    for (int i = 0; i < n_planes; i++) {
+        const vkx_lut_plane &pl = planes[i];
+        VKX_REQUIRE((pl.n_bytes == 0 || (pl.src && pl.dst)) && pl.lut_host, "NULL plane or table");
+        VKX_REQUIRE((((uintptr_t)pl.src | (uintptr_t)pl.dst) & 15) == 0, "planes are 16-byte aligned, dense");
+        P.src[i] = pl.src; P.dst[i] = pl.dst; P.n[i] = pl.n_bytes;
+        n_max = std::max(n_max, pl.n_bytes);
+        memcpy((uint8_t *)staged + 256 * i, pl.lut_host, 256);
+    }
+    if (n_max == 0) return VKX_OK;
+    const uint8_t *tables = (const uint8_t *)vkx_ring_device_ptr(staged);
+    if (!tables) {
+        if ((rc = vkx_scratch_reserve(ctx, &ctx->misc, 2048))) return rc;
+        VKX_HIP(hipMemcpyAsync(ctx->misc.ptr, staged, (size_t)256 * n_planes, hipMemcpyHostToDevice, ctx->stream));
+        tables = (const uint8_t *)ctx->misc.ptr;
+    }
+    vkx_device_guard guard(ctx);
+    dim3 grid(vkx_blocks((n_max + 15) / 16, 256), n_planes);
+    { VKX_TIMED(ctx, "k_apply_lut"); k_apply_lut16_planes<<<grid, 256, 0, ctx->stream>>>(P, tables); }
     VKX_LAUNCH_CHECK();
     return VKX_OK;
 }
