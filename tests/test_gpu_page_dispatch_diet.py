@@ -215,3 +215,18 @@ def test_paint_sets_equal_separate_paints(N):
     m = ctx.to_device(rng.integers(1, 256, (40, 50), dtype=np.uint8))
     N.paint_poly_sets_fresh([(np.zeros((0, 2), np.int32), np.zeros(1, np.int32), None, m, None)], (40, 50))
     assert not m.host().any()
+
+
+def test_lookup_tables_of_several_planes_in_one_launch(N):
+    """vkx_apply_lut_u8_planes_dev: one to eight dense planes of different sizes (1 byte .. a megapixel, lengths that are no multiple of 16),
+    each through its own table, equal to numpy's take."""
+    ctx = N.default_ctx()
+    rng = default_rng(53)
+    for shapes in (((1, 1),), ((3, 5), (64, 64), (1, 17)), ((257, 131),) * 4, ((1024, 1024), (7, 9), (33, 1), (2, 8), (100, 101), (1, 1), (640, 3), (5, 5))):
+        planes = [rng.integers(0, 256, s, dtype=np.uint8) for s in shapes]
+        luts = [rng.integers(0, 256, 256, dtype=np.uint8) for _ in shapes]
+        outs = N.apply_lut_planes([ctx.to_device(p) for p in planes], luts)
+        for p, t, o in zip(planes, luts, outs):
+            np.testing.assert_array_equal(o.host(), t[p])
+    with pytest.raises(Exception):
+        N.apply_lut_planes([ctx.to_device(planes[0])] * 9, [luts[0]] * 9)
